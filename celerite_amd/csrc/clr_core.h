@@ -1,0 +1,442 @@
+// celerite_amd/csrc/clr_core.h
+//
+// Per-lane arithmetic of the batched semiseparable-Cholesky log-likelihood for
+// small widths (J = J_real + 2 J_comp <= 8): everything one GPU lane does for
+// one (problem, chunk-of-the-time-axis) pair, with all state in registers.
+//
+// The reference (cpp/include/celerite/solver/cholesky.h:126-179, :348-357)
+// walks n = 1..N-1 sequentially.  Here the time axis is cut into chunks and the
+// recurrence is evaluated as a three-phase associative scan:
+//
+//   summarize  (parallel over chunks)  fold the chunk's steps, started from the
+//              zero state, into one "transfer element" (A, b, C, eta, Jm) that
+//              maps the state (P, f) at the chunk's first sample to the state at
+//              the next chunk's first sample;
+//   prefix     (sequential over a problem's chunks, parallel over problems)
+//              apply the elements in order -> exact start state of every chunk;
+//   replay     (parallel over chunks)  the reference recurrence itself, started
+//              from that state, accumulating sum(log D_n), sum(x_n^2 / D_n) and
+//              (optionally) writing the factor phi, u, W, D to HBM.
+//
+// State convention.  "State at sample n" = (P_n, f_n) BEFORE sample n is used:
+//   P_n = the reference's S after its update at step n (cholesky.h:154-160),
+//   f_n = the reference's f after its update at step n (cholesky.h:350-352).
+// One step (use sample n, then move to n+1):
+//   q = P u_n ; D_n = a_n - u_n.q ; z = v_n - q ; W_n = z / D_n      (:162-178)
+//   x_n = y_n - u_n.f                                                  (:349-355)
+//   P_{n+1} = Phi (P + z z^T / D_n) Phi ; f_{n+1} = Phi (f + W_n x_n)  (:154-160, :351)
+// with u_n = U~(t_n), v_n = V~(t_n), Phi = diag(exp(-c (t_{n+1} - t_n))).
+//
+// The chunk map is a linear-fractional (Riccati) map; in the form used for
+// parallel Kalman filtering (Sarkka & Garcia-Fernandez, IEEE TAC 66 (2021)):
+//   P' = C + A P (I + Jm P)^-1 A^T ,   f' = A (I + P Jm)^-1 (f + P eta) + b .
+// A single step has A = Phi (I - v u^T / a), b = Phi v y / a, C = Phi v v^T Phi / a,
+// eta = -u y / a, Jm = -u u^T / a.  Folding one step onto a running element
+// (A, b, C, eta, Jm) needs no matrix inverse (Sherman-Morrison collapses it):
+//   q = C u ; D = a - u.q ; z = v - q ; W = z / D ; x = y - u.b ; r = A^T u
+//   eta -= r x / D ; Jm -= r r^T / D
+//   C <- Phi (C + z z^T / D) Phi ; b <- Phi (b + W x) ; A <- Phi (A - W r^T)
+// i.e. (C, b) is the zero-start trajectory and (A, eta, Jm) ride along.
+//
+// This header is plain C++14 usable from hipcc (device) and from g++ (the
+// host-side algebra check in tests/hostcheck -- test infrastructure, not a
+// product path: libcelerite_hip.so contains no CPU implementation).
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CLR_HD __host__ __device__ __forceinline__
+#define CLR_UNROLL _Pragma("unroll")
+#else
+#define CLR_HD inline
+#define CLR_UNROLL
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#endif
+
+namespace clr {
+
+// Packed upper triangle of a symmetric J x J matrix: (k <= j) -> k + j(j+1)/2.
+CLR_HD constexpr int tri(int k, int j) { return k + j * (j + 1) / 2; }
+CLR_HD constexpr int sym(int i, int j) { return i <= j ? tri(i, j) : tri(j, i); }
+CLR_HD constexpr int nz(int n) { return n > 0 ? n : 1; }
+
+template <int JR, int JC>
+struct Widths {
+  static constexpr int J = JR + 2 * JC;
+  static constexpr int SZ = J * (J + 1) / 2;
+  // doubles per transfer element / per chunk start state in the workspace
+  static constexpr int ELEM = J * J + J + SZ + J + SZ;
+  static constexpr int START = SZ + J;
+};
+
+// Kernel hyper-parameters of one problem (wave-uniform in the batch kernels).
+template <int JR, int JC>
+struct Problem {
+  double ar[nz(JR)], cr[nz(JR)];
+  double ac[nz(JC)], bc[nz(JC)], cc[nz(JC)], dc[nz(JC)];
+  double sum_ar, sum_ac, jitter;
+
+  CLR_HD void load(const double* a_real, const double* c_real, const double* a_comp,
+                   const double* b_comp, const double* c_comp, const double* d_comp,
+                   double jit) {
+    sum_ar = 0.0;
+    sum_ac = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < JR; ++j) { ar[j] = a_real[j]; cr[j] = c_real[j]; sum_ar += ar[j]; }
+    CLR_UNROLL
+    for (int j = 0; j < JC; ++j) {
+      ac[j] = a_comp[j]; bc[j] = b_comp[j]; cc[j] = c_comp[j]; dc[j] = d_comp[j];
+      sum_ac += ac[j];
+    }
+    jitter = jit;
+  }
+  // Diagonal of K at one sample, summed in the reference's order (cholesky.h:98).
+  CLR_HD double diagonal(double diag_n) const { return ((diag_n + sum_ar) + sum_ac) + jitter; }
+};
+
+// U~(t), V~(t): cholesky.h:129-147 (real rows: a, 1; complex pair: (a cd + b sd,
+// a sd - b cd), (cd, sd) with the ABSOLUTE time in the phase, :137).
+template <int JR, int JC>
+CLR_HD void features_uv(const Problem<JR, JC>& p, double t, double* u, double* v) {
+  CLR_UNROLL
+  for (int j = 0; j < JR; ++j) { u[j] = p.ar[j]; v[j] = 1.0; }
+  CLR_UNROLL
+  for (int j = 0; j < JC; ++j) {
+    const int k = JR + 2 * j;
+    double sd, cd;
+    sincos(p.dc[j] * t, &sd, &cd);
+    u[k] = p.ac[j] * cd + p.bc[j] * sd;
+    u[k + 1] = p.ac[j] * sd - p.bc[j] * cd;
+    v[k] = cd;
+    v[k + 1] = sd;
+  }
+}
+
+// phi for the move from t to t + dx: cholesky.h:130,140-142.
+template <int JR, int JC>
+CLR_HD void features_phi(const Problem<JR, JC>& p, double dx, double* phi) {
+  CLR_UNROLL
+  for (int j = 0; j < JR; ++j) phi[j] = exp(-p.cr[j] * dx);
+  CLR_UNROLL
+  for (int j = 0; j < JC; ++j) {
+    const double e = exp(-p.cc[j] * dx);
+    phi[JR + 2 * j] = e;
+    phi[JR + 2 * j + 1] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// summarize: fold samples [n0, n1) of one problem (n1 < N: the element ends at
+// sample n1's "before" state) into a transfer element.  elem layout:
+//   A[J*J] row-major | b[J] | C[SZ] | eta[J] | Jm[SZ]
+// ---------------------------------------------------------------------------
+template <int JR, int JC>
+CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const double* t, const double* diag,
+                            const double* y, int n0, int n1, double* elem_out) {
+  constexpr int J = Widths<JR, JC>::J;
+  constexpr int SZ = Widths<JR, JC>::SZ;
+  double A[J * J], b[J], C[SZ], eta[J], Jm[SZ];
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) A[i * J + j] = (i == j) ? 1.0 : 0.0;
+    b[i] = 0.0;
+    eta[i] = 0.0;
+  }
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) { C[i] = 0.0; Jm[i] = 0.0; }
+
+  double tn = t[n0];
+  double t_next = t[n0 + 1], diag_n = diag[n0], y_n = y[n0];
+  for (int n = n0; n < n1; ++n) {
+    // register prefetch of the next sample (n1 < N so n + 2 may reach N only
+    // when n + 1 == n1 == N - 1; clamp keeps the read in bounds)
+    const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
+    if (n + 1 < n1) {
+      t_next = t[n + 2];
+      diag_n = diag[n + 1];
+      y_n = y[n + 1];
+    }
+
+    double u[J], v[J], phi[J];
+    features_uv<JR, JC>(p, tn, u, v);
+    features_phi<JR, JC>(p, t_cur_next - tn, phi);
+
+    double q[J], r[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0, racc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) {
+        acc += C[sym(k, j)] * u[k];
+        racc += A[k * J + j] * u[k];
+      }
+      q[j] = acc;
+      r[j] = racc;
+    }
+    double s = 0.0, ub = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) { s += u[j] * q[j]; ub += u[j] * b[j]; }
+    const double D = p.diagonal(diag_cur) - s;
+    const double invD = 1.0 / D;
+    const double x = y_cur - ub;
+    const double xs = x * invD;
+
+    double z[J], W[J], rs[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      z[j] = v[j] - q[j];
+      W[j] = z[j] * invD;
+      rs[j] = r[j] * invD;
+      eta[j] -= r[j] * xs;
+    }
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k) {
+        Jm[tri(k, j)] -= r[k] * rs[j];
+        C[tri(k, j)] = phi[j] * (phi[k] * (C[tri(k, j)] + z[k] * W[j]));
+      }
+      b[j] = phi[j] * (b[j] + W[j] * x);
+    }
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) {
+      const double pw = phi[i] * W[i];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) A[i * J + j] = phi[i] * A[i * J + j] - pw * r[j];
+    }
+    tn = t_cur_next;
+  }
+
+  double* o = elem_out;
+  CLR_UNROLL
+  for (int i = 0; i < J * J; ++i) o[i] = A[i];
+  o += J * J;
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) o[i] = b[i];
+  o += J;
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) o[i] = C[i];
+  o += SZ;
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) o[i] = eta[i];
+  o += J;
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) o[i] = Jm[i];
+}
+
+// ---------------------------------------------------------------------------
+// prefix: apply one transfer element to a state.  (P, f) are updated in place.
+//   M^T = I + P Jm ;  [G | g] = M^-T [P | f + P eta]   (G = P (I + Jm P)^-1, symmetric)
+//   P' = C + A G A^T ;  f' = A g + b
+// Gaussian elimination with partial pivoting; rows are exchanged with selects
+// so that every index stays a compile-time constant (registers, no scratch).
+// ---------------------------------------------------------------------------
+template <int J>
+CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J]*/) {
+  constexpr int SZ = J * (J + 1) / 2;
+  constexpr int NC = 2 * J + 1;  // [ M^T | P | h ]
+  const double* A = elem;
+  const double* b = elem + J * J;
+  const double* C = b + J;
+  const double* eta = C + SZ;
+  const double* Jm = eta + J;
+
+  double T[J][NC];
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    double h = f[i];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = (i == j) ? 1.0 : 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += P[sym(i, k)] * Jm[sym(k, j)];
+      T[i][j] = acc;
+      T[i][J + j] = P[sym(i, j)];
+      h += P[sym(i, j)] * eta[j];
+    }
+    T[i][2 * J] = h;
+  }
+
+  CLR_UNROLL
+  for (int col = 0; col < J; ++col) {
+    // pivot search
+    int piv = col;
+    double best = fabs(T[col][col]);
+    CLR_UNROLL
+    for (int i = col + 1; i < J; ++i) {
+      const double cand = fabs(T[i][col]);
+      const bool take = cand > best;
+      best = take ? cand : best;
+      piv = take ? i : piv;
+    }
+    // bring the pivot row to position `col`
+    CLR_UNROLL
+    for (int c = col; c < NC; ++c) {
+      double top = T[col][c];
+      const double old_top = top;
+      CLR_UNROLL
+      for (int i = col + 1; i < J; ++i) {
+        const bool hit = (i == piv);
+        top = hit ? T[i][c] : top;
+        T[i][c] = hit ? old_top : T[i][c];
+      }
+      T[col][c] = top;
+    }
+    const double inv = 1.0 / T[col][col];
+    CLR_UNROLL
+    for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) {
+      if (i == col) continue;
+      const double m = T[i][col];
+      CLR_UNROLL
+      for (int c = col + 1; c < NC; ++c) T[i][c] -= m * T[col][c];
+    }
+  }
+  // now T[i][J + j] = G[i][j], T[i][2J] = g[i]  (Gauss-Jordan: no back-substitution)
+
+  double AG[J][J];
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) {
+        // symmetrised G: average of the two computed halves
+        acc += A[i * J + k] * (0.5 * (T[k][J + j] + T[j][J + k]));
+      }
+      AG[i][j] = acc;
+    }
+  }
+  CLR_UNROLL
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL
+    for (int k = 0; k <= j; ++k) {
+      double acc = C[tri(k, j)];
+      CLR_UNROLL
+      for (int i = 0; i < J; ++i) acc += AG[k][i] * A[j * J + i];
+      P[tri(k, j)] = acc;
+    }
+  }
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    double acc = b[i];
+    CLR_UNROLL
+    for (int k = 0; k < J; ++k) acc += A[i * J + k] * T[k][2 * J];
+    f[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// replay: the reference recurrence over samples [n0, n1) from a known state.
+// Accumulates sum(log D_n) and sum(x_n^2 / D_n); flags the first D_n < 0 with
+// n >= 1 (cholesky.h:176 -- sample 0 is never checked, :100-117).  When
+// MATERIALIZE, writes the factor in the reference's storage (cholesky.h:76-78,
+// :703-706): phi[:, n] (move n -> n+1), u[:, n-1] = U~(t_n), W[:, n], D[n].
+// ---------------------------------------------------------------------------
+template <int JR, int JC, bool MATERIALIZE>
+CLR_HD void replay_chunk(const Problem<JR, JC>& p, const double* t, const double* diag,
+                         const double* y, int N, int n0, int n1,
+                         const double* start /* P[SZ] f[J] or nullptr => zero */,
+                         double* logdet_out, double* quad_out, int* flag_out,
+                         double* phi_o, double* u_o, double* W_o, double* D_o) {
+  constexpr int J = Widths<JR, JC>::J;
+  constexpr int SZ = Widths<JR, JC>::SZ;
+  double P[SZ], f[J];
+  if (start) {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) P[i] = start[i];
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) f[i] = start[SZ + i];
+  } else {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) P[i] = 0.0;
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) f[i] = 0.0;
+  }
+
+  double logdet = 0.0, quad = 0.0;
+  int flag = 0;
+  double tn = t[n0];
+  double t_next = (n0 + 1 < N) ? t[n0 + 1] : tn;
+  double diag_n = diag[n0], y_n = y[n0];
+  for (int n = n0; n < n1; ++n) {
+    const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
+    if (n + 1 < n1) {
+      t_next = (n + 2 < N) ? t[n + 2] : t_next;
+      diag_n = diag[n + 1];
+      y_n = y[n + 1];
+    }
+
+    double u[J], v[J];
+    features_uv<JR, JC>(p, tn, u, v);
+
+    double q[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += P[sym(k, j)] * u[k];
+      q[j] = acc;
+    }
+    double s = 0.0, uf = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
+    const double D = p.diagonal(diag_cur) - s;
+    if (n >= 1 && D < 0.0 && !flag) flag = 1;
+    const double invD = 1.0 / D;
+    const double x = y_cur - uf;
+    logdet += log(D);
+    quad += x * x * invD;
+
+    double z[J], W[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      z[j] = v[j] - q[j];
+      W[j] = z[j] * invD;
+    }
+    if (MATERIALIZE) {
+      D_o[n] = D;
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) W_o[(long)J * n + j] = W[j];
+      if (n >= 1) {
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) u_o[(long)J * (n - 1) + j] = u[j];
+      }
+    }
+    if (n + 1 < N) {
+      double phi[J];
+      features_phi<JR, JC>(p, t_cur_next - tn, phi);
+      if (MATERIALIZE) {
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) phi_o[(long)J * n + j] = phi[j];
+      }
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        CLR_UNROLL
+        for (int k = 0; k <= j; ++k)
+          P[tri(k, j)] = phi[j] * (phi[k] * (P[tri(k, j)] + z[k] * W[j]));
+        f[j] = phi[j] * (f[j] + W[j] * x);
+      }
+    }
+    tn = t_cur_next;
+  }
+  *logdet_out = logdet;
+  *quad_out = quad;
+  *flag_out = flag;
+}
+
+// -0.5 (quad + logdet + N log 2 pi) with the -inf rules of
+// celerite/celerite.py:211-218.
+CLR_HD double combine_loglike(double logdet, double quad, int N) {
+  if (!isfinite(logdet)) return -INFINITY;
+  const double ll = -0.5 * (quad + logdet + N * 1.8378770664093453 /* log(2 pi) */);
+  return isfinite(ll) ? ll : -INFINITY;
+}
+
+}  // namespace clr

@@ -1,0 +1,224 @@
+/*
+ * include/celerite_hip.h -- C ABI of libcelerite_hip.so, the MI355X (gfx950)
+ * implementation of celerite's semiseparable-Cholesky hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one member of
+ * the reference's C++ solver class as it is bound by the reference's pybind11
+ * translation unit (celerite/solver.cpp).  The reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md.  Conventions:
+ *
+ *   - extern "C", plain pointers + sizes, no C++ types, no exceptions: every
+ *     call returns a clr_status (the pybind11 layer maps CLR_NOT_POSITIVE_DEFINITE
+ *     -> celerite.solver.LinAlgError and the other non-zero codes ->
+ *     RuntimeError with the reference's what() strings, exceptions.h:14-36).
+ *   - all pointers are caller-owned HOST memory unless a name says `_dev`;
+ *     inputs are const and are not retained past the call (the reference's
+ *     pybind11/Eigen casters copy every argument, solver.cpp:467-483).
+ *   - a handle is thread-compatible (one thread at a time), like the reference
+ *     object; distinct handles may be used concurrently.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry returns CLR_NO_DEVICE.
+ *   - fp64 throughout.  Matrices of the factor use the reference's storage
+ *     (Eigen column-major J x N: element (j, n) at [j + J*n], cholesky.h:703-706).
+ *     U and V (general terms) are ROW-major [J_general][N], as the NumPy arrays
+ *     arrive at the Python boundary.
+ */
+#ifndef CELERITE_HIP_H
+#define CELERITE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum clr_status {
+  CLR_OK = 0,
+  CLR_DIMENSION_MISMATCH = 1,    /* celerite::dimension_mismatch  exceptions.h:20-24 */
+  CLR_NOT_POSITIVE_DEFINITE = 2, /* celerite::linalg_exception    exceptions.h:32-36 */
+  CLR_NOT_COMPUTED = 3,          /* celerite::compute_exception   exceptions.h:14-18 */
+  CLR_NO_DEVICE = 4,             /* no gfx950 GPU visible / HIP runtime unusable    */
+  CLR_HIP_ERROR = 5,             /* a HIP call failed; see clr_last_error()          */
+  CLR_INVALID_ARGUMENT = 6,
+  CLR_UNSUPPORTED = 7            /* e.g. width above CLR_MAX_WIDTH                   */
+} clr_status;
+
+/* Widest semiseparable rank J = J_real + 2 J_comp + J_general accepted. */
+#define CLR_MAX_WIDTH 128
+
+/* ---- library / device ------------------------------------------------------ */
+
+/* CELERITE_VERSION_STRING, cpp/include/celerite/version.h:4-13 ("0.3.0");
+ * bound as solver.get_library_version (solver.cpp:76). */
+const char* clr_version(void);
+/* Message of the last non-OK status on the calling thread. */
+const char* clr_last_error(void);
+/* what() string of the reference exception a status stands for. */
+const char* clr_status_string(int status);
+/* Number of visible gfx950 devices (0 without a GPU; never fails). */
+int clr_device_count(void);
+/* Device used by handles created afterwards on this thread (default 0). */
+int clr_set_device(int device);
+int clr_get_device(int* device);
+/* hipDeviceSynchronize on the current device. */
+int clr_device_synchronize(void);
+/* Name + CU count of the current device (for logs). */
+int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm_bytes);
+
+/* ---- single-problem solver: celerite::solver::CholeskySolver<double> ----------
+ * (cpp/include/celerite/solver/cholesky.h, solver.h), the object behind
+ * celerite.solver.CholeskySolver (solver.cpp:241-244).  The factor
+ * (phi, u, W, D) stays resident in HBM between calls. */
+
+typedef struct clr_solver clr_solver;
+
+clr_solver* clr_solver_create(void);       /* CholeskySolver()   solver.cpp:244 */
+void clr_solver_destroy(clr_solver* s);
+
+/* CholeskySolver::compute, cholesky.h:41-210 (bound at solver.cpp:467-483).
+ * Each array carries its own length so the reference's dimension checks
+ * (cholesky.h:59-69) are made here.  n_A == 0 means "no general terms".
+ * On CLR_NOT_POSITIVE_DEFINITE (some D_n < 0, n >= 1: cholesky.h:176) or
+ * CLR_DIMENSION_MISMATCH the handle is left "not computed" (cholesky.h:57). */
+int clr_solver_compute(clr_solver* s, double jitter,
+                       int n_a_real, const double* a_real,
+                       int n_c_real, const double* c_real,
+                       int n_a_comp, const double* a_comp,
+                       int n_b_comp, const double* b_comp,
+                       int n_c_comp, const double* c_comp,
+                       int n_d_comp, const double* d_comp,
+                       int n_A, const double* A,
+                       int U_rows, int U_cols, const double* U,
+                       int V_rows, int V_cols, const double* V,
+                       int n_x, const double* x,
+                       int n_diag, const double* diag);
+
+/* Solver::computed / log_determinant, solver.h:74-81 (solver.cpp:620-634). */
+int clr_solver_computed(const clr_solver* s);
+int clr_solver_log_determinant(const clr_solver* s, double* out);
+
+/* CholeskySolver::dot_solve, cholesky.h:326-401 (solver.cpp:527-529):
+ * out = b^T K^-1 b. */
+int clr_solver_dot_solve(const clr_solver* s, int n_b, const double* b, double* out);
+
+/* CholeskySolver::solve, cholesky.h:218-318 (solver.cpp:507-509).
+ * b, x: COLUMN-major (N, nrhs): right-hand side k is b + k*N. */
+int clr_solver_solve(const clr_solver* s, int b_rows, int nrhs, const double* b, double* x);
+
+/* CholeskySolver::dot_L, cholesky.h:409-431 (solver.cpp:547-549): y = L z with
+ * K = L L^T.  Column-major (N, nrhs). */
+int clr_solver_dot_L(const clr_solver* s, int z_rows, int nrhs, const double* z, double* y);
+
+/* CholeskySolver::dot, cholesky.h:444-590 (solver.cpp:567-581): y = K z without
+ * factorising (stateless; the handle only supplies the device).  z, y:
+ * column-major (N, nrhs). */
+int clr_solver_dot(clr_solver* s, double jitter,
+                   int n_a_real, const double* a_real,
+                   int n_c_real, const double* c_real,
+                   int n_a_comp, const double* a_comp,
+                   int n_b_comp, const double* b_comp,
+                   int n_c_comp, const double* c_comp,
+                   int n_d_comp, const double* d_comp,
+                   int n_A, const double* A,
+                   int U_rows, int U_cols, const double* U,
+                   int V_rows, int V_cols, const double* V,
+                   int n_x, const double* x,
+                   int z_rows, int nrhs, const double* z, double* y);
+
+/* CholeskySolver::predict, cholesky.h:599-698 (solver.cpp:611-615): conditional
+ * mean at the M sorted-or-not coordinates xs given observations y. */
+int clr_solver_predict(const clr_solver* s, int n_y, const double* y,
+                       int M, const double* xs, double* pred);
+
+/* PicklableCholeskySolver::serialize / deserialize, solver.cpp:36-58 (bound as
+ * __getstate__/__setstate__, solver.cpp:644-663).  get_dims first, then
+ * get_state into caller buffers of J*(N-1), J*(N-1), J*N and N doubles
+ * (reference storage order). */
+int clr_solver_get_dims(const clr_solver* s, int* computed, int* N, int* J, double* log_det);
+int clr_solver_get_state(const clr_solver* s, double* phi, double* u, double* W, double* D);
+int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_det,
+                         const double* phi, const double* u, const double* W, const double* D);
+
+/* ---- batched log-likelihood (new; the data-parallel axis) ---------------------
+ * B independent problems = (time series x hyper-parameter draw) pairs that
+ * share N, J_real and J_comp.  One call evaluates, for every problem p,
+ *     loglike[p] = -0.5 (y^T K_p^-1 y + log det K_p + N log 2 pi)
+ * i.e. exactly GP.compute + GP.log_likelihood (celerite/celerite.py:103-219)
+ * with the -inf rules of celerite.py:205-218 applied (quiet=True semantics:
+ * status[p] = CLR_NOT_POSITIVE_DEFINITE and loglike[p] = -inf instead of an
+ * exception; a bad problem never disturbs its neighbours).
+ *
+ * Coefficients are [B][J_real] / [B][J_comp] row-major, jitter is [B].
+ * A series array is [B][N] with *_stride = N, or one shared [N] series with
+ * *_stride = 0 (the "one light curve, B posterior draws" case). */
+
+typedef struct clr_batch clr_batch;
+
+/* Plans device buffers + workspace for (B, N, J_real, J_comp) on `device`.
+ * General terms are not part of the batched path.  J_real + 2 J_comp must be
+ * in [1, 8] for now (CLR_UNSUPPORTED otherwise). */
+clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device);
+void clr_batch_destroy(clr_batch* h);
+
+/* Host -> HBM. */
+int clr_batch_set_series(clr_batch* h,
+                         const double* t, long t_stride,
+                         const double* diag, long diag_stride,
+                         const double* y, long y_stride);
+int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
+                               const double* a_real, const double* c_real,
+                               const double* a_comp, const double* b_comp,
+                               const double* c_comp, const double* d_comp);
+
+/* Tuning: number of chunks the N axis is cut into for the scan (0 = auto). */
+int clr_batch_set_chunks(clr_batch* h, int nchunk);
+int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);
+
+/* Enqueue one evaluation of all B problems on the handle's stream (inputs
+ * already resident in HBM).  `materialize` != 0 additionally writes the
+ * reference-layout factor (phi, u, W, D per problem; 8 N (3J+1) bytes each)
+ * to HBM, as B separate CholeskySolver.compute calls would. */
+int clr_batch_enqueue(clr_batch* h, int materialize);
+/* Wait for the stream. */
+int clr_batch_synchronize(clr_batch* h);
+/* HBM -> host; any pointer may be NULL. */
+int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
+                          double* quad, int* status);
+/* After a materialising run: copy problem p's factor to host buffers. */
+int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D);
+
+/* Runs `steps` evaluations back to back, bracketing every kernel with HIP
+ * events recorded on the handle's stream.  kernel_ms[4] receives the SUMMED
+ * device time of the summarise / prefix / replay / finalise kernels,
+ * total_ms the first-event-to-last-event time. */
+int clr_batch_run_timed(clr_batch* h, int materialize, int steps,
+                        double* total_ms, double* kernel_ms /* [4] */);
+
+/* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
+int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,
+                             const double* jitter,
+                             const double* a_real, const double* c_real,
+                             const double* a_comp, const double* b_comp,
+                             const double* c_comp, const double* d_comp,
+                             const double* t, long t_stride,
+                             const double* diag, long diag_stride,
+                             const double* y, long y_stride,
+                             double* loglike, double* logdet, double* quad,
+                             int* status, int device);
+
+/* ---- O(J) host helpers the Python layer imports (celerite/terms.py:18) --------
+ * Plain host C++ (no device work): cpp/include/celerite/utils.h:106-163,27-104. */
+double clr_kernel_value(int J_real, const double* a_real, const double* c_real,
+                        int J_comp, const double* a_comp, const double* b_comp,
+                        const double* c_comp, const double* d_comp, double tau);
+double clr_psd_value(int J_real, const double* a_real, const double* c_real,
+                     int J_comp, const double* a_comp, const double* b_comp,
+                     const double* c_comp, const double* d_comp, double omega);
+int clr_check_coefficients(int n_a_real, const double* a_real, int n_c_real, const double* c_real,
+                           int n_a_comp, const double* a_comp, int n_b_comp, const double* b_comp,
+                           int n_c_comp, const double* c_comp, int n_d_comp, const double* d_comp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELERITE_HIP_H */

@@ -1,0 +1,89 @@
+// tests/hostcheck/hostcheck.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host (g++) instantiation of the per-lane device templates in
+// celerite_amd/csrc/clr_core.h, with the GPU grid replaced by plain loops, so
+// the scan algebra (summarize -> prefix -> replay) can be checked against the
+// oracle in the CPU-only test run.  Not linked into libcelerite_hip.so, never
+// used by the product: the shipped library has no CPU implementation.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../celerite_amd/csrc/clr_core.h"
+
+using namespace clr;
+
+template <int JR, int JC>
+static int run(int B, int N, int nchunk, const double* jitter, const double* a_real,
+               const double* c_real, const double* a_comp, const double* b_comp,
+               const double* c_comp, const double* d_comp, const double* t, long ts,
+               const double* diag, long ds, const double* y, long ys, int materialize,
+               double* ll, double* logdet, double* quad, int* status, double* phi, double* u,
+               double* W, double* D) {
+  using Wd = Widths<JR, JC>;
+  constexpr int J = Wd::J;
+  const int L = (N + nchunk - 1) / nchunk;
+  std::vector<double> elems((size_t)nchunk * Wd::ELEM), starts((size_t)nchunk * Wd::START);
+  for (int b = 0; b < B; ++b) {
+    Problem<JR, JC> p;
+    p.load(a_real + (long)b * JR, c_real + (long)b * JR, a_comp + (long)b * JC,
+           b_comp + (long)b * JC, c_comp + (long)b * JC, d_comp + (long)b * JC, jitter[b]);
+    const double *tb = t + b * ts, *db = diag + b * ds, *yb = y + b * ys;
+    for (int c = 0; c + 1 < nchunk; ++c) {
+      if ((c + 1) * L >= N) continue;  // element would run past the data; never applied
+      summarize_chunk<JR, JC>(p, tb, db, yb, c * L, (c + 1) * L, &elems[(size_t)c * Wd::ELEM]);
+    }
+    double S[Wd::SZ] = {0}, f[J] = {0};
+    for (int c = 0; c + 1 < nchunk; ++c) {
+      if ((c + 1) * L >= N) break;
+      apply_element<J>(&elems[(size_t)c * Wd::ELEM], S, f);
+      memcpy(&starts[(size_t)(c + 1) * Wd::START], S, sizeof(S));
+      memcpy(&starts[(size_t)(c + 1) * Wd::START + Wd::SZ], f, sizeof(f));
+    }
+    double ld = 0, qd = 0;
+    int bad = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const int n0 = c * L;
+      if (n0 >= N) break;
+      const int n1 = n0 + L < N ? n0 + L : N;
+      double l, q;
+      int fl;
+      const long Nm1 = N - 1;
+      if (materialize)
+        replay_chunk<JR, JC, true>(p, tb, db, yb, N, n0, n1,
+                                   c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
+                                   phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
+                                   W + (long)b * J * N, D + (long)b * N);
+      else
+        replay_chunk<JR, JC, false>(p, tb, db, yb, N, n0, n1,
+                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
+                                    nullptr, nullptr, nullptr, nullptr);
+      ld += l;
+      qd += q;
+      bad |= fl;
+    }
+    status[b] = bad ? 2 : 0;
+    logdet[b] = bad ? NAN : ld;
+    quad[b] = bad ? NAN : qd;
+    ll[b] = bad ? -INFINITY : combine_loglike(ld, qd, N);
+  }
+  return 0;
+}
+
+#define CASE(R, C)                                                                          \
+  if (JR == R && JC == C)                                                                   \
+    return run<R, C>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,  \
+                     t, ts, diag, ds, y, ys, materialize, ll, logdet, quad, status, phi, u, \
+                     W, D);
+
+extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const double* jitter,
+                               const double* a_real, const double* c_real,
+                               const double* a_comp, const double* b_comp,
+                               const double* c_comp, const double* d_comp, const double* t,
+                               long ts, const double* diag, long ds, const double* y, long ys,
+                               int materialize, double* ll, double* logdet, double* quad,
+                               int* status, double* phi, double* u, double* W, double* D) {
+  CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(0, 2) CASE(2, 2)
+  CASE(2, 3) CASE(0, 4) CASE(4, 2) CASE(8, 0)
+  return -1;
+}
