@@ -1,0 +1,51 @@
+# Build of the MI355X (gfx950) celerite hot path.
+#
+#   make            -> celerite_amd/libcelerite_hip.so   (HIP kernels + C ABI, include/celerite_hip.h)
+#                      celerite_amd/solver.<ext>.so      (pybind11 module `celerite_amd.solver`)
+#                      oracle/libcelerite_ref.so         (CPU oracle; test infrastructure only)
+#
+# hipcc cross-compiles gfx950 code objects without a GPU.  The built .so files are
+# git-ignored but travel to the GPU box with the source snapshot.
+HIPCC      ?= /opt/rocm/bin/hipcc
+CXX        ?= g++
+PYTHON     ?= python3
+ARCH       ?= gfx950
+HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+CXXFLAGS   ?= -O2 -std=c++17 -fPIC -Wall
+EXT_SUFFIX := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
+PY_INC     := $(shell $(PYTHON) -m pybind11 --includes)
+
+CSRC   := celerite_amd/csrc
+BUILD  := build
+LIB    := celerite_amd/libcelerite_hip.so
+PYMOD  := celerite_amd/solver$(EXT_SUFFIX)
+ORACLE := oracle/libcelerite_ref.so
+
+HIP_SRCS := api generic_kernels batch_w1 batch_w2 batch_w3 batch_w4 batch_w5 batch_w6 batch_w7 batch_w8
+HIP_OBJS := $(addprefix $(BUILD)/,$(addsuffix .o,$(HIP_SRCS)))
+HDRS     := $(CSRC)/clr_core.h $(CSRC)/clr_batch_kernels.h $(CSRC)/clr_generic_kernels.h include/celerite_hip.h
+
+all: $(LIB) $(PYMOD) $(ORACLE)
+
+$(BUILD):
+	mkdir -p $(BUILD)
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(HDRS) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/host_helpers.o: $(CSRC)/host_helpers.cpp include/celerite_hip.h | $(BUILD)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJS) $(BUILD)/host_helpers.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+
+$(PYMOD): $(CSRC)/solver_pybind.cpp include/celerite_hip.h $(LIB)
+	$(CXX) $(CXXFLAGS) $(PY_INC) -shared $< -o $@ -Lcelerite_amd -lcelerite_hip -Wl,-rpath,'$$ORIGIN'
+
+$(ORACLE): oracle/celerite_ref.c oracle/celerite_ref_loops.inc oracle/celerite_ref.h
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(BUILD) $(LIB) $(PYMOD) $(ORACLE)
+
+.PHONY: all clean

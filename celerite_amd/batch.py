@@ -1,0 +1,251 @@
+# -*- coding: utf-8 -*-
+"""Batched log-likelihoods: B independent (time series x hyper-parameter draw)
+problems per call -- the data-parallel axis the reference does not have.
+
+One evaluation of problem ``p`` is exactly ``GP.compute`` + ``GP.log_likelihood``
+of the reference (celerite/celerite.py:103-219):
+``-0.5 (r^T K_p^-1 r + log det K_p + N log 2 pi)``, with ``quiet=True``
+semantics for matrices that are not positive definite (``status[p] == 2`` and
+``-inf``).  The arithmetic runs as the chunked-scan HIP kernels of
+``csrc/clr_core.h`` through ``clr_batch_*`` in ``include/celerite_hip.h``; this
+file is plumbing (ctypes).  There is no CPU fallback: without an MI355X every
+call raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["BatchedGP", "batch_log_likelihood", "kernel_coefficient_table", "LIB_PATH"]
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcelerite_hip.so")
+
+CLR_OK, CLR_NOT_POSITIVE_DEFINITE = 0, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libcelerite_hip.so is not built: run `make` at the repository "
+                          "root; there is no pure-Python fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.clr_last_error.restype = C.c_char_p
+    lib.clr_status_string.restype = C.c_char_p
+    lib.clr_status_string.argtypes = [C.c_int]
+    lib.clr_version.restype = C.c_char_p
+    lib.clr_batch_create.restype = C.c_void_p
+    lib.clr_batch_create.argtypes = [C.c_int] * 5
+    lib.clr_batch_destroy.argtypes = [C.c_void_p]
+    lib.clr_batch_set_series.argtypes = [C.c_void_p, _dp, C.c_long, _dp, C.c_long, _dp, C.c_long]
+    lib.clr_batch_set_coefficients.argtypes = [C.c_void_p] + [_dp] * 7
+    lib.clr_batch_set_chunks.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_get_chunks.argtypes = [C.c_void_p, _ip, _ip]
+    lib.clr_batch_enqueue.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_synchronize.argtypes = [C.c_void_p]
+    lib.clr_batch_get_results.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
+    lib.clr_batch_get_factor.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+    lib.clr_batch_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
+    lib.clr_device_info.argtypes = [C.c_char_p, C.c_size_t, _ip, C.POINTER(C.c_size_t)]
+    lib.clr_set_device.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status == CLR_OK:
+        return
+    lib = _load()
+    msg = lib.clr_status_string(status).decode()
+    detail = lib.clr_last_error().decode()
+    raise RuntimeError(msg + (": " + detail if detail else ""))
+
+
+def device_count():
+    return int(_load().clr_device_count())
+
+
+def device_synchronize():
+    _check(_load().clr_device_synchronize())
+
+
+def device_info():
+    lib = _load()
+    name = C.create_string_buffer(256)
+    cus = C.c_int()
+    mem = C.c_size_t()
+    _check(lib.clr_device_info(name, 256, C.byref(cus), C.byref(mem)))
+    return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=mem.value)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class BatchedGP(object):
+    """Device-resident plan for B problems of N samples and a fixed kernel shape.
+
+    Args:
+        B, N: batch size and samples per series.
+        J_real, J_comp: number of real / complex celerite terms
+            (width ``J = J_real + 2 J_comp`` must be in 1..8).
+        device: GPU index (one process per GPU; shard the batch across ranks).
+    """
+
+    def __init__(self, B, N, J_real, J_comp, device=0):
+        lib = _load()
+        self.B, self.N, self.J_real, self.J_comp = int(B), int(N), int(J_real), int(J_comp)
+        self.J = self.J_real + 2 * self.J_comp
+        self._h = lib.clr_batch_create(self.B, self.N, self.J_real, self.J_comp, int(device))
+        if not self._h:
+            raise RuntimeError("clr_batch_create failed: " + lib.clr_last_error().decode())
+        self._h = C.c_void_p(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().clr_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs -------------------------------------------------------------
+    def set_series(self, t, diag, y):
+        """``t``, ``diag`` (= yerr**2), ``y`` (mean already subtracted): each
+        ``(B, N)`` or ``(N,)`` for one series shared by all problems.  ``t``
+        must be sorted along the last axis (checked: GP.compute does the same,
+        celerite.py:126-129)."""
+        arrs, strides = [], []
+        for a in (t, diag, y):
+            a = _f64(a)
+            if a.shape == (self.N,):
+                strides.append(0)
+            elif a.shape == (self.B, self.N):
+                strides.append(self.N)
+            else:
+                raise ValueError("dimension mismatch")
+            arrs.append(a)
+        if np.any(np.diff(arrs[0], axis=-1) < 0.0):
+            raise ValueError("the input coordinates must be sorted")
+        _check(_load().clr_batch_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
+                                            strides[1], _ptr(arrs[2]), strides[2]))
+
+    def set_coefficients(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
+        """Coefficient tables ``(B, J_real)`` / ``(B, J_comp)``; ``jitter`` scalar or ``(B,)``."""
+        try:
+            blocks = [_f64(a_real, (self.B, self.J_real)), _f64(c_real, (self.B, self.J_real)),
+                      _f64(a_comp, (self.B, self.J_comp)), _f64(b_comp, (self.B, self.J_comp)),
+                      _f64(c_comp, (self.B, self.J_comp)), _f64(d_comp, (self.B, self.J_comp))]
+        except ValueError:
+            raise ValueError("dimension mismatch")
+        jit = np.ascontiguousarray(np.broadcast_to(np.asarray(jitter, dtype=np.float64), (self.B,)))
+        _check(_load().clr_batch_set_coefficients(self._h, _ptr(jit), *[_ptr(b) for b in blocks]))
+
+    # -- tuning -------------------------------------------------------------
+    def set_chunks(self, nchunk):
+        _check(_load().clr_batch_set_chunks(self._h, int(nchunk)))
+
+    @property
+    def chunks(self):
+        n, l = C.c_int(), C.c_int()
+        _load().clr_batch_get_chunks(self._h, C.byref(n), C.byref(l))
+        return n.value, l.value
+
+    # -- evaluation -----------------------------------------------------------
+    def enqueue(self, materialize=False):
+        _check(_load().clr_batch_enqueue(self._h, int(bool(materialize))))
+
+    def synchronize(self):
+        _check(_load().clr_batch_synchronize(self._h))
+
+    def results(self):
+        ll = np.empty(self.B)
+        ld = np.empty(self.B)
+        q = np.empty(self.B)
+        st = np.empty(self.B, dtype=np.int32)
+        _check(_load().clr_batch_get_results(self._h, _ptr(ll), _ptr(ld), _ptr(q),
+                                             st.ctypes.data_as(_ip)))
+        return ll, ld, q, st
+
+    def log_likelihood(self, materialize=False):
+        """Evaluate all B problems; returns ``(loglike, logdet, quad, status)``."""
+        self.enqueue(materialize)
+        return self.results()
+
+    def factor(self, p):
+        """``(phi, u, W, D)`` of problem ``p`` after a materialising run, shaped
+        like the reference's pickled state (solver.cpp:36-42)."""
+        N, J = self.N, self.J
+        phi = np.empty((N - 1, J))
+        u = np.empty((N - 1, J))
+        W = np.empty((N, J))
+        D = np.empty(N)
+        _check(_load().clr_batch_get_factor(self._h, int(p), _ptr(phi), _ptr(u), _ptr(W), _ptr(D)))
+        return phi.T, u.T, W.T, D
+
+    def run_timed(self, steps, materialize=False):
+        """``steps`` back-to-back evaluations bracketed by HIP events on the
+        plan's stream.  Returns ``(total_ms, [summarize, prefix, replay,
+        finalize] summed ms)``."""
+        tot = C.c_double()
+        k = (C.c_double * 4)()
+        _check(_load().clr_batch_run_timed(self._h, int(bool(materialize)), int(steps),
+                                           C.byref(tot), k))
+        return tot.value, [k[i] for i in range(4)]
+
+
+def batch_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y,
+                         jitter=0.0, device=0, nchunk=0):
+    """One-shot batched evaluation; see :class:`BatchedGP`."""
+    a_real = np.atleast_2d(_f64(a_real))
+    B, J_real = a_real.shape
+    a_comp = _f64(a_comp).reshape(B, -1)
+    N = np.asarray(t).shape[-1]
+    plan = BatchedGP(B, N, J_real, a_comp.shape[1], device=device)
+    try:
+        if nchunk:
+            plan.set_chunks(nchunk)
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter)
+        return plan.log_likelihood()
+    finally:
+        plan.close()
+
+
+def kernel_coefficient_table(kernel, parameter_vectors):
+    """Coefficient tables for many hyper-parameter draws of one ``terms.Term``.
+
+    ``parameter_vectors``: ``(B, kernel.vector_size)``.  Returns
+    ``(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter)`` ready for
+    :meth:`BatchedGP.set_coefficients`.  The kernel's parameters are restored.
+    Every draw must give the same number of real / complex terms.
+    """
+    saved = kernel.get_parameter_vector()
+    rows, jit = [], []
+    try:
+        for p in np.atleast_2d(parameter_vectors):
+            kernel.set_parameter_vector(p)
+            rows.append([np.array(b, dtype=np.float64) for b in kernel.coefficients])
+            jit.append(float(kernel.jitter))
+    finally:
+        kernel.set_parameter_vector(saved)
+    shapes = set(tuple(len(b) for b in r) for r in rows)
+    if len(shapes) != 1:
+        raise ValueError("the draws do not share one (J_real, J_comp) shape")
+    blocks = [np.array([r[i] for r in rows]).reshape(len(rows), -1) for i in range(6)]
+    return tuple(blocks) + (np.array(jit),)

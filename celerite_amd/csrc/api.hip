@@ -1,0 +1,949 @@
+// celerite_amd/csrc/api.hip -- the C ABI of include/celerite_hip.h: handles, HBM
+// residency, path selection and kernel launches.  No arithmetic of the hot path
+// happens on the host: without a gfx950 device every compute entry fails with
+// CLR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/celerite_hip.h"
+#include "clr_batch_kernels.h"
+#include "clr_generic_kernels.h"
+
+namespace clr {
+const BatchLaunchers* batch_launchers_w1(int, int);
+const BatchLaunchers* batch_launchers_w2(int, int);
+const BatchLaunchers* batch_launchers_w3(int, int);
+const BatchLaunchers* batch_launchers_w4(int, int);
+const BatchLaunchers* batch_launchers_w5(int, int);
+const BatchLaunchers* batch_launchers_w6(int, int);
+const BatchLaunchers* batch_launchers_w7(int, int);
+const BatchLaunchers* batch_launchers_w8(int, int);
+
+const BatchLaunchers* find_batch_launchers(int JR, int JC) {
+  switch (JR + 2 * JC) {
+    case 1: return batch_launchers_w1(JR, JC);
+    case 2: return batch_launchers_w2(JR, JC);
+    case 3: return batch_launchers_w3(JR, JC);
+    case 4: return batch_launchers_w4(JR, JC);
+    case 5: return batch_launchers_w5(JR, JC);
+    case 6: return batch_launchers_w6(JR, JC);
+    case 7: return batch_launchers_w7(JR, JC);
+    case 8: return batch_launchers_w8(JR, JC);
+    default: return nullptr;
+  }
+}
+
+__global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B) return;
+  double ld = 0.0, qd = 0.0;
+  int bad = 0;
+  for (int c = 0; c < P.nchunk; ++c) {
+    ld += P.part[((long)b * P.nchunk + c) * 2 + 0];
+    qd += P.part[((long)b * P.nchunk + c) * 2 + 1];
+    bad |= P.flags[(long)b * P.nchunk + c];
+  }
+  if (bad) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
+    P.out_status[b] = CLR_NOT_POSITIVE_DEFINITE;
+    P.out_ll[b] = -INFINITY;
+    P.out_logdet[b] = NAN;
+    P.out_quad[b] = NAN;
+    return;
+  }
+  P.out_status[b] = CLR_OK;
+  P.out_logdet[b] = ld;
+  P.out_quad[b] = qd;
+  P.out_ll[b] = combine_loglike(ld, qd, P.N);
+}
+
+void launch_finalize(const BatchParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+}
+}  // namespace clr
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local int g_device = 0;
+
+int fail(int status, const std::string& msg) {
+  g_last_error = msg;
+  return status;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(CLR_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+int visible_gfx950() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int ok = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess &&
+        strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+      ++ok;
+  }
+  return ok;
+}
+
+int require_device(int device) {
+  static int count = -1;
+  if (count < 0) count = visible_gfx950();
+  if (count <= 0)
+    return fail(CLR_NO_DEVICE,
+                "no gfx950 (MI355X) device is visible; libcelerite_hip has no CPU path");
+  if (device < 0 || device >= count) return fail(CLR_INVALID_ARGUMENT, "bad device index");
+  HIP_TRY(hipSetDevice(device));
+  return CLR_OK;
+}
+
+// Grow-only device buffer.
+struct DevBuf {
+  double* p = nullptr;
+  size_t cap = 0;  // doubles
+  int reserve(size_t n) {
+    if (n <= cap && p) return CLR_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(n, 1);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(double)));
+    cap = want;
+    return CLR_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+int upload(DevBuf& buf, const double* host, size_t n, hipStream_t s) {
+  int st = buf.reserve(n);
+  if (st != CLR_OK) return st;
+  if (n) HIP_TRY(hipMemcpyAsync(buf.p, host, n * sizeof(double), hipMemcpyHostToDevice, s));
+  return CLR_OK;
+}
+
+// Chunk count for the scan on `B` problems of `N` samples.
+int auto_chunks(int B, int N) {
+  if (N < 128) return 1;
+  // aim at ~2 waves per SIMD (256 CUs x 4 SIMDs x 64 lanes x 2) over the batch,
+  // keep chunks at least 48 samples long, and a multiple of 64 lanes per problem
+  const long target_lanes = 131072;
+  long per = (target_lanes + B - 1) / B;
+  per = ((per + 63) / 64) * 64;
+  const long max_by_len = std::max<long>(1, N / 48);
+  if (per > max_by_len) per = max_by_len;
+  if (per > 64) per = (per / 64) * 64;
+  if (per < 1) per = 1;
+  return (int)per;
+}
+
+}  // namespace
+
+/* ======================================================================== */
+struct clr_solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool have_stream = false;
+  int computed = 0, N = 0, J = 0;
+  double log_det = 0.0;
+  int J_real = 0, J_comp = 0, J_general = 0;
+  DevBuf phi, u, W, D;                  // the factor (reference layout)
+  DevBuf coeffs;                        // a_real c_real a_comp b_comp c_comp d_comp
+  DevBuf t, U, V;                       // inputs kept for predict / dot
+  DevBuf scratch, scratch2, scalars;    // right-hand sides, results
+  DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
+  int* ws_flags = nullptr;
+  size_t ws_flags_cap = 0;
+  int* d_status = nullptr;
+};
+
+struct clr_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
+  int nchunk = 1, L = 0;
+  const clr::BatchLaunchers* launch = nullptr;
+  DevBuf jitter, coeffs, t, diag, y;
+  long t_stride = 0, diag_stride = 0, y_stride = 0;
+  bool have_series = false, have_coeffs = false, have_factor = false;
+  DevBuf elems, starts, part, out;  // out: ll | logdet | quad
+  int* flags = nullptr;
+  int* status = nullptr;
+  DevBuf phi, u, W, D;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int ensure_stream(clr_solver* s) {
+  int st = require_device(s->device);
+  if (st != CLR_OK) return st;
+  if (!s->have_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_status), sizeof(int) * 4));
+    s->have_stream = true;
+  }
+  return CLR_OK;
+}
+
+clr::GenericProblem generic_view(const clr_solver* s) {
+  clr::GenericProblem g;
+  g.N = s->N;
+  g.J = s->J;
+  g.J_real = s->J_real;
+  g.J_comp = s->J_comp;
+  g.J_general = s->J_general;
+  const double* c = s->coeffs.p;
+  g.a_real = c;
+  g.c_real = c + s->J_real;
+  g.a_comp = c + 2 * s->J_real;
+  g.b_comp = g.a_comp + s->J_comp;
+  g.c_comp = g.b_comp + s->J_comp;
+  g.d_comp = g.c_comp + s->J_comp;
+  g.U = s->U.p;
+  g.V = s->V.p;
+  g.t = s->t.p;
+  return g;
+}
+
+int reserve_flags(int*& p, size_t& cap, size_t n) {
+  if (n <= cap && p) return CLR_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(int)));
+  cap = std::max<size_t>(n, 1);
+  return CLR_OK;
+}
+
+int check_coeff_dims(int n_a_real, int n_c_real, int n_a_comp, int n_b_comp, int n_c_comp,
+                     int n_d_comp, int n_A, int U_rows, int U_cols, int V_rows, int V_cols,
+                     int N) {
+  // cholesky.h:59-69 / :459-469
+  if (n_a_real != n_c_real || n_a_comp != n_b_comp || n_a_comp != n_c_comp ||
+      n_a_comp != n_d_comp)
+    return CLR_DIMENSION_MISMATCH;
+  const bool has_general = (n_A != 0);
+  if (has_general && (n_A != N || U_cols != N || V_cols != N)) return CLR_DIMENSION_MISMATCH;
+  if (U_rows != V_rows) return CLR_DIMENSION_MISMATCH;
+  return CLR_OK;
+}
+
+// Packs the six coefficient blocks contiguously and uploads them.
+int upload_coeffs(DevBuf& buf, int J_real, const double* a_real, const double* c_real,
+                  int J_comp, const double* a_comp, const double* b_comp, const double* c_comp,
+                  const double* d_comp, hipStream_t stream, std::vector<double>& host) {
+  host.clear();
+  host.insert(host.end(), a_real, a_real + J_real);
+  host.insert(host.end(), c_real, c_real + J_real);
+  host.insert(host.end(), a_comp, a_comp + J_comp);
+  host.insert(host.end(), b_comp, b_comp + J_comp);
+  host.insert(host.end(), c_comp, c_comp + J_comp);
+  host.insert(host.end(), d_comp, d_comp + J_comp);
+  return upload(buf, host.data(), host.size(), stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ---- library / device ------------------------------------------------------ */
+const char* clr_version(void) { return "0.3.0"; }
+const char* clr_last_error(void) { return g_last_error.c_str(); }
+
+const char* clr_status_string(int status) {
+  switch (status) {
+    case CLR_OK: return "ok";
+    case CLR_DIMENSION_MISMATCH: return "dimension mismatch";
+    case CLR_NOT_POSITIVE_DEFINITE: return "failed to factorize or solve matrix";
+    case CLR_NOT_COMPUTED: return "you must call 'compute' first";
+    case CLR_NO_DEVICE: return "no gfx950 device available (libcelerite_hip has no CPU path)";
+    case CLR_HIP_ERROR: return "HIP runtime error";
+    case CLR_INVALID_ARGUMENT: return "invalid argument";
+    case CLR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+int clr_device_count(void) { return visible_gfx950(); }
+
+int clr_set_device(int device) {
+  int st = require_device(device);
+  if (st == CLR_OK) g_device = device;
+  return st;
+}
+
+int clr_get_device(int* device) {
+  *device = g_device;
+  return CLR_OK;
+}
+
+int clr_device_synchronize(void) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  HIP_TRY(hipDeviceSynchronize());
+  return CLR_OK;
+}
+
+int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm_bytes) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return CLR_OK;
+}
+
+/* ---- single-problem solver --------------------------------------------------- */
+clr_solver* clr_solver_create(void) {
+  clr_solver* s = new clr_solver();
+  s->device = g_device;
+  return s;  // device resources are acquired lazily, so construction never fails
+}
+
+void clr_solver_destroy(clr_solver* s) {
+  if (!s) return;
+  if (s->have_stream) {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
+                      &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
+                      &s->ws_part})
+      b->release();
+    if (s->ws_flags) (void)hipFree(s->ws_flags);
+    if (s->d_status) (void)hipFree(s->d_status);
+    (void)hipStreamDestroy(s->stream);
+  }
+  delete s;
+}
+
+int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double* a_real,
+                       int n_c_real, const double* c_real, int n_a_comp, const double* a_comp,
+                       int n_b_comp, const double* b_comp, int n_c_comp, const double* c_comp,
+                       int n_d_comp, const double* d_comp, int n_A, const double* A, int U_rows,
+                       int U_cols, const double* U, int V_rows, int V_cols, const double* V,
+                       int n_x, const double* x, int n_diag, const double* diag) {
+  const int N = n_x;
+  s->computed = 0;  // cholesky.h:57
+  if (N != n_diag) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+  int st = check_coeff_dims(n_a_real, n_c_real, n_a_comp, n_b_comp, n_c_comp, n_d_comp, n_A,
+                            U_rows, U_cols, V_rows, V_cols, N);
+  if (st != CLR_OK) return fail(st, "dimension mismatch");
+  if (N < 1) return fail(CLR_INVALID_ARGUMENT, "compute needs at least one sample");
+  const bool has_general = (n_A != 0);
+  const int J_general = U_rows, J_real = n_a_real, J_comp = n_a_comp;
+  const int J = J_real + 2 * J_comp + J_general;
+  if (J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  // rows of U/V are only read when general terms are active (cholesky.h:148-152
+  // would read them regardless; a non-empty U with empty A is a caller error)
+  if (J_general > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+
+  st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  hipStream_t stream = s->stream;
+
+  s->N = N;
+  s->J = J;
+  s->J_real = J_real;
+  s->J_comp = J_comp;
+  s->J_general = J_general;
+  const size_t Nm1 = (size_t)(N - 1);
+  if ((st = s->phi.reserve((size_t)J * Nm1)) != CLR_OK) return st;
+  if ((st = s->u.reserve((size_t)J * Nm1)) != CLR_OK) return st;
+  if ((st = s->W.reserve((size_t)J * N)) != CLR_OK) return st;
+  if ((st = s->D.reserve((size_t)N)) != CLR_OK) return st;
+  if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
+
+  std::vector<double> hc;
+  if ((st = upload_coeffs(s->coeffs, J_real, a_real, c_real, J_comp, a_comp, b_comp, c_comp,
+                          d_comp, stream, hc)) != CLR_OK)
+    return st;
+  if ((st = upload(s->t, x, (size_t)N, stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(stream));  // hc is about to go out of use below
+
+  int h_status = 0;
+  double h_logdet = 0.0;
+
+  if (J == 0) {  // cholesky.h:90-95
+    if ((st = upload(s->scratch, diag, (size_t)N, stream)) != CLR_OK) return st;
+    clr::launch_diag_only(N, s->scratch.p, jitter, s->D.p, s->scalars.p, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h_logdet, s->scalars.p, sizeof(double), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  } else if (!has_general && J <= 8 && clr::find_batch_launchers(J_real, J_comp)) {
+    // fixed-width chunked scan, materialising the reference-layout factor
+    const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
+    if ((st = upload(s->scratch, diag, (size_t)N, stream)) != CLR_OK) return st;
+    if ((st = upload(s->scratch2, &jitter, 1, stream)) != CLR_OK) return st;
+    clr::BatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.B = 1;
+    P.N = N;
+    P.nchunk = auto_chunks(1, N);
+    P.L = (N + P.nchunk - 1) / P.nchunk;
+    P.nchunk = (N + P.L - 1) / P.L;  // drop empty trailing chunks
+    if ((st = s->ws_elems.reserve((size_t)P.nchunk * L->elem_doubles)) != CLR_OK) return st;
+    if ((st = s->ws_starts.reserve((size_t)P.nchunk * L->start_doubles)) != CLR_OK) return st;
+    if ((st = s->ws_part.reserve((size_t)P.nchunk * 2)) != CLR_OK) return st;
+    if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk)) != CLR_OK) return st;
+    const clr::GenericProblem g = generic_view(s);
+    P.jitter = s->scratch2.p;
+    P.a_real = g.a_real; P.c_real = g.c_real;
+    P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
+    P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;  // y is irrelevant for compute
+    P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
+    P.flags = s->ws_flags;
+    P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
+    P.out_status = s->d_status;
+    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    L->summarize(P, stream);
+    L->prefix(P, stream);
+    L->replay(P, true, stream);
+    clr::launch_finalize(P, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&h_logdet, s->scalars.p + 1, sizeof(double), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
+  } else {
+    // any width / general terms: diagonal summed on the host in the reference's
+    // order (cholesky.h:98-99), recurrence on the device
+    double sum_ar = 0.0, sum_ac = 0.0;
+    for (int j = 0; j < J_real; ++j) sum_ar += a_real[j];
+    for (int j = 0; j < J_comp; ++j) sum_ac += a_comp[j];
+    std::vector<double> d0((size_t)N);
+    for (int n = 0; n < N; ++n) {
+      d0[n] = ((diag[n] + sum_ar) + sum_ac) + jitter;
+      if (has_general) d0[n] += A[n];
+    }
+    if ((st = upload(s->D, d0.data(), (size_t)N, stream)) != CLR_OK) return st;
+    if (J_general) {
+      if ((st = upload(s->U, U, (size_t)J_general * N, stream)) != CLR_OK) return st;
+      if ((st = upload(s->V, V, (size_t)J_general * N, stream)) != CLR_OK) return st;
+    }
+    const clr::GenericProblem g = generic_view(s);
+    clr::launch_factor_generic(g, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p,
+                               stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&h_logdet, s->scalars.p, sizeof(double), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+
+  if (h_status != 0)
+    return fail(CLR_NOT_POSITIVE_DEFINITE, "failed to factorize or solve matrix");
+  s->log_det = h_logdet;
+  s->computed = 1;
+  return CLR_OK;
+}
+
+int clr_solver_computed(const clr_solver* s) { return s->computed; }
+
+int clr_solver_log_determinant(const clr_solver* s, double* out) {
+  if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
+  *out = s->log_det;
+  return CLR_OK;
+}
+
+int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double* out) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  if (n_b != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // :327
+  if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
+  int st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
+  if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
+  clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                        s->scalars.p, s->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, s->scalars.p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return CLR_OK;
+}
+
+static int sweep_common(clr_solver* s, int rows, int nrhs, const double* in) {
+  if (rows != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+  if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
+  int st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  const size_t n = (size_t)s->N * (size_t)std::max(nrhs, 0);
+  if ((st = upload(s->scratch, in, n, s->stream)) != CLR_OK) return st;
+  return s->scratch2.reserve(n);
+}
+
+int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b, double* x) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  int st = sweep_common(s, b_rows, nrhs, b);
+  if (st != CLR_OK) return st;
+  if (nrhs <= 0) return CLR_OK;
+  clr::launch_solve(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                    s->scratch2.p, s->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(x, s->scratch2.p, sizeof(double) * (size_t)s->N * nrhs,
+                         hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return CLR_OK;
+}
+
+int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z, double* y) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  int st = sweep_common(s, z_rows, nrhs, z);
+  if (st != CLR_OK) return st;
+  if (nrhs <= 0) return CLR_OK;
+  clr::launch_dot_L(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                    s->scratch2.p, s->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(y, s->scratch2.p, sizeof(double) * (size_t)s->N * nrhs,
+                         hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return CLR_OK;
+}
+
+int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_real,
+                   int n_c_real, const double* c_real, int n_a_comp, const double* a_comp,
+                   int n_b_comp, const double* b_comp, int n_c_comp, const double* c_comp,
+                   int n_d_comp, const double* d_comp, int n_A, const double* A, int U_rows,
+                   int U_cols, const double* U, int V_rows, int V_cols, const double* V, int n_x,
+                   const double* x, int z_rows, int nrhs, const double* z, double* y) {
+  const int N = z_rows;
+  if (n_x != z_rows) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // :459
+  int st = check_coeff_dims(n_a_real, n_c_real, n_a_comp, n_b_comp, n_c_comp, n_d_comp, n_A,
+                            U_rows, U_cols, V_rows, V_cols, N);
+  if (st != CLR_OK) return fail(st, "dimension mismatch");
+  const bool has_general = (n_A != 0);
+  const int J_general = U_rows, J_real = n_a_real, J_comp = n_a_comp;
+  const int J = J_real + 2 * J_comp + J_general;
+  if (J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  if (J_general > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+  if (N < 1 || nrhs < 1) return CLR_OK;
+
+  if ((st = ensure_stream(s)) != CLR_OK) return st;
+  hipStream_t stream = s->stream;
+  const size_t total = (size_t)N * nrhs;
+
+  if (J == 0) {  // cholesky.h:477-481: y = jitter * z (scaling done by the device copy engine
+                 // would need a kernel; reuse the sweep with an all-zero width instead)
+    if ((st = upload(s->scratch, z, total, stream)) != CLR_OK) return st;
+    std::vector<double> dg((size_t)N, jitter);
+    DevBuf tmp;
+    if ((st = upload(tmp, dg.data(), (size_t)N, stream)) != CLR_OK) return st;
+    if ((st = s->scratch2.reserve(total)) != CLR_OK) { tmp.release(); return st; }
+    clr::launch_dot(N, 0, nrhs, nullptr, nullptr, nullptr, tmp.p, s->scratch.p, s->scratch2.p,
+                    stream);
+    hipError_t e = hipMemcpyAsync(y, s->scratch2.p, sizeof(double) * total,
+                                  hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    tmp.release();
+    if (e != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e));
+    return CLR_OK;
+  }
+
+  // this call must not disturb a previously computed factor: use private buffers
+  DevBuf coeffs, tt, dU, dV, phi, u, v, dg, zin, yout;
+  auto cleanup = [&]() {
+    for (DevBuf* b : {&coeffs, &tt, &dU, &dV, &phi, &u, &v, &dg, &zin, &yout}) b->release();
+  };
+  std::vector<double> hc;
+  double sum_ar = 0.0, sum_ac = 0.0;
+  for (int j = 0; j < J_real; ++j) sum_ar += a_real[j];
+  for (int j = 0; j < J_comp; ++j) sum_ac += a_comp[j];
+  std::vector<double> hdg((size_t)N);
+  for (int n = 0; n < N; ++n) {
+    hdg[n] = (sum_ar + sum_ac) + jitter;  // cholesky.h:483-485
+    if (has_general) hdg[n] += A[n];
+  }
+#define DOT_TRY(e)                \
+  if ((st = (e)) != CLR_OK) {     \
+    (void)hipStreamSynchronize(stream); \
+    cleanup();                    \
+    return st;                    \
+  }
+  DOT_TRY(upload_coeffs(coeffs, J_real, a_real, c_real, J_comp, a_comp, b_comp, c_comp, d_comp,
+                        stream, hc));
+  DOT_TRY(upload(tt, x, (size_t)N, stream));
+  DOT_TRY(upload(dg, hdg.data(), (size_t)N, stream));
+  DOT_TRY(upload(zin, z, total, stream));
+  if (J_general) {
+    DOT_TRY(upload(dU, U, (size_t)J_general * N, stream));
+    DOT_TRY(upload(dV, V, (size_t)J_general * N, stream));
+  }
+  DOT_TRY(phi.reserve((size_t)J * N));
+  DOT_TRY(u.reserve((size_t)J * N));
+  DOT_TRY(v.reserve((size_t)J * N));
+  DOT_TRY(yout.reserve(total));
+  clr::GenericProblem g;
+  g.N = N; g.J = J; g.J_real = J_real; g.J_comp = J_comp; g.J_general = J_general;
+  g.a_real = coeffs.p; g.c_real = coeffs.p + J_real; g.a_comp = coeffs.p + 2 * J_real;
+  g.b_comp = g.a_comp + J_comp; g.c_comp = g.b_comp + J_comp; g.d_comp = g.c_comp + J_comp;
+  g.U = dU.p; g.V = dV.p; g.t = tt.p;
+  clr::launch_dot_setup(g, phi.p, u.p, v.p, stream);
+  clr::launch_dot(N, J, nrhs, phi.p, u.p, v.p, dg.p, zin.p, yout.p, stream);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(y, yout.p, sizeof(double) * total, hipMemcpyDeviceToHost, stream);
+  hipError_t e2 = hipStreamSynchronize(stream);
+  cleanup();
+#undef DOT_TRY
+  if (e != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e2));
+  return CLR_OK;
+}
+
+int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, const double* xs,
+                       double* pred) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  int st = sweep_common(s, n_y, 1, y);  // also checks N / computed (:600-601)
+  if (st != CLR_OK) return st;
+  if (M <= 0) return CLR_OK;
+  if (s->t.cap < (size_t)s->N || s->coeffs.p == nullptr)
+    return fail(CLR_UNSUPPORTED,
+                "predict needs the inputs of compute(); a solver restored from a pickled "
+                "state does not carry them (same as the reference, solver.cpp:36-42)");
+  hipStream_t stream = s->stream;
+  // alpha = K^-1 y  (:608)
+  clr::launch_solve(s->N, s->J, 1, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                    s->scratch2.p, stream);
+  DevBuf dxs, dpred;
+  if ((st = upload(dxs, xs, (size_t)M, stream)) != CLR_OK) return st;
+  if ((st = dpred.reserve((size_t)M)) != CLR_OK) { dxs.release(); return st; }
+  hipError_t e = hipMemsetAsync(dpred.p, 0, sizeof(double) * (size_t)M, stream);
+  const clr::GenericProblem g = generic_view(s);
+  clr::launch_predict(g, s->scratch2.p, M, dxs.p, dpred.p, stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(pred, dpred.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, stream);
+  hipError_t e2 = hipStreamSynchronize(stream);
+  dxs.release();
+  dpred.release();
+  if (e != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e2));
+  return CLR_OK;
+}
+
+int clr_solver_get_dims(const clr_solver* s, int* computed, int* N, int* J, double* log_det) {
+  if (computed) *computed = s->computed;
+  if (N) *N = s->N;
+  if (J) *J = s->J;
+  if (log_det) *log_det = s->log_det;
+  return CLR_OK;
+}
+
+int clr_solver_get_state(const clr_solver* cs, double* phi, double* u, double* W, double* D) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
+  int st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  const size_t N = (size_t)s->N, J = (size_t)s->J, Nm1 = N - 1;
+  if (J * Nm1) {
+    HIP_TRY(hipMemcpyAsync(phi, s->phi.p, sizeof(double) * J * Nm1, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(u, s->u.p, sizeof(double) * J * Nm1, hipMemcpyDeviceToHost, s->stream));
+  }
+  if (J * N)
+    HIP_TRY(hipMemcpyAsync(W, s->W.p, sizeof(double) * J * N, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(D, s->D.p, sizeof(double) * N, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return CLR_OK;
+}
+
+int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_det,
+                         const double* phi, const double* u, const double* W, const double* D) {
+  // solver.cpp:44-58: plain member assignment; coefficients and t are NOT part
+  // of the state (so predict is unavailable afterwards, as in the reference).
+  s->computed = 0;
+  s->N = N;
+  s->J = J;
+  s->log_det = log_det;
+  s->J_real = s->J_comp = s->J_general = 0;
+  if (!computed) return CLR_OK;
+  if (J < 0 || J > CLR_MAX_WIDTH || N < 1) return fail(CLR_INVALID_ARGUMENT, "Invalid state!");
+  int st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  const size_t Nn = (size_t)N, Jn = (size_t)J, Nm1 = Nn - 1;
+  if ((st = upload(s->phi, phi, Jn * Nm1, s->stream)) != CLR_OK) return st;
+  if ((st = upload(s->u, u, Jn * Nm1, s->stream)) != CLR_OK) return st;
+  if ((st = upload(s->W, W, Jn * Nn, s->stream)) != CLR_OK) return st;
+  if ((st = upload(s->D, D, Nn, s->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->coeffs.release();  // marks "inputs unknown" for predict
+  s->computed = 1;
+  return CLR_OK;
+}
+
+/* ---- batched log-likelihood ---------------------------------------------------- */
+clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
+  if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) {
+    fail(CLR_INVALID_ARGUMENT, "clr_batch_create: bad sizes");
+    return nullptr;
+  }
+  const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
+  if (!L) {
+    fail(CLR_UNSUPPORTED, "batched path supports widths 1..8 (J_real + 2 J_comp)");
+    return nullptr;
+  }
+  if (require_device(device) != CLR_OK) return nullptr;
+  clr_batch* h = new clr_batch();
+  h->device = device;
+  h->B = B;
+  h->N = N;
+  h->J_real = J_real;
+  h->J_comp = J_comp;
+  h->J = J_real + 2 * J_comp;
+  h->launch = L;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(CLR_HIP_ERROR, "hipStreamCreate failed");
+    delete h;
+    return nullptr;
+  }
+  for (auto& e : h->ev) (void)hipEventCreate(&e);
+  if (clr_batch_set_chunks(h, 0) != CLR_OK) {
+    clr_batch_destroy(h);
+    return nullptr;
+  }
+  return h;
+}
+
+void clr_batch_destroy(clr_batch* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->elems, &h->starts,
+                    &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D})
+    b->release();
+  if (h->flags) (void)hipFree(h->flags);
+  if (h->status) (void)hipFree(h->status);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int clr_batch_set_chunks(clr_batch* h, int nchunk) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (nchunk <= 0) nchunk = auto_chunks(h->B, h->N);
+  if (nchunk > h->N) nchunk = h->N;
+  h->L = (h->N + nchunk - 1) / nchunk;
+  h->nchunk = (h->N + h->L - 1) / h->L;
+  const size_t pc = (size_t)h->B * h->nchunk;
+  if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
+  if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+  if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->out.reserve((size_t)h->B * 3)) != CLR_OK) return st;
+  if (h->flags) (void)hipFree(h->flags);
+  h->flags = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), pc * sizeof(int)));
+  if (!h->status) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->status), (size_t)h->B * sizeof(int)));
+  return CLR_OK;
+}
+
+int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len) {
+  if (nchunk) *nchunk = h->nchunk;
+  if (chunk_len) *chunk_len = h->L;
+  return CLR_OK;
+}
+
+int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const double* diag,
+                         long diag_stride, const double* y, long y_stride) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const long N = h->N;
+  for (long sd : {t_stride, diag_stride, y_stride})
+    if (sd != 0 && sd != N)
+      return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
+  auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
+  if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->t_stride = t_stride;
+  h->diag_stride = diag_stride;
+  h->y_stride = y_stride;
+  h->have_series = true;
+  return CLR_OK;
+}
+
+int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double* a_real,
+                               const double* c_real, const double* a_comp, const double* b_comp,
+                               const double* c_comp, const double* d_comp) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
+  std::vector<double> pack;
+  pack.reserve(2 * nr + 4 * nc);
+  pack.insert(pack.end(), a_real, a_real + nr);
+  pack.insert(pack.end(), c_real, c_real + nr);
+  pack.insert(pack.end(), a_comp, a_comp + nc);
+  pack.insert(pack.end(), b_comp, b_comp + nc);
+  pack.insert(pack.end(), c_comp, c_comp + nc);
+  pack.insert(pack.end(), d_comp, d_comp + nc);
+  if ((st = upload(h->coeffs, pack.data(), pack.size(), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->jitter, jitter, B, h->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->have_coeffs = true;
+  return CLR_OK;
+}
+
+static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
+  if (!h->have_series || !h->have_coeffs)
+    return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
+  int st = CLR_OK;
+  if (materialize && !h->have_factor) {
+    const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J;
+    if ((st = h->phi.reserve(B * J * (N - 1))) != CLR_OK) return st;
+    if ((st = h->u.reserve(B * J * (N - 1))) != CLR_OK) return st;
+    if ((st = h->W.reserve(B * J * N)) != CLR_OK) return st;
+    if ((st = h->D.reserve(B * N)) != CLR_OK) return st;
+    h->have_factor = true;
+  }
+  memset(&P, 0, sizeof(P));
+  const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
+  P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
+  P.jitter = h->jitter.p;
+  P.a_real = h->coeffs.p;
+  P.c_real = P.a_real + nr;
+  P.a_comp = P.c_real + nr;
+  P.b_comp = P.a_comp + nc;
+  P.c_comp = P.b_comp + nc;
+  P.d_comp = P.c_comp + nc;
+  P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
+  P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
+  P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
+  P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
+  P.out_status = h->status;
+  P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
+  return CLR_OK;
+}
+
+int clr_batch_enqueue(clr_batch* h, int materialize) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  clr::BatchParams P;
+  if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  h->launch->summarize(P, h->stream);
+  h->launch->prefix(P, h->stream);
+  h->launch->replay(P, materialize != 0, h->stream);
+  clr::launch_finalize(P, h->stream);
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
+int clr_batch_synchronize(clr_batch* h) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double* quad,
+                          int* status) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const size_t B = (size_t)h->B;
+  if (loglike) HIP_TRY(hipMemcpyAsync(loglike, h->out.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (logdet) HIP_TRY(hipMemcpyAsync(logdet, h->out.p + B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (quad) HIP_TRY(hipMemcpyAsync(quad, h->out.p + 2 * B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (status) HIP_TRY(hipMemcpyAsync(status, h->status, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->have_factor) return fail(CLR_NOT_COMPUTED, "no materialising run has been made");
+  if (p < 0 || p >= h->B) return fail(CLR_INVALID_ARGUMENT, "problem index out of range");
+  const size_t N = (size_t)h->N, J = (size_t)h->J, Nm1 = N - 1;
+  if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->phi.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->u.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (W) HIP_TRY(hipMemcpyAsync(W, h->W.p + p * J * N, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (D) HIP_TRY(hipMemcpyAsync(D, h->D.p + p * N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_run_timed(clr_batch* h, int materialize, int steps, double* total_ms,
+                        double* kernel_ms) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  clr::BatchParams P;
+  if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  if (steps < 1) steps = 1;
+  // one event per kernel boundary per step, all recorded on the handle's stream
+  std::vector<hipEvent_t> ev((size_t)steps * 5);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < steps; ++i) {
+    hipEvent_t* e = &ev[(size_t)i * 5];
+    HIP_TRY(hipEventRecord(e[0], h->stream));
+    h->launch->summarize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[1], h->stream));
+    h->launch->prefix(P, h->stream);
+    HIP_TRY(hipEventRecord(e[2], h->stream));
+    h->launch->replay(P, materialize != 0, h->stream);
+    HIP_TRY(hipEventRecord(e[3], h->stream));
+    clr::launch_finalize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[4], h->stream));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double k[4] = {0, 0, 0, 0};
+  for (int i = 0; i < steps; ++i) {
+    hipEvent_t* e = &ev[(size_t)i * 5];
+    for (int j = 0; j < 4; ++j) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e[j], e[j + 1]));
+      k[j] += ms;
+    }
+  }
+  float tot = 0.f;
+  HIP_TRY(hipEventElapsedTime(&tot, ev.front(), ev.back()));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (total_ms) *total_ms = tot;
+  if (kernel_ms)
+    for (int j = 0; j < 4; ++j) kernel_ms[j] = k[j];
+  return CLR_OK;
+}
+
+int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,
+                             const double* a_real, const double* c_real, const double* a_comp,
+                             const double* b_comp, const double* c_comp, const double* d_comp,
+                             const double* t, long t_stride, const double* diag,
+                             long diag_stride, const double* y, long y_stride, double* loglike,
+                             double* logdet, double* quad, int* status, int device) {
+  clr_batch* h = clr_batch_create(B, N, J_real, J_comp, device);
+  if (!h) {
+    // clr_batch_create recorded why
+    if (clr::find_batch_launchers(J_real, J_comp) == nullptr) return CLR_UNSUPPORTED;
+    return visible_gfx950() > 0 ? CLR_INVALID_ARGUMENT : CLR_NO_DEVICE;
+  }
+  int st = clr_batch_set_series(h, t, t_stride, diag, diag_stride, y, y_stride);
+  if (st == CLR_OK)
+    st = clr_batch_set_coefficients(h, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+  if (st == CLR_OK) st = clr_batch_enqueue(h, 0);
+  if (st == CLR_OK) st = clr_batch_get_results(h, loglike, logdet, quad, status);
+  clr_batch_destroy(h);
+  return st;
+}
+
+}  // extern "C"

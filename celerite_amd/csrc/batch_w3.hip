@@ -1,0 +1,12 @@
+// celerite_amd/csrc/batch_w3.hip -- explicit instantiations of the batched scan
+// kernels for width J = 3 (one translation unit per width so the fully
+// unrolled kernels compile in parallel).  See clr_batch_kernels.h / clr_core.h.
+#include "clr_batch_kernels.h"
+
+namespace clr {
+const BatchLaunchers* batch_launchers_w3(int JR, int JC) {
+  if (JR == 3 && JC == 0) { static const BatchLaunchers L = BatchImpl<3, 0>::table(); return &L; }
+  if (JR == 1 && JC == 1) { static const BatchLaunchers L = BatchImpl<1, 1>::table(); return &L; }
+  return nullptr;
+}
+}  // namespace clr

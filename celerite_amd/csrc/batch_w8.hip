@@ -1,0 +1,15 @@
+// celerite_amd/csrc/batch_w8.hip -- explicit instantiations of the batched scan
+// kernels for width J = 8 (one translation unit per width so the fully
+// unrolled kernels compile in parallel).  See clr_batch_kernels.h / clr_core.h.
+#include "clr_batch_kernels.h"
+
+namespace clr {
+const BatchLaunchers* batch_launchers_w8(int JR, int JC) {
+  if (JR == 8 && JC == 0) { static const BatchLaunchers L = BatchImpl<8, 0>::table(); return &L; }
+  if (JR == 6 && JC == 1) { static const BatchLaunchers L = BatchImpl<6, 1>::table(); return &L; }
+  if (JR == 4 && JC == 2) { static const BatchLaunchers L = BatchImpl<4, 2>::table(); return &L; }
+  if (JR == 2 && JC == 3) { static const BatchLaunchers L = BatchImpl<2, 3>::table(); return &L; }
+  if (JR == 0 && JC == 4) { static const BatchLaunchers L = BatchImpl<0, 4>::table(); return &L; }
+  return nullptr;
+}
+}  // namespace clr

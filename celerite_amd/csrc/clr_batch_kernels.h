@@ -109,30 +109,6 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   P.flags[(long)b * P.nchunk + c] = flag;
 }
 
-// status codes mirror include/celerite_hip.h
-__global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.B) return;
-  double ld = 0.0, qd = 0.0;
-  int bad = 0;
-  for (int c = 0; c < P.nchunk; ++c) {
-    ld += P.part[((long)b * P.nchunk + c) * 2 + 0];
-    qd += P.part[((long)b * P.nchunk + c) * 2 + 1];
-    bad |= P.flags[(long)b * P.nchunk + c];
-  }
-  if (bad) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
-    P.out_status[b] = 2;
-    P.out_ll[b] = -INFINITY;
-    P.out_logdet[b] = NAN;
-    P.out_quad[b] = NAN;
-    return;
-  }
-  P.out_status[b] = 0;
-  P.out_logdet[b] = ld;
-  P.out_quad[b] = qd;
-  P.out_ll[b] = combine_loglike(ld, qd, P.N);
-}
-
 // One table entry per (JR, JC): host-callable launchers.
 struct BatchLaunchers {
   void (*summarize)(const BatchParams&, hipStream_t);
@@ -165,9 +141,8 @@ struct BatchImpl {
   }
 };
 
-inline void launch_finalize(const BatchParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3((P.B + 63) / 64), dim3(64), 0, s, P);
-}
+// Per-problem reduction of the chunk partials + the -inf rules (api.hip).
+void launch_finalize(const BatchParams& P, hipStream_t s);
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);

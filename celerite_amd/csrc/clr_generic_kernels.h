@@ -1,0 +1,55 @@
+// celerite_amd/csrc/clr_generic_kernels.h
+//
+// Any-width (J <= CLR_MAX_WIDTH, including "general" A/U/V rows) kernels for the
+// single-problem solver object.  These cover what the fixed-width scan kernels
+// do not: widths above 8, general semiseparable terms, and every consumer of the
+// stored factor (dot_solve / solve / dot_L / dot / predict).  They are
+// sequential in n like the reference and parallel across the width:
+//   factor_generic   one 256-thread workgroup per problem; S (J x J) in LDS.
+//   the sweep kernels   one 64-lane wave per right-hand side; lane j (and j+64)
+//                       carries row j of the running J-vector f, the inner
+//                       products are wave reductions (DPP/shuffle).
+// Loads of the factor are coalesced along j (reference storage [j + J n]).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace clr {
+
+struct GenericProblem {
+  int N, J, J_real, J_comp, J_general;
+  const double *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;  // device
+  const double *U, *V;  // device, row-major [J_general][N] (may be null)
+  const double* t;      // device [N]
+};
+
+// cholesky.h:41-210.  D must arrive initialised to the full diagonal
+// (diag + sum a_real + sum a_comp + jitter [+ A], cholesky.h:98-99).
+// status[0] = 1 when some D_n < 0 (n >= 1), log_det[0] = sum log D_n.
+void launch_factor_generic(const GenericProblem& g, double* phi, double* u, double* W,
+                           double* D, int* status, double* log_det, hipStream_t s);
+
+// Builds phi, u, v for `dot` (cholesky.h:487-531); v is J x N.
+void launch_dot_setup(const GenericProblem& g, double* phi, double* u, double* v,
+                      hipStream_t s);
+
+// cholesky.h:326-401: out[0] = b^T K^-1 b.
+void launch_dot_solve(int N, int J, const double* phi, const double* u, const double* W,
+                      const double* D, const double* b, double* out, hipStream_t s);
+// cholesky.h:218-318, column-major (N, nrhs).
+void launch_solve(int N, int J, int nrhs, const double* phi, const double* u, const double* W,
+                  const double* D, const double* b, double* x, hipStream_t s);
+// cholesky.h:409-431.
+void launch_dot_L(int N, int J, int nrhs, const double* phi, const double* u, const double* W,
+                  const double* D, const double* z, double* y, hipStream_t s);
+// cholesky.h:533-560: y = K z given phi, u, v and the constant diagonal dg[N].
+void launch_dot(int N, int J, int nrhs, const double* phi, const double* u, const double* v,
+                const double* dg, const double* z, double* y, hipStream_t s);
+// cholesky.h:599-698 given alpha = K^-1 y.
+void launch_predict(const GenericProblem& g, const double* alpha, int M, const double* xs,
+                    double* pred, hipStream_t s);
+// J == 0 and small element-wise helpers.
+void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,
+                      hipStream_t s);
+
+}  // namespace clr

@@ -1,0 +1,465 @@
+// celerite_amd/csrc/generic_kernels.hip -- see clr_generic_kernels.h.
+#include "clr_generic_kernels.h"
+
+#include <math.h>
+
+namespace clr {
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Row j of (phi, u~, v~) for the move t_prev -> t (cholesky.h:127-152).
+__device__ __forceinline__ void row_features(const GenericProblem& g, int j, int n, double t,
+                                             double dx, double& phi, double& u, double& v) {
+  if (j < g.J_real) {
+    phi = exp(-g.c_real[j] * dx);
+    u = g.a_real[j];
+    v = 1.0;
+  } else if (j < g.J_real + 2 * g.J_comp) {
+    const int jj = (j - g.J_real) >> 1;
+    const bool odd = (j - g.J_real) & 1;
+    const double a = g.a_comp[jj], b = g.b_comp[jj];
+    double sd, cd;
+    sincos(g.d_comp[jj] * t, &sd, &cd);
+    phi = exp(-g.c_comp[jj] * dx);
+    u = odd ? (a * sd - b * cd) : (a * cd + b * sd);
+    v = odd ? sd : cd;
+  } else {
+    const int jg = j - g.J_real - 2 * g.J_comp;
+    phi = 1.0;
+    u = g.U[(long)jg * g.N + n];
+    v = g.V[(long)jg * g.N + n];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Factorisation, any width.  One workgroup; S lives in LDS (upper triangle
+// used, column-major S[k + J j], k <= j).  Follows the reference's step order.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) factor_generic_kernel(GenericProblem g, double* phi,
+                                                             double* u, double* W, double* D,
+                                                             int* status, double* log_det) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int J = g.J, N = g.N, tid = threadIdx.x, nt = blockDim.x;
+  double* S = reinterpret_cast<double*>(smem);
+  double* sphi = S + (long)J * J;
+  double* su = sphi + J;
+  double* sv = su + J;
+  double* swp = sv + J;
+  double* sq = swp + J;
+  double* sp = sq + J;
+  double* sscal = sp + J;  // [0] = D_n, [1] = failure flag
+
+  for (int i = tid; i < J * J; i += nt) S[i] = 0.0;
+  if (tid == 0) sscal[1] = 0.0;
+
+  // sample 0: cholesky.h:100-117
+  double Dprev = D[0];
+  double ld = log(Dprev);
+  {
+    const double value = 1.0 / Dprev;
+    for (int j = tid; j < J; j += nt) {
+      double ph, uu, vv;
+      row_features(g, j, 0, g.t[0], 0.0, ph, uu, vv);
+      const double w = vv * value;
+      W[j] = w;
+      swp[j] = w;
+    }
+  }
+  __syncthreads();
+
+  for (int n = 1; n < N; ++n) {
+    const double t = g.t[n], dx = t - g.t[n - 1];
+    for (int j = tid; j < J; j += nt) {
+      double ph, uu, vv;
+      row_features(g, j, n, t, dx, ph, uu, vv);
+      sphi[j] = ph;
+      su[j] = uu;
+      sv[j] = vv;
+      phi[(long)J * (n - 1) + j] = ph;
+      u[(long)J * (n - 1) + j] = uu;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < J * J; idx += nt) {  // cholesky.h:154-160
+      const int k = idx % J, j = idx / J;
+      if (k <= j) {
+        const double xj = Dprev * swp[j];
+        S[idx] = sphi[j] * (sphi[k] * (S[idx] + xj * swp[k]));
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < J; j += nt) {  // q = S u~ ; cholesky.h:163-175
+      double acc = 0.0;
+      for (int k = 0; k < J; ++k) acc += (k <= j ? S[k + (long)J * j] : S[j + (long)J * k]) * su[k];
+      sq[j] = acc;
+      sp[j] = su[j] * acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double part = 0.0;
+      for (int j = tid; j < J; j += 64) part += sp[j];
+      part = wave_sum(part);
+      if (tid == 0) {
+        const double Dn = D[n] - part;
+        if (Dn < 0.0) sscal[1] = 1.0;  // cholesky.h:176
+        sscal[0] = Dn;
+        D[n] = Dn;
+        ld += log(Dn);
+      }
+    }
+    __syncthreads();
+    if (sscal[1] != 0.0) {
+      if (tid == 0) { status[0] = 1; log_det[0] = NAN; }
+      return;
+    }
+    const double Dn = sscal[0];
+    for (int j = tid; j < J; j += nt) {  // cholesky.h:170-178
+      const double w = (sv[j] - sq[j]) / Dn;
+      W[(long)J * n + j] = w;
+      swp[j] = w;
+    }
+    Dprev = Dn;
+    __syncthreads();
+  }
+  if (tid == 0) { status[0] = 0; log_det[0] = ld; }
+}
+
+// J == 0: cholesky.h:90-95.
+__global__ void __launch_bounds__(256) diag_only_kernel(int N, const double* diag, double jitter,
+                                                        double* D, double* log_det) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const double d = diag[n] + jitter;
+    D[n] = d;
+    acc += log(d);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) log_det[0] = red[0];
+}
+
+// ---------------------------------------------------------------------------
+// Sweeps over a stored factor: one wave per right-hand side, rows j0 = lane and
+// j1 = lane + 64 in registers.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) dot_solve_kernel(int N, int J, const double* phi,
+                                                       const double* u, const double* W,
+                                                       const double* D, const double* b,
+                                                       double* out) {
+  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  const bool h0 = j0 < J, h1 = j1 < J;
+  double f0 = 0.0, f1 = 0.0;
+  double xm1 = b[0];
+  double result = xm1 * (xm1 / D[0]);  // cholesky.h:347
+  // register prefetch of row n = 1
+  double p0 = 0, u0 = 0, w0 = 0, p1 = 0, u1 = 0, w1 = 0, bn = 0, dn = 1;
+  if (N > 1) {
+    if (h0) { p0 = phi[j0]; u0 = u[j0]; w0 = W[j0]; }
+    if (h1) { p1 = phi[j1]; u1 = u[j1]; w1 = W[j1]; }
+    bn = b[1];
+    dn = D[1];
+  }
+  for (int n = 1; n < N; ++n) {
+    const double cp0 = p0, cu0 = u0, cw0 = w0, cp1 = p1, cu1 = u1, cw1 = w1, cb = bn, cd = dn;
+    if (n + 1 < N) {
+      const long base = (long)J * n;
+      if (h0) { p0 = phi[base + j0]; u0 = u[base + j0]; w0 = W[base + j0]; }
+      if (h1) { p1 = phi[base + j1]; u1 = u[base + j1]; w1 = W[base + j1]; }
+      bn = b[n + 1];
+      dn = D[n + 1];
+    }
+    double part = 0.0;  // cholesky.h:350-354
+    if (h0) { f0 = cp0 * (f0 + cw0 * xm1); part += cu0 * f0; }
+    if (h1) { f1 = cp1 * (f1 + cw1 * xm1); part += cu1 * f1; }
+    const double x = cb - wave_sum(part);
+    xm1 = x;
+    result += x * x / cd;  // :356
+  }
+  if (threadIdx.x == 0) out[0] = result;
+}
+
+__global__ void __launch_bounds__(64) solve_kernel(int N, int J, const double* phi,
+                                                   const double* u, const double* W,
+                                                   const double* D, const double* b, double* x) {
+  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  const bool h0 = j0 < J, h1 = j1 < J;
+  const double* bk = b + (long)blockIdx.x * N;
+  double* xk = x + (long)blockIdx.x * N;
+
+  // forward, cholesky.h:240-248 (x holds the undivided values for now)
+  double f0 = 0.0, f1 = 0.0;
+  double xm1 = bk[0];
+  if (threadIdx.x == 0) xk[0] = xm1;
+  for (int n = 1; n < N; ++n) {
+    const long base = (long)J * (n - 1);
+    double part = 0.0;
+    if (h0) { f0 = phi[base + j0] * (f0 + W[base + j0] * xm1); part += u[base + j0] * f0; }
+    if (h1) { f1 = phi[base + j1] * (f1 + W[base + j1] * xm1); part += u[base + j1] * f1; }
+    xm1 = bk[n] - wave_sum(part);
+    if (threadIdx.x == 0) xk[n] = xm1;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // backward with the /D of :249 folded in, cholesky.h:251-259
+  f0 = 0.0;
+  f1 = 0.0;
+  double value = xk[N - 1] / D[N - 1];
+  if (threadIdx.x == 0) xk[N - 1] = value;
+  for (int n = N - 2; n >= 0; --n) {
+    const long base = (long)J * n;
+    double part = 0.0;
+    if (h0) { f0 = phi[base + j0] * (f0 + u[base + j0] * value); part += W[base + j0] * f0; }
+    if (h1) { f1 = phi[base + j1] * (f1 + u[base + j1] * value); part += W[base + j1] * f1; }
+    value = xk[n] / D[n] - wave_sum(part);
+    if (threadIdx.x == 0) xk[n] = value;
+  }
+}
+
+__global__ void __launch_bounds__(64) dot_L_kernel(int N, int J, const double* phi,
+                                                   const double* u, const double* W,
+                                                   const double* D, const double* z, double* y) {
+  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  const bool h0 = j0 < J, h1 = j1 < J;
+  const double* zk = z + (long)blockIdx.x * N;
+  double* yk = y + (long)blockIdx.x * N;
+  double f0 = 0.0, f1 = 0.0;
+  double tmp = zk[0] * sqrt(D[0]);  // cholesky.h:421-422
+  if (threadIdx.x == 0) yk[0] = tmp;
+  for (int n = 1; n < N; ++n) {  // :423-427
+    const long base = (long)J * (n - 1);
+    double part = 0.0;
+    if (h0) { f0 = phi[base + j0] * (f0 + W[base + j0] * tmp); part += u[base + j0] * f0; }
+    if (h1) { f1 = phi[base + j1] * (f1 + W[base + j1] * tmp); part += u[base + j1] * f1; }
+    tmp = sqrt(D[n]) * zk[n];
+    const double yn = tmp + wave_sum(part);
+    if (threadIdx.x == 0) yk[n] = yn;
+  }
+}
+
+// phi, u, v of `dot` (cholesky.h:487-531): parallel over samples (blockIdx) and rows.
+__global__ void __launch_bounds__(128) dot_setup_kernel(GenericProblem g, double* phi, double* u,
+                                                        double* v) {
+  const int J = g.J, N = g.N;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+      const bool general = j >= g.J_real + 2 * g.J_comp;
+      double ph, uu, vv;
+      if (!general) {
+        row_features(g, j, n, g.t[n], 0.0, ph, uu, vv);
+        v[(long)J * n + j] = vv;  // v at t_n (:492-499, :505, :517-518)
+        if (n >= 1) {             // u at t_n and the decay n-1 -> n are column n-1
+          row_features(g, j, n, g.t[n], g.t[n] - g.t[n - 1], ph, uu, vv);
+          phi[(long)J * (n - 1) + j] = ph;
+          u[(long)J * (n - 1) + j] = uu;
+        }
+      } else {
+        const int jg = j - g.J_real - 2 * g.J_comp;  // :526-530
+        if (n < N - 1) {
+          v[(long)J * n + j] = g.V[(long)jg * N + n];
+          u[(long)J * n + j] = g.U[(long)jg * N + n + 1];
+          phi[(long)J * n + j] = 1.0;
+        } else {
+          v[(long)J * n + j] = 0.0;  // never read by the sweeps
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) dot_kernel(int N, int J, const double* phi, const double* u,
+                                                 const double* v, const double* dg,
+                                                 const double* z, double* y) {
+  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  const bool h0 = j0 < J, h1 = j1 < J;
+  const double* zk = z + (long)blockIdx.x * N;
+  double* yk = y + (long)blockIdx.x * N;
+  // upper triangle, cholesky.h:536-547
+  double f0 = 0.0, f1 = 0.0;
+  if (threadIdx.x == 0) yk[N - 1] = dg[N - 1] * zk[N - 1];
+  for (int n = N - 2; n >= 0; --n) {
+    const long base = (long)J * n;
+    const double z0 = zk[n + 1];
+    double part = 0.0;
+    if (h0) { f0 = phi[base + j0] * (f0 + u[base + j0] * z0); part += v[base + j0] * f0; }
+    if (h1) { f1 = phi[base + j1] * (f1 + u[base + j1] * z0); part += v[base + j1] * f1; }
+    const double y0 = dg[n] * zk[n] + wave_sum(part);
+    if (threadIdx.x == 0) yk[n] = y0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // lower triangle, :549-559
+  f0 = 0.0;
+  f1 = 0.0;
+  for (int n = 1; n < N; ++n) {
+    const long base = (long)J * (n - 1);
+    const double z0 = zk[n - 1];
+    double part = 0.0;
+    if (h0) { f0 = phi[base + j0] * (f0 + v[base + j0] * z0); part += u[base + j0] * f0; }
+    if (h1) { f1 = phi[base + j1] * (f1 + v[base + j1] * z0); part += u[base + j1] * f1; }
+    const double y0 = yk[n] + wave_sum(part);
+    if (threadIdx.x == 0) yk[n] = y0;
+  }
+}
+
+// cholesky.h:599-698.  Row types: real rows carry one Q, a complex pair carries
+// the cos-like and sin-like Q; general rows do not take part (as in the reference).
+__global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const double* alpha,
+                                                     int M, const double* xs, double* pred) {
+  const int N = g.N, Jrc = g.J_real + 2 * g.J_comp;
+  const double* t_ = g.t;
+  // each lane serves rows lane and lane + 64
+  double a[2] = {0, 0}, b[2] = {0, 0}, c[2] = {0, 0}, d[2] = {0, 0};
+  int kind[2] = {-1, -1};  // 0 real, 1 complex-cos row, 2 complex-sin row
+  for (int r = 0; r < 2; ++r) {
+    const int j = threadIdx.x + 64 * r;
+    if (j < g.J_real) {
+      kind[r] = 0; a[r] = g.a_real[j]; c[r] = g.c_real[j];
+    } else if (j < Jrc) {
+      const int jj = (j - g.J_real) >> 1;
+      kind[r] = 1 + ((j - g.J_real) & 1);
+      a[r] = g.a_comp[jj]; b[r] = g.b_comp[jj]; c[r] = g.c_comp[jj]; d[r] = g.d_comp[jj];
+    }
+  }
+  double Q[2] = {0.0, 0.0};
+
+  // forward pass :615-653
+  int m = 0;
+  while (m < M && xs[m] <= t_[0]) ++m;
+  for (int n = 0; n < N; ++n) {
+    const double alphan = alpha[n];
+    const double tref = (n < N - 1) ? t_[n + 1] : t_[N - 1];
+    const double tn = t_[n];
+    double dt = tref - tn;
+    for (int r = 0; r < 2; ++r) {
+      if (kind[r] == 0) {
+        Q[r] = (Q[r] + alphan) * exp(-c[r] * dt);
+      } else if (kind[r] > 0) {
+        const double tmp = exp(-c[r] * dt);
+        const double tr = (kind[r] == 1) ? cos(d[r] * tn) : sin(d[r] * tn);
+        Q[r] = (Q[r] + alphan * tr) * tmp;
+      }
+    }
+    while (m < M && (n == N - 1 || xs[m] <= tref)) {
+      const double xm = xs[m];
+      dt = xm - tref;
+      double pm = 0.0;
+      for (int r = 0; r < 2; ++r) {
+        if (kind[r] == 0) {
+          pm += a[r] * exp(-c[r] * dt) * Q[r];
+        } else if (kind[r] > 0) {
+          double sd, cd;
+          sincos(d[r] * xm, &sd, &cd);
+          const double tmp = exp(-c[r] * dt);
+          const double coef = (kind[r] == 1) ? (a[r] * cd + b[r] * sd) : (a[r] * sd - b[r] * cd);
+          pm += coef * tmp * Q[r];
+        }
+      }
+      pm = wave_sum(pm);
+      if (threadIdx.x == 0) pred[m] = pm;
+      ++m;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // backward pass :656-695
+  m = M - 1;
+  while (m >= 0 && xs[m] > t_[N - 1]) --m;
+  Q[0] = Q[1] = 0.0;
+  for (int n = N - 1; n >= 0; --n) {
+    const double alphan = alpha[n];
+    const double tref = (n > 0) ? t_[n - 1] : t_[0];
+    const double tn = t_[n];
+    double dt = tn - tref;
+    for (int r = 0; r < 2; ++r) {
+      if (kind[r] == 0) {
+        Q[r] = (Q[r] + alphan * a[r]) * exp(-c[r] * dt);
+      } else if (kind[r] > 0) {
+        double sd, cd;
+        sincos(d[r] * tn, &sd, &cd);
+        const double coef = (kind[r] == 1) ? (a[r] * cd + b[r] * sd) : (a[r] * sd - b[r] * cd);
+        Q[r] = (Q[r] + alphan * coef) * exp(-c[r] * dt);
+      }
+    }
+    while (m >= 0 && (n == 0 || xs[m] > tref)) {
+      const double xm = xs[m];
+      dt = tref - xm;
+      double pm = 0.0;
+      for (int r = 0; r < 2; ++r) {
+        if (kind[r] == 0) {
+          pm += exp(-c[r] * dt) * Q[r];
+        } else if (kind[r] > 0) {
+          const double tmp = exp(-c[r] * dt);
+          const double tr = (kind[r] == 1) ? cos(d[r] * xm) : sin(d[r] * xm);
+          pm += tr * tmp * Q[r];
+        }
+      }
+      pm = wave_sum(pm);
+      if (threadIdx.x == 0) pred[m] += pm;
+      --m;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_factor_generic(const GenericProblem& g, double* phi, double* u, double* W, double* D,
+                           int* status, double* log_det, hipStream_t s) {
+  const size_t lds = sizeof(double) * ((size_t)g.J * g.J + 6 * (size_t)g.J + 4);
+  static size_t configured = 0;
+  if (lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_generic_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  const int threads = g.J <= 8 ? 64 : 256;
+  hipLaunchKernelGGL(factor_generic_kernel, dim3(1), dim3(threads), lds, s, g, phi, u, W, D,
+                     status, log_det);
+}
+
+void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(diag_only_kernel, dim3(1), dim3(256), 0, s, N, diag, jitter, D, log_det);
+}
+
+void launch_dot_solve(int N, int J, const double* phi, const double* u, const double* W,
+                      const double* D, const double* b, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(dot_solve_kernel, dim3(1), dim3(64), 0, s, N, J, phi, u, W, D, b, out);
+}
+
+void launch_solve(int N, int J, int nrhs, const double* phi, const double* u, const double* W,
+                  const double* D, const double* b, double* x, hipStream_t s) {
+  hipLaunchKernelGGL(solve_kernel, dim3(nrhs), dim3(64), 0, s, N, J, phi, u, W, D, b, x);
+}
+
+void launch_dot_L(int N, int J, int nrhs, const double* phi, const double* u, const double* W,
+                  const double* D, const double* z, double* y, hipStream_t s) {
+  hipLaunchKernelGGL(dot_L_kernel, dim3(nrhs), dim3(64), 0, s, N, J, phi, u, W, D, z, y);
+}
+
+void launch_dot_setup(const GenericProblem& g, double* phi, double* u, double* v, hipStream_t s) {
+  const int blocks = g.N < 4096 ? g.N : 4096;
+  hipLaunchKernelGGL(dot_setup_kernel, dim3(blocks), dim3(128), 0, s, g, phi, u, v);
+}
+
+void launch_dot(int N, int J, int nrhs, const double* phi, const double* u, const double* v,
+                const double* dg, const double* z, double* y, hipStream_t s) {
+  hipLaunchKernelGGL(dot_kernel, dim3(nrhs), dim3(64), 0, s, N, J, phi, u, v, dg, z, y);
+}
+
+void launch_predict(const GenericProblem& g, const double* alpha, int M, const double* xs,
+                    double* pred, hipStream_t s) {
+  hipLaunchKernelGGL(predict_kernel, dim3(1), dim3(64), 0, s, g, alpha, M, xs, pred);
+}
+
+}  // namespace clr
