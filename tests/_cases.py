@@ -1,0 +1,100 @@
+# -*- coding: utf-8 -*-
+"""Seeded inputs shared by the oracle-pinning tests and the GPU parity tests.
+
+The first group regenerates, with ``np.random.seed(42)`` (legacy RandomState:
+stable across NumPy versions), exactly the inputs the reference's own tests use
+(tests/test_celerite.py, cited per case).  The second group is this repo's
+synthetic families.
+"""
+import numpy as np
+
+NO_GENERAL = (np.empty(0), np.empty((0, 0)), np.empty((0, 0)))
+
+# coefficient sets of tests/test_celerite.py:66-84 / :132-150
+COEFFS_W4 = (np.array([1.5, 0.1]), np.array([1.0, 0.3]), np.array([1.0]), np.array([0.1]),
+             np.array([1.0]), np.array([1.0]))
+COEFFS_W10 = (np.array([1.5, 0.1, 0.6, 0.3, 0.8, 0.7]), np.array([1.0, 0.3, 0.05, 0.01, 0.1, 0.2]),
+              np.array([1.0, 2.0]), np.array([0.1, 0.5]), np.array([1.0, 1.0]), np.array([1.0, 1.0]))
+# tests/test_celerite.py:160-165 (test_dot / test_dot_L)
+COEFFS_DOT = (np.array([1.3, 0.2]), np.array([0.5, 0.8]), np.array([0.1]), np.array([0.0]),
+              np.array([1.5]), np.array([0.1]))
+# tests/test_celerite.py:256-261 (test_pickle)
+COEFFS_PICKLE = (np.array([1.3, 1.5]), np.array([0.5, 0.2]), np.array([1.0]), np.array([0.1]),
+                 np.array([1.0]), np.array([1.0]))
+# cpp/src/test_solvers.cc:39-46
+COEFFS_CC_REAL = (np.array([1.3, 1.5]), np.array([0.5, 0.2]))
+COEFFS_CC_COMP = (np.array([1.0, 2.0]), np.array([0.1, 0.05]), np.array([1.0, 0.8]), np.array([1.0, 0.1]))
+
+
+def general_terms(t, rng_rand):
+    """U, V, A of tests/test_celerite.py:102-105."""
+    U = np.vander(t - np.mean(t), 4).T
+    V = U * rng_rand(4)[:, None]
+    A = np.sum(U * V, axis=0) + 1e-8
+    return A, U, V
+
+
+def logdet_case(seed=42):
+    """tests/test_celerite.py:49-52 (N = 5)."""
+    np.random.seed(seed)
+    t = np.sort(np.random.rand(5))
+    diag = np.random.uniform(0.1, 0.5, len(t))
+    return t, diag
+
+
+def solve_case(with_general, seed=42):
+    """tests/test_celerite.py:92-109 (N = 500)."""
+    np.random.seed(seed)
+    t = np.sort(np.random.rand(500))
+    diag = np.random.uniform(0.1, 0.5, len(t))
+    b = np.random.randn(len(t))
+    gen = general_terms(t, np.random.rand) if with_general else NO_GENERAL
+    return t, diag, b, gen
+
+
+def first_tutorial_case():
+    """docs/tutorials/first.rst:24-31,74-87: data + the two-SHO kernel; the printed
+    log-likelihood at :101 is -6.756596382629468."""
+    np.random.seed(42)
+    t = np.sort(np.append(np.random.uniform(0, 3.8, 57), np.random.uniform(5.5, 10, 68)))
+    yerr = np.random.uniform(0.08, 0.22, len(t))
+    y = 0.2 * (t - 5) + np.sin(3 * t + 0.1 * (t - 5) ** 2) + yerr * np.random.randn(len(t))
+    return t, yerr, y
+
+
+FIRST_TUTORIAL_LOGLIKE = -6.756596382629468
+
+
+def synthetic(B, N, J_real, J_comp, family, seed=0, b_frac=0.3):
+    """The repo's synthetic families: 'bench' mirrors
+    examples/benchmark/run.py:66-69,80-84; 'accuracy' mirrors
+    paper/figures/error/error.py:24-25.  Per-draw log-parameter scatter 0.1."""
+    rng = np.random.RandomState(seed)
+    if family == "bench":
+        t = np.sort(rng.rand(B, N), axis=1)
+        sig = rng.uniform(0.1, 0.2, (B, N))
+        y = np.sin(t)
+    elif family == "accuracy":
+        t = np.sort(rng.uniform(0, 0.8 * N, (B, N)), axis=1)
+        sig = rng.uniform(1.0, 1.5, (B, N))
+        y = rng.randn(B, N)
+    else:
+        raise ValueError(family)
+    a_real = np.exp(1.0 + 0.1 * rng.randn(B, J_real))
+    c_real = np.exp(0.1 + 0.1 * rng.randn(B, J_real))
+    a_comp = np.exp(0.1 + 0.1 * rng.randn(B, J_comp))
+    b_comp = b_frac * a_comp * rng.rand(B, J_comp)
+    c_comp = np.exp(2.0 + 0.1 * rng.randn(B, J_comp))
+    d_comp = np.exp(1.6 + 0.1 * rng.randn(B, J_comp))
+    return dict(a_real=a_real, c_real=c_real, a_comp=a_comp, b_comp=b_comp, c_comp=c_comp,
+                d_comp=d_comp, t=t, diag=sig ** 2, y=y)
+
+
+def coeffs_of(case, p=None):
+    keys = ("a_real", "c_real", "a_comp", "b_comp", "c_comp", "d_comp")
+    if p is None:
+        return tuple(case[k] for k in keys)
+    return tuple(case[k][p] for k in keys)
+
+
+ALL_WIDTH_SHAPES = [(jr, jc) for jc in range(5) for jr in range(9) if 1 <= jr + 2 * jc <= 8]
