@@ -50,7 +50,8 @@ def _load():
     lib.clr_batch_synchronize.argtypes = [C.c_void_p]
     lib.clr_batch_get_results.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
     lib.clr_batch_get_factor.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
-    lib.clr_batch_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
+    lib.clr_batch_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp]
+    lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_device_info.argtypes = [C.c_char_p, C.c_size_t, _ip, C.POINTER(C.c_size_t)]
     lib.clr_set_device.argtypes = [C.c_int]
     _lib = lib
@@ -198,15 +199,21 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_factor(self._h, int(p), _ptr(phi), _ptr(u), _ptr(W), _ptr(D)))
         return phi.T, u.T, W.T, D
 
-    def run_timed(self, steps, materialize=False):
+    KERNEL_NAMES = ("relayout", "summarize", "prefix", "replay", "finalize")
+
+    def set_layout(self, interleaved=True):
+        """Kernels read a chunk-interleaved copy of the series (default) or the
+        row-major arrays directly (slower; for A/B measurements)."""
+        _check(_load().clr_batch_set_layout(self._h, int(bool(interleaved))))
+
+    def run_timed(self, steps, materialize=False, relayout_each_step=True):
         """``steps`` back-to-back evaluations bracketed by HIP events on the
-        plan's stream.  Returns ``(total_ms, [summarize, prefix, replay,
-        finalize] summed ms)``."""
+        plan's stream.  Returns ``(total_ms, {kernel name: summed ms})``."""
         tot = C.c_double()
-        k = (C.c_double * 4)()
+        k = (C.c_double * 5)()
         _check(_load().clr_batch_run_timed(self._h, int(bool(materialize)), int(steps),
-                                           C.byref(tot), k))
-        return tot.value, [k[i] for i in range(4)]
+                                           int(bool(relayout_each_step)), C.byref(tot), k))
+        return tot.value, dict(zip(self.KERNEL_NAMES, [k[i] for i in range(5)]))
 
 
 def batch_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y,

@@ -66,6 +66,34 @@ __global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
 void launch_finalize(const BatchParams& P, hipStream_t s) {
   hipLaunchKernelGGL(finalize_kernel, dim3((P.B + 63) / 64), dim3(64), 0, s, P);
 }
+
+// Tiled transpose through LDS: reads coalesced along i (the time axis), writes
+// coalesced along the chunk axis.  Pure data movement: 8 B in + 8 B out per sample.
+__global__ void __launch_bounds__(256) relayout_kernel(const double* __restrict__ src,
+                                                       long src_stride, double* __restrict__ dst,
+                                                       long dst_stride, int N, int L, int nchunk) {
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z, i0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const double* in = src + (long)b * src_stride;
+  double* out = dst + (long)b * dst_stride;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int c = c0 + r, i = i0 + threadIdx.x;
+    const long n = (long)c * L + i;
+    tile[r][threadIdx.x] = (c < nchunk && i < L && n < N) ? in[n] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = i0 + r, c = c0 + threadIdx.x;
+    if (i < L && c < nchunk) out[(long)i * nchunk + c] = tile[threadIdx.x][r];
+  }
+}
+
+void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
+                     int N, int L, int nchunk, hipStream_t s) {
+  dim3 grid((L + 31) / 32, (nchunk + 31) / 32, nsrc);
+  hipLaunchKernelGGL(relayout_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride,
+                     N, L, nchunk);
+}
 }  // namespace clr
 
 namespace {
@@ -170,6 +198,7 @@ struct clr_solver {
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
+  DevBuf ws_t, ws_d;                    // chunk-interleaved t / diag for the scan
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
@@ -181,8 +210,11 @@ struct clr_batch {
   int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
   int nchunk = 1, L = 0;
   const clr::BatchLaunchers* launch = nullptr;
-  DevBuf jitter, coeffs, t, diag, y;
+  DevBuf jitter, coeffs, t, diag, y;  // series in the API's row-major layout
+  DevBuf tT, dT, yT;                  // chunk-interleaved copies the kernels read
   long t_stride = 0, diag_stride = 0, y_stride = 0;
+  int interleaved = 1;                // 0: kernels read the row-major arrays directly
+  bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
   DevBuf elems, starts, part, out;  // out: ll | logdet | quad
   int* flags = nullptr;
@@ -327,7 +359,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part})
+                      &s->ws_part, &s->ws_t, &s->ws_d})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -410,7 +442,18 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.jitter = s->scratch2.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
-    P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;  // y is irrelevant for compute
+    if (P.nchunk > 1) {  // chunk-interleaved copies so that wave loads coalesce
+      const size_t cells = (size_t)P.nchunk * P.L;
+      if ((st = s->ws_t.reserve(cells)) != CLR_OK) return st;
+      if ((st = s->ws_d.reserve(cells)) != CLR_OK) return st;
+      clr::launch_relayout(s->t.p, 0, s->ws_t.p, 0, 1, N, P.L, P.nchunk, stream);
+      clr::launch_relayout(s->scratch.p, 0, s->ws_d.p, 0, 1, N, P.L, P.nchunk, stream);
+      P.t = s->ws_t.p; P.diag = s->ws_d.p; P.y = s->ws_t.p;  // y is irrelevant for compute
+      P.lane_is = P.nchunk; P.lane_cs = 1;
+    } else {
+      P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;
+      P.lane_is = 1; P.lane_cs = P.L;
+    }
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
     P.flags = s->ws_flags;
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
@@ -728,8 +771,8 @@ void clr_batch_destroy(clr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->elems, &h->starts,
-                    &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D})
+  for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
+                    &h->elems, &h->starts, &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->status) (void)hipFree(h->status);
@@ -746,6 +789,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (nchunk > h->N) nchunk = h->N;
   h->L = (h->N + nchunk - 1) / nchunk;
   h->nchunk = (h->N + h->L - 1) / h->L;
+  h->relayout_pending = true;
   const size_t pc = (size_t)h->B * h->nchunk;
   if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
   if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
@@ -781,6 +825,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->diag_stride = diag_stride;
   h->y_stride = y_stride;
   h->have_series = true;
+  h->relayout_pending = true;
   return CLR_OK;
 }
 
@@ -827,12 +872,43 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.b_comp = P.a_comp + nc;
   P.c_comp = P.b_comp + nc;
   P.d_comp = P.c_comp + nc;
-  P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
-  P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
+  if (h->interleaved && h->nchunk > 1) {
+    const long cells = (long)h->nchunk * h->L;
+    auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
+    if ((st = h->tT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
+    if ((st = h->dT.reserve(nsrc(h->diag_stride) * cells)) != CLR_OK) return st;
+    if ((st = h->yT.reserve(nsrc(h->y_stride) * cells)) != CLR_OK) return st;
+    P.t = h->tT.p; P.diag = h->dT.p; P.y = h->yT.p;
+    P.t_stride = h->t_stride ? cells : 0;
+    P.diag_stride = h->diag_stride ? cells : 0;
+    P.y_stride = h->y_stride ? cells : 0;
+    P.lane_is = h->nchunk; P.lane_cs = 1;
+  } else {
+    P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
+    P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
+    P.lane_is = 1; P.lane_cs = h->L;
+  }
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = h->status;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
+  return CLR_OK;
+}
+
+// Row-major API layout -> chunk-interleaved layout (3 tiled transposes).
+static void batch_relayout(clr_batch* h) {
+  if (!(h->interleaved && h->nchunk > 1)) return;
+  const long cells = (long)h->nchunk * h->L;
+  struct { DevBuf* src; DevBuf* dst; long stride; } jobs[3] = {
+      {&h->t, &h->tT, h->t_stride}, {&h->diag, &h->dT, h->diag_stride}, {&h->y, &h->yT, h->y_stride}};
+  for (auto& j : jobs)
+    clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
+                         h->N, h->L, h->nchunk, h->stream);
+}
+
+int clr_batch_set_layout(clr_batch* h, int interleaved) {
+  h->interleaved = interleaved ? 1 : 0;
+  h->relayout_pending = true;
   return CLR_OK;
 }
 
@@ -841,6 +917,10 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (st != CLR_OK) return st;
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  if (h->relayout_pending) {
+    batch_relayout(h);
+    h->relayout_pending = false;
+  }
   h->launch->summarize(P, h->stream);
   h->launch->prefix(P, h->stream);
   h->launch->replay(P, materialize != 0, h->stream);
@@ -883,34 +963,42 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   return CLR_OK;
 }
 
-int clr_batch_run_timed(clr_batch* h, int materialize, int steps, double* total_ms,
-                        double* kernel_ms) {
+int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
+                        double* total_ms, double* kernel_ms) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
+  if (h->relayout_pending && !relayout_each_step) {
+    batch_relayout(h);
+    h->relayout_pending = false;
+  }
   // one event per kernel boundary per step, all recorded on the handle's stream
-  std::vector<hipEvent_t> ev((size_t)steps * 5);
+  const int NK = 5;
+  std::vector<hipEvent_t> ev((size_t)steps * (NK + 1));
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int i = 0; i < steps; ++i) {
-    hipEvent_t* e = &ev[(size_t)i * 5];
+    hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
     HIP_TRY(hipEventRecord(e[0], h->stream));
-    h->launch->summarize(P, h->stream);
+    if (relayout_each_step) batch_relayout(h);
     HIP_TRY(hipEventRecord(e[1], h->stream));
-    h->launch->prefix(P, h->stream);
+    h->launch->summarize(P, h->stream);
     HIP_TRY(hipEventRecord(e[2], h->stream));
-    h->launch->replay(P, materialize != 0, h->stream);
+    h->launch->prefix(P, h->stream);
     HIP_TRY(hipEventRecord(e[3], h->stream));
-    clr::launch_finalize(P, h->stream);
+    h->launch->replay(P, materialize != 0, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
+    clr::launch_finalize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[5], h->stream));
   }
+  if (relayout_each_step) h->relayout_pending = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  double k[4] = {0, 0, 0, 0};
+  double k[NK] = {0, 0, 0, 0, 0};
   for (int i = 0; i < steps; ++i) {
-    hipEvent_t* e = &ev[(size_t)i * 5];
-    for (int j = 0; j < 4; ++j) {
+    hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
+    for (int j = 0; j < NK; ++j) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, e[j], e[j + 1]));
       k[j] += ms;
@@ -921,7 +1009,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, double* total_
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (total_ms) *total_ms = tot;
   if (kernel_ms)
-    for (int j = 0; j < 4; ++j) kernel_ms[j] = k[j];
+    for (int j = 0; j < NK; ++j) kernel_ms[j] = k[j];
   return CLR_OK;
 }
 

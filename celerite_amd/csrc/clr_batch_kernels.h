@@ -8,9 +8,13 @@
 //       scalar loads) and only the recurrence state lives in VGPRs.
 //   prefix / finalize  : one lane per problem (sequential over that problem's
 //       chunks; the work is O(nchunk J^3), a few percent of the total).
-// HBM traffic: every lane streams its own contiguous run of t / diag / y (24 B per
-// sample, each 64-B line consumed over 8 consecutive steps out of L2/L1); the
-// workspace (elements, start states, partial sums) is O(nchunk) per problem.
+// HBM traffic: 24 B per sample per pass (t, diag, y).  The series are read in the
+// chunk-interleaved layout [problem][i][chunk] (relayout_kernel in api.hip), so
+// the 64 lanes of a wave -- 64 consecutive chunks at the same local step i -- load
+// 512 contiguous bytes per array per step: every cache line is touched once.
+// (With the row-major API layout each lane streams its own 8 B/step run and the
+// 64-B lines must survive 8 steps in L1/L2: measured 2x slower at 2 waves/SIMD.)
+// The workspace (elements, start states, partial sums) is O(nchunk) per problem.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,8 +26,11 @@ namespace clr {
 struct BatchParams {
   int B, N, nchunk, L;
   const double *jitter, *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;
+  // series as the kernels read them (see SeriesLane): element (chunk c, local i) of
+  // problem b is at  base[b * stride + c * lane_cs + i * lane_is]
   const double *t, *diag, *y;
   long t_stride, diag_stride, y_stride;
+  long lane_is, lane_cs;
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
   double* part;    // [B][nchunk][2]  (sum log D, sum x^2/D)
@@ -49,11 +56,9 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   if (c >= P.nchunk - 1) return;  // the last chunk's element is never needed
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
-  const int n0 = c * P.L;
-  const int n1 = n0 + P.L;  // < N because c is not the last chunk
-  summarize_chunk<JR, JC>(p, P.t + b * P.t_stride, P.diag + b * P.diag_stride,
-                          P.y + b * P.y_stride, n0, n1,
-                          P.elems + ((long)b * P.nchunk + c) * Wd::ELEM);
+  const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
+                      P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
+  summarize_chunk<JR, JC>(p, sl, P.elems + ((long)b * P.nchunk + c) * Wd::ELEM);
 }
 
 template <int JR, int JC>
@@ -97,8 +102,10 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   double ld, qd;
   int flag;
   const long Nm1 = P.N - 1;
+  const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
+                      P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
   replay_chunk<JR, JC, MATERIALIZE>(
-      p, P.t + b * P.t_stride, P.diag + b * P.diag_stride, P.y + b * P.y_stride, P.N, n0, n1,
+      p, sl, P.N, n0, n1,
       c == 0 ? nullptr : P.starts + ((long)b * P.nchunk + c) * Wd::START, &ld, &qd, &flag,
       MATERIALIZE ? P.phi + (long)b * J * Nm1 : nullptr,
       MATERIALIZE ? P.u + (long)b * J * Nm1 : nullptr,
@@ -143,6 +150,9 @@ struct BatchImpl {
 
 // Per-problem reduction of the chunk partials + the -inf rules (api.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
+// [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api.hip).
+void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
+                     int N, int L, int nchunk, hipStream_t s);
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);

@@ -97,6 +97,20 @@ struct Problem {
   CLR_HD double diagonal(double diag_n) const { return ((diag_n + sum_ar) + sum_ac) + jitter; }
 };
 
+// One lane's view of the three input series for its chunk of L samples.  Sample i
+// of the chunk is element off(i); i may run up to L + 1, i.e. into the first two
+// samples of the NEXT chunk (t_{n+1} is needed for the decay of the last step).
+//   row-major  ([problem][n], the layout of the public API):  is = 1,      cs = L
+//   interleaved ([problem][i][chunk], written by relayout_kernel so that the 64
+//   lanes of a wave -- 64 consecutive chunks at the same i -- read 512 contiguous
+//   bytes):                                                     is = nchunk, cs = 1
+struct SeriesLane {
+  const double *t, *diag, *y;  // already offset to this lane's (problem, chunk) origin
+  long is, cs;
+  int L;
+  CLR_HD long off(int i) const { return i < L ? (long)i * is : cs + (long)(i - L) * is; }
+};
+
 // U~(t), V~(t): cholesky.h:129-147 (real rows: a, 1; complex pair: (a cd + b sd,
 // a sd - b cd), (cd, sd) with the ABSOLUTE time in the phase, :137).
 template <int JR, int JC>
@@ -129,13 +143,12 @@ CLR_HD void features_phi(const Problem<JR, JC>& p, double dx, double* phi) {
 }
 
 // ---------------------------------------------------------------------------
-// summarize: fold samples [n0, n1) of one problem (n1 < N: the element ends at
-// sample n1's "before" state) into a transfer element.  elem layout:
+// summarize: fold the L samples of one (full, non-final) chunk into a transfer
+// element that ends at the next chunk's first sample.  elem layout:
 //   A[J*J] row-major | b[J] | C[SZ] | eta[J] | Jm[SZ]
 // ---------------------------------------------------------------------------
 template <int JR, int JC>
-CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const double* t, const double* diag,
-                            const double* y, int n0, int n1, double* elem_out) {
+CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, double* elem_out) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   double A[J * J], b[J], C[SZ], eta[J], Jm[SZ];
@@ -149,16 +162,18 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const double* t, const dou
   CLR_UNROLL
   for (int i = 0; i < SZ; ++i) { C[i] = 0.0; Jm[i] = 0.0; }
 
-  double tn = t[n0];
-  double t_next = t[n0 + 1], diag_n = diag[n0], y_n = y[n0];
-  for (int n = n0; n < n1; ++n) {
-    // register prefetch of the next sample (n1 < N so n + 2 may reach N only
-    // when n + 1 == n1 == N - 1; clamp keeps the read in bounds)
+  // A summarised chunk is always a full one (L samples) followed by at least
+  // one more sample, so reads run to local index L (never L + 1).
+  const int len = sl.L;
+  double tn = sl.t[sl.off(0)];
+  double t_next = sl.t[sl.off(1)], diag_n = sl.diag[sl.off(0)], y_n = sl.y[sl.off(0)];
+  for (int i = 0; i < len; ++i) {
+    // register prefetch of the next sample
     const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
-    if (n + 1 < n1) {
-      t_next = t[n + 2];
-      diag_n = diag[n + 1];
-      y_n = y[n + 1];
+    if (i + 1 < len) {
+      t_next = sl.t[sl.off(i + 2)];
+      diag_n = sl.diag[sl.off(i + 1)];
+      y_n = sl.y[sl.off(i + 1)];
     }
 
     double u[J], v[J], phi[J];
@@ -340,8 +355,7 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
 // :703-706): phi[:, n] (move n -> n+1), u[:, n-1] = U~(t_n), W[:, n], D[n].
 // ---------------------------------------------------------------------------
 template <int JR, int JC, bool MATERIALIZE>
-CLR_HD void replay_chunk(const Problem<JR, JC>& p, const double* t, const double* diag,
-                         const double* y, int N, int n0, int n1,
+CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, int n0, int n1,
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
                          double* phi_o, double* u_o, double* W_o, double* D_o) {
@@ -362,15 +376,16 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const double* t, const double
 
   double logdet = 0.0, quad = 0.0;
   int flag = 0;
-  double tn = t[n0];
-  double t_next = (n0 + 1 < N) ? t[n0 + 1] : tn;
-  double diag_n = diag[n0], y_n = y[n0];
+  double tn = sl.t[sl.off(0)];
+  double t_next = (n0 + 1 < N) ? sl.t[sl.off(1)] : tn;
+  double diag_n = sl.diag[sl.off(0)], y_n = sl.y[sl.off(0)];
   for (int n = n0; n < n1; ++n) {
+    const int i = n - n0;
     const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
     if (n + 1 < n1) {
-      t_next = (n + 2 < N) ? t[n + 2] : t_next;
-      diag_n = diag[n + 1];
-      y_n = y[n + 1];
+      t_next = (n + 2 < N) ? sl.t[sl.off(i + 2)] : t_next;
+      diag_n = sl.diag[sl.off(i + 1)];
+      y_n = sl.y[sl.off(i + 1)];
     }
 
     double u[J], v[J];

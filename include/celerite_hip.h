@@ -170,7 +170,13 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp);
 
-/* Tuning: number of chunks the N axis is cut into for the scan (0 = auto). */
+/* Tuning.  The kernels read the series from a chunk-interleaved copy
+ * ([problem][i][chunk]; one coalesced 512-B wave load per array per step) that
+ * enqueue builds with a tiled-transpose kernel whenever the series or the
+ * chunking changed.  set_layout(h, 0) makes them read the row-major arrays
+ * directly (slower; kept for A/B measurements). */
+int clr_batch_set_layout(clr_batch* h, int interleaved);
+/* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);
 
@@ -188,11 +194,15 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
 int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D);
 
 /* Runs `steps` evaluations back to back, bracketing every kernel with HIP
- * events recorded on the handle's stream.  kernel_ms[4] receives the SUMMED
- * device time of the summarise / prefix / replay / finalise kernels,
- * total_ms the first-event-to-last-event time. */
-int clr_batch_run_timed(clr_batch* h, int materialize, int steps,
-                        double* total_ms, double* kernel_ms /* [4] */);
+ * events recorded on the handle's stream.  kernel_ms[5] receives the SUMMED
+ * device time of the relayout / summarise / prefix / replay / finalise
+ * kernels, total_ms the first-event-to-last-event time.  With
+ * relayout_each_step != 0 the row-major -> interleaved transposition is redone
+ * inside every step (the cost when every evaluation brings NEW series);
+ * otherwise it is done once, outside the timed region (fixed series, new
+ * hyper-parameters: the MCMC / optimiser loop of celerite.py:160-219). */
+int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
+                        double* total_ms, double* kernel_ms /* [5] */);
 
 /* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,

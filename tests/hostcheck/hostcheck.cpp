@@ -18,20 +18,36 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
                const double* c_real, const double* a_comp, const double* b_comp,
                const double* c_comp, const double* d_comp, const double* t, long ts,
                const double* diag, long ds, const double* y, long ys, int materialize,
+               int interleaved,
                double* ll, double* logdet, double* quad, int* status, double* phi, double* u,
                double* W, double* D) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
   const int L = (N + nchunk - 1) / nchunk;
   std::vector<double> elems((size_t)nchunk * Wd::ELEM), starts((size_t)nchunk * Wd::START);
+  // optional chunk-interleaved copies [i][chunk] (what relayout_kernel writes on the GPU)
+  std::vector<double> tT((size_t)L * nchunk), dT((size_t)L * nchunk), yT((size_t)L * nchunk);
   for (int b = 0; b < B; ++b) {
     Problem<JR, JC> p;
     p.load(a_real + (long)b * JR, c_real + (long)b * JR, a_comp + (long)b * JC,
            b_comp + (long)b * JC, c_comp + (long)b * JC, d_comp + (long)b * JC, jitter[b]);
     const double *tb = t + b * ts, *db = diag + b * ds, *yb = y + b * ys;
+    long is = 1, cs = L;
+    if (interleaved) {
+      for (int c = 0; c < nchunk; ++c)
+        for (int i = 0; i < L; ++i) {
+          const long n = (long)c * L + i;
+          tT[(size_t)i * nchunk + c] = n < N ? tb[n] : 0.0;
+          dT[(size_t)i * nchunk + c] = n < N ? db[n] : 0.0;
+          yT[(size_t)i * nchunk + c] = n < N ? yb[n] : 0.0;
+        }
+      tb = tT.data(); db = dT.data(); yb = yT.data();
+      is = nchunk; cs = 1;
+    }
+    auto lane = [&](int c) { return SeriesLane{tb + c * cs, db + c * cs, yb + c * cs, is, cs, L}; };
     for (int c = 0; c + 1 < nchunk; ++c) {
       if ((c + 1) * L >= N) continue;  // element would run past the data; never applied
-      summarize_chunk<JR, JC>(p, tb, db, yb, c * L, (c + 1) * L, &elems[(size_t)c * Wd::ELEM]);
+      summarize_chunk<JR, JC>(p, lane(c), &elems[(size_t)c * Wd::ELEM]);
     }
     double S[Wd::SZ] = {0}, f[J] = {0};
     for (int c = 0; c + 1 < nchunk; ++c) {
@@ -50,12 +66,12 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       int fl;
       const long Nm1 = N - 1;
       if (materialize)
-        replay_chunk<JR, JC, true>(p, tb, db, yb, N, n0, n1,
+        replay_chunk<JR, JC, true>(p, lane(c), N, n0, n1,
                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                    phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
                                    W + (long)b * J * N, D + (long)b * N);
       else
-        replay_chunk<JR, JC, false>(p, tb, db, yb, N, n0, n1,
+        replay_chunk<JR, JC, false>(p, lane(c), N, n0, n1,
                                     c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                     nullptr, nullptr, nullptr, nullptr);
       ld += l;
@@ -73,15 +89,16 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
 #define CASE(R, C)                                                                          \
   if (JR == R && JC == C)                                                                   \
     return run<R, C>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,  \
-                     t, ts, diag, ds, y, ys, materialize, ll, logdet, quad, status, phi, u, \
-                     W, D);
+                     t, ts, diag, ds, y, ys, materialize, interleaved, ll, logdet, quad,    \
+                     status, phi, u, W, D);
 
 extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const double* jitter,
                                const double* a_real, const double* c_real,
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp, const double* t,
                                long ts, const double* diag, long ds, const double* y, long ys,
-                               int materialize, double* ll, double* logdet, double* quad,
+                               int materialize, int interleaved, double* ll, double* logdet,
+                               double* quad,
                                int* status, double* phi, double* u, double* W, double* D) {
   CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(0, 2) CASE(2, 2)
   CASE(2, 3) CASE(0, 4) CASE(4, 2) CASE(8, 0)
