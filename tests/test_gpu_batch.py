@@ -1,0 +1,166 @@
+# -*- coding: utf-8 -*-
+"""`-m gpu`: the batched log-likelihood path (the hot path of the north star)
+through the C ABI, against the CPU oracle on identical seeded inputs.
+
+Tolerance: relative error <= 1e-10 on log_det and on the quadratic form
+(BASELINE.json north_star); integer status words must match exactly.  At the
+full bench size (N = 1e5) the oracle is only run on a sample of problems and
+the rest is covered by size-independent properties."""
+import numpy as np
+import pytest
+
+from celerite_amd import batch
+from oracle import ref
+from _cases import ALL_WIDTH_SHAPES, synthetic, coeffs_of
+
+pytestmark = pytest.mark.gpu
+REL = 1e-10
+
+
+def check(case, nchunk=0, interleaved=True, B=None):
+    B = case["t"].shape[0] if B is None else B
+    plan = batch.BatchedGP(B, case["t"].shape[-1], case["a_real"].shape[1], case["a_comp"].shape[1])
+    try:
+        if nchunk:
+            plan.set_chunks(nchunk)
+        plan.set_layout(interleaved)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case), jitter=case.get("jitter", 0.0))
+        ll, ld, q, st = plan.log_likelihood()
+    finally:
+        plan.close()
+    l0, d0, q0, s0 = ref.batch_log_likelihood(case.get("jitter", 0.0), *coeffs_of(case), case["t"],
+                                              case["diag"], case["y"])
+    assert np.array_equal(st, s0)
+    ok = s0 == 0
+    assert np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
+    assert np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])) <= REL
+    assert np.max(np.abs(ll[ok] - l0[ok]) / np.abs(l0[ok])) <= REL
+    assert np.all(np.isneginf(ll[~ok]))
+    return ll, ld, q, st
+
+
+@pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
+def test_every_width_shape(JR, JC):
+    for family, N, nchunk in [("bench", 3000, 0), ("accuracy", 3000, 64), ("bench", 257, 5)]:
+        check(synthetic(5, N, JR, JC, family, seed=JR * 10 + JC), nchunk=nchunk)
+
+
+@pytest.mark.parametrize("N,nchunk", [(1, 0), (2, 0), (3, 2), (7, 3), (64, 64), (100, 7), (127, 0),
+                                      (128, 0), (129, 0), (1000, 1), (1000, 999), (4097, 64)])
+def test_edge_sizes_and_chunkings(N, nchunk):
+    check(synthetic(3, N, 2, 3, "accuracy", seed=N), nchunk=nchunk)
+    check(synthetic(3, N, 1, 1, "bench", seed=N + 1), nchunk=nchunk, interleaved=False)
+
+
+def test_config2_shape():
+    """BASELINE config 2: batch 256, N = 1e4, width 4 (2 complex terms)."""
+    check(synthetic(256, 10000, 0, 2, "bench", seed=2))
+
+
+def test_shared_series_many_draws():
+    """One light curve, B hyper-parameter draws (stride-0 series)."""
+    case = synthetic(64, 5000, 2, 3, "bench", seed=11)
+    shared = dict(case)
+    for k in ("t", "diag", "y"):
+        shared[k] = case[k][0]
+    ll, ld, q, st = check(shared, B=64)
+    assert len(set(np.round(ld, 6))) > 32  # draws really differ
+
+
+def test_jitter_and_not_positive_definite_neighbours():
+    case = synthetic(9, 2000, 1, 1, "bench", seed=5)
+    case["jitter"] = np.linspace(0.0, 0.4, 9)
+    case["a_real"][4, 0] = -5.0   # not positive definite (tests/test_celerite.py:324-331 analogue)
+    case["diag"][4] = 0.0
+    case["a_comp"][7, 0] = -3.0
+    case["diag"][7] = 1e-6
+    ll, ld, q, st = check(case, nchunk=16)
+    assert st[4] == 2 and st[7] == 2 and (np.delete(st, [4, 7]) == 0).all()
+
+
+def test_materialised_factor_matches_oracle_state():
+    case = synthetic(3, 5000, 2, 3, "bench", seed=8)
+    plan = batch.BatchedGP(3, 5000, 2, 3)
+    plan.set_chunks(40)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    ll, ld, q, st = plan.log_likelihood(materialize=True)
+    for p in range(3):
+        phi, u, W, D = plan.factor(p)
+        r = ref.RefSolver()
+        r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)),
+                  case["t"][p], case["diag"][p])
+        _, N, J, logdet, rphi, ru, rW, rD = r.state()
+        assert abs(ld[p] - logdet) <= REL * abs(logdet)
+        assert np.allclose(phi, rphi, rtol=1e-13, atol=0)
+        assert np.allclose(u, ru, rtol=1e-12, atol=1e-15)
+        assert np.allclose(W, rW, rtol=1e-9, atol=1e-12)
+        assert np.allclose(D, rD, rtol=1e-11, atol=0)
+    plan.close()
+
+
+def test_results_independent_of_chunking_and_layout():
+    """Sharding/chunking must not change the answer beyond rounding (the scan
+    re-associates): every chunking agrees with every other to 1e-11."""
+    case = synthetic(4, 30000, 2, 3, "bench", seed=21)
+    plan = batch.BatchedGP(4, 30000, 2, 3)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    outs = []
+    for nchunk, inter in [(1, True), (7, True), (64, True), (64, False), (600, True)]:
+        plan.set_chunks(nchunk)
+        plan.set_layout(inter)
+        outs.append(plan.log_likelihood())
+    plan.close()
+    for o in outs[1:]:
+        assert np.max(np.abs(o[1] - outs[0][1]) / np.abs(outs[0][1])) < 1e-11
+        assert np.max(np.abs(o[2] - outs[0][2]) / np.abs(outs[0][2])) < 1e-11
+
+
+def test_bench_size_sample_and_properties():
+    """BASELINE config 3 shape (N = 1e5, width 8 = 2 real + 3 complex) on a 32-problem
+    batch: oracle parity on a sample of 4, plus size-independent properties on all:
+      * log det does not depend on y; the quadratic form is homogeneous of degree 2
+        (y -> 2 y multiplies it by exactly 4: scaling by 2 is exact in fp64);
+      * y = 0 gives quad = 0 exactly and loglike = -(logdet + N log 2 pi) / 2."""
+    B, N = 32, 100000
+    case = synthetic(B, N, 2, 3, "bench", seed=42)
+    plan = batch.BatchedGP(B, N, 2, 3)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    ll, ld, q, st = plan.log_likelihood()
+    assert (st == 0).all()
+    sample = [0, 7, 19, 31]
+    sub = {k: v[sample] for k, v in case.items()}
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(sub), sub["t"], sub["diag"], sub["y"])
+    assert np.max(np.abs(ld[sample] - d0) / np.abs(d0)) <= REL
+    assert np.max(np.abs(q[sample] - q0) / np.abs(q0)) <= REL
+
+    plan.set_series(case["t"], case["diag"], 2.0 * case["y"])
+    ll2, ld2, q2, _ = plan.log_likelihood()
+    assert np.array_equal(ld2, ld)
+    assert np.array_equal(q2, 4.0 * q)
+    plan.set_series(case["t"], case["diag"], np.zeros_like(case["y"]))
+    ll3, ld3, q3, _ = plan.log_likelihood()
+    assert np.array_equal(ld3, ld) and np.all(q3 == 0.0)
+    assert np.allclose(ll3, -0.5 * (ld + N * np.log(2 * np.pi)), rtol=1e-15)
+    plan.close()
+
+
+def test_one_shot_helper_and_coefficient_table():
+    from celerite_amd import terms, GP
+
+    kernel = terms.RealTerm(0.1, 0.5) + terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5)
+    rng = np.random.RandomState(3)
+    t = np.sort(rng.uniform(0, 50, 1000))      # BASELINE config 1 shape: N = 1000, width 3
+    yerr = rng.uniform(0.1, 0.3, 1000)
+    y = np.sin(t) + yerr * rng.randn(1000)
+    draws = kernel.get_parameter_vector()[None, :] + 0.05 * rng.randn(16, 5)
+    tab = batch.kernel_coefficient_table(kernel, draws)
+    ll, ld, q, st = batch.batch_log_likelihood(*tab[:6], t, yerr ** 2, y, jitter=tab[6])
+    gp = GP(kernel)
+    for i in (0, 5, 15):  # the batched entry equals GP.compute + GP.log_likelihood
+        gp.set_parameter_vector(draws[i])
+        gp.compute(t, yerr)
+        assert abs(gp.log_likelihood(y) - ll[i]) <= REL * abs(ll[i])

@@ -1,0 +1,381 @@
+# -*- coding: utf-8 -*-
+"""`-m gpu`: the single-problem solver object and the GP front-end on an MI355X.
+
+Two kinds of assertion:
+  * the reference's own tests (tests/test_celerite.py), re-authored against
+    `celerite_amd` -- same seeded inputs, same dense-LAPACK comparators, same
+    exception / flag protocol;
+  * parity with the CPU oracle on identical inputs at the north-star bar:
+    |delta| / |value| <= 1e-10 on log_determinant and dot_solve (stated per
+    assertion; observed ~1e-13).
+Everything goes through the pybind11 module, i.e. through the C ABI."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import celerite_amd
+from celerite_amd import GP, terms
+from celerite_amd.solver import get_kernel_value, LinAlgError
+from oracle import dense, ref
+from _cases import (COEFFS_W4, COEFFS_W10, COEFFS_DOT, COEFFS_PICKLE, COEFFS_CC_REAL, COEFFS_CC_COMP,
+                    NO_GENERAL, FIRST_TUTORIAL_LOGLIKE, first_tutorial_case, general_terms,
+                    logdet_case, solve_case, synthetic, coeffs_of)
+
+pytestmark = pytest.mark.gpu
+REL = 1e-10  # north-star tolerance on log_determinant and dot_solve
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+# ---- the reference's tests, re-authored ------------------------------------
+@pytest.mark.parametrize("coeffs", [COEFFS_W4, COEFFS_W10])
+def test_log_determinant(coeffs):  # tests/test_celerite.py:45-85
+    t, diag = logdet_case()
+    s = celerite_amd.CholeskySolver()
+    s.compute(0.0, *coeffs, *NO_GENERAL, t, diag)
+    K = get_kernel_value(*coeffs, t[:, None] - t[None, :])
+    K[np.diag_indices_from(K)] += diag
+    assert np.allclose(s.log_determinant(), np.linalg.slogdet(K)[1])
+
+
+@pytest.mark.parametrize("with_general", [True, False])
+@pytest.mark.parametrize("coeffs", [COEFFS_W4, COEFFS_W10])
+def test_solve(coeffs, with_general):  # tests/test_celerite.py:88-151
+    t, diag, b, (A, U, V) = solve_case(with_general)
+    s = celerite_amd.CholeskySolver()
+    with pytest.raises(RuntimeError):
+        s.log_determinant()
+    with pytest.raises(RuntimeError):
+        s.dot_solve(b)
+    s.compute(0.0, *coeffs, A, U, V, t, diag)
+    K = get_kernel_value(*coeffs, t[:, None] - t[None, :])
+    K[np.diag_indices_from(K)] += diag
+    if len(A):
+        K[np.diag_indices_from(K)] += A
+        K += np.tril(np.dot(U.T, V), -1) + np.triu(np.dot(V.T, U), 1)
+    x = s.solve(b)
+    assert x.shape == (len(t), 1)  # always 2-D, like the reference
+    assert np.allclose(x.T, np.linalg.solve(K, b))
+    b5 = np.random.randn(len(t), 5)
+    assert np.allclose(s.solve(b5), np.linalg.solve(K, b5))
+    # parity with the oracle at the north-star bar
+    r = ref.RefSolver()
+    r.compute(0.0, *coeffs, A, U, V, t, diag)
+    assert rel(s.log_determinant(), r.log_determinant()) <= REL
+    assert rel(s.dot_solve(b), r.dot_solve(b)) <= REL
+    assert np.abs(s.solve(b5) - r.solve(b5)).max() <= 1e-10 * np.abs(r.solve(b5)).max()
+
+
+@pytest.mark.parametrize("with_general", [True, False])
+def test_dot(with_general):  # tests/test_celerite.py:154-192
+    s = celerite_amd.CholeskySolver()
+    np.random.seed(42)
+    t = np.sort(np.random.rand(500))
+    b = np.random.randn(len(t), 5)
+    K = get_kernel_value(*COEFFS_DOT, t[:, None] - t[None, :])
+    if with_general:
+        A, U, V = general_terms(t, np.random.rand)
+        K[np.diag_indices_from(K)] += A
+        K += np.tril(np.dot(U.T, V), -1) + np.triu(np.dot(V.T, U), 1)
+    else:
+        A, U, V = NO_GENERAL
+    x = s.dot(0.0, *COEFFS_DOT, A, U, V, t, b)
+    assert np.allclose(np.dot(K, b), x)
+    x1 = s.dot(0.0, *COEFFS_DOT, A, U, V, t, b[:, 0])
+    assert x1.shape == (len(t), 1) and np.allclose(x1[:, 0], x[:, 0])
+
+
+@pytest.mark.parametrize("with_general", [True, False])
+def test_dot_L(with_general):  # tests/test_celerite.py:194-235
+    s = celerite_amd.CholeskySolver()
+    np.random.seed(42)
+    t = np.sort(np.random.rand(5))
+    b = np.random.randn(len(t), 5)
+    yerr = np.random.uniform(0.1, 0.5, len(t))
+    K = get_kernel_value(*COEFFS_DOT, t[:, None] - t[None, :])
+    K[np.diag_indices_from(K)] += yerr ** 2
+    if with_general:
+        A, U, V = general_terms(t, np.random.rand)
+        K[np.diag_indices_from(K)] += A
+        K += np.tril(np.dot(U.T, V), -1) + np.triu(np.dot(V.T, U), 1)
+    else:
+        A, U, V = NO_GENERAL
+    s.compute(0.0, *COEFFS_DOT, A, U, V, t, yerr ** 2)
+    assert np.allclose(np.dot(np.linalg.cholesky(K), b), s.dot_L(b))
+
+
+@pytest.mark.parametrize("with_general", [True, False])
+def test_pickle(with_general):  # tests/test_celerite.py:237-289
+    s = celerite_amd.CholeskySolver()
+    np.random.seed(42)
+    t = np.sort(np.random.rand(500))
+    diag = np.random.uniform(0.1, 0.5, len(t))
+    y = np.sin(t)
+    A, U, V = general_terms(t, np.random.rand) if with_general else NO_GENERAL
+
+    def compare(s1, s2):
+        assert s1.computed() == s2.computed()
+        if not s1.computed():
+            return
+        assert np.allclose(s1.log_determinant(), s2.log_determinant())
+        assert np.allclose(s1.dot_solve(y), s2.dot_solve(y))
+
+    compare(s, pickle.loads(pickle.dumps(s, -1)))
+    s.compute(0.0, *COEFFS_PICKLE, A, U, V, t, diag)
+    s2 = pickle.loads(pickle.dumps(s, -1))
+    compare(s, s2)
+    # the pickled state is the reference's 8-tuple (solver.cpp:36-42), bit-identical
+    st, st2 = s.__getstate__(), s2.__getstate__()
+    J = 4 + (4 if with_general else 0)
+    assert st[:3] == (True, 500, J) and st[4].shape == (J, 499) and st[6].shape == (J, 500)
+    for a, b in zip(st[4:], st2[4:]):
+        assert np.array_equal(a, b)
+    # ... and equals the oracle's factor
+    r = ref.RefSolver()
+    r.compute(0.0, *COEFFS_PICKLE, A, U, V, t, diag)
+    rs = r.state()
+    assert np.allclose(st[4], rs[4], rtol=1e-13, atol=0)       # phi
+    assert np.allclose(st[5], rs[5], rtol=1e-12, atol=1e-15)   # u
+    assert np.allclose(st[6], rs[6], rtol=1e-9, atol=1e-12)    # W
+    assert np.allclose(st[7], rs[7], rtol=1e-11, atol=0)       # D
+
+    kernel = terms.RealTerm(0.5, 0.1)
+    kernel += terms.ComplexTerm(0.6, 0.7, 1.0)
+    gp1 = GP(kernel)
+    gp1.compute(t, diag)
+    gp2 = pickle.loads(pickle.dumps(gp1, -1))
+    assert np.allclose(gp1.log_likelihood(y), gp2.log_likelihood(y))
+
+
+@pytest.mark.parametrize("with_general", [True, False])
+def test_log_likelihood(with_general):  # tests/test_celerite.py:311-404
+    np.random.seed(42)
+    x = np.sort(np.random.rand(10))
+    yerr = np.random.uniform(0.1, 0.5, len(x))
+    y = np.sin(x)
+    A, U, V = general_terms(x, np.random.rand) if with_general else NO_GENERAL
+
+    class NPDTerm(terms.Term):
+        parameter_names = ("par1", )
+
+        def get_real_coefficients(self, params):
+            return [params[0]], [0.1]
+
+    gp = GP(NPDTerm(-1.0))
+    with pytest.raises(LinAlgError):
+        gp.compute(x, 0.0)
+    with pytest.raises(LinAlgError):
+        gp.log_likelihood(y)
+    assert np.isinf(gp.log_likelihood(y, quiet=True))
+
+    kernel = terms.RealTerm(0.1, 0.5)
+    gp = GP(kernel)
+    with pytest.raises(RuntimeError):
+        gp.log_likelihood(y)
+
+    termlist = [(0.1 + 10. / j, 0.5 + 10. / j) for j in range(1, 4)]
+    termlist += [(1.0 + 10. / j, 0.01 + 10. / j, 0.5, 0.01) for j in range(1, 10)]
+    termlist += [(0.6, 0.7, 1.0), (0.3, 0.05, 0.5, 0.6)]
+    for term in termlist:  # widths 2 .. 26 (30 with general terms): every kernel path
+        kernel += terms.ComplexTerm(*term) if len(term) > 2 else terms.RealTerm(*term)
+        gp = GP(kernel)
+        assert gp.computed is False
+        with pytest.raises(ValueError):
+            gp.compute(np.random.rand(len(x)), yerr)
+        gp.compute(x, yerr, A=A, U=U, V=V)
+        assert gp.computed is True
+        assert gp.dirty is False
+        ll = gp.log_likelihood(y)
+        K = gp.get_matrix(include_diagonal=True)
+        ll0 = -0.5 * np.dot(y, np.linalg.solve(K, y))
+        ll0 -= 0.5 * np.linalg.slogdet(K)[1]
+        ll0 -= 0.5 * len(x) * np.log(2 * np.pi)
+        assert np.allclose(ll, ll0)
+
+    gp.set_parameter_vector(gp.get_parameter_vector())
+    assert gp.dirty is True
+    assert gp.computed is False
+
+    gp.compute(x, yerr, A=A, U=U, V=V)
+    ll1 = gp.log_likelihood(y)
+    params = gp.get_parameter_vector()
+    params[0] += 10.0
+    gp.set_parameter_vector(params)
+    gp.compute(x, yerr, A=A, U=U, V=V)
+    ll2 = gp.log_likelihood(y)
+    assert not np.allclose(ll1, ll2)
+
+    gp[1] += 10.0
+    assert gp.dirty is True
+    gp.compute(x, yerr, A=A, U=U, V=V)
+    ll3 = gp.log_likelihood(y)
+    assert not np.allclose(ll2, ll3)
+
+    ind = len(x) // 2  # zero delta t
+    x = np.concatenate((x[:ind], [x[ind]], x[ind:]))
+    y = np.concatenate((y[:ind], [y[ind]], y[ind:]))
+    yerr = np.concatenate((yerr[:ind], [yerr[ind]], yerr[ind:]))
+    gp.compute(x, yerr)
+    ll = gp.log_likelihood(y)
+    K = gp.get_matrix(include_diagonal=True)
+    ll0 = -0.5 * np.dot(y, np.linalg.solve(K, y))
+    ll0 -= 0.5 * np.linalg.slogdet(K)[1]
+    ll0 -= 0.5 * len(x) * np.log(2 * np.pi)
+    assert np.allclose(ll, ll0)
+
+
+def test_grad_log_likelihood_contract():  # tests/test_celerite.py:407-446 (no-autodiff arm)
+    gp = GP(terms.RealTerm(log_a=0.1, log_c=0.5))
+    np.random.seed(42)
+    x = np.sort(np.random.rand(100))
+    gp.compute(x, np.random.uniform(0.1, 0.5, len(x)))
+    with pytest.raises((ImportError, RuntimeError)):
+        gp.grad_log_likelihood(np.sin(x))
+
+
+def test_predict():  # tests/test_celerite.py:468-496
+    np.random.seed(42)
+    x = np.linspace(1, 59, 300)
+    t = np.sort(np.random.uniform(10, 50, 100))
+    yerr = np.random.uniform(0.1, 0.5, len(t))
+    y = np.sin(t)
+    kernel = terms.RealTerm(0.1, 0.5)
+    for term in [(0.6, 0.7, 1.0), (0.1, 0.05, 0.5, -0.1)]:
+        kernel += terms.ComplexTerm(*term)
+    gp = GP(kernel)
+    gp.compute(t, yerr)
+    K = gp.get_matrix(include_diagonal=True)
+    Ks = gp.get_matrix(x, t)
+    true_mu = np.dot(Ks, np.linalg.solve(K, y))
+    true_cov = gp.get_matrix(x, x) - np.dot(Ks, np.linalg.solve(K, Ks.T))
+    mu, cov = gp.predict(y, x)
+    _, var = gp.predict(y, x, return_var=True)
+    assert np.allclose(mu, true_mu)
+    assert np.allclose(cov, true_cov)
+    assert np.allclose(var, np.diag(true_cov))
+    mu0, cov0 = gp.predict(y, t)
+    mu, cov = gp.predict(y)
+    assert np.allclose(mu0, mu)
+    assert np.allclose(cov0, cov)
+
+
+def test_nyquist_singularity():  # tests/test_celerite.py:501-525
+    np.random.seed(4220)
+    gp = GP(terms.ComplexTerm(1.0, np.log(1e-6), np.log(1.0)))
+    ts = np.array([0.0, 0.5, 1.0, 1.5])
+    ts[1] = ts[1] + 1e-9 * np.random.randn()
+    ts[2] = ts[2] + 1e-8 * np.random.randn()
+    ts[3] = ts[3] + 1e-7 * np.random.randn()
+    yerr = np.random.uniform(low=0.1, high=0.2, size=len(ts))
+    y = np.random.randn(len(ts))
+    gp.compute(ts, yerr)
+    llgp = gp.log_likelihood(y)
+    K = gp.get_matrix(ts)
+    K[np.diag_indices_from(K)] += yerr ** 2.0
+    ll = (-0.5 * np.dot(y, np.linalg.solve(K, y)) - 0.5 * np.linalg.slogdet(K)[1]
+          - 0.5 * len(y) * np.log(2.0 * np.pi))
+    assert np.allclose(ll, llgp)
+
+
+# ---- golden value and 1e-10 parity -----------------------------------------------
+def test_first_tutorial_known_answer():  # docs/tutorials/first.rst:24-31,74-101
+    t, yerr, y = first_tutorial_case()
+    Q = 1.0 / np.sqrt(2.0)
+    w0 = 3.0
+    S0 = np.var(y) / (w0 * Q)
+    bounds = dict(log_S0=(-15, 15), log_Q=(-15, 15), log_omega0=(-15, 15))
+    kernel = terms.SHOTerm(log_S0=np.log(S0), log_Q=np.log(Q), log_omega0=np.log(w0), bounds=bounds)
+    kernel.freeze_parameter("log_Q")
+    Q = 1.0
+    S0 = np.var(y) / (w0 * Q)
+    kernel += terms.SHOTerm(log_S0=np.log(S0), log_Q=np.log(Q), log_omega0=np.log(w0), bounds=bounds)
+    gp = celerite_amd.GP(kernel, mean=np.mean(y))
+    gp.compute(t, yerr)
+    assert abs(gp.log_likelihood(y) - FIRST_TUTORIAL_LOGLIKE) <= 1e-10 * abs(FIRST_TUTORIAL_LOGLIKE)
+    assert gp.get_parameter_names() == ("kernel:terms[0]:log_S0", "kernel:terms[0]:log_omega0",
+                                        "kernel:terms[1]:log_S0", "kernel:terms[1]:log_Q",
+                                        "kernel:terms[1]:log_omega0")
+
+
+def test_cc_suite_1e10():
+    """cpp/src/test_solvers.cc:79-97: real / complex / mixed / general kernels, N = 1024,
+    jitter 0.01; there the bar is 1e-10 ABSOLUTE against a dense LDL^T."""
+    rng = np.random.RandomState(42)
+    N = 1024
+    x = np.sort(rng.uniform(-1, 1, N))
+    yerr2 = 0.3 + 0.1 * rng.uniform(-1, 1, N)
+    y = np.sin(x)
+    U = np.array([x ** j for j in range(3)])
+    V = np.array([x ** j / (1.0 + j) for j in range(3)])
+    A = 1e-6 + np.sum(U * V, axis=0)
+    e = np.empty(0)
+    for coeffs, gen in [(COEFFS_CC_REAL + (e, e, e, e), NO_GENERAL), ((e, e) + COEFFS_CC_COMP, NO_GENERAL),
+                        (COEFFS_CC_REAL + COEFFS_CC_COMP, NO_GENERAL),
+                        (COEFFS_CC_REAL + COEFFS_CC_COMP, (A, U, V))]:
+        s = celerite_amd.CholeskySolver()
+        s.compute(0.01, *coeffs, *gen, x, yerr2)
+        K = dense.dense_matrix(0.01, *coeffs, *gen, x, yerr2)
+        assert abs(s.log_determinant() - dense.dense_logdet(K)) < 1e-10
+        assert abs(s.dot_solve(y) - y @ np.linalg.solve(K, y)) < 1e-10
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 127, 128, 129, 1000, 20000])
+@pytest.mark.parametrize("shape", [(1, 0), (1, 1), (2, 3), (8, 0), (0, 4)])
+def test_solver_vs_oracle_small_widths(N, shape):
+    """Widths <= 8 take the chunked-scan path inside compute(); N straddles the
+    single-chunk / multi-chunk switch."""
+    case = synthetic(1, N, shape[0], shape[1], "accuracy" if N % 2 else "bench", seed=N)
+    co = coeffs_of(case, 0)
+    t, diag, y = case["t"][0], case["diag"][0], case["y"][0]
+    s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+    s.compute(0.0, *co, *NO_GENERAL, t, diag)
+    r.compute(0.0, *co, *NO_GENERAL, t, diag)
+    assert rel(s.log_determinant(), r.log_determinant()) <= REL
+    assert rel(s.dot_solve(y), r.dot_solve(y)) <= REL
+    xs, xr = s.solve(y), r.solve(y)
+    assert np.abs(xs - xr).max() <= 1e-9 * np.abs(xr).max()
+
+
+def test_wide_and_jitter_only_kernels_vs_oracle():
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                         "terms_golden.json")))
+    co = [np.array(b) for b in golden["test_log_likelihood full kernel (width 26)"]["coefficients"]]
+    np.random.seed(1)
+    t = np.sort(np.random.rand(300))
+    diag = np.random.uniform(0.1, 0.5, 300)
+    y = np.random.randn(300)
+    gen = general_terms(t, np.random.rand)
+    for g in (NO_GENERAL, gen):  # widths 26 and 30
+        s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+        s.compute(0.01, *co, *g, t, diag)
+        r.compute(0.01, *co, *g, t, diag)
+        assert rel(s.log_determinant(), r.log_determinant()) <= REL
+        assert rel(s.dot_solve(y), r.dot_solve(y)) <= REL
+    e = np.empty(0)
+    s, r = celerite_amd.CholeskySolver(), ref.RefSolver()  # J == 0: cholesky.h:90-95
+    s.compute(0.3, e, e, e, e, e, e, *NO_GENERAL, t, diag)
+    r.compute(0.3, e, e, e, e, e, e, *NO_GENERAL, t, diag)
+    assert rel(s.log_determinant(), r.log_determinant()) <= REL
+    assert rel(s.dot_solve(y), r.dot_solve(y)) <= REL
+    assert np.allclose(s.solve(y)[:, 0], y / (diag + 0.3))
+    assert np.allclose(s.dot(0.3, e, e, e, e, e, e, *NO_GENERAL, t, y)[:, 0], 0.3 * y)
+
+
+def test_failed_compute_leaves_solver_not_computed():  # cholesky.h:57
+    e = np.empty(0)
+    s = celerite_amd.CholeskySolver()
+    t = np.linspace(0, 1, 50)
+    s.compute(0.0, np.ones(1), np.ones(1), e, e, e, e, *NO_GENERAL, t, np.ones(50))
+    assert s.computed()
+    with pytest.raises(LinAlgError):
+        s.compute(0.0, -np.ones(1), 0.1 * np.ones(1), e, e, e, e, *NO_GENERAL, t, np.zeros(50))
+    assert not s.computed()
+    with pytest.raises(RuntimeError):
+        s.log_determinant()
+    with pytest.raises(RuntimeError, match="dimension mismatch"):
+        s.compute(0.0, np.ones(1), np.ones(1), e, e, e, e, *NO_GENERAL, t, np.ones(49))

@@ -1,0 +1,198 @@
+# -*- coding: utf-8 -*-
+"""Host-side logic that needs no GPU: the modelling protocol, the GP front-end's
+bookkeeping and error contract, the compiled module's import surface, that the
+C-ABI library exports every symbol include/celerite_hip.h declares, and that
+the product fails LOUDLY (no CPU fallback) when no MI355X is present."""
+import ctypes
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import celerite_amd
+from celerite_amd import GP, batch, modeling, solver, terms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = batch.device_count() == 0
+E = np.empty(0)
+NOGEN = (np.empty(0), np.empty((0, 0)), np.empty((0, 0)))
+
+
+def test_public_surface():  # celerite/__init__.py:20-33
+    for name in ("terms", "solver", "modeling", "GP", "CholeskySolver", "__library_version__"):
+        assert hasattr(celerite_amd, name)
+    assert celerite_amd.__library_version__ == "0.3.0"  # version.h:4-13
+    for name in ("get_library_version", "has_autodiff", "LinAlgError", "get_kernel_value",
+                 "get_psd_value", "check_coefficients", "CholeskySolver", "CARMASolver"):
+        assert hasattr(solver, name)
+    s = solver.CholeskySolver()
+    for meth in ("compute", "solve", "dot_solve", "dot_L", "dot", "predict", "log_determinant",
+                 "computed", "grad_log_likelihood", "__getstate__", "__setstate__"):
+        assert hasattr(s, meth)
+    assert issubclass(solver.LinAlgError, Exception)
+
+
+def test_abi_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+
+    lib = ctypes.CDLL(batch.LIB_PATH)
+    declared = entry.declared_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert missing == []
+    lib.clr_version.restype = ctypes.c_char_p
+    assert lib.clr_version() == b"0.3.0"
+    lib.clr_status_string.restype = ctypes.c_char_p
+    # what() strings of exceptions.h:14-36
+    assert lib.clr_status_string(1) == b"dimension mismatch"
+    assert lib.clr_status_string(2) == b"failed to factorize or solve matrix"
+    assert lib.clr_status_string(3) == b"you must call 'compute' first"
+
+
+def test_no_product_code_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under celerite_amd/ may import,
+    link or mention it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "celerite_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "celerite_ref" not in text and "from oracle" not in text \
+                    and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_solver_state_machine_without_compute():
+    s = solver.CholeskySolver()
+    assert s.computed() is False
+    with pytest.raises(RuntimeError, match="you must call 'compute' first"):
+        s.log_determinant()
+    # the reference checks the row count before `computed` (cholesky.h:327-328)
+    with pytest.raises(RuntimeError):
+        s.dot_solve(np.ones(3))
+    # dimension checks come before any device work (cholesky.h:59-69)
+    with pytest.raises(RuntimeError, match="dimension mismatch"):
+        s.compute(0.0, np.ones(1), np.ones(2), E, E, E, E, *NOGEN, np.arange(4.0), np.ones(4))
+    with pytest.raises(RuntimeError, match="dimension mismatch"):
+        s.compute(0.0, np.ones(1), np.ones(1), E, E, E, E, *NOGEN, np.arange(4.0), np.ones(5))
+    assert s.computed() is False
+    s2 = pickle.loads(pickle.dumps(s, -1))  # un-computed round trip, test_celerite.py:270-272
+    assert s2.computed() is False
+    fresh = solver.CholeskySolver.__new__(solver.CholeskySolver)  # what pickle.loads does
+    with pytest.raises(RuntimeError, match="Invalid state"):  # solver.cpp:649
+        fresh.__setstate__((1, 2, 3))
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
+def test_fails_loudly_without_a_gpu():
+    s = solver.CholeskySolver()
+    with pytest.raises(RuntimeError, match="no gfx950"):
+        s.compute(0.0, np.ones(1), np.ones(1), E, E, E, E, *NOGEN, np.arange(4.0), np.ones(4))
+    with pytest.raises(RuntimeError, match="no gfx950|clr_batch_create failed"):
+        batch.BatchedGP(2, 10, 1, 0)
+    gp = GP(terms.RealTerm(0.1, 0.5))
+    with pytest.raises(RuntimeError, match="no gfx950"):
+        gp.compute(np.arange(5.0), 0.1)
+
+
+def test_host_helpers():
+    tau = np.array([[0.0, 0.5], [1.0, -2.0]])
+    a, c = np.array([1.5, 0.1]), np.array([1.0, 0.3])
+    ac, bc, cc, dc = np.array([1.0]), np.array([0.1]), np.array([1.0]), np.array([1.0])
+    k = solver.get_kernel_value(a, c, ac, bc, cc, dc, tau)
+    at = np.abs(tau)
+    want = sum(ai * np.exp(-ci * at) for ai, ci in zip(a, c)) + np.exp(-cc[0] * at) * (
+        ac[0] * np.cos(dc[0] * at) + bc[0] * np.sin(dc[0] * at))
+    assert k.shape == tau.shape and np.allclose(k, want, rtol=1e-15)
+    assert solver.check_coefficients(a, c, ac, bc, cc, dc) is True
+    assert solver.check_coefficients(a, c[:1], ac, bc, cc, dc) is False  # utils.h:41
+    with pytest.raises(NotImplementedError):
+        solver.CARMASolver(-0.5, np.array([0.1]), np.array([0.2]))
+    assert solver.has_autodiff() is False
+
+
+def test_build_gp():  # tests/test_celerite.py:292-309
+    kernel = terms.RealTerm(0.5, 0.1)
+    kernel += terms.ComplexTerm(0.6, 0.7, 1.0)
+    gp = GP(kernel)
+    assert gp.vector_size == 5
+    assert np.allclose(gp.get_parameter_vector(), [0.5, 0.1, 0.6, 0.7, 1.0])
+    gp.set_parameter_vector([0.5, 0.8, 0.6, 0.7, 2.0])
+    assert np.allclose(gp.get_parameter_vector(), [0.5, 0.8, 0.6, 0.7, 2.0])
+    with pytest.raises(ValueError):
+        gp.set_parameter_vector([0.5, 0.8, -0.6])
+    with pytest.raises(ValueError):
+        gp.set_parameter_vector("face1")
+
+
+def test_gp_bookkeeping_and_errors():
+    gp = GP(terms.RealTerm(0.1, 0.5), mean=1.5, fit_mean=True)
+    assert gp.get_parameter_names() == ("kernel:log_a", "kernel:log_c", "mean:value")
+    assert gp.computed is False and gp.dirty is True
+    with pytest.raises(RuntimeError, match="you must call 'compute' first"):
+        gp.log_likelihood(np.ones(3))  # tests/test_celerite.py:341-344
+    with pytest.raises(ValueError, match="sorted"):
+        gp.compute(np.array([0.0, 2.0, 1.0]), 0.1)  # :358-359
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        gp.compute(np.zeros((3, 2)), 0.1)
+    with pytest.raises(RuntimeError):
+        gp.get_matrix()
+    K = gp.get_matrix(np.array([0.0, 1.0]), np.array([0.0, 0.5, 1.0]))
+    assert K.shape == (2, 3) and np.isclose(K[0, 0], np.exp(0.1))
+    with pytest.raises(RuntimeError, match="autodiff"):
+        gp.grad_log_likelihood(np.ones(3))  # celerite.py:247-251 when has_autodiff() is False
+    gp["kernel:log_a"] = 0.3
+    assert gp.get_parameter("kernel:log_a") == 0.3
+    gp.freeze_parameter("kernel:log_c")
+    assert gp.vector_size == 2
+    with pytest.warns(UserWarning):
+        gp2 = GP(terms.RealTerm(0.1, 0.5), log_white_noise=0.2)
+    assert np.isclose(gp2.kernel.jitter, np.exp(0.4)) and gp2.vector_size == 2
+
+
+def test_modeling_protocol():
+    class Line(modeling.Model):
+        parameter_names = ("m", "b")
+
+        def get_value(self, x):
+            return self.m * x + self.b
+
+        def compute_gradient(self, x):
+            return np.array([x, np.ones_like(x)])
+
+    m = Line(m=2.0, b=1.0, bounds=dict(m=(0, 5)))
+    assert m.full_size == 2 and len(m) == 2 and m.dirty
+    m.dirty = False
+    m.set_parameter_vector([3.0, 0.5])
+    assert m.dirty and np.allclose(m.get_value(np.array([1.0])), 3.5)
+    m.freeze_parameter("b")
+    assert m.get_parameter_names() == ("m",) and m.get_gradient(np.ones(2)).shape == (1, 2)
+    assert m.get_parameter_bounds(include_frozen=True) == [(0, 5), (None, None)]
+    m.set_parameter("m", 9.0)
+    assert m.log_prior() == -np.inf
+    with pytest.raises(ValueError):
+        Line(1.0)
+    with pytest.raises(ValueError):
+        Line(1.0, 2.0, b=3.0)
+    with pytest.raises(ValueError):
+        Line(m=1.0)
+    with pytest.raises(ValueError):
+        Line(m=1.0, b=2.0, c=3.0)
+    ms = modeling.ModelSet([("one", Line(1.0, 2.0)), ("two", modeling.ConstantModel(3.0))])
+    assert ms.get_parameter_names() == ("one:m", "one:b", "two:value")
+    assert ms.get_parameter_dict()["two:value"] == 3.0
+    ms.freeze_parameter("one:b")
+    assert ms.vector_size == 2 and np.array_equal(ms.unfrozen_mask, [True, False, True])
+    with pytest.raises(ValueError):
+        ms.freeze_parameter("nope:x")
+
+
+def test_batch_front_end_validation():
+    k = terms.RealTerm(0.1, 0.5) + terms.ComplexTerm(0.6, 0.7, 1.0)
+    draws = np.array([[0.1, 0.5, 0.6, 0.7, 1.0], [0.2, 0.4, 0.5, 0.6, 0.9]])
+    ar, cr, ac, bc, cc, dc, jit = batch.kernel_coefficient_table(k, draws)
+    assert ar.shape == (2, 1) and ac.shape == (2, 1) and np.allclose(jit, 0)
+    assert np.allclose(ar[:, 0], np.exp(draws[:, 0])) and np.allclose(dc[:, 0], np.exp(draws[:, 4]))
+    assert np.allclose(k.get_parameter_vector(), [0.1, 0.5, 0.6, 0.7, 1.0])  # restored
+    sho = terms.SHOTerm(log_S0=0.1, log_Q=0.0, log_omega0=0.5)
+    with pytest.raises(ValueError):  # Q crosses 1/2: term count changes between draws
+        batch.kernel_coefficient_table(sho, np.array([[0.1, 1.0, 0.5], [0.1, -1.0, 0.5]]))

@@ -1,0 +1,92 @@
+# -*- coding: utf-8 -*-
+"""The scan algebra of celerite_amd/csrc/clr_core.h (summarize -> prefix ->
+replay; both series layouts) instantiated on the HOST by tests/hostcheck and
+compared with the oracle.  This checks the mathematics the GPU kernels execute
+(same templates, same source) in the CPU-only run; the device build itself is
+checked by the `-m gpu` tests.  Tolerance: 1e-11 relative (the bar is 1e-10)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ref
+from _cases import synthetic, coeffs_of
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
+SO = os.path.join(HERE, "libhostcheck.so")
+SHAPES = [(1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 2), (2, 3), (0, 4), (4, 2), (8, 0)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    src = os.path.join(HERE, "hostcheck.cpp")
+    core = os.path.join(os.path.dirname(HERE), "..", "celerite_amd", "csrc", "clr_core.h")
+    if (not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(core))):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", "-ffp-contract=off",
+                               "-o", SO, src])
+    return C.CDLL(SO)
+
+
+def run(lib, JR, JC, nchunk, case, interleaved, materialize=False):
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    B, N = case["t"].shape
+    J = JR + 2 * JC
+    ll, ld, q = np.empty(B), np.empty(B), np.empty(B)
+    st = np.zeros(B, dtype=np.int32)
+    phi, u = np.zeros((B, max(N - 1, 1), J)), np.zeros((B, max(N - 1, 1), J))
+    W, D = np.zeros((B, N, J)), np.zeros((B, N))
+    jit = np.zeros(B)
+    keep = [np.ascontiguousarray(case[k], dtype=np.float64) for k in
+            ("a_real", "c_real", "a_comp", "b_comp", "c_comp", "d_comp", "t", "diag", "y")]
+    rc = lib.hostcheck_batch(B, N, JR, JC, nchunk, P(jit), *[k.ctypes.data_as(dp) for k in keep[:6]],
+                             keep[6].ctypes.data_as(dp), C.c_long(N), keep[7].ctypes.data_as(dp),
+                             C.c_long(N), keep[8].ctypes.data_as(dp), C.c_long(N), int(materialize),
+                             int(interleaved), P(ll), P(ld), P(q), st.ctypes.data_as(ip),
+                             P(phi), P(u), P(W), P(D))
+    assert rc == 0
+    return ll, ld, q, st, (phi, u, W, D)
+
+
+@pytest.mark.parametrize("JR,JC", SHAPES)
+@pytest.mark.parametrize("family", ["bench", "accuracy"])
+def test_scan_matches_oracle(lib, JR, JC, family):
+    for N, nchunk in [(1, 1), (2, 1), (7, 3), (100, 1), (1000, 7), (1000, 64), (3000, 100)]:
+        case = synthetic(3, N, JR, JC, family, seed=N + 10 * JR + JC)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        for inter in (0, 1):
+            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter)
+            assert np.array_equal(st, s0)
+            assert np.max(np.abs(ld - d0) / np.abs(d0)) < 1e-11
+            assert np.max(np.abs(q - q0) / np.abs(q0)) < 1e-11
+            assert np.max(np.abs(ll - l0) / np.abs(l0)) < 1e-11
+
+
+def test_materialised_factor_matches_oracle_state(lib):
+    case = synthetic(2, 700, 2, 3, "bench", seed=9)
+    _, _, _, _, (phi, u, W, D) = run(lib, 2, 3, 9, case, 1, materialize=True)
+    for p in range(2):
+        s = ref.RefSolver()
+        s.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)),
+                  case["t"][p], case["diag"][p])
+        _, N, J, _, rphi, ru, rW, rD = s.state()
+        assert np.allclose(phi[p].T, rphi, rtol=1e-13, atol=0)
+        assert np.allclose(u[p].T, ru, rtol=1e-12, atol=1e-15)
+        assert np.allclose(W[p].T, rW, rtol=1e-9, atol=1e-12)
+        assert np.allclose(D[p], rD, rtol=1e-11, atol=0)
+
+
+def test_not_positive_definite_is_flagged_not_propagated(lib):
+    case = synthetic(3, 600, 1, 0, "bench", seed=4)
+    case["a_real"][1, 0] = -1.0  # tests/test_celerite.py:324-327
+    case["diag"][1] = 0.0
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    assert list(s0) == [0, 2, 0]
+    for nchunk in (1, 5, 40):
+        ll, ld, q, st, _ = run(lib, 1, 0, nchunk, case, 1)
+        assert list(st) == [0, 2, 0]
+        assert ll[1] == -np.inf
+        for p in (0, 2):
+            assert abs(ld[p] - d0[p]) < 1e-11 * abs(d0[p]) and abs(q[p] - q0[p]) < 1e-11 * abs(q0[p])
