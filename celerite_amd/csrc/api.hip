@@ -171,9 +171,10 @@ int upload(DevBuf& buf, const double* host, size_t n, hipStream_t s) {
 // Chunk count for the scan on `B` problems of `N` samples.
 int auto_chunks(int B, int N) {
   if (N < 128) return 1;
-  // aim at ~2 waves per SIMD (256 CUs x 4 SIMDs x 64 lanes x 2) over the batch,
+  // aim at one wave per SIMD (256 CUs x 4 SIMDs x 64 lanes) over the batch (the prefix
+  // phase is sequential in the chunk count, so fewer, longer chunks win: measured),
   // keep chunks at least 48 samples long, and a multiple of 64 lanes per problem
-  const long target_lanes = 131072;
+  const long target_lanes = 65536;
   long per = (target_lanes + B - 1) / B;
   per = ((per + 63) / 64) * 64;
   const long max_by_len = std::max<long>(1, N / 48);
@@ -214,6 +215,8 @@ struct clr_batch {
   DevBuf tT, dT, yT;                  // chunk-interleaved copies the kernels read
   long t_stride = 0, diag_stride = 0, y_stride = 0;
   int interleaved = 1;                // 0: kernels read the row-major arrays directly
+  double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
+  int force_library_trig = 0;
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
   DevBuf elems, starts, part, out;  // out: ll | logdet | quad
@@ -431,6 +434,12 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     memset(&P, 0, sizeof(P));
     P.B = 1;
     P.N = N;
+    {
+      double dmax = 0.0;
+      for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
+      const double t0 = fabs(x[0]), t1 = fabs(x[N - 1]);
+      P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+    }
     P.nchunk = auto_chunks(1, N);
     P.L = (N + P.nchunk - 1) / P.nchunk;
     P.nchunk = (N + P.L - 1) / P.L;  // drop empty trailing chunks
@@ -817,6 +826,13 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
     if (sd != 0 && sd != N)
       return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
+  // t is sorted per series, so max |t| is at one of its two ends
+  h->tmax = 0.0;
+  for (long b = 0; b < (t_stride == 0 ? 1 : (long)h->B); ++b) {
+    const double lo = fabs(t[b * t_stride]), hi = fabs(t[b * t_stride + N - 1]);
+    const double m = lo > hi ? lo : hi;
+    if (!(m <= h->tmax)) h->tmax = m;  // NaN sticks
+  }
   if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
@@ -835,6 +851,11 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
+  h->dmax = 0.0;
+  for (size_t i = 0; i < nc; ++i) {
+    const double m = fabs(d_comp[i]);
+    if (!(m <= h->dmax)) h->dmax = m;
+  }
   std::vector<double> pack;
   pack.reserve(2 * nr + 4 * nc);
   pack.insert(pack.end(), a_real, a_real + nr);
@@ -865,6 +886,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   memset(&P, 0, sizeof(P));
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
+  P.fast_trig = (!h->force_library_trig && h->dmax * h->tmax < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
   P.jitter = h->jitter.p;
   P.a_real = h->coeffs.p;
   P.c_real = P.a_real + nr;
@@ -904,6 +926,11 @@ static void batch_relayout(clr_batch* h) {
   for (auto& j : jobs)
     clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
                          h->N, h->L, h->nchunk, h->stream);
+}
+
+int clr_batch_set_library_trig(clr_batch* h, int force) {
+  h->force_library_trig = force ? 1 : 0;
+  return CLR_OK;
 }
 
 int clr_batch_set_layout(clr_batch* h, int interleaved) {

@@ -31,6 +31,7 @@ struct BatchParams {
   const double *t, *diag, *y;
   long t_stride, diag_stride, y_stride;
   long lane_is, lane_cs;
+  int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
   double* part;    // [B][nchunk][2]  (sum log D, sum x^2/D)
@@ -48,7 +49,7 @@ __device__ __forceinline__ void load_problem(const BatchParams& P, int b, Proble
          P.jitter[b]);
 }
 
-template <int JR, int JC>
+template <int JR, int JC, bool FAST>
 __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   const int b = blockIdx.y;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   load_problem<JR, JC>(P, b, p);
   const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
                       P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
-  summarize_chunk<JR, JC>(p, sl, P.elems + ((long)b * P.nchunk + c) * Wd::ELEM);
+  summarize_chunk<JR, JC, FAST>(p, sl, P.elems + ((long)b * P.nchunk + c) * Wd::ELEM);
 }
 
 template <int JR, int JC>
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
   }
 }
 
-template <int JR, int JC, bool MATERIALIZE>
+template <int JR, int JC, bool MATERIALIZE, bool FAST>
 __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   const long Nm1 = P.N - 1;
   const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
                       P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
-  replay_chunk<JR, JC, MATERIALIZE>(
+  replay_chunk<JR, JC, MATERIALIZE, FAST>(
       p, sl, P.N, n0, n1,
       c == 0 ? nullptr : P.starts + ((long)b * P.nchunk + c) * Wd::START, &ld, &qd, &flag,
       MATERIALIZE ? P.phi + (long)b * J * Nm1 : nullptr,
@@ -129,7 +130,10 @@ struct BatchImpl {
   static void summarize(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
     dim3 grid((P.nchunk - 1 + 63) / 64, P.B);
-    hipLaunchKernelGGL((summarize_kernel<JR, JC>), grid, dim3(64), 0, s, P);
+    if (P.fast_trig)
+      hipLaunchKernelGGL((summarize_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    else
+      hipLaunchKernelGGL((summarize_kernel<JR, JC, false>), grid, dim3(64), 0, s, P);
   }
   static void prefix(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
@@ -137,10 +141,17 @@ struct BatchImpl {
   }
   static void replay(const BatchParams& P, bool materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
-    if (materialize)
-      hipLaunchKernelGGL((replay_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
-    else
-      hipLaunchKernelGGL((replay_kernel<JR, JC, false>), grid, dim3(64), 0, s, P);
+    if (materialize) {
+      if (P.fast_trig)
+        hipLaunchKernelGGL((replay_kernel<JR, JC, true, true>), grid, dim3(64), 0, s, P);
+      else
+        hipLaunchKernelGGL((replay_kernel<JR, JC, true, false>), grid, dim3(64), 0, s, P);
+    } else {
+      if (P.fast_trig)
+        hipLaunchKernelGGL((replay_kernel<JR, JC, false, true>), grid, dim3(64), 0, s, P);
+      else
+        hipLaunchKernelGGL((replay_kernel<JR, JC, false, false>), grid, dim3(64), 0, s, P);
+    }
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &replay, Widths<JR, JC>::ELEM,

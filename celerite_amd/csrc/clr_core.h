@@ -111,9 +111,80 @@ struct SeriesLane {
   CLR_HD long off(int i) const { return i < L ? (long)i * is : cs + (long)(i - L) * is; }
 };
 
+// ---------------------------------------------------------------------------
+// sin and cos of the absolute phase d * t.  ocml's fp64 sincos spends 108 fp64
+// instructions per call (double-double reduction and polynomial tails) to be
+// correctly rounded RELATIVE to results near zero; the recurrence only needs
+// ABSOLUTE accuracy ~1 ulp(1) because sin/cos enter U~, V~ linearly
+// (cholesky.h:143-146).  This version: 3-term Cody-Waite reduction with FMA
+// (exact products, so pi/2 is split into full 53-bit pieces), then the fdlibm
+// minimax kernels on [-pi/4, pi/4].  Measured against long-double libm over
+// |x| < 1e9: max abs error 1.8e-16 (tests/test_hostcheck.py).  There is no
+// in-kernel fallback branch (an inlined ocml sincos under a branch costs ~60
+// registers even when never taken): the HOST checks max|d| * max|t| -- O(B),
+// t is sorted -- and launches the <FAST = false> instantiation (ocml sincos)
+// when the product is >= 1e9 or not finite.
+// ---------------------------------------------------------------------------
+CLR_HD void sincos_fast(double x, double* s_out, double* c_out) {
+  const double k = rint(x * 0.63661977236758134308);  // 2/pi
+  double r = fma(-k, 1.57079632679489655800e+00, x);  // pi/2 = P1 + P2 + P3 (each fl())
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  r = fma(-k, -1.49738490485916983043e-33, r);
+  const double z = r * r;
+  // fdlibm __kernel_sin / __kernel_cos coefficients
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sn = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)k & 3;
+  const double s0 = (q & 1) ? cs : sn;
+  const double c0 = (q & 1) ? sn : cs;
+  *s_out = (q & 2) ? -s0 : s0;
+  *c_out = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// FAST is chosen on the host per launch: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT.
+#define CLR_FAST_TRIG_LIMIT 1.0e9
+template <bool FAST>
+CLR_HD void sincos_phase(double x, double* s_out, double* c_out) {
+  if (FAST)
+    sincos_fast(x, s_out, c_out);
+  else
+    sincos(x, s_out, c_out);
+}
+
+// sum of log(D_n) without a log per step: keep the product of the mantissas and
+// the sum of the exponents (ocml's fp64 log is 76 fp64 instructions; this is 3).
+// D = 0 -> product 0 -> log = -inf; D < 0 is flagged by the caller; NaN propagates
+// -- the same non-finite outcomes as log(D_).sum() (cholesky.h:208, celerite.py:212).
+struct LogProduct {
+  double mant;
+  int expo, since;
+  CLR_HD void init() { mant = 1.0; expo = 0; since = 0; }
+  CLR_HD void mul(double d) {
+    int e;
+    mant *= frexp(d, &e);
+    expo += e;
+    if (++since == 32) {  // 2^-32 at worst per renormalisation window: no underflow
+      mant = frexp(mant, &e);
+      expo += e;
+      since = 0;
+    }
+  }
+  CLR_HD double log_value() const { return log(mant) + expo * 0.693147180559945309417232; }
+};
+
 // U~(t), V~(t): cholesky.h:129-147 (real rows: a, 1; complex pair: (a cd + b sd,
 // a sd - b cd), (cd, sd) with the ABSOLUTE time in the phase, :137).
-template <int JR, int JC>
+template <int JR, int JC, bool FAST>
 CLR_HD void features_uv(const Problem<JR, JC>& p, double t, double* u, double* v) {
   CLR_UNROLL
   for (int j = 0; j < JR; ++j) { u[j] = p.ar[j]; v[j] = 1.0; }
@@ -121,7 +192,7 @@ CLR_HD void features_uv(const Problem<JR, JC>& p, double t, double* u, double* v
   for (int j = 0; j < JC; ++j) {
     const int k = JR + 2 * j;
     double sd, cd;
-    sincos(p.dc[j] * t, &sd, &cd);
+    sincos_phase<FAST>(p.dc[j] * t, &sd, &cd);
     u[k] = p.ac[j] * cd + p.bc[j] * sd;
     u[k + 1] = p.ac[j] * sd - p.bc[j] * cd;
     v[k] = cd;
@@ -147,7 +218,7 @@ CLR_HD void features_phi(const Problem<JR, JC>& p, double dx, double* phi) {
 // element that ends at the next chunk's first sample.  elem layout:
 //   A[J*J] row-major | b[J] | C[SZ] | eta[J] | Jm[SZ]
 // ---------------------------------------------------------------------------
-template <int JR, int JC>
+template <int JR, int JC, bool FAST>
 CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, double* elem_out) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
@@ -177,7 +248,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, doub
     }
 
     double u[J], v[J], phi[J];
-    features_uv<JR, JC>(p, tn, u, v);
+    features_uv<JR, JC, FAST>(p, tn, u, v);
     features_phi<JR, JC>(p, t_cur_next - tn, phi);
 
     double q[J], r[J];
@@ -354,7 +425,7 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
 // MATERIALIZE, writes the factor in the reference's storage (cholesky.h:76-78,
 // :703-706): phi[:, n] (move n -> n+1), u[:, n-1] = U~(t_n), W[:, n], D[n].
 // ---------------------------------------------------------------------------
-template <int JR, int JC, bool MATERIALIZE>
+template <int JR, int JC, bool MATERIALIZE, bool FAST>
 CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, int n0, int n1,
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
@@ -374,7 +445,9 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
     for (int i = 0; i < J; ++i) f[i] = 0.0;
   }
 
-  double logdet = 0.0, quad = 0.0;
+  double quad = 0.0;
+  LogProduct lp;
+  lp.init();
   int flag = 0;
   double tn = sl.t[sl.off(0)];
   double t_next = (n0 + 1 < N) ? sl.t[sl.off(1)] : tn;
@@ -389,7 +462,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
     }
 
     double u[J], v[J];
-    features_uv<JR, JC>(p, tn, u, v);
+    features_uv<JR, JC, FAST>(p, tn, u, v);
 
     double q[J];
     CLR_UNROLL
@@ -406,7 +479,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
     if (n >= 1 && D < 0.0 && !flag) flag = 1;
     const double invD = 1.0 / D;
     const double x = y_cur - uf;
-    logdet += log(D);
+    lp.mul(D);
     quad += x * x * invD;
 
     double z[J], W[J];
@@ -441,7 +514,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
     }
     tn = t_cur_next;
   }
-  *logdet_out = logdet;
+  *logdet_out = lp.log_value();
   *quad_out = quad;
   *flag_out = flag;
 }

@@ -176,6 +176,11 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
  * chunking changed.  set_layout(h, 0) makes them read the row-major arrays
  * directly (slower; kept for A/B measurements). */
 int clr_batch_set_layout(clr_batch* h, int interleaved);
+/* The kernels evaluate sin/cos(d_comp * t) with a 25-instruction FMA Cody-Waite
+ * routine (abs. error < 1 ulp(1)) when the host-side check max|d_comp| * max|t| <
+ * 1e9 holds, and with the library (ocml) sincos otherwise.  force != 0 selects the
+ * library routine unconditionally (for A/B measurements). */
+int clr_batch_set_library_trig(clr_batch* h, int force);
 /* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);

@@ -13,7 +13,7 @@
 
 using namespace clr;
 
-template <int JR, int JC>
+template <int JR, int JC, bool FAST>
 static int run(int B, int N, int nchunk, const double* jitter, const double* a_real,
                const double* c_real, const double* a_comp, const double* b_comp,
                const double* c_comp, const double* d_comp, const double* t, long ts,
@@ -47,7 +47,7 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
     auto lane = [&](int c) { return SeriesLane{tb + c * cs, db + c * cs, yb + c * cs, is, cs, L}; };
     for (int c = 0; c + 1 < nchunk; ++c) {
       if ((c + 1) * L >= N) continue;  // element would run past the data; never applied
-      summarize_chunk<JR, JC>(p, lane(c), &elems[(size_t)c * Wd::ELEM]);
+      summarize_chunk<JR, JC, FAST>(p, lane(c), &elems[(size_t)c * Wd::ELEM]);
     }
     double S[Wd::SZ] = {0}, f[J] = {0};
     for (int c = 0; c + 1 < nchunk; ++c) {
@@ -66,12 +66,12 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       int fl;
       const long Nm1 = N - 1;
       if (materialize)
-        replay_chunk<JR, JC, true>(p, lane(c), N, n0, n1,
+        replay_chunk<JR, JC, true, FAST>(p, lane(c), N, n0, n1,
                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                    phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
                                    W + (long)b * J * N, D + (long)b * N);
       else
-        replay_chunk<JR, JC, false>(p, lane(c), N, n0, n1,
+        replay_chunk<JR, JC, false, FAST>(p, lane(c), N, n0, n1,
                                     c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                     nullptr, nullptr, nullptr, nullptr);
       ld += l;
@@ -87,8 +87,12 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
 }
 
 #define CASE(R, C)                                                                          \
+  if (JR == R && JC == C && fast)                                                           \
+    return run<R, C, true>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp,    \
+                           d_comp, t, ts, diag, ds, y, ys, materialize, interleaved, ll,    \
+                           logdet, quad, status, phi, u, W, D);                             \
   if (JR == R && JC == C)                                                                   \
-    return run<R, C>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,  \
+    return run<R, C, false>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,  \
                      t, ts, diag, ds, y, ys, materialize, interleaved, ll, logdet, quad,    \
                      status, phi, u, W, D);
 
@@ -97,10 +101,21 @@ extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const d
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp, const double* t,
                                long ts, const double* diag, long ds, const double* y, long ys,
-                               int materialize, int interleaved, double* ll, double* logdet,
-                               double* quad,
+                               int materialize, int interleaved, int fast, double* ll,
+                               double* logdet, double* quad,
                                int* status, double* phi, double* u, double* W, double* D) {
   CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(0, 2) CASE(2, 2)
   CASE(2, 3) CASE(0, 4) CASE(4, 2) CASE(8, 0)
   return -1;
+}
+
+// Accuracy probes for the two device math helpers (host instantiation).
+extern "C" void hostcheck_sincos(int n, const double* x, double* s, double* c) {
+  for (int i = 0; i < n; ++i) sincos_fast(x[i], s + i, c + i);
+}
+extern "C" double hostcheck_logprod(int n, const double* d) {
+  LogProduct lp;
+  lp.init();
+  for (int i = 0; i < n; ++i) lp.mul(d[i]);
+  return lp.log_value();
 }

@@ -25,11 +25,11 @@ def lib():
     core = os.path.join(os.path.dirname(HERE), "..", "celerite_amd", "csrc", "clr_core.h")
     if (not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(core))):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", "-ffp-contract=off",
-                               "-o", SO, src])
+                               "-mfma", "-o", SO, src])
     return C.CDLL(SO)
 
 
-def run(lib, JR, JC, nchunk, case, interleaved, materialize=False):
+def run(lib, JR, JC, nchunk, case, interleaved, materialize=False, fast=True):
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
     B, N = case["t"].shape
@@ -44,7 +44,7 @@ def run(lib, JR, JC, nchunk, case, interleaved, materialize=False):
     rc = lib.hostcheck_batch(B, N, JR, JC, nchunk, P(jit), *[k.ctypes.data_as(dp) for k in keep[:6]],
                              keep[6].ctypes.data_as(dp), C.c_long(N), keep[7].ctypes.data_as(dp),
                              C.c_long(N), keep[8].ctypes.data_as(dp), C.c_long(N), int(materialize),
-                             int(interleaved), P(ll), P(ld), P(q), st.ctypes.data_as(ip),
+                             int(interleaved), int(fast), P(ll), P(ld), P(q), st.ctypes.data_as(ip),
                              P(phi), P(u), P(W), P(D))
     assert rc == 0
     return ll, ld, q, st, (phi, u, W, D)
@@ -56,8 +56,8 @@ def test_scan_matches_oracle(lib, JR, JC, family):
     for N, nchunk in [(1, 1), (2, 1), (7, 3), (100, 1), (1000, 7), (1000, 64), (3000, 100)]:
         case = synthetic(3, N, JR, JC, family, seed=N + 10 * JR + JC)
         l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
-        for inter in (0, 1):
-            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter)
+        for inter, fast in ((0, True), (1, True), (1, False)):
+            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter, fast=fast)
             assert np.array_equal(st, s0)
             assert np.max(np.abs(ld - d0) / np.abs(d0)) < 1e-11
             assert np.max(np.abs(q - q0) / np.abs(q0)) < 1e-11
@@ -90,3 +90,32 @@ def test_not_positive_definite_is_flagged_not_propagated(lib):
         assert ll[1] == -np.inf
         for p in (0, 2):
             assert abs(ld[p] - d0[p]) < 1e-11 * abs(d0[p]) and abs(q[p] - q0[p]) < 1e-11 * abs(q0[p])
+
+
+def test_phase_sincos_and_log_product(lib):
+    """The two device math helpers of clr_core.h, host-instantiated: the FMA
+    Cody-Waite sincos (absolute error < 1 ulp(1) = 2.2e-16 for |x| < 1e9, the
+    host-checked validity range) and the mantissa-product form of sum(log D)."""
+    dp = C.POINTER(C.c_double)
+    rng = np.random.RandomState(0)
+    k = np.arange(-200000, 200000, 7, dtype=np.float64) * (np.pi / 2)
+    x = np.concatenate([rng.uniform(-10, 10, 200000), rng.uniform(-1e3, 1e3, 200000),
+                        rng.uniform(-1e6, 1e6, 200000), rng.uniform(-1e9, 1e9, 200000),
+                        k, np.nextafter(k, 1e300), np.nextafter(k, -1e300),
+                        [0.0, -0.0, 1e-300, 999999999.5]])
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib.hostcheck_sincos(len(x), x.ctypes.data_as(dp), s.ctypes.data_as(dp), c.ctypes.data_as(dp))
+    xl = x.astype(np.longdouble)
+    err = max(np.max(np.abs(s - np.sin(xl))), np.max(np.abs(c - np.cos(xl))))
+    assert float(err) < 2.3e-16
+
+    lib.hostcheck_logprod.restype = C.c_double
+    d = np.exp(rng.uniform(-5, 5, 100000))
+    got = lib.hostcheck_logprod(len(d), d.ctypes.data_as(dp))
+    want = float(np.sum(np.log(d.astype(np.longdouble))))
+    assert abs(got - want) < 1e-15 * abs(want)
+    for scale in (1e-300, 1e300):  # exponent range: no under/overflow of the running product
+        d = np.full(5000, scale)
+        assert abs(lib.hostcheck_logprod(5000, d.ctypes.data_as(dp)) - 5000 * np.log(scale)) < 1e-9
+    z = np.array([2.0, 0.0, 3.0])
+    assert lib.hostcheck_logprod(3, z.ctypes.data_as(dp)) == -np.inf  # D = 0: cholesky.h:208 gives -inf too
