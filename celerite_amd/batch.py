@@ -53,6 +53,7 @@ def _load():
     lib.clr_batch_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp]
     lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_device_info.argtypes = [C.c_char_p, C.c_size_t, _ip, C.POINTER(C.c_size_t)]
     lib.clr_set_device.argtypes = [C.c_int]
     _lib = lib
@@ -206,6 +207,10 @@ class BatchedGP(object):
         """Kernels read a chunk-interleaved copy of the series (default) or the
         row-major arrays directly (slower; for A/B measurements)."""
         _check(_load().clr_batch_set_layout(self._h, int(bool(interleaved))))
+
+    def set_prefix_mode(self, cooperative=True):
+        """Prefix phase with 16 lanes per problem (default) or one (cross-check)."""
+        _check(_load().clr_batch_set_prefix_mode(self._h, int(bool(cooperative))))
 
     def set_library_trig(self, force=True):
         """Use the library (ocml) sincos instead of the FMA Cody-Waite routine

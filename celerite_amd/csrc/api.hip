@@ -217,6 +217,7 @@ struct clr_batch {
   int interleaved = 1;                // 0: kernels read the row-major arrays directly
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
   int force_library_trig = 0;
+  int coop_prefix = 1;
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
   DevBuf elems, starts, part, out;  // out: ll | logdet | quad
@@ -440,6 +441,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       const double t0 = fabs(x[0]), t1 = fabs(x[N - 1]);
       P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
     }
+    P.coop_prefix = 1;
     P.nchunk = auto_chunks(1, N);
     P.L = (N + P.nchunk - 1) / P.nchunk;
     P.nchunk = (N + P.L - 1) / P.L;  // drop empty trailing chunks
@@ -887,6 +889,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
   P.fast_trig = (!h->force_library_trig && h->dmax * h->tmax < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+  P.coop_prefix = h->coop_prefix;
   P.jitter = h->jitter.p;
   P.a_real = h->coeffs.p;
   P.c_real = P.a_real + nr;
@@ -926,6 +929,11 @@ static void batch_relayout(clr_batch* h) {
   for (auto& j : jobs)
     clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
                          h->N, h->L, h->nchunk, h->stream);
+}
+
+int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
+  h->coop_prefix = cooperative ? 1 : 0;
+  return CLR_OK;
 }
 
 int clr_batch_set_library_trig(clr_batch* h, int force) {

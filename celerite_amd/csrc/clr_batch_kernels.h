@@ -32,6 +32,7 @@ struct BatchParams {
   long t_stride, diag_stride, y_stride;
   long lane_is, lane_cs;
   int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
+  int coop_prefix;  // 16 lanes per problem in the prefix phase (0: one lane, the reference version)
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
   double* part;    // [B][nchunk][2]  (sum log D, sum x^2/D)
@@ -80,6 +81,157 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
     for (int i = 0; i < Wd::SZ; ++i) o[i] = S[i];
 #pragma unroll
     for (int i = 0; i < J; ++i) o[Wd::SZ + i] = f[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cooperative prefix: 16 lanes per problem (4 problems per wave) instead of one.
+// Same algebra as apply_element (clr_core.h), distributed column-per-lane:
+//   lanes 0..7  of a group hold the columns of  M^T = I + P Jm
+//   lanes 8..15 hold the columns of P; Gauss-Jordan on [M^T | P] turns them into
+//               the columns of  G = M^-T P  (pivot row and multipliers are
+//               broadcast from the pivot column's lane with wave shuffles).
+//   g = M^-T h  is obtained without a 17th column from  M^-T = I - G Jm.
+// Then, still one column per lane:  X = G A^T (rows, using G = G^T), an 8x8
+// transpose through LDS, P' = C + A X, f' = A g + b.  The running P is kept in
+// LDS (pbuf) so the matrix lanes can form M^T.  ~750 instructions per lane per
+// chunk instead of ~5500, and 16x more lanes in flight: the single-lane version
+// ran on 16 of the chip's 1024 SIMDs (profiles/r01b_pmc_counters.txt).
+// ---------------------------------------------------------------------------
+template <int J>
+__global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
+  constexpr int SZ = J * (J + 1) / 2;
+  constexpr int ELEM = J * J + J + SZ + J + SZ;
+  constexpr int START = SZ + J;
+  __shared__ double pbuf[4][8][8];  // pbuf[g][j][i] = P[i][j] (column j contiguous)
+  __shared__ double xbuf[4][8][9];  // transpose buffer, padded
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int base = lane & 48;
+  const bool rhs = (l >> 3) != 0;
+  const int col = l & 7;
+  const bool cv = col < J;
+  const int cc = cv ? col : J - 1;
+  const int prob = blockIdx.x * 4 + g;
+  const bool active = prob < P_.B;
+  const long pb = active ? prob : P_.B - 1;
+  const bool writer = rhs && cv && active;
+
+  double Pc[J];  // column `col` of the running P (rhs lanes)
+  double fj = 0.0;
+#pragma unroll
+  for (int i = 0; i < J; ++i) Pc[i] = 0.0;
+  if (rhs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pbuf[g][col][i] = 0.0;
+  }
+  __syncthreads();
+
+  for (int c = 0; c + 1 < P_.nchunk; ++c) {
+    const double* E = P_.elems + (pb * P_.nchunk + c) * ELEM;
+    const double* A = E;
+    const double* bv = E + J * J;
+    const double* C = bv + J;
+    const double* eta = C + SZ;
+    const double* Jm = eta + J;
+
+    double jc[J], et[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      jc[i] = cv ? Jm[sym(i, cc)] : 0.0;
+      et[i] = eta[i];
+    }
+    // column of [M^T | P]
+    double T[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double acc = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc += pbuf[g][j][i] * jc[j];
+      T[i] = rhs ? Pc[i] : acc;
+    }
+    // h = f + P eta (component `col` in rhs lane `col`), v = Jm h
+    double hj = fj;
+#pragma unroll
+    for (int i = 0; i < J; ++i) hj += Pc[i] * et[i];
+    double vj = 0.0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) vj += jc[i] * __shfl(hj, base + 8 + i, 64);
+
+    // Gauss-Jordan with partial pivoting on the 2J columns of the group
+#pragma unroll
+    for (int c0 = 0; c0 < J; ++c0) {
+      int piv = c0;
+      double best = fabs(T[c0]);
+#pragma unroll
+      for (int i = c0 + 1; i < J; ++i) {
+        const double cand = fabs(T[i]);
+        const bool take = cand > best;
+        best = take ? cand : best;
+        piv = take ? i : piv;
+      }
+      piv = __shfl(piv, base + c0, 64);  // the decision of the pivot column's lane
+      double top = T[c0];
+      const double old_top = top;
+#pragma unroll
+      for (int i = c0 + 1; i < J; ++i) {
+        const bool hit = (i == piv);
+        top = hit ? T[i] : top;
+        T[i] = hit ? old_top : T[i];
+      }
+      T[c0] = top;
+      double m[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i) m[i] = __shfl(T[i], base + c0, 64);
+      const double t = T[c0] * (1.0 / m[c0]);
+#pragma unroll
+      for (int i = 0; i < J; ++i) T[i] = (i == c0) ? t : (T[i] - m[i] * t);
+    }
+    // rhs lanes: T = G[:, col] = G[col, :]
+    double gj = hj;  // g = h - G v
+#pragma unroll
+    for (int i = 0; i < J; ++i) gj -= T[i] * __shfl(vj, base + 8 + i, 64);
+    double fn = cv ? bv[cc] : 0.0;  // f' = A g + b
+#pragma unroll
+    for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * __shfl(gj, base + 8 + i, 64);
+
+    // X = G A^T: lane `col` computes row `col`; transpose through LDS to columns
+    double Xr[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < J; ++i) acc += T[i] * A[j * J + i];
+      Xr[j] = acc;
+    }
+    if (rhs) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) xbuf[g][col][j] = Xr[j];
+    }
+    __syncthreads();
+    double Pn[J];  // P'[:, col] = C[:, col] + A X[:, col]
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+      double acc = cv ? C[sym(k, cc)] : 0.0;
+#pragma unroll
+      for (int a = 0; a < J; ++a) acc += A[k * J + a] * xbuf[g][a][col];
+      Pn[k] = acc;
+    }
+    if (rhs) {
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        Pc[i] = cv ? Pn[i] : 0.0;
+        pbuf[g][col][i] = Pc[i];
+      }
+      fj = fn;
+    }
+    if (writer) {
+      double* o = P_.starts + (pb * P_.nchunk + c + 1) * START;
+#pragma unroll
+      for (int k = 0; k < J; ++k)
+        if (k <= col) o[tri(k, cc)] = Pn[k];
+      o[SZ + cc] = fn;
+    }
+    __syncthreads();
   }
 }
 
@@ -137,7 +289,10 @@ struct BatchImpl {
   }
   static void prefix(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
-    hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+    if (P.coop_prefix)
+      hipLaunchKernelGGL((prefix_coop_kernel<JR + 2 * JC>), dim3((P.B + 3) / 4), dim3(64), 0, s, P);
+    else
+      hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
   }
   static void replay(const BatchParams& P, bool materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);

@@ -222,11 +222,17 @@ template <int JR, int JC, bool FAST>
 CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, double* elem_out) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
-  double A[J * J], b[J], C[SZ], eta[J], Jm[SZ];
+  // State: 152 doubles at J = 8, more than the 128 that 256 VGPRs hold; the compiler
+  // parks the excess (in practice A) in AGPRs and pays one VALU slot per 32-bit
+  // move.  Keeping part of it in LDS instead was measured SLOWER (exposed LDS
+  // latency at one wave per SIMD): profiles/r01c_lds_state_ab.log.
+  // A is held COLUMN-major (Acol[j * J + i] = A[i][j]): column j only ever needs
+  // r_j = u . A[:, j], so each column is read, used and rewritten in one visit.
+  double Acol[J * J], b[J], C[SZ], eta[J], Jm[SZ];
   CLR_UNROLL
   for (int i = 0; i < J; ++i) {
     CLR_UNROLL
-    for (int j = 0; j < J; ++j) A[i * J + j] = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < J; ++j) Acol[j * J + i] = (i == j) ? 1.0 : 0.0;
     b[i] = 0.0;
     eta[i] = 0.0;
   }
@@ -251,17 +257,13 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, doub
     features_uv<JR, JC, FAST>(p, tn, u, v);
     features_phi<JR, JC>(p, t_cur_next - tn, phi);
 
-    double q[J], r[J];
+    double q[J];
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
-      double acc = 0.0, racc = 0.0;
+      double acc = 0.0;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) {
-        acc += C[sym(k, j)] * u[k];
-        racc += A[k * J + j] * u[k];
-      }
+      for (int k = 0; k < J; ++k) acc += C[sym(k, j)] * u[k];
       q[j] = acc;
-      r[j] = racc;
     }
     double s = 0.0, ub = 0.0;
     CLR_UNROLL
@@ -271,35 +273,44 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, doub
     const double x = y_cur - ub;
     const double xs = x * invD;
 
-    double z[J], W[J], rs[J];
+    double z[J], W[J], pw[J];
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
       z[j] = v[j] - q[j];
       W[j] = z[j] * invD;
-      rs[j] = r[j] * invD;
-      eta[j] -= r[j] * xs;
+      pw[j] = phi[j] * W[j];
+    }
+    // one visit per column of A: r_j = u . A[:, j] ; A[:, j] <- Phi (A[:, j] - W r_j)
+    double r[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double racc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
+      r[j] = racc;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) Acol[j * J + k] = phi[k] * Acol[j * J + k] - pw[k] * racc;
     }
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
+      const double rsj = r[j] * invD;
+      eta[j] -= r[j] * xs;
       CLR_UNROLL
       for (int k = 0; k <= j; ++k) {
-        Jm[tri(k, j)] -= r[k] * rs[j];
+        Jm[tri(k, j)] -= r[k] * rsj;
         C[tri(k, j)] = phi[j] * (phi[k] * (C[tri(k, j)] + z[k] * W[j]));
       }
       b[j] = phi[j] * (b[j] + W[j] * x);
     }
-    CLR_UNROLL
-    for (int i = 0; i < J; ++i) {
-      const double pw = phi[i] * W[i];
-      CLR_UNROLL
-      for (int j = 0; j < J; ++j) A[i * J + j] = phi[i] * A[i * J + j] - pw * r[j];
-    }
     tn = t_cur_next;
   }
 
-  double* o = elem_out;
+  double* o = elem_out;  // A is written row-major
   CLR_UNROLL
-  for (int i = 0; i < J * J; ++i) o[i] = A[i];
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) o[i * J + j] = Acol[j * J + i];
+  }
   o += J * J;
   CLR_UNROLL
   for (int i = 0; i < J; ++i) o[i] = b[i];

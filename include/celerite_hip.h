@@ -181,6 +181,9 @@ int clr_batch_set_layout(clr_batch* h, int interleaved);
  * 1e9 holds, and with the library (ocml) sincos otherwise.  force != 0 selects the
  * library routine unconditionally (for A/B measurements). */
 int clr_batch_set_library_trig(clr_batch* h, int force);
+/* Prefix phase: 16 lanes per problem (default) or the single-lane version (kept as
+ * the on-device cross-check and for A/B measurements). */
+int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
 /* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);

@@ -118,6 +118,47 @@ def test_results_independent_of_chunking_and_layout():
         assert np.max(np.abs(o[2] - outs[0][2]) / np.abs(outs[0][2])) < 1e-11
 
 
+@pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
+def test_prefix_modes_agree(JR, JC):
+    """The 16-lanes-per-problem prefix kernel against the single-lane one (the
+    same algebra as the host-checked apply_element) and against the oracle."""
+    case = synthetic(7, 6000, JR, JC, "accuracy" if (JR + JC) % 2 else "bench", seed=JR + 9 * JC)
+    plan = batch.BatchedGP(7, 6000, JR, JC)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    outs = {}
+    for coop in (True, False):
+        plan.set_prefix_mode(coop)
+        for nchunk in (5, 64, 125):
+            plan.set_chunks(nchunk)
+            outs[(coop, nchunk)] = plan.log_likelihood()
+    plan.close()
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    for key, (ll, ld, q, st) in outs.items():
+        assert np.array_equal(st, s0), key
+        assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, key
+        assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, key
+
+
+def test_prefix_modes_with_failures_and_ragged_batch():
+    case = synthetic(9, 3000, 1, 1, "bench", seed=15)  # 9 problems: last wave of the coop kernel is ragged
+    case["a_real"][2, 0] = -4.0
+    case["diag"][2] = 0.0
+    for coop in (True, False):
+        plan = batch.BatchedGP(9, 3000, 1, 1)
+        plan.set_prefix_mode(coop)
+        plan.set_chunks(32)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        ll, ld, q, st = plan.log_likelihood()
+        plan.close()
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        assert np.array_equal(st, s0) and st[2] == 2
+        ok = s0 == 0
+        assert np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
+        assert np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])) <= REL
+
+
 def test_bench_size_sample_and_properties():
     """BASELINE config 3 shape (N = 1e5, width 8 = 2 real + 3 complex) on a 32-problem
     batch: oracle parity on a sample of 4, plus size-independent properties on all:

@@ -71,22 +71,22 @@ plan = batch.BatchedGP(B, N, JR, JC)
 plan.set_series(a[6], a[7], a[8])
 plan.set_coefficients(*a[:6])
 res = {}
-for lib_trig in (0, 1):
-    plan.set_library_trig(bool(lib_trig))
-    for nch in ((32, 64, 96, 128, 192, 256) if not lib_trig else (64,)):
+for coop in (0, 1):
+    plan.set_prefix_mode(bool(coop))
+    for nch in (64, 128, 256):
         plan.set_chunks(nch)
         plan.log_likelihood()  # warm
         tot, k = plan.run_timed(3, relayout_each_step=True)
-        res["%d_%d" % (lib_trig, nch)] = dict(ms=tot / 3, kernels={a: b / 3 for a, b in k.items()}, chunks=plan.chunks)
-        print("library_trig=%d nchunk %4d L %5d: %.3f ms/step  (%s) -> %.0f loglik/s" % (
-            lib_trig, plan.chunks[0], plan.chunks[1], tot / 3,
+        res["coop%d_%d" % (coop, nch)] = dict(ms=tot / 3, kernels={a: b / 3 for a, b in k.items()}, chunks=plan.chunks)
+        print("coop_prefix=%d nchunk %4d L %5d: %.3f ms/step  (%s) -> %.0f loglik/s" % (
+            coop, plan.chunks[0], plan.chunks[1], tot / 3,
             " ".join("%s %.3f" % (a, b / 3) for a, b in k.items()), B / (tot / 3) * 1e3), flush=True)
+        ll, ld, q, st = plan.log_likelihood()
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[x[:4] for x in a[:6]], a[6][:4], a[7][:4], a[8][:4])
+        print("   parity (4 problems): logdet rel %.2e quad rel %.2e" % (
+            np.max(np.abs(ld[:4] - d0) / np.abs(d0)), np.max(np.abs(q[:4] - q0) / np.abs(q0))), flush=True)
 out["sweep"] = res
-plan.set_library_trig(False)
 plan.set_chunks(64)
-tot, k = plan.run_timed(2, materialize=True)
-print("materialize nchunk 64: %.3f ms/step kernels %s" % (tot / 2, {a: b / 2 for a, b in k.items()}), flush=True)
-out["materialize_64"] = dict(ms=tot / 2, kernels={a: b / 2 for a, b in k.items()})
 ll, ld, q, st = plan.log_likelihood()
 l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[x[:8] for x in a[:6]], a[6][:8], a[7][:8], a[8][:8])
 print("N=1e5 parity (8 problems): logdet rel %.2e quad rel %.2e" % (
