@@ -203,10 +203,14 @@ class BatchedGP(object):
 
     KERNEL_NAMES = ("relayout", "summarize", "prefix", "replay", "finalize")
 
-    def set_layout(self, interleaved=True):
-        """Kernels read a chunk-interleaved copy of the series (default) or the
-        row-major arrays directly (slower; for A/B measurements)."""
-        _check(_load().clr_batch_set_layout(self._h, int(bool(interleaved))))
+    LAYOUTS = {"rowmajor": 0, "interleaved": 1, "staged": 2}
+
+    def set_layout(self, layout="staged"):
+        """How the kernels read the series: ``"staged"`` (default: coalesced tiles
+        transposed through LDS, no extra pass), ``"interleaved"`` (a cached
+        chunk-interleaved copy built by a transpose kernel when the series change)
+        or ``"rowmajor"`` (direct, slow; for A/B measurements)."""
+        _check(_load().clr_batch_set_layout(self._h, self.LAYOUTS.get(layout, layout)))
 
     def set_prefix_mode(self, cooperative=True):
         """Prefix phase with 16 lanes per problem (default) or one (cross-check)."""

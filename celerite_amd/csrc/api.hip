@@ -199,7 +199,6 @@ struct clr_solver {
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
-  DevBuf ws_t, ws_d;                    // chunk-interleaved t / diag for the scan
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
@@ -214,7 +213,7 @@ struct clr_batch {
   DevBuf jitter, coeffs, t, diag, y;  // series in the API's row-major layout
   DevBuf tT, dT, yT;                  // chunk-interleaved copies the kernels read
   long t_stride = 0, diag_stride = 0, y_stride = 0;
-  int interleaved = 1;                // 0: kernels read the row-major arrays directly
+  int layout = 2;                     // 0 row-major direct, 1 interleaved copy, 2 staged through LDS
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
   int force_library_trig = 0;
   int coop_prefix = 1;
@@ -363,7 +362,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part, &s->ws_t, &s->ws_d})
+                      &s->ws_part})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -453,18 +452,10 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.jitter = s->scratch2.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
-    if (P.nchunk > 1) {  // chunk-interleaved copies so that wave loads coalesce
-      const size_t cells = (size_t)P.nchunk * P.L;
-      if ((st = s->ws_t.reserve(cells)) != CLR_OK) return st;
-      if ((st = s->ws_d.reserve(cells)) != CLR_OK) return st;
-      clr::launch_relayout(s->t.p, 0, s->ws_t.p, 0, 1, N, P.L, P.nchunk, stream);
-      clr::launch_relayout(s->scratch.p, 0, s->ws_d.p, 0, 1, N, P.L, P.nchunk, stream);
-      P.t = s->ws_t.p; P.diag = s->ws_d.p; P.y = s->ws_t.p;  // y is irrelevant for compute
-      P.lane_is = P.nchunk; P.lane_cs = 1;
-    } else {
-      P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;
-      P.lane_is = 1; P.lane_cs = P.L;
-    }
+    // row-major arrays; with more than one chunk the kernels stage them through LDS
+    P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;  // y is irrelevant for compute
+    P.lane_is = 1; P.lane_cs = P.L;
+    P.staged = P.nchunk > 1 ? 1 : 0;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
     P.flags = s->ws_flags;
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
@@ -799,6 +790,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (nchunk <= 0) nchunk = auto_chunks(h->B, h->N);
   if (nchunk > h->N) nchunk = h->N;
   h->L = (h->N + nchunk - 1) / nchunk;
+  if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->relayout_pending = true;
   const size_t pc = (size_t)h->B * h->nchunk;
@@ -897,7 +889,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.b_comp = P.a_comp + nc;
   P.c_comp = P.b_comp + nc;
   P.d_comp = P.c_comp + nc;
-  if (h->interleaved && h->nchunk > 1) {
+  if (h->layout == 1 && h->nchunk > 1) {
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
     if ((st = h->tT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
@@ -908,10 +900,12 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.diag_stride = h->diag_stride ? cells : 0;
     P.y_stride = h->y_stride ? cells : 0;
     P.lane_is = h->nchunk; P.lane_cs = 1;
+    P.staged = 0;
   } else {
     P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
     P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
     P.lane_is = 1; P.lane_cs = h->L;
+    P.staged = (h->layout == 2 && h->nchunk > 1) ? 1 : 0;
   }
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
@@ -922,7 +916,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
 
 // Row-major API layout -> chunk-interleaved layout (3 tiled transposes).
 static void batch_relayout(clr_batch* h) {
-  if (!(h->interleaved && h->nchunk > 1)) return;
+  if (!(h->layout == 1 && h->nchunk > 1)) return;
   const long cells = (long)h->nchunk * h->L;
   struct { DevBuf* src; DevBuf* dst; long stride; } jobs[3] = {
       {&h->t, &h->tT, h->t_stride}, {&h->diag, &h->dT, h->diag_stride}, {&h->y, &h->yT, h->y_stride}};
@@ -941,8 +935,9 @@ int clr_batch_set_library_trig(clr_batch* h, int force) {
   return CLR_OK;
 }
 
-int clr_batch_set_layout(clr_batch* h, int interleaved) {
-  h->interleaved = interleaved ? 1 : 0;
+int clr_batch_set_layout(clr_batch* h, int layout) {
+  if (layout < 0 || layout > 2) return fail(CLR_INVALID_ARGUMENT, "layout must be 0, 1 or 2");
+  h->layout = layout;
   h->relayout_pending = true;
   return CLR_OK;
 }

@@ -8,12 +8,12 @@
 //       scalar loads) and only the recurrence state lives in VGPRs.
 //   prefix / finalize  : one lane per problem (sequential over that problem's
 //       chunks; the work is O(nchunk J^3), a few percent of the total).
-// HBM traffic: 24 B per sample per pass (t, diag, y).  The series are read in the
-// chunk-interleaved layout [problem][i][chunk] (relayout_kernel in api.hip), so
-// the 64 lanes of a wave -- 64 consecutive chunks at the same local step i -- load
-// 512 contiguous bytes per array per step: every cache line is touched once.
-// (With the row-major API layout each lane streams its own 8 B/step run and the
-// 64-B lines must survive 8 steps in L1/L2: measured 2x slower at 2 waves/SIMD.)
+// HBM traffic: 24 B per sample per pass (t, diag, y).  A lane streaming its own
+// 8 B/step run of the row-major arrays needs every 64-B line to survive 8 steps
+// in L1/L2 (measured: replay 2x slower at 2 waves/SIMD), so the series are read
+// either through StagedSeries (default: cooperative coalesced tiles transposed in
+// LDS, no extra pass) or from a chunk-interleaved copy [problem][i][chunk] made by
+// relayout_kernel (api.hip; one coalesced 512-B wave load per array per step).
 // The workspace (elements, start states, partial sums) is O(nchunk) per problem.
 #pragma once
 
@@ -26,11 +26,13 @@ namespace clr {
 struct BatchParams {
   int B, N, nchunk, L;
   const double *jitter, *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;
-  // series as the kernels read them (see SeriesLane): element (chunk c, local i) of
-  // problem b is at  base[b * stride + c * lane_cs + i * lane_is]
+  // series as the kernels read them.  staged == 0 (DirectSeries): element (chunk c,
+  // local i) of problem b is at base[b * stride + c * lane_cs + i * lane_is].
+  // staged == 1 (StagedSeries): the row-major API arrays, base[b * stride + n].
   const double *t, *diag, *y;
   long t_stride, diag_stride, y_stride;
   long lane_is, lane_cs;
+  int staged;
   int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
   int coop_prefix;  // 16 lanes per problem in the prefix phase (0: one lane, the reference version)
   double* elems;   // [B][nchunk][ELEM]
@@ -50,17 +52,113 @@ __device__ __forceinline__ void load_problem(const BatchParams& P, int b, Proble
          P.jitter[b]);
 }
 
-template <int JR, int JC, bool FAST>
+// ---------------------------------------------------------------------------
+// StagedSeries: the wave's 64 lanes (64 consecutive chunks of one problem) read
+// the ROW-MAJOR series cooperatively in tiles of 8 steps x 64 chunks -- each load
+// instruction covers 8 chunk rows x 64 contiguous bytes -- and transpose them
+// through LDS (row stride 9 doubles: conflict-free ds_read_b64 by row).  The
+// group g = (i+1) & 7 of the NEXT tile is requested at the beginning of step i and
+// written to the other LDS buffer at the beginning of step i+1, so the HBM latency
+// hides behind a whole step of arithmetic, and the per-lane reads for step i+1 are
+// issued during step i.  t is staged shifted by one sample (the lane needs t_{n+1} and t_{n+2}).
+// This replaces a separate relayout pass (0.87 ms for 3 x 0.82 GB at 5.7 TB/s).
+// ---------------------------------------------------------------------------
+struct StagedSeries {
+  double* lds;  // [2 buffers][3 arrays][64 rows][9]
+  const double *g0, *g1, *g2;  // problem bases: t + 1, diag, y
+  long lim0, lim1, lim2;       // valid elements from each base
+  int L, row0, nchunk, lane;
+  double tfirst;
+  double p0, p1, p2;  // loads in flight
+  __device__ __forceinline__ void issue(int tile, int group) {
+    const int r = group * 8 + (lane >> 3), col = tile * 8 + (lane & 7);
+    const long n = (long)(row0 + r) * L + col;
+    const bool ok = (row0 + r < nchunk) && (col < L);
+    p0 = (ok && n < lim0) ? g0[n] : 0.0;
+    p1 = (ok && n < lim1) ? g1[n] : 0.0;
+    p2 = (ok && n < lim2) ? g2[n] : 0.0;
+  }
+  __device__ __forceinline__ void commit(int tile, int group) {
+    double* d = lds + (tile & 1) * 1728 + (group * 8 + (lane >> 3)) * 9 + (lane & 7);
+    d[0] = p0;
+    d[576] = p1;
+    d[1152] = p2;
+  }
+  __device__ __forceinline__ void prologue() {
+#pragma unroll
+    for (int gidx = 0; gidx < 8; ++gidx) {
+      issue(0, gidx);
+      commit(0, gidx);
+    }
+    issue(1, 0);
+    commit(1, 0);
+    __syncthreads();
+  }
+  // Two-stage pipeline across the loop back-edge: the loads requested at the top of
+  // step i-1 are written to LDS at the top of step i (a whole step of latency
+  // hiding by construction -- if the write sits in the same step as the loads the
+  // compiler schedules it right behind them and every step stalls on HBM: +12 %
+  // measured), then the next group is requested.
+  __device__ __forceinline__ void step_begin(int i) {
+    if (i > 0) {
+      commit((i >> 3) + 1, i & 7);
+      if ((i & 7) == 7) __syncthreads();
+    }
+    issue(((i + 1) >> 3) + 1, (i + 1) & 7);
+  }
+  __device__ __forceinline__ void step_end(int) {}
+  __device__ __forceinline__ double rd(int a, int idx) const {
+    return lds[((idx >> 3) & 1) * 1728 + a * 576 + lane * 9 + (idx & 7)];
+  }
+  __device__ __forceinline__ double t(int i) const { return i == 0 ? tfirst : rd(0, i - 1); }
+  __device__ __forceinline__ double diag(int i) const { return rd(1, i); }
+  __device__ __forceinline__ double y(int i) const { return rd(2, i); }
+};
+
+__device__ __forceinline__ StagedSeries make_staged(const BatchParams& P, int b, int c, double* lds) {
+  StagedSeries s;
+  s.lds = lds;
+  const double* tb = P.t + b * P.t_stride;
+  s.g0 = tb + 1;
+  s.g1 = P.diag + b * P.diag_stride;
+  s.g2 = P.y + b * P.y_stride;
+  s.lim0 = (long)P.N - 1;
+  s.lim1 = P.N;
+  s.lim2 = P.N;
+  s.L = P.L;
+  s.row0 = blockIdx.x * 64;
+  s.nchunk = P.nchunk;
+  s.lane = threadIdx.x;
+  const long n0 = (long)c * P.L;
+  s.tfirst = n0 < P.N ? tb[n0] : 0.0;
+  s.p0 = s.p1 = s.p2 = 0.0;
+  return s;
+}
+
+__device__ __forceinline__ DirectSeries make_direct(const BatchParams& P, int b, int c) {
+  return DirectSeries{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
+                      P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L,
+                      (long)P.N - (long)c * P.L};
+}
+
+template <int JR, int JC, bool FAST, bool STAGED>
 __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
+  __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= P.nchunk - 1) return;  // the last chunk's element is never needed
+  const bool store = c < P.nchunk - 1;  // the last chunk's element is never needed
+  if (!STAGED && !store) return;        // (staged: every lane helps loading the tiles)
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
-  const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
-                      P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
-  summarize_chunk<JR, JC, FAST>(p, sl, P.elems + ((long)b * P.nchunk + c) * Wd::ELEM);
+  double* out = P.elems + ((long)b * P.nchunk + (store ? c : 0)) * Wd::ELEM;
+  if (STAGED) {
+    StagedSeries src = make_staged(P, b, c, tiles);
+    summarize_chunk<JR, JC, FAST>(p, src, P.L, store, out);
+  } else {
+    DirectSeries src = make_direct(P, b, c);
+    summarize_chunk<JR, JC, FAST>(p, src, P.L, store, out);
+  }
 }
 
 template <int JR, int JC>
@@ -235,35 +333,36 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   }
 }
 
-template <int JR, int JC, bool MATERIALIZE, bool FAST>
+template <int JR, int JC, bool MATERIALIZE, bool FAST, bool STAGED>
 __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
+  __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= P.nchunk) return;
-  const int n0 = c * P.L;
-  if (n0 >= P.N) {  // empty trailing chunk (nchunk * L may exceed N)
-    P.part[((long)b * P.nchunk + c) * 2 + 0] = 0.0;
-    P.part[((long)b * P.nchunk + c) * 2 + 1] = 0.0;
-    P.flags[(long)b * P.nchunk + c] = 0;
-    return;
-  }
-  const int n1 = min(n0 + P.L, P.N);
+  const bool mine = c < P.nchunk;
+  if (!STAGED && !mine) return;
+  const int n0 = c * P.L;  // >= N for lanes past the last chunk: all their steps are padding
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
   double ld, qd;
   int flag;
   const long Nm1 = P.N - 1;
-  const SeriesLane sl{P.t + b * P.t_stride + c * P.lane_cs, P.diag + b * P.diag_stride + c * P.lane_cs,
-                      P.y + b * P.y_stride + c * P.lane_cs, P.lane_is, P.lane_cs, P.L};
-  replay_chunk<JR, JC, MATERIALIZE, FAST>(
-      p, sl, P.N, n0, n1,
-      c == 0 ? nullptr : P.starts + ((long)b * P.nchunk + c) * Wd::START, &ld, &qd, &flag,
-      MATERIALIZE ? P.phi + (long)b * J * Nm1 : nullptr,
-      MATERIALIZE ? P.u + (long)b * J * Nm1 : nullptr,
-      MATERIALIZE ? P.W + (long)b * J * P.N : nullptr,
-      MATERIALIZE ? P.D + (long)b * P.N : nullptr);
+  const double* start = (mine && c > 0) ? P.starts + ((long)b * P.nchunk + c) * Wd::START : nullptr;
+  double* phi_o = MATERIALIZE ? P.phi + (long)b * J * Nm1 : nullptr;
+  double* u_o = MATERIALIZE ? P.u + (long)b * J * Nm1 : nullptr;
+  double* W_o = MATERIALIZE ? P.W + (long)b * J * P.N : nullptr;
+  double* D_o = MATERIALIZE ? P.D + (long)b * P.N : nullptr;
+  if (STAGED) {
+    StagedSeries src = make_staged(P, b, c, tiles);
+    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
+                                            W_o, D_o);
+  } else {
+    DirectSeries src = make_direct(P, b, c);
+    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
+                                            W_o, D_o);
+  }
+  if (!mine) return;
   P.part[((long)b * P.nchunk + c) * 2 + 0] = ld;
   P.part[((long)b * P.nchunk + c) * 2 + 1] = qd;
   P.flags[(long)b * P.nchunk + c] = flag;
@@ -281,11 +380,12 @@ template <int JR, int JC>
 struct BatchImpl {
   static void summarize(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
-    dim3 grid((P.nchunk - 1 + 63) / 64, P.B);
-    if (P.fast_trig)
-      hipLaunchKernelGGL((summarize_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
-    else
-      hipLaunchKernelGGL((summarize_kernel<JR, JC, false>), grid, dim3(64), 0, s, P);
+    // staged: the wave that holds the last chunk must exist too (it helps loading)
+    dim3 grid(((P.staged ? P.nchunk : P.nchunk - 1) + 63) / 64, P.B);
+#define CLR_GO(F, S) hipLaunchKernelGGL((summarize_kernel<JR, JC, F, S>), grid, dim3(64), 0, s, P)
+    if (P.fast_trig) { if (P.staged) CLR_GO(true, true); else CLR_GO(true, false); }
+    else             { if (P.staged) CLR_GO(false, true); else CLR_GO(false, false); }
+#undef CLR_GO
   }
   static void prefix(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
@@ -296,17 +396,13 @@ struct BatchImpl {
   }
   static void replay(const BatchParams& P, bool materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
-    if (materialize) {
-      if (P.fast_trig)
-        hipLaunchKernelGGL((replay_kernel<JR, JC, true, true>), grid, dim3(64), 0, s, P);
-      else
-        hipLaunchKernelGGL((replay_kernel<JR, JC, true, false>), grid, dim3(64), 0, s, P);
-    } else {
-      if (P.fast_trig)
-        hipLaunchKernelGGL((replay_kernel<JR, JC, false, true>), grid, dim3(64), 0, s, P);
-      else
-        hipLaunchKernelGGL((replay_kernel<JR, JC, false, false>), grid, dim3(64), 0, s, P);
-    }
+#define CLR_GO(M, F, S) hipLaunchKernelGGL((replay_kernel<JR, JC, M, F, S>), grid, dim3(64), 0, s, P)
+#define CLR_GO2(M)                                                                \
+  if (P.fast_trig) { if (P.staged) CLR_GO(M, true, true); else CLR_GO(M, true, false); } \
+  else             { if (P.staged) CLR_GO(M, false, true); else CLR_GO(M, false, false); }
+    if (materialize) { CLR_GO2(true) } else { CLR_GO2(false) }
+#undef CLR_GO2
+#undef CLR_GO
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &replay, Widths<JR, JC>::ELEM,

@@ -97,18 +97,31 @@ struct Problem {
   CLR_HD double diagonal(double diag_n) const { return ((diag_n + sum_ar) + sum_ac) + jitter; }
 };
 
-// One lane's view of the three input series for its chunk of L samples.  Sample i
-// of the chunk is element off(i); i may run up to L + 1, i.e. into the first two
-// samples of the NEXT chunk (t_{n+1} is needed for the decay of the last step).
-//   row-major  ([problem][n], the layout of the public API):  is = 1,      cs = L
-//   interleaved ([problem][i][chunk], written by relayout_kernel so that the 64
-//   lanes of a wave -- 64 consecutive chunks at the same i -- read 512 contiguous
-//   bytes):                                                     is = nchunk, cs = 1
-struct SeriesLane {
-  const double *t, *diag, *y;  // already offset to this lane's (problem, chunk) origin
+// How a lane reads the three input series for its chunk of L samples.  The chunk
+// routines below are written against a small policy ("Src") so that the same
+// arithmetic serves three data paths:
+//   t(i), diag(i), y(i)   sample i of the lane's chunk (i <= L for t: the decay of
+//                         the chunk's last step needs the next chunk's first time)
+//   prologue(), step_begin(i), step_end(i)   hooks around every step; the loops run
+//                         a WAVE-UNIFORM number of steps (L) so that a cooperative
+//                         policy may load tiles and hit barriers inside them.
+// DirectSeries: plain addressing, element (chunk c, local i) at base[c * cs + i * is]
+//   row-major    ([problem][n], the layout of the public API)      is = 1,      cs = L
+//   interleaved  ([problem][i][chunk], written by relayout_kernel)  is = nchunk, cs = 1
+// StagedSeries (clr_batch_kernels.h, device only): the wave reads the row-major
+//   arrays in coalesced 8-step tiles and transposes them through LDS.
+struct DirectSeries {
+  const double *tp, *dp, *yp;  // already offset to this lane's (problem, chunk) origin
   long is, cs;
   int L;
+  long nleft;  // samples from this lane's origin to the end of the series (may be <= 0)
   CLR_HD long off(int i) const { return i < L ? (long)i * is : cs + (long)(i - L) * is; }
+  CLR_HD double t(int i) const { return i < nleft ? tp[off(i)] : 0.0; }
+  CLR_HD double diag(int i) const { return i < nleft ? dp[off(i)] : 0.0; }
+  CLR_HD double y(int i) const { return i < nleft ? yp[off(i)] : 0.0; }
+  CLR_HD void prologue() {}
+  CLR_HD void step_begin(int) {}
+  CLR_HD void step_end(int) {}
 };
 
 // ---------------------------------------------------------------------------
@@ -218,8 +231,9 @@ CLR_HD void features_phi(const Problem<JR, JC>& p, double dx, double* phi) {
 // element that ends at the next chunk's first sample.  elem layout:
 //   A[J*J] row-major | b[J] | C[SZ] | eta[J] | Jm[SZ]
 // ---------------------------------------------------------------------------
-template <int JR, int JC, bool FAST>
-CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, double* elem_out) {
+template <int JR, int JC, bool FAST, class Src>
+CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool store,
+                            double* elem_out) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   // State: 152 doubles at J = 8, more than the 128 that 256 VGPRs hold; the compiler
@@ -239,18 +253,22 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, doub
   CLR_UNROLL
   for (int i = 0; i < SZ; ++i) { C[i] = 0.0; Jm[i] = 0.0; }
 
-  // A summarised chunk is always a full one (L samples) followed by at least
-  // one more sample, so reads run to local index L (never L + 1).
-  const int len = sl.L;
-  double tn = sl.t[sl.off(0)];
-  double t_next = sl.t[sl.off(1)], diag_n = sl.diag[sl.off(0)], y_n = sl.y[sl.off(0)];
+  // A summarised chunk is always a full one (L samples) followed by at least one
+  // more sample, so t is read up to local index L.  Lanes without a chunk to
+  // summarise (store == false) run the same L steps on whatever they read -- the
+  // loop count must be wave-uniform for the staged source -- and store nothing.
+  const int len = L;
+  src.prologue();
+  double tn = src.t(0);
+  double t_next = src.t(1), diag_n = src.diag(0), y_n = src.y(0);
   for (int i = 0; i < len; ++i) {
+    src.step_begin(i);
     // register prefetch of the next sample
     const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
     if (i + 1 < len) {
-      t_next = sl.t[sl.off(i + 2)];
-      diag_n = sl.diag[sl.off(i + 1)];
-      y_n = sl.y[sl.off(i + 1)];
+      t_next = src.t(i + 2);
+      diag_n = src.diag(i + 1);
+      y_n = src.y(i + 1);
     }
 
     double u[J], v[J], phi[J];
@@ -303,7 +321,9 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, doub
       b[j] = phi[j] * (b[j] + W[j] * x);
     }
     tn = t_cur_next;
+    src.step_end(i);
   }
+  if (!store) return;
 
   double* o = elem_out;  // A is written row-major
   CLR_UNROLL
@@ -436,8 +456,8 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
 // MATERIALIZE, writes the factor in the reference's storage (cholesky.h:76-78,
 // :703-706): phi[:, n] (move n -> n+1), u[:, n-1] = U~(t_n), W[:, n], D[n].
 // ---------------------------------------------------------------------------
-template <int JR, int JC, bool MATERIALIZE, bool FAST>
-CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, int n0, int n1,
+template <int JR, int JC, bool MATERIALIZE, bool FAST, class Src>
+CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0,
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
                          double* phi_o, double* u_o, double* W_o, double* D_o) {
@@ -460,16 +480,22 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
   LogProduct lp;
   lp.init();
   int flag = 0;
-  double tn = sl.t[sl.off(0)];
-  double t_next = (n0 + 1 < N) ? sl.t[sl.off(1)] : tn;
-  double diag_n = sl.diag[sl.off(0)], y_n = sl.y[sl.off(0)];
-  for (int n = n0; n < n1; ++n) {
-    const int i = n - n0;
+  // Every lane runs L steps (wave-uniform, see DirectSeries); steps at or beyond
+  // the end of the series (short last chunk, lanes past the last chunk) are
+  // computed on padding and contribute nothing.
+  src.prologue();
+  double tn = src.t(0);
+  double t_next = src.t(1);
+  double diag_n = src.diag(0), y_n = src.y(0);
+  for (int i = 0; i < L; ++i) {
+    src.step_begin(i);
+    const int n = n0 + i;
+    const bool valid = n < N;
     const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
-    if (n + 1 < n1) {
-      t_next = (n + 2 < N) ? sl.t[sl.off(i + 2)] : t_next;
-      diag_n = sl.diag[sl.off(i + 1)];
-      y_n = sl.y[sl.off(i + 1)];
+    if (i + 1 < L) {
+      t_next = src.t(i + 2);
+      diag_n = src.diag(i + 1);
+      y_n = src.y(i + 1);
     }
 
     double u[J], v[J];
@@ -487,11 +513,13 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
     CLR_UNROLL
     for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
     const double D = p.diagonal(diag_cur) - s;
-    if (n >= 1 && D < 0.0 && !flag) flag = 1;
     const double invD = 1.0 / D;
     const double x = y_cur - uf;
-    lp.mul(D);
-    quad += x * x * invD;
+    if (valid) {
+      if (n >= 1 && D < 0.0) flag = 1;  // cholesky.h:176 (sample 0 is never checked)
+      lp.mul(D);
+      quad += x * x * invD;
+    }
 
     double z[J], W[J];
     CLR_UNROLL
@@ -499,7 +527,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
       z[j] = v[j] - q[j];
       W[j] = z[j] * invD;
     }
-    if (MATERIALIZE) {
+    if (MATERIALIZE && valid) {
       D_o[n] = D;
       CLR_UNROLL
       for (int j = 0; j < J; ++j) W_o[(long)J * n + j] = W[j];
@@ -508,10 +536,10 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
         for (int j = 0; j < J; ++j) u_o[(long)J * (n - 1) + j] = u[j];
       }
     }
-    if (n + 1 < N) {
+    {
       double phi[J];
       features_phi<JR, JC>(p, t_cur_next - tn, phi);
-      if (MATERIALIZE) {
+      if (MATERIALIZE && n + 1 < N) {
         CLR_UNROLL
         for (int j = 0; j < J; ++j) phi_o[(long)J * n + j] = phi[j];
       }
@@ -524,6 +552,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, const SeriesLane& sl, int N, 
       }
     }
     tn = t_cur_next;
+    src.step_end(i);
   }
   *logdet_out = lp.log_value();
   *quad_out = quad;

@@ -170,12 +170,15 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp);
 
-/* Tuning.  The kernels read the series from a chunk-interleaved copy
- * ([problem][i][chunk]; one coalesced 512-B wave load per array per step) that
- * enqueue builds with a tiled-transpose kernel whenever the series or the
- * chunking changed.  set_layout(h, 0) makes them read the row-major arrays
- * directly (slower; kept for A/B measurements). */
-int clr_batch_set_layout(clr_batch* h, int interleaved);
+/* Tuning: how the kernels read the series.
+ *   2 (default) staged: each wave loads the row-major arrays in coalesced tiles of
+ *       8 steps x 64 chunks and transposes them through LDS; no extra pass or copy.
+ *   1 interleaved: enqueue first builds a chunk-interleaved copy ([problem][i][chunk])
+ *       with a tiled-transpose kernel whenever the series or the chunking changed;
+ *       marginally faster per evaluation when the SAME series are evaluated many
+ *       times, but costs a 0.87 ms pass (B=1024, N=1e5) whenever they change.
+ *   0 row-major direct: every lane streams its own run (slow; kept for A/B). */
+int clr_batch_set_layout(clr_batch* h, int layout);
 /* The kernels evaluate sin/cos(d_comp * t) with a 25-instruction FMA Cody-Waite
  * routine (abs. error < 1 ulp(1)) when the host-side check max|d_comp| * max|t| <
  * 1e9 holds, and with the library (ocml) sincos otherwise.  force != 0 selects the
@@ -204,9 +207,9 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
 /* Runs `steps` evaluations back to back, bracketing every kernel with HIP
  * events recorded on the handle's stream.  kernel_ms[5] receives the SUMMED
  * device time of the relayout / summarise / prefix / replay / finalise
- * kernels, total_ms the first-event-to-last-event time.  With
- * relayout_each_step != 0 the row-major -> interleaved transposition is redone
- * inside every step (the cost when every evaluation brings NEW series);
+ * kernels, total_ms the first-event-to-last-event time.  In layout 1 only:
+ * with relayout_each_step != 0 the row-major -> interleaved transposition is
+ * redone inside every step (the cost when every evaluation brings NEW series);
  * otherwise it is done once, outside the timed region (fixed series, new
  * hyper-parameters: the MCMC / optimiser loop of celerite.py:160-219). */
 int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,

@@ -44,10 +44,13 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       tb = tT.data(); db = dT.data(); yb = yT.data();
       is = nchunk; cs = 1;
     }
-    auto lane = [&](int c) { return SeriesLane{tb + c * cs, db + c * cs, yb + c * cs, is, cs, L}; };
+    auto lane = [&](int c) {
+      return DirectSeries{tb + c * cs, db + c * cs, yb + c * cs, is, cs, L, (long)N - (long)c * L};
+    };
     for (int c = 0; c + 1 < nchunk; ++c) {
       if ((c + 1) * L >= N) continue;  // element would run past the data; never applied
-      summarize_chunk<JR, JC, FAST>(p, lane(c), &elems[(size_t)c * Wd::ELEM]);
+      DirectSeries src = lane(c);
+      summarize_chunk<JR, JC, FAST>(p, src, L, true, &elems[(size_t)c * Wd::ELEM]);
     }
     double S[Wd::SZ] = {0}, f[J] = {0};
     for (int c = 0; c + 1 < nchunk; ++c) {
@@ -61,17 +64,17 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
     for (int c = 0; c < nchunk; ++c) {
       const int n0 = c * L;
       if (n0 >= N) break;
-      const int n1 = n0 + L < N ? n0 + L : N;
       double l, q;
       int fl;
       const long Nm1 = N - 1;
+      DirectSeries src = lane(c);
       if (materialize)
-        replay_chunk<JR, JC, true, FAST>(p, lane(c), N, n0, n1,
+        replay_chunk<JR, JC, true, FAST>(p, src, L, N, n0,
                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                    phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
                                    W + (long)b * J * N, D + (long)b * N);
       else
-        replay_chunk<JR, JC, false, FAST>(p, lane(c), N, n0, n1,
+        replay_chunk<JR, JC, false, FAST>(p, src, L, N, n0,
                                     c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                     nullptr, nullptr, nullptr, nullptr);
       ld += l;

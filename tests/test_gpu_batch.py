@@ -17,13 +17,13 @@ pytestmark = pytest.mark.gpu
 REL = 1e-10
 
 
-def check(case, nchunk=0, interleaved=True, B=None):
+def check(case, nchunk=0, layout="staged", B=None):
     B = case["t"].shape[0] if B is None else B
     plan = batch.BatchedGP(B, case["t"].shape[-1], case["a_real"].shape[1], case["a_comp"].shape[1])
     try:
         if nchunk:
             plan.set_chunks(nchunk)
-        plan.set_layout(interleaved)
+        plan.set_layout(layout)
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case), jitter=case.get("jitter", 0.0))
         ll, ld, q, st = plan.log_likelihood()
@@ -50,7 +50,8 @@ def test_every_width_shape(JR, JC):
                                       (128, 0), (129, 0), (1000, 1), (1000, 999), (4097, 64)])
 def test_edge_sizes_and_chunkings(N, nchunk):
     check(synthetic(3, N, 2, 3, "accuracy", seed=N), nchunk=nchunk)
-    check(synthetic(3, N, 1, 1, "bench", seed=N + 1), nchunk=nchunk, interleaved=False)
+    check(synthetic(3, N, 1, 1, "bench", seed=N + 1), nchunk=nchunk, layout="rowmajor")
+    check(synthetic(3, N, 0, 2, "accuracy", seed=N + 2), nchunk=nchunk, layout="interleaved")
 
 
 def test_config2_shape():
@@ -108,9 +109,10 @@ def test_results_independent_of_chunking_and_layout():
     plan.set_series(case["t"], case["diag"], case["y"])
     plan.set_coefficients(*coeffs_of(case))
     outs = []
-    for nchunk, inter in [(1, True), (7, True), (64, True), (64, False), (600, True)]:
+    for nchunk, layout in [(1, "staged"), (7, "staged"), (64, "staged"), (64, "rowmajor"),
+                           (64, "interleaved"), (600, "staged"), (600, "interleaved")]:
         plan.set_chunks(nchunk)
-        plan.set_layout(inter)
+        plan.set_layout(layout)
         outs.append(plan.log_likelihood())
     plan.close()
     for o in outs[1:]:

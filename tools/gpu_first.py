@@ -71,20 +71,21 @@ plan = batch.BatchedGP(B, N, JR, JC)
 plan.set_series(a[6], a[7], a[8])
 plan.set_coefficients(*a[:6])
 res = {}
-for coop in (0, 1):
-    plan.set_prefix_mode(bool(coop))
-    for nch in (64, 128, 256):
+for layout in ("staged", "interleaved"):
+    plan.set_layout(layout)
+    for nch in (64, 128):
         plan.set_chunks(nch)
         plan.log_likelihood()  # warm
         tot, k = plan.run_timed(3, relayout_each_step=True)
-        res["coop%d_%d" % (coop, nch)] = dict(ms=tot / 3, kernels={a: b / 3 for a, b in k.items()}, chunks=plan.chunks)
-        print("coop_prefix=%d nchunk %4d L %5d: %.3f ms/step  (%s) -> %.0f loglik/s" % (
-            coop, plan.chunks[0], plan.chunks[1], tot / 3,
+        res["%s_%d" % (layout, nch)] = dict(ms=tot / 3, kernels={a: b / 3 for a, b in k.items()}, chunks=plan.chunks)
+        print("layout=%s nchunk %4d L %5d: %.3f ms/step  (%s) -> %.0f loglik/s" % (
+            layout, plan.chunks[0], plan.chunks[1], tot / 3,
             " ".join("%s %.3f" % (a, b / 3) for a, b in k.items()), B / (tot / 3) * 1e3), flush=True)
         ll, ld, q, st = plan.log_likelihood()
         l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[x[:4] for x in a[:6]], a[6][:4], a[7][:4], a[8][:4])
         print("   parity (4 problems): logdet rel %.2e quad rel %.2e" % (
             np.max(np.abs(ld[:4] - d0) / np.abs(d0)), np.max(np.abs(q[:4] - q0) / np.abs(q0))), flush=True)
+plan.set_layout("staged")
 out["sweep"] = res
 plan.set_chunks(64)
 ll, ld, q, st = plan.log_likelihood()
