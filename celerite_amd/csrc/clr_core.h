@@ -213,16 +213,69 @@ CLR_HD void features_uv(const Problem<JR, JC>& p, double t, double* u, double* v
   }
 }
 
-// phi for the move from t to t + dx: cholesky.h:130,140-142.
+// Wave-level "all lanes agree" (host: the single lane's own condition).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CLR_WAVE_ALL(cond) (__all(cond) != 0)
+#else
+#define CLR_WAVE_ALL(cond) (cond)
+#endif
+
+// exp(x) for |x| < 2^-7 by a degree-6 Taylor polynomial: truncation x^7/7! < 3.5e-19
+// relative, i.e. below half an ulp -- the result is the correctly rounded one up to
+// the rounding of the 6 FMAs (same as the library's own polynomial).
+CLR_HD double exp_small(double x) {
+  double p = fma(x, 1.0 / 720.0, 1.0 / 120.0);
+  p = fma(x, p, 1.0 / 24.0);
+  p = fma(x, p, 1.0 / 6.0);
+  p = fma(x, p, 0.5);
+  p = fma(x, p, 1.0);
+  return fma(x, p, 1.0);
+}
+
+// The distinct decay factors of one step: phid[0..JR) for the real terms, then one
+// per complex PAIR (both rows of a pair share it, cholesky.h:140-142), for the move
+// from t to t + dx (cholesky.h:130,140).  Densely sampled series (|c dx| < 2^-7 in
+// every lane of the wave -- the large-N regime) take the 6-FMA polynomial instead of
+// the library exp (19 fp64 instructions); the choice is wave-uniform, no divergence.
 template <int JR, int JC>
-CLR_HD void features_phi(const Problem<JR, JC>& p, double dx, double* phi) {
+CLR_HD void features_phi_distinct(const Problem<JR, JC>& p, double dx, double* phid) {
+  double x[nz(JR + JC)];
+  double amax = 0.0;
   CLR_UNROLL
-  for (int j = 0; j < JR; ++j) phi[j] = exp(-p.cr[j] * dx);
+  for (int j = 0; j < JR; ++j) { x[j] = -p.cr[j] * dx; amax = fmax(amax, fabs(x[j])); }
   CLR_UNROLL
-  for (int j = 0; j < JC; ++j) {
-    const double e = exp(-p.cc[j] * dx);
-    phi[JR + 2 * j] = e;
-    phi[JR + 2 * j + 1] = e;
+  for (int j = 0; j < JC; ++j) { x[JR + j] = -p.cc[j] * dx; amax = fmax(amax, fabs(x[JR + j])); }
+  if (CLR_WAVE_ALL(amax < 0.0078125)) {
+    CLR_UNROLL
+    for (int j = 0; j < JR + JC; ++j) phid[j] = exp_small(x[j]);
+  } else {
+    CLR_UNROLL
+    for (int j = 0; j < JR + JC; ++j) phid[j] = exp(x[j]);
+  }
+}
+
+// row k of the width-J state -> index of its decay factor in phid
+template <int JR>
+CLR_HD constexpr int phi_index(int k) { return k < JR ? k : JR + (k - JR) / 2; }
+
+// S <- Phi (S + z w^T) Phi on the packed upper triangle, with the (JR+JC)(JR+JC+1)/2
+// distinct products phi_a phi_b formed once (cholesky.h:154-160 does 3 flops per
+// entry; this is 1 fma + 1 mul per entry + 15 products at J = 8).
+template <int JR, int JC>
+CLR_HD void decay_rank1_update(const double* phid, const double* z, const double* w, double* S) {
+  constexpr int J = JR + 2 * JC;
+  constexpr int M = JR + JC;
+  double pp[nz(M * (M + 1) / 2)];
+  CLR_UNROLL
+  for (int b = 0; b < M; ++b) {
+    CLR_UNROLL
+    for (int a = 0; a <= b; ++a) pp[tri(a, b)] = phid[a] * phid[b];
+  }
+  CLR_UNROLL
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL
+    for (int k = 0; k <= j; ++k)
+      S[tri(k, j)] = pp[tri(phi_index<JR>(k), phi_index<JR>(j))] * fma(z[k], w[j], S[tri(k, j)]);
   }
 }
 
@@ -271,9 +324,9 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
       y_n = src.y(i + 1);
     }
 
-    double u[J], v[J], phi[J];
+    double u[J], v[J], phid[nz(JR + JC)];
     features_uv<JR, JC, FAST>(p, tn, u, v);
-    features_phi<JR, JC>(p, t_cur_next - tn, phi);
+    features_phi_distinct<JR, JC>(p, t_cur_next - tn, phid);
 
     double q[J];
     CLR_UNROLL
@@ -296,7 +349,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
     for (int j = 0; j < J; ++j) {
       z[j] = v[j] - q[j];
       W[j] = z[j] * invD;
-      pw[j] = phi[j] * W[j];
+      pw[j] = phid[phi_index<JR>(j)] * W[j];
     }
     // one visit per column of A: r_j = u . A[:, j] ; A[:, j] <- Phi (A[:, j] - W r_j)
     double r[J];
@@ -307,19 +360,18 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
       for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
       r[j] = racc;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) Acol[j * J + k] = phi[k] * Acol[j * J + k] - pw[k] * racc;
+      for (int k = 0; k < J; ++k)
+        Acol[j * J + k] = phid[phi_index<JR>(k)] * Acol[j * J + k] - pw[k] * racc;
     }
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
       const double rsj = r[j] * invD;
       eta[j] -= r[j] * xs;
       CLR_UNROLL
-      for (int k = 0; k <= j; ++k) {
-        Jm[tri(k, j)] -= r[k] * rsj;
-        C[tri(k, j)] = phi[j] * (phi[k] * (C[tri(k, j)] + z[k] * W[j]));
-      }
-      b[j] = phi[j] * (b[j] + W[j] * x);
+      for (int k = 0; k <= j; ++k) Jm[tri(k, j)] -= r[k] * rsj;
+      b[j] = phid[phi_index<JR>(j)] * (b[j] + W[j] * x);
     }
+    decay_rank1_update<JR, JC>(phid, z, W, C);
     tn = t_cur_next;
     src.step_end(i);
   }
@@ -537,19 +589,15 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
       }
     }
     {
-      double phi[J];
-      features_phi<JR, JC>(p, t_cur_next - tn, phi);
+      double phid[nz(JR + JC)];
+      features_phi_distinct<JR, JC>(p, t_cur_next - tn, phid);
       if (MATERIALIZE && n + 1 < N) {
         CLR_UNROLL
-        for (int j = 0; j < J; ++j) phi_o[(long)J * n + j] = phi[j];
+        for (int j = 0; j < J; ++j) phi_o[(long)J * n + j] = phid[phi_index<JR>(j)];
       }
       CLR_UNROLL
-      for (int j = 0; j < J; ++j) {
-        CLR_UNROLL
-        for (int k = 0; k <= j; ++k)
-          P[tri(k, j)] = phi[j] * (phi[k] * (P[tri(k, j)] + z[k] * W[j]));
-        f[j] = phi[j] * (f[j] + W[j] * x);
-      }
+      for (int j = 0; j < J; ++j) f[j] = phid[phi_index<JR>(j)] * (f[j] + W[j] * x);
+      decay_rank1_update<JR, JC>(phid, z, W, P);
     }
     tn = t_cur_next;
     src.step_end(i);
