@@ -60,23 +60,23 @@ __device__ __forceinline__ void load_problem(const BatchParams& P, int b, Proble
 // group g = (i+1) & 7 of the NEXT tile is requested at the beginning of step i and
 // written to the other LDS buffer at the beginning of step i+1, so the HBM latency
 // hides behind a whole step of arithmetic, and the per-lane reads for step i+1 are
-// issued during step i.  t is staged shifted by one sample (the lane needs t_{n+1} and t_{n+2}).
+// issued during step i.
 // This replaces a separate relayout pass (0.87 ms for 3 x 0.82 GB at 5.7 TB/s).
 // ---------------------------------------------------------------------------
 struct StagedSeries {
   double* lds;  // [2 buffers][3 arrays][64 rows][9]
-  const double *g0, *g1, *g2;  // problem bases: t + 1, diag, y
-  long lim0, lim1, lim2;       // valid elements from each base
+  const double *g0, *g1, *g2;  // problem bases: t, diag, y (row-major)
+  long lim;                    // N
   int L, row0, nchunk, lane;
-  double tfirst;
   double p0, p1, p2;  // loads in flight
   __device__ __forceinline__ void issue(int tile, int group) {
     const int r = group * 8 + (lane >> 3), col = tile * 8 + (lane & 7);
     const long n = (long)(row0 + r) * L + col;
-    const bool ok = (row0 + r < nchunk) && (col < L);
-    p0 = (ok && n < lim0) ? g0[n] : 0.0;
-    p1 = (ok && n < lim1) ? g1[n] : 0.0;
-    p2 = (ok && n < lim2) ? g2[n] : 0.0;
+    // a row may read up to 2 samples into the next one (t_{n+1}, t_{n+2} of its last steps)
+    const bool ok = (row0 + r < nchunk) && (col < L + 2) && (n < lim);
+    p0 = ok ? g0[n] : 0.0;
+    p1 = ok ? g1[n] : 0.0;
+    p2 = ok ? g2[n] : 0.0;
   }
   __device__ __forceinline__ void commit(int tile, int group) {
     double* d = lds + (tile & 1) * 1728 + (group * 8 + (lane >> 3)) * 9 + (lane & 7);
@@ -84,6 +84,13 @@ struct StagedSeries {
     d[576] = p1;
     d[1152] = p2;
   }
+  // Schedule (tile k = local samples 8k .. 8k+7 of all 64 rows, buffer k & 1):
+  //   step i reads t at i+2 and diag, y at i+1, so tile k must be complete at the top
+  //   of step 8k-2.  Its group g is requested at the top of step 8(k-1) + g - 2 and
+  //   written at the top of the following step (a whole step of latency hiding across
+  //   the loop back-edge: if the write sits in the same step as the loads the compiler
+  //   schedules it right behind them and every step stalls on HBM, +12 % measured).
+  //   The prologue loads tile 0 and groups 0, 1 of tile 1.
   __device__ __forceinline__ void prologue() {
 #pragma unroll
     for (int gidx = 0; gidx < 8; ++gidx) {
@@ -92,25 +99,22 @@ struct StagedSeries {
     }
     issue(1, 0);
     commit(1, 0);
+    issue(1, 1);
+    commit(1, 1);
     __syncthreads();
   }
-  // Two-stage pipeline across the loop back-edge: the loads requested at the top of
-  // step i-1 are written to LDS at the top of step i (a whole step of latency
-  // hiding by construction -- if the write sits in the same step as the loads the
-  // compiler schedules it right behind them and every step stalls on HBM: +12 %
-  // measured), then the next group is requested.
   __device__ __forceinline__ void step_begin(int i) {
     if (i > 0) {
-      commit((i >> 3) + 1, i & 7);
-      if ((i & 7) == 7) __syncthreads();
+      commit(((i + 1) >> 3) + 1, (i + 1) & 7);
+      if (((i + 1) & 7) == 7) __syncthreads();
     }
-    issue(((i + 1) >> 3) + 1, (i + 1) & 7);
+    issue(((i + 2) >> 3) + 1, (i + 2) & 7);
   }
   __device__ __forceinline__ void step_end(int) {}
   __device__ __forceinline__ double rd(int a, int idx) const {
     return lds[((idx >> 3) & 1) * 1728 + a * 576 + lane * 9 + (idx & 7)];
   }
-  __device__ __forceinline__ double t(int i) const { return i == 0 ? tfirst : rd(0, i - 1); }
+  __device__ __forceinline__ double t(int i) const { return rd(0, i); }
   __device__ __forceinline__ double diag(int i) const { return rd(1, i); }
   __device__ __forceinline__ double y(int i) const { return rd(2, i); }
 };
@@ -118,19 +122,14 @@ struct StagedSeries {
 __device__ __forceinline__ StagedSeries make_staged(const BatchParams& P, int b, int c, double* lds) {
   StagedSeries s;
   s.lds = lds;
-  const double* tb = P.t + b * P.t_stride;
-  s.g0 = tb + 1;
+  s.g0 = P.t + b * P.t_stride;
   s.g1 = P.diag + b * P.diag_stride;
   s.g2 = P.y + b * P.y_stride;
-  s.lim0 = (long)P.N - 1;
-  s.lim1 = P.N;
-  s.lim2 = P.N;
+  s.lim = P.N;
   s.L = P.L;
   s.row0 = blockIdx.x * 64;
   s.nchunk = P.nchunk;
   s.lane = threadIdx.x;
-  const long n0 = (long)c * P.L;
-  s.tfirst = n0 < P.N ? tb[n0] : 0.0;
   s.p0 = s.p1 = s.p2 = 0.0;
   return s;
 }
