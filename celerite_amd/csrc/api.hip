@@ -88,6 +88,35 @@ __global__ void __launch_bounds__(256) relayout_kernel(const double* __restrict_
   }
 }
 
+// [i][j][chunk] (one problem of a materialising batch run) -> the reference's
+// [n][j] storage with its index conventions (u one column earlier, cholesky.h:131-151).
+__global__ void __launch_bounds__(256) deinterleave_factor_kernel(
+    const double* __restrict__ phi_i, const double* __restrict__ u_i,
+    const double* __restrict__ W_i, const double* __restrict__ D_i, double* __restrict__ phi,
+    double* __restrict__ u, double* __restrict__ W, double* __restrict__ D, int N, int J, int L,
+    int nchunk) {
+  const long total = (long)N * J;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / J), j = (int)(e % J);
+    const int c = n / L, i = n % L;
+    const long src = ((long)i * J + j) * nchunk + c;
+    W[e] = W_i[src];
+    if (n + 1 < N) phi[e] = phi_i[src];
+    if (n >= 1) u[e - J] = u_i[src];
+    if (j == 0) D[n] = D_i[(long)i * nchunk + c];
+  }
+}
+
+void launch_deinterleave_factor(const double* phi_i, const double* u_i, const double* W_i,
+                                const double* D_i, double* phi, double* u, double* W, double* D,
+                                int N, int J, int L, int nchunk, hipStream_t s) {
+  const long total = (long)N * J;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(deinterleave_factor_kernel, dim3(blocks), dim3(256), 0, s, phi_i, u_i, W_i,
+                     D_i, phi, u, W, D, N, J, L, nchunk);
+}
+
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, hipStream_t s) {
   dim3 grid((L + 31) / 32, (nchunk + 31) / 32, nsrc);
@@ -222,7 +251,8 @@ struct clr_batch {
   DevBuf elems, starts, part, out;  // out: ll | logdet | quad
   int* flags = nullptr;
   int* status = nullptr;
-  DevBuf phi, u, W, D;
+  DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
+  DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -463,7 +493,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
     L->summarize(P, stream);
     L->prefix(P, stream);
-    L->replay(P, true, stream);
+    L->replay(P, 1, stream);
     clr::launch_finalize(P, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -774,7 +804,8 @@ void clr_batch_destroy(clr_batch* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
-                    &h->elems, &h->starts, &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D})
+                    &h->elems, &h->starts, &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D,
+                    &h->fphi, &h->fu, &h->fW, &h->fD})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->status) (void)hipFree(h->status);
@@ -793,6 +824,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->relayout_pending = true;
+  h->have_factor = false;  // its layout depends on the chunking
   const size_t pc = (size_t)h->B * h->nchunk;
   if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
   if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
@@ -870,11 +902,11 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
   int st = CLR_OK;
   if (materialize && !h->have_factor) {
-    const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J;
-    if ((st = h->phi.reserve(B * J * (N - 1))) != CLR_OK) return st;
-    if ((st = h->u.reserve(B * J * (N - 1))) != CLR_OK) return st;
-    if ((st = h->W.reserve(B * J * N)) != CLR_OK) return st;
-    if ((st = h->D.reserve(B * N)) != CLR_OK) return st;
+    const size_t B = (size_t)h->B, J = (size_t)h->J, cells = (size_t)h->L * h->nchunk;
+    if ((st = h->phi.reserve(B * J * cells)) != CLR_OK) return st;
+    if ((st = h->u.reserve(B * J * cells)) != CLR_OK) return st;
+    if ((st = h->W.reserve(B * J * cells)) != CLR_OK) return st;
+    if ((st = h->D.reserve(B * cells)) != CLR_OK) return st;
     h->have_factor = true;
   }
   memset(&P, 0, sizeof(P));
@@ -953,7 +985,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   }
   h->launch->summarize(P, h->stream);
   h->launch->prefix(P, h->stream);
-  h->launch->replay(P, materialize != 0, h->stream);
+  h->launch->replay(P, materialize ? 2 : 0, h->stream);
   clr::launch_finalize(P, h->stream);
   HIP_TRY(hipGetLastError());
   return CLR_OK;
@@ -984,11 +1016,19 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   if (st != CLR_OK) return st;
   if (!h->have_factor) return fail(CLR_NOT_COMPUTED, "no materialising run has been made");
   if (p < 0 || p >= h->B) return fail(CLR_INVALID_ARGUMENT, "problem index out of range");
-  const size_t N = (size_t)h->N, J = (size_t)h->J, Nm1 = N - 1;
-  if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->phi.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->u.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (W) HIP_TRY(hipMemcpyAsync(W, h->W.p + p * J * N, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (D) HIP_TRY(hipMemcpyAsync(D, h->D.p + p * N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const size_t N = (size_t)h->N, J = (size_t)h->J, Nm1 = N - 1, cells = (size_t)h->L * h->nchunk;
+  if ((st = h->fphi.reserve(J * Nm1)) != CLR_OK) return st;
+  if ((st = h->fu.reserve(J * Nm1)) != CLR_OK) return st;
+  if ((st = h->fW.reserve(J * N)) != CLR_OK) return st;
+  if ((st = h->fD.reserve(N)) != CLR_OK) return st;
+  clr::launch_deinterleave_factor(h->phi.p + p * J * cells, h->u.p + p * J * cells,
+                                  h->W.p + p * J * cells, h->D.p + p * cells, h->fphi.p, h->fu.p,
+                                  h->fW.p, h->fD.p, h->N, h->J, h->L, h->nchunk, h->stream);
+  HIP_TRY(hipGetLastError());
+  if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->fphi.p, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->fu.p, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (W) HIP_TRY(hipMemcpyAsync(W, h->fW.p, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (D) HIP_TRY(hipMemcpyAsync(D, h->fD.p, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CLR_OK;
 }
@@ -1017,7 +1057,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[2], h->stream));
     h->launch->prefix(P, h->stream);
     HIP_TRY(hipEventRecord(e[3], h->stream));
-    h->launch->replay(P, materialize != 0, h->stream);
+    h->launch->replay(P, materialize ? 2 : 0, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
     clr::launch_finalize(P, h->stream);
     HIP_TRY(hipEventRecord(e[5], h->stream));

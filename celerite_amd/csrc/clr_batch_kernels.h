@@ -41,7 +41,8 @@ struct BatchParams {
   int* flags;      // [B][nchunk]
   double *out_ll, *out_logdet, *out_quad;
   int* out_status;
-  // factor (reference layout), only for materialising runs
+  // factor, only for materialising runs (replay mode 1: reference storage per
+  // problem; mode 2: chunk-interleaved [problem][i][j][chunk], see replay_chunk)
   double *phi, *u, *W, *D;
 };
 
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   }
 }
 
-template <int JR, int JC, bool MATERIALIZE, bool FAST, bool STAGED>
+template <int JR, int JC, int MATERIALIZE, bool FAST, bool STAGED>
 __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
@@ -348,18 +349,30 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   int flag;
   const long Nm1 = P.N - 1;
   const double* start = (mine && c > 0) ? P.starts + ((long)b * P.nchunk + c) * Wd::START : nullptr;
-  double* phi_o = MATERIALIZE ? P.phi + (long)b * J * Nm1 : nullptr;
-  double* u_o = MATERIALIZE ? P.u + (long)b * J * Nm1 : nullptr;
-  double* W_o = MATERIALIZE ? P.W + (long)b * J * P.N : nullptr;
-  double* D_o = MATERIALIZE ? P.D + (long)b * P.N : nullptr;
+  double *phi_o = nullptr, *u_o = nullptr, *W_o = nullptr, *D_o = nullptr;
+  long fstride = 0;
+  if (MATERIALIZE == 1) {  // reference storage, one problem after the other
+    phi_o = P.phi + (long)b * J * Nm1;
+    u_o = P.u + (long)b * J * Nm1;
+    W_o = P.W + (long)b * J * P.N;
+    D_o = P.D + (long)b * P.N;
+  } else if (MATERIALIZE == 2) {  // [problem][i][j][chunk]
+    const long cells = (long)P.L * P.nchunk;
+    const int cc = mine ? c : 0;
+    fstride = P.nchunk;
+    phi_o = P.phi + (long)b * J * cells + cc;
+    u_o = P.u + (long)b * J * cells + cc;
+    W_o = P.W + (long)b * J * cells + cc;
+    D_o = P.D + (long)b * cells + cc;
+  }
   if (STAGED) {
     StagedSeries src = make_staged(P, b, c, tiles);
     replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
-                                            W_o, D_o);
+                                            W_o, D_o, fstride);
   } else {
     DirectSeries src = make_direct(P, b, c);
     replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
-                                            W_o, D_o);
+                                            W_o, D_o, fstride);
   }
   if (!mine) return;
   P.part[((long)b * P.nchunk + c) * 2 + 0] = ld;
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
 struct BatchLaunchers {
   void (*summarize)(const BatchParams&, hipStream_t);
   void (*prefix)(const BatchParams&, hipStream_t);
-  void (*replay)(const BatchParams&, bool materialize, hipStream_t);
+  void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
   int elem_doubles, start_doubles;
 };
 
@@ -393,13 +406,13 @@ struct BatchImpl {
     else
       hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
   }
-  static void replay(const BatchParams& P, bool materialize, hipStream_t s) {
+  static void replay(const BatchParams& P, int materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
 #define CLR_GO(M, F, S) hipLaunchKernelGGL((replay_kernel<JR, JC, M, F, S>), grid, dim3(64), 0, s, P)
 #define CLR_GO2(M)                                                                \
   if (P.fast_trig) { if (P.staged) CLR_GO(M, true, true); else CLR_GO(M, true, false); } \
   else             { if (P.staged) CLR_GO(M, false, true); else CLR_GO(M, false, false); }
-    if (materialize) { CLR_GO2(true) } else { CLR_GO2(false) }
+    if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
 #undef CLR_GO2
 #undef CLR_GO
   }
@@ -411,6 +424,10 @@ struct BatchImpl {
 
 // Per-problem reduction of the chunk partials + the -inf rules (api.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
+// One problem's interleaved factor -> the reference's storage (api.hip).
+void launch_deinterleave_factor(const double* phi_i, const double* u_i, const double* W_i,
+                                const double* D_i, double* phi, double* u, double* W, double* D,
+                                int N, int J, int L, int nchunk, hipStream_t s);
 // [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api.hip).
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, hipStream_t s);

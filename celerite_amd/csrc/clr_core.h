@@ -508,11 +508,17 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
 // MATERIALIZE, writes the factor in the reference's storage (cholesky.h:76-78,
 // :703-706): phi[:, n] (move n -> n+1), u[:, n-1] = U~(t_n), W[:, n], D[n].
 // ---------------------------------------------------------------------------
-template <int JR, int JC, bool MATERIALIZE, bool FAST, class Src>
+template <int JR, int JC, int MATERIALIZE, bool FAST, class Src>
 CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0,
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
-                         double* phi_o, double* u_o, double* W_o, double* D_o) {
+                         double* phi_o, double* u_o, double* W_o, double* D_o, long fstride) {
+  // MATERIALIZE: 0 = nothing is stored; 1 = the reference's storage (cholesky.h:76-78,
+  // :703-706: phi[:, n], u[:, n-1], W[:, n], D[n] with element (j, n) at [j + J n];
+  // pointers are the problem's arrays); 2 = chunk-interleaved device layout: the
+  // pointers are already offset to this lane's chunk column and element (local step
+  // i, row j) is at [(i * J + j) * fstride] -- the 64 lanes of a wave then store 512
+  // contiguous bytes per instruction (u and phi both at their own sample's slot).
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   double P[SZ], f[J];
@@ -579,7 +585,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
       z[j] = v[j] - q[j];
       W[j] = z[j] * invD;
     }
-    if (MATERIALIZE && valid) {
+    if (MATERIALIZE == 1 && valid) {
       D_o[n] = D;
       CLR_UNROLL
       for (int j = 0; j < J; ++j) W_o[(long)J * n + j] = W[j];
@@ -588,12 +594,24 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
         for (int j = 0; j < J; ++j) u_o[(long)J * (n - 1) + j] = u[j];
       }
     }
+    if (MATERIALIZE == 2 && valid) {
+      D_o[(long)i * fstride] = D;
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        W_o[((long)i * J + j) * fstride] = W[j];
+        u_o[((long)i * J + j) * fstride] = u[j];
+      }
+    }
     {
       double phid[nz(JR + JC)];
       features_phi_distinct<JR, JC>(p, t_cur_next - tn, phid);
-      if (MATERIALIZE && n + 1 < N) {
+      if (MATERIALIZE == 1 && n + 1 < N) {
         CLR_UNROLL
         for (int j = 0; j < J; ++j) phi_o[(long)J * n + j] = phid[phi_index<JR>(j)];
+      }
+      if (MATERIALIZE == 2 && n + 1 < N) {
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) phi_o[((long)i * J + j) * fstride] = phid[phi_index<JR>(j)];
       }
       CLR_UNROLL
       for (int j = 0; j < J; ++j) f[j] = phid[phi_index<JR>(j)] * (f[j] + W[j] * x);

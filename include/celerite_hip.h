@@ -192,9 +192,11 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);
 
 /* Enqueue one evaluation of all B problems on the handle's stream (inputs
- * already resident in HBM).  `materialize` != 0 additionally writes the
- * reference-layout factor (phi, u, W, D per problem; 8 N (3J+1) bytes each)
- * to HBM, as B separate CholeskySolver.compute calls would. */
+ * already resident in HBM).  `materialize` != 0 additionally writes the factor
+ * (phi, u, W, D per problem; 8 N (3J+1) bytes each) to HBM, as B separate
+ * CholeskySolver.compute calls would.  On the device it is kept chunk-interleaved
+ * ([i][j][chunk]: every store instruction of a wave writes 512 contiguous bytes);
+ * clr_batch_get_factor returns it in the reference's storage order. */
 int clr_batch_enqueue(clr_batch* h, int materialize);
 /* Wait for the stream. */
 int clr_batch_synchronize(clr_batch* h);

@@ -69,14 +69,14 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       const long Nm1 = N - 1;
       DirectSeries src = lane(c);
       if (materialize)
-        replay_chunk<JR, JC, true, FAST>(p, src, L, N, n0,
+        replay_chunk<JR, JC, 1, FAST>(p, src, L, N, n0,
                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
                                    phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
-                                   W + (long)b * J * N, D + (long)b * N);
+                                   W + (long)b * J * N, D + (long)b * N, 0);
       else
-        replay_chunk<JR, JC, false, FAST>(p, src, L, N, n0,
+        replay_chunk<JR, JC, 0, FAST>(p, src, L, N, n0,
                                     c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
-                                    nullptr, nullptr, nullptr, nullptr);
+                                    nullptr, nullptr, nullptr, nullptr, 0);
       ld += l;
       qd += q;
       bad |= fl;

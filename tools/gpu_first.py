@@ -86,6 +86,17 @@ for layout in ("staged", "interleaved"):
         print("   parity (4 problems): logdet rel %.2e quad rel %.2e" % (
             np.max(np.abs(ld[:4] - d0) / np.abs(d0)), np.max(np.abs(q[:4] - q0) / np.abs(q0))), flush=True)
 plan.set_layout("staged")
+plan.set_chunks(64)
+tot, k = plan.run_timed(3, materialize=True)
+fb = B * N * (3 * 8 + 1) * 8.0
+print("materialize (staged, 64 chunks): %.3f ms/step kernels %s ; factor bytes %.2f GB -> replay write rate %.2f TB/s" % (
+    tot / 3, {a: round(b / 3, 3) for a, b in k.items()}, fb / 1e9, fb / (k["replay"] / 3 * 1e-3) / 1e12), flush=True)
+phi, u, W, D = plan.factor(3)
+rs = ref.RefSolver()
+rs.compute(0.0, *[x[3] for x in a[:6]], np.empty(0), np.empty((0, 0)), np.empty((0, 0)), a[6][3], a[7][3])
+st = rs.state()
+print("factor parity problem 3: phi %.2e u %.2e W %.2e D %.2e" % (
+    np.abs(phi - st[4]).max(), np.abs(u - st[5]).max(), np.abs(W / st[6] - 1).max(), np.abs(D / st[7] - 1).max()), flush=True)
 out["sweep"] = res
 plan.set_chunks(64)
 ll, ld, q, st = plan.log_likelihood()
