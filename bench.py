@@ -173,6 +173,12 @@ def main(argv=None):
     fixed_total_ms, _ = plan.run_timed(max(args.steps // 2, 1), relayout_each_step=False)
     fixed_rate = B * max(args.steps // 2, 1) / (fixed_total_ms * 1e-3)
     plan.set_layout("staged")
+    # the materialising variant (SURVEY.md 8d "A-ref": the factor phi, u, W, D of every
+    # problem written to HBM, as B CholeskySolver.compute calls would) -- HBM-bound
+    mat_steps = max(args.steps // 4, 2)
+    plan.enqueue(materialize=True)
+    plan.synchronize()
+    mat_total_ms, mat_kernel_ms = plan.run_timed(mat_steps, materialize=True)
 
     out = None
     if dist.rank == 0:
@@ -227,6 +233,20 @@ def main(argv=None):
                 "whole_step": {"achieved_tflops": flops / step_s / 1e12,
                                "frac_fp64_valu": flops / step_s / 1e12 / PEAK_FP64_VALU_TFLOPS},
             },
+        }
+        factor_bytes = B * 8.0 * N * (3 * W + 1)           # phi, u, W, D written
+        mat_replay_s = mat_kernel_ms["replay"] / mat_steps * 1e-3
+        out["materialize"] = {
+            "what": "same step, additionally writing the factor (phi, u, W, D) of all problems to HBM",
+            "ms_per_step": mat_total_ms / mat_steps,
+            "value": B / (mat_total_ms / mat_steps * 1e-3) * dist.world,
+            "kernels_ms": {k: v / mat_steps for k, v in mat_kernel_ms.items()},
+            "roofline": {"kernel": "replay (materialising)", "bound": "hbm",
+                         "achieved": (factor_bytes + bytes_) / mat_replay_s / 1e9, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": (factor_bytes + bytes_) / mat_replay_s / 1e9 / PEAK_HBM_GBS,
+                         "bytes_per_launch": factor_bytes + bytes_,
+                         "note": "factor written (8 N (3W+1) B per problem) + t, diag, y read, over the "
+                                 "replay kernel's HIP-event time"},
         }
         if dist.world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, B, N))
