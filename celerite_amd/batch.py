@@ -54,6 +54,8 @@ def _load():
     lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_exact.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
     lib.clr_device_info.argtypes = [C.c_char_p, C.c_size_t, _ip, C.POINTER(C.c_size_t)]
     lib.clr_set_device.argtypes = [C.c_int]
     _lib = lib
@@ -201,7 +203,7 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_factor(self._h, int(p), _ptr(phi), _ptr(u), _ptr(W), _ptr(D)))
         return phi.T, u.T, W.T, D
 
-    KERNEL_NAMES = ("relayout", "summarize", "prefix", "replay", "finalize")
+    KERNEL_NAMES = ("relayout", "summarize", "prefix", "correct", "replay", "finalize")
 
     LAYOUTS = {"rowmajor": 0, "interleaved": 1, "staged": 2}
 
@@ -216,6 +218,17 @@ class BatchedGP(object):
         """Prefix phase with 16 lanes per problem (default) or one (cross-check)."""
         _check(_load().clr_batch_set_prefix_mode(self._h, int(bool(cooperative))))
 
+    def set_exact(self, force=True):
+        """Replay every problem step by step (the reference's recurrence) instead
+        of settling it from the chunk summaries; for A/B runs and cross-checks."""
+        _check(_load().clr_batch_set_exact(self._h, int(bool(force))))
+
+    def exact_count(self):
+        """Problems of the last (synchronised) run that needed the exact replay."""
+        n = C.c_int()
+        _check(_load().clr_batch_get_exact_count(self._h, C.byref(n)))
+        return n.value
+
     def set_library_trig(self, force=True):
         """Use the library (ocml) sincos instead of the FMA Cody-Waite routine
         (which is picked automatically when max|d| * max|t| < 1e9)."""
@@ -225,10 +238,10 @@ class BatchedGP(object):
         """``steps`` back-to-back evaluations bracketed by HIP events on the
         plan's stream.  Returns ``(total_ms, {kernel name: summed ms})``."""
         tot = C.c_double()
-        k = (C.c_double * 5)()
+        k = (C.c_double * 6)()
         _check(_load().clr_batch_run_timed(self._h, int(bool(materialize)), int(steps),
                                            int(bool(relayout_each_step)), C.byref(tot), k))
-        return tot.value, dict(zip(self.KERNEL_NAMES, [k[i] for i in range(5)]))
+        return tot.value, dict(zip(self.KERNEL_NAMES, [k[i] for i in range(6)]))
 
 
 def batch_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y,

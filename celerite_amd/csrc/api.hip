@@ -43,12 +43,16 @@ const BatchLaunchers* find_batch_launchers(int JR, int JC) {
 __global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.B) return;
+  // replay-free sums unless the problem was marked for (or the run forces) the exact replay
+  const bool exact = P.force_exact || P.need_exact[b] != 0;
+  const double* part = exact ? P.partx : P.part;
+  const int* flags = exact ? P.flagsx : P.flags;
   double ld = 0.0, qd = 0.0;
   int bad = 0;
   for (int c = 0; c < P.nchunk; ++c) {
-    ld += P.part[((long)b * P.nchunk + c) * 2 + 0];
-    qd += P.part[((long)b * P.nchunk + c) * 2 + 1];
-    bad |= P.flags[(long)b * P.nchunk + c];
+    ld += part[((long)b * P.nchunk + c) * 2 + 0];
+    qd += part[((long)b * P.nchunk + c) * 2 + 1];
+    bad |= flags[(long)b * P.nchunk + c];
   }
   if (bad) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
     P.out_status[b] = CLR_NOT_POSITIVE_DEFINITE;
@@ -248,12 +252,12 @@ struct clr_batch {
   int coop_prefix = 1;
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
-  DevBuf elems, starts, part, out;  // out: ll | logdet | quad
-  int* flags = nullptr;
+  DevBuf elems, starts, part, partx, out;  // out: ll | logdet | quad
+  int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int* status = nullptr;
+  int force_exact = 0;
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
   DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -477,7 +481,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if ((st = s->ws_elems.reserve((size_t)P.nchunk * L->elem_doubles)) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve((size_t)P.nchunk * L->start_doubles)) != CLR_OK) return st;
     if ((st = s->ws_part.reserve((size_t)P.nchunk * 2)) != CLR_OK) return st;
-    if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk)) != CLR_OK) return st;
+    if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
     P.jitter = s->scratch2.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
@@ -488,6 +492,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.staged = P.nchunk > 1 ? 1 : 0;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
     P.flags = s->ws_flags;
+    // the factor is wanted: always the exact replay, which overwrites the zero-start sums
+    P.partx = P.part; P.flagsx = P.flags; P.need_exact = s->ws_flags + P.nchunk; P.force_exact = 1;
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = s->d_status;
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
@@ -791,7 +797,6 @@ clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
     delete h;
     return nullptr;
   }
-  for (auto& e : h->ev) (void)hipEventCreate(&e);
   if (clr_batch_set_chunks(h, 0) != CLR_OK) {
     clr_batch_destroy(h);
     return nullptr;
@@ -804,13 +809,11 @@ void clr_batch_destroy(clr_batch* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
-                    &h->elems, &h->starts, &h->part, &h->out, &h->phi, &h->u, &h->W, &h->D,
+                    &h->elems, &h->starts, &h->part, &h->partx, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->status) (void)hipFree(h->status);
-  for (auto& e : h->ev)
-    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -829,10 +832,11 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
   if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->out.reserve((size_t)h->B * 3)) != CLR_OK) return st;
   if (h->flags) (void)hipFree(h->flags);
   h->flags = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), pc * sizeof(int)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), (2 * pc + (size_t)h->B) * sizeof(int)));
   if (!h->status) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->status), (size_t)h->B * sizeof(int)));
   return CLR_OK;
 }
@@ -940,6 +944,11 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.staged = (h->layout == 2 && h->nchunk > 1) ? 1 : 0;
   }
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
+  {
+    const size_t pc = B * (size_t)h->nchunk;
+    P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
+    P.force_exact = (materialize || h->force_exact) ? 1 : 0;
+  }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = h->status;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
@@ -955,6 +964,26 @@ static void batch_relayout(clr_batch* h) {
   for (auto& j : jobs)
     clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
                          h->N, h->L, h->nchunk, h->stream);
+}
+
+int clr_batch_set_exact(clr_batch* h, int force) {
+  h->force_exact = force ? 1 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_get_exact_count(clr_batch* h, int* count) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
+  std::vector<int> need((size_t)h->B);
+  const size_t pc = (size_t)h->B * h->nchunk;
+  HIP_TRY(hipMemcpyAsync(need.data(), h->flags + 2 * pc, need.size() * sizeof(int),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int n = 0;
+  for (int v : need) n += v != 0;
+  *count = n;
+  return CLR_OK;
 }
 
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
@@ -985,7 +1014,8 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   }
   h->launch->summarize(P, h->stream);
   h->launch->prefix(P, h->stream);
-  h->launch->replay(P, materialize ? 2 : 0, h->stream);
+  if (!P.force_exact) h->launch->correct(P, h->stream);
+  h->launch->replay(P, materialize ? 2 : 0, h->stream);  // exits at once for settled problems
   clr::launch_finalize(P, h->stream);
   HIP_TRY(hipGetLastError());
   return CLR_OK;
@@ -1045,7 +1075,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     h->relayout_pending = false;
   }
   // one event per kernel boundary per step, all recorded on the handle's stream
-  const int NK = 5;
+  const int NK = 6;
   std::vector<hipEvent_t> ev((size_t)steps * (NK + 1));
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int i = 0; i < steps; ++i) {
@@ -1057,15 +1087,17 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[2], h->stream));
     h->launch->prefix(P, h->stream);
     HIP_TRY(hipEventRecord(e[3], h->stream));
-    h->launch->replay(P, materialize ? 2 : 0, h->stream);
+    if (!P.force_exact) h->launch->correct(P, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
-    clr::launch_finalize(P, h->stream);
+    h->launch->replay(P, materialize ? 2 : 0, h->stream);
     HIP_TRY(hipEventRecord(e[5], h->stream));
+    clr::launch_finalize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[6], h->stream));
   }
   if (relayout_each_step) h->relayout_pending = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  double k[NK] = {0, 0, 0, 0, 0};
+  double k[NK] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < steps; ++i) {
     hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
     for (int j = 0; j < NK; ++j) {

@@ -37,8 +37,15 @@ struct BatchParams {
   int coop_prefix;  // 16 lanes per problem in the prefix phase (0: one lane, the reference version)
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
+  // replay-free path: summarize writes each chunk's ZERO-START sums, correct_kernel
+  // adds the chunk_update corrections and raises need_exact[b] for suspicious problems
   double* part;    // [B][nchunk][2]  (sum log D, sum x^2/D)
-  int* flags;      // [B][nchunk]
+  int* flags;      // [B][nchunk]     zero-start pivot <= 0 seen / chunk suspicious
+  int* need_exact; // [B]             problem must be settled by the exact replay
+  // exact path (replay): only for problems with need_exact, or all if force_exact
+  double* partx;   // [B][nchunk][2]
+  int* flagsx;     // [B][nchunk]     D_n < 0 (n >= 1) seen: cholesky.h:176
+  int force_exact; // materialising runs and clr_batch_set_exact(h, 1)
   double *out_ll, *out_logdet, *out_quad;
   int* out_status;
   // factor, only for materialising runs (replay mode 1: reference storage per
@@ -147,18 +154,28 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
-  const bool store = c < P.nchunk - 1;  // the last chunk's element is never needed
-  if (!STAGED && !store) return;        // (staged: every lane helps loading the tiles)
+  const bool store = c < P.nchunk;
+  if (!STAGED && !store) return;  // (staged: every lane helps loading the tiles)
+  if (c == 0) P.need_exact[b] = 0;
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
-  double* out = P.elems + ((long)b * P.nchunk + (store ? c : 0)) * Wd::ELEM;
+  const long slot = (long)b * P.nchunk + (store ? c : 0);
+  double ld0 = 0.0, q0 = 0.0;
+  int flag0 = 0;
   if (STAGED) {
     StagedSeries src = make_staged(P, b, c, tiles);
-    summarize_chunk<JR, JC, FAST>(p, src, P.L, store, out);
+    summarize_chunk<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, P.elems + slot * Wd::ELEM, &ld0,
+                                  &q0, &flag0);
   } else {
     DirectSeries src = make_direct(P, b, c);
-    summarize_chunk<JR, JC, FAST>(p, src, P.L, store, out);
+    summarize_chunk<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, P.elems + slot * Wd::ELEM, &ld0,
+                                  &q0, &flag0);
   }
+  if (!store) return;
+  P.part[slot * 2 + 0] = ld0;
+  P.part[slot * 2 + 1] = q0;
+  P.flags[slot] = flag0;
+  if (flag0) atomicOr(P.need_exact + b, 1);
 }
 
 template <int JR, int JC>
@@ -173,7 +190,10 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
 #pragma unroll
   for (int i = 0; i < J; ++i) f[i] = 0.0;
   for (int c = 0; c + 1 < P.nchunk; ++c) {
-    apply_element<J>(P.elems + ((long)b * P.nchunk + c) * Wd::ELEM, S, f);
+    double dld, dq;
+    int sus;
+    chunk_update<J>(P.elems + ((long)b * P.nchunk + c) * Wd::ELEM, S, f, false, true, 0.0, 0.0, &dld,
+                    &dq, &sus);
     double* o = P.starts + ((long)b * P.nchunk + c + 1) * Wd::START;
 #pragma unroll
     for (int i = 0; i < Wd::SZ; ++i) o[i] = S[i];
@@ -184,7 +204,7 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
 
 // ---------------------------------------------------------------------------
 // Cooperative prefix: 16 lanes per problem (4 problems per wave) instead of one.
-// Same algebra as apply_element (clr_core.h), distributed column-per-lane:
+// Same algebra as the advance part of chunk_update (clr_core.h), column-per-lane:
 //   lanes 0..7  of a group hold the columns of  M^T = I + P Jm
 //   lanes 8..15 hold the columns of P; Gauss-Jordan on [M^T | P] turns them into
 //               the columns of  G = M^-T P  (pivot row and multipliers are
@@ -333,12 +353,48 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// correct: once the prefix phase has produced every chunk's start state, the
+// corrections of chunk_update (true log-det / quadratic contributions from the
+// zero-start sums, plus the positive-definiteness certificate) depend only on
+// (start state, element) of that chunk: one lane per (problem, chunk), the
+// host-checked single-lane code, ~20 us for 65 536 chunks.  This is what makes the
+// replay pass unnecessary for the fused log-likelihood.
+// ---------------------------------------------------------------------------
+template <int J>
+__global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
+  constexpr int SZ = J * (J + 1) / 2;
+  constexpr int ELEM = J * J + J + SZ + J + SZ;
+  constexpr int START = SZ + J;
+  const long slot = (long)blockIdx.x * 64 + threadIdx.x;
+  if (slot >= (long)P.B * P.nchunk) return;
+  const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
+  if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
+  double S[SZ], f[J];
+  const double* st = P.starts + slot * START;
+#pragma unroll
+  for (int i = 0; i < SZ; ++i) S[i] = st[i];
+#pragma unroll
+  for (int i = 0; i < J; ++i) f[i] = st[SZ + i];
+  double dld = 0.0, dq = 0.0;
+  int sus = 0;
+  chunk_update<J>(P.elems + slot * ELEM, S, f, true, false, P.part[slot * 2 + 0], P.part[slot * 2 + 1],
+                  &dld, &dq, &sus);
+  P.part[slot * 2 + 0] += dld;
+  P.part[slot * 2 + 1] += dq;
+  if (sus) {
+    P.flags[slot] |= 2;
+    atomicOr(P.need_exact + b, 1);
+  }
+}
+
 template <int JR, int JC, int MATERIALIZE, bool FAST, bool STAGED>
 __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
   __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
+  if (!P.force_exact && P.need_exact[b] == 0) return;  // settled by the replay-free path
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool mine = c < P.nchunk;
   if (!STAGED && !mine) return;
@@ -375,15 +431,16 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
                                             W_o, D_o, fstride);
   }
   if (!mine) return;
-  P.part[((long)b * P.nchunk + c) * 2 + 0] = ld;
-  P.part[((long)b * P.nchunk + c) * 2 + 1] = qd;
-  P.flags[(long)b * P.nchunk + c] = flag;
+  P.partx[((long)b * P.nchunk + c) * 2 + 0] = ld;
+  P.partx[((long)b * P.nchunk + c) * 2 + 1] = qd;
+  P.flagsx[(long)b * P.nchunk + c] = flag;
 }
 
 // One table entry per (JR, JC): host-callable launchers.
 struct BatchLaunchers {
   void (*summarize)(const BatchParams&, hipStream_t);
   void (*prefix)(const BatchParams&, hipStream_t);
+  void (*correct)(const BatchParams&, hipStream_t);
   void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
   int elem_doubles, start_doubles;
 };
@@ -391,9 +448,7 @@ struct BatchLaunchers {
 template <int JR, int JC>
 struct BatchImpl {
   static void summarize(const BatchParams& P, hipStream_t s) {
-    if (P.nchunk < 2) return;
-    // staged: the wave that holds the last chunk must exist too (it helps loading)
-    dim3 grid(((P.staged ? P.nchunk : P.nchunk - 1) + 63) / 64, P.B);
+    dim3 grid((P.nchunk + 63) / 64, P.B);
 #define CLR_GO(F, S) hipLaunchKernelGGL((summarize_kernel<JR, JC, F, S>), grid, dim3(64), 0, s, P)
     if (P.fast_trig) { if (P.staged) CLR_GO(true, true); else CLR_GO(true, false); }
     else             { if (P.staged) CLR_GO(false, true); else CLR_GO(false, false); }
@@ -406,6 +461,12 @@ struct BatchImpl {
     else
       hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
   }
+  static void correct(const BatchParams& P, hipStream_t s) {
+    if (P.nchunk < 2) return;
+    const long lanes = (long)P.B * P.nchunk;
+    hipLaunchKernelGGL((correct_kernel<JR + 2 * JC>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s,
+                       P);
+  }
   static void replay(const BatchParams& P, int materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
 #define CLR_GO(M, F, S) hipLaunchKernelGGL((replay_kernel<JR, JC, M, F, S>), grid, dim3(64), 0, s, P)
@@ -417,7 +478,7 @@ struct BatchImpl {
 #undef CLR_GO
   }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &replay, Widths<JR, JC>::ELEM,
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, Widths<JR, JC>::ELEM,
                           Widths<JR, JC>::START};
   }
 };

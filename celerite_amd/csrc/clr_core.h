@@ -285,8 +285,8 @@ CLR_HD void decay_rank1_update(const double* phid, const double* z, const double
 //   A[J*J] row-major | b[J] | C[SZ] | eta[J] | Jm[SZ]
 // ---------------------------------------------------------------------------
 template <int JR, int JC, bool FAST, class Src>
-CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool store,
-                            double* elem_out) {
+CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, int N, bool store,
+                            double* elem_out, double* ld0_out, double* q0_out, int* flag0_out) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   // State: 152 doubles at J = 8, more than the 128 that 256 VGPRs hold; the compiler
@@ -306,11 +306,16 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
   CLR_UNROLL
   for (int i = 0; i < SZ; ++i) { C[i] = 0.0; Jm[i] = 0.0; }
 
-  // A summarised chunk is always a full one (L samples) followed by at least one
-  // more sample, so t is read up to local index L.  Lanes without a chunk to
-  // summarise (store == false) run the same L steps on whatever they read -- the
-  // loop count must be wave-uniform for the staged source -- and store nothing.
+  // Every lane runs L steps (the loop count must be wave-uniform for the staged
+  // source).  Steps at or beyond the end of the series (the short last chunk, lanes
+  // past the last chunk) run on padding: they must not touch the accumulate-only
+  // outputs (Jm, eta, the zero-start sums); what they do to A, C, b is irrelevant
+  // because the last chunk's element is never applied.
   const int len = L;
+  double q0 = 0.0;
+  LogProduct lp0;
+  lp0.init();
+  int flag0 = 0;
   src.prologue();
   double tn = src.t(0);
   double t_next = src.t(1), diag_n = src.diag(0), y_n = src.y(0);
@@ -342,6 +347,15 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
     const double D = p.diagonal(diag_cur) - s;
     const double invD = 1.0 / D;
     const double x = y_cur - ub;
+    const bool valid = n0 + i < N;
+    // zero-start sums of this chunk (corrected for the true start state by
+    // chunk_correction); a zero-start pivot <= 0 means the chunk's own block of K is
+    // not positive definite: the problem is sent to the exact replay
+    if (valid) {
+      if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
+      lp0.mul(D);
+      q0 += x * x * invD;
+    }
     const double xs = x * invD;
 
     double z[J], W[J], pw[J];
@@ -363,19 +377,25 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
       for (int k = 0; k < J; ++k)
         Acol[j * J + k] = phid[phi_index<JR>(k)] * Acol[j * J + k] - pw[k] * racc;
     }
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) {
-      const double rsj = r[j] * invD;
-      eta[j] -= r[j] * xs;
+    if (valid) {  // (a select, not a multiply by 0: padding steps may carry inf / NaN)
       CLR_UNROLL
-      for (int k = 0; k <= j; ++k) Jm[tri(k, j)] -= r[k] * rsj;
-      b[j] = phid[phi_index<JR>(j)] * (b[j] + W[j] * x);
+      for (int j = 0; j < J; ++j) {
+        const double rsj = r[j] * invD;
+        eta[j] -= r[j] * xs;
+        CLR_UNROLL
+        for (int k = 0; k <= j; ++k) Jm[tri(k, j)] -= r[k] * rsj;
+      }
     }
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) b[j] = phid[phi_index<JR>(j)] * (b[j] + W[j] * x);
     decay_rank1_update<JR, JC>(phid, z, W, C);
     tn = t_cur_next;
     src.step_end(i);
   }
   if (!store) return;
+  *ld0_out = lp0.log_value();
+  *q0_out = q0;
+  *flag0_out = flag0;
 
   double* o = elem_out;  // A is written row-major
   CLR_UNROLL
@@ -398,14 +418,112 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, bool stor
 }
 
 // ---------------------------------------------------------------------------
-// prefix: apply one transfer element to a state.  (P, f) are updated in place.
-//   M^T = I + P Jm ;  [G | g] = M^-T [P | f + P eta]   (G = P (I + Jm P)^-1, symmetric)
-//   P' = C + A G A^T ;  f' = A g + b
-// Gaussian elimination with partial pivoting; rows are exchanged with selects
-// so that every index stays a compile-time constant (registers, no scratch).
+// prefix: one chunk of the sequential phase.  Given the state (P, f) at the
+// chunk's first sample and the chunk's element (A, b, C, eta, Jm):
+//
+//  (1) the chunk's TRUE contributions to log det K and b^T K^-1 b from its
+//      zero-start sums, WITHOUT replaying it.  With N = -Jm = O^T D0^-1 O >= 0 and
+//      eta = -O^T D0^-1 x0 (O: the chunk's whitened observation map, rows r_n^T):
+//        sum log D   = sum log D0 + log det(I + Jm P)            (determinant lemma)
+//        sum x^2 / D = sum x0^2 / D0 + 2 eta.f - f.Jm f + w.G w  (Woodbury)
+//        w = Jm f - eta ,  G = P (I + Jm P)^-1
+//      (check: one step gives log(a - u.Pu) and (y - u.f)^2 / (a - u.Pu));
+//  (2) the state at the next chunk's first sample:
+//        P' = C + A G A^T ,  f' = A (I + P Jm)^-1 (f + P eta) + b .
+//
+// VALUES come from one Gauss-Jordan elimination with partial pivoting on
+// [M^T | P | h], M^T = I + P Jm, h = f + P eta (rows are exchanged with selects so
+// every index stays a compile-time constant): G = M^-T P, g = M^-T h, and det M from
+// the pivots.  N (entries ~1e5) and P (graded, with tiny directions) multiply to
+// O(1) eigenvalues; the LU of M keeps 1e-13 accuracy there, whereas factorising N or
+// P first (a symmetric route through I - F^T P F) was measured to lose 6+ digits.
+//
+// CERTIFICATE.  The reference throws when a true pivot D_n < 0 (cholesky.h:176).
+// The chunk has only positive true pivots iff its block conditioned on the past is
+// positive definite iff every eigenvalue 1 - lambda_i(N P) of M is positive.  det M
+// > 0 alone would miss an even number of negative ones, so positivity is certified
+// by a sufficient test that needs no accuracy: with F F^T = N + delta I (un-pivoted
+// Cholesky is stable for the regularised matrix, and over-estimating N only makes
+// the test stricter), I - F^T P F must have a Cholesky factorisation with pivots
+// > 1e-5.  The smallest pivot mu also estimates the conditioning of M: the chunk is
+// marked SUSPICIOUS -- and the caller runs the exact replay for that problem -- when
+// the certificate fails, when det M <= 0, when J eps / mu exceeds 3e-12 of the
+// chunk's own log-det or quadratic contribution (tiny chunks only), or when
+// anything is non-finite.
+// Single-lane form (host check, single-lane prefix kernel); prefix_coop_kernel
+// distributes the same algebra over 16 lanes.
 // ---------------------------------------------------------------------------
 template <int J>
-CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J]*/) {
+CLR_HD double pd_certificate(const double* P /*[SZ]*/, const double* Jm /*[SZ]*/) {
+  // returns the smallest Cholesky pivot of I - F^T P F (<= 0 when it breaks down)
+  double F[J][J], S[J][J];
+  double nmax = 0.0;
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) nmax = fmax(nmax, -Jm[tri(i, i)]);
+  const double delta = 4e-13 * nmax;
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) S[i][j] = -Jm[sym(i, j)] + ((i == j) ? delta : 0.0);
+  }
+  CLR_UNROLL
+  for (int k = 0; k < J; ++k) {
+    const double rs = 1.0 / sqrt(S[k][k]);
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) F[i][k] = (i >= k) ? S[i][k] * rs : 0.0;
+    CLR_UNROLL
+    for (int i = k + 1; i < J; ++i) {
+      CLR_UNROLL
+      for (int j = k + 1; j <= i; ++j) {
+        S[i][j] -= F[i][k] * F[j][k];
+        S[j][i] = S[i][j];
+      }
+    }
+  }
+  double PF[J][J], E[J][J];
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int k = 0; k < J; ++k) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int m = k; m < J; ++m) acc += P[sym(i, m)] * F[m][k];
+      PF[i][k] = acc;
+    }
+  }
+  CLR_UNROLL
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL
+    for (int k = 0; k <= j; ++k) {
+      double acc = (j == k) ? 1.0 : 0.0;
+      CLR_UNROLL
+      for (int i = k; i < J; ++i) acc -= F[i][k] * PF[i][j];
+      E[j][k] = acc;
+    }
+  }
+  double mu = 1.0;
+  bool broke = false;
+  CLR_UNROLL
+  for (int k = 0; k < J; ++k) {
+    const double d = E[k][k];
+    if (!(d > 0.0)) broke = true;
+    mu = (d < mu) ? d : mu;
+    const double rs = 1.0 / sqrt(d);
+    CLR_UNROLL
+    for (int i = k; i < J; ++i) E[i][k] *= rs;
+    CLR_UNROLL
+    for (int i = k + 1; i < J; ++i) {
+      CLR_UNROLL
+      for (int j = k + 1; j <= i; ++j) E[i][j] -= E[i][k] * E[j][k];
+    }
+  }
+  return broke ? -1.0 : mu;
+}
+
+template <int J>
+CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]*/, bool correct,
+                         bool advance, double ld0, double q0, double* dld, double* dq,
+                         int* suspicious) {
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int NC = 2 * J + 1;  // [ M^T | P | h ]
   const double* A = elem;
@@ -430,9 +548,9 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
     T[i][2 * J] = h;
   }
 
+  double det = 1.0;
   CLR_UNROLL
   for (int col = 0; col < J; ++col) {
-    // pivot search
     int piv = col;
     double best = fabs(T[col][col]);
     CLR_UNROLL
@@ -442,7 +560,6 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
       best = take ? cand : best;
       piv = take ? i : piv;
     }
-    // bring the pivot row to position `col`
     CLR_UNROLL
     for (int c = col; c < NC; ++c) {
       double top = T[col][c];
@@ -455,6 +572,7 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
       }
       T[col][c] = top;
     }
+    det *= (piv != col) ? -T[col][col] : T[col][col];
     const double inv = 1.0 / T[col][col];
     CLR_UNROLL
     for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
@@ -466,38 +584,72 @@ CLR_HD void apply_element(const double* elem, double* P /*[SZ]*/, double* f /*[J
       for (int c = col + 1; c < NC; ++c) T[i][c] -= m * T[col][c];
     }
   }
-  // now T[i][J + j] = G[i][j], T[i][2J] = g[i]  (Gauss-Jordan: no back-substitution)
+  // now T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
 
-  double AG[J][J];
-  CLR_UNROLL
-  for (int i = 0; i < J; ++i) {
+  if (correct) {
+    int bad = 0;
+    const double mu = pd_certificate<J>(P, Jm);
+    if (!(mu > 1e-5)) bad = 1;
+    if (!(det > 0.0)) bad = 1;
+    double w[J];
+    double ef = 0.0, fJf = 0.0;
     CLR_UNROLL
-    for (int j = 0; j < J; ++j) {
+    for (int i = 0; i < J; ++i) {
       double acc = 0.0;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) {
-        // symmetrised G: average of the two computed halves
-        acc += A[i * J + k] * (0.5 * (T[k][J + j] + T[j][J + k]));
-      }
-      AG[i][j] = acc;
+      for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * f[k];
+      w[i] = acc - eta[i];
+      ef += eta[i] * f[i];
+      fJf += f[i] * acc;
     }
-  }
-  CLR_UNROLL
-  for (int j = 0; j < J; ++j) {
+    double wGw = 0.0;
     CLR_UNROLL
-    for (int k = 0; k <= j; ++k) {
-      double acc = C[tri(k, j)];
+    for (int i = 0; i < J; ++i) {
+      double acc = 0.0;
       CLR_UNROLL
-      for (int i = 0; i < J; ++i) acc += AG[k][i] * A[j * J + i];
-      P[tri(k, j)] = acc;
+      for (int k = 0; k < J; ++k) acc += 0.5 * (T[i][J + k] + T[k][J + i]) * w[k];
+      wGw += w[i] * acc;
     }
+    const double q = 2.0 * ef - fJf + wGw;
+    const double ld = log(det);
+    const double err = J * 2.2e-16 / mu;  // rounding-error estimate of the corrections
+    if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
+    if (!(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
+    if (!isfinite(q) || !isfinite(ld)) bad = 1;
+    *dld = ld;
+    *dq = q;
+    *suspicious = bad;
   }
-  CLR_UNROLL
-  for (int i = 0; i < J; ++i) {
-    double acc = b[i];
+
+  if (advance) {
+    double AG[J][J];
     CLR_UNROLL
-    for (int k = 0; k < J; ++k) acc += A[i * J + k] * T[k][2 * J];
-    f[i] = acc;
+    for (int i = 0; i < J; ++i) {
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) acc += A[i * J + k] * (0.5 * (T[k][J + j] + T[j][J + k]));
+        AG[i][j] = acc;
+      }
+    }
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k) {
+        double acc = C[tri(k, j)];
+        CLR_UNROLL
+        for (int i = 0; i < J; ++i) acc += AG[k][i] * A[j * J + i];
+        P[tri(k, j)] = acc;
+      }
+    }
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) {
+      double acc = b[i];
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += A[i * J + k] * T[k][2 * J];
+      f[i] = acc;
+    }
   }
 }
 

@@ -187,6 +187,16 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
 /* Prefix phase: 16 lanes per problem (default) or the single-lane version (kept as
  * the on-device cross-check and for A/B measurements). */
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
+/* The fused log-likelihood normally needs no second pass over the series: each
+ * chunk's true log-det / quadratic contributions follow from its zero-start sums and
+ * its start state (determinant lemma + Woodbury), and only
+ * problems with a chunk the positive-definiteness certificate or the error estimate
+ * cannot settle are re-run through the exact replay.  force != 0 replays every
+ * problem (the reference's recurrence step by step; for A/B measurements and as the
+ * on-device cross-check).  Materialising runs always replay. */
+int clr_batch_set_exact(clr_batch* h, int force);
+/* After a synchronised run: how many problems went through the exact replay. */
+int clr_batch_get_exact_count(clr_batch* h, int* count);
 /* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);
@@ -207,15 +217,15 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
 int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D);
 
 /* Runs `steps` evaluations back to back, bracketing every kernel with HIP
- * events recorded on the handle's stream.  kernel_ms[5] receives the SUMMED
- * device time of the relayout / summarise / prefix / replay / finalise
+ * events recorded on the handle's stream.  kernel_ms[6] receives the SUMMED
+ * device time of the relayout / summarise / prefix / correct / replay / finalise
  * kernels, total_ms the first-event-to-last-event time.  In layout 1 only:
  * with relayout_each_step != 0 the row-major -> interleaved transposition is
  * redone inside every step (the cost when every evaluation brings NEW series);
  * otherwise it is done once, outside the timed region (fixed series, new
  * hyper-parameters: the MCMC / optimiser loop of celerite.py:160-219). */
 int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
-                        double* total_ms, double* kernel_ms /* [5] */);
+                        double* total_ms, double* kernel_ms /* [6] */);
 
 /* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,

@@ -98,3 +98,26 @@ def coeffs_of(case, p=None):
 
 
 ALL_WIDTH_SHAPES = [(jr, jc) for jc in range(5) for jr in range(9) if 1 <= jr + 2 * jc <= 8]
+
+
+def adversarial(B, N, J_real, J_comp, seed=0):
+    """Near-singular and outright indefinite problems: white noise from exactly zero
+    to 0.1, amplitudes over four decades with ~10 % negative ones, time spans from
+    0.1 to 1000.  About a sixth of them make the reference throw linalg_exception
+    (cholesky.h:176); most of the rest have condition numbers of 1e6 and beyond, where
+    the reference's own recurrence is only accurate to cond * eps (checked against a
+    60-digit dense factorisation during development)."""
+    rng = np.random.RandomState(seed)
+    span = 10 ** rng.uniform(-1, 3)
+    t = np.sort(rng.uniform(0, span, (B, N)), axis=1)
+    kind = rng.randint(0, 5)
+    diag = {0: np.zeros((B, N)), 1: np.full((B, N), 1e-12), 2: 10 ** rng.uniform(-10, 0, (B, N)),
+            3: np.full((B, N), 1e-6), 4: rng.uniform(0.01, 0.1, (B, N))}[kind]
+    a_real = 10 ** rng.uniform(-2, 2, (B, J_real)) * np.where(rng.rand(B, J_real) < 0.15, -1, 1)
+    c_real = 10 ** rng.uniform(-3, 2, (B, J_real))
+    a_comp = 10 ** rng.uniform(-2, 2, (B, J_comp)) * np.where(rng.rand(B, J_comp) < 0.1, -1, 1)
+    b_comp = a_comp * rng.uniform(-1.5, 1.5, (B, J_comp)) * (rng.rand(B, J_comp) < 0.5)
+    c_comp = 10 ** rng.uniform(-3, 1, (B, J_comp))
+    d_comp = 10 ** rng.uniform(-2, 2, (B, J_comp))
+    return dict(a_real=a_real, c_real=c_real, a_comp=a_comp, b_comp=b_comp, c_comp=c_comp,
+                d_comp=d_comp, t=t, diag=diag, y=rng.randn(B, N))

@@ -18,9 +18,9 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
                const double* c_real, const double* a_comp, const double* b_comp,
                const double* c_comp, const double* d_comp, const double* t, long ts,
                const double* diag, long ds, const double* y, long ys, int materialize,
-               int interleaved,
+               int interleaved, int exact,
                double* ll, double* logdet, double* quad, int* status, double* phi, double* u,
-               double* W, double* D) {
+               double* W, double* D, int* used_exact) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J;
   const int L = (N + nchunk - 1) / nchunk;
@@ -47,40 +47,58 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
     auto lane = [&](int c) {
       return DirectSeries{tb + c * cs, db + c * cs, yb + c * cs, is, cs, L, (long)N - (long)c * L};
     };
-    for (int c = 0; c + 1 < nchunk; ++c) {
-      if ((c + 1) * L >= N) continue;  // element would run past the data; never applied
-      DirectSeries src = lane(c);
-      summarize_chunk<JR, JC, FAST>(p, src, L, true, &elems[(size_t)c * Wd::ELEM]);
-    }
-    double S[Wd::SZ] = {0}, f[J] = {0};
-    for (int c = 0; c + 1 < nchunk; ++c) {
-      if ((c + 1) * L >= N) break;
-      apply_element<J>(&elems[(size_t)c * Wd::ELEM], S, f);
-      memcpy(&starts[(size_t)(c + 1) * Wd::START], S, sizeof(S));
-      memcpy(&starts[(size_t)(c + 1) * Wd::START + Wd::SZ], f, sizeof(f));
-    }
-    double ld = 0, qd = 0;
-    int bad = 0;
+    // summarize every chunk that has data (zero-start sums + element)
+    std::vector<double> ld0(nchunk, 0.0), q0(nchunk, 0.0);
+    std::vector<int> fl0(nchunk, 0);
+    int nreal = 0;
     for (int c = 0; c < nchunk; ++c) {
-      const int n0 = c * L;
-      if (n0 >= N) break;
-      double l, q;
-      int fl;
-      const long Nm1 = N - 1;
+      if ((long)c * L >= N) break;
+      nreal = c + 1;
       DirectSeries src = lane(c);
-      if (materialize)
-        replay_chunk<JR, JC, 1, FAST>(p, src, L, N, n0,
-                                   c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
-                                   phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
-                                   W + (long)b * J * N, D + (long)b * N, 0);
-      else
-        replay_chunk<JR, JC, 0, FAST>(p, src, L, N, n0,
-                                    c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
-                                    nullptr, nullptr, nullptr, nullptr, 0);
-      ld += l;
-      qd += q;
-      bad |= fl;
+      summarize_chunk<JR, JC, FAST>(p, src, L, c * L, N, true, &elems[(size_t)c * Wd::ELEM], &ld0[c],
+                                    &q0[c], &fl0[c]);
     }
+    // prefix: corrections with the incoming state, then advance
+    double S[Wd::SZ] = {0}, f[J] = {0};
+    double ld = 0, qd = 0;
+    int need_exact = 0;
+    for (int c = 0; c < nreal; ++c) {
+      double dld = 0, dq = 0;
+      int sus = 0;
+      // chunk 0 starts from the zero state: no correction (E = I)
+      chunk_update<J>(&elems[(size_t)c * Wd::ELEM], S, f, c > 0, c + 1 < nreal, ld0[c], q0[c], &dld,
+                      &dq, &sus);
+      ld += ld0[c] + dld;
+      qd += q0[c] + dq;
+      need_exact |= sus | fl0[c];
+      if (c + 1 < nreal) {
+        memcpy(&starts[(size_t)(c + 1) * Wd::START], S, sizeof(S));
+        memcpy(&starts[(size_t)(c + 1) * Wd::START + Wd::SZ], f, sizeof(f));
+      }
+    }
+    int bad = 0;
+    if (exact || need_exact || materialize) {  // the exact replay (reference semantics)
+      ld = 0;
+      qd = 0;
+      for (int c = 0; c < nreal; ++c) {
+        const int n0 = c * L;
+        double l, q;
+        int fl;
+        const long Nm1 = N - 1;
+        DirectSeries src = lane(c);
+        if (materialize)
+          replay_chunk<JR, JC, 1, FAST>(p, src, L, N, n0, c ? &starts[(size_t)c * Wd::START] : nullptr,
+                                        &l, &q, &fl, phi + (long)b * J * Nm1, u + (long)b * J * Nm1,
+                                        W + (long)b * J * N, D + (long)b * N, 0);
+        else
+          replay_chunk<JR, JC, 0, FAST>(p, src, L, N, n0, c ? &starts[(size_t)c * Wd::START] : nullptr,
+                                        &l, &q, &fl, nullptr, nullptr, nullptr, nullptr, 0);
+        ld += l;
+        qd += q;
+        bad |= fl;
+      }
+    }
+    used_exact[b] = (exact || need_exact || materialize) ? 1 : 0;
     status[b] = bad ? 2 : 0;
     logdet[b] = bad ? NAN : ld;
     quad[b] = bad ? NAN : qd;
@@ -92,21 +110,22 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
 #define CASE(R, C)                                                                          \
   if (JR == R && JC == C && fast)                                                           \
     return run<R, C, true>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp,    \
-                           d_comp, t, ts, diag, ds, y, ys, materialize, interleaved, ll,    \
-                           logdet, quad, status, phi, u, W, D);                             \
+                           d_comp, t, ts, diag, ds, y, ys, materialize, interleaved, exact, \
+                           ll, logdet, quad, status, phi, u, W, D, used_exact);             \
   if (JR == R && JC == C)                                                                   \
     return run<R, C, false>(B, N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,  \
-                     t, ts, diag, ds, y, ys, materialize, interleaved, ll, logdet, quad,    \
-                     status, phi, u, W, D);
+                     t, ts, diag, ds, y, ys, materialize, interleaved, exact, ll, logdet,   \
+                     quad, status, phi, u, W, D, used_exact);
 
 extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const double* jitter,
                                const double* a_real, const double* c_real,
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp, const double* t,
                                long ts, const double* diag, long ds, const double* y, long ys,
-                               int materialize, int interleaved, int fast, double* ll,
-                               double* logdet, double* quad,
-                               int* status, double* phi, double* u, double* W, double* D) {
+                               int materialize, int interleaved, int fast, int exact,
+                               double* ll, double* logdet, double* quad,
+                               int* status, double* phi, double* u, double* W, double* D,
+                               int* used_exact) {
   CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(0, 2) CASE(2, 2)
   CASE(2, 3) CASE(0, 4) CASE(4, 2) CASE(8, 0)
   return -1;

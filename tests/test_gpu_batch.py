@@ -11,7 +11,7 @@ import pytest
 
 from celerite_amd import batch
 from oracle import ref
-from _cases import ALL_WIDTH_SHAPES, synthetic, coeffs_of
+from _cases import ALL_WIDTH_SHAPES, synthetic, adversarial, coeffs_of
 
 pytestmark = pytest.mark.gpu
 REL = 1e-10
@@ -123,7 +123,7 @@ def test_results_independent_of_chunking_and_layout():
 @pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
 def test_prefix_modes_agree(JR, JC):
     """The 16-lanes-per-problem prefix kernel against the single-lane one (the
-    same algebra as the host-checked apply_element) and against the oracle."""
+    host-checked chunk_update) and against the oracle."""
     case = synthetic(7, 6000, JR, JC, "accuracy" if (JR + JC) % 2 else "bench", seed=JR + 9 * JC)
     plan = batch.BatchedGP(7, 6000, JR, JC)
     plan.set_series(case["t"], case["diag"], case["y"])
@@ -140,6 +140,92 @@ def test_prefix_modes_agree(JR, JC):
         assert np.array_equal(st, s0), key
         assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, key
         assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, key
+
+
+@pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
+def test_replay_free_path_against_exact_replay(JR, JC):
+    """The fused log-likelihood is settled from the chunk summaries (determinant
+    lemma + Woodbury, chunk_update in clr_core.h) without a second pass; forcing the
+    exact replay (the reference's recurrence, step by step) must give the same numbers,
+    and well-conditioned problems must not need the replay at all."""
+    case = synthetic(6, 8000, JR, JC, "bench" if (JR + JC) % 2 else "accuracy", seed=3 * JR + JC)
+    plan = batch.BatchedGP(6, 8000, JR, JC)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    for nchunk in (8, 64, 250):
+        plan.set_chunks(nchunk)
+        plan.set_exact(False)
+        fast = plan.log_likelihood()
+        assert plan.exact_count() == 0
+        plan.set_exact(True)
+        exact = plan.log_likelihood()
+        for out in (fast, exact):
+            assert np.array_equal(out[3], s0)
+            assert np.max(np.abs(out[1] - d0) / np.abs(d0)) <= REL
+            assert np.max(np.abs(out[2] - q0) / np.abs(q0)) <= REL
+        assert np.max(np.abs(fast[1] - exact[1]) / np.abs(exact[1])) <= 1e-11
+        assert np.max(np.abs(fast[2] - exact[2]) / np.abs(exact[2])) <= 1e-11
+    plan.close()
+
+
+def test_indefinite_only_once_conditioned_on_the_past():
+    """Every chunk's own block is positive definite (zero-start pivots > 0) but the
+    matrix is not: only the certificate of the replay-free path can notice.  The
+    problem must be routed to the exact replay and get the reference's status, and
+    its well-behaved neighbours in the batch must not be affected."""
+    rng = np.random.RandomState(12)
+    B, N = 5, 400
+    t = np.sort(rng.uniform(0, 40, (B, N)), axis=1)
+    case = dict(a_real=np.tile([3.0, 2.9], (B, 1)), c_real=np.tile([0.05, 0.06], (B, 1)),
+                a_comp=np.empty((B, 0)), b_comp=np.empty((B, 0)), c_comp=np.empty((B, 0)),
+                d_comp=np.empty((B, 0)), t=t, diag=np.full((B, N), 1e-3), y=np.sin(t))
+    case["a_real"][1, 1] = -2.9
+    case["a_real"][3, 1] = -2.9
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    assert list(s0) == [0, 2, 0, 2, 0]
+    plan = batch.BatchedGP(B, N, 2, 0)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    for nchunk in (4, 25, 50):
+        plan.set_chunks(nchunk)
+        ll, ld, q, st = plan.log_likelihood()
+        assert np.array_equal(st, s0)
+        assert 2 <= plan.exact_count() <= B
+        ok = s0 == 0
+        assert np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
+        assert np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])) <= REL
+        assert np.all(np.isneginf(ll[~ok]))
+    plan.close()
+
+
+def test_adversarial_problems_keep_the_reference_status():
+    """tests/_cases.adversarial (near-singular and indefinite problems): the status
+    word must be the oracle's for every problem whatever route settles it; values only
+    loosely (the reference itself is cond * eps from the exact answer there)."""
+    shapes = [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 2), (2, 3), (0, 4), (4, 2), (8, 0), (3, 0)]
+    n_bad = n_exact = n_total = 0
+    for trial in range(36):
+        JR, JC = shapes[trial % len(shapes)]
+        N = (50, 200, 1000)[trial % 3]
+        case = adversarial(4, N, JR, JC, seed=1000 + trial)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        n_bad += int((s0 != 0).sum())
+        plan = batch.BatchedGP(4, N, JR, JC)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        for nchunk in (max(2, N // 40), max(2, N // 8)):
+            plan.set_chunks(nchunk)
+            ll, ld, q, st = plan.log_likelihood()
+            assert np.array_equal(st, s0), (trial, nchunk)
+            n_total += 4
+            n_exact += plan.exact_count()
+            ok = (s0 == 0) & np.isfinite(d0) & np.isfinite(q0)
+            if ok.any():
+                assert np.max(np.abs(ld[ok] - d0[ok]) / (1 + np.abs(d0[ok]))) < 1e-5
+                assert np.max(np.abs(q[ok] - q0[ok]) / (1 + np.abs(q0[ok]))) < 1e-4
+        plan.close()
+    assert n_bad >= 6 and 0 < n_exact < n_total
 
 
 def test_prefix_modes_with_failures_and_ragged_batch():

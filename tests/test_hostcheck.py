@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import ref
-from _cases import synthetic, coeffs_of
+from _cases import synthetic, adversarial, coeffs_of
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
 SO = os.path.join(HERE, "libhostcheck.so")
@@ -29,13 +29,14 @@ def lib():
     return C.CDLL(SO)
 
 
-def run(lib, JR, JC, nchunk, case, interleaved, materialize=False, fast=True):
+def run(lib, JR, JC, nchunk, case, interleaved, materialize=False, fast=True, exact=False):
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
     B, N = case["t"].shape
     J = JR + 2 * JC
     ll, ld, q = np.empty(B), np.empty(B), np.empty(B)
     st = np.zeros(B, dtype=np.int32)
+    used = np.zeros(B, dtype=np.int32)
     phi, u = np.zeros((B, max(N - 1, 1), J)), np.zeros((B, max(N - 1, 1), J))
     W, D = np.zeros((B, N, J)), np.zeros((B, N))
     jit = np.zeros(B)
@@ -44,9 +45,10 @@ def run(lib, JR, JC, nchunk, case, interleaved, materialize=False, fast=True):
     rc = lib.hostcheck_batch(B, N, JR, JC, nchunk, P(jit), *[k.ctypes.data_as(dp) for k in keep[:6]],
                              keep[6].ctypes.data_as(dp), C.c_long(N), keep[7].ctypes.data_as(dp),
                              C.c_long(N), keep[8].ctypes.data_as(dp), C.c_long(N), int(materialize),
-                             int(interleaved), int(fast), P(ll), P(ld), P(q), st.ctypes.data_as(ip),
-                             P(phi), P(u), P(W), P(D))
+                             int(interleaved), int(fast), int(exact), P(ll), P(ld), P(q),
+                             st.ctypes.data_as(ip), P(phi), P(u), P(W), P(D), used.ctypes.data_as(ip))
     assert rc == 0
+    run.used_exact = used
     return ll, ld, q, st, (phi, u, W, D)
 
 
@@ -56,8 +58,12 @@ def test_scan_matches_oracle(lib, JR, JC, family):
     for N, nchunk in [(1, 1), (2, 1), (7, 3), (100, 1), (1000, 7), (1000, 64), (3000, 100)]:
         case = synthetic(3, N, JR, JC, family, seed=N + 10 * JR + JC)
         l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
-        for inter, fast in ((0, True), (1, True), (1, False)):
-            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter, fast=fast)
+        for inter, fast, exact in ((0, True, False), (1, True, False), (1, False, False), (1, True, True)):
+            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter, fast=fast, exact=exact)
+            if not exact and N >= 1000 and nchunk <= N // 8:
+                # positive-definite problems with chunks of >= 8 samples must be settled by
+                # the replay-free path (chunk_correction), not by the exact fallback
+                assert not run.used_exact.any()
             assert np.array_equal(st, s0)
             assert np.max(np.abs(ld - d0) / np.abs(d0)) < 1e-11
             assert np.max(np.abs(q - q0) / np.abs(q0)) < 1e-11
@@ -87,6 +93,7 @@ def test_not_positive_definite_is_flagged_not_propagated(lib):
     for nchunk in (1, 5, 40):
         ll, ld, q, st, _ = run(lib, 1, 0, nchunk, case, 1)
         assert list(st) == [0, 2, 0]
+        assert run.used_exact[1] == 1 or nchunk == 1  # flagged by the zero-start pivots -> exact replay
         assert ll[1] == -np.inf
         for p in (0, 2):
             assert abs(ld[p] - d0[p]) < 1e-11 * abs(d0[p]) and abs(q[p] - q0[p]) < 1e-11 * abs(q0[p])
@@ -119,3 +126,50 @@ def test_phase_sincos_and_log_product(lib):
         assert abs(lib.hostcheck_logprod(5000, d.ctypes.data_as(dp)) - 5000 * np.log(scale)) < 1e-9
     z = np.array([2.0, 0.0, 3.0])
     assert lib.hostcheck_logprod(3, z.ctypes.data_as(dp)) == -np.inf  # D = 0: cholesky.h:208 gives -inf too
+
+
+def test_indefinite_chunks_are_caught_by_the_inertia_check(lib):
+    """A matrix that is NOT positive definite although every chunk's own block is:
+    the failure only shows once a chunk is conditioned on the past.  Zero-start
+    pivots stay positive, so only the certificate of chunk_update (or det(I + Jm P))
+    can flag it; the problem must be routed to the exact replay and come out with
+    the oracle's status."""
+    rng = np.random.RandomState(12)
+    N = 400
+    t = np.sort(rng.uniform(0, 40, (1, N)), axis=1)
+    # a_real = (+3, -2.9): k(0) > 0 and small blocks are PD, the long-range part is not
+    case = dict(a_real=np.array([[3.0, -2.9]]), c_real=np.array([[0.05, 0.06]]),
+                a_comp=np.empty((1, 0)), b_comp=np.empty((1, 0)), c_comp=np.empty((1, 0)),
+                d_comp=np.empty((1, 0)), t=t, diag=np.full((1, N), 1e-3), y=np.sin(t))
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    assert s0[0] == 2, "test kernel is expected to be indefinite"
+    for nchunk in (4, 25, 50):
+        ll, ld, q, st, _ = run(lib, 2, 0, nchunk, case, 1)
+        assert st[0] == 2 and ll[0] == -np.inf
+        assert run.used_exact[0] == 1
+
+
+def test_adversarial_problems_keep_the_reference_status(lib):
+    """Near-singular / indefinite problems (tests/_cases.adversarial): whatever the
+    replay-free path decides, the status word (linalg_exception or not) must be the
+    oracle's for every problem, chunking and width; values are compared only loosely
+    because at these condition numbers the reference itself is cond * eps away from
+    the exact answer."""
+    n_bad = n_exact = n_total = 0
+    for trial in range(60):
+        JR, JC = SHAPES[trial % len(SHAPES)]
+        N = (50, 200, 1000)[trial % 3]
+        case = adversarial(4, N, JR, JC, seed=1000 + trial)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        n_bad += int((s0 != 0).sum())
+        for nchunk in (max(2, N // 40), max(2, N // 8)):
+            ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, 1)
+            assert np.array_equal(st, s0), (trial, nchunk)
+            n_total += 4
+            n_exact += int(run.used_exact.sum())
+            ok = (s0 == 0) & np.isfinite(d0) & np.isfinite(q0)
+            if ok.any():
+                assert np.max(np.abs(ld[ok] - d0[ok]) / (1 + np.abs(d0[ok]))) < 1e-5
+                assert np.max(np.abs(q[ok] - q0[ok]) / (1 + np.abs(q0[ok]))) < 1e-4
+    assert n_bad >= 10              # the family does contain indefinite problems
+    assert 0 < n_exact < n_total    # and both routes are exercised

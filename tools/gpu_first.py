@@ -71,7 +71,7 @@ plan = batch.BatchedGP(B, N, JR, JC)
 plan.set_series(a[6], a[7], a[8])
 plan.set_coefficients(*a[:6])
 res = {}
-for layout in ("staged", "interleaved"):
+for layout in ("staged",):
     plan.set_layout(layout)
     for nch in (64, 128):
         plan.set_chunks(nch)
@@ -86,6 +86,22 @@ for layout in ("staged", "interleaved"):
         print("   parity (4 problems): logdet rel %.2e quad rel %.2e" % (
             np.max(np.abs(ld[:4] - d0) / np.abs(d0)), np.max(np.abs(q[:4] - q0) / np.abs(q0))), flush=True)
 plan.set_layout("staged")
+for nch in (32, 64, 128):
+    plan.set_chunks(nch)
+    outs = {}
+    for exact in (False, True):
+        plan.set_exact(exact)
+        plan.log_likelihood()
+        tot, k = plan.run_timed(5)
+        outs[exact] = plan.log_likelihood()
+        print("exact=%d nchunk %3d: %.3f ms/step (%s) -> %.0f loglik/s ; problems replayed: %d" % (
+            exact, plan.chunks[0], tot / 5, " ".join("%s %.3f" % (a, b / 5) for a, b in k.items()),
+            B / (tot / 5) * 1e3, plan.exact_count()), flush=True)
+        res["exact%d_%d" % (exact, nch)] = dict(ms=tot / 5, kernels={a: b / 5 for a, b in k.items()})
+    print("   replay-free vs exact: logdet rel %.2e quad rel %.2e status equal %s" % (
+        np.max(np.abs(outs[0][1] - outs[1][1]) / np.abs(outs[1][1])),
+        np.max(np.abs(outs[0][2] - outs[1][2]) / np.abs(outs[1][2])), np.array_equal(outs[0][3], outs[1][3])), flush=True)
+plan.set_exact(False)
 plan.set_chunks(64)
 tot, k = plan.run_timed(3, materialize=True)
 fb = B * N * (3 * 8 + 1) * 8.0
