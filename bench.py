@@ -11,10 +11,15 @@ Workload (BASELINE.json configs[2] per GPU; configs[3] = the same on 8 GPUs):
     U(0.1,0.2), y = sin t.
 
 One "step" = one evaluation of all B log-likelihoods from inputs resident in
-HBM in the public API's row-major layout: summarize -> prefix -> replay ->
-finalize (celerite_amd/csrc); both big kernels read the row-major arrays through
-cooperative LDS-transposed tiles ("staged" layout), so nothing is cached between
-steps and a step costs the same whether or not the series changed.  For
+HBM in the public API's row-major layout: summarize -> prefix -> correct ->
+replay -> finalize (celerite_amd/csrc).  summarize is the one pass over the
+series (read through cooperative LDS-transposed tiles, "staged" layout: nothing is
+cached between steps); correct turns every chunk's zero-start sums into its true
+log-det / quadratic contributions (determinant lemma + Woodbury), and the replay
+kernel -- the reference's recurrence step by step -- only runs for problems with a
+chunk that could not be certified (config.problems_replayed; it exits at once for
+the others).  config.exact_replay_ms_per_step is the same step with the replay
+forced for every problem.  For
 information, config.value_fixed_series is the rate with a cached
 chunk-interleaved copy of the series (layout "interleaved", relayout outside the
 timed region): the optimiser / MCMC case where only hyper-parameters change.
@@ -166,6 +171,13 @@ def main(argv=None):
     dt = dist.max(time.perf_counter() - t0)
 
     ll, ld, q, st = plan.results()
+    replayed = plan.exact_count()
+    # the same step with the exact replay forced for every problem (A/B, for information)
+    plan.set_exact(True)
+    plan.enqueue()
+    plan.synchronize()
+    exact_total_ms, _ = plan.run_timed(max(args.steps // 2, 1))
+    plan.set_exact(False)
     # fixed-series variant (cached interleaved copy), reported for information
     plan.set_layout("interleaved")
     plan.enqueue()
@@ -205,12 +217,15 @@ def main(argv=None):
             "config": {
                 "workload": "BASELINE configs[2]: batch=%d problems/GPU x N=%d samples, width J=%d "
                             "(%d real + %d complex terms), fp64, fused log-likelihood "
-                            "(compute + dot_solve + log_determinant), chunked-scan over N" % (B, N, W, JR, JC),
+                            "(compute + dot_solve + log_determinant), chunked scan over N, one pass "
+                            "over the series" % (B, N, W, JR, JC),
                 "batch_per_gpu": B, "N": N, "width": W, "J_real": JR, "J_comp": JC,
                 "scan_chunks": plan.chunks[0], "chunk_len": plan.chunks[1],
                 "parallelism": "batch-sharded x%d, no collective" % dist.world,
                 "series_layout": "staged (row-major arrays read through LDS tiles; no per-step relayout pass)",
                 "value_fixed_series": fixed_rate * dist.world,
+                "problems_replayed": replayed,
+                "exact_replay_ms_per_step": exact_total_ms / max(args.steps // 2, 1),
             },
             "kernels_ms": per,
             "hip_event_ms_per_step": ev_total_ms / args.steps,
