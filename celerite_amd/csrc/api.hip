@@ -947,7 +947,8 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   {
     const size_t pc = B * (size_t)h->nchunk;
     P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
-    P.force_exact = (materialize || h->force_exact) ? 1 : 0;
+    // a single chunk starts from the zero state: its replay IS the whole recurrence
+    P.force_exact = (materialize || h->force_exact || h->nchunk < 2) ? 1 : 0;
   }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = h->status;

@@ -60,6 +60,13 @@ __device__ __forceinline__ void load_problem(const BatchParams& P, int b, Proble
          P.jitter[b]);
 }
 
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also
+// drains vmcnt, which would expose the HBM latency of the staged tile prefetch (loads
+// issued in step i are consumed in step i + 1) at every step.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------
 // StagedSeries: the wave's 64 lanes (64 consecutive chunks of one problem) read
 // the ROW-MAJOR series cooperatively in tiles of 8 steps x 64 chunks -- each load
@@ -114,7 +121,7 @@ struct StagedSeries {
   __device__ __forceinline__ void step_begin(int i) {
     if (i > 0) {
       commit(((i + 1) >> 3) + 1, (i + 1) & 7);
-      if (((i + 1) & 7) == 7) __syncthreads();
+      if (((i + 1) & 7) == 7) lds_barrier();  // (not __syncthreads: keep the prefetch in flight)
     }
     issue(((i + 2) >> 3) + 1, (i + 2) & 7);
   }
@@ -156,7 +163,6 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool store = c < P.nchunk;
   if (!STAGED && !store) return;  // (staged: every lane helps loading the tiles)
-  if (c == 0) P.need_exact[b] = 0;
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
   const long slot = (long)b * P.nchunk + (store ? c : 0);
@@ -174,8 +180,7 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   if (!store) return;
   P.part[slot * 2 + 0] = ld0;
   P.part[slot * 2 + 1] = q0;
-  P.flags[slot] = flag0;
-  if (flag0) atomicOr(P.need_exact + b, 1);
+  P.flags[slot] = flag0;  // (correct_kernel raises need_exact[b] from it)
 }
 
 template <int JR, int JC>
@@ -184,6 +189,7 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
   constexpr int J = Wd::J;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.B) return;
+  P.need_exact[b] = 0;  // raised by correct_kernel
   double S[Wd::SZ], f[J];
 #pragma unroll
   for (int i = 0; i < Wd::SZ; ++i) S[i] = 0.0;
@@ -233,6 +239,8 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   const bool active = prob < P_.B;
   const long pb = active ? prob : P_.B - 1;
   const bool writer = rhs && cv && active;
+
+  if (l == 0 && active) P_.need_exact[prob] = 0;  // raised by correct_kernel
 
   double Pc[J];  // column `col` of the running P (rhs lanes)
   double fj = 0.0;
@@ -369,6 +377,7 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   const long slot = (long)blockIdx.x * 64 + threadIdx.x;
   if (slot >= (long)P.B * P.nchunk) return;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
+  if (P.flags[slot]) atomicOr(P.need_exact + b, 1);  // a zero-start pivot <= 0 (summarize)
   if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
   double S[SZ], f[J];
   const double* st = P.starts + slot * START;

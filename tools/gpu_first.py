@@ -86,7 +86,7 @@ for layout in ("staged",):
         print("   parity (4 problems): logdet rel %.2e quad rel %.2e" % (
             np.max(np.abs(ld[:4] - d0) / np.abs(d0)), np.max(np.abs(q[:4] - q0) / np.abs(q0))), flush=True)
 plan.set_layout("staged")
-for nch in (32, 64, 128):
+for nch in (64,):
     plan.set_chunks(nch)
     outs = {}
     for exact in (False, True):
