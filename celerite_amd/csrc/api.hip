@@ -779,8 +779,9 @@ clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
     return nullptr;
   }
   const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
-  if (!L) {
-    fail(CLR_UNSUPPORTED, "batched path supports widths 1..8 (J_real + 2 J_comp)");
+  const int width = J_real + 2 * J_comp;
+  if (!L && (width < 1 || width > clr::wide_max_width())) {
+    fail(CLR_UNSUPPORTED, "batched path supports widths 1..64 (J_real + 2 J_comp)");
     return nullptr;
   }
   if (require_device(device) != CLR_OK) return nullptr;
@@ -791,7 +792,7 @@ clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
   h->J_real = J_real;
   h->J_comp = J_comp;
   h->J = J_real + 2 * J_comp;
-  h->launch = L;
+  h->launch = L;  // null: widths 9..64, one wave per problem (wide_kernels.hip)
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     fail(CLR_HIP_ERROR, "hipStreamCreate failed");
     delete h;
@@ -823,14 +824,17 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (st != CLR_OK) return st;
   if (nchunk <= 0) nchunk = auto_chunks(h->B, h->N);
   if (nchunk > h->N) nchunk = h->N;
+  if (!h->launch) nchunk = 1;  // wide path: one wave per problem, sequential in n
   h->L = (h->N + nchunk - 1) / nchunk;
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->relayout_pending = true;
   h->have_factor = false;  // its layout depends on the chunking
   const size_t pc = (size_t)h->B * h->nchunk;
-  if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
-  if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+  if (h->launch) {
+    if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
+    if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+  }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->out.reserve((size_t)h->B * 3)) != CLR_OK) return st;
@@ -904,6 +908,8 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   if (!h->have_series || !h->have_coeffs)
     return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
+  if (materialize && !h->launch)
+    return fail(CLR_UNSUPPORTED, "materialising batched runs support widths 1..8; use CholeskySolver for wider kernels");
   int st = CLR_OK;
   if (materialize && !h->have_factor) {
     const size_t B = (size_t)h->B, J = (size_t)h->J, cells = (size_t)h->L * h->nchunk;
@@ -976,6 +982,10 @@ int clr_batch_get_exact_count(clr_batch* h, int* count) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
+  if (!h->launch) {  // the wide path IS the reference recurrence
+    *count = h->B;
+    return CLR_OK;
+  }
   std::vector<int> need((size_t)h->B);
   const size_t pc = (size_t)h->B * h->nchunk;
   HIP_TRY(hipMemcpyAsync(need.data(), h->flags + 2 * pc, need.size() * sizeof(int),
@@ -1009,6 +1019,11 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (st != CLR_OK) return st;
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  if (!h->launch) {
+    clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
   if (h->relayout_pending) {
     batch_relayout(h);
     h->relayout_pending = false;
@@ -1082,6 +1097,12 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   for (int i = 0; i < steps; ++i) {
     hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
     HIP_TRY(hipEventRecord(e[0], h->stream));
+    if (!h->launch) {  // wide path: the one kernel is reported in the "summarize" slot
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+      for (int j = 2; j <= NK; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      continue;
+    }
     if (relayout_each_step) batch_relayout(h);
     HIP_TRY(hipEventRecord(e[1], h->stream));
     h->launch->summarize(P, h->stream);

@@ -504,5 +504,8 @@ void launch_relayout(const double* src, long src_stride, double* dst, long dst_s
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);
+// widths 9..wide_max_width(): one wave per problem, sequential in n (wide_kernels.hip)
+int wide_max_width();
+void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s);
 
 }  // namespace clr

@@ -1,0 +1,257 @@
+// celerite_amd/csrc/wide_kernels.hip -- batched fused log-likelihood for widths 9..64
+// (BASELINE config 5: 16 complex terms = width 32, N = 1e5, 256 problems).
+//
+// At these widths one problem's state S (cholesky.h:154-160) no longer fits a lane, so
+// the mapping turns around: ONE WAVE PER PROBLEM, sequential in n exactly as the
+// reference (cholesky.h:126-179 fused with dot_solve, :348-357), with the W x W matrix
+// distributed over the 64 lanes in registers:
+//     WMAX = 16: 4 lanes per row, 4 columns each      (LPR = 4, COLS = 4)
+//     WMAX = 32: 2 lanes per row, 16 columns each     (LPR = 2, COLS = 16)
+//     WMAX = 64: 1 lane  per row, 64 columns          (LPR = 1, COLS = 64)
+// S is kept in FULL (not packed-symmetric) storage: every lane updates its own row
+// segment, no lane idles on a triangle.
+//
+// One step (state before sample n: S = P_n, f = f_n, the reference's S and f after
+// their updates at step n; features u~, v~ at t_n, decay phi for t_n -> t_{n+1}):
+//     q = S u ; D = a - u.q ; z = v - q ; w = z / D ; x = y_n - u.f
+//     S <- Phi (S + z w^T) Phi ; f <- Phi (f + w x)
+// * every lane evaluates its own row's features (sin/cos of the absolute phase,
+//   cholesky.h:137; exp of the step, :130,140);
+// * the three vectors a lane needs for its COLUMNS (u, phi, phi*w) cross the wave
+//   through small LDS buffers (one write + broadcast b128 reads; a wave's LDS
+//   operations execute in program order, so no barrier is needed); u and phi do not
+//   depend on the state and are published one step ahead, so phi*w is the only
+//   exchange on a step's critical path;
+// * row dot products finish with log2(LPR) DPP butterfly stages, u.q and u.f with
+//   the remaining DPP stages inside 16 lanes and four v_readlane pairs across them
+//   (a lone wave would wait ~100 cycles on every ds_bpermute of a __shfl_xor);
+// * t, diag, y are fetched 64 samples at a time (one coalesced 512-B load per array)
+//   and handed out with v_readlane.
+// Flops per step ~ 3.5 W^2; instruction slots per step and lane at W = 32: ~240.
+// B problems use B of the chip's 1024 SIMDs: the batch axis is the parallelism here
+// (at B = 256 a chunked scan on top would at best halve the time for 2.4x the work).
+#include "../../include/celerite_hip.h"
+#include "clr_batch_kernels.h"
+
+namespace clr {
+
+namespace {
+
+template <int WMAX>
+struct WideGeom {
+  static constexpr int LPR = 64 / WMAX;     // lanes per row
+  static constexpr int COLS = WMAX / LPR;   // columns per lane
+};
+
+// lane `k` (wave-uniform) of a per-lane double: two v_readlane_b32
+__device__ __forceinline__ double lane_value(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// v + (v of the DPP-selected lane): two v_mov_b32_dpp + one v_add_f64, no LDS crossbar
+// latency (a __shfl_xor is two ds_bpermute_b32, ~100 cycles each for a lone wave).
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  // (mov_dpp: every lane has a valid source for these controls, no `old` value to set up)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: i <-> 7 - i within 8 lanes
+constexpr int DPP_MIRROR = 0x140;       // row_mirror:      i <-> 15 - i within 16 lanes
+
+// Sum over the rows of the matrix of a value every lane of a row holds identically.
+// Rows are LPR adjacent lanes, so the first log2(LPR) butterfly stages are skipped; the
+// four 16-lane groups are combined through SGPRs.  The result is wave-uniform.
+template <int LPR>
+__device__ __forceinline__ double row_sum(double v) {
+  if (LPR < 2) v = dpp_add<DPP_QUAD_XOR1>(v);
+  if (LPR < 4) v = dpp_add<DPP_QUAD_XOR2>(v);
+  v = dpp_add<DPP_HALF_MIRROR>(v);
+  v = dpp_add<DPP_MIRROR>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+// One row's features: u~, v~ (cholesky.h:129-147) at t and the decay to t + dx, without
+// selects: u = u0 + uc cos(d t) + us sin(d t), v = v0 + vc cos + vs sin with per-row
+// constants (real row: u0 = a, v0 = 1; cos row: uc = a, us = b, vc = 1; sin row:
+// uc = -b, us = a, vs = 1; padding rows: all 0, c = 0 so phi = 1 and S stays 0).
+struct RowCoeffs {
+  double u0, uc, us, v0, vc, vs, c, d;
+};
+template <bool FAST>
+__device__ __forceinline__ void row_features(const RowCoeffs& r, double t, double dx, double* u,
+                                             double* v, double* phi) {
+  double sd, cs;
+  sincos_phase<FAST>(r.d * t, &sd, &cs);
+  const double x = -r.c * dx;
+  // densely sampled series: the 6-FMA polynomial (see features_phi_distinct); wave-uniform choice
+  *phi = CLR_WAVE_ALL(fabs(x) < 0.0078125) ? exp_small(x) : exp(x);
+  *u = fma(r.uc, cs, fma(r.us, sd, r.u0));
+  *v = fma(r.vc, cs, fma(r.vs, sd, r.v0));
+}
+
+template <int WMAX, bool FAST>
+__global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, int JR, int JC) {
+  using G = WideGeom<WMAX>;
+  constexpr int LPR = G::LPR, COLS = G::COLS;
+  // u and phi of a step are written one step AHEAD (they do not depend on the state),
+  // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
+  // operations execute in program order, so no barrier or explicit wait is needed.
+  __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int row = lane / LPR, seg = lane % LPR;
+  const int W = JR + 2 * JC;
+  const bool writer = seg == 0;
+
+  RowCoeffs rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (row < JR) {
+    rc.u0 = P.a_real[(long)b * JR + row];
+    rc.v0 = 1.0;
+    rc.c = P.c_real[(long)b * JR + row];
+  } else if (row < W) {
+    const int j = (row - JR) >> 1;
+    const double a = P.a_comp[(long)b * JC + j], bb = P.b_comp[(long)b * JC + j];
+    if (((row - JR) & 1) == 0) { rc.uc = a; rc.us = bb; rc.vc = 1.0; }   // cholesky.h:143,145
+    else                       { rc.uc = -bb; rc.us = a; rc.vs = 1.0; }  // cholesky.h:144,146
+    rc.c = P.c_comp[(long)b * JC + j];
+    rc.d = P.d_comp[(long)b * JC + j];
+  }
+  // K(0) = sum a_real + sum a_comp (+ jitter): the same summation order as the scan
+  // kernels' Problem::diagonal (cholesky.h:98-100,120)
+  double sum_ar = 0.0, sum_ac = 0.0;
+  for (int j = 0; j < JR; ++j) sum_ar += P.a_real[(long)b * JR + j];
+  for (int j = 0; j < JC; ++j) sum_ac += P.a_comp[(long)b * JC + j];
+  const double jitter = P.jitter[b];
+
+  const double* tp = P.t + b * P.t_stride;
+  const double* dp = P.diag + b * P.diag_stride;
+  const double* yp = P.y + b * P.y_stride;
+  const int N = P.N;
+
+  double S[COLS];
+#pragma unroll
+  for (int c = 0; c < COLS; ++c) S[c] = 0.0;
+  double f = 0.0, quad = 0.0;
+  LogProduct lp;
+  lp.init();
+  int flag = 0;
+
+  // 64-sample register tiles of the series (one coalesced 512-B load per array),
+  // handed out with v_readlane; t needs two samples of look-ahead
+  double tv, dv, yv, tv2;
+  {
+    tv = lane < N ? tp[lane] : 0.0;
+    dv = lane < N ? dp[lane] : 0.0;
+    yv = lane < N ? yp[lane] : 0.0;
+    tv2 = lane + 64 < N ? tp[lane + 64] : 0.0;
+  }
+  auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };  // k < 66
+
+  // features of sample 0
+  double u, v, phi;
+  row_features<FAST>(rc, t_at(0), N > 1 ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
+  if (writer) { ubuf[0][row] = u; pbuf[0][row] = phi; }
+
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int nend = (N - n0 < 64) ? N - n0 : 64;
+    for (int k = 0; k < nend; ++k) {
+      const int n = n0 + k, cur = n & 1;
+      const double diag_n = lane_value(dv, k);
+      const double y_n = lane_value(yv, k);
+
+      // next sample's features (independent of the state): computed and published now
+      double u1 = 0.0, v1 = 0.0, phi1 = 1.0;
+      if (n + 1 < N) {
+        const double t1 = t_at(k + 1);
+        const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        row_features<FAST>(rc, t1, dx1, &u1, &v1, &phi1);
+        if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
+      }
+
+      // q = S u (own columns, then across the row's lanes)
+      double q = 0.0;
+      {
+        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 uu = uv[c];
+          q = fma(S[2 * c], uu.x, q);
+          q = fma(S[2 * c + 1], uu.y, q);
+        }
+      }
+      if (LPR >= 2) q = dpp_add<DPP_QUAD_XOR1>(q);
+      if (LPR >= 4) q = dpp_add<DPP_QUAD_XOR2>(q);
+      const double s = row_sum<LPR>(u * q), ub = row_sum<LPR>(u * f);
+      const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
+      const double invD = 1.0 / D;
+      const double x = y_n - ub;
+      if (n >= 1 && D < 0.0) flag = 1;  // cholesky.h:176 (sample 0 is never checked)
+      lp.mul(D);
+      quad += x * x * invD;
+
+      const double z = v - q;
+      const double w = z * invD;
+      if (writer) wbuf[row] = phi * w;
+      {
+        const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
+        const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
+        const double zr = phi * z;
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 pk = pv[c], pw = wv[c];
+          S[2 * c] = fma(zr, pw.x, (phi * pk.x) * S[2 * c]);
+          S[2 * c + 1] = fma(zr, pw.y, (phi * pk.y) * S[2 * c + 1]);
+        }
+      }
+      f = phi * (f + w * x);
+      u = u1; v = v1; phi = phi1;
+    }
+    // next tile of the series
+    const int m = n0 + 64 + lane;
+    tv = tv2;
+    dv = m < N ? dp[m] : 0.0;
+    yv = m < N ? yp[m] : 0.0;
+    tv2 = m + 64 < N ? tp[m + 64] : 0.0;
+  }
+  if (lane == 0) {
+    const double ld = lp.log_value();
+    if (flag) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
+      P.out_status[b] = CLR_NOT_POSITIVE_DEFINITE;
+      P.out_ll[b] = -INFINITY;
+      P.out_logdet[b] = NAN;
+      P.out_quad[b] = NAN;
+    } else {
+      P.out_status[b] = CLR_OK;
+      P.out_logdet[b] = ld;
+      P.out_quad[b] = quad;
+      P.out_ll[b] = combine_loglike(ld, quad, N);
+    }
+  }
+}
+
+}  // namespace
+
+int wide_max_width() { return 64; }
+
+void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s) {
+  const int W = JR + 2 * JC;
+#define CLR_GO(WM)                                                                                \
+  do {                                                                                            \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_loglike_kernel<WM, true>), dim3(P.B), dim3(64), 0, s, P, JR, JC); \
+    else hipLaunchKernelGGL((wide_loglike_kernel<WM, false>), dim3(P.B), dim3(64), 0, s, P, JR, JC);            \
+  } while (0)
+  if (W <= 16) CLR_GO(16);
+  else if (W <= 32) CLR_GO(32);
+  else CLR_GO(64);
+#undef CLR_GO
+}
+
+}  // namespace clr

@@ -155,8 +155,13 @@ int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_d
 typedef struct clr_batch clr_batch;
 
 /* Plans device buffers + workspace for (B, N, J_real, J_comp) on `device`.
- * General terms are not part of the batched path.  J_real + 2 J_comp must be
- * in [1, 8] for now (CLR_UNSUPPORTED otherwise). */
+ * General terms are not part of the batched path.  Width W = J_real + 2 J_comp:
+ *   1..8   chunked scan over n, one lane per (problem, chunk)  (the headline path);
+ *   9..64  one wave per problem, sequential in n, S distributed over the lanes
+ *          (BASELINE config 5: 16 complex terms); fused log-likelihood only --
+ *          materialising runs, chunking, layouts and the exact/replay switch do not
+ *          apply (the kernel IS the reference recurrence);
+ *   else   CLR_UNSUPPORTED. */
 clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device);
 void clr_batch_destroy(clr_batch* h);
 

@@ -293,3 +293,53 @@ def test_one_shot_helper_and_coefficient_table():
         gp.set_parameter_vector(draws[i])
         gp.compute(t, yerr)
         assert abs(gp.log_likelihood(y) - ll[i]) <= REL * abs(ll[i])
+
+
+WIDE_SHAPES = [(9, 0), (1, 4), (0, 8), (2, 7), (16, 0), (0, 16), (4, 14), (10, 11), (1, 16), (0, 20), (64, 0), (2, 31)]
+
+
+@pytest.mark.parametrize("JR,JC", WIDE_SHAPES)
+def test_wide_kernels_every_layout_class(JR, JC):
+    """Widths 9..64 (wide_kernels.hip: one wave per problem, S distributed over the
+    lanes as 4 / 2 / 1 lanes per row) against the oracle, both input families, sizes
+    around the 64-sample register tile."""
+    for N in (1, 2, 63, 64, 65, 130, 1000):
+        for family in ("bench", "accuracy"):
+            case = synthetic(3, N, JR, JC, family, seed=N + JR + 7 * JC)
+            check(case)
+
+
+def test_wide_config5_shape_sample():
+    """BASELINE config 5 shape: 16 complex terms (width 32), log d spread over U(0, 3)
+    (SURVEY.md 8d), a reduced N and batch here; oracle parity on every problem."""
+    B, N = 6, 20000
+    case = synthetic(B, N, 0, 16, "bench", seed=5)
+    rng = np.random.RandomState(50)
+    case["d_comp"] = np.exp(rng.uniform(0.0, 3.0, (B, 16)))
+    check(case)
+
+
+def test_wide_failures_jitter_and_shared_series():
+    case = synthetic(5, 700, 3, 5, "bench", seed=21)   # width 13
+    case["jitter"] = np.linspace(0.0, 0.2, 5)
+    case["a_real"][1, :] = -6.0                        # indefinite: linalg_exception in the reference
+    case["diag"][1] = 0.0
+    ll, ld, q, st = check(case)
+    assert st[1] == 2 and (np.delete(st, 1) == 0).all()
+    shared = dict(synthetic(8, 900, 0, 9, "accuracy", seed=4))
+    for k in ("t", "diag", "y"):
+        shared[k] = shared[k][0]
+    check(shared, B=8)
+
+
+def test_wide_plan_rejects_what_does_not_apply():
+    plan = batch.BatchedGP(2, 100, 0, 5)
+    case = synthetic(2, 100, 0, 5, "bench", seed=1)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    assert plan.chunks[0] == 1
+    with pytest.raises(RuntimeError):
+        plan.enqueue(materialize=True)
+    plan.close()
+    with pytest.raises(RuntimeError):
+        batch.BatchedGP(2, 100, 1, 32)     # width 65
