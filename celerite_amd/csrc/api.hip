@@ -232,6 +232,7 @@ struct clr_solver {
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
+  DevBuf gradbuf;                       // grad_log_likelihood staging
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
@@ -396,7 +397,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part})
+                      &s->ws_part, &s->gradbuf})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -537,6 +538,74 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     return fail(CLR_NOT_POSITIVE_DEFINITE, "failed to factorize or solve matrix");
   s->log_det = h_logdet;
   s->computed = 1;
+  return CLR_OK;
+}
+
+int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, const double* a_real,
+                                   int n_c_real, const double* c_real, int n_a_comp,
+                                   const double* a_comp, int n_b_comp, const double* b_comp,
+                                   int n_c_comp, const double* c_comp, int n_d_comp,
+                                   const double* d_comp, int n_A, const double* A, int U_rows,
+                                   int U_cols, const double* U, int V_rows, int V_cols,
+                                   const double* V, int n_x, const double* x, int n_y,
+                                   const double* y, int n_diag, const double* diag, double* value,
+                                   int n_grad, double* grad) {
+  const int N = n_x;
+  if (N != n_diag || N != n_y) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+  int st = check_coeff_dims(n_a_real, n_c_real, n_a_comp, n_b_comp, n_c_comp, n_d_comp, n_A,
+                            U_rows, U_cols, V_rows, V_cols, N);
+  if (st != CLR_OK) return fail(st, "dimension mismatch");
+  if (N < 1) return fail(CLR_INVALID_ARGUMENT, "grad_log_likelihood needs at least one sample");
+  const bool has_general = (n_A != 0);
+  const int JG = U_rows, JR = n_a_real, JC = n_a_comp;
+  if (JG > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
+  if (JR + 2 * JC + JG > 64) return fail(CLR_UNSUPPORTED, "grad_log_likelihood supports widths up to 64");
+  const int G = 1 + 2 * JR + 4 * JC;
+  if (n_grad != G || !value || !grad) return fail(CLR_INVALID_ARGUMENT, "grad must hold 1 + 2 J_real + 4 J_comp values");
+  if ((st = ensure_stream(s)) != CLR_OK) return st;
+  hipStream_t stream = s->stream;
+
+  // one staging buffer: coefficients | A | U | V | t | diag | y | value, grad | status
+  std::vector<double> host;
+  host.reserve((size_t)2 * JR + 4 * JC + (size_t)N * (4 + 2 * JG));
+  auto put = [&](const double* p, size_t n) { const size_t at = host.size(); if (n) host.insert(host.end(), p, p + n); return at; };
+  const size_t o_ar = put(a_real, JR), o_cr = put(c_real, JR), o_ac = put(a_comp, JC), o_bc = put(b_comp, JC),
+               o_cc = put(c_comp, JC), o_dc = put(d_comp, JC);
+  const size_t o_A = put(A, has_general ? (size_t)N : 0), o_U = put(U, (size_t)JG * N), o_V = put(V, (size_t)JG * N);
+  const size_t o_t = put(x, N), o_d = put(diag, N), o_y = put(y, N);
+  const size_t o_out = host.size();
+  if ((st = s->gradbuf.reserve(o_out + (size_t)G + 2)) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(s->gradbuf.p, host.data(), o_out * sizeof(double), hipMemcpyHostToDevice, stream));
+
+  clr::GradParams P;
+  memset(&P, 0, sizeof(P));
+  const double* base = s->gradbuf.p;
+  P.N = N; P.J_real = JR; P.J_comp = JC; P.J_general = JG;
+  P.a_real = base + o_ar; P.c_real = base + o_cr; P.a_comp = base + o_ac; P.b_comp = base + o_bc;
+  P.c_comp = base + o_cc; P.d_comp = base + o_dc;
+  P.jitter = jitter;
+  P.A = has_general ? base + o_A : nullptr; P.U = base + o_U; P.V = base + o_V;
+  P.t = base + o_t; P.diag = base + o_d; P.y = base + o_y;
+  {
+    double dmax = 0.0;
+    for (int j = 0; j < JC; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
+    const double t0 = fabs(x[0]), t1 = fabs(x[N - 1]);
+    P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+  }
+  P.out_value = s->gradbuf.p + o_out;
+  P.out_grad = s->gradbuf.p + o_out + 1;
+  P.out_status = s->d_status;
+  clr::launch_grad(P, stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> out((size_t)G + 1);
+  int h_status = 0;
+  HIP_TRY(hipMemcpyAsync(out.data(), s->gradbuf.p + o_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (h_status != CLR_OK) return fail(CLR_NOT_POSITIVE_DEFINITE, "failed to factorize or solve matrix");
+  *value = out[0];
+  for (int i = 0; i < G; ++i) grad[i] = out[(size_t)i + 1];
+  if (!(jitter > 2.220446049250313e-16)) grad[0] = 0.0;  // solver.cpp:379-389,419-426
   return CLR_OK;
 }
 

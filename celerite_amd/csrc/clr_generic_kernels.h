@@ -23,6 +23,20 @@ struct GenericProblem {
   const double* t;      // device [N]
 };
 
+// solver.cpp:347-463 (grad_kernels.hip): one wave per partial derivative.
+struct GradParams {
+  int N, J_real, J_comp, J_general;
+  const double *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;  // device
+  double jitter;
+  const double *A, *U, *V;      // device; A null without general terms; U, V row-major [J_general][N]
+  const double *t, *diag, *y;   // device [N]
+  int fast_trig;                // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
+  double* out_value;            // [1]  -(quad + log det + pi log N) / 2
+  double* out_grad;             // [1 + 2 J_real + 4 J_comp]
+  int* out_status;              // [1]
+};
+void launch_grad(const GradParams& P, hipStream_t s);
+
 // cholesky.h:41-210.  D must arrive initialised to the full diagonal
 // (diag + sum a_real + sum a_comp + jitter [+ A], cholesky.h:98-99).
 // status[0] = 1 when some D_n < 0 (n >= 1), log_det[0] = sum log D_n.

@@ -1,0 +1,50 @@
+// celerite_amd/csrc/clr_wide.h -- device helpers shared by the wave-per-problem kernels
+// (wide_kernels.hip: batched log-likelihood for widths 9..64; grad_kernels.hip:
+// forward-mode gradient): lane geometry, DPP butterflies, wave-uniform lane reads.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "clr_core.h"
+
+namespace clr {
+
+template <int WMAX>
+struct WideGeom {
+  static constexpr int LPR = 64 / WMAX;     // lanes per row
+  static constexpr int COLS = WMAX / LPR;   // columns per lane
+};
+
+// lane `k` (wave-uniform) of a per-lane double: two v_readlane_b32
+__device__ __forceinline__ double lane_value(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// v + (v of the DPP-selected lane): two v_mov_b32_dpp + one v_add_f64, no LDS crossbar
+// latency (a __shfl_xor is two ds_bpermute_b32, ~100 cycles each for a lone wave).
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  // (mov_dpp: every lane has a valid source for these controls, no `old` value to set up)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: i <-> 7 - i within 8 lanes
+constexpr int DPP_MIRROR = 0x140;       // row_mirror:      i <-> 15 - i within 16 lanes
+
+// Sum over the rows of the matrix of a value every lane of a row holds identically.
+// Rows are LPR adjacent lanes, so the first log2(LPR) butterfly stages are skipped; the
+// four 16-lane groups are combined through SGPRs.  The result is wave-uniform.
+template <int LPR>
+__device__ __forceinline__ double row_sum(double v) {
+  if (LPR < 2) v = dpp_add<DPP_QUAD_XOR1>(v);
+  if (LPR < 4) v = dpp_add<DPP_QUAD_XOR2>(v);
+  v = dpp_add<DPP_HALF_MIRROR>(v);
+  v = dpp_add<DPP_MIRROR>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+}  // namespace clr

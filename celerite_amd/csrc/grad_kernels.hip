@@ -1,0 +1,257 @@
+// celerite_amd/csrc/grad_kernels.hip -- CholeskySolver.grad_log_likelihood on the GPU.
+//
+// The reference differentiates by running its solver template on Eigen's forward-mode
+// AutoDiffScalar (celerite/solver.cpp:347-463): compute (cholesky.h:41-210) and
+// dot_solve (:326-401) on dual numbers carrying 1 + 2 J_real + 4 J_comp partials.
+// Forward mode is one independent tangent recurrence per partial on top of the same
+// base recurrence, so the natural GPU mapping is ONE WAVE PER PARTIAL (grid.x = number
+// of partials): every wave recomputes the base step (the wave-per-problem layout of
+// wide_kernels.hip: S distributed over the lanes, DPP reductions) and carries the
+// tangent of its own direction p:
+//     q = S u                      dq = dS u + S du
+//     D = a - u.q                  dD = da - (du.q + u.dq)
+//     z = v - q ; w = z / D        dz = dv - dq ; dw = (dz - w dD) / D
+//     x = y - u.f                  dx = -(du.f + u.df)
+//     S <- Phi (S + z w^T) Phi     dS <- the product rule on phi_i (phi_k S_ik + z_i phi_k w_k)
+//     f <- Phi (f + w x)           df <- dPhi (f + w x) + Phi (df + dw x + w dx)
+//     log det += log D             d(log det) += dD / D
+//     quad += x^2 / D              d(quad) += (2 x dx - x^2 dD / D) / D
+// A direction only touches the rows of its own term: per-lane constants select
+// du = du0 + duc cos + dus sin + ddf t (us cos - uc sin), dphi = -dcf dx phi, and da = 1
+// for jitter / a_real / a_comp (K(0) = sum of the amplitudes + jitter, cholesky.h:98).
+// General terms (A, U, V: cholesky.h:65-72,114-116,148-152) are constants of the
+// differentiation and enter as extra rows whose u, v are read from memory two steps
+// ahead.  Result: value = -(quad + log det + pi log N) / 2 -- the reference's constant,
+// solver.cpp:415 -- and grad[p] = -(d quad + d log det) / 2.
+#include "../../include/celerite_hip.h"
+#include "clr_generic_kernels.h"
+#include "clr_wide.h"
+
+namespace clr {
+
+namespace {
+
+template <int WMAX, bool FAST>
+__global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams P) {
+  using G = WideGeom<WMAX>;
+  constexpr int LPR = G::LPR, COLS = G::COLS;
+  __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX], dubuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX], dpbuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) double wbuf[WMAX], dwbuf[WMAX];
+  const int lane = threadIdx.x;
+  const int row = lane / LPR, seg = lane % LPR;
+  const bool writer = seg == 0;
+  const int JR = P.J_real, JC = P.J_comp, JG = P.J_general, N = P.N;
+  const int Wc = JR + 2 * JC;
+
+  // ---- this lane's row ------------------------------------------------------------
+  double u0 = 0.0, uc = 0.0, us = 0.0, v0 = 0.0, vc = 0.0, vs = 0.0, cdec = 0.0, dfreq = 0.0;
+  int pair = -1;        // complex pair index of this row, if any
+  bool cosrow = false;
+  const double *ug = nullptr, *vg = nullptr;  // general row: U[j][:], V[j][:]
+  if (row < JR) {
+    u0 = P.a_real[row];
+    v0 = 1.0;
+    cdec = P.c_real[row];
+  } else if (row < Wc) {
+    pair = (row - JR) >> 1;
+    cosrow = ((row - JR) & 1) == 0;
+    const double a = P.a_comp[pair], b = P.b_comp[pair];
+    if (cosrow) { uc = a; us = b; vc = 1.0; }   // cholesky.h:143,145
+    else        { uc = -b; us = a; vs = 1.0; }  // cholesky.h:144,146
+    cdec = P.c_comp[pair];
+    dfreq = P.d_comp[pair];
+  } else if (row < Wc + JG) {
+    ug = P.U + (long)(row - Wc) * N;
+    vg = P.V + (long)(row - Wc) * N;
+  }
+  // ---- this wave's direction (solver.cpp:379-406: jitter, a_real, c_real, a_comp,
+  //      b_comp, c_comp, d_comp) ----------------------------------------------------
+  double du0 = 0.0, duc = 0.0, dus = 0.0, dcf = 0.0, ddf = 0.0, da = 0.0;
+  {
+    int q = blockIdx.x;
+    if (q == 0) {
+      da = 1.0;
+    } else if ((q -= 1) < JR) {
+      da = 1.0;
+      if (row == q) du0 = 1.0;
+    } else if ((q -= JR) < JR) {
+      if (row == q) dcf = 1.0;
+    } else if ((q -= JR) < JC) {
+      da = 1.0;
+      if (pair == q) { if (cosrow) duc = 1.0; else dus = 1.0; }
+    } else if ((q -= JC) < JC) {
+      if (pair == q) { if (cosrow) dus = 1.0; else duc = -1.0; }
+    } else if ((q -= JC) < JC) {
+      if (pair == q) dcf = 1.0;
+    } else {
+      q -= JC;
+      if (pair == q) ddf = 1.0;
+    }
+  }
+  double sum_ar = 0.0, sum_ac = 0.0;  // cholesky.h:98
+  for (int j = 0; j < JR; ++j) sum_ar += P.a_real[j];
+  for (int j = 0; j < JC; ++j) sum_ac += P.a_comp[j];
+  const double jitter = P.jitter;
+  const bool has_general = P.A != nullptr;
+
+  auto features = [&](double t, double dx, double ugen, double vgen, double* u, double* du,
+                      double* v, double* dv, double* phi, double* dphi) {
+    double sd, cs;
+    sincos_phase<FAST>(dfreq * t, &sd, &cs);
+    const double x = -cdec * dx;
+    const double e = CLR_WAVE_ALL(fabs(x) < 0.0078125) ? exp_small(x) : exp(x);
+    *phi = e;
+    *dphi = -(dcf * dx) * e;
+    *u = fma(uc, cs, fma(us, sd, u0)) + ugen;
+    *v = fma(vc, cs, fma(vs, sd, v0)) + vgen;
+    const double tt = ddf * t;
+    *du = fma(duc, cs, fma(dus, sd, du0)) + tt * (us * cs - uc * sd);
+    *dv = tt * (vs * cs - vc * sd);
+  };
+
+  double S[COLS], dS[COLS];
+#pragma unroll
+  for (int c = 0; c < COLS; ++c) { S[c] = 0.0; dS[c] = 0.0; }
+  double f = 0.0, df = 0.0, quad = 0.0, dquad = 0.0, dld = 0.0;
+  LogProduct lp;
+  lp.init();
+  int flag = 0;
+
+  // 64-sample register tiles (t with two samples of look-ahead)
+  double tv = lane < N ? P.t[lane] : 0.0;
+  double tv2 = lane + 64 < N ? P.t[lane + 64] : 0.0;
+  double dv_ = lane < N ? P.diag[lane] : 0.0;
+  double yv = lane < N ? P.y[lane] : 0.0;
+  double av = (has_general && lane < N) ? P.A[lane] : 0.0;
+  auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };
+
+  // general rows: u, v of sample n are fetched during step n - 2
+  double ug1 = 0.0, vg1 = 0.0, ug2 = 0.0, vg2 = 0.0;
+  if (ug) {
+    ug1 = N > 1 ? ug[1] : 0.0; vg1 = N > 1 ? vg[1] : 0.0;
+    ug2 = N > 2 ? ug[2] : 0.0; vg2 = N > 2 ? vg[2] : 0.0;
+  }
+  double u, du, v, dv, phi, dphi;
+  features(t_at(0), N > 1 ? t_at(1) - t_at(0) : 0.0, ug ? ug[0] : 0.0, ug ? vg[0] : 0.0, &u, &du, &v,
+           &dv, &phi, &dphi);
+  if (writer) { ubuf[0][row] = u; dubuf[0][row] = du; pbuf[0][row] = phi; dpbuf[0][row] = dphi; }
+
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int nend = (N - n0 < 64) ? N - n0 : 64;
+    for (int k = 0; k < nend; ++k) {
+      const int n = n0 + k, cur = n & 1;
+      const double diag_n = lane_value(dv_, k), y_n = lane_value(yv, k);
+      double a_n = ((diag_n + sum_ar) + sum_ac) + jitter;
+      if (has_general) a_n += lane_value(av, k);  // cholesky.h:99
+
+      // next sample's features and their tangents: published one step ahead
+      double u1 = 0.0, du1 = 0.0, v1 = 0.0, dv1 = 0.0, phi1 = 1.0, dphi1 = 0.0;
+      if (n + 1 < N) {
+        const double t1 = t_at(k + 1);
+        const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        features(t1, dx1, ug1, vg1, &u1, &du1, &v1, &dv1, &phi1, &dphi1);
+        if (writer) {
+          ubuf[cur ^ 1][row] = u1; dubuf[cur ^ 1][row] = du1;
+          pbuf[cur ^ 1][row] = phi1; dpbuf[cur ^ 1][row] = dphi1;
+        }
+        ug1 = ug2; vg1 = vg2;
+        if (ug && n + 3 < N) { ug2 = ug[n + 3]; vg2 = vg[n + 3]; }
+      }
+
+      double q = 0.0, dq = 0.0;
+      {
+        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+        const double2* duv = reinterpret_cast<const double2*>(&dubuf[cur][seg * COLS]);
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 uu = uv[c], dd = duv[c];
+          q = fma(S[2 * c], uu.x, q);
+          q = fma(S[2 * c + 1], uu.y, q);
+          dq = fma(dS[2 * c], uu.x, fma(S[2 * c], dd.x, dq));
+          dq = fma(dS[2 * c + 1], uu.y, fma(S[2 * c + 1], dd.y, dq));
+        }
+      }
+      if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); dq = dpp_add<DPP_QUAD_XOR1>(dq); }
+      if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); dq = dpp_add<DPP_QUAD_XOR2>(dq); }
+      const double s = row_sum<LPR>(u * q), ds = row_sum<LPR>(fma(du, q, u * dq));
+      const double ub = row_sum<LPR>(u * f), dub = row_sum<LPR>(fma(du, f, u * df));
+      const double D = a_n - s, dD = da - ds;
+      const double invD = 1.0 / D;
+      const double x = y_n - ub, dx = -dub;
+      if (n >= 1 && D < 0.0) flag = 1;  // cholesky.h:176 (sample 0 is never checked)
+      lp.mul(D);
+      dld = fma(dD, invD, dld);
+      const double xs = x * invD;
+      quad = fma(x, xs, quad);
+      dquad += (2.0 * dx - xs * dD) * xs;
+
+      const double z = v - q, dz = dv - dq;
+      const double w = z * invD;
+      const double dw = (dz - w * dD) * invD;
+      if (writer) { wbuf[row] = phi * w; dwbuf[row] = fma(dphi, w, phi * dw); }
+      {
+        const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
+        const double2* dpv = reinterpret_cast<const double2*>(&dpbuf[cur][seg * COLS]);
+        const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
+        const double2* dwv = reinterpret_cast<const double2*>(&dwbuf[seg * COLS]);
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 pk = pv[c], dpk = dpv[c], pw = wv[c], dpw = dwv[c];
+          {
+            const double inner = fma(z, pw.x, pk.x * S[2 * c]);
+            const double dinner = fma(dpk.x, S[2 * c], fma(pk.x, dS[2 * c], fma(dz, pw.x, z * dpw.x)));
+            dS[2 * c] = fma(dphi, inner, phi * dinner);
+            S[2 * c] = phi * inner;
+          }
+          {
+            const double inner = fma(z, pw.y, pk.y * S[2 * c + 1]);
+            const double dinner =
+                fma(dpk.y, S[2 * c + 1], fma(pk.y, dS[2 * c + 1], fma(dz, pw.y, z * dpw.y)));
+            dS[2 * c + 1] = fma(dphi, inner, phi * dinner);
+            S[2 * c + 1] = phi * inner;
+          }
+        }
+      }
+      {
+        const double g = fma(w, x, f);
+        const double dg = df + fma(dw, x, w * dx);
+        df = fma(dphi, g, phi * dg);
+        f = phi * g;
+      }
+      u = u1; du = du1; v = v1; dv = dv1; phi = phi1; dphi = dphi1;
+    }
+    const int m = n0 + 64 + lane;
+    tv = tv2;
+    tv2 = m + 64 < N ? P.t[m + 64] : 0.0;
+    dv_ = m < N ? P.diag[m] : 0.0;
+    yv = m < N ? P.y[m] : 0.0;
+    av = (has_general && m < N) ? P.A[m] : 0.0;
+  }
+  if (lane == 0) {
+    P.out_grad[blockIdx.x] = -0.5 * (dquad + dld);
+    if (blockIdx.x == 0) {
+      const double ld = lp.log_value();
+      P.out_status[0] = flag ? CLR_NOT_POSITIVE_DEFINITE : CLR_OK;
+      P.out_value[0] = -0.5 * (quad + ld + 3.14159265358979323846 * log((double)N));  // solver.cpp:415
+    }
+  }
+}
+
+}  // namespace
+
+void launch_grad(const GradParams& P, hipStream_t s) {
+  const int W = P.J_real + 2 * P.J_comp + P.J_general;
+  const dim3 grid(1 + 2 * P.J_real + 4 * P.J_comp);
+#define CLR_GO(WM)                                                                           \
+  do {                                                                                       \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<WM, true>), grid, dim3(64), 0, s, P); \
+    else hipLaunchKernelGGL((wide_grad_kernel<WM, false>), grid, dim3(64), 0, s, P);            \
+  } while (0)
+  if (W <= 16) CLR_GO(16);
+  else if (W <= 32) CLR_GO(32);
+  else CLR_GO(64);
+#undef CLR_GO
+}
+
+}  // namespace clr

@@ -138,9 +138,9 @@ PYBIND11_MODULE(solver, m) {
 
   m.def("get_library_version", []() { return std::string(clr_version()); },
         "The version of the linked library");
-  // forward-mode gradients (solver.cpp:246-463) are not built yet; report it the
-  // way a -DNO_AUTODIFF reference build does (solver.cpp:79-85)
-  m.def("has_autodiff", []() { return false; },
+  // forward-mode gradients (solver.cpp:246-463) run as one wave per partial on the GPU
+  // (csrc/grad_kernels.hip): report it like a reference build with autodiff (solver.cpp:79-85)
+  m.def("has_autodiff", []() { return true; },
         "Returns True if the module was compiled with autodiff support");
   m.def("device_count", []() { return clr_device_count(); },
         "Number of visible gfx950 devices");
@@ -288,11 +288,31 @@ PYBIND11_MODULE(solver, m) {
           "Conditional mean at x given y in O(N + M) (solver.cpp:611-615)");
 
   cls.def("grad_log_likelihood",
-          [](Solver&, py::args, py::kwargs) -> py::object {
-            throw std::runtime_error(
-                "celerite must be compiled with autodiff support to use the gradient methods");
+          [](Solver& s, double jitter, const darray& ar, const darray& cr, const darray& ac,
+             const darray& bc, const darray& cc, const darray& dc, const darray& A,
+             const darray& U, const darray& V, const darray& x, const darray& y,
+             const darray& diag) {
+            CoeffArgs c(ar, cr, ac, bc, cc, dc, A, U, V);
+            Vec xs(x), ys(y), dg(diag);
+            const int G = 1 + 2 * c.a_real.n() + 4 * c.a_comp.n();
+            py::array_t<double> grad((py::ssize_t)G);
+            double value = 0.0;
+            double* gp = grad.mutable_data();
+            int st;
+            {
+              py::gil_scoped_release nogil;
+              st = clr_solver_grad_log_likelihood(
+                  s.h(), jitter, c.a_real.n(), c.a_real.p(), c.c_real.n(), c.c_real.p(),
+                  c.a_comp.n(), c.a_comp.p(), c.b_comp.n(), c.b_comp.p(), c.c_comp.n(),
+                  c.c_comp.p(), c.d_comp.n(), c.d_comp.p(), c.A.n(), c.A.p(), c.U.rows, c.U.cols,
+                  c.U.p(), c.V.rows, c.V.cols, c.V.p(), xs.n(), xs.p(), ys.n(), ys.p(), dg.n(),
+                  dg.p(), &value, G, gp);
+            }
+            check(st);
+            return py::make_tuple(value, grad);
           },
-          "Not built yet (solver.cpp:347-463); has_autodiff() is False.");
+          "grad_log_likelihood(jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, A, U, V, x, y, diag)\n"
+          "(value, gradient with respect to the jitter and the coefficients), solver.cpp:347-463.");
 
   cls.def("log_determinant",
           [](Solver& s) {

@@ -130,6 +130,32 @@ int clr_solver_dot(clr_solver* s, double jitter,
 int clr_solver_predict(const clr_solver* s, int n_y, const double* y,
                        int M, const double* xs, double* pred);
 
+/* grad_log_likelihood, celerite/solver.cpp:347-463 (the reference runs compute +
+ * dot_solve on forward-mode dual numbers; the handle's factorisation is neither used
+ * nor changed, as in the reference where the bound object is ignored).  Same argument
+ * conventions as clr_solver_compute plus the observations y.
+ *   *value = -(y^T K^-1 y + log det K + pi log N) / 2   (the reference's constant,
+ *            solver.cpp:415 -- not N log 2 pi);
+ *   grad[0] = d/d jitter (0 when jitter <= DBL_EPSILON, solver.cpp:379-389,419-426),
+ *   then d/d a_real, c_real, a_comp, b_comp, c_comp, d_comp: n_grad must be
+ *   1 + 2 n_a_real + 4 n_a_comp.
+ * Returns CLR_NOT_POSITIVE_DEFINITE where the reference throws linalg_exception.
+ * Total width (with general terms) up to 64. */
+int clr_solver_grad_log_likelihood(clr_solver* s, double jitter,
+                                   int n_a_real, const double* a_real,
+                                   int n_c_real, const double* c_real,
+                                   int n_a_comp, const double* a_comp,
+                                   int n_b_comp, const double* b_comp,
+                                   int n_c_comp, const double* c_comp,
+                                   int n_d_comp, const double* d_comp,
+                                   int n_A, const double* A,
+                                   int U_rows, int U_cols, const double* U,
+                                   int V_rows, int V_cols, const double* V,
+                                   int n_x, const double* x,
+                                   int n_y, const double* y,
+                                   int n_diag, const double* diag,
+                                   double* value, int n_grad, double* grad);
+
 /* PicklableCholeskySolver::serialize / deserialize, solver.cpp:36-58 (bound as
  * __getstate__/__setstate__, solver.cpp:644-663).  get_dims first, then
  * get_state into caller buffers of J*(N-1), J*(N-1), J*N and N doubles

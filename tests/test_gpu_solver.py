@@ -229,13 +229,80 @@ def test_log_likelihood(with_general):  # tests/test_celerite.py:311-404
     assert np.allclose(ll, ll0)
 
 
-def test_grad_log_likelihood_contract():  # tests/test_celerite.py:407-446 (no-autodiff arm)
-    gp = GP(terms.RealTerm(log_a=0.1, log_c=0.5))
+GRAD_KERNELS = [  # tests/test_celerite.py:407-423
+    lambda: terms.RealTerm(log_a=0.1, log_c=0.5),
+    lambda: terms.RealTerm(log_a=0.1, log_c=0.5) + terms.RealTerm(log_a=-0.1, log_c=0.7),
+    lambda: terms.ComplexTerm(log_a=0.1, log_c=0.5, log_d=0.1),
+    lambda: terms.ComplexTerm(log_a=0.1, log_b=-0.2, log_c=0.5, log_d=0.1),
+    lambda: terms.JitterTerm(log_sigma=0.1),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=-1, log_omega0=0.5) + terms.JitterTerm(log_sigma=0.1),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=-1, log_omega0=0.5),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5) + terms.RealTerm(log_a=0.1, log_c=0.4),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5) * terms.RealTerm(log_a=0.1, log_c=0.4),
+]
+
+
+@pytest.mark.parametrize("make_kernel", GRAD_KERNELS)
+@pytest.mark.parametrize("with_general", [False, True])
+def test_grad_log_likelihood(make_kernel, with_general):  # tests/test_celerite.py:425-446
+    """The solver-level gradient (value + d/d(jitter, coefficients), solver.cpp:347-463)
+    against the dual-number oracle on the reference test's inputs; the GP-level call
+    then stops where the reference's does without autograd (ImportError, :441-446)."""
+    from oracle import grad as ograd
+
+    kernel = make_kernel()
     np.random.seed(42)
     x = np.sort(np.random.rand(100))
-    gp.compute(x, np.random.uniform(0.1, 0.5, len(x)))
-    with pytest.raises((ImportError, RuntimeError)):
-        gp.grad_log_likelihood(np.sin(x))
+    yerr = np.random.uniform(0.1, 0.5, len(x))
+    y = np.sin(x)
+    if with_general:
+        A, U, V = general_terms(x, np.random.rand)
+    else:
+        A, U, V = NO_GENERAL
+    gp = GP(kernel)
+    gp.compute(x, yerr, A=A, U=U, V=V)
+    args = (kernel.jitter,) + tuple(kernel.coefficients) + (A, U, V, x, y, yerr ** 2)
+    value, g = gp.solver.grad_log_likelihood(*args)
+    v0, g0 = ograd.grad_log_likelihood(*args)
+    assert g.shape == g0.shape == (1 + 2 * len(args[1]) + 4 * len(args[3]),)
+    assert abs(value - v0) <= 1e-11 * abs(v0)
+    assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
+    # the value is the log-likelihood up to the reference's odd constant (solver.cpp:415)
+    ll = gp.log_likelihood(y)
+    assert np.isclose(value + 0.5 * np.pi * np.log(len(x)), ll + 0.5 * len(x) * np.log(2 * np.pi), rtol=1e-12)
+    if not terms.HAS_AUTOGRAD:
+        if kernel.vector_size:
+            with pytest.raises(ImportError):
+                gp.grad_log_likelihood(y)
+
+
+def test_grad_log_likelihood_wide_and_long():
+    """Widths 17 and 40 (both register layouts above 16) at N = 700, zero-jitter rule,
+    dimension checks and the exception of an indefinite matrix."""
+    from oracle import grad as ograd
+
+    rng = np.random.RandomState(3)
+    N = 700
+    x = np.sort(rng.uniform(0, 30, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    y = rng.randn(N)
+    s = celerite_amd.CholeskySolver()
+    for JR, JC in ((1, 8), (4, 18)):
+        co = (np.exp(rng.uniform(-1, 1, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0, JC)),
+              0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
+        for jitter in (0.0, 0.3):
+            args = (jitter,) + co + NO_GENERAL + (x, y, diag)
+            value, g = s.grad_log_likelihood(*args)
+            v0, g0 = ograd.grad_log_likelihood(*args)
+            assert abs(value - v0) <= 1e-11 * abs(v0)
+            assert np.max(np.abs(g - g0) / (1.0 + np.abs(g0))) <= 1e-9
+            assert (g[0] == 0.0) == (jitter == 0.0)   # solver.cpp:379-389,419-426
+    co = (np.array([-3.0]), np.array([0.5]), np.empty(0), np.empty(0), np.empty(0), np.empty(0))
+    with pytest.raises(celerite_amd.solver.LinAlgError):
+        s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y, np.zeros(N))
+    with pytest.raises(RuntimeError):
+        s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
 def test_predict():  # tests/test_celerite.py:468-496

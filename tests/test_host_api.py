@@ -107,7 +107,7 @@ def test_host_helpers():
     assert solver.check_coefficients(a, c[:1], ac, bc, cc, dc) is False  # utils.h:41
     with pytest.raises(NotImplementedError):
         solver.CARMASolver(-0.5, np.array([0.1]), np.array([0.2]))
-    assert solver.has_autodiff() is False
+    assert solver.has_autodiff() is True   # forward-mode gradient kernels (csrc/grad_kernels.hip)
 
 
 def test_build_gp():  # tests/test_celerite.py:292-309
@@ -138,8 +138,8 @@ def test_gp_bookkeeping_and_errors():
         gp.get_matrix()
     K = gp.get_matrix(np.array([0.0, 1.0]), np.array([0.0, 0.5, 1.0]))
     assert K.shape == (2, 3) and np.isclose(K[0, 0], np.exp(0.1))
-    with pytest.raises(RuntimeError, match="autodiff"):
-        gp.grad_log_likelihood(np.ones(3))  # celerite.py:247-251 when has_autodiff() is False
+    with pytest.raises(RuntimeError, match="you must call 'compute' first"):
+        gp.grad_log_likelihood(np.ones(3))  # celerite.py:256 -> _process_input
     gp["kernel:log_a"] = 0.3
     assert gp.get_parameter("kernel:log_a") == 0.3
     gp.freeze_parameter("kernel:log_c")

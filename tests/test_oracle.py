@@ -242,3 +242,53 @@ def test_batch_threads_agree():
     four = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"], nthreads=4)
     for a, b in zip(one, four):
         assert np.array_equal(a, b)
+
+
+# ---- gradient oracle (oracle/grad.py: solver.cpp:347-463 on dual numbers) ----------------
+@pytest.mark.parametrize("with_general", [False, True])
+@pytest.mark.parametrize("jitter", [0.0, 0.05])
+def test_grad_oracle_value_and_finite_differences(with_general, jitter):
+    """Pins the dual-number restatement the way the reference's own gradient test does
+    (tests/test_celerite.py:452-481: finite differences, eps = 1.34e-7): its value
+    equals the pinned log-likelihood (up to the reference's pi*log(N) constant) and
+    every partial equals a central difference of it."""
+    from oracle import grad as ograd
+
+    np.random.seed(42)
+    x = np.sort(np.random.rand(100))          # tests/test_celerite.py:427-430
+    yerr = np.random.uniform(0.1, 0.5, len(x))
+    y = np.sin(x)
+    gen = general_terms(x, np.random.rand) if with_general else NO_GENERAL
+    co = [np.array([1.5, 0.3]), np.array([0.7, 2.0]), np.array([1.0, 0.4]), np.array([0.1, 0.3]),
+          np.array([1.2, 0.5]), np.array([3.0, 1.5])]
+
+    def ll(jit, c):
+        s = ref.RefSolver()
+        s.compute(jit, *c, *gen, x, yerr ** 2)
+        return -0.5 * (s.dot_solve(y) + s.log_determinant() + np.pi * np.log(len(x)))
+
+    value, g = ograd.grad_log_likelihood(jitter, *co, *gen, x, y, yerr ** 2)
+    assert g.shape == (13,)
+    assert abs(value - ll(jitter, co)) <= 1e-12 * abs(value)
+    eps = 1e-6
+    fd = []
+    for i in range(6):
+        for j in range(2):
+            cp = [c.copy() for c in co]
+            cm = [c.copy() for c in co]
+            cp[i][j] += eps
+            cm[i][j] -= eps
+            fd.append((ll(jitter, cp) - ll(jitter, cm)) / (2 * eps))
+    assert np.allclose(g[1:], fd, rtol=2e-6, atol=1e-7)
+    if jitter > 0:
+        assert np.isclose(g[0], (ll(jitter + eps, co) - ll(jitter - eps, co)) / (2 * eps), rtol=2e-6)
+    else:
+        assert g[0] == 0.0                     # solver.cpp:379-389,419-426
+
+
+def test_grad_oracle_raises_like_the_reference():
+    from oracle import grad as ograd
+
+    x = np.linspace(0, 1, 20)
+    with pytest.raises(ograd.LinAlgError):
+        ograd.grad_log_likelihood(0.0, [-3.0], [0.5], [], [], [], [], *NO_GENERAL, x, np.sin(x), np.zeros(20))
