@@ -202,19 +202,32 @@ int upload(DevBuf& buf, const double* host, size_t n, hipStream_t s) {
 }
 
 // Chunk count for the scan on `B` problems of `N` samples.
-int auto_chunks(int B, int N) {
+int auto_chunks(int B, int N, bool with_replay = false) {
   if (N < 128) return 1;
-  // aim at one wave per SIMD (256 CUs x 4 SIMDs x 64 lanes) over the batch (the prefix
-  // phase is sequential in the chunk count, so fewer, longer chunks win: measured),
-  // keep chunks at least 48 samples long, and a multiple of 64 lanes per problem
-  const long target_lanes = 65536;
-  long per = (target_lanes + B - 1) / B;
-  per = ((per + 63) / 64) * 64;
-  const long max_by_len = std::max<long>(1, N / 48);
-  if (per > max_by_len) per = max_by_len;
-  if (per > 64) per = (per / 64) * 64;
-  if (per < 1) per = 1;
-  return (int)per;
+  // Cost model (measured on MI355X): the big kernels run
+  // ceil(B * ceil(nchunk / 64) / 1024) rounds of waves (one per SIMD) over L = N / nchunk
+  // steps at ~2.4 us per step (3.3 us when the replay pass runs too); the prefix phase is
+  // sequential in the chunk count at ~2.6 us per chunk (4096 problems per round).  Many
+  // problems want exactly one wave per SIMD; a single long series wants ~sqrt(N) chunks.
+  const double c_step = with_replay ? 3.3e-6 : 2.4e-6, c_chunk = 2.6e-6;
+  const long max_by_len = std::max<long>(1, N / 16);
+  auto cost = [&](long nc) {
+    long L = (N + nc - 1) / nc;
+    if (nc > 1 && L > 8) L = (L + 7) & ~7L;
+    const long waves = (long)B * ((nc + 63) / 64);
+    const long rounds = (waves + 1023) / 1024;
+    return rounds * L * c_step + nc * c_chunk * ((B + 4095) / 4096);
+  };
+  long best = 1;
+  double best_cost = cost(1);
+  auto consider = [&](long nc) {
+    if (nc < 1 || nc > max_by_len) return;
+    const double c = cost(nc);
+    if (c < best_cost) { best_cost = c; best = nc; }
+  };
+  for (long nc : {2L, 3L, 4L, 6L, 8L, 12L, 16L, 24L, 32L, 48L}) consider(nc);
+  for (long nc = 64; nc <= max_by_len && nc <= 65536; nc += 64) consider(nc);
+  return (int)best;
 }
 
 }  // namespace
@@ -476,7 +489,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
     }
     P.coop_prefix = 1;
-    P.nchunk = auto_chunks(1, N);
+    P.nchunk = auto_chunks(1, N, true);
     P.L = (N + P.nchunk - 1) / P.nchunk;
     P.nchunk = (N + P.L - 1) / P.L;  // drop empty trailing chunks
     if ((st = s->ws_elems.reserve((size_t)P.nchunk * L->elem_doubles)) != CLR_OK) return st;
@@ -617,6 +630,22 @@ int clr_solver_log_determinant(const clr_solver* s, double* out) {
   return CLR_OK;
 }
 
+// dot_solve / solve as chunked scans for long series of width <= 8 (sweep_kernels.hip)
+static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, double* quad, int backward) {
+  clr::SweepParams P;
+  memset(&P, 0, sizeof(P));
+  P.N = s->N; P.J = s->J; P.nrhs = nrhs;
+  P.nchunk = clr::sweep_chunks(s->N);
+  P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
+  P.nchunk = (s->N - 1 + P.L - 1) / P.L;
+  P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+  P.in = in; P.out = out; P.quad = quad; P.backward = backward;
+  int st = s->ws_elems.reserve(clr::sweep_workspace_doubles(s->J, P.nchunk, nrhs));
+  if (st != CLR_OK) return st;
+  clr::launch_sweep_scan(P, s->ws_elems.p, s->stream);
+  return CLR_OK;
+}
+
 int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double* out) {
   clr_solver* s = const_cast<clr_solver*>(cs);
   if (n_b != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // :327
@@ -625,8 +654,12 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   if (st != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
-  clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
-                        s->scalars.p, s->stream);
+  if (clr::sweep_scan_supported(s->N, s->J)) {
+    if ((st = sweep_scan(s, 1, s->scratch.p, nullptr, s->scalars.p, 0)) != CLR_OK) return st;
+  } else {
+    clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                          s->scalars.p, s->stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, s->scalars.p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -648,8 +681,13 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
   int st = sweep_common(s, b_rows, nrhs, b);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  clr::launch_solve(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
-                    s->scratch2.p, s->stream);
+  if (clr::sweep_scan_supported(s->N, s->J)) {
+    if ((st = sweep_scan(s, nrhs, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;   // :240-248
+    if ((st = sweep_scan(s, nrhs, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;  // :249-259
+  } else {
+    clr::launch_solve(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                      s->scratch2.p, s->stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(x, s->scratch2.p, sizeof(double) * (size_t)s->N * nrhs,
                          hipMemcpyDeviceToHost, s->stream));

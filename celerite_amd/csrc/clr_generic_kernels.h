@@ -14,6 +14,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 namespace clr {
 
 struct GenericProblem {
@@ -22,6 +24,21 @@ struct GenericProblem {
   const double *U, *V;  // device, row-major [J_general][N] (may be null)
   const double* t;      // device [N]
 };
+
+// dot_solve / solve on a stored factor as chunked scans over n (sweep_kernels.hip).
+struct SweepParams {
+  int N, J, nchunk, L, nrhs;
+  const double *phi, *u, *W, *D;  // the factor, reference storage
+  const double* in;               // forward: b; backward: the forward sweep's output (undivided)
+  double* out;                    // x per column (may alias `in` going backward) or null
+  double* quad;                   // [nrhs] sum x_n^2 / D_n (dot_solve) or null
+  int backward;
+  double *elems, *starts, *part;  // workspace, set by launch_sweep_scan
+};
+bool sweep_scan_supported(int N, int J);
+int sweep_chunks(int N);
+size_t sweep_workspace_doubles(int J, int nchunk, int nrhs);
+void launch_sweep_scan(SweepParams P, double* workspace, hipStream_t s);
 
 // solver.cpp:347-463 (grad_kernels.hip): one wave per partial derivative.
 struct GradParams {

@@ -305,6 +305,41 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
+@pytest.mark.parametrize("N", [2048, 5000, 40000])
+@pytest.mark.parametrize("shape", ["real", "w4", "w8", "w4+general"])
+def test_long_series_sweeps_are_chunked_scans(N, shape):
+    """dot_solve / solve on a stored factor switch to chunked scans over n at N >= 2048 and
+    width <= 8 (csrc/sweep_kernels.hip): same numbers as the oracle's sequential sweeps
+    (cholesky.h:218-401), several right-hand sides, general terms included."""
+    rng = np.random.RandomState(N % 97)
+    t = np.sort(rng.uniform(0, N / 50.0, N))
+    diag = rng.uniform(0.1, 0.4, N)
+    gen = NO_GENERAL
+    if shape == "real":
+        co = (np.array([1.3]), np.array([0.5]), np.empty(0), np.empty(0), np.empty(0), np.empty(0))
+    elif shape == "w8":
+        co = (np.array([1.3, 0.4]), np.array([0.5, 0.05]), np.array([1.0, 0.3, 0.6]), np.array([0.1, 0.0, 0.2]),
+              np.array([0.3, 0.8, 0.1]), np.array([1.0, 2.5, 0.4]))
+    else:
+        co = COEFFS_W4
+        if shape == "w4+general":
+            U = np.vander((t - t.mean()) / (t.max() - t.min()), 4).T
+            V = U * rng.rand(4)[:, None]
+            gen = (np.sum(U * V, axis=0) + 1e-8, U, V)
+    s = celerite_amd.CholeskySolver()
+    r = ref.RefSolver()
+    s.compute(0.0, *co, *gen, t, diag)
+    r.compute(0.0, *co, *gen, t, diag)
+    b = rng.randn(N, 3)
+    q, q0 = s.dot_solve(b[:, 0]), r.dot_solve(b[:, 0])
+    assert abs(q - q0) <= 1e-12 * abs(q0)
+    x, x0 = s.solve(b), r.solve(b)
+    assert x.shape == (N, 3)
+    assert np.max(np.abs(x - x0)) <= 1e-11 * np.max(np.abs(x0))
+    x1 = s.solve(b[:, 1])
+    assert np.max(np.abs(x1[:, 0] - x0[:, 1])) <= 1e-11 * np.max(np.abs(x0))
+
+
 def test_predict():  # tests/test_celerite.py:468-496
     np.random.seed(42)
     x = np.linspace(1, 59, 300)
