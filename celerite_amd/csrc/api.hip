@@ -700,8 +700,21 @@ int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z
   int st = sweep_common(s, z_rows, nrhs, z);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  clr::launch_dot_L(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
-                    s->scratch2.p, s->stream);
+  if (clr::sweep_scan_supported(s->N, s->J)) {
+    clr::SweepParams P;
+    memset(&P, 0, sizeof(P));
+    P.N = s->N; P.J = s->J; P.nrhs = nrhs;
+    P.nchunk = clr::sweep_chunks(s->N);
+    P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
+    P.nchunk = (s->N - 1 + P.L - 1) / P.L;
+    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    P.in = s->scratch.p; P.out = s->scratch2.p;
+    if ((st = s->ws_elems.reserve((size_t)nrhs * P.nchunk * 3 * s->J)) != CLR_OK) return st;
+    clr::launch_dot_L_scan(P, s->ws_elems.p, s->stream);
+  } else {
+    clr::launch_dot_L(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                      s->scratch2.p, s->stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(y, s->scratch2.p, sizeof(double) * (size_t)s->N * nrhs,
                          hipMemcpyDeviceToHost, s->stream));
@@ -811,14 +824,32 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
                 "state does not carry them (same as the reference, solver.cpp:36-42)");
   hipStream_t stream = s->stream;
   // alpha = K^-1 y  (:608)
-  clr::launch_solve(s->N, s->J, 1, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
-                    s->scratch2.p, stream);
+  if (clr::sweep_scan_supported(s->N, s->J)) {
+    if ((st = sweep_scan(s, 1, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;
+    if ((st = sweep_scan(s, 1, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;
+  } else {
+    clr::launch_solve(s->N, s->J, 1, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
+                      s->scratch2.p, stream);
+  }
+  // the reference's two passes walk the prediction points in order (:616-653,657-695):
+  // with sorted points both passes become scans + one thread per point
+  bool sorted = true;
+  for (int m = 1; m < M && sorted; ++m) sorted = xs[m - 1] <= xs[m];
+  const bool scan = sorted && clr::predict_scan_supported(s->N, s->J_real, s->J_comp);
+  int pchunk = 0, pL = 0;
+  if (scan) {
+    pchunk = clr::sweep_chunks(s->N);
+    pL = (s->N + pchunk - 1) / pchunk;
+    pchunk = (s->N + pL - 1) / pL;
+    if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk))) != CLR_OK) return st;
+  }
   DevBuf dxs, dpred;
   if ((st = upload(dxs, xs, (size_t)M, stream)) != CLR_OK) return st;
   if ((st = dpred.reserve((size_t)M)) != CLR_OK) { dxs.release(); return st; }
   hipError_t e = hipMemsetAsync(dpred.p, 0, sizeof(double) * (size_t)M, stream);
   const clr::GenericProblem g = generic_view(s);
-  clr::launch_predict(g, s->scratch2.p, M, dxs.p, dpred.p, stream);
+  if (scan) clr::launch_predict_scan(g, s->scratch2.p, M, dxs.p, dpred.p, s->ws_elems.p, pchunk, pL, stream);
+  else clr::launch_predict(g, s->scratch2.p, M, dxs.p, dpred.p, stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess)
     e = hipMemcpyAsync(pred, dpred.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, stream);

@@ -39,6 +39,13 @@ bool sweep_scan_supported(int N, int J);
 int sweep_chunks(int N);
 size_t sweep_workspace_doubles(int J, int nchunk, int nrhs);
 void launch_sweep_scan(SweepParams P, double* workspace, hipStream_t s);
+// dot_L (cholesky.h:409-431) as a chunked diagonal scan; workspace: nrhs * nchunk * 3 J doubles
+void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s);
+// predict (cholesky.h:599-698): chunked diagonal scans + one thread per (sorted) prediction point
+bool predict_scan_supported(int N, int J_real, int J_comp);
+size_t predict_workspace_doubles(int nchunk);
+void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, const double* xs, double* pred,
+                         double* workspace, int nchunk, int L, hipStream_t s);
 
 // solver.cpp:347-463 (grad_kernels.hip): one wave per partial derivative.
 struct GradParams {

@@ -174,7 +174,249 @@ void run(const SweepParams& P, hipStream_t s) {
   if (P.quad) hipLaunchKernelGGL(sweep_finalize_kernel, dim3((P.nrhs + 63) / 64), dim3(64), 0, s, P);
 }
 
+// ---------------------------------------------------------------------------
+// dot_L (cholesky.h:409-431): no feedback -- f_n = phi o (f_{n-1} + W t_{n-1}) with
+// t_n = sqrt(D_n) z_n, y_n = t_n + u . f_n: a DIAGONAL affine recurrence, element (a, c).
+// ---------------------------------------------------------------------------
+template <int J, bool REPLAY>
+__global__ void __launch_bounds__(64) dotl_kernel(const SweepParams P) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= P.nchunk) return;
+  const double* z = P.in + (long)blockIdx.y * P.N;
+  double* y = P.out + (long)blockIdx.y * P.N;
+  double* e = P.elems + ((long)blockIdx.y * P.nchunk + c) * (2 * J);
+  double a[J], f[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { a[j] = 1.0; f[j] = REPLAY ? P.starts[((long)blockIdx.y * P.nchunk + c) * J + j] : 0.0; }
+  const int s0 = c * P.L + 1;
+  const int s1 = min(s0 + P.L, P.N);
+  if (REPLAY && c == 0) y[0] = sqrt(P.D[0]) * z[0];  // :421-422
+  for (int n = s0; n < s1; ++n) {
+    const long col = (long)J * (n - 1);
+    const double tprev = sqrt(P.D[n - 1]) * z[n - 1];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {  // :424-426
+      const double ph = P.phi[col + j];
+      f[j] = ph * (f[j] + P.W[col + j] * tprev);
+      if (!REPLAY) a[j] *= ph;
+      acc += P.u[col + j] * f[j];
+    }
+    if (REPLAY) y[n] = sqrt(P.D[n]) * z[n] + acc;
+  }
+  if (!REPLAY) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) { e[j] = a[j]; e[J + j] = f[j]; }
+  }
+}
+
+template <int J>
+__global__ void __launch_bounds__(64) dotl_prefix_kernel(const SweepParams P) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= P.nrhs) return;
+  double f[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) f[j] = 0.0;
+  for (int c = 0; c < P.nchunk; ++c) {
+    const double* e = P.elems + ((long)col * P.nchunk + c) * (2 * J);
+    double* st = P.starts + ((long)col * P.nchunk + c) * J;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      st[j] = f[j];
+      f[j] = e[j] * f[j] + e[J + j];
+    }
+  }
+}
+
+template <int J>
+void run_dotl(const SweepParams& P, hipStream_t s) {
+  const dim3 grid((P.nchunk + 63) / 64, P.nrhs);
+  hipLaunchKernelGGL((dotl_kernel<J, false>), grid, dim3(64), 0, s, P);
+  hipLaunchKernelGGL((dotl_prefix_kernel<J>), dim3((P.nrhs + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL((dotl_kernel<J, true>), grid, dim3(64), 0, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// predict (cholesky.h:599-698): two diagonal recurrences over the samples,
+//   forward   Q_r <- (Q_r + alpha_n v_r(t_n)) exp(-c_r (t_{n+1} - t_n))       (:618-636)
+//   backward  Q_r <- (Q_r + alpha_n u_r(t_n)) exp(-c_r (t_n - t_{n-1}))       (:662-679)
+// and every prediction point x_m reads the forward Q of the sample interval it falls in
+// (t_n < x_m <= t_{n+1}; n = N-1 beyond the data; none at or before t_0, :616,638) and
+// the backward Q of t_{n-1} < x_m <= t_n (n = 0 at or before t_0; none beyond the
+// data, :657,681).  Chunk starts of both recurrences come from a chunked scan; then ONE
+// THREAD PER PREDICTION POINT walks from its chunk start to its interval (<= L steps)
+// and evaluates both sums.  Needs the prediction points sorted (the reference's while
+// loops assume it); api.hip checks and otherwise uses the sequential kernel.
+// ---------------------------------------------------------------------------
+constexpr int PJ = 8;  // rows (J_real + 2 J_comp) handled per thread
+
+struct PredictRows {
+  double a[PJ], b[PJ], c[PJ], d[PJ];
+  int kind[PJ];  // 0 real, 1 cos row, 2 sin row, -1 unused
+  int rows;
+};
+
+__device__ __forceinline__ void load_rows(const GenericProblem& g, PredictRows& r) {
+  r.rows = g.J_real + 2 * g.J_comp;
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) {
+    r.kind[j] = -1; r.a[j] = r.b[j] = r.c[j] = r.d[j] = 0.0;
+    if (j < g.J_real) {
+      r.kind[j] = 0; r.a[j] = g.a_real[j]; r.c[j] = g.c_real[j];
+    } else if (j < r.rows) {
+      const int jj = (j - g.J_real) >> 1;
+      r.kind[j] = 1 + ((j - g.J_real) & 1);
+      r.a[j] = g.a_comp[jj]; r.b[j] = g.b_comp[jj]; r.c[j] = g.c_comp[jj]; r.d[j] = g.d_comp[jj];
+    }
+  }
+}
+// v_r(t): 1 | cos | sin (:622,627,629);  u_r(t): a | a cos + b sin | a sin - b cos (:666,672-677)
+__device__ __forceinline__ void row_uv(const PredictRows& r, int j, double t, double* u, double* v) {
+  if (r.kind[j] <= 0) { *u = r.a[j]; *v = 1.0; return; }
+  double sd, cd;
+  sincos(r.d[j] * t, &sd, &cd);
+  *v = r.kind[j] == 1 ? cd : sd;
+  *u = r.kind[j] == 1 ? r.a[j] * cd + r.b[j] * sd : r.a[j] * sd - r.b[j] * cd;
+}
+// one step of the forward (dir = 0) or backward (dir = 1) recurrence at sample n
+__device__ __forceinline__ void predict_step(const PredictRows& r, const double* t, const double* alpha,
+                                             int N, int n, int dir, double* Q, double* A) {
+  const double tn = t[n];
+  const double dt = dir == 0 ? ((n < N - 1) ? t[n + 1] - tn : 0.0) : ((n > 0) ? tn - t[n - 1] : 0.0);
+  const double al = alpha[n];
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) {
+    if (r.kind[j] < 0) continue;
+    double u, v;
+    row_uv(r, j, tn, &u, &v);
+    const double e = exp(-r.c[j] * dt);
+    Q[j] = (Q[j] + al * (dir == 0 ? v : u)) * e;
+    if (A) A[j] *= e;
+  }
+}
+
+// elems: [dir][chunk][2 PJ] = (a, c);  starts: [dir][chunk][PJ]
+__global__ void __launch_bounds__(64) predict_summarize_kernel(GenericProblem g, const double* alpha,
+                                                               int nchunk, int L, double* elems) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= nchunk) return;
+  const int dir = blockIdx.y;
+  PredictRows r;
+  load_rows(g, r);
+  double Q[PJ], A[PJ];
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) { Q[j] = 0.0; A[j] = 1.0; }
+  const int lo = c * L, hi = min(lo + L, g.N);
+  if (dir == 0) for (int n = lo; n < hi; ++n) predict_step(r, g.t, alpha, g.N, n, 0, Q, A);
+  else          for (int n = hi - 1; n >= lo; --n) predict_step(r, g.t, alpha, g.N, n, 1, Q, A);
+  double* e = elems + ((long)dir * nchunk + c) * (2 * PJ);
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) { e[j] = A[j]; e[PJ + j] = Q[j]; }
+}
+
+__global__ void __launch_bounds__(64) predict_prefix_kernel(int nchunk, const double* elems, double* starts) {
+  const int dir = threadIdx.x;
+  if (dir > 1) return;
+  double Q[PJ];
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) Q[j] = 0.0;
+  for (int i = 0; i < nchunk; ++i) {
+    const int c = dir == 0 ? i : nchunk - 1 - i;  // the backward recurrence meets the chunks in reverse
+    const double* e = elems + ((long)dir * nchunk + c) * (2 * PJ);
+    double* st = starts + ((long)dir * nchunk + c) * PJ;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      st[j] = Q[j];
+      Q[j] = e[j] * Q[j] + e[PJ + j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) predict_points_kernel(GenericProblem g, const double* alpha, int nchunk,
+                                                            int L, const double* starts, int M,
+                                                            const double* xs, double* pred) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= M) return;
+  const int N = g.N;
+  const double* t = g.t;
+  const double xm = xs[m];
+  PredictRows r;
+  load_rows(g, r);
+  // k = number of samples with t_n < x_m  (lower bound)
+  int lo = 0, hi = N;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (t[mid] < xm) lo = mid + 1; else hi = mid;
+  }
+  const int k = lo;
+  double total = 0.0;
+  if (k >= 1) {  // forward: interval n = k - 1 (t_n < x_m <= t_{n+1}, or beyond the last sample)
+    const int nf = k - 1, c = nf / L;
+    double Q[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) Q[j] = starts[((long)0 * nchunk + c) * PJ + j];
+    for (int n = c * L; n <= nf; ++n) predict_step(r, t, alpha, N, n, 0, Q, nullptr);
+    const double tref = nf < N - 1 ? t[nf + 1] : t[N - 1];
+    const double dt = xm - tref;  // :640
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      if (r.kind[j] < 0) continue;
+      double u, v;
+      row_uv(r, j, xm, &u, &v);
+      total += u * exp(-r.c[j] * dt) * Q[j];  // :643,649-650
+    }
+  }
+  if (k < N) {  // backward: interval n = k (t_{n-1} < x_m <= t_n, or at / before the first sample)
+    const int nb = k, c = nb / L;
+    double Q[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) Q[j] = starts[((long)1 * nchunk + c) * PJ + j];
+    for (int n = min(c * L + L, N) - 1; n >= nb; --n) predict_step(r, t, alpha, N, n, 1, Q, nullptr);
+    const double tref = nb > 0 ? t[nb - 1] : t[0];
+    const double dt = tref - xm;  // :683
+    double pm = 0.0;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      if (r.kind[j] < 0) continue;
+      double u, v;
+      row_uv(r, j, xm, &u, &v);
+      pm += v * exp(-r.c[j] * dt) * Q[j];  // :686,690-691
+    }
+    total += pm;
+  }
+  pred[m] = total;
+}
+
 }  // namespace
+
+bool predict_scan_supported(int N, int J_real, int J_comp) { return J_real + 2 * J_comp <= PJ && N >= 2048; }
+size_t predict_workspace_doubles(int nchunk) { return (size_t)2 * nchunk * (3 * PJ); }
+
+void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, const double* xs, double* pred,
+                         double* workspace, int nchunk, int L, hipStream_t s) {
+  double* elems = workspace;
+  double* starts = workspace + (size_t)2 * nchunk * 2 * PJ;
+  hipLaunchKernelGGL(predict_summarize_kernel, dim3((nchunk + 63) / 64, 2), dim3(64), 0, s, g, alpha, nchunk, L, elems);
+  hipLaunchKernelGGL(predict_prefix_kernel, dim3(1), dim3(64), 0, s, nchunk, elems, starts);
+  hipLaunchKernelGGL(predict_points_kernel, dim3((M + 63) / 64), dim3(64), 0, s, g, alpha, nchunk, L, starts, M, xs, pred);
+}
+
+void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s) {
+  const size_t pc = (size_t)P.nrhs * P.nchunk;
+  P.elems = workspace;
+  P.starts = P.elems + pc * 2 * P.J;
+  switch (P.J) {
+    case 1: run_dotl<1>(P, s); break;
+    case 2: run_dotl<2>(P, s); break;
+    case 3: run_dotl<3>(P, s); break;
+    case 4: run_dotl<4>(P, s); break;
+    case 5: run_dotl<5>(P, s); break;
+    case 6: run_dotl<6>(P, s); break;
+    case 7: run_dotl<7>(P, s); break;
+    case 8: run_dotl<8>(P, s); break;
+    default: break;
+  }
+}
 
 bool sweep_scan_supported(int N, int J) { return J >= 1 && J <= 8 && N >= 2048; }
 

@@ -338,6 +338,14 @@ def test_long_series_sweeps_are_chunked_scans(N, shape):
     assert np.max(np.abs(x - x0)) <= 1e-11 * np.max(np.abs(x0))
     x1 = s.solve(b[:, 1])
     assert np.max(np.abs(x1[:, 0] - x0[:, 1])) <= 1e-11 * np.max(np.abs(x0))
+    yl, yl0 = s.dot_L(b), r.dot_L(b)                     # cholesky.h:409-431, diagonal scan
+    assert np.max(np.abs(yl - yl0)) <= 1e-12 * np.max(np.abs(yl0))
+    if shape != "w4+general":                            # predict: cholesky.h:599-698
+        y = np.sin(t) + 0.1 * b[:, 0]
+        for xs in (np.linspace(t[0] - 1.0, t[-1] + 1.0, 777),
+                   np.sort(np.concatenate([t[::37], t[:5], rng.uniform(t[0], t[-1], 200)]))):
+            p, p0 = s.predict(y, xs), r.predict(y, xs)
+            assert np.max(np.abs(p - p0)) <= 1e-10 * max(1.0, np.max(np.abs(p0)))
 
 
 def test_predict():  # tests/test_celerite.py:468-496
