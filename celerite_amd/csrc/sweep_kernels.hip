@@ -14,7 +14,7 @@
 // ("dot_solve / solve are affine-linear once the factor exists").
 // A lane reads its own run of the factor: J contiguous doubles per array and step (one
 // 64-B line at J = 8).  Widths 1..8 (compile-time); wider factors and short series keep
-// the sequential kernels of generic_kernels.hip.  Results differ from the sequential
+// the sequential kernels of generic_kernels.hip (N < 256 or J > 8).  Results differ from the sequential
 // sweep only by re-association (tests: <= 1e-12 relative against the oracle).
 #include "clr_generic_kernels.h"
 
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(64) predict_points_kernel(GenericProblem g, co
 
 }  // namespace
 
-bool predict_scan_supported(int N, int J_real, int J_comp) { return J_real + 2 * J_comp <= PJ && N >= 2048; }
+bool predict_scan_supported(int N, int J_real, int J_comp) { return J_real + 2 * J_comp <= PJ && N >= 256; }
 size_t predict_workspace_doubles(int nchunk) { return (size_t)2 * nchunk * (3 * PJ); }
 
 void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, const double* xs, double* pred,
@@ -418,7 +418,8 @@ void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s) {
   }
 }
 
-bool sweep_scan_supported(int N, int J) { return J >= 1 && J <= 8 && N >= 2048; }
+// (a sequential sweep costs ~0.37 us per sample; three launches of the scan ~15 us)
+bool sweep_scan_supported(int N, int J) { return J >= 1 && J <= 8 && N >= 256; }
 
 // ~1.8 sqrt(N) chunks balance the parallel phases (0.65 us per step) against the
 // sequential prefix (0.2 us per chunk); a multiple of 64 lanes

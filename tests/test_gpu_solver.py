@@ -305,10 +305,10 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
-@pytest.mark.parametrize("N", [2048, 5000, 40000])
+@pytest.mark.parametrize("N", [256, 700, 5000, 40000])
 @pytest.mark.parametrize("shape", ["real", "w4", "w8", "w4+general"])
 def test_long_series_sweeps_are_chunked_scans(N, shape):
-    """dot_solve / solve on a stored factor switch to chunked scans over n at N >= 2048 and
+    """dot_solve / solve on a stored factor switch to chunked scans over n at N >= 256 and
     width <= 8 (csrc/sweep_kernels.hip): same numbers as the oracle's sequential sweeps
     (cholesky.h:218-401), several right-hand sides, general terms included."""
     rng = np.random.RandomState(N % 97)
