@@ -343,3 +343,47 @@ def test_wide_plan_rejects_what_does_not_apply():
     plan.close()
     with pytest.raises(RuntimeError):
         batch.BatchedGP(2, 100, 1, 32)     # width 65
+
+
+def test_many_problems_short_series():
+    """More problems than one prefix round holds (4 problems per wave, 4096 per round) and a
+    ragged last wave everywhere; every problem against the oracle."""
+    B, N = 4133, 320
+    case = synthetic(B, N, 1, 1, "accuracy", seed=77)
+    case["a_real"][100, 0] = -9.0      # one indefinite problem in the middle of the batch
+    case["diag"][100] = 0.0
+    ll, ld, q, st = check(case, nchunk=6)
+    assert st[100] == 2 and st.sum() == 2
+
+
+def test_non_finite_observations_stay_in_their_problem():
+    """A NaN observation poisons only its own problem: the quadratic form is NaN, the
+    log-likelihood -inf (celerite.py:212-214), the status stays 0 and the log-determinant
+    is untouched; neighbours are exact."""
+    case = synthetic(6, 3000, 2, 1, "bench", seed=8)
+    case["y"][2, 1234] = np.nan
+    plan = batch.BatchedGP(6, 3000, 2, 1)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    for nchunk in (1, 20):
+        plan.set_chunks(nchunk)
+        ll, ld, q, st = plan.log_likelihood()
+        clean = dict(case)
+        clean["y"] = np.where(np.isnan(case["y"]), 0.0, case["y"])
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(clean), clean["t"], clean["diag"], clean["y"])
+        assert (st == 0).all()
+        assert np.isneginf(ll[2]) and np.isnan(q[2])
+        assert abs(ld[2] - d0[2]) <= REL * abs(d0[2])
+        ok = np.arange(6) != 2
+        assert np.max(np.abs(ll[ok] - l0[ok]) / np.abs(l0[ok])) <= REL
+    plan.close()
+
+
+def test_time_origin_and_scale_do_not_matter():
+    """Large absolute times (phase d*t ~ 1e6: still the FMA Cody-Waite range) and a
+    phase beyond 1e9 (library sincos flavour chosen on the host)."""
+    for scale, offset in ((1.0, 3.0e5), (1.0, -7.5e4), (1.0, 5.0e8)):   # the last: max|d| * max|t| = 2.8e9
+        case = synthetic(4, 2500, 1, 2, "bench", seed=12)
+        case["t"] = case["t"] * scale + offset
+        ll, ld, q, st = check(case, nchunk=16)
+        assert (st == 0).all()
