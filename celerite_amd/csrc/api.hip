@@ -207,9 +207,9 @@ int auto_chunks(int B, int N, bool with_replay = false) {
   // Cost model (measured on MI355X): the big kernels run
   // ceil(B * ceil(nchunk / 64) / 1024) rounds of waves (one per SIMD) over L = N / nchunk
   // steps at ~2.4 us per step (3.3 us when the replay pass runs too); the prefix phase is
-  // sequential in the chunk count at ~2.6 us per chunk (4096 problems per round).  Many
+  // sequential in the chunk count at ~2 us per chunk (4096 problems per round).  Many
   // problems want exactly one wave per SIMD; a single long series wants ~sqrt(N) chunks.
-  const double c_step = with_replay ? 3.3e-6 : 2.4e-6, c_chunk = 2.6e-6;
+  const double c_step = with_replay ? 3.3e-6 : 2.4e-6, c_chunk = 2.0e-6;
   const long max_by_len = std::max<long>(1, N / 16);
   auto cost = [&](long nc) {
     long L = (N + nc - 1) / nc;

@@ -208,6 +208,24 @@ __global__ void __launch_bounds__(64) prefix_kernel(const BatchParams P) {
   }
 }
 
+// Lane k (0..15, compile-time after unrolling) of the caller's 16-lane DPP row, for every
+// lane of that row: two v_mov_b32_dpp row_newbcast.  The prefix kernel's groups ARE DPP
+// rows; a __shfl is two ds_bpermute_b32 through the LDS crossbar (~100 cycles each for a
+// lone wave), and the Gauss-Jordan sweep does ~90 of these broadcasts per chunk.
+__device__ __forceinline__ int row_bcast_i32(int v, int k) {
+#define CLR_BC(K) case K: return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true)  /* row_newbcast:K */
+  switch (k) {
+    CLR_BC(0); CLR_BC(1); CLR_BC(2); CLR_BC(3); CLR_BC(4); CLR_BC(5); CLR_BC(6); CLR_BC(7);
+    CLR_BC(8); CLR_BC(9); CLR_BC(10); CLR_BC(11); CLR_BC(12); CLR_BC(13); CLR_BC(14);
+    default: return __builtin_amdgcn_mov_dpp(v, 0x15F, 0xf, 0xf, true);
+  }
+#undef CLR_BC
+}
+__device__ __forceinline__ double row_bcast(double v, int k) {
+  return __hiloint2double(row_bcast_i32(__double2hiint(v), k), row_bcast_i32(__double2loint(v), k));
+}
+__device__ __forceinline__ int row_bcast_int(int v, int k) { return row_bcast_i32(v, k); }
+
 // ---------------------------------------------------------------------------
 // Cooperative prefix: 16 lanes per problem (4 problems per wave) instead of one.
 // Same algebra as the advance part of chunk_update (clr_core.h), column-per-lane:
@@ -229,8 +247,15 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   constexpr int START = SZ + J;
   __shared__ double pbuf[4][8][8];  // pbuf[g][j][i] = P[i][j] (column j contiguous)
   __shared__ double xbuf[4][8][9];  // transpose buffer, padded
+  // the chunk's element, staged through LDS one chunk AHEAD: every lane of a group needs
+  // all of A (72 load instructions per lane and chunk with their HBM latency exposed);
+  // instead the group's 16 lanes fetch element c + 1 cooperatively (<= 10 coalesced loads
+  // each) while chunk c is processed, and everybody reads it from LDS (group stride 162
+  // doubles: the four groups' broadcast reads fall into disjoint banks)
+  constexpr int ESTRIDE = ((ELEM + 15) / 16) * 16 + 2;
+  constexpr int EPER = (ELEM + 15) / 16;
+  __shared__ double ebuf[2][4][ESTRIDE];
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
-  const int base = lane & 48;
   const bool rhs = (l >> 3) != 0;
   const int col = l & 7;
   const bool cv = col < J;
@@ -250,10 +275,23 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) pbuf[g][col][i] = 0.0;
   }
+  {
+    const double* E0 = P_.elems + (pb * P_.nchunk) * ELEM;
+#pragma unroll
+    for (int m = 0; m < EPER; ++m)
+      if (l + 16 * m < ELEM) ebuf[0][g][l + 16 * m] = E0[l + 16 * m];
+  }
   __syncthreads();
 
   for (int c = 0; c + 1 < P_.nchunk; ++c) {
-    const double* E = P_.elems + (pb * P_.nchunk + c) * ELEM;
+    double nx[EPER];  // this lane's share of element c + 1, in flight during the whole iteration
+    const bool more = c + 2 < P_.nchunk;
+    if (more) {
+      const double* En = P_.elems + (pb * P_.nchunk + c + 1) * ELEM;
+#pragma unroll
+      for (int m = 0; m < EPER; ++m) nx[m] = (l + 16 * m < ELEM) ? En[l + 16 * m] : 0.0;
+    }
+    const double* E = ebuf[c & 1][g];
     const double* A = E;
     const double* bv = E + J * J;
     const double* C = bv + J;
@@ -281,7 +319,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     for (int i = 0; i < J; ++i) hj += Pc[i] * et[i];
     double vj = 0.0;
 #pragma unroll
-    for (int i = 0; i < J; ++i) vj += jc[i] * __shfl(hj, base + 8 + i, 64);
+    for (int i = 0; i < J; ++i) vj += jc[i] * row_bcast(hj, 8 + i);
 
     // Gauss-Jordan with partial pivoting on the 2J columns of the group
 #pragma unroll
@@ -295,7 +333,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
         best = take ? cand : best;
         piv = take ? i : piv;
       }
-      piv = __shfl(piv, base + c0, 64);  // the decision of the pivot column's lane
+      piv = row_bcast_int(piv, c0);  // the decision of the pivot column's lane
       double top = T[c0];
       const double old_top = top;
 #pragma unroll
@@ -307,7 +345,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
       T[c0] = top;
       double m[J];
 #pragma unroll
-      for (int i = 0; i < J; ++i) m[i] = __shfl(T[i], base + c0, 64);
+      for (int i = 0; i < J; ++i) m[i] = row_bcast(T[i], c0);
       const double t = T[c0] * (1.0 / m[c0]);
 #pragma unroll
       for (int i = 0; i < J; ++i) T[i] = (i == c0) ? t : (T[i] - m[i] * t);
@@ -315,10 +353,10 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     // rhs lanes: T = G[:, col] = G[col, :]
     double gj = hj;  // g = h - G v
 #pragma unroll
-    for (int i = 0; i < J; ++i) gj -= T[i] * __shfl(vj, base + 8 + i, 64);
+    for (int i = 0; i < J; ++i) gj -= T[i] * row_bcast(vj, 8 + i);
     double fn = cv ? bv[cc] : 0.0;  // f' = A g + b
 #pragma unroll
-    for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * __shfl(gj, base + 8 + i, 64);
+    for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * row_bcast(gj, 8 + i);
 
     // X = G A^T: lane `col` computes row `col`; transpose through LDS to columns
     double Xr[J];
@@ -356,6 +394,11 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
       for (int k = 0; k < J; ++k)
         if (k <= col) o[tri(k, cc)] = Pn[k];
       o[SZ + cc] = fn;
+    }
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < EPER; ++m)
+        if (l + 16 * m < ELEM) ebuf[(c + 1) & 1][g][l + 16 * m] = nx[m];
     }
     __syncthreads();
   }
