@@ -257,7 +257,9 @@ struct clr_batch {
   int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
   int nchunk = 1, L = 0;
   const clr::BatchLaunchers* launch = nullptr;
-  DevBuf jitter, coeffs, t, diag, y;  // series in the API's row-major layout
+  DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout
+  double* pin = nullptr;              // pinned host staging: coefficient uploads, result downloads
+  size_t pin_cap = 0;
   DevBuf tT, dT, yT;                  // chunk-interleaved copies the kernels read
   long t_stride = 0, diag_stride = 0, y_stride = 0;
   int layout = 2;                     // 0 row-major direct, 1 interleaved copy, 2 staged through LDS
@@ -266,13 +268,13 @@ struct clr_batch {
   int coop_prefix = 1;
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
-  DevBuf elems, starts, part, partx, out;  // out: ll | logdet | quad
+  DevBuf elems, starts, part, partx, out;  // out: ll | logdet | quad | status (B ints)
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
-  int* status = nullptr;
   int force_exact = 0;
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
   DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
 };
+
 
 namespace {
 
@@ -947,12 +949,12 @@ void clr_batch_destroy(clr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->jitter, &h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
+  for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
-  if (h->status) (void)hipFree(h->status);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -975,11 +977,10 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
-  if ((st = h->out.reserve((size_t)h->B * 3)) != CLR_OK) return st;
+  if ((st = h->out.reserve((size_t)h->B * 3 + ((size_t)h->B + 1) / 2)) != CLR_OK) return st;
   if (h->flags) (void)hipFree(h->flags);
   h->flags = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), (2 * pc + (size_t)h->B) * sizeof(int)));
-  if (!h->status) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->status), (size_t)h->B * sizeof(int)));
   return CLR_OK;
 }
 
@@ -1017,6 +1018,19 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   return CLR_OK;
 }
 
+static int reserve_pinned(clr_batch* h, size_t doubles) {
+  if (doubles <= h->pin_cap && h->pin) return CLR_OK;
+  if (h->pin) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+  }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin), doubles * sizeof(double), hipHostMallocDefault));
+  h->pin_cap = doubles;
+  return CLR_OK;
+}
+
 int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double* a_real,
                                const double* c_real, const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp) {
@@ -1028,17 +1042,16 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
     const double m = fabs(d_comp[i]);
     if (!(m <= h->dmax)) h->dmax = m;
   }
-  std::vector<double> pack;
-  pack.reserve(2 * nr + 4 * nc);
-  pack.insert(pack.end(), a_real, a_real + nr);
-  pack.insert(pack.end(), c_real, c_real + nr);
-  pack.insert(pack.end(), a_comp, a_comp + nc);
-  pack.insert(pack.end(), b_comp, b_comp + nc);
-  pack.insert(pack.end(), c_comp, c_comp + nc);
-  pack.insert(pack.end(), d_comp, d_comp + nc);
-  if ((st = upload(h->coeffs, pack.data(), pack.size(), h->stream)) != CLR_OK) return st;
-  if ((st = upload(h->jitter, jitter, B, h->stream)) != CLR_OK) return st;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  // one pinned staging buffer, one copy: a_real c_real a_comp b_comp c_comp d_comp | jitter
+  const size_t total = 2 * nr + 4 * nc + B;
+  if ((st = reserve_pinned(h, std::max(total, 3 * B + (B + 1) / 2))) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (a previous upload may still read the staging buffer)
+  double* w = h->pin;
+  auto put = [&](const double* p, size_t n) { if (n) memcpy(w, p, n * sizeof(double)); w += n; };
+  put(a_real, nr); put(c_real, nr); put(a_comp, nc); put(b_comp, nc); put(c_comp, nc); put(d_comp, nc);
+  put(jitter, B);
+  if ((st = h->coeffs.reserve(total)) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->coeffs.p, h->pin, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->have_coeffs = true;
   return CLR_OK;
 }
@@ -1062,7 +1075,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
   P.fast_trig = (!h->force_library_trig && h->dmax * h->tmax < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
   P.coop_prefix = h->coop_prefix;
-  P.jitter = h->jitter.p;
+  P.jitter = h->coeffs.p + 2 * nr + 4 * nc;
   P.a_real = h->coeffs.p;
   P.c_real = P.a_real + nr;
   P.a_comp = P.c_real + nr;
@@ -1095,7 +1108,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.force_exact = (materialize || h->force_exact || h->nchunk < 2) ? 1 : 0;
   }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
-  P.out_status = h->status;
+  P.out_status = reinterpret_cast<int*>(h->out.p + 3 * B);
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
 }
@@ -1171,6 +1184,8 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (!P.force_exact) h->launch->correct(P, h->stream);
   h->launch->replay(P, materialize ? 2 : 0, h->stream);  // exits at once for settled problems
   clr::launch_finalize(P, h->stream);
+  // (capturing these five launches in a hipGraph was measured: no gain -- the gaps between
+  //  dependent kernels are on the device side; profiles/r01r_small_batches.log)
   HIP_TRY(hipGetLastError());
   return CLR_OK;
 }
@@ -1186,12 +1201,15 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double*
                           int* status) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  const size_t B = (size_t)h->B;
-  if (loglike) HIP_TRY(hipMemcpyAsync(loglike, h->out.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (logdet) HIP_TRY(hipMemcpyAsync(logdet, h->out.p + B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (quad) HIP_TRY(hipMemcpyAsync(quad, h->out.p + 2 * B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (status) HIP_TRY(hipMemcpyAsync(status, h->status, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
+  if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
+  // one copy into the pinned staging buffer (ll | logdet | quad | status), then host memcpys
+  HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (loglike) memcpy(loglike, h->pin, B * sizeof(double));
+  if (logdet) memcpy(logdet, h->pin + B, B * sizeof(double));
+  if (quad) memcpy(quad, h->pin + 2 * B, B * sizeof(double));
+  if (status) memcpy(status, h->pin + 3 * B, B * sizeof(int));
   return CLR_OK;
 }
 
