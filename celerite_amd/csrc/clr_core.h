@@ -14,9 +14,14 @@
 //              the next chunk's first sample;
 //   prefix     (sequential over a problem's chunks, parallel over problems)
 //              apply the elements in order -> exact start state of every chunk;
+//   correct    (parallel over chunks)  turn each chunk's zero-start sums into its
+//              true log-det / quadratic contributions from its start state alone
+//              (determinant lemma + Woodbury, chunk_update below) and certify
+//              positive definiteness -- the fused log-likelihood needs no second
+//              pass over the series;
 //   replay     (parallel over chunks)  the reference recurrence itself, started
-//              from that state, accumulating sum(log D_n), sum(x_n^2 / D_n) and
-//              (optionally) writing the factor phi, u, W, D to HBM.
+//              from that state: only for problems the certificate could not
+//              settle, and to write the factor phi, u, W, D to HBM when asked.
 //
 // State convention.  "State at sample n" = (P_n, f_n) BEFORE sample n is used:
 //   P_n = the reference's S after its update at step n (cholesky.h:154-160),
@@ -359,7 +364,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
     const double x = y_cur - ub;
     const bool valid = n0 + i < N;
     // zero-start sums of this chunk (corrected for the true start state by
-    // chunk_correction); a zero-start pivot <= 0 means the chunk's own block of K is
+    // chunk_update); a zero-start pivot <= 0 means the chunk's own block of K is
     // not positive definite: the problem is sent to the exact replay
     if (valid) {
       if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;

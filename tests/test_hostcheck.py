@@ -62,7 +62,7 @@ def test_scan_matches_oracle(lib, JR, JC, family):
             ll, ld, q, st, _ = run(lib, JR, JC, nchunk, case, inter, fast=fast, exact=exact)
             if not exact and N >= 1000 and nchunk <= N // 8:
                 # positive-definite problems with chunks of >= 8 samples must be settled by
-                # the replay-free path (chunk_correction), not by the exact fallback
+                # the replay-free path (chunk_update), not by the exact fallback
                 assert not run.used_exact.any()
             assert np.array_equal(st, s0)
             assert np.max(np.abs(ld - d0) / np.abs(d0)) < 1e-11
