@@ -80,3 +80,40 @@ def mp_logdet_quad(K, y, dps=40):
             z[i] -= L[i][k] * z[k]
     quad = sum(z[i] * z[i] / D[i] for i in range(n))
     return float(logdet), float(quad)
+
+
+def mp_exact_logdet_quad(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, dps=60):
+    """log det K and y^T K^-1 y with K BUILT and factorised in `dps`-digit arithmetic from
+    the fp64 inputs (kernel of celerite/terms.py:59-65 / utils.h:106-132): the exact answer
+    both the reference's recurrence and the scan are approximations of.  N <~ 100."""
+    import mpmath as mp
+
+    mp.mp.dps = dps
+    n = len(t)
+    tm = [mp.mpf(float(v)) for v in t]
+    ar = [mp.mpf(float(v)) for v in np.atleast_1d(a_real)]
+    cr = [mp.mpf(float(v)) for v in np.atleast_1d(c_real)]
+    ac = [mp.mpf(float(v)) for v in np.atleast_1d(a_comp)]
+    bc = [mp.mpf(float(v)) for v in np.atleast_1d(b_comp)]
+    cc = [mp.mpf(float(v)) for v in np.atleast_1d(c_comp)]
+    dc = [mp.mpf(float(v)) for v in np.atleast_1d(d_comp)]
+
+    def kern(tau):
+        s = mp.mpf(0)
+        for a, c in zip(ar, cr):
+            s += a * mp.exp(-c * tau)
+        for a, b, c, d in zip(ac, bc, cc, dc):
+            s += mp.exp(-c * tau) * (a * mp.cos(d * tau) + b * mp.sin(d * tau))
+        return s
+
+    K = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(i + 1):
+            K[i, j] = K[j, i] = kern(abs(tm[i] - tm[j]))
+        K[i, i] += mp.mpf(float(diag[i]))
+    L = mp.cholesky(K)
+    logdet = 2 * sum(mp.log(L[i, i]) for i in range(n))
+    yv = mp.matrix([mp.mpf(float(v)) for v in y])
+    z = mp.lu_solve(K, yv)
+    quad = sum(yv[i] * z[i] for i in range(n))
+    return float(logdet), float(quad)
