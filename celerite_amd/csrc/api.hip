@@ -246,6 +246,7 @@ struct clr_solver {
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
   DevBuf gradbuf;                       // grad_log_likelihood staging
+  std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
@@ -458,12 +459,11 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   if ((st = s->D.reserve((size_t)N)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
 
-  std::vector<double> hc;
+  HIP_TRY(hipStreamSynchronize(stream));  // (a previous upload may still read host_coeffs)
   if ((st = upload_coeffs(s->coeffs, J_real, a_real, c_real, J_comp, a_comp, b_comp, c_comp,
-                          d_comp, stream, hc)) != CLR_OK)
+                          d_comp, stream, s->host_coeffs)) != CLR_OK)
     return st;
   if ((st = upload(s->t, x, (size_t)N, stream)) != CLR_OK) return st;
-  HIP_TRY(hipStreamSynchronize(stream));  // hc is about to go out of use below
 
   int h_status = 0;
   double h_logdet = 0.0;
@@ -511,17 +511,18 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     // the factor is wanted: always the exact replay, which overwrites the zero-start sums
     P.partx = P.part; P.flagsx = P.flags; P.need_exact = s->ws_flags + P.nchunk; P.force_exact = 1;
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
-    P.out_status = s->d_status;
+    P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
     L->summarize(P, stream);
     L->prefix(P, stream);
     L->replay(P, 1, stream);
     clr::launch_finalize(P, stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&h_logdet, s->scalars.p + 1, sizeof(double), hipMemcpyDeviceToHost,
-                           stream));
+    double back[4];  // ll | logdet | quad | status (int in the 4th slot): one copy
+    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, sizeof(back), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    h_logdet = back[1];
+    memcpy(&h_status, &back[3], sizeof(int));
     h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
   } else {
     // any width / general terms: diagonal summed on the host in the reference's
