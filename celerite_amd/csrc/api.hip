@@ -963,9 +963,22 @@ void clr_batch_destroy(clr_batch* h) {
 int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  if (nchunk <= 0) nchunk = auto_chunks(h->B, h->N);
+  if (!h->launch) {
+    // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
+    // unless the batch alone leaves SIMDs idle: then enough chunks for one wave per SIMD,
+    // at ~2.3x the work per sample (summarize + replay); widths above 32 stay sequential
+    if (h->J > clr::wide_scan_max_width()) nchunk = 1;
+    else if (nchunk <= 0) {
+      nchunk = 2048 / h->B;  // (measured, profiles/r01s: the replay phase gains from 2-3 waves per SIMD)
+      if (nchunk < 3) nchunk = 1;  // (two chunks would not pay for the second pass)
+      if (nchunk > 16) nchunk = 16;
+      while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    }
+    if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
+  } else if (nchunk <= 0) {
+    nchunk = auto_chunks(h->B, h->N);
+  }
   if (nchunk > h->N) nchunk = h->N;
-  if (!h->launch) nchunk = 1;  // wide path: one wave per problem, sequential in n
   h->L = (h->N + nchunk - 1) / nchunk;
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
@@ -975,6 +988,10 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+  } else if (h->nchunk > 1) {  // elements / start states at the padded width (16 or 32)
+    const size_t JP = h->J <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    if ((st = h->elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
+    if ((st = h->starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
   }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
@@ -1083,7 +1100,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.b_comp = P.a_comp + nc;
   P.c_comp = P.b_comp + nc;
   P.d_comp = P.c_comp + nc;
-  if (h->layout == 1 && h->nchunk > 1) {
+  if (h->launch && h->layout == 1 && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
     if ((st = h->tT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
@@ -1106,7 +1123,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     const size_t pc = B * (size_t)h->nchunk;
     P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
     // a single chunk starts from the zero state: its replay IS the whole recurrence
-    P.force_exact = (materialize || h->force_exact || h->nchunk < 2) ? 1 : 0;
+    P.force_exact = (materialize || h->force_exact || h->nchunk < 2 || !h->launch) ? 1 : 0;
   }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = reinterpret_cast<int*>(h->out.p + 3 * B);
@@ -1166,13 +1183,28 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
   return CLR_OK;
 }
 
+// wide path: the sequential sweep, or summarize -> prefix -> replay -> finalize over chunks
+static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
+  auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
+  mark(1);
+  if (P.nchunk > 1) clr::launch_wide_summarize(P, h->J_real, h->J_comp, h->stream);
+  mark(2);
+  clr::launch_wide_prefix(P, h->J <= 16 ? 16 : 32, h->stream);
+  mark(3);
+  mark(4);
+  clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+  mark(5);
+  if (P.nchunk > 1) clr::launch_finalize(P, h->stream);
+  mark(6);
+}
+
 int clr_batch_enqueue(clr_batch* h, int materialize) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (!h->launch) {
-    clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+    wide_launch(h, P, nullptr);
     HIP_TRY(hipGetLastError());
     return CLR_OK;
   }
@@ -1254,10 +1286,8 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   for (int i = 0; i < steps; ++i) {
     hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
     HIP_TRY(hipEventRecord(e[0], h->stream));
-    if (!h->launch) {  // wide path: the one kernel is reported in the "summarize" slot
-      HIP_TRY(hipEventRecord(e[1], h->stream));
-      clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
-      for (int j = 2; j <= NK; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+    if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
+      wide_launch(h, P, e);
       continue;
     }
     if (relayout_each_step) batch_relayout(h);

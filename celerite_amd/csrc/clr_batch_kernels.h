@@ -225,6 +225,18 @@ __device__ __forceinline__ double row_bcast(double v, int k) {
   return __hiloint2double(row_bcast_i32(__double2hiint(v), k), row_bcast_i32(__double2loint(v), k));
 }
 __device__ __forceinline__ int row_bcast_int(int v, int k) { return row_bcast_i32(v, k); }
+// lane k of the caller's GROUP-lane group: DPP for 16-lane groups (= DPP rows), the LDS
+// crossbar for the 32- and 64-lane groups of the wide widths (few chunks there)
+template <int GROUP>
+__device__ __forceinline__ double group_bcast(double v, int k) {
+  if (GROUP == 16) return row_bcast(v, k);
+  return __shfl(v, (threadIdx.x & ~(GROUP - 1)) + k, 64);
+}
+template <int GROUP>
+__device__ __forceinline__ int group_bcast_int(int v, int k) {
+  if (GROUP == 16) return row_bcast_i32(v, k);
+  return __shfl(v, (threadIdx.x & ~(GROUP - 1)) + k, 64);
+}
 
 // ---------------------------------------------------------------------------
 // Cooperative prefix: 16 lanes per problem (4 problems per wave) instead of one.
@@ -240,27 +252,28 @@ __device__ __forceinline__ int row_bcast_int(int v, int k) { return row_bcast_i3
 // chunk instead of ~5500, and 16x more lanes in flight: the single-lane version
 // ran on 16 of the chip's 1024 SIMDs (profiles/r01b_pmc_counters.txt).
 // ---------------------------------------------------------------------------
-template <int J>
+template <int J, int HALF>
 __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
+  constexpr int GROUP = 2 * HALF, NG = 64 / GROUP;  // lanes per problem, problems per wave
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int ELEM = J * J + J + SZ + J + SZ;
   constexpr int START = SZ + J;
-  __shared__ double pbuf[4][8][8];  // pbuf[g][j][i] = P[i][j] (column j contiguous)
-  __shared__ double xbuf[4][8][9];  // transpose buffer, padded
+  __shared__ double pbuf[NG][HALF][HALF];      // pbuf[g][j][i] = P[i][j] (column j contiguous)
+  __shared__ double xbuf[NG][HALF][HALF + 1];  // transpose buffer, padded
   // the chunk's element, staged through LDS one chunk AHEAD: every lane of a group needs
   // all of A (72 load instructions per lane and chunk with their HBM latency exposed);
   // instead the group's 16 lanes fetch element c + 1 cooperatively (<= 10 coalesced loads
   // each) while chunk c is processed, and everybody reads it from LDS (group stride 162
   // doubles: the four groups' broadcast reads fall into disjoint banks)
   constexpr int ESTRIDE = ((ELEM + 15) / 16) * 16 + 2;
-  constexpr int EPER = (ELEM + 15) / 16;
-  __shared__ double ebuf[2][4][ESTRIDE];
-  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
-  const bool rhs = (l >> 3) != 0;
-  const int col = l & 7;
+  constexpr int EPER = (ELEM + GROUP - 1) / GROUP;
+  __shared__ double ebuf[2][NG][ESTRIDE];
+  const int lane = threadIdx.x, g = lane / GROUP, l = lane % GROUP;
+  const bool rhs = l >= HALF;
+  const int col = l % HALF;
   const bool cv = col < J;
   const int cc = cv ? col : J - 1;
-  const int prob = blockIdx.x * 4 + g;
+  const int prob = blockIdx.x * NG + g;
   const bool active = prob < P_.B;
   const long pb = active ? prob : P_.B - 1;
   const bool writer = rhs && cv && active;
@@ -273,13 +286,13 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
   for (int i = 0; i < J; ++i) Pc[i] = 0.0;
   if (rhs) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pbuf[g][col][i] = 0.0;
+    for (int i = 0; i < HALF; ++i) pbuf[g][col][i] = 0.0;
   }
   {
     const double* E0 = P_.elems + (pb * P_.nchunk) * ELEM;
 #pragma unroll
     for (int m = 0; m < EPER; ++m)
-      if (l + 16 * m < ELEM) ebuf[0][g][l + 16 * m] = E0[l + 16 * m];
+      if (l + GROUP * m < ELEM) ebuf[0][g][l + GROUP * m] = E0[l + GROUP * m];
   }
   __syncthreads();
 
@@ -289,7 +302,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     if (more) {
       const double* En = P_.elems + (pb * P_.nchunk + c + 1) * ELEM;
 #pragma unroll
-      for (int m = 0; m < EPER; ++m) nx[m] = (l + 16 * m < ELEM) ? En[l + 16 * m] : 0.0;
+      for (int m = 0; m < EPER; ++m) nx[m] = (l + GROUP * m < ELEM) ? En[l + GROUP * m] : 0.0;
     }
     const double* E = ebuf[c & 1][g];
     const double* A = E;
@@ -319,7 +332,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     for (int i = 0; i < J; ++i) hj += Pc[i] * et[i];
     double vj = 0.0;
 #pragma unroll
-    for (int i = 0; i < J; ++i) vj += jc[i] * row_bcast(hj, 8 + i);
+    for (int i = 0; i < J; ++i) vj += jc[i] * group_bcast<GROUP>(hj, HALF + i);
 
     // Gauss-Jordan with partial pivoting on the 2J columns of the group
 #pragma unroll
@@ -333,7 +346,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
         best = take ? cand : best;
         piv = take ? i : piv;
       }
-      piv = row_bcast_int(piv, c0);  // the decision of the pivot column's lane
+      piv = group_bcast_int<GROUP>(piv, c0);  // the decision of the pivot column's lane
       double top = T[c0];
       const double old_top = top;
 #pragma unroll
@@ -345,7 +358,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
       T[c0] = top;
       double m[J];
 #pragma unroll
-      for (int i = 0; i < J; ++i) m[i] = row_bcast(T[i], c0);
+      for (int i = 0; i < J; ++i) m[i] = group_bcast<GROUP>(T[i], c0);
       const double t = T[c0] * (1.0 / m[c0]);
 #pragma unroll
       for (int i = 0; i < J; ++i) T[i] = (i == c0) ? t : (T[i] - m[i] * t);
@@ -353,10 +366,10 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     // rhs lanes: T = G[:, col] = G[col, :]
     double gj = hj;  // g = h - G v
 #pragma unroll
-    for (int i = 0; i < J; ++i) gj -= T[i] * row_bcast(vj, 8 + i);
+    for (int i = 0; i < J; ++i) gj -= T[i] * group_bcast<GROUP>(vj, HALF + i);
     double fn = cv ? bv[cc] : 0.0;  // f' = A g + b
 #pragma unroll
-    for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * row_bcast(gj, 8 + i);
+    for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * group_bcast<GROUP>(gj, HALF + i);
 
     // X = G A^T: lane `col` computes row `col`; transpose through LDS to columns
     double Xr[J];
@@ -398,7 +411,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
     if (more) {
 #pragma unroll
       for (int m = 0; m < EPER; ++m)
-        if (l + 16 * m < ELEM) ebuf[(c + 1) & 1][g][l + 16 * m] = nx[m];
+        if (l + GROUP * m < ELEM) ebuf[(c + 1) & 1][g][l + GROUP * m] = nx[m];
     }
     __syncthreads();
   }
@@ -509,7 +522,7 @@ struct BatchImpl {
   static void prefix(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
     if (P.coop_prefix)
-      hipLaunchKernelGGL((prefix_coop_kernel<JR + 2 * JC>), dim3((P.B + 3) / 4), dim3(64), 0, s, P);
+      hipLaunchKernelGGL((prefix_coop_kernel<JR + 2 * JC, 8>), dim3((P.B + 3) / 4), dim3(64), 0, s, P);
     else
       hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
   }
@@ -547,6 +560,10 @@ void launch_relayout(const double* src, long src_stride, double* dst, long dst_s
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);
+// prefix phase at the padded widths of the wide scan (16: 2 problems per wave, 32: one)
+void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s);
+int wide_scan_max_width();
+void launch_wide_summarize(const BatchParams& P, int JR, int JC, hipStream_t s);
 // widths 9..wide_max_width(): one wave per problem, sequential in n (wide_kernels.hip)
 int wide_max_width();
 void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s);

@@ -28,8 +28,10 @@
 // * t, diag, y are fetched 64 samples at a time (one coalesced 512-B load per array)
 //   and handed out with v_readlane.
 // Flops per step ~ 3.5 W^2; instruction slots per step and lane at W = 32: ~240.
-// B problems use B of the chip's 1024 SIMDs: the batch axis is the parallelism here
-// (at B = 256 a chunked scan on top would at best halve the time for 2.4x the work).
+// B problems alone use B of the chip's 1024 SIMDs; for smaller batches (widths <= 32) the
+// time axis is cut into chunks as in the narrow scan: MODE 1 of the kernel also builds the
+// chunk's transfer element, prefix_coop_kernel<16 | 32> chains the chunks, MODE 0 replays
+// from the chunk start states (profiles/r01s_wide_scan.log: config 5, 80.6 -> 33.5 ms).
 #include "../../include/celerite_hip.h"
 #include "clr_batch_kernels.h"
 #include "clr_wide.h"
@@ -57,18 +59,31 @@ __device__ __forceinline__ void row_features(const RowCoeffs& r, double t, doubl
   *v = fma(r.vc, cs, fma(r.vs, sd, r.v0));
 }
 
-template <int WMAX, bool FAST>
-__global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, int JR, int JC) {
+// MODE 0: the log-likelihood recurrence over samples [n_lo, n_hi) of chunk blockIdx.x from a
+//         given start state (zero for the first chunk).  With one chunk the kernel writes the
+//         problem's results itself; with several it writes the chunk's partial sums for
+//         finalize_kernel ("replay" of the scan).
+// MODE 1: "summarize": the same recurrence from the ZERO state plus the chunk's transfer
+//         element (A, b, C, eta, Jm) in the layout of the narrow scan kernels at width
+//         J = WMAX (padding rows behave as identity), so that prefix_coop_kernel<WMAX> can
+//         chain the chunks.  A is held transposed (lane (j, seg) owns A[seg*COLS ..][j]):
+//         r_j = u . A[:, j] is then a lane-local dot product like q, and the update
+//         A[i][j] <- phi_i A[i][j] - (phi w)_i r_j reuses the phi / phi*w reads of the S update.
+template <int WMAX, bool FAST, int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
   using G = WideGeom<WMAX>;
   constexpr int LPR = G::LPR, COLS = G::COLS;
+  constexpr int J = WMAX, SZ = J * (J + 1) / 2;
+  constexpr int ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
   __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX];
   __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX];
   __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
+  __shared__ __attribute__((aligned(16))) double rbuf[MODE == 1 ? WMAX : 2];
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
   const int row = lane / LPR, seg = lane % LPR;
   const int W = JR + 2 * JC;
   const bool writer = seg == 0;
@@ -97,11 +112,25 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
   const double* dp = P.diag + b * P.diag_stride;
   const double* yp = P.y + b * P.y_stride;
   const int N = P.N;
+  const int n_lo = chunk * P.L;
+  const int n_hi = (n_lo + P.L < N) ? n_lo + P.L : N;
+  const long slot = (long)b * P.nchunk + chunk;
 
   double S[COLS];
+  double f = 0.0, quad = 0.0;
 #pragma unroll
   for (int c = 0; c < COLS; ++c) S[c] = 0.0;
-  double f = 0.0, quad = 0.0;
+  if (MODE == 0 && chunk > 0) {  // start state of this chunk (packed upper triangle | f), from the prefix phase
+    const double* st = P.starts + slot * START;
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) S[c] = st[sym(row, seg * COLS + c)];
+    f = st[SZ + row];
+  }
+  double AT[MODE == 1 ? COLS : 1], Jm[MODE == 1 ? COLS : 1], eta = 0.0;
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) { AT[c] = (seg * COLS + c == row) ? 1.0 : 0.0; Jm[c] = 0.0; }
+  }
   LogProduct lp;
   lp.init();
   int flag = 0;
@@ -110,20 +139,21 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
   // handed out with v_readlane; t needs two samples of look-ahead
   double tv, dv, yv, tv2;
   {
-    tv = lane < N ? tp[lane] : 0.0;
-    dv = lane < N ? dp[lane] : 0.0;
-    yv = lane < N ? yp[lane] : 0.0;
-    tv2 = lane + 64 < N ? tp[lane + 64] : 0.0;
+    const int m = n_lo + lane;
+    tv = m < N ? tp[m] : 0.0;
+    dv = m < N ? dp[m] : 0.0;
+    yv = m < N ? yp[m] : 0.0;
+    tv2 = m + 64 < N ? tp[m + 64] : 0.0;
   }
   auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };  // k < 66
 
-  // features of sample 0
+  // features of the chunk's first sample
   double u, v, phi;
-  row_features<FAST>(rc, t_at(0), N > 1 ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
-  if (writer) { ubuf[0][row] = u; pbuf[0][row] = phi; }
+  row_features<FAST>(rc, t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
+  if (writer) { ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi; }
 
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int nend = (N - n0 < 64) ? N - n0 : 64;
+  for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
+    const int nend = (n_hi - n0 < 64) ? n_hi - n0 : 64;
     for (int k = 0; k < nend; ++k) {
       const int n = n0 + k, cur = n & 1;
       const double diag_n = lane_value(dv, k);
@@ -138,8 +168,8 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
         if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
       }
 
-      // q = S u (own columns, then across the row's lanes)
-      double q = 0.0;
+      // q = S u and (summarize) r = A^T u: own columns, then across the row's lanes
+      double q = 0.0, r = 0.0;
       {
         const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
 #pragma unroll
@@ -147,10 +177,14 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
           const double2 uu = uv[c];
           q = fma(S[2 * c], uu.x, q);
           q = fma(S[2 * c + 1], uu.y, q);
+          if (MODE == 1) {
+            r = fma(AT[2 * c], uu.x, r);
+            r = fma(AT[2 * c + 1], uu.y, r);
+          }
         }
       }
-      if (LPR >= 2) q = dpp_add<DPP_QUAD_XOR1>(q);
-      if (LPR >= 4) q = dpp_add<DPP_QUAD_XOR2>(q);
+      if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR1>(r); }
+      if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR2>(r); }
       const double s = row_sum<LPR>(u * q), ub = row_sum<LPR>(u * f);
       const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
       const double invD = 1.0 / D;
@@ -161,18 +195,30 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
 
       const double z = v - q;
       const double w = z * invD;
-      if (writer) wbuf[row] = phi * w;
+      if (writer) {
+        wbuf[row] = phi * w;
+        if (MODE == 1) rbuf[row] = r;
+      }
       {
         const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
-        const double zr = phi * z;
+        const double2* rv = reinterpret_cast<const double2*>(&rbuf[MODE == 1 ? seg * COLS : 0]);
+        const double zr = phi * z, rs = r * invD;
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
           const double2 pk = pv[c], pw = wv[c];
           S[2 * c] = fma(zr, pw.x, (phi * pk.x) * S[2 * c]);
           S[2 * c + 1] = fma(zr, pw.y, (phi * pk.y) * S[2 * c + 1]);
+          if (MODE == 1) {
+            const double2 rr = rv[c];
+            AT[2 * c] = fma(-pw.x, r, pk.x * AT[2 * c]);
+            AT[2 * c + 1] = fma(-pw.y, r, pk.y * AT[2 * c + 1]);
+            Jm[2 * c] = fma(-rs, rr.x, Jm[2 * c]);
+            Jm[2 * c + 1] = fma(-rs, rr.y, Jm[2 * c + 1]);
+          }
         }
       }
+      if (MODE == 1) eta = fma(-r, x * invD, eta);
       f = phi * (f + w * x);
       u = u1; v = v1; phi = phi1;
     }
@@ -183,9 +229,31 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
   }
+
+  if (MODE == 1) {  // the element, in the narrow kernels' layout at width J = WMAX
+    double* e = P.elems + slot * ELEM;
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+      const int col = seg * COLS + c;
+      e[col * J + row] = AT[c];                                  // A[col][row] = AT[row][col]
+      if (row <= col) {
+        e[J * J + J + tri(row, col)] = S[c];                     // C, packed upper triangle
+        e[J * J + J + SZ + J + tri(row, col)] = Jm[c];           // Jm
+      }
+    }
+    if (writer) {
+      e[J * J + row] = f;                                        // b (the zero-start f)
+      e[J * J + J + SZ + row] = eta;
+    }
+    return;
+  }
   if (lane == 0) {
     const double ld = lp.log_value();
-    if (flag) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
+    if (P.nchunk > 1) {  // partial sums of this chunk; finalize_kernel adds them up
+      P.partx[slot * 2 + 0] = ld;
+      P.partx[slot * 2 + 1] = quad;
+      P.flagsx[slot] = flag;
+    } else if (flag) {  // celerite::linalg_exception (cholesky.h:176); quiet => -inf (celerite.py:205-208)
       P.out_status[b] = CLR_NOT_POSITIVE_DEFINITE;
       P.out_ll[b] = -INFINITY;
       P.out_logdet[b] = NAN;
@@ -202,18 +270,40 @@ __global__ void __launch_bounds__(64) wide_loglike_kernel(const BatchParams P, i
 }  // namespace
 
 int wide_max_width() { return 64; }
+int wide_scan_max_width() { return 32; }  // the chunk algebra runs in prefix_coop_kernel<16 | 32>
 
-void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s) {
+static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
+  const dim3 grid(P.nchunk, P.B);
+  if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0>), grid, dim3(64), 0, s, P, JR, JC);
+  else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0>), grid, dim3(64), 0, s, P, JR, JC);
+}
+
+template <int MODE>
+static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const int W = JR + 2 * JC;
-#define CLR_GO(WM)                                                                                \
-  do {                                                                                            \
-    if (P.fast_trig) hipLaunchKernelGGL((wide_loglike_kernel<WM, true>), dim3(P.B), dim3(64), 0, s, P, JR, JC); \
-    else hipLaunchKernelGGL((wide_loglike_kernel<WM, false>), dim3(P.B), dim3(64), 0, s, P, JR, JC);            \
+  const dim3 grid(P.nchunk, P.B);
+#define CLR_GO(WM)                                                                                  \
+  do {                                                                                              \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, MODE>), grid, dim3(64), 0, s, P, JR, JC); \
+    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, MODE>), grid, dim3(64), 0, s, P, JR, JC);            \
   } while (0)
   if (W <= 16) CLR_GO(16);
-  else if (W <= 32) CLR_GO(32);
-  else CLR_GO(64);
+  else if (W <= 32 || MODE == 1) CLR_GO(32);
+  else launch_wide64(P, JR, JC, s);
 #undef CLR_GO
 }
+
+void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
+  if (P.nchunk < 2) return;
+  if (width_padded <= 16)
+    hipLaunchKernelGGL((prefix_coop_kernel<16, 16>), dim3((P.B + 1) / 2), dim3(64), 0, s, P);
+  else
+    hipLaunchKernelGGL((prefix_coop_kernel<32, 32>), dim3(P.B), dim3(64), 0, s, P);
+}
+
+// one chunk: the whole recurrence, results written directly; several chunks: the replay phase
+void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s) { launch_wide<0>(P, JR, JC, s); }
+// the chunks' transfer elements (widths 9..32 only)
+void launch_wide_summarize(const BatchParams& P, int JR, int JC, hipStream_t s) { launch_wide<1>(P, JR, JC, s); }
 
 }  // namespace clr

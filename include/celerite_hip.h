@@ -183,10 +183,12 @@ typedef struct clr_batch clr_batch;
 /* Plans device buffers + workspace for (B, N, J_real, J_comp) on `device`.
  * General terms are not part of the batched path.  Width W = J_real + 2 J_comp:
  *   1..8   chunked scan over n, one lane per (problem, chunk)  (the headline path);
- *   9..64  one wave per problem, sequential in n, S distributed over the lanes
- *          (BASELINE config 5: 16 complex terms); fused log-likelihood only --
- *          materialising runs, chunking, layouts and the exact/replay switch do not
- *          apply (the kernel IS the reference recurrence);
+ *   9..64  one wave per (problem, chunk), S distributed over the lanes (BASELINE
+ *          config 5: 16 complex terms); fused log-likelihood only.  One chunk = the
+ *          reference recurrence itself; widths <= 32 are cut into chunks (two-pass
+ *          scan) when B alone leaves SIMDs idle (clr_batch_set_chunks(h, 0) picks
+ *          2048 / B, at most 16).  Materialising runs, layouts and the exact/replay
+ *          switch do not apply;
  *   else   CLR_UNSUPPORTED. */
 clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device);
 void clr_batch_destroy(clr_batch* h);

@@ -387,3 +387,39 @@ def test_time_origin_and_scale_do_not_matter():
         case["t"] = case["t"] * scale + offset
         ll, ld, q, st = check(case, nchunk=16)
         assert (st == 0).all()
+
+
+@pytest.mark.parametrize("JR,JC", [(9, 0), (2, 7), (0, 8), (16, 0), (1, 8), (0, 16), (4, 14), (10, 11)])
+def test_wide_scan_over_chunks(JR, JC):
+    """Widths 9..32 cut into chunks (wide_scan_kernel summarize + prefix_coop_kernel<16|32> +
+    replay): every chunking must reproduce the one-chunk sweep and the oracle, failures
+    included."""
+    N = 3000
+    case = synthetic(3, N, JR, JC, "accuracy" if (JR + JC) % 2 else "bench", seed=JR + 3 * JC)
+    case["a_real"] = np.array(case["a_real"], copy=True)
+    case["diag"] = np.array(case["diag"], copy=True)
+    if JR:
+        case["a_real"][1, :] = -7.0       # an indefinite problem in the middle
+        case["diag"][1] = 0.0
+    ref_out = None
+    for nchunk in (1, 2, 5, 16):
+        ll, ld, q, st = check(case, nchunk=nchunk)
+        if ref_out is None:
+            ref_out = (ld, q, st)
+        else:
+            ok = st == 0
+            assert np.array_equal(st, ref_out[2])
+            assert np.max(np.abs(ld[ok] - ref_out[0][ok]) / np.abs(ref_out[0][ok])) <= 1e-11
+            assert np.max(np.abs(q[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])) <= 1e-11
+
+
+def test_wide_scan_is_chosen_for_small_batches():
+    plan = batch.BatchedGP(64, 20000, 0, 16)       # 64 problems: 16 chunks each fill the chip
+    assert plan.chunks[0] == 16
+    plan.close()
+    plan = batch.BatchedGP(2048, 20000, 0, 16)     # enough problems: plain sequential sweeps
+    assert plan.chunks[0] == 1
+    plan.close()
+    plan = batch.BatchedGP(8, 20000, 0, 17)        # width 34: no scan above 32
+    assert plan.chunks[0] == 1
+    plan.close()
