@@ -965,12 +965,12 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (st != CLR_OK) return st;
   if (!h->launch) {
     // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
-    // unless the batch alone leaves SIMDs idle: then enough chunks for one wave per SIMD,
-    // at ~2.3x the work per sample (summarize + replay); widths above 32 stay sequential
+    // unless the batch alone leaves the chip underused: then ~2 waves per SIMD worth of
+    // chunks, at ~1.25x the work per sample (profiles/r01s); widths above 32 stay sequential
     if (h->J > clr::wide_scan_max_width()) nchunk = 1;
     else if (nchunk <= 0) {
-      nchunk = 2048 / h->B;  // (measured, profiles/r01s: the replay phase gains from 2-3 waves per SIMD)
-      if (nchunk < 3) nchunk = 1;  // (two chunks would not pay for the second pass)
+      nchunk = 2048 / h->B;
+      if (nchunk < 2) nchunk = 1;
       if (nchunk > 16) nchunk = 16;
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
     }
@@ -1123,7 +1123,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     const size_t pc = B * (size_t)h->nchunk;
     P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
     // a single chunk starts from the zero state: its replay IS the whole recurrence
-    P.force_exact = (materialize || h->force_exact || h->nchunk < 2 || !h->launch) ? 1 : 0;
+    P.force_exact = (materialize || h->force_exact || h->nchunk < 2) ? 1 : 0;
   }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = reinterpret_cast<int*>(h->out.p + 3 * B);
@@ -1151,7 +1151,7 @@ int clr_batch_get_exact_count(clr_batch* h, int* count) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
-  if (!h->launch) {  // the wide path IS the reference recurrence
+  if (h->nchunk < 2 || h->force_exact) {  // every problem went through the reference recurrence
     *count = h->B;
     return CLR_OK;
   }
@@ -1191,6 +1191,7 @@ static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
   mark(2);
   clr::launch_wide_prefix(P, h->J <= 16 ? 16 : 32, h->stream);
   mark(3);
+  if (!P.force_exact) clr::launch_wide_correct(P, h->J <= 16 ? 16 : 32, h->stream);
   mark(4);
   clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
   mark(5);

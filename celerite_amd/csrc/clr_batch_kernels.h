@@ -564,6 +564,7 @@ const BatchLaunchers* find_batch_launchers(int JR, int JC);
 void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s);
 int wide_scan_max_width();
 void launch_wide_summarize(const BatchParams& P, int JR, int JC, hipStream_t s);
+void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s);
 // widths 9..wide_max_width(): one wave per problem, sequential in n (wide_kernels.hip)
 int wide_max_width();
 void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s);

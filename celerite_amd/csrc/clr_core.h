@@ -53,9 +53,13 @@
 #if defined(__HIPCC__)
 #define CLR_HD __host__ __device__ __forceinline__
 #define CLR_UNROLL _Pragma("unroll")
+// inside templates on the width J: full unrolling (register-resident arrays) up to width 8,
+// rolled loops (arrays in scratch) for the padded widths 16 / 32 of the wide scan
+#define CLR_UNROLL_J _Pragma("clang loop unroll_count(J <= 8 ? 64 : 1)")
 #else
 #define CLR_HD inline
 #define CLR_UNROLL
+#define CLR_UNROLL_J
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE
 #endif
@@ -473,22 +477,22 @@ CLR_HD double pd_certificate(const double* P /*[SZ]*/, const double* Jm /*[SZ]*/
   // returns the smallest Cholesky pivot of I - F^T P F (<= 0 when it breaks down)
   double F[J][J], S[J][J];
   double nmax = 0.0;
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int i = 0; i < J; ++i) nmax = fmax(nmax, -Jm[tri(i, i)]);
   const double delta = 4e-13 * nmax;
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int i = 0; i < J; ++i) {
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int j = 0; j < J; ++j) S[i][j] = -Jm[sym(i, j)] + ((i == j) ? delta : 0.0);
   }
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int k = 0; k < J; ++k) {
     const double rs = 1.0 / sqrt(S[k][k]);
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) F[i][k] = (i >= k) ? S[i][k] * rs : 0.0;
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = k + 1; i < J; ++i) {
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int j = k + 1; j <= i; ++j) {
         S[i][j] -= F[i][k] * F[j][k];
         S[j][i] = S[i][j];
@@ -496,39 +500,39 @@ CLR_HD double pd_certificate(const double* P /*[SZ]*/, const double* Jm /*[SZ]*/
     }
   }
   double PF[J][J], E[J][J];
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int i = 0; i < J; ++i) {
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int k = 0; k < J; ++k) {
       double acc = 0.0;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int m = k; m < J; ++m) acc += P[sym(i, m)] * F[m][k];
       PF[i][k] = acc;
     }
   }
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int j = 0; j < J; ++j) {
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int k = 0; k <= j; ++k) {
       double acc = (j == k) ? 1.0 : 0.0;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int i = k; i < J; ++i) acc -= F[i][k] * PF[i][j];
       E[j][k] = acc;
     }
   }
   double mu = 1.0;
   bool broke = false;
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int k = 0; k < J; ++k) {
     const double d = E[k][k];
     if (!(d > 0.0)) broke = true;
     mu = (d < mu) ? d : mu;
     const double rs = 1.0 / sqrt(d);
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = k; i < J; ++i) E[i][k] *= rs;
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = k + 1; i < J; ++i) {
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int j = k + 1; j <= i; ++j) E[i][j] -= E[i][k] * E[j][k];
     }
   }
@@ -548,13 +552,13 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
   const double* Jm = eta + J;
 
   double T[J][NC];
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int i = 0; i < J; ++i) {
     double h = f[i];
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int j = 0; j < J; ++j) {
       double acc = (i == j) ? 1.0 : 0.0;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int k = 0; k < J; ++k) acc += P[sym(i, k)] * Jm[sym(k, j)];
       T[i][j] = acc;
       T[i][J + j] = P[sym(i, j)];
@@ -564,22 +568,22 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
   }
 
   double det = 1.0;
-  CLR_UNROLL
+  CLR_UNROLL_J
   for (int col = 0; col < J; ++col) {
     int piv = col;
     double best = fabs(T[col][col]);
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = col + 1; i < J; ++i) {
       const double cand = fabs(T[i][col]);
       const bool take = cand > best;
       best = take ? cand : best;
       piv = take ? i : piv;
     }
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int c = col; c < NC; ++c) {
       double top = T[col][c];
       const double old_top = top;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int i = col + 1; i < J; ++i) {
         const bool hit = (i == piv);
         top = hit ? T[i][c] : top;
@@ -589,13 +593,13 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
     }
     det *= (piv != col) ? -T[col][col] : T[col][col];
     const double inv = 1.0 / T[col][col];
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) {
       if (i == col) continue;
       const double m = T[i][col];
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int c = col + 1; c < NC; ++c) T[i][c] -= m * T[col][c];
     }
   }
@@ -608,20 +612,20 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
     if (!(det > 0.0)) bad = 1;
     double w[J];
     double ef = 0.0, fJf = 0.0;
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) {
       double acc = 0.0;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * f[k];
       w[i] = acc - eta[i];
       ef += eta[i] * f[i];
       fJf += f[i] * acc;
     }
     double wGw = 0.0;
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) {
       double acc = 0.0;
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int k = 0; k < J; ++k) acc += 0.5 * (T[i][J + k] + T[k][J + i]) * w[k];
       wGw += w[i] * acc;
     }
@@ -638,30 +642,30 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
 
   if (advance) {
     double AG[J][J];
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) {
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int j = 0; j < J; ++j) {
         double acc = 0.0;
-        CLR_UNROLL
+        CLR_UNROLL_J
         for (int k = 0; k < J; ++k) acc += A[i * J + k] * (0.5 * (T[k][J + j] + T[j][J + k]));
         AG[i][j] = acc;
       }
     }
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int j = 0; j < J; ++j) {
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int k = 0; k <= j; ++k) {
         double acc = C[tri(k, j)];
-        CLR_UNROLL
+        CLR_UNROLL_J
         for (int i = 0; i < J; ++i) acc += AG[k][i] * A[j * J + i];
         P[tri(k, j)] = acc;
       }
     }
-    CLR_UNROLL
+    CLR_UNROLL_J
     for (int i = 0; i < J; ++i) {
       double acc = b[i];
-      CLR_UNROLL
+      CLR_UNROLL_J
       for (int k = 0; k < J; ++k) acc += A[i * J + k] * T[k][2 * J];
       f[i] = acc;
     }

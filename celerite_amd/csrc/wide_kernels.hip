@@ -30,8 +30,9 @@
 // Flops per step ~ 3.5 W^2; instruction slots per step and lane at W = 32: ~240.
 // B problems alone use B of the chip's 1024 SIMDs; for smaller batches (widths <= 32) the
 // time axis is cut into chunks as in the narrow scan: MODE 1 of the kernel also builds the
-// chunk's transfer element, prefix_coop_kernel<16 | 32> chains the chunks, MODE 0 replays
-// from the chunk start states (profiles/r01s_wide_scan.log: config 5, 80.6 -> 33.5 ms).
+// chunk's transfer element and zero-start sums, prefix_coop_kernel<16 | 32> chains the chunks,
+// wide_correct_kernel turns the sums into the true contributions, and MODE 0 replays only the
+// problems it could not certify (profiles/r01s_wide_scan.log: config 5, 80.6 -> 21.5 ms).
 #include "../../include/celerite_hip.h"
 #include "clr_batch_kernels.h"
 #include "clr_wide.h"
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   const double* dp = P.diag + b * P.diag_stride;
   const double* yp = P.y + b * P.y_stride;
   const int N = P.N;
+  if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] == 0) return;  // settled without replay
   const int n_lo = chunk * P.L;
   const int n_hi = (n_lo + P.L < N) ? n_lo + P.L : N;
   const long slot = (long)b * P.nchunk + chunk;
@@ -189,7 +191,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
       const double invD = 1.0 / D;
       const double x = y_n - ub;
-      if (n >= 1 && D < 0.0) flag = 1;  // cholesky.h:176 (sample 0 is never checked)
+      // replay: the reference's test (cholesky.h:176; sample 0 is never checked); summarize: a
+      // zero-start pivot <= 0 sends the problem to the replay (as in summarize_chunk)
+      if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
       lp.mul(D);
       quad += x * x * invD;
 
@@ -245,6 +249,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       e[J * J + row] = f;                                        // b (the zero-start f)
       e[J * J + J + SZ + row] = eta;
     }
+    if (lane == 0) {  // zero-start sums: correct_kernel<WMAX> turns them into the true contributions
+      P.part[slot * 2 + 0] = lp.log_value();
+      P.part[slot * 2 + 1] = quad;
+      P.flags[slot] = flag;
+    }
     return;
   }
   if (lane == 0) {
@@ -263,6 +272,191 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       P.out_logdet[b] = ld;
       P.out_quad[b] = quad;
       P.out_ll[b] = combine_loglike(ld, quad, N);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// correct at the padded widths 16 / 32: chunk_update + pd_certificate of clr_core.h (same
+// formulas, same thresholds), one WAVE per (problem, chunk) with the matrices in LDS -- the
+// single-lane form keeps 2080 doubles per lane in scratch at width 32 and was measured at
+// 24 ms for 2048 chunks, slower than the replay pass it is meant to replace.
+//   T = [ I + P Jm | P | f + P eta ]  --Gauss-Jordan, partial pivoting-->  [ . | G | g ], det
+//   log det correction = log det ;  quad correction = 2 eta.f - f.Jm f + w.G w , w = Jm f - eta
+//   certificate: F F^T = -Jm + delta I ; smallest Cholesky pivot of I - F^T P F > 1e-5
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int J>
+__global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
+  constexpr int SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
+  constexpr int NC = 2 * J + 1, LD = J + 1, LT = NC + 1;  // padded leading dimensions
+  __shared__ double Pm[J * LD], Jmm[J * LD], Sm[J * LD], PF[J * LD], T[J * LT], fv[J], ev[J], wv[J];
+  const int lane = threadIdx.x;
+  const long slot = blockIdx.x;
+  const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
+  if (lane == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 1);  // a zero-start pivot <= 0 (summarize)
+  if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
+  const double* st = P.starts + slot * START;
+  const double* E = P.elems + slot * ELEM;
+  const double* eta = E + J * J + J + SZ;
+  const double* Jm = eta + J;
+  for (int idx = lane; idx < J * J; idx += 64) {
+    const int i = idx / J, j = idx % J;
+    Pm[i * LD + j] = st[sym(i, j)];
+    Jmm[i * LD + j] = Jm[sym(i, j)];
+  }
+  if (lane < J) { fv[lane] = st[SZ + lane]; ev[lane] = eta[lane]; }
+  __syncthreads();
+
+  // T = [ I + P Jm | P | f + P eta ]
+  for (int idx = lane; idx < J * J; idx += 64) {
+    const int i = idx / J, j = idx % J;
+    double acc = (i == j) ? 1.0 : 0.0;
+    for (int k = 0; k < J; ++k) acc += Pm[i * LD + k] * Jmm[k * LD + j];
+    T[i * LT + j] = acc;
+    T[i * LT + J + j] = Pm[i * LD + j];
+  }
+  if (lane < J) {
+    double h = fv[lane];
+    for (int j = 0; j < J; ++j) h += Pm[lane * LD + j] * ev[j];
+    T[lane * LT + 2 * J] = h;
+  }
+  __syncthreads();
+
+  double det = 1.0;
+  for (int col = 0; col < J; ++col) {
+    // pivot row: the largest |T[i][col]|, i >= col (first one on ties, as the single-lane scan)
+    double best = (lane < J && lane >= col) ? fabs(T[lane * LT + col]) : -1.0;
+    int piv = lane;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const double ob = __shfl_xor(best, m, 64);
+      const int op = __shfl_xor(piv, m, 64);
+      const bool take = ob > best || (ob == best && op < piv);
+      best = take ? ob : best;
+      piv = take ? op : piv;
+    }
+    if (piv != col) {
+      for (int cc = lane; cc < NC; cc += 64) {
+        const double a = T[col * LT + cc], bb = T[piv * LT + cc];
+        T[col * LT + cc] = bb;
+        T[piv * LT + cc] = a;
+      }
+    }
+    __syncthreads();
+    const double p = T[col * LT + col];
+    det *= (piv != col) ? -p : p;
+    const double inv = 1.0 / p;
+    __syncthreads();
+    for (int cc = lane; cc < NC; cc += 64)
+      if (cc > col) T[col * LT + cc] *= inv;
+    __syncthreads();
+    for (int idx = lane; idx < J * NC; idx += 64) {
+      const int i = idx / NC, cc = idx % NC;
+      if (i != col && cc > col) T[i * LT + cc] -= T[i * LT + col] * T[col * LT + cc];
+    }
+    __syncthreads();
+  }
+  // T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
+
+  double ef = 0.0, fJf = 0.0, wGw = 0.0;
+  if (lane < J) {
+    double acc = 0.0;
+    for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * fv[k];
+    wv[lane] = acc - ev[lane];
+    ef = ev[lane] * fv[lane];
+    fJf = fv[lane] * acc;
+  }
+  __syncthreads();
+  if (lane < J) {
+    double acc = 0.0;
+    for (int k = 0; k < J; ++k) acc += 0.5 * (T[lane * LT + J + k] + T[k * LT + J + lane]) * wv[k];
+    wGw = wv[lane] * acc;
+  }
+  ef = wave_sum64(ef);
+  fJf = wave_sum64(fJf);
+  wGw = wave_sum64(wGw);
+
+  // certificate: F F^T = N + delta I (N = -Jm), then the Cholesky pivots of I - F^T P F
+  double nmax = (lane < J) ? -Jmm[lane * LD + lane] : 0.0;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) nmax = fmax(nmax, __shfl_xor(nmax, m, 64));
+  const double delta = 4e-13 * nmax;
+  for (int idx = lane; idx < J * J; idx += 64) {
+    const int i = idx / J, j = idx % J;
+    Sm[i * LD + j] = -Jmm[i * LD + j] + ((i == j) ? delta : 0.0);
+  }
+  __syncthreads();
+  for (int k = 0; k < J; ++k) {  // in place: column k of F replaces column k of S (rows >= k)
+    const double rs = 1.0 / sqrt(Sm[k * LD + k]);
+    __syncthreads();
+    if (lane < J) Sm[lane * LD + k] = (lane >= k) ? Sm[lane * LD + k] * rs : 0.0;
+    __syncthreads();
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      if (j > k && i >= j) {
+        Sm[i * LD + j] -= Sm[i * LD + k] * Sm[j * LD + k];
+      }
+    }
+    __syncthreads();
+  }
+  // (F is the lower triangle of Sm; the strict upper triangle still holds N)
+  for (int idx = lane; idx < J * J; idx += 64) {  // PF = P F
+    const int i = idx / J, k = idx % J;
+    double acc = 0.0;
+    for (int m = k; m < J; ++m) acc += Pm[i * LD + m] * Sm[m * LD + k];
+    PF[i * LD + k] = acc;
+  }
+  __syncthreads();
+  double* Em = T;  // T is no longer needed: E = I - F^T (P F), lower triangle, leading dimension LT
+  for (int idx = lane; idx < J * J; idx += 64) {
+    const int j = idx / J, k = idx % J;
+    if (k <= j) {
+      double acc = (j == k) ? 1.0 : 0.0;
+      for (int i = k; i < J; ++i) acc -= Sm[i * LD + k] * PF[i * LD + j];
+      Em[j * LT + k] = acc;
+    }
+  }
+  __syncthreads();
+  double mu = 1.0;
+  bool broke = false;
+  for (int k = 0; k < J; ++k) {
+    const double d = Em[k * LT + k];
+    if (!(d > 0.0)) broke = true;
+    mu = (d < mu) ? d : mu;
+    const double rs = 1.0 / sqrt(d);
+    __syncthreads();
+    if (lane < J && lane >= k) Em[lane * LT + k] *= rs;
+    __syncthreads();
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      if (j > k && i >= j) Em[i * LT + j] -= Em[i * LT + k] * Em[j * LT + k];
+    }
+    __syncthreads();
+  }
+  if (broke) mu = -1.0;
+
+  if (lane == 0) {
+    int bad = 0;
+    if (!(mu > 1e-5)) bad = 1;
+    if (!(det > 0.0)) bad = 1;
+    const double ld0 = P.part[slot * 2 + 0], q0 = P.part[slot * 2 + 1];
+    const double q = 2.0 * ef - fJf + wGw;
+    const double ld = log(det);
+    const double err = J * 2.2e-16 / mu;  // rounding-error estimate of the corrections
+    if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
+    if (!(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
+    if (!isfinite(q) || !isfinite(ld)) bad = 1;
+    P.part[slot * 2 + 0] = ld0 + ld;
+    P.part[slot * 2 + 1] = q0 + q;
+    if (bad) {
+      P.flags[slot] |= 2;
+      atomicOr(P.need_exact + b, 1);
     }
   }
 }
@@ -299,6 +493,14 @@ void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
     hipLaunchKernelGGL((prefix_coop_kernel<16, 16>), dim3((P.B + 1) / 2), dim3(64), 0, s, P);
   else
     hipLaunchKernelGGL((prefix_coop_kernel<32, 32>), dim3(P.B), dim3(64), 0, s, P);
+}
+
+// the scan's correct phase (determinant lemma + Woodbury + certificate) at the padded width
+void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) {
+  if (P.nchunk < 2) return;
+  const dim3 grid((unsigned)((long)P.B * P.nchunk));
+  if (width_padded <= 16) hipLaunchKernelGGL((wide_correct_kernel<16>), grid, dim3(64), 0, s, P);
+  else hipLaunchKernelGGL((wide_correct_kernel<32>), grid, dim3(64), 0, s, P);
 }
 
 // one chunk: the whole recurrence, results written directly; several chunks: the replay phase

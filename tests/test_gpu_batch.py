@@ -402,8 +402,18 @@ def test_wide_scan_over_chunks(JR, JC):
         case["a_real"][1, :] = -7.0       # an indefinite problem in the middle
         case["diag"][1] = 0.0
     ref_out = None
-    for nchunk in (1, 2, 5, 16):
-        ll, ld, q, st = check(case, nchunk=nchunk)
+    for nchunk in (1, 2, 5, 16, -5):       # -5: five chunks with the exact replay forced
+        if nchunk < 0:
+            plan = batch.BatchedGP(3, N, JR, JC)
+            plan.set_chunks(-nchunk)
+            plan.set_exact(True)
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            ll, ld, q, st = plan.log_likelihood()
+            assert plan.exact_count() == 3
+            plan.close()
+        else:
+            ll, ld, q, st = check(case, nchunk=nchunk)
         if ref_out is None:
             ref_out = (ld, q, st)
         else:
@@ -411,6 +421,19 @@ def test_wide_scan_over_chunks(JR, JC):
             assert np.array_equal(st, ref_out[2])
             assert np.max(np.abs(ld[ok] - ref_out[0][ok]) / np.abs(ref_out[0][ok])) <= 1e-11
             assert np.max(np.abs(q[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])) <= 1e-11
+
+
+def test_wide_scan_settles_well_conditioned_problems_without_replay():
+    case = synthetic(4, 6000, 0, 16, "bench", seed=9)
+    plan = batch.BatchedGP(4, 6000, 0, 16)
+    plan.set_chunks(6)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    ll, ld, q, st = plan.log_likelihood()
+    assert plan.exact_count() == 0 and (st == 0).all()
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL and np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+    plan.close()
 
 
 def test_wide_scan_is_chosen_for_small_batches():

@@ -16,8 +16,10 @@ from _cases import adversarial, coeffs_of, ALL_WIDTH_SHAPES  # noqa: E402
 
 n_total = n_exact = n_bad = mism = 0
 worst_ok = 0.0
+WIDE = [(9, 0), (1, 4), (3, 5), (16, 0), (0, 8), (2, 9), (0, 16), (6, 13), (32, 0)]
+SHAPES = ALL_WIDTH_SHAPES + WIDE + WIDE   # narrow scan (widths 1..8) and wide scan (9..32)
 for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
-    JR, JC = ALL_WIDTH_SHAPES[trial % len(ALL_WIDTH_SHAPES)]
+    JR, JC = SHAPES[trial % len(SHAPES)]
     N = (50, 200, 1000, 3000)[trial % 4]
     case = adversarial(4, N, JR, JC, seed=5000 + trial)
     l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])

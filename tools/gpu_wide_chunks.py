@@ -11,14 +11,14 @@ from celerite_amd import batch  # noqa: E402
 
 rng = np.random.RandomState(3)
 N, JR, JC = 100000, 0, 16
-for B in (64, 256, 512):
+for B in (256, 1024, 2048):
     t = np.sort(rng.rand(B, N), axis=1); sig = rng.uniform(0.1, 0.2, (B, N)); y = np.sin(t)
     ac = np.exp(0.1 + 0.1 * rng.randn(B, JC)); bc = np.zeros((B, JC))
     cc = np.exp(2.0 + 0.1 * rng.randn(B, JC)); dc = np.exp(rng.uniform(0.0, 3.0, (B, JC)))
     plan = batch.BatchedGP(B, N, JR, JC)
     plan.set_series(t, sig ** 2, y)
     plan.set_coefficients(np.empty((B, 0)), np.empty((B, 0)), ac, bc, cc, dc)
-    for nch in (1, 2, 4, 8, 12, 16, 24, 32):
+    for nch in (1, 2, 3, 4, 6, 8, 16):
         plan.set_chunks(nch)
         plan.log_likelihood()
         tot, k = plan.run_timed(2)
