@@ -105,8 +105,8 @@ class BatchedGP(object):
     Args:
         B, N: batch size and samples per series.
         J_real, J_comp: number of real / complex celerite terms
-            (width ``J = J_real + 2 J_comp``: 1..8 run the chunked scan, 9..64 one
-            wave per problem, sequential in n).
+            (width ``J = J_real + 2 J_comp``: 1..8 run the chunked scan with one lane
+            per (problem, chunk), 9..64 one wave per (problem, chunk)).
         device: GPU index (one process per GPU; shard the batch across ranks).
     """
 
