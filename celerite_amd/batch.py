@@ -53,6 +53,7 @@ def _load():
     lib.clr_batch_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp]
     lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_summarize_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_exact.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
@@ -229,6 +230,12 @@ class BatchedGP(object):
         n = C.c_int()
         _check(_load().clr_batch_get_exact_count(self._h, C.byref(n)))
         return n.value
+
+    def set_summarize_mode(self, mode=-1):
+        """summarize kernel of widths 7, 8: -1 / 1 = two roles on two waves per SIMD
+        (default; reads a chunk-interleaved copy of the series), 0 = the single-wave
+        kernel (csrc/clr_split_kernels.h; for A/B measurements)."""
+        _check(_load().clr_batch_set_summarize_mode(self._h, int(mode)))
 
     def set_library_trig(self, force=True):
         """Use the library (ocml) sincos instead of the FMA Cody-Waite routine

@@ -178,11 +178,13 @@ class GP(ModelSet):
     def grad_log_likelihood(self, y, quiet=False):
         """Value and gradient w.r.t. :meth:`get_parameter_vector`.
 
-        Needs the forward-mode gradient in the compiled module
-        (``solver.has_autodiff()``) and, for the chain rule through the term
-        parameters, ``autograd`` -- neither ships in this build yet
-        (SURVEY.md section 8f, item 3), so this raises like a reference built
-        with ``-DNO_AUTODIFF`` does (celerite.py:247-251).
+        The forward-mode gradient of ``compute`` + ``dot_solve`` with respect to
+        the coefficients runs on the device (``solver.has_autodiff()`` is True:
+        csrc/grad_kernels.hip, the counterpart of solver.cpp:347-463, including
+        its ``pi * log(N)`` constant).  The chain rule through the term
+        parameters needs ``autograd`` for ``get_coeffs_jacobian`` /
+        ``get_jitter_jacobian`` exactly as the reference does (terms.py:197-215):
+        without it those raise ``ImportError`` (tests/test_celerite.py:441-446).
         """
         if not solver.has_autodiff():
             raise RuntimeError("celerite must be compiled with autodiff "

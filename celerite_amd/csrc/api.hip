@@ -1,7 +1,8 @@
 // celerite_amd/csrc/api.hip -- the C ABI of include/celerite_hip.h: handles, HBM
-// residency, path selection and kernel launches.  No arithmetic of the hot path
-// happens on the host: without a gfx950 device every compute entry fails with
-// CLR_NO_DEVICE.
+// residency, path selection and kernel launches.  The recurrences run on the device
+// only (without a gfx950 device every compute entry fails with CLR_NO_DEVICE); the one
+// piece of host arithmetic is the O(N) diagonal a_n = diag_n + sum(a) + jitter (+ A_n)
+// that the general-terms / wide single-solver path forms before its upload.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -201,6 +202,18 @@ int upload(DevBuf& buf, const double* host, size_t n, hipStream_t s) {
   return CLR_OK;
 }
 
+// max |t| over a series (NaN sticks).  A full O(N) pass, not the two ends: the C ABI does
+// not require sorted times (GP.compute(check_sorted=False) reaches it unsorted), and the
+// fast sincos is only valid for |d t| < CLR_FAST_TRIG_LIMIT at EVERY sample.
+double max_abs(const double* x, long n) {
+  double m = 0.0;
+  for (long i = 0; i < n; ++i) {
+    const double a = fabs(x[i]);
+    if (!(a <= m)) m = a;
+  }
+  return m;
+}
+
 // Chunk count for the scan on `B` problems of `N` samples.
 int auto_chunks(int B, int N, bool with_replay = false) {
   if (N < 128) return 1;
@@ -267,6 +280,7 @@ struct clr_batch {
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
   int force_library_trig = 0;
   int coop_prefix = 1;
+  int summarize_mode = -1;            // -1 auto, 0 single wave, 1 role split (widths 7, 8)
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
   DevBuf elems, starts, part, partx, out;  // out: ll | logdet | quad | status (B ints)
@@ -487,8 +501,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     {
       double dmax = 0.0;
       for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
-      const double t0 = fabs(x[0]), t1 = fabs(x[N - 1]);
-      P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+      P.fast_trig = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
     }
     P.coop_prefix = 1;
     P.nchunk = auto_chunks(1, N, true);
@@ -605,8 +618,7 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   {
     double dmax = 0.0;
     for (int j = 0; j < JC; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
-    const double t0 = fabs(x[0]), t1 = fabs(x[N - 1]);
-    P.fast_trig = (dmax * (t0 > t1 ? t0 : t1) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+    P.fast_trig = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
   }
   P.out_value = s->gradbuf.p + o_out;
   P.out_grad = s->gradbuf.p + o_out + 1;
@@ -1017,13 +1029,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
     if (sd != 0 && sd != N)
       return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
-  // t is sorted per series, so max |t| is at one of its two ends
-  h->tmax = 0.0;
-  for (long b = 0; b < (t_stride == 0 ? 1 : (long)h->B); ++b) {
-    const double lo = fabs(t[b * t_stride]), hi = fabs(t[b * t_stride + N - 1]);
-    const double m = lo > hi ? lo : hi;
-    if (!(m <= h->tmax)) h->tmax = m;  // NaN sticks
-  }
+  h->tmax = max_abs(t, (long)count(t_stride));  // every sample (sortedness is not assumed)
   if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
@@ -1074,6 +1080,12 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   return CLR_OK;
 }
 
+static bool split_active(const clr_batch* h) {
+  // (auto = off: measured 5-7 % faster at width 8 with >= 2 complex terms, slower for real-only
+  //  kernels and at width 7 -- profiles/r02h_split_ab.txt)
+  return h->launch && h->nchunk > 1 && h->summarize_mode > 0 && clr::have_summarize_split(h->J_real, h->J_comp);
+}
+
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   if (!h->have_series || !h->have_coeffs)
     return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
@@ -1100,7 +1112,11 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.b_comp = P.a_comp + nc;
   P.c_comp = P.b_comp + nc;
   P.d_comp = P.c_comp + nc;
-  if (h->launch && h->layout == 1 && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
+  // role-split summarize (two waves per SIMD, clr_split_kernels.h) for the widths whose element
+  // does not fit one wave's registers; it reads the chunk-interleaved copy of the series
+  const bool split = split_active(h);
+  P.split = split ? (h->summarize_mode > 1 ? h->summarize_mode : 1) : 0;
+  if (h->launch && (h->layout == 1 || split) && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
     if ((st = h->tT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
@@ -1133,7 +1149,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
 
 // Row-major API layout -> chunk-interleaved layout (3 tiled transposes).
 static void batch_relayout(clr_batch* h) {
-  if (!(h->layout == 1 && h->nchunk > 1)) return;
+  if (!((h->layout == 1 || split_active(h)) && h->nchunk > 1)) return;
   const long cells = (long)h->nchunk * h->L;
   struct { DevBuf* src; DevBuf* dst; long stride; } jobs[3] = {
       {&h->t, &h->tT, h->t_stride}, {&h->diag, &h->dT, h->diag_stride}, {&h->y, &h->yT, h->y_stride}};
@@ -1168,6 +1184,13 @@ int clr_batch_get_exact_count(clr_batch* h, int* count) {
 
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
   h->coop_prefix = cooperative ? 1 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_summarize_mode(clr_batch* h, int mode) {
+  if (mode < -1 || mode > 7) return fail(CLR_INVALID_ARGUMENT, "summarize mode must be -1, 0 or 1");
+  if (mode != h->summarize_mode) h->relayout_pending = true;
+  h->summarize_mode = mode;
   return CLR_OK;
 }
 
@@ -1333,9 +1356,11 @@ int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double*
                              double* logdet, double* quad, int* status, int device) {
   clr_batch* h = clr_batch_create(B, N, J_real, J_comp, device);
   if (!h) {
-    // clr_batch_create recorded why
-    if (clr::find_batch_launchers(J_real, J_comp) == nullptr) return CLR_UNSUPPORTED;
-    return visible_gfx950() > 0 ? CLR_INVALID_ARGUMENT : CLR_NO_DEVICE;
+    // clr_batch_create recorded why (message in clr_last_error)
+    if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) return CLR_INVALID_ARGUMENT;
+    const int width = J_real + 2 * J_comp;
+    if (width < 1 || width > clr::wide_max_width()) return CLR_UNSUPPORTED;
+    return visible_gfx950() > 0 ? CLR_HIP_ERROR : CLR_NO_DEVICE;
   }
   int st = clr_batch_set_series(h, t, t_stride, diag, diag_stride, y, y_stride);
   if (st == CLR_OK)

@@ -34,6 +34,8 @@ struct BatchParams {
   long lane_is, lane_cs;
   int staged;
   int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
+  int split;      // summarize as two roles on two waves per SIMD (widths 7, 8; clr_split_kernels.h);
+                  // needs the chunk-interleaved series (staged == 0, lane_cs == 1)
   int coop_prefix;  // 16 lanes per problem in the prefix phase (0: one lane, the reference version)
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
@@ -78,7 +80,12 @@ __device__ __forceinline__ void lds_barrier() {
 // issued during step i.
 // This replaces a separate relayout pass (0.87 ms for 3 x 0.82 GB at 5.7 TB/s).
 // ---------------------------------------------------------------------------
-struct StagedSeries {
+// PRIVATE = false: the wave is its workgroup (the fences are workgroup barriers, free for a
+// lone wave); PRIVATE = true: the wave shares its workgroup with other roles
+// (clr_split_kernels.h) -- the tiles are still written and read by this wave only, LDS
+// operations of one wave complete in order, so a compiler fence + lgkmcnt wait suffices.
+template <bool PRIVATE>
+struct StagedSeriesT {
   double* lds;  // [2 buffers][3 arrays][64 rows][9]
   const double *g0, *g1, *g2;  // problem bases: t, diag, y (row-major)
   long lim;                    // N
@@ -116,12 +123,16 @@ struct StagedSeries {
     commit(1, 0);
     issue(1, 1);
     commit(1, 1);
-    __syncthreads();
+    if (PRIVATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
   }
   __device__ __forceinline__ void step_begin(int i) {
     if (i > 0) {
       commit(((i + 1) >> 3) + 1, (i + 1) & 7);
-      if (((i + 1) & 7) == 7) lds_barrier();  // (not __syncthreads: keep the prefetch in flight)
+      if (((i + 1) & 7) == 7) {  // (not __syncthreads: keep the prefetch in flight)
+        if (PRIVATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else lds_barrier();
+      }
     }
     issue(((i + 2) >> 3) + 1, (i + 2) & 7);
   }
@@ -133,6 +144,7 @@ struct StagedSeries {
   __device__ __forceinline__ double diag(int i) const { return rd(1, i); }
   __device__ __forceinline__ double y(int i) const { return rd(2, i); }
 };
+using StagedSeries = StagedSeriesT<false>;
 
 __device__ __forceinline__ StagedSeries make_staged(const BatchParams& P, int b, int c, double* lds) {
   StagedSeries s;
@@ -503,16 +515,18 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
 
 // One table entry per (JR, JC): host-callable launchers.
 struct BatchLaunchers {
-  void (*summarize)(const BatchParams&, hipStream_t);
+  void (*summarize)(const BatchParams&, hipStream_t);  // (role-split kernel when P.split > 0, widths 7, 8)
   void (*prefix)(const BatchParams&, hipStream_t);
   void (*correct)(const BatchParams&, hipStream_t);
   void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
   int elem_doubles, start_doubles;
 };
 
+bool launch_summarize_split(const BatchParams& P, int JR, int JC, hipStream_t s);
 template <int JR, int JC>
 struct BatchImpl {
   static void summarize(const BatchParams& P, hipStream_t s) {
+    if (P.split && !P.staged && launch_summarize_split(P, JR, JC, s)) return;
     dim3 grid((P.nchunk + 63) / 64, P.B);
 #define CLR_GO(F, S) hipLaunchKernelGGL((summarize_kernel<JR, JC, F, S>), grid, dim3(64), 0, s, P)
     if (P.fast_trig) { if (P.staged) CLR_GO(true, true); else CLR_GO(true, false); }
@@ -547,6 +561,11 @@ struct BatchImpl {
                           Widths<JR, JC>::START};
   }
 };
+
+// Role-split summarize (clr_split_kernels.h; batch_split*.hip): false when (JR, JC, P.split) has no
+// instantiation (widths below 7) -- the caller then runs the single-wave kernel.
+bool launch_summarize_split(const BatchParams& P, int JR, int JC, hipStream_t s);
+bool have_summarize_split(int JR, int JC);
 
 // Per-problem reduction of the chunk partials + the -inf rules (api.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);

@@ -416,12 +416,11 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
 void launch_factor_generic(const GenericProblem& g, double* phi, double* u, double* W, double* D,
                            int* status, double* log_det, hipStream_t s) {
   const size_t lds = sizeof(double) * ((size_t)g.J * g.J + 6 * (size_t)g.J + 4);
-  static size_t configured = 0;
-  if (lds > configured) {
+  // (the attribute is per device: set it on every launch that needs more than the
+  //  64 KB default -- J >= ~90 -- instead of caching a process-wide flag)
+  if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_generic_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
   const int threads = g.J <= 8 ? 64 : 256;
   hipLaunchKernelGGL(factor_generic_kernel, dim3(1), dim3(threads), lds, s, g, phi, u, W, D,
                      status, log_det);

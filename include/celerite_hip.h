@@ -217,6 +217,14 @@ int clr_batch_set_layout(clr_batch* h, int layout);
  * 1e9 holds, and with the library (ocml) sincos otherwise.  force != 0 selects the
  * library routine unconditionally (for A/B measurements). */
 int clr_batch_set_library_trig(clr_batch* h, int force);
+/* summarize kernel of widths 7 and 8: 1 = two roles on two waves per SIMD -- a "trajectory"
+ * wave (C, b) and a "riders" wave (A, eta in registers, Jm in LDS) linked through LDS,
+ * csrc/clr_split_kernels.h; it reads a chunk-interleaved copy of the series made once per
+ * clr_batch_set_series (layout 1 below is implied).  0 / -1 (default) = the single-wave
+ * kernel (one wave per SIMD, part of the state in AGPRs).  Measured on MI355X: the split is
+ * 5-7 % faster at width 8 with two or more complex terms and slower for real-only kernels
+ * (the fp64 FMA issue rate, not occupancy, is the bound: profiles/r02a_issue_rates2.txt). */
+int clr_batch_set_summarize_mode(clr_batch* h, int mode);
 /* Prefix phase: 16 lanes per problem (default) or the single-lane version (kept as
  * the on-device cross-check and for A/B measurements). */
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
