@@ -36,8 +36,11 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS) | $(BUILD)
 $(BUILD)/host_helpers.o: $(CSRC)/host_helpers.cpp include/celerite_hip.h | $(BUILD)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIB): $(HIP_OBJS) $(BUILD)/host_helpers.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+$(BUILD)/sharded.o: $(CSRC)/sharded.cpp include/celerite_hip.h | $(BUILD)
+	$(CXX) $(CXXFLAGS) -pthread -c $< -o $@
+
+$(LIB): $(HIP_OBJS) $(BUILD)/host_helpers.o $(BUILD)/sharded.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -pthread -o $@ $^
 
 $(PYMOD): $(CSRC)/solver_pybind.cpp include/celerite_hip.h $(LIB)
 	$(CXX) $(CXXFLAGS) $(PY_INC) -shared $< -o $@ -Lcelerite_amd -lcelerite_hip -Wl,-rpath,'$$ORIGIN'

@@ -10,32 +10,38 @@ Workload (BASELINE.json configs[2] per GPU; configs[3] = the same on 8 GPUs):
     fp64, synthetic "bench" family (run.py:66-69): t = sort(U(0,1)), sigma =
     U(0.1,0.2), y = sin t.
 
-One "step" = one evaluation of all B log-likelihoods from inputs resident in
-HBM in the public API's row-major layout: summarize -> prefix -> correct ->
-replay -> finalize (celerite_amd/csrc).  summarize is the one pass over the
-series (read through cooperative LDS-transposed tiles, "staged" layout: nothing is
-cached between steps); correct turns every chunk's zero-start sums into its true
-log-det / quadratic contributions (determinant lemma + Woodbury), and the replay
-kernel -- the reference's recurrence step by step -- only runs for problems with a
-chunk that could not be certified (config.problems_replayed; it exits at once for
-the others).  config.exact_replay_ms_per_step is the same step with the replay
-forced for every problem.  For
-information, config.value_fixed_series is the rate with a cached
-chunk-interleaved copy of the series (layout "interleaved", relayout outside the
-timed region): the optimiser / MCMC case where only hyper-parameters change.
+One "step" = what an optimiser / MCMC iteration pays (celerite.py:160-219 per
+problem): a FRESH draw of hyper-parameters for all B problems goes host -> HBM
+(`set_coefficients`), the five kernels run (summarize -> prefix -> correct ->
+replay -> finalize, csrc/), and the B log-likelihoods come back to the host
+(`results`, which synchronises).  The series are resident in HBM (uploaded
+before the timed region, in the public API's row-major layout).  `value` is
+that loop's rate; `device_only` is the same kernels launched back to back
+without the per-step transfers (what round 1 reported as `value`).
+
+Per-kernel times come from HIP events recorded on the plan's stream around
+every kernel INSIDE the timed loop (`clr_batch_set_profiling`).
 
 Multi-GPU: the batch axis shards embarrassingly -- one process per GPU, no
 collective on the data path; torch.distributed (gloo) is used
 only for the rendezvous, the timing barrier and the max-over-ranks reduction.
-Weak scaling: every rank evaluates its own B problems.
+Weak scaling: every rank evaluates its own B problems.  Launched without
+WORLD_SIZE and with --gpus N > 1, this script starts its own N ranks
+(torch.distributed.run) and fails if fewer than N GPUs are visible.  (The
+single-process alternative is the product's `ShardedBatchedGP` /
+`clr_sharded_*`: one host thread per GPU.)
 
-Rank 0 prints ONE JSON line (see the keys below).
+Rank 0 prints ONE JSON line; `configs` under it carries BASELINE configs
+0, 1 and 4 (object API at N = 1e3; B = 256 x N = 1e4 width 4; B = 256 x N = 1e5
+width 32), each with its own time, rate, roofline and parity on a sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+import timeit
 
 import numpy as np
 
@@ -43,7 +49,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X datasheet: 256 CU x 4 SIMD x 16 FMA lanes x 2 flop x 2.4 GHz
+# MI355X datasheet: 256 CU x 4 SIMD x 16 FMA lanes x 2 flop x 2.4 GHz (matrix = vector rate for fp64)
+PEAK_FP64_TFLOPS = 78.6
+# what the VECTOR ALU sustains on an all-FMA stream with every SIMD busy: one wave64 fp64 FMA per
+# 2.46 ns per SIMD (tools/microbench/issue_rates2.hip, profiles/r02a_issue_rates2.txt)
+MEASURED_VALU_FMA_TFLOPS = 1024 * 64 * 2 / 2.46e-9 / 1e12
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 measured)
 
 
@@ -78,7 +88,7 @@ def pmc_traffic(kernel, B, N, JR, JC, chunks):
     return None
 
 
-def make_inputs(B, N, J_real, J_comp, seed):
+def make_inputs(B, N, J_real, J_comp, seed, d_spread=False):
     rng = np.random.RandomState(seed)
     t = np.sort(rng.rand(B, N), axis=1)
     sig = rng.uniform(0.1, 0.2, (B, N))
@@ -88,8 +98,32 @@ def make_inputs(B, N, J_real, J_comp, seed):
     a_comp = np.exp(0.1 + 0.1 * rng.randn(B, J_comp))
     b_comp = np.zeros((B, J_comp))
     c_comp = np.exp(2.0 + 0.1 * rng.randn(B, J_comp))
-    d_comp = np.exp(1.6 + 0.1 * rng.randn(B, J_comp))
+    if d_spread:  # log d spread over U(0, 3)
+        d_comp = np.exp(rng.uniform(0.0, 3.0, (B, J_comp)))
+    else:
+        d_comp = np.exp(1.6 + 0.1 * rng.randn(B, J_comp))
     return (a_real, c_real, a_comp, b_comp, c_comp, d_comp), t, sig ** 2, y
+
+
+def fresh_draws(coeffs, count, seed):
+    """`count` hyper-parameter proposals around `coeffs` (1 % log-normal steps, b_comp kept):
+    what an MCMC sampler hands over per iteration."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        out.append(tuple(np.ascontiguousarray(c * np.exp(0.01 * rng.randn(*c.shape))) for c in coeffs))
+    return out
+
+
+def best_of_3(fn, min_time=0.2):
+    """celerite/timer.py:8-15: double the repeat count until three repeats take >= 0.2 s in
+    total, return the best per-call time."""
+    k = 1
+    while True:
+        times = timeit.repeat(fn, repeat=3, number=k)
+        if sum(times) >= min_time or k >= 1 << 20:
+            return min(times) / k
+        k *= 2
 
 
 class Dist(object):
@@ -126,6 +160,145 @@ class Dist(object):
             self.pg.destroy_process_group()
 
 
+def spawn_ranks(n, argv):
+    """--gpus n without a launcher: start n ranks of this script on this node."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def real_loop(plan, draws, steps, offset=0):
+    """`steps` optimiser-style evaluations: upload a fresh draw, launch, fetch the results."""
+    out = None
+    for k in range(steps):
+        plan.set_coefficients(*draws[(offset + k) % len(draws)])
+        plan.enqueue()
+        out = plan.results()
+    return out
+
+
+def roofline_block(per_kernel_ms, B, N, W, traffic=None):
+    dom = max(per_kernel_ms, key=per_kernel_ms.get)
+    dom_s = per_kernel_ms[dom] * 1e-3
+    step_s = sum(per_kernel_ms.values()) * 1e-3
+    flops = B * algorithmic_flops_per_loglik(N, W)
+    bytes_ = B * algorithmic_bytes_per_loglik(N)
+    ach = flops / dom_s / 1e12
+    return {
+        "kernel": dom, "bound": "fp64_valu", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach / PEAK_FP64_TFLOPS, "traffic": traffic, "launch_ms": per_kernel_ms[dom],
+        "algorithmic_flops_per_launch": flops,
+        "frac_of_measured_valu_fma_rate": ach / MEASURED_VALU_FMA_TFLOPS,
+        "measured_valu_fma_rate_tflops": MEASURED_VALU_FMA_TFLOPS,
+        "hbm_view": {"bound": "hbm", "achieved": bytes_ / dom_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": bytes_ / dom_s / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": bytes_},
+        "whole_step": {"achieved_tflops": flops / step_s / 1e12,
+                       "frac_fp64": flops / step_s / 1e12 / PEAK_FP64_TFLOPS},
+    }
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b))) if len(a) else 0.0
+
+
+def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
+    """One of the other BASELINE batch configurations: real loop + device-only rate, roofline of
+    its dominant kernel, parity against the oracle on `sample` problems, CPU time beside it."""
+    from celerite_amd import batch
+    from oracle import ref
+
+    W = JR + 2 * JC
+    coeffs, t, diag, y = make_inputs(B, N, JR, JC, seed, d_spread=d_spread)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        draws = [coeffs] + fresh_draws(coeffs, 3, seed + 1)
+        real_loop(plan, draws, 2)
+        plan.set_profiling(True)
+        batch.device_synchronize()
+        t0 = time.perf_counter()
+        real_loop(plan, draws, steps, offset=1)
+        dt = time.perf_counter() - t0
+        kms, nrec = plan.profile()
+        plan.set_profiling(False)
+        per = {k: v / max(nrec, 1) for k, v in kms.items()}
+        plan.set_coefficients(*coeffs)
+        ll, ld, q, st = plan.log_likelihood()
+        dev_ms, _ = plan.run_timed(steps, relayout_each_step=False)
+        chunks = plan.chunks
+    finally:
+        plan.close()
+    S = min(sample, B)
+    sub = [c[:S] for c in coeffs]
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *sub, t[:S], diag[:S], y[:S], nthreads=1)
+    cpu = best_of_3(lambda: ref.batch_log_likelihood(0.0, *[c[:1] for c in coeffs], t[:1], diag[:1], y[:1],
+                                                     nthreads=1))
+    ok = s0 == 0
+    return {
+        "workload": name, "batch": B, "N": N, "width": W, "J_real": JR, "J_comp": JC,
+        "scan_chunks": chunks[0], "chunk_len": chunks[1], "steps": steps,
+        "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
+        "device_only": {"ms_per_step": dev_ms / steps, "value": B / (dev_ms / steps * 1e-3)},
+        "kernels_ms": per, "roofline": roofline_block(per, B, N, W),
+        "cpu_oracle": {"ms_per_loglik": cpu * 1e3, "value": 1.0 / cpu, "cores": 1, "timing": "best of 3 (timer.py)"},
+        "parity": {"problems_checked": int(S), "status_equal": bool(np.array_equal(st[:S], s0)),
+                   "logdet_rel_max": rel_err(ld[:S][ok], d0[ok]), "quad_rel_max": rel_err(q[:S][ok], q0[ok]),
+                   "tolerance": 1e-10},
+    }
+
+
+def object_api_config():
+    """BASELINE configs[0]: one series, N = 1000, 1 real + 1 SHO term (width 3) through the
+    drop-in object API (GP.compute + GP.log_likelihood), oracle timed the same way."""
+    import celerite_amd
+    from celerite_amd import terms
+    from oracle import ref
+
+    rng = np.random.RandomState(42)
+    N = 1000
+    t = np.sort(rng.uniform(0, 10, N))
+    yerr = rng.uniform(0.1, 0.2, N)
+    y = np.sin(t) + yerr * rng.randn(N)
+    kernel = terms.RealTerm(log_a=0.1, log_c=0.5) + terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5)
+    gp = celerite_amd.GP(kernel)
+    gp.compute(t, yerr)
+    ll = gp.log_likelihood(y)
+    a_r, c_r, a_c, b_c, c_c, d_c = kernel.coefficients
+    empty, empty2 = np.empty(0), np.empty((0, 0))
+
+    def gpu_call():
+        gp.solver.compute(0.0, a_r, c_r, a_c, b_c, c_c, d_c, empty, empty2, empty2, t, yerr ** 2)
+        return gp.solver.dot_solve(y) + gp.solver.log_determinant()
+
+    r = ref.RefSolver()
+
+    def cpu_call():
+        r.compute(0.0, a_r, c_r, a_c, b_c, c_c, d_c, empty, empty2, empty2, t, yerr ** 2)
+        return r.dot_solve(y) + r.log_determinant()
+
+    g, c = gpu_call(), cpu_call()
+    tg, tc = best_of_3(gpu_call), best_of_3(cpu_call)
+    ll0 = -0.5 * (c + N * np.log(2 * np.pi))
+    W = 3
+    return {
+        "workload": "BASELINE configs[0]: single series N=1000, RealTerm + SHOTerm (width 3), "
+                    "CholeskySolver.compute + dot_solve + log_determinant through the object API",
+        "N": N, "width": W, "ms_per_loglik": tg * 1e3, "value": 1.0 / tg, "unit": "log-likelihoods/s",
+        "cpu_oracle": {"ms_per_loglik": tc * 1e3, "value": 1.0 / tc, "cores": 1, "timing": "best of 3 (timer.py)"},
+        "roofline": {"bound": "launch latency", "note": "one problem of 1.3e5 flop: the call is launch- and "
+                     "copy-bound; algorithmic rate below", "achieved": algorithmic_flops_per_loglik(N, W) / tg / 1e12,
+                     "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": algorithmic_flops_per_loglik(N, W) / tg / 1e12 / PEAK_FP64_TFLOPS},
+        "parity": {"loglike_rel": abs(ll - ll0) / abs(ll0), "value_rel": abs(g - c) / abs(c), "tolerance": 1e-10},
+    }
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,172 +310,194 @@ def main(argv=None):
     ap.add_argument("--jcomp", type=int, default=3)
     ap.add_argument("--chunks", type=int, default=0, help="scan chunks per problem (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 0/1/4 block")
+    ap.add_argument("--steady-seconds", type=float, default=2.5)
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from celerite_amd import batch as _b
+
+        if _b.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but only %d MI355X visible" % (args.gpus, _b.device_count()))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+
     dist = Dist()
-    if dist.world != args.gpus and dist.world > 1:
+    if dist.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world))
 
     from celerite_amd import batch  # raises if the HIP extension is missing
 
-    if batch.device_count() < 1:
+    ndev = batch.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: libcelerite_hip has no CPU path")
+    if dist.local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (dist.local_rank, ndev))
     B, N, JR, JC = args.batch, args.nsamples, args.jreal, args.jcomp
     W = JR + 2 * JC
+    K, Wm = max(args.steps, 1), max(args.warmup, 0)
 
     coeffs, t, diag, y = make_inputs(B, N, JR, JC, seed=42 + dist.rank)
-    plan = batch.BatchedGP(B, N, JR, JC, device=dist.local_rank % batch.device_count())
+    draws = [coeffs] + fresh_draws(coeffs, 7, seed=1042 + dist.rank)
+    plan = batch.BatchedGP(B, N, JR, JC, device=dist.local_rank)
     if args.chunks:
         plan.set_chunks(args.chunks)
     plan.set_series(t, diag, y)          # host -> HBM, outside the timed region
-    plan.set_coefficients(*coeffs)
-
-    for _ in range(max(args.warmup, 0)):
-        plan.enqueue()
+    real_loop(plan, draws, Wm)
     plan.synchronize()
+    plan.set_profiling(True)
 
     # ---- the timed region: exactly K steps between barrier + device sync -------
     dist.barrier()
     batch.device_synchronize()
     t0 = time.perf_counter()
-    ev_total_ms, kernel_ms = plan.run_timed(args.steps, relayout_each_step=True)
+    real_loop(plan, draws, K, offset=1)
     batch.device_synchronize()
     dist.barrier()
     dt = dist.max(time.perf_counter() - t0)
-
-    ll, ld, q, st = plan.results()
-    replayed = plan.exact_count()
-    # the same step with the exact replay forced for every problem (A/B, for information)
-    plan.set_exact(True)
-    plan.enqueue()
-    plan.synchronize()
-    exact_total_ms, _ = plan.run_timed(max(args.steps // 2, 1))
-    plan.set_exact(False)
-    # fixed-series variant (cached interleaved copy), reported for information
-    plan.set_layout("interleaved")
-    plan.enqueue()
-    plan.synchronize()
-    fixed_total_ms, _ = plan.run_timed(max(args.steps // 2, 1), relayout_each_step=False)
-    fixed_rate = B * max(args.steps // 2, 1) / (fixed_total_ms * 1e-3)
-    plan.set_layout("staged")
-    # the materialising variant (SURVEY.md 8d "A-ref": the factor phi, u, W, D of every
-    # problem written to HBM, as B CholeskySolver.compute calls would) -- HBM-bound
-    mat_steps = max(args.steps // 4, 2)
-    plan.enqueue(materialize=True)
-    plan.synchronize()
-    mat_total_ms, mat_kernel_ms = plan.run_timed(mat_steps, materialize=True)
+    kernel_ms, nrec = plan.profile()
+    plan.set_profiling(False)
 
     out = None
     if dist.rank == 0:
-        value = dist.world * B * args.steps / dt
-        per = {k: v / args.steps for k, v in kernel_ms.items()}
-        dom = max(per, key=per.get)
-        dom_s = per[dom] * 1e-3
-        flops = B * algorithmic_flops_per_loglik(N, W)
-        bytes_ = B * algorithmic_bytes_per_loglik(N)
-        step_s = sum(per.values()) * 1e-3
+        per = {k: v / max(nrec, 1) for k, v in kernel_ms.items()}
+        # parity inputs: the base draw
+        plan.set_coefficients(*coeffs)
+        ll, ld, q, st = plan.log_likelihood()
+        replayed = plan.exact_count()
+        # the same kernels back to back without the per-step transfers
+        dev_ms, dev_k = plan.run_timed(K, relayout_each_step=True)
+        # a longer steady-state leg of the real loop (lets the driver's utilisation sampler see the device)
+        n_steady, t_s = 0, time.perf_counter()
+        while time.perf_counter() - t_s < args.steady_seconds:
+            real_loop(plan, draws, 10, offset=n_steady)
+            n_steady += 10
+        steady_dt = time.perf_counter() - t_s
+        # A/B legs, for information
+        plan.set_exact(True)
+        plan.enqueue(); plan.synchronize()
+        exact_ms, _ = plan.run_timed(max(K // 2, 1))
+        plan.set_exact(False)
+        plan.set_coefficients(*coeffs)
+        plan.set_summarize_mode(1)      # role-split summarize, two waves per SIMD (clr_split_kernels.h)
+        plan.enqueue(); plan.synchronize()
+        split_ms, split_k = plan.run_timed(max(K // 2, 1), relayout_each_step=False)
+        ll2, ld2, q2, st2 = plan.results()
+        plan.set_summarize_mode(-1)
+        mat_steps = max(K // 4, 2)
+        plan.enqueue(materialize=True); plan.synchronize()
+        mat_ms, mat_k = plan.run_timed(mat_steps, materialize=True)
+
+        value = dist.world * B * K / dt
         out = {
             "metric": "GP log-likelihoods/sec, N=1e5 J=8 batch=1024; log_det rel-err vs CPU ref",
-            "value": value,
-            "unit": "log-likelihoods/s",
-            "n_gpus": dist.world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
+            "value": value, "unit": "log-likelihoods/s", "n_gpus": dist.world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: batch=%d problems/GPU x N=%d samples, width J=%d "
-                            "(%d real + %d complex terms), fp64, fused log-likelihood "
-                            "(compute + dot_solve + log_determinant), chunked scan over N, one pass "
-                            "over the series" % (B, N, W, JR, JC),
+                "workload": "BASELINE configs[2]: batch=%d problems/GPU x N=%d samples, width J=%d (%d real + %d "
+                            "complex terms), fp64, fused log-likelihood (compute + dot_solve + log_determinant), "
+                            "chunked scan over N; per step: fresh hyper-parameter draw host->HBM, 5 kernels, "
+                            "results HBM->host" % (B, N, W, JR, JC),
                 "batch_per_gpu": B, "N": N, "width": W, "J_real": JR, "J_comp": JC,
                 "scan_chunks": plan.chunks[0], "chunk_len": plan.chunks[1],
                 "parallelism": "batch-sharded x%d, no collective" % dist.world,
-                "series_layout": "staged (row-major arrays read through LDS tiles; no per-step relayout pass)",
-                "value_fixed_series": fixed_rate * dist.world,
+                "series_layout": "staged (row-major arrays read through LDS tiles; nothing cached between steps)",
                 "problems_replayed": replayed,
-                "exact_replay_ms_per_step": exact_total_ms / max(args.steps // 2, 1),
             },
-            "kernels_ms": per,
-            "hip_event_ms_per_step": ev_total_ms / args.steps,
+            "kernels_ms": per, "kernel_events_recorded_steps": nrec,
+            "device_only": {"what": "the same kernels back to back, coefficients resident (round 1's `value`)",
+                            "ms_per_step": dev_ms / K, "value": B / (dev_ms / K * 1e-3) * dist.world,
+                            "kernels_ms": {k: v / K for k, v in dev_k.items()}},
+            "steady_state": {"seconds": steady_dt, "steps": n_steady, "value": B * n_steady / steady_dt * dist.world},
             "status_not_ok": int((st != 0).sum()),
-            # dominant kernel, SURVEY.md 8(d) op (B): the fused likelihood is bound by the
-            # fp64 vector ALU, not by HBM (24 N bytes vs 431 N flop per problem).
-            "roofline": {
-                "kernel": dom,
-                "bound": "fp64_valu",
-                "achieved": flops / dom_s / 1e12,
-                "peak": PEAK_FP64_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": flops / dom_s / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "traffic": pmc_traffic(dom, B, N, JR, JC, plan.chunks[0]),
-                "launch_ms": per[dom],
-                "algorithmic_flops_per_launch": flops,
-                "hbm_view": {"bound": "hbm", "achieved": bytes_ / dom_s / 1e9, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": bytes_ / dom_s / 1e9 / PEAK_HBM_GBS,
-                             "algorithmic_bytes_per_launch": bytes_},
-                "whole_step": {"achieved_tflops": flops / step_s / 1e12,
-                               "frac_fp64_valu": flops / step_s / 1e12 / PEAK_FP64_VALU_TFLOPS},
+            "roofline": roofline_block(per, B, N, W, pmc_traffic(max(per, key=per.get), B, N, JR, JC, plan.chunks[0])),
+            "ab": {
+                "exact_replay_ms_per_step": exact_ms / max(K // 2, 1),
+                "role_split_summarize": {"what": "summarize as two roles on two waves per SIMD (clr_split_kernels.h), "
+                                                 "series from the cached chunk-interleaved copy",
+                                         "ms_per_step": split_ms / max(K // 2, 1),
+                                         "summarize_ms": split_k["summarize"] / max(K // 2, 1),
+                                         "vs_default_logdet_rel": rel_err(ld2[st == 0], ld[st == 0]),
+                                         "vs_default_quad_rel": rel_err(q2[st == 0], q[st == 0])},
             },
         }
         factor_bytes = B * 8.0 * N * (3 * W + 1)           # phi, u, W, D written
-        mat_replay_s = mat_kernel_ms["replay"] / mat_steps * 1e-3
+        bytes_ = B * algorithmic_bytes_per_loglik(N)
+        mat_replay_s = mat_k["replay"] / mat_steps * 1e-3
+        mat_step_s = mat_ms / mat_steps * 1e-3
         out["materialize"] = {
             "what": "same step, additionally writing the factor (phi, u, W, D) of all problems to HBM",
-            "ms_per_step": mat_total_ms / mat_steps,
-            "value": B / (mat_total_ms / mat_steps * 1e-3) * dist.world,
-            "kernels_ms": {k: v / mat_steps for k, v in mat_kernel_ms.items()},
+            "ms_per_step": mat_ms / mat_steps, "value": B / mat_step_s * dist.world,
+            "kernels_ms": {k: v / mat_steps for k, v in mat_k.items()},
             "roofline": {"kernel": "replay (materialising)", "bound": "hbm",
                          "achieved": (factor_bytes + bytes_) / mat_replay_s / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": (factor_bytes + bytes_) / mat_replay_s / 1e9 / PEAK_HBM_GBS,
                          "bytes_per_launch": factor_bytes + bytes_,
-                         "note": "factor written (8 N (3W+1) B per problem) + t, diag, y read, over the "
-                                 "replay kernel's HIP-event time"},
+                         "whole_step_frac": (factor_bytes + 2 * bytes_) / mat_step_s / 1e9 / PEAK_HBM_GBS,
+                         "note": "factor written (8 N (3W+1) B per problem) + t, diag, y read, over the replay "
+                                 "kernel's HIP-event time; whole_step_frac = (factor + two passes over the "
+                                 "series) over the whole materialising step (summarize runs first)"},
         }
         if dist.world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, B, N))
-    dist.barrier()
+            out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, st, B, N))
     plan.close()
+    if dist.rank == 0 and dist.world == 1 and not args.no_configs:
+        cfg = {}
+        for key, fn in [("config0_object_api", object_api_config),
+                        ("config1_b256_n1e4_w4", lambda: batch_config(
+                            "BASELINE configs[1]: batch=256, N=1e4, width 4 (2 complex terms)", 256, 10000, 0, 2, 20, 64, 7)),
+                        ("config4_b256_n1e5_w32", lambda: batch_config(
+                            "BASELINE configs[4]: batch=256, N=1e5, width 32 (16 complex terms, log d ~ U(0,3))",
+                            256, 100000, 0, 16, 5, 4, 11, d_spread=True))]:
+            try:
+                cfg[key] = fn()
+            except Exception as e:  # a failing side leg must not lose the headline line
+                cfg[key] = {"error": repr(e)}
+        out["configs"] = cfg
+    dist.barrier()
     dist.close()
     if out is not None:
         print(json.dumps(out))
     return out
 
 
-def cpu_baseline_and_parity(coeffs, t, diag, y, ld_gpu, q_gpu, B, N):
-    """Times the CPU oracle (a like-for-like port of the reference's
-    cholesky.h loops; the reference itself needs Eigen and cannot be built
-    here) on this box's host cores and checks the GPU results against it."""
+def cpu_baseline_and_parity(coeffs, t, diag, y, ld_gpu, q_gpu, st_gpu, B, N):
+    """Times the CPU oracle (a like-for-like port of the reference's cholesky.h loops; the
+    reference itself needs Eigen and cannot be built here) on this box's host cores with the
+    reference's own protocol (celerite/timer.py: best of 3) and checks the GPU results against it."""
     from oracle import ref
 
-    # single thread, as the reference runs (no threads, GIL held): first S problems
-    S = min(B, 1024)
+    S = min(B, 256)
     sub = [c[:S] for c in coeffs]
-    t0 = time.perf_counter()
-    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *sub, t[:S], diag[:S], y[:S], nthreads=1)
-    t1 = time.perf_counter() - t0
+    times, res = [], None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = ref.batch_log_likelihood(0.0, *sub, t[:S], diag[:S], y[:S], nthreads=1)
+        times.append(time.perf_counter() - t0)
+    l0, d0, q0, s0 = res
+    t1 = min(times)
     cores = os.cpu_count() or 1
-    S2 = min(B, max(cores * 8, 64))
+    S2 = min(B, max(cores * 4, 64))
     sub2 = [c[:S2] for c in coeffs]
-    t0 = time.perf_counter()
-    ref.batch_log_likelihood(0.0, *sub2, t[:S2], diag[:S2], y[:S2], nthreads=cores)
-    t2 = time.perf_counter() - t0
+    times2 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref.batch_log_likelihood(0.0, *sub2, t[:S2], diag[:S2], y[:S2], nthreads=cores)
+        times2.append(time.perf_counter() - t0)
+    t2 = min(times2)
     ok = s0 == 0
     return {
         "cpu_baseline": {
             "value": S / t1, "unit": "log-likelihoods/s", "cores": 1, "kind": "port",
-            "sample": "the first %d of the %d problems of the GPU batch (N=%d, width 8), oracle/"
-                      "celerite_ref.c, gcc -O3, 1 thread, %.1f s" % (S, B, N, t1),
+            "sample": "the first %d of the %d problems of the GPU batch (N=%d, width 8), oracle/celerite_ref.c, "
+                      "gcc -O3, 1 thread, best of 3 passes (%.1f s each)" % (S, B, N, t1),
             "all_cores": {"value": S2 / t2, "cores": cores,
-                          "sample": "%d problems, one per thread over %d threads, %.1f s" % (S2, cores, t2)},
+                          "sample": "%d problems, one per thread over %d threads, best of 3 (%.1f s each)"
+                                    % (S2, cores, t2)},
         },
         "parity": {
-            "logdet_rel_max": float(np.max(np.abs(ld_gpu[:S][ok] - d0[ok]) / np.abs(d0[ok]))),
-            "quad_rel_max": float(np.max(np.abs(q_gpu[:S][ok] - q0[ok]) / np.abs(q0[ok]))),
+            "logdet_rel_max": rel_err(ld_gpu[:S][ok], d0[ok]), "quad_rel_max": rel_err(q_gpu[:S][ok], q0[ok]),
+            "status_equal": bool(np.array_equal(st_gpu[:S], s0)),
             "problems_checked": int(S), "tolerance": 1e-10,
         },
     }

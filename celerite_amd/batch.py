@@ -16,7 +16,8 @@ import os
 
 import numpy as np
 
-__all__ = ["BatchedGP", "batch_log_likelihood", "kernel_coefficient_table", "LIB_PATH"]
+__all__ = ["BatchedGP", "ShardedBatchedGP", "shard_bounds", "batch_log_likelihood",
+           "kernel_coefficient_table", "LIB_PATH"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcelerite_hip.so")
 
@@ -54,9 +55,27 @@ def _load():
     lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_summarize_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_exact.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
+    lib.clr_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
+    lib.clr_sharded_create.restype = C.c_void_p
+    lib.clr_sharded_create.argtypes = [C.c_int] * 4 + [_ip, C.c_int]
+    lib.clr_sharded_destroy.argtypes = [C.c_void_p]
+    lib.clr_sharded_last_error.restype = C.c_char_p
+    lib.clr_sharded_num_shards.argtypes = [C.c_void_p]
+    lib.clr_sharded_get_shard.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
+    lib.clr_sharded_set_chunks.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_sharded_get_chunks.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
+    lib.clr_sharded_set_series.argtypes = [C.c_void_p, _dp, C.c_long, _dp, C.c_long, _dp, C.c_long]
+    lib.clr_sharded_set_coefficients.argtypes = [C.c_void_p] + [_dp] * 7
+    lib.clr_sharded_enqueue.argtypes = [C.c_void_p]
+    lib.clr_sharded_synchronize.argtypes = [C.c_void_p]
+    lib.clr_sharded_get_results.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
+    lib.clr_sharded_evaluate.argtypes = [C.c_void_p] + [_dp] * 7 + [_dp, _dp, _dp, _ip]
+    lib.clr_sharded_run_timed.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.clr_device_info.argtypes = [C.c_char_p, C.c_size_t, _ip, C.POINTER(C.c_size_t)]
     lib.clr_set_device.argtypes = [C.c_int]
     _lib = lib
@@ -242,6 +261,17 @@ class BatchedGP(object):
         (which is picked automatically when max|d| * max|t| < 1e9)."""
         _check(_load().clr_batch_set_library_trig(self._h, int(bool(force))))
 
+    def set_profiling(self, on=True):
+        """Bracket the kernels of every following :meth:`enqueue` with HIP events."""
+        _check(_load().clr_batch_set_profiling(self._h, int(bool(on))))
+
+    def profile(self):
+        """``({kernel name: summed ms}, evaluations recorded)`` since :meth:`set_profiling`."""
+        k = (C.c_double * 6)()
+        n = C.c_int()
+        _check(_load().clr_batch_get_profile(self._h, k, C.byref(n)))
+        return dict(zip(self.KERNEL_NAMES, [k[i] for i in range(6)])), n.value
+
     def run_timed(self, steps, materialize=False, relayout_each_step=True):
         """``steps`` back-to-back evaluations bracketed by HIP events on the
         plan's stream.  Returns ``(total_ms, {kernel name: summed ms})``."""
@@ -250,6 +280,129 @@ class BatchedGP(object):
         _check(_load().clr_batch_run_timed(self._h, int(bool(materialize)), int(steps),
                                            int(bool(relayout_each_step)), C.byref(tot), k))
         return tot.value, dict(zip(self.KERNEL_NAMES, [k[i] for i in range(6)]))
+
+
+def shard_bounds(total, nshards, shard):
+    """``[lo, hi)`` of ``shard`` when ``total`` problems are cut into ``nshards``
+    contiguous slices (``clr_shard_bounds``; pure host arithmetic, needs no GPU)."""
+    lo, hi = C.c_int(), C.c_int()
+    if _load().clr_shard_bounds(int(total), int(nshards), int(shard), C.byref(lo), C.byref(hi)) != CLR_OK:
+        raise ValueError("bad shard arguments")
+    return lo.value, hi.value
+
+
+class ShardedBatchedGP(object):
+    """The batch axis over several GPUs: ``len(devices)`` contiguous shards, one
+    :class:`BatchedGP`-like plan and one host thread per shard, no collective
+    (problems are independent: cholesky.h:703-706).  ``devices`` defaults to every
+    visible GPU; a device may be listed more than once (shards sharing a GPU), which
+    is how the sharding is tested on one GPU.  Results do not depend on the sharding
+    bit for bit when every shard uses the same chunk count (:meth:`set_chunks`)."""
+
+    def __init__(self, B, N, J_real, J_comp, devices=None):
+        lib = _load()
+        if devices is None:
+            devices = list(range(device_count()))
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise RuntimeError("no gfx950 (MI355X) device is visible; libcelerite_hip has no CPU path")
+        self.B, self.N, self.J_real, self.J_comp = int(B), int(N), int(J_real), int(J_comp)
+        arr = (C.c_int * len(devices))(*devices)
+        h = lib.clr_sharded_create(self.B, self.N, self.J_real, self.J_comp, arr, len(devices))
+        if not h:
+            raise RuntimeError("clr_sharded_create failed: " + lib.clr_sharded_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    def _ok(self, status):
+        if status != CLR_OK:
+            lib = _load()
+            raise RuntimeError(lib.clr_status_string(status).decode() + ": " +
+                               lib.clr_sharded_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().clr_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shards(self):
+        """``[(device, lo, hi), ...]``"""
+        lib = _load()
+        out = []
+        for s in range(lib.clr_sharded_num_shards(self._h)):
+            d, lo, hi = C.c_int(), C.c_int(), C.c_int()
+            lib.clr_sharded_get_shard(self._h, s, C.byref(d), C.byref(lo), C.byref(hi))
+            out.append((d.value, lo.value, hi.value))
+        return out
+
+    def set_chunks(self, nchunk):
+        self._ok(_load().clr_sharded_set_chunks(self._h, int(nchunk)))
+
+    def set_series(self, t, diag, y):
+        arrs, strides = [], []
+        for a in (t, diag, y):
+            a = _f64(a)
+            if a.shape == (self.N,):
+                strides.append(0)
+            elif a.shape == (self.B, self.N):
+                strides.append(self.N)
+            else:
+                raise ValueError("dimension mismatch")
+            arrs.append(a)
+        if np.any(np.diff(arrs[0], axis=-1) < 0.0):
+            raise ValueError("the input coordinates must be sorted")
+        self._ok(_load().clr_sharded_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
+                                                strides[1], _ptr(arrs[2]), strides[2]))
+
+    def _coeff_blocks(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter):
+        try:
+            blocks = [_f64(a_real, (self.B, self.J_real)), _f64(c_real, (self.B, self.J_real)),
+                      _f64(a_comp, (self.B, self.J_comp)), _f64(b_comp, (self.B, self.J_comp)),
+                      _f64(c_comp, (self.B, self.J_comp)), _f64(d_comp, (self.B, self.J_comp))]
+        except ValueError:
+            raise ValueError("dimension mismatch")
+        jit = np.ascontiguousarray(np.broadcast_to(np.asarray(jitter, dtype=np.float64), (self.B,)))
+        return jit, blocks
+
+    def set_coefficients(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
+        jit, blocks = self._coeff_blocks(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter)
+        self._ok(_load().clr_sharded_set_coefficients(self._h, _ptr(jit), *[_ptr(b) for b in blocks]))
+
+    def enqueue(self):
+        self._ok(_load().clr_sharded_enqueue(self._h))
+
+    def synchronize(self):
+        self._ok(_load().clr_sharded_synchronize(self._h))
+
+    def _out(self):
+        return np.empty(self.B), np.empty(self.B), np.empty(self.B), np.empty(self.B, dtype=np.int32)
+
+    def results(self):
+        ll, ld, q, st = self._out()
+        self._ok(_load().clr_sharded_get_results(self._h, _ptr(ll), _ptr(ld), _ptr(q), st.ctypes.data_as(_ip)))
+        return ll, ld, q, st
+
+    def evaluate(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
+        """One optimiser / MCMC evaluation: new coefficients in, ``(loglike, logdet,
+        quad, status)`` of all B problems out."""
+        jit, blocks = self._coeff_blocks(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter)
+        ll, ld, q, st = self._out()
+        self._ok(_load().clr_sharded_evaluate(self._h, _ptr(jit), *([_ptr(b) for b in blocks] +
+                                              [_ptr(ll), _ptr(ld), _ptr(q), st.ctypes.data_as(_ip)])))
+        return ll, ld, q, st
+
+    def run_timed(self, steps):
+        """``steps`` evaluations on every shard concurrently; per-shard HIP-event ms."""
+        n = _load().clr_sharded_num_shards(self._h)
+        ms = np.zeros(n)
+        self._ok(_load().clr_sharded_run_timed(self._h, int(steps), _ptr(ms)))
+        return ms
 
 
 def batch_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y,

@@ -288,6 +288,9 @@ struct clr_batch {
   int force_exact = 0;
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
   DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
+  // optional per-kernel HIP events around the launches of clr_batch_enqueue (clr_batch_set_profiling)
+  int prof_on = 0, prof_steps = 0;
+  std::vector<hipEvent_t> prof_events;  // 7 per recorded step
 };
 
 
@@ -967,6 +970,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->fphi, &h->fu, &h->fW, &h->fD})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1222,25 +1226,74 @@ static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
   mark(6);
 }
 
+static const int PROF_NK = 6, PROF_MAX_STEPS = 4096;
+
+int clr_batch_set_profiling(clr_batch* h, int on) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  h->prof_on = on ? 1 : 0;
+  h->prof_steps = 0;
+  return CLR_OK;
+}
+
+int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double k[PROF_NK] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < h->prof_steps; ++i)
+    for (int j = 0; j < PROF_NK; ++j) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, h->prof_events[(size_t)i * (PROF_NK + 1) + j],
+                                  h->prof_events[(size_t)i * (PROF_NK + 1) + j + 1]));
+      k[j] += ms;
+    }
+  if (kernel_ms)
+    for (int j = 0; j < PROF_NK; ++j) kernel_ms[j] = k[j];
+  if (steps) *steps = h->prof_steps;
+  return CLR_OK;
+}
+
 int clr_batch_enqueue(clr_batch* h, int materialize) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  // profiling: one event per kernel boundary of this evaluation, on the plan's stream
+  hipEvent_t* ev = nullptr;
+  if (h->prof_on && h->prof_steps < PROF_MAX_STEPS) {
+    const size_t need = (size_t)(h->prof_steps + 1) * (PROF_NK + 1);
+    while (h->prof_events.size() < need) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      h->prof_events.push_back(e);
+    }
+    ev = &h->prof_events[(size_t)h->prof_steps * (PROF_NK + 1)];
+    ++h->prof_steps;
+  }
+  auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
   if (!h->launch) {
-    wide_launch(h, P, nullptr);
+    mark(0);
+    wide_launch(h, P, ev);
     HIP_TRY(hipGetLastError());
     return CLR_OK;
   }
+  mark(0);
   if (h->relayout_pending) {
     batch_relayout(h);
     h->relayout_pending = false;
   }
+  mark(1);
   h->launch->summarize(P, h->stream);
+  mark(2);
   h->launch->prefix(P, h->stream);
+  mark(3);
   if (!P.force_exact) h->launch->correct(P, h->stream);
+  mark(4);
   h->launch->replay(P, materialize ? 2 : 0, h->stream);  // exits at once for settled problems
+  mark(5);
   clr::launch_finalize(P, h->stream);
+  mark(6);
   // (capturing these five launches in a hipGraph was measured: no gain -- the gaps between
   //  dependent kernels are on the device side; profiles/r01r_small_batches.log)
   HIP_TRY(hipGetLastError());

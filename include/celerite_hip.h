@@ -268,6 +268,13 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
 int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
                         double* total_ms, double* kernel_ms /* [6] */);
 
+/* Per-kernel device times of the REAL loop: with profiling on, every clr_batch_enqueue
+ * brackets its kernels with HIP events on the plan's stream (up to 4096 evaluations since
+ * the switch); clr_batch_get_profile synchronises and returns the summed milliseconds per
+ * kernel (same order as clr_batch_run_timed) and the number of evaluations recorded. */
+int clr_batch_set_profiling(clr_batch* h, int on);
+int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps);
+
 /* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,
                              const double* jitter,
@@ -279,6 +286,55 @@ int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,
                              const double* y, long y_stride,
                              double* loglike, double* logdet, double* quad,
                              int* status, int device);
+
+/* ---- the batch axis over several GPUs (BASELINE config 4) ---------
+ * Problems are independent -- every member of the reference solver is per object
+ * (cholesky.h:703-706) -- so the batch axis shards embarrassingly: shard s of S owns the
+ * contiguous slice clr_shard_bounds(B, S, s) and is an ordinary clr_batch plan on
+ * devices[s], driven by its own host thread (stream + pinned staging per shard).  No
+ * collective, no device-to-device traffic; results are concatenated on the host.
+ * A device may be listed more than once (the shards then share it): results do not depend
+ * on the sharding, bit for bit, as long as every shard uses the same chunk count
+ * (clr_sharded_set_chunks; the automatic choice depends on the shard's batch size). */
+typedef struct clr_sharded clr_sharded;
+
+/* [lo, hi) of `shard` when `total` problems are cut into `nshards` contiguous slices
+ * (the first total % nshards slices are one longer).  Pure host arithmetic. */
+int clr_shard_bounds(int total, int nshards, int shard, int* lo, int* hi);
+/* nshards = number of entries of `devices` (clamped to B).  NULL on failure:
+ * clr_sharded_last_error() says why (no device, bad index, allocation). */
+clr_sharded* clr_sharded_create(int B, int N, int J_real, int J_comp, const int* devices, int nshards);
+void clr_sharded_destroy(clr_sharded* h);
+const char* clr_sharded_last_error(void);
+int clr_sharded_num_shards(const clr_sharded* h);
+int clr_sharded_get_shard(const clr_sharded* h, int shard, int* device, int* lo, int* hi);
+/* As the clr_batch_* entries of the same name, over the whole batch (host arrays of B
+ * problems; every shard takes its slice).  The calls return when every shard has. */
+int clr_sharded_set_chunks(clr_sharded* h, int nchunk);
+int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* chunk_len);
+int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
+                           long diag_stride, const double* y, long y_stride);
+int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const double* a_real,
+                                 const double* c_real, const double* a_comp, const double* b_comp,
+                                 const double* c_comp, const double* d_comp);
+int clr_sharded_enqueue(clr_sharded* h);
+int clr_sharded_synchronize(clr_sharded* h);
+int clr_sharded_get_results(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status);
+/* One optimiser / MCMC evaluation: new coefficients in, B log-likelihoods out
+ * (set_coefficients + enqueue + get_results on every shard concurrently). */
+int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_real, const double* c_real,
+                         const double* a_comp, const double* b_comp, const double* c_comp,
+                         const double* d_comp, double* loglike, double* logdet, double* quad, int* status);
+/* `steps` back-to-back evaluations on every shard concurrently (HIP events per shard);
+ * shard_ms[s] = that shard's first-to-last event time. */
+int clr_sharded_run_timed(clr_sharded* h, int steps, double* shard_ms);
+/* clr_batch_log_likelihood over `ndevices` shards (create + set + evaluate + destroy). */
+int clr_batch_log_likelihood_sharded(int B, int N, int J_real, int J_comp, const double* jitter,
+                                     const double* a_real, const double* c_real, const double* a_comp,
+                                     const double* b_comp, const double* c_comp, const double* d_comp,
+                                     const double* t, long t_stride, const double* diag, long diag_stride,
+                                     const double* y, long y_stride, double* loglike, double* logdet,
+                                     double* quad, int* status, const int* devices, int ndevices);
 
 /* ---- O(J) host helpers the Python layer imports (celerite/terms.py:18) --------
  * Plain host C++ (no device work): cpp/include/celerite/utils.h:106-163,27-104. */

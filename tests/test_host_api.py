@@ -196,3 +196,19 @@ def test_batch_front_end_validation():
     sho = terms.SHOTerm(log_S0=0.1, log_Q=0.0, log_omega0=0.5)
     with pytest.raises(ValueError):  # Q crosses 1/2: term count changes between draws
         batch.kernel_coefficient_table(sho, np.array([[0.1, 1.0, 0.5], [0.1, -1.0, 0.5]]))
+
+
+def test_shard_bounds_and_sharded_plan_without_a_gpu():
+    """clr_shard_bounds is host arithmetic; a sharded plan fails loudly without a device."""
+    from celerite_amd import batch
+    for total, S in [(1024, 8), (8192, 8), (10, 3), (7, 7), (5, 1)]:
+        cuts = [batch.shard_bounds(total, S, s) for s in range(S)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(S - 1))
+        sizes = [hi - lo for lo, hi in cuts]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        batch.shard_bounds(10, 3, 3)
+    if batch.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no gfx950"):
+            batch.ShardedBatchedGP(8, 100, 1, 1, devices=[0, 0])
