@@ -60,6 +60,9 @@ def _load():
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_exact.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
+    lib.clr_batch_get_exact_flags.argtypes = [C.c_void_p, _ip]
+    lib.clr_batch_get_conditioning.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.clr_batch_set_certificate.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.clr_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.clr_sharded_create.restype = C.c_void_p
     lib.clr_sharded_create.argtypes = [C.c_int] * 4 + [_ip, C.c_int]
@@ -249,6 +252,29 @@ class BatchedGP(object):
         n = C.c_int()
         _check(_load().clr_batch_get_exact_count(self._h, C.byref(n)))
         return n.value
+
+    def exact_flags(self):
+        """Boolean mask: which problems of the last run went through the exact recurrence."""
+        return self.exact_levels() != 0
+
+    def exact_levels(self):
+        """Per problem: 0 settled from the chunk summaries, 1 chunked replay (end states
+        consistent with the scan), 2 truly sequential recurrence."""
+        f = np.zeros(self.B, dtype=np.int32)
+        _check(_load().clr_batch_get_exact_flags(self._h, f.ctypes.data_as(_ip)))
+        return f
+
+    def set_certificate(self, max_gamma_over_mu=1e6, max_residual=1e-11):
+        """Routing of ill-conditioned problems (``clr_batch_set_certificate``)."""
+        _check(_load().clr_batch_set_certificate(self._h, float(max_gamma_over_mu), float(max_residual)))
+
+    def conditioning(self):
+        """``(gamma_max, mu_min)`` per problem of the last run: largest ``a_n / D_n`` over the
+        zero-start pivots, smallest certificate pivot (see ``clr_batch_get_conditioning``)."""
+        g, m, r = np.empty(self.B), np.empty(self.B), np.empty(self.B)
+        _check(_load().clr_batch_get_conditioning(self._h, _ptr(g), _ptr(m), _ptr(r)))
+        self.last_residual = r
+        return g, m
 
     def set_summarize_mode(self, mode=-1):
         """summarize kernel of widths 7, 8: -1 / 1 = two roles on two waves per SIMD

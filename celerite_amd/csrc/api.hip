@@ -257,7 +257,7 @@ struct clr_solver {
   DevBuf coeffs;                        // a_real c_real a_comp b_comp c_comp d_comp
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
-  DevBuf ws_elems, ws_starts, ws_part;  // scan workspace
+  DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
   DevBuf gradbuf;                       // grad_log_likelihood staging
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   int* ws_flags = nullptr;
@@ -280,10 +280,12 @@ struct clr_batch {
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
   int force_library_trig = 0;
   int coop_prefix = 1;
+  double cert_resid = 1e-11;          // end-state mismatch of the chunked replay that still counts as consistent
+  double cert_gamma = 1e6;            // conditioning record above which the sequential recurrence settles a problem
   int summarize_mode = -1;            // -1 auto, 0 single wave, 1 role split (widths 7, 8)
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
-  DevBuf elems, starts, part, partx, out;  // out: ll | logdet | quad | status (B ints)
+  DevBuf elems, starts, part, partx, cond, out;  // out: ll | logdet | quad | status (B ints)
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int force_exact = 0;
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
@@ -430,7 +432,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part, &s->gradbuf})
+                      &s->ws_part, &s->ws_cond, &s->gradbuf})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -513,6 +515,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if ((st = s->ws_elems.reserve((size_t)P.nchunk * L->elem_doubles)) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve((size_t)P.nchunk * L->start_doubles)) != CLR_OK) return st;
     if ((st = s->ws_part.reserve((size_t)P.nchunk * 2)) != CLR_OK) return st;
+    if ((st = s->ws_cond.reserve((size_t)P.nchunk * 3)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
     P.jitter = s->scratch2.p;
@@ -529,9 +532,12 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = 1;
     L->summarize(P, stream);
     L->prefix(P, stream);
-    L->replay(P, 1, stream);
+    L->correct(P, stream);        // flags + conditioning record (its sums are overwritten by the replay)
+    L->replay(P, 1, stream);      // chunked, from the scanned start states
+    L->sequential(P, 1, stream);  // the whole recurrence in one lane if those cannot be trusted
     clr::launch_finalize(P, stream);
     HIP_TRY(hipGetLastError());
     double back[4];  // ll | logdet | quad | status (int in the 4th slot): one copy
@@ -966,7 +972,7 @@ void clr_batch_destroy(clr_batch* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
-                    &h->elems, &h->starts, &h->part, &h->partx, &h->out, &h->phi, &h->u, &h->W, &h->D,
+                    &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
@@ -1011,6 +1017,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->cond.reserve(pc * 3)) != CLR_OK) return st;
   if ((st = h->out.reserve((size_t)h->B * 3 + ((size_t)h->B + 1) / 2)) != CLR_OK) return st;
   if (h->flags) (void)hipFree(h->flags);
   h->flags = nullptr;
@@ -1139,6 +1146,9 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.staged = (h->layout == 2 && h->nchunk > 1) ? 1 : 0;
   }
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
+  P.cond = h->cond.p;
+  P.cert_gamma = h->cert_gamma;
+  P.cert_resid = h->cert_resid;
   {
     const size_t pc = B * (size_t)h->nchunk;
     P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
@@ -1186,6 +1196,50 @@ int clr_batch_get_exact_count(clr_batch* h, int* count) {
   return CLR_OK;
 }
 
+int clr_batch_get_exact_flags(clr_batch* h, int* flags) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!flags) return fail(CLR_INVALID_ARGUMENT, "flags is null");
+  if (h->nchunk < 2) {
+    for (int b = 0; b < h->B; ++b) flags[b] = 2;  // one chunk: the replay from the zero state is the recurrence
+    return CLR_OK;
+  }
+  const size_t pc = (size_t)h->B * h->nchunk;
+  HIP_TRY(hipMemcpyAsync(flags, h->flags + 2 * pc, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->force_exact)
+    for (int b = 0; b < h->B; ++b) flags[b] = flags[b] < 1 ? 1 : flags[b];
+  return CLR_OK;
+}
+
+int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const size_t pc = (size_t)h->B * h->nchunk;
+  std::vector<double> c(pc * 3);
+  HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; ++b) {
+    double g = 0.0, m = 1.0, r = 0.0;
+    for (int k = 0; k < h->nchunk; ++k) {
+      const double* e = &c[((size_t)b * h->nchunk + k) * 3];
+      if (!(e[0] <= g)) g = e[0];
+      if (!(e[1] >= m)) m = e[1];
+      if (!(e[2] <= r)) r = e[2];
+    }
+    if (gamma_max) gamma_max[b] = g;
+    if (mu_min) mu_min[b] = m;
+    if (resid_max) resid_max[b] = r;
+  }
+  return CLR_OK;
+}
+
+int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual) {
+  h->cert_gamma = max_gamma_over_mu;
+  h->cert_resid = max_residual;
+  return CLR_OK;
+}
+
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
   h->coop_prefix = cooperative ? 1 : 0;
   return CLR_OK;
@@ -1210,19 +1264,29 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
   return CLR_OK;
 }
 
-// wide path: the sequential sweep, or summarize -> prefix -> replay -> finalize over chunks
+// wide path.  One chunk: the sequential sweep (one wave per problem).  Several chunks: summarize ->
+// prefix -> correct (+ conditioning decision) -> finalize from the chunk summaries; forced-exact runs
+// also replay every chunk from its scanned start state.  Problems the certificate or the
+// conditioning record flagged are then walked by the sequential sweep itself (one wave per flagged
+// problem over all N samples), which overwrites their results: nothing of theirs depends on the scan.
 static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
+  const int JP = h->J <= 16 ? 16 : 32;
   mark(1);
   if (P.nchunk > 1) clr::launch_wide_summarize(P, h->J_real, h->J_comp, h->stream);
   mark(2);
-  clr::launch_wide_prefix(P, h->J <= 16 ? 16 : 32, h->stream);
+  clr::launch_wide_prefix(P, JP, h->stream);
   mark(3);
-  if (!P.force_exact) clr::launch_wide_correct(P, h->J <= 16 ? 16 : 32, h->stream);
+  clr::launch_wide_correct(P, JP, h->stream);
   mark(4);
-  clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+  if (P.nchunk < 2 || P.force_exact) clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+  if (P.nchunk > 1) {
+    clr::launch_finalize(P, h->stream);
+    clr::BatchParams S = P;  // the flagged problems, sequentially
+    S.nchunk = 1; S.L = P.N; S.seq_only = 1; S.force_exact = 1;
+    clr::launch_wide_loglike(S, h->J_real, h->J_comp, h->stream);
+  }
   mark(5);
-  if (P.nchunk > 1) clr::launch_finalize(P, h->stream);
   mark(6);
 }
 
@@ -1288,9 +1352,10 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   mark(2);
   h->launch->prefix(P, h->stream);
   mark(3);
-  if (!P.force_exact) h->launch->correct(P, h->stream);
+  h->launch->correct(P, h->stream);  // (also on forced-exact runs: flags + conditioning record)
   mark(4);
-  h->launch->replay(P, materialize ? 2 : 0, h->stream);  // exits at once for settled problems
+  h->launch->replay(P, materialize ? 2 : 0, h->stream);      // forced-exact / materialising runs only
+  h->launch->sequential(P, materialize ? 2 : 0, h->stream);  // flagged / ill-conditioned problems only
   mark(5);
   clr::launch_finalize(P, h->stream);
   mark(6);
@@ -1373,9 +1438,10 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[2], h->stream));
     h->launch->prefix(P, h->stream);
     HIP_TRY(hipEventRecord(e[3], h->stream));
-    if (!P.force_exact) h->launch->correct(P, h->stream);
+    h->launch->correct(P, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
     h->launch->replay(P, materialize ? 2 : 0, h->stream);
+    h->launch->sequential(P, materialize ? 2 : 0, h->stream);
     HIP_TRY(hipEventRecord(e[5], h->stream));
     clr::launch_finalize(P, h->stream);
     HIP_TRY(hipEventRecord(e[6], h->stream));

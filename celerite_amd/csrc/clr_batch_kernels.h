@@ -42,12 +42,24 @@ struct BatchParams {
   // replay-free path: summarize writes each chunk's ZERO-START sums, correct_kernel
   // adds the chunk_update corrections and raises need_exact[b] for suspicious problems
   double* part;    // [B][nchunk][2]  (sum log D, sum x^2/D)
+  double* cond;    // [B][nchunk][3]  conditioning record, may be null: max a_n / D0_n of the chunk's
+                   //                 zero-start pivots (summarize), certificate pivot mu (correct), and
+                   //                 the replay's end state against the scanned start of the next chunk
+                   //                 (relative residual; replay_kernel)
   int* flags;      // [B][nchunk]     zero-start pivot <= 0 seen / chunk suspicious
-  int* need_exact; // [B]             problem must be settled by the exact replay
+  int* need_exact; // [B]             0 settled from the chunk summaries; 1 ill-conditioned: chunked replay
+                   //                 with its end states checked against the scanned starts; >= 2
+                   //                 (certificate failed / that check failed): sequential recurrence
   // exact path (replay): only for problems with need_exact, or all if force_exact
   double* partx;   // [B][nchunk][2]
   int* flagsx;     // [B][nchunk]     D_n < 0 (n >= 1) seen: cholesky.h:176
   int force_exact; // materialising runs and clr_batch_set_exact(h, 1)
+  int seq_only;       // wide path: this launch only walks the problems with need_exact != 0 (one chunk = all N)
+  int logdet_only;    // no right-hand side (CholeskySolver.compute): the quadratic form is not checked
+  double cert_gamma;  // a problem whose conditioning record gamma_max / mu_min reaches this leaves the
+                      // replay-free route (decide_kernel); <= 0: never
+  double cert_resid;  // largest relative mismatch between a replayed chunk's end state and the scanned
+                      // start state of the next chunk that still counts as consistent
   double *out_ll, *out_logdet, *out_quad;
   int* out_status;
   // factor, only for materialising runs (replay mode 1: reference storage per
@@ -178,18 +190,19 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
   const long slot = (long)b * P.nchunk + (store ? c : 0);
-  double ld0 = 0.0, q0 = 0.0;
+  double ld0 = 0.0, q0 = 0.0, gamma = 0.0;
   int flag0 = 0;
   if (STAGED) {
     StagedSeries src = make_staged(P, b, c, tiles);
     summarize_chunk<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, P.elems + slot * Wd::ELEM, &ld0,
-                                  &q0, &flag0);
+                                  &q0, &flag0, &gamma);
   } else {
     DirectSeries src = make_direct(P, b, c);
     summarize_chunk<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, P.elems + slot * Wd::ELEM, &ld0,
-                                  &q0, &flag0);
+                                  &q0, &flag0, &gamma);
   }
   if (!store) return;
+  if (P.cond) { P.cond[slot * 3 + 0] = gamma; P.cond[slot * 3 + 1] = 1.0; P.cond[slot * 3 + 2] = 0.0; }
   P.part[slot * 2 + 0] = ld0;
   P.part[slot * 2 + 1] = q0;
   P.flags[slot] = flag0;  // (correct_kernel raises need_exact[b] from it)
@@ -445,7 +458,7 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   const long slot = (long)blockIdx.x * 64 + threadIdx.x;
   if (slot >= (long)P.B * P.nchunk) return;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
-  if (P.flags[slot]) atomicOr(P.need_exact + b, 1);  // a zero-start pivot <= 0 (summarize)
+  if (P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
   if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
   double S[SZ], f[J];
   const double* st = P.starts + slot * START;
@@ -455,13 +468,15 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   for (int i = 0; i < J; ++i) f[i] = st[SZ + i];
   double dld = 0.0, dq = 0.0;
   int sus = 0;
+  double mu = 1.0;
   chunk_update<J>(P.elems + slot * ELEM, S, f, true, false, P.part[slot * 2 + 0], P.part[slot * 2 + 1],
-                  &dld, &dq, &sus);
+                  &dld, &dq, &sus, &mu, !P.logdet_only);
+  if (P.cond) P.cond[slot * 3 + 1] = mu;
   P.part[slot * 2 + 0] += dld;
   P.part[slot * 2 + 1] += dq;
   if (sus) {
     P.flags[slot] |= 2;
-    atomicOr(P.need_exact + b, 1);
+    atomicOr(P.need_exact + b, 2);
   }
 }
 
@@ -471,7 +486,9 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   constexpr int J = Wd::J;
   __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
-  if (!P.force_exact && P.need_exact[b] == 0) return;  // settled by the replay-free path
+  // forced-exact / materialising runs replay everything; otherwise only the problems decide_kernel
+  // marked ill-conditioned (level 1; level >= 2 goes straight to sequential_kernel)
+  if (!P.force_exact && P.need_exact[b] != 1) return;
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool mine = c < P.nchunk;
   if (!STAGED && !mine) return;
@@ -498,19 +515,118 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
     W_o = P.W + (long)b * J * cells + cc;
     D_o = P.D + (long)b * cells + cc;
   }
+  double endst[Wd::START];
   if (STAGED) {
     StagedSeries src = make_staged(P, b, c, tiles);
     replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
-                                            W_o, D_o, fstride);
+                                            W_o, D_o, fstride, endst);
   } else {
     DirectSeries src = make_direct(P, b, c);
     replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
-                                            W_o, D_o, fstride);
+                                            W_o, D_o, fstride, endst);
   }
   if (!mine) return;
+  if (P.cond) {
+    // the recurrence carried this chunk from the scanned start state of chunk c to sample (c+1) L:
+    // how far is that from the scanned start state of chunk c+1?  (Both are the same quantity; the
+    // difference is the rounding inconsistency of the scan algebra, measured, not estimated.)
+    double res = 0.0;
+    if (c + 1 < P.nchunk) {
+      const double* nx = P.starts + ((long)b * P.nchunk + c + 1) * Wd::START;
+      double pmax = 0.0, fmaxv = 0.0, dp = 0.0, df = 0.0;
+#pragma unroll
+      for (int i = 0; i < Wd::SZ; ++i) { pmax = fmax(pmax, fabs(nx[i])); dp = fmax(dp, fabs(nx[i] - endst[i])); }
+#pragma unroll
+      for (int i = 0; i < J; ++i) { fmaxv = fmax(fmaxv, fabs(nx[Wd::SZ + i])); df = fmax(df, fabs(nx[Wd::SZ + i] - endst[Wd::SZ + i])); }
+      res = dp / pmax;  // (0/0 = NaN counts as inconsistent)
+      if (!P.logdet_only && fmaxv > 0.0) res = fmax(res, df / fmaxv);
+      if (!(pmax > 0.0)) res = (dp == 0.0) ? 0.0 : INFINITY;
+    }
+    P.cond[((long)b * P.nchunk + c) * 3 + 2] = res;
+  }
   P.partx[((long)b * P.nchunk + c) * 2 + 0] = ld;
   P.partx[((long)b * P.nchunk + c) * 2 + 1] = qd;
   P.flagsx[(long)b * P.nchunk + c] = flag;
+}
+
+// decide: after correct_kernel, one lane per problem: a problem the certificate did not flag but
+// whose conditioning record gamma_max / mu_min reaches cert_gamma leaves the replay-free route
+// (level 1: chunked replay + end-state check).
+template <int J>
+__global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B || !P.cond || !(P.cert_gamma > 0.0) || P.need_exact[b] != 0) return;
+  double g = 0.0, m = 1.0;
+  for (int c = 0; c < P.nchunk; ++c) {
+    const double gc = P.cond[((long)b * P.nchunk + c) * 3], mc = P.cond[((long)b * P.nchunk + c) * 3 + 1];
+    if (!(gc <= g)) g = gc;
+    if (!(mc >= m)) m = mc;
+  }
+  if (!(g < P.cert_gamma * m)) P.need_exact[b] = 1;  // (NaN records count as ill-conditioned)
+}
+
+// ---------------------------------------------------------------------------
+// sequential: the reference recurrence, truly sequential -- one lane per problem walks its
+// chunks in order and carries the state in registers, so nothing depends on the scanned
+// start states.  It settles (a) problems with a chunk the certificate could not settle
+// (need_exact raised by correct_kernel) and (b) problems whose conditioning record says the
+// scanned start states cannot be trusted to 1e-10: gamma_max / mu_min >= cert_gamma, where
+// gamma = a_n / D_n measures the cancellation in the pivots and 1 / mu the conditioning of
+// the chunk corrections (calibrated on tests/_cases.adversarial, profiles/r02k_adv_probe.txt:
+// below 1e6 the scan stays within 2.8e-11 of the oracle, above it reaches 1e-6).  The chunked
+// replay from scanned starts inherits their error: it is only used to write the
+// factor of well-conditioned problems; a flagged problem's factor columns are rewritten here.
+// Outputs are per-chunk partials in partx / flagsx exactly like replay_kernel's.
+// ---------------------------------------------------------------------------
+template <int JR, int JC, int MATERIALIZE, bool FAST>
+__global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
+  using Wd = Widths<JR, JC>;
+  constexpr int J = Wd::J;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B) return;
+  int level = P.need_exact[b];
+  if (level < 2 && (level == 1 || P.force_exact) && P.cond) {
+    // the chunked replay ran for this problem: trust it iff every chunk's end state met the scanned
+    // start state of the next chunk
+    double r = 0.0;
+    for (int c = 0; c < P.nchunk; ++c) {
+      const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
+      if (!(rc <= r)) r = rc;
+    }
+    if (!(r <= P.cert_resid)) level = 2;
+  }
+  if (level < 2) return;
+  P.need_exact[b] = 2;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  double state[Wd::START];
+  const long Nm1 = P.N - 1;
+  for (int c = 0; c < P.nchunk; ++c) {
+    DirectSeries src = make_direct(P, b, c);
+    double ld, qd;
+    int flag;
+    double *phi_o = nullptr, *u_o = nullptr, *W_o = nullptr, *D_o = nullptr;
+    long fstride = 0;
+    if (MATERIALIZE == 1) {
+      phi_o = P.phi + (long)b * J * Nm1;
+      u_o = P.u + (long)b * J * Nm1;
+      W_o = P.W + (long)b * J * P.N;
+      D_o = P.D + (long)b * P.N;
+    } else if (MATERIALIZE == 2) {
+      const long cells = (long)P.L * P.nchunk;
+      fstride = P.nchunk;
+      phi_o = P.phi + (long)b * J * cells + c;
+      u_o = P.u + (long)b * J * cells + c;
+      W_o = P.W + (long)b * J * cells + c;
+      D_o = P.D + (long)b * cells + c;
+    }
+    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, c * P.L, c > 0 ? state : nullptr, &ld, &qd, &flag,
+                                            phi_o, u_o, W_o, D_o, fstride, state);
+    const long slot = (long)b * P.nchunk + c;
+    P.partx[slot * 2 + 0] = ld;
+    P.partx[slot * 2 + 1] = qd;
+    P.flagsx[slot] = flag;
+  }
 }
 
 // One table entry per (JR, JC): host-callable launchers.
@@ -519,6 +635,7 @@ struct BatchLaunchers {
   void (*prefix)(const BatchParams&, hipStream_t);
   void (*correct)(const BatchParams&, hipStream_t);
   void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
+  void (*sequential)(const BatchParams&, int materialize, hipStream_t);
   int elem_doubles, start_doubles;
 };
 
@@ -545,6 +662,7 @@ struct BatchImpl {
     const long lanes = (long)P.B * P.nchunk;
     hipLaunchKernelGGL((correct_kernel<JR + 2 * JC>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s,
                        P);
+    hipLaunchKernelGGL((decide_kernel<JR + 2 * JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
   }
   static void replay(const BatchParams& P, int materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
@@ -556,8 +674,17 @@ struct BatchImpl {
 #undef CLR_GO2
 #undef CLR_GO
   }
+  static void sequential(const BatchParams& P, int materialize, hipStream_t s) {
+    if (P.nchunk < 2) return;  // (one chunk: the replay from the zero state IS the recurrence)
+    dim3 grid((P.B + 63) / 64);
+#define CLR_GO(M, F) hipLaunchKernelGGL((sequential_kernel<JR, JC, M, F>), grid, dim3(64), 0, s, P)
+#define CLR_GO2(M) if (P.fast_trig) CLR_GO(M, true); else CLR_GO(M, false);
+    if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
+#undef CLR_GO2
+#undef CLR_GO
+  }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &correct, &replay, Widths<JR, JC>::ELEM,
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, Widths<JR, JC>::ELEM,
                           Widths<JR, JC>::START};
   }
 };
@@ -567,6 +694,8 @@ struct BatchImpl {
 bool launch_summarize_split(const BatchParams& P, int JR, int JC, hipStream_t s);
 bool have_summarize_split(int JR, int JC);
 
+// decide_kernel at the padded widths of the wide scan
+void launch_wide_decide(const BatchParams& P, hipStream_t s);
 // Per-problem reduction of the chunk partials + the -inf rules (api.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
 // One problem's interleaved factor -> the reference's storage (api.hip).

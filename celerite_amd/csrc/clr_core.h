@@ -305,7 +305,8 @@ CLR_HD void decay_rank1_update(const double* phid, const double* z, const double
 // ---------------------------------------------------------------------------
 template <int JR, int JC, bool FAST, class Src>
 CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, int N, bool store,
-                            double* elem_out, double* ld0_out, double* q0_out, int* flag0_out) {
+                            double* elem_out, double* ld0_out, double* q0_out, int* flag0_out,
+                            double* gamma_out = nullptr) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   // State: 152 doubles at J = 8, more than the 128 that 256 VGPRs hold; the compiler
@@ -332,6 +333,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
   // because the last chunk's element is never applied.
   const int len = L;
   double q0 = 0.0;
+  double gamma = 0.0;  // max a_n / D_n of the zero-start pivots: the cancellation in D = a - u.Pu
   LogProduct lp0;
   lp0.init();
   int flag0 = 0;
@@ -374,6 +376,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
       if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
       lp0.mul(D);
       q0 += x * x * invD;
+      gamma = fmax(gamma, fabs(p.diagonal(diag_cur) * invD));
     }
     const double xs = x * invD;
 
@@ -415,6 +418,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
   *ld0_out = lp0.log_value();
   *q0_out = q0;
   *flag0_out = flag0;
+  if (gamma_out) *gamma_out = gamma;
 
   double* o = elem_out;  // A is written row-major
   CLR_UNROLL
@@ -542,7 +546,7 @@ CLR_HD double pd_certificate(const double* P /*[SZ]*/, const double* Jm /*[SZ]*/
 template <int J>
 CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]*/, bool correct,
                          bool advance, double ld0, double q0, double* dld, double* dq,
-                         int* suspicious) {
+                         int* suspicious, double* mu_out = nullptr, bool check_quad = true) {
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int NC = 2 * J + 1;  // [ M^T | P | h ]
   const double* A = elem;
@@ -608,6 +612,7 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
   if (correct) {
     int bad = 0;
     const double mu = pd_certificate<J>(P, Jm);
+    if (mu_out) *mu_out = mu;
     if (!(mu > 1e-5)) bad = 1;
     if (!(det > 0.0)) bad = 1;
     double w[J];
@@ -633,8 +638,8 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
     const double ld = log(det);
     const double err = J * 2.2e-16 / mu;  // rounding-error estimate of the corrections
     if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
-    if (!(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
-    if (!isfinite(q) || !isfinite(ld)) bad = 1;
+    if (check_quad && !(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
+    if ((check_quad && !isfinite(q)) || !isfinite(ld)) bad = 1;
     *dld = ld;
     *dq = q;
     *suspicious = bad;
@@ -683,7 +688,8 @@ template <int JR, int JC, int MATERIALIZE, bool FAST, class Src>
 CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0,
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
-                         double* phi_o, double* u_o, double* W_o, double* D_o, long fstride) {
+                         double* phi_o, double* u_o, double* W_o, double* D_o, long fstride,
+                         double* end_out = nullptr /* state after the chunk: P[SZ] f[J] */) {
   // MATERIALIZE: 0 = nothing is stored; 1 = the reference's storage (cholesky.h:76-78,
   // :703-706: phi[:, n], u[:, n-1], W[:, n], D[n] with element (j, n) at [j + J n];
   // pointers are the problem's arrays); 2 = chunk-interleaved device layout: the
@@ -794,6 +800,12 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
   *logdet_out = lp.log_value();
   *quad_out = quad;
   *flag_out = flag;
+  if (end_out) {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) end_out[i] = P[i];
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) end_out[SZ + i] = f[i];
+  }
 }
 
 // -0.5 (quad + logdet + N log 2 pi) with the -inf rules of

@@ -293,6 +293,7 @@ summarize_split_kernel(const BatchParams P) {
     int flag0 = 0;
     split_trajectory<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, slot, elem, &ld0, &q0, &flag0, P.split);
     if (store) {
+      if (P.cond) { P.cond[cell * 3 + 0] = 0.0; P.cond[cell * 3 + 1] = 1.0; P.cond[cell * 3 + 2] = 0.0; }
       P.part[cell * 2 + 0] = ld0;
       P.part[cell * 2 + 1] = q0;
       P.flags[cell] = flag0;

@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   const double* yp = P.y + b * P.y_stride;
   const int N = P.N;
   if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] == 0) return;  // settled without replay
+  if (MODE == 0 && P.seq_only && P.need_exact[b] == 0) return;  // sequential pass: flagged problems only
   const int n_lo = chunk * P.L;
   const int n_hi = (n_lo + P.L < N) ? n_lo + P.L : N;
   const long slot = (long)b * P.nchunk + chunk;
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   LogProduct lp;
   lp.init();
   int flag = 0;
+  double gam = 0.0;  // summarize: max a_n / D_n of the zero-start pivots (conditioning record)
 
   // 64-sample register tiles of the series (one coalesced 512-B load per array),
   // handed out with v_readlane; t needs two samples of look-ahead
@@ -196,6 +198,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
       lp.mul(D);
       quad += x * x * invD;
+      if (MODE == 1) gam = fmax(gam, fabs(((((diag_n + sum_ar) + sum_ac) + jitter)) * invD));
 
       const double z = v - q;
       const double w = z * invD;
@@ -253,6 +256,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       P.part[slot * 2 + 0] = lp.log_value();
       P.part[slot * 2 + 1] = quad;
       P.flags[slot] = flag;
+      if (P.cond) { P.cond[slot * 3 + 0] = gam; P.cond[slot * 3 + 1] = 1.0; P.cond[slot * 3 + 2] = 0.0; }
     }
     return;
   }
@@ -299,7 +303,7 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   const int lane = threadIdx.x;
   const long slot = blockIdx.x;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
-  if (lane == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 1);  // a zero-start pivot <= 0 (summarize)
+  if (lane == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
   if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
   const double* st = P.starts + slot * START;
   const double* E = P.elems + slot * ELEM;
@@ -454,9 +458,10 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     if (!isfinite(q) || !isfinite(ld)) bad = 1;
     P.part[slot * 2 + 0] = ld0 + ld;
     P.part[slot * 2 + 1] = q0 + q;
+    if (P.cond) P.cond[slot * 3 + 1] = mu;
     if (bad) {
       P.flags[slot] |= 2;
-      atomicOr(P.need_exact + b, 1);
+      atomicOr(P.need_exact + b, 2);
     }
   }
 }
@@ -501,6 +506,11 @@ void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) 
   const dim3 grid((unsigned)((long)P.B * P.nchunk));
   if (width_padded <= 16) hipLaunchKernelGGL((wide_correct_kernel<16>), grid, dim3(64), 0, s, P);
   else hipLaunchKernelGGL((wide_correct_kernel<32>), grid, dim3(64), 0, s, P);
+  launch_wide_decide(P, s);
+}
+
+void launch_wide_decide(const BatchParams& P, hipStream_t s) {
+  hipLaunchKernelGGL((decide_kernel<32>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
 }
 
 // one chunk: the whole recurrence, results written directly; several chunks: the replay phase

@@ -238,6 +238,26 @@ int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
 int clr_batch_set_exact(clr_batch* h, int force);
 /* After a synchronised run: how many problems went through the exact replay. */
 int clr_batch_get_exact_count(clr_batch* h, int* count);
+/* ... and how: level[p] = 0 settled from the chunk summaries (no second pass); 1 = the
+ * conditioning record was above the bound, the chunked replay ran and every chunk's end state
+ * met the scanned start state of the next chunk; 2 = settled by the truly sequential recurrence
+ * (certificate failed, or the replay's end states did not meet the scanned ones).  On forced
+ * exact / single-chunk runs every problem is at least 1. */
+int clr_batch_get_exact_flags(clr_batch* h, int* level /* [B] */);
+/* Conditioning record of the last run (widths 1..8), per problem: gamma_max = the largest
+ * a_n / D_n over the zero-start pivots of its chunks (the cancellation in D_n = a_n - u.Su,
+ * cholesky.h:162-175), mu_min = the smallest pivot of the chunk certificates (1 = the start
+ * state does not eat into the chunk's pivots), resid_max = (after a replay) the largest
+ * relative mismatch between a replayed chunk's end state and the scanned start state of the
+ * next chunk.  Any pointer may be NULL. */
+int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max);
+/* Routing of ill-conditioned problems.  A problem whose gamma_max / mu_min reaches
+ * max_gamma_over_mu (default 1e6; <= 0: never) is not settled from the chunk summaries: the
+ * chunked replay (the reference recurrence from the scanned start states, parallel over chunks)
+ * runs for it and its end states are compared with the scanned start states; a mismatch above
+ * max_residual (default 1e-11, relative) sends it to the truly sequential recurrence (one lane
+ * walks the whole series; slow, exact).  Calibration: profiles/r02n_adv_probe.txt. */
+int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual);
 /* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);

@@ -16,6 +16,8 @@ from _cases import adversarial, coeffs_of, ALL_WIDTH_SHAPES  # noqa: E402
 
 n_total = n_exact = n_bad = mism = 0
 worst_ok = 0.0
+n_level = [0, 0, 0]
+worst_level = [0.0, 0.0, 0.0]
 WIDE = [(9, 0), (1, 4), (3, 5), (16, 0), (0, 8), (2, 9), (0, 16), (6, 13), (32, 0)]
 SHAPES = ALL_WIDTH_SHAPES + WIDE + WIDE   # narrow scan (widths 1..8) and wide scan (9..32)
 for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
@@ -35,9 +37,15 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
         if not np.array_equal(st, s0):
             mism += 1
             print("STATUS MISMATCH trial", trial, JR, JC, N, nchunk, st, s0, flush=True)
-        ok = (s0 == 0) & (st == 0) & np.isfinite(d0) & np.isfinite(q0) & (plan.exact_count() == 0)
-        if ok.any():
-            worst_ok = max(worst_ok, np.max(np.abs(ld[ok] - d0[ok]) / (1 + np.abs(d0[ok]))))
+        levels = plan.exact_levels() if JR + 2 * JC <= 8 else np.where(plan.exact_flags(), 2, 0)
+        for p in range(4):
+            if s0[p] != 0 or st[p] != 0 or not (np.isfinite(d0[p]) and np.isfinite(q0[p])):
+                continue
+            dev = max(abs(ld[p] - d0[p]) / abs(d0[p]), abs(q[p] - q0[p]) / abs(q0[p]))
+            n_level[levels[p]] += 1
+            worst_level[levels[p]] = max(worst_level[levels[p]], dev)
     plan.close()
-print("problem x chunking combinations %d, settled without replay %d, indefinite problems %d, status mismatches %d, "
-      "worst log-det deviation on replay-free batches %.2e" % (n_total, n_total - n_exact, n_bad, mism, worst_ok), flush=True)
+print("problem x chunking combinations %d, indefinite problems %d, status mismatches %d" % (n_total, n_bad, mism))
+print("positive definite problems by route: settled from the chunk summaries %d (worst deviation from the oracle, log-det or "
+      "quadratic form, relative: %.2e); checked chunked replay %d (%.2e); sequential recurrence %d (%.2e)"
+      % (n_level[0], worst_level[0], n_level[1], worst_level[1], n_level[2], worst_level[2]), flush=True)
