@@ -1265,9 +1265,10 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
 }
 
 // wide path.  One chunk: the sequential sweep (one wave per problem).  Several chunks: summarize ->
-// prefix -> correct (+ conditioning decision) -> finalize from the chunk summaries; forced-exact runs
-// also replay every chunk from its scanned start state.  Problems the certificate or the
-// conditioning record flagged are then walked by the sequential sweep itself (one wave per flagged
+// prefix -> correct (+ conditioning decision) -> finalize from the chunk summaries.  Forced-exact runs
+// and the problems whose conditioning record is above the bound replay every chunk from its scanned
+// start state and check the end states against the scan.  Problems the certificate flagged, or whose
+// replay did not meet the scan, are then walked by the sequential sweep itself (one wave per such
 // problem over all N samples), which overwrites their results: nothing of theirs depends on the scan.
 static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
@@ -1279,8 +1280,11 @@ static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
   mark(3);
   clr::launch_wide_correct(P, JP, h->stream);
   mark(4);
-  if (P.nchunk < 2 || P.force_exact) clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+  // one chunk: the sweep itself; several: the chunked replay of forced runs and of the problems the
+  // conditioning record marked (level 1), with its end states checked against the scan
+  clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
   if (P.nchunk > 1) {
+    clr::launch_wide_check_replay(P, h->stream);
     clr::launch_finalize(P, h->stream);
     clr::BatchParams S = P;  // the flagged problems, sequentially
     S.nchunk = 1; S.L = P.N; S.seq_only = 1; S.force_exact = 1;

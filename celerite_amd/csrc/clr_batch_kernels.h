@@ -696,6 +696,7 @@ bool have_summarize_split(int JR, int JC);
 
 // decide_kernel at the padded widths of the wide scan
 void launch_wide_decide(const BatchParams& P, hipStream_t s);
+void launch_wide_check_replay(const BatchParams& P, hipStream_t s);
 // Per-problem reduction of the chunk partials + the -inf rules (api.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
 // One problem's interleaved factor -> the reference's storage (api.hip).

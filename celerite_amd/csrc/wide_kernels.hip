@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   const double* dp = P.diag + b * P.diag_stride;
   const double* yp = P.y + b * P.y_stride;
   const int N = P.N;
-  if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] == 0) return;  // settled without replay
-  if (MODE == 0 && P.seq_only && P.need_exact[b] == 0) return;  // sequential pass: flagged problems only
+  // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
+  if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] != 1) return;
+  if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
   const int n_lo = chunk * P.L;
   const int n_hi = (n_lo + P.L < N) ? n_lo + P.L : N;
   const long slot = (long)b * P.nchunk + chunk;
@@ -259,6 +260,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       if (P.cond) { P.cond[slot * 3 + 0] = gam; P.cond[slot * 3 + 1] = 1.0; P.cond[slot * 3 + 2] = 0.0; }
     }
     return;
+  }
+  if (MODE == 0 && P.nchunk > 1 && P.cond) {
+    // end state of this chunk against the scanned start state of the next one (as replay_kernel)
+    double dp = 0.0, pm = 0.0, df = 0.0, fm = 0.0;
+    if (chunk + 1 < P.nchunk) {
+      const double* nx = P.starts + (slot + 1) * START;
+#pragma unroll
+      for (int c = 0; c < COLS; ++c) {
+        const double ref = nx[sym(row, seg * COLS + c)];
+        pm = fmax(pm, fabs(ref));
+        dp = fmax(dp, fabs(ref - S[c]));
+      }
+      fm = fabs(nx[SZ + row]);
+      df = fabs(nx[SZ + row] - f);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      dp = fmax(dp, __shfl_xor(dp, m, 64)); pm = fmax(pm, __shfl_xor(pm, m, 64));
+      df = fmax(df, __shfl_xor(df, m, 64)); fm = fmax(fm, __shfl_xor(fm, m, 64));
+    }
+    if (lane == 0) {
+      double res = (pm > 0.0) ? dp / pm : (dp == 0.0 ? 0.0 : INFINITY);
+      if (fm > 0.0) res = fmax(res, df / fm);
+      P.cond[slot * 3 + 2] = (chunk + 1 < P.nchunk) ? res : 0.0;
+    }
   }
   if (lane == 0) {
     const double ld = lp.log_value();
@@ -511,6 +537,24 @@ void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) 
 
 void launch_wide_decide(const BatchParams& P, hipStream_t s) {
   hipLaunchKernelGGL((decide_kernel<32>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+}
+
+// after the chunked replay: a replayed problem whose chunks did not meet the scanned start states
+// goes to the sequential sweep (level 2)
+__global__ void __launch_bounds__(64) wide_check_replay_kernel(const BatchParams P) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B || !P.cond) return;
+  const int level = P.need_exact[b];
+  if (level >= 2 || !(level == 1 || P.force_exact)) return;
+  double r = 0.0;
+  for (int c = 0; c < P.nchunk; ++c) {
+    const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
+    if (!(rc <= r)) r = rc;
+  }
+  if (!(r <= P.cert_resid)) P.need_exact[b] = 2;
+}
+void launch_wide_check_replay(const BatchParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(wide_check_replay_kernel, dim3((P.B + 63) / 64), dim3(64), 0, s, P);
 }
 
 // one chunk: the whole recurrence, results written directly; several chunks: the replay phase

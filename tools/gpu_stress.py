@@ -19,7 +19,7 @@ worst_ok = 0.0
 n_level = [0, 0, 0]
 worst_level = [0.0, 0.0, 0.0]
 WIDE = [(9, 0), (1, 4), (3, 5), (16, 0), (0, 8), (2, 9), (0, 16), (6, 13), (32, 0)]
-SHAPES = ALL_WIDTH_SHAPES + WIDE + WIDE   # narrow scan (widths 1..8) and wide scan (9..32)
+SHAPES = (WIDE if os.environ.get("WIDE_ONLY") else ALL_WIDTH_SHAPES + WIDE + WIDE)   # narrow scan (widths 1..8) and wide scan (9..32)
 for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
     JR, JC = SHAPES[trial % len(SHAPES)]
     N = (50, 200, 1000, 3000)[trial % 4]
@@ -29,6 +29,8 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 600):
     plan = batch.BatchedGP(4, N, JR, JC)
     plan.set_series(case["t"], case["diag"], case["y"])
     plan.set_coefficients(*coeffs_of(case))
+    if os.environ.get("CERT"):
+        plan.set_certificate(float(os.environ["CERT"]), 1e-11)
     for nchunk in (max(2, N // 40), max(2, N // 8)):
         plan.set_chunks(nchunk)
         ll, ld, q, st = plan.log_likelihood()
