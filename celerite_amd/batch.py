@@ -55,6 +55,7 @@ def _load():
     lib.clr_batch_set_layout.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_summarize_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_get_summarize_kernel.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
@@ -72,6 +73,7 @@ def _load():
     lib.clr_sharded_get_shard.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
     lib.clr_sharded_set_chunks.argtypes = [C.c_void_p, C.c_int]
     lib.clr_sharded_get_chunks.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
+    lib.clr_sharded_set_summarize_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_sharded_set_series.argtypes = [C.c_void_p, _dp, C.c_long, _dp, C.c_long, _dp, C.c_long]
     lib.clr_sharded_set_coefficients.argtypes = [C.c_void_p] + [_dp] * 7
     lib.clr_sharded_enqueue.argtypes = [C.c_void_p]
@@ -277,10 +279,16 @@ class BatchedGP(object):
         return g, m
 
     def set_summarize_mode(self, mode=-1):
-        """summarize kernel of widths 7, 8: -1 / 1 = two roles on two waves per SIMD
-        (default; reads a chunk-interleaved copy of the series), 0 = the single-wave
-        kernel (csrc/clr_split_kernels.h; for A/B measurements)."""
+        """summarize kernel of widths 7, 8: 0 single wave, 1 two roles on two waves per
+        SIMD, 2 the same with the decay factored out of the state on dense series, -1 auto
+        (``clr_batch_set_summarize_mode``; csrc/clr_split_kernels.h)."""
         _check(_load().clr_batch_set_summarize_mode(self._h, int(mode)))
+
+    def summarize_kernel(self):
+        """Name of the summarize kernel the next evaluation runs."""
+        k = C.c_int()
+        _check(_load().clr_batch_get_summarize_kernel(self._h, C.byref(k)))
+        return ("single wave", "role split", "role split, lazy decay")[k.value]
 
     def set_library_trig(self, force=True):
         """Use the library (ocml) sincos instead of the FMA Cody-Waite routine
@@ -369,6 +377,9 @@ class ShardedBatchedGP(object):
 
     def set_chunks(self, nchunk):
         self._ok(_load().clr_sharded_set_chunks(self._h, int(nchunk)))
+
+    def set_summarize_mode(self, mode=-1):
+        self._ok(_load().clr_sharded_set_summarize_mode(self._h, int(mode)))
 
     def set_series(self, t, diag, y):
         arrs, strides = [], []

@@ -278,6 +278,7 @@ struct clr_batch {
   long t_stride = 0, diag_stride = 0, y_stride = 0;
   int layout = 2;                     // 0 row-major direct, 1 interleaved copy, 2 staged through LDS
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
+  double dxmax = 0.0, cmax = 0.0;     // max |t[n+1] - t[n]|, max decay rate: the lazy-decay kernels need cmax * dxmax < 2^-7
   int force_library_trig = 0;
   int coop_prefix = 1;
   double cert_resid = 1e-11;          // end-state mismatch of the chunked replay that still counts as consistent
@@ -1041,6 +1042,14 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
       return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
   h->tmax = max_abs(t, (long)count(t_stride));  // every sample (sortedness is not assumed)
+  h->dxmax = 0.0;
+  for (long b = 0; b < (t_stride == 0 ? 1 : (long)h->B); ++b) {
+    const double* tb = t + b * t_stride;
+    for (long n = 0; n + 1 < N; ++n) {
+      const double d = fabs(tb[n + 1] - tb[n]);
+      if (!(d <= h->dxmax)) h->dxmax = d;
+    }
+  }
   if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
@@ -1073,9 +1082,15 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   if (st != CLR_OK) return st;
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   h->dmax = 0.0;
+  h->cmax = 0.0;
   for (size_t i = 0; i < nc; ++i) {
-    const double m = fabs(d_comp[i]);
+    const double m = fabs(d_comp[i]), c = fabs(c_comp[i]);
     if (!(m <= h->dmax)) h->dmax = m;
+    if (!(c <= h->cmax)) h->cmax = c;
+  }
+  for (size_t i = 0; i < nr; ++i) {
+    const double c = fabs(c_real[i]);
+    if (!(c <= h->cmax)) h->cmax = c;
   }
   // one pinned staging buffer, one copy: a_real c_real a_comp b_comp c_comp d_comp | jitter
   const size_t total = 2 * nr + 4 * nc + B;
@@ -1091,10 +1106,18 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   return CLR_OK;
 }
 
+static bool lazy_eligible(const clr_batch* h) {
+  // |c dx| < 2^-7 at every step: Psi stays within [0.88, 1] over the 16 steps between renormalisations
+  return h->have_series && h->have_coeffs && h->J_real + h->J_comp <= 6 && h->cmax * h->dxmax < 0.0078125;
+}
+
 static bool split_active(const clr_batch* h) {
-  // (auto = off: measured 5-7 % faster at width 8 with >= 2 complex terms, slower for real-only
-  //  kernels and at width 7 -- profiles/r02h_split_ab.txt)
-  return h->launch && h->nchunk > 1 && h->summarize_mode > 0 && clr::have_summarize_split(h->J_real, h->J_comp);
+  // explicit modes 1 / 2, or auto (-1): width 8 with at least two complex terms on a densely sampled
+  // series, where the split kernel with the decay factored out of the state (lazy) is the faster one
+  // (profiles/r02h_split_ab.txt, r02r_lazy_ab.txt); real-only kernels and width 7 stay single-wave
+  if (!(h->launch && h->nchunk > 1 && clr::have_summarize_split(h->J_real, h->J_comp))) return false;
+  if (h->summarize_mode > 0) return true;
+  return h->summarize_mode < 0 && h->J == 8 && h->J_comp >= 2 && lazy_eligible(h);
 }
 
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
@@ -1126,7 +1149,8 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   // role-split summarize (two waves per SIMD, clr_split_kernels.h) for the widths whose element
   // does not fit one wave's registers; it reads the chunk-interleaved copy of the series
   const bool split = split_active(h);
-  P.split = split ? (h->summarize_mode > 1 ? h->summarize_mode : 1) : 0;
+  P.split = split ? 1 : 0;
+  P.split_lazy = (split && h->summarize_mode != 1 && lazy_eligible(h)) ? 1 : 0;
   if (h->launch && (h->layout == 1 || split) && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
@@ -1161,15 +1185,18 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   return CLR_OK;
 }
 
-// Row-major API layout -> chunk-interleaved layout (3 tiled transposes).
-static void batch_relayout(clr_batch* h) {
-  if (!((h->layout == 1 || split_active(h)) && h->nchunk > 1)) return;
+// Row-major API layout -> chunk-interleaved layout (3 tiled transposes).  Returns whether the copy
+// was (re)built: `relayout_pending` may only be cleared then -- the need for the copy can appear later
+// (a new coefficient draw can switch the summarize kernel) with the series unchanged.
+static bool batch_relayout(clr_batch* h) {
+  if (!((h->layout == 1 || split_active(h)) && h->nchunk > 1)) return false;
   const long cells = (long)h->nchunk * h->L;
   struct { DevBuf* src; DevBuf* dst; long stride; } jobs[3] = {
       {&h->t, &h->tT, h->t_stride}, {&h->diag, &h->dT, h->diag_stride}, {&h->y, &h->yT, h->y_stride}};
   for (auto& j : jobs)
     clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
                          h->N, h->L, h->nchunk, h->stream);
+  return true;
 }
 
 int clr_batch_set_exact(clr_batch* h, int force) {
@@ -1246,9 +1273,15 @@ int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
 }
 
 int clr_batch_set_summarize_mode(clr_batch* h, int mode) {
-  if (mode < -1 || mode > 7) return fail(CLR_INVALID_ARGUMENT, "summarize mode must be -1, 0 or 1");
+  if (mode < -1 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "summarize mode must be -1, 0, 1 or 2");
   if (mode != h->summarize_mode) h->relayout_pending = true;
   h->summarize_mode = mode;
+  return CLR_OK;
+}
+
+int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
+  if (!kind) return fail(CLR_INVALID_ARGUMENT, "kind is null");
+  *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
   return CLR_OK;
 }
 
@@ -1347,10 +1380,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     return CLR_OK;
   }
   mark(0);
-  if (h->relayout_pending) {
-    batch_relayout(h);
-    h->relayout_pending = false;
-  }
+  if (h->relayout_pending && batch_relayout(h)) h->relayout_pending = false;
   mark(1);
   h->launch->summarize(P, h->stream);
   mark(2);
@@ -1421,10 +1451,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
-  if (h->relayout_pending && !relayout_each_step) {
-    batch_relayout(h);
-    h->relayout_pending = false;
-  }
+  if (h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
   // one event per kernel boundary per step, all recorded on the handle's stream
   const int NK = 6;
   std::vector<hipEvent_t> ev((size_t)steps * (NK + 1));
@@ -1450,7 +1477,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     clr::launch_finalize(P, h->stream);
     HIP_TRY(hipEventRecord(e[6], h->stream));
   }
-  if (relayout_each_step) h->relayout_pending = false;
+  if (relayout_each_step && (h->layout == 1 || split_active(h)) && h->nchunk > 1) h->relayout_pending = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   double k[NK] = {0, 0, 0, 0, 0, 0};

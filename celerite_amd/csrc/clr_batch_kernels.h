@@ -54,6 +54,7 @@ struct BatchParams {
   double* partx;   // [B][nchunk][2]
   int* flagsx;     // [B][nchunk]     D_n < 0 (n >= 1) seen: cholesky.h:176
   int force_exact; // materialising runs and clr_batch_set_exact(h, 1)
+  int split_lazy;     // role-split summarize with the decay factored out of the state (dense series only)
   int seq_only;       // wide path: this launch only walks the problems with need_exact != 0 (one chunk = all N)
   int logdet_only;    // no right-hand side (CholeskySolver.compute): the quadratic form is not checked
   double cert_gamma;  // a problem whose conditioning record gamma_max / mu_min reaches this leaves the

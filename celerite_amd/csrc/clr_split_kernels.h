@@ -79,11 +79,12 @@ template <int JR, int JC, bool FAST>
 __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, DirectSeries& src, int L, int n0,
                                                  int N, bool store, double* slot0 /* + lane */,
                                                  double* elem_out, double* ld0_out, double* q0_out,
-                                                 int* flag0_out, int dbg) {
+                                                 int* flag0_out, double* gamma_out, int dbg) {
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   using Lk = SplitLink<JR, JC>;
   constexpr int SLOT_STRIDE = Lk::NPAY * 64;
+  double gamma = 0.0;
   double b[J], C[SZ];
 #pragma unroll
   for (int i = 0; i < J; ++i) b[i] = 0.0;
@@ -139,6 +140,7 @@ __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, Direc
       if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
       lp0.mul(D);
       q0 += x * x * invD;
+      gamma = fmax(gamma, fabs(p.diagonal(diag_cur) * invD));
     }
     const double xs = x * invD;
     double z[J], W[J];
@@ -161,6 +163,7 @@ __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, Direc
   *ld0_out = lp0.log_value();
   *q0_out = q0;
   *flag0_out = flag0;
+  *gamma_out = gamma;
   double* o = elem_out + J * J;
 #pragma unroll
   for (int i = 0; i < J; ++i) o[i] = b[i];
@@ -248,13 +251,293 @@ __device__ __forceinline__ void split_riders(const Problem<JR, JC>& p, int L, in
   }
 }
 
-// 8 waves: 4 sets (problem b, block x of 64 chunks), one T and one R wave per set.
+// ---------------------------------------------------------------------------------------------------
+// LAZY decay (densely sampled series: max c * max dx < 2^-7, checked on the host).  The reference
+// multiplies S, f (and here A) by the decays of every step (cholesky.h:154-160: 3 flops per entry).
+// Factor the decay accumulated since the last renormalisation out of the state instead:
+//     C = Psi Cbar Psi ,  b = Psi bbar ,  A = Psi Abar ,      Psi = diag(prod phi)
+// Then with ubar = Psi u, vbar = Psi^-1 v:
+//     q = Psi qbar, qbar = Cbar ubar ;  D = a - ubar.qbar ;  zbar = vbar - qbar ;  Wbar = zbar / D
+//     x = y - ubar.bbar ;  r = Abar^T ubar ;  Abar -= Wbar r^T ;  Cbar += zbar Wbar^T ;  bbar += Wbar x
+// and Psi <- Phi Psi: one FMA per state entry instead of FMA + MUL, the rider wave no longer needs phi
+// or Phi W (18 published doubles instead of 21), ~110 fp64 instructions fewer per step of ~590.  Every
+// 16 steps (and at the end of the chunk) the state is multiplied out and Psi reset to 1, so Psi stays
+// within [0.88, 1] and Psi^-1 (accumulated beside it from exp(+c dx)) within [1, 1.14]: the scaling is
+// rounding-neutral, and the drift of Psi * Psi^-1 from 1 is bounded by 16 roundings.
+// ---------------------------------------------------------------------------------------------------
+template <int JR, int JC>
+struct SplitLinkLazy {
+  static constexpr int J = JR + 2 * JC;
+  static constexpr int F_U = 0, F_W = J, F_INVD = 2 * J, F_Y = 2 * J + 1, NPAY = 2 * J + 2;
+  static constexpr int M = JR + JC;  // distinct decays: one slot area of M doubles per lane for Psi
+  static constexpr int RENORM = 16;
+};
+
+// phi = exp(-c dx) and 1/phi = exp(+c dx) of the distinct decays, sharing the even / odd parts
+template <int JR, int JC>
+__device__ __forceinline__ void features_phi_pair(const Problem<JR, JC>& p, double dx, double* phid, double* phinv) {
+  constexpr int M = JR + JC;
+  double x[nz(M)];
+  double amax = 0.0;
+#pragma unroll
+  for (int j = 0; j < JR; ++j) { x[j] = -p.cr[j] * dx; amax = fmax(amax, fabs(x[j])); }
+#pragma unroll
+  for (int j = 0; j < JC; ++j) { x[JR + j] = -p.cc[j] * dx; amax = fmax(amax, fabs(x[JR + j])); }
+  if (CLR_WAVE_ALL(amax < 0.0009765625)) {  // 2^-10: even part to x^4, odd part to x^3 (next terms < 7.4e-18)
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const double x2 = x[j] * x[j];
+      const double ch = fma(x2, fma(x2, 1.0 / 24.0, 0.5), 1.0);
+      const double sh = x[j] * fma(x2, 1.0 / 6.0, 1.0);
+      phid[j] = ch + sh;
+      phinv[j] = ch - sh;
+    }
+  } else if (CLR_WAVE_ALL(amax < 0.0078125)) {  // 2^-7: to x^6 / x^5 (next term x^7/5040 < 3.5e-19)
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const double x2 = x[j] * x[j];
+      const double ch = fma(x2, fma(x2, fma(x2, 1.0 / 720.0, 1.0 / 24.0), 0.5), 1.0);
+      const double sh = x[j] * fma(x2, fma(x2, 1.0 / 120.0, 1.0 / 6.0), 1.0);
+      phid[j] = ch + sh;
+      phinv[j] = ch - sh;
+    }
+  } else {  // (the host only selects the lazy kernels for dense series; kept for safety)
+#pragma unroll
+    for (int j = 0; j < M; ++j) { phid[j] = exp(x[j]); phinv[j] = exp(-x[j]); }
+  }
+}
+
 template <int JR, int JC, bool FAST>
+__device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, DirectSeries& src, int L, int n0,
+                                                      int N, bool store, double* slot0 /* + lane */,
+                                                      double* psi_area /* + lane */, double* elem_out,
+                                                      double* ld0_out, int* flag0_out, double* gamma_out, int dbg) {
+  // (in the lazy variant the zero-start f-trajectory bbar, x and the quadratic sum live in the RIDER
+  //  wave: they need only ubar, Wbar, 1/D and y, and the registers they free here pay for Psi, Psi^-1)
+  constexpr int J = Widths<JR, JC>::J;
+  constexpr int SZ = Widths<JR, JC>::SZ;
+  using Lk = SplitLinkLazy<JR, JC>;
+  constexpr int M = Lk::M;
+  constexpr int SLOT_STRIDE = Lk::NPAY * 64;
+  double C[SZ], psi[nz(M)], psinv[nz(M)];
+#pragma unroll
+  for (int i = 0; i < SZ; ++i) C[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < M; ++i) { psi[i] = 1.0; psinv[i] = 1.0; }
+  double gamma = 0.0;
+  LogProduct lp0;
+  lp0.init();
+  int flag0 = 0;
+  constexpr int PF = 4;
+  double tq[PF + 1], dq[PF], yq[PF];
+  double tn = src.t(0);
+#pragma unroll
+  for (int k = 0; k < PF; ++k) { tq[k] = src.t(1 + k); dq[k] = src.diag(k); yq[k] = src.y(k); }
+  for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
+    const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
+    for (int i = i0; i < i1; ++i) {
+      const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
+#pragma unroll
+      for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
+      if (!(dbg & 2)) {
+        tq[PF - 1] = src.t(i + PF + 1);
+        dq[PF - 1] = src.diag(i + PF);
+        yq[PF - 1] = src.y(i + PF);
+      }
+      double* slot = slot0 + (i & 1) * SLOT_STRIDE;
+      slot[Lk::F_Y * 64] = y_cur;
+      double u[J], v[J];
+      features_uv<JR, JC, FAST>(p, tn, u, v);
+#pragma unroll
+      for (int k = 0; k < J; ++k) {
+        u[k] *= psi[phi_index<JR>(k)];                                               // ubar
+        v[k] = (k < JR) ? psinv[phi_index<JR>(k)] : v[k] * psinv[phi_index<JR>(k)];  // vbar (v = 1 on real rows)
+        slot[(Lk::F_U + k) * 64] = u[k];
+      }
+      {  // Psi for the NEXT step (this step's decay included); the old one is no longer needed
+        double phid[nz(M)], phinv[nz(M)];
+        features_phi_pair<JR, JC>(p, t_cur_next - tn, phid, phinv);
+#pragma unroll
+        for (int m = 0; m < M; ++m) { psi[m] *= phid[m]; psinv[m] *= phinv[m]; }
+      }
+      double q[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) acc += C[sym(k, j)] * u[k];
+        q[j] = acc;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) s += u[j] * q[j];
+      const double a_n = p.diagonal(diag_cur);
+      const double D = a_n - s;
+      const double invD = 1.0 / D;
+      if (n0 + i < N) {
+        if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
+        lp0.mul(D);
+        gamma = fmax(gamma, fabs(a_n * invD));
+      }
+      double z[J], W[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        z[j] = v[j] - q[j];   // zbar
+        W[j] = z[j] * invD;   // Wbar
+        slot[(Lk::F_W + j) * 64] = W[j];
+      }
+      slot[Lk::F_INVD * 64] = invD;
+      if (i + 1 == i1) {  // last step of the block: the rider multiplies Psi out after folding it in
+#pragma unroll
+        for (int m = 0; m < M; ++m) psi_area[m * 64] = psi[m];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      split_barrier();  // B(i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) C[tri(k, j)] = fma(z[k], W[j], C[tri(k, j)]);
+      }
+      tn = t_cur_next;
+    }
+    {  // multiply the accumulated decay out (the rider does the same to Abar, bbar)
+      double pp[nz(M * (M + 1) / 2)];
+#pragma unroll
+      for (int bb = 0; bb < M; ++bb) {
+#pragma unroll
+        for (int aa = 0; aa <= bb; ++aa) pp[tri(aa, bb)] = psi[aa] * psi[bb];
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) C[tri(k, j)] *= pp[tri(phi_index<JR>(k), phi_index<JR>(j))];
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) { psi[m] = 1.0; psinv[m] = 1.0; }
+    }
+  }
+  if (!store) return;
+  *ld0_out = lp0.log_value();
+  *flag0_out = flag0;
+  *gamma_out = gamma;
+  double* o = elem_out + J * J + J;
+#pragma unroll
+  for (int i = 0; i < SZ; ++i) o[i] = C[i];
+}
+
+template <int JR, int JC>
+__device__ __forceinline__ void split_riders_lazy(int L, int n0, int N, bool store, const double* slot0 /* + lane */,
+                                                  const double* psi_area /* + lane */, double2* jm /* + lane */,
+                                                  double* elem_out, double* q0_out, int dbg) {
+  constexpr int J = Widths<JR, JC>::J;
+  constexpr int SZ = Widths<JR, JC>::SZ;
+  using Lk = SplitLinkLazy<JR, JC>;
+  using LkJ = SplitLink<JR, JC>;
+  constexpr int M = Lk::M;
+  double Acol[J * J], eta[J], b[J];  // Acol[j * J + i] = Abar[i][j]; b = bbar
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+#pragma unroll
+    for (int i = 0; i < J; ++i) Acol[j * J + i] = (i == j) ? 1.0 : 0.0;
+    eta[j] = 0.0;
+    b[j] = 0.0;
+  }
+  double q0 = 0.0;
+#pragma unroll
+  for (int f = 0; f < LkJ::NJM; ++f) jm[f * 64] = make_double2(0.0, 0.0);
+  for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
+    const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
+    for (int i = i0; i < i1; ++i) {
+      split_barrier();  // B(i)
+      const double* slot = slot0 + (i & 1) * (Lk::NPAY * 64);
+      double u[J], W[J], r[J];
+#pragma unroll
+      for (int k = 0; k < J; ++k) u[k] = slot[(Lk::F_U + k) * 64];
+#pragma unroll
+      for (int k = 0; k < J; ++k) W[k] = slot[(Lk::F_W + k) * 64];
+      const double invD = slot[Lk::F_INVD * 64];
+      const double y = slot[Lk::F_Y * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool valid = n0 + i < N;
+      double ub = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) ub += u[k] * b[k];
+      const double x = y - ub;           // cholesky.h:353-355 from the zero start
+      const double xs = x * invD;
+#pragma unroll
+      for (int k = 0; k < J; ++k) b[k] = fma(W[k], x, b[k]);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double racc = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
+        r[j] = racc;
+#pragma unroll
+        for (int k = 0; k < J; ++k) Acol[j * J + k] = fma(-W[k], racc, Acol[j * J + k]);
+      }
+      if (valid) {
+        q0 += x * xs;
+        double rs[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          rs[j] = r[j] * invD;
+          eta[j] -= r[j] * xs;
+        }
+#pragma unroll
+        for (int f = 0; f < LkJ::NJM; ++f) {
+          double2 d = jm[f * 64];
+          d.x -= r[tri_row(2 * f)] * rs[tri_col(2 * f)];
+          if (2 * f + 1 < SZ) d.y -= r[tri_row(2 * f + 1)] * rs[tri_col(2 * f + 1)];
+          jm[f * 64] = d;
+          if ((f % 6) == 5) __builtin_amdgcn_sched_barrier(0);  // (keep the 18 cells from being loaded all at once)
+        }
+      }
+    }
+    {  // the block's accumulated decay (published by T with the block's last step; T rewrites it 16 steps on)
+      double psi[nz(M)];
+#pragma unroll
+      for (int m = 0; m < M; ++m) psi[m] = psi_area[m * 64];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        b[j] *= psi[phi_index<JR>(j)];
+#pragma unroll
+        for (int k = 0; k < J; ++k) Acol[j * J + k] *= psi[phi_index<JR>(k)];
+      }
+    }
+  }
+  if (!store) return;
+  *q0_out = q0;
+  double* o = elem_out;
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) o[i * J + j] = Acol[j * J + i];
+  }
+  o += J * J;
+#pragma unroll
+  for (int i = 0; i < J; ++i) o[i] = b[i];
+  o += J + SZ;
+#pragma unroll
+  for (int i = 0; i < J; ++i) o[i] = eta[i];
+  o += J;
+#pragma unroll
+  for (int f = 0; f < LkJ::NJM; ++f) {
+    const double2 d = jm[f * 64];
+    o[2 * f] = d.x;
+    if (2 * f + 1 < SZ) o[2 * f + 1] = d.y;
+  }
+}
+
+// 8 waves: 4 sets (problem b, block x of 64 chunks), one T and one R wave per set.
+template <int JR, int JC, bool FAST, bool LAZY>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 summarize_split_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   using Lk = SplitLink<JR, JC>;
-  __shared__ double ring[4][2 * Lk::NPAY * 64];  // two slots per set: T fills one while R reads the other
+  using LkL = SplitLinkLazy<JR, JC>;
+  constexpr int NPAY = LAZY ? LkL::NPAY : Lk::NPAY;
+  __shared__ double ring[4][2 * NPAY * 64];  // two slots per set: T fills one while R reads the other
+  __shared__ double psibuf[LAZY ? 4 : 1][(LAZY ? LkL::M : 1) * 64];  // Psi of the renormalisation steps
   __shared__ double2 jmbuf[4][Lk::NJM * 64];
   int* placed = reinterpret_cast<int*>(&jmbuf[0][0]);  // (LDS is full: borrowed until the roles are fixed)
   const int lane = threadIdx.x & 63;
@@ -289,17 +572,27 @@ summarize_split_kernel(const BatchParams P) {
   if (role == 0) {
     DirectSeries src = make_direct(P, b, store ? c : 0);
     if (!store) src.nleft = 0;  // lanes past the last chunk / dead sets: padding only
-    double ld0 = 0.0, q0 = 0.0;
+    double ld0 = 0.0, q0 = 0.0, gamma = 0.0;
     int flag0 = 0;
-    split_trajectory<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, slot, elem, &ld0, &q0, &flag0, P.split);
+    if (LAZY)
+      split_trajectory_lazy<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, slot, psibuf[LAZY ? set : 0] + lane, elem,
+                                          &ld0, &flag0, &gamma, P.split);
+    else
+      split_trajectory<JR, JC, FAST>(p, src, P.L, c * P.L, P.N, store, slot, elem, &ld0, &q0, &flag0, &gamma, P.split);
     if (store) {
-      if (P.cond) { P.cond[cell * 3 + 0] = 0.0; P.cond[cell * 3 + 1] = 1.0; P.cond[cell * 3 + 2] = 0.0; }
+      if (P.cond) { P.cond[cell * 3 + 0] = gamma; P.cond[cell * 3 + 1] = 1.0; P.cond[cell * 3 + 2] = 0.0; }
       P.part[cell * 2 + 0] = ld0;
-      P.part[cell * 2 + 1] = q0;
+      if (!LAZY) P.part[cell * 2 + 1] = q0;  // (lazy: the rider wave owns the quadratic sum)
       P.flags[cell] = flag0;
     }
   } else {
-    split_riders<JR, JC>(p, P.L, c * P.L, P.N, store, slot, jmbuf[set] + lane, elem, P.split);
+    if (LAZY) {
+      double q0 = 0.0;
+      split_riders_lazy<JR, JC>(P.L, c * P.L, P.N, store, slot, psibuf[LAZY ? set : 0] + lane, jmbuf[set] + lane, elem,
+                                &q0, P.split);
+      if (store) P.part[cell * 2 + 1] = q0;
+    } else
+      split_riders<JR, JC>(p, P.L, c * P.L, P.N, store, slot, jmbuf[set] + lane, elem, P.split);
   }
 }
 
@@ -309,8 +602,10 @@ inline void launch_split_shape(const BatchParams& P, hipStream_t s) {
   const int nblk = (P.nchunk + 63) / 64;
   const long sets = (long)P.B * nblk;
   const dim3 grid((unsigned)((sets + 3) / 4)), block(512);
-  if (P.fast_trig) hipLaunchKernelGGL((summarize_split_kernel<JR, JC, true>), grid, block, 0, s, P);
-  else hipLaunchKernelGGL((summarize_split_kernel<JR, JC, false>), grid, block, 0, s, P);
+#define CLR_GO(F, Z) hipLaunchKernelGGL((summarize_split_kernel<JR, JC, F, Z>), grid, block, 0, s, P)
+  if (P.split_lazy) { if (P.fast_trig) CLR_GO(true, true); else CLR_GO(false, true); }
+  else              { if (P.fast_trig) CLR_GO(true, false); else CLR_GO(false, false); }
+#undef CLR_GO
 }
 #define CLR_SPLIT_SHAPE(R, C) if (JR == R && JC == C) { launch_split_shape<R, C>(P, s); return true; }
 

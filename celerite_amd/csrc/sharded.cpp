@@ -187,6 +187,10 @@ int clr_sharded_set_chunks(clr_sharded* h, int nchunk) {
   return h->all([=](int s) { return clr_batch_set_chunks(h->plan[s], nchunk); });
 }
 
+int clr_sharded_set_summarize_mode(clr_sharded* h, int mode) {
+  return h->all([=](int s) { return clr_batch_set_summarize_mode(h->plan[s], mode); });
+}
+
 int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* chunk_len) {
   if (shard < 0 || shard >= (int)h->plan.size()) return CLR_INVALID_ARGUMENT;
   return clr_batch_get_chunks(h->plan[shard], nchunk, chunk_len);

@@ -217,14 +217,18 @@ int clr_batch_set_layout(clr_batch* h, int layout);
  * 1e9 holds, and with the library (ocml) sincos otherwise.  force != 0 selects the
  * library routine unconditionally (for A/B measurements). */
 int clr_batch_set_library_trig(clr_batch* h, int force);
-/* summarize kernel of widths 7 and 8: 1 = two roles on two waves per SIMD -- a "trajectory"
- * wave (C, b) and a "riders" wave (A, eta in registers, Jm in LDS) linked through LDS,
- * csrc/clr_split_kernels.h; it reads a chunk-interleaved copy of the series made once per
- * clr_batch_set_series (layout 1 below is implied).  0 / -1 (default) = the single-wave
- * kernel (one wave per SIMD, part of the state in AGPRs).  Measured on MI355X: the split is
- * 5-7 % faster at width 8 with two or more complex terms and slower for real-only kernels
- * (the fp64 FMA issue rate, not occupancy, is the bound: profiles/r02a_issue_rates2.txt). */
+/* summarize kernel of widths 7 and 8 (csrc/clr_split_kernels.h):
+ *   0  the single-wave kernel (one wave per SIMD, part of the state in AGPRs);
+ *   1  two roles on two waves per SIMD: a "trajectory" wave (C, b) and a "riders" wave (A, eta in
+ *      registers, Jm in LDS) linked through LDS; reads a chunk-interleaved copy of the series made
+ *      once per clr_batch_set_series (layout 1 below is implied);
+ *   2  the same with the decay factored out of the state ("lazy": one FMA per state entry and step
+ *      instead of FMA + MUL, renormalised every 16 steps) when the series is densely sampled
+ *      (max c * max dx < 2^-7, at most 6 distinct decays), else as 1;
+ *  -1  (default) 2 at width 8 with two or more complex terms on a dense series, else 0. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
+/* Which one the next evaluation will run (0, 1 or 2 as above), given the series and coefficients set. */
+int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind);
 /* Prefix phase: 16 lanes per problem (default) or the single-lane version (kept as
  * the on-device cross-check and for A/B measurements). */
 int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
@@ -332,6 +336,9 @@ int clr_sharded_get_shard(const clr_sharded* h, int shard, int* device, int* lo,
  * problems; every shard takes its slice).  The calls return when every shard has. */
 int clr_sharded_set_chunks(clr_sharded* h, int nchunk);
 int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* chunk_len);
+/* (the automatic choice of the summarize kernel looks at the shard's own series and coefficients:
+ * pin it too when bit-identical results across shardings are wanted) */
+int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
                            long diag_stride, const double* y, long y_stride);
 int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const double* a_real,

@@ -479,6 +479,7 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
         plan.set_chunks(nchunk)
+        plan.set_summarize_mode(0)
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case))
         want = plan.log_likelihood()
@@ -489,6 +490,7 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
         sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
         try:
             sp.set_chunks(nchunk)
+            sp.set_summarize_mode(0)
             assert [(lo, hi) for _, lo, hi in sp.shards] == [batch.shard_bounds(B, S, s) for s in range(S)]
             sp.set_series(case["t"], case["diag"], case["y"])
             got = sp.evaluate(*coeffs_of(case))
@@ -526,3 +528,31 @@ def test_sharded_one_shot_and_shared_series():
     assert np.array_equal(st, want[3])
     for a, b in zip(out, want[:3]):
         assert np.max(np.abs(a - b) / np.abs(b)) <= REL
+
+
+@pytest.mark.parametrize("JR,JC", [(2, 3), (0, 4), (4, 2), (6, 1), (8, 0), (1, 3), (3, 2), (7, 0)])
+def test_role_split_summarize_kernels(JR, JC):
+    """summarize as two roles on two waves per SIMD (csrc/clr_split_kernels.h), plain (mode 1) and
+    with the decay factored out of the state (mode 2, dense series), against the oracle and against
+    the single-wave kernel, including a ragged last chunk, lanes past the last chunk and a short series."""
+    for N, nchunk, dense in [(6000, 64, True), (4099, 37, True), (3000, 100, False), (700, 9, True)]:
+        case = synthetic(5, N, JR, JC, "bench" if dense else "accuracy", seed=JR + 7 * JC + N)
+        if dense:   # sort(U(0,1)) at N ~ 5e3 has gaps up to ~2e-3: squeeze the time axis into the lazy regime
+            case["t"] = case["t"] * 0.2
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(5, N, JR, JC)
+        plan.set_chunks(nchunk)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        outs = {}
+        for mode in (0, 1, 2):
+            plan.set_summarize_mode(mode)
+            outs[mode] = plan.log_likelihood()
+            ll, ld, q, st = outs[mode]
+            assert np.array_equal(st, s0), (N, mode)
+            assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, (N, mode)
+            assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, (N, mode)
+        plan.close()
+        for mode in (1, 2):
+            assert np.max(np.abs(outs[mode][1] - outs[0][1]) / np.abs(outs[0][1])) <= 1e-11
+            assert np.max(np.abs(outs[mode][2] - outs[0][2]) / np.abs(outs[0][2])) <= 1e-11

@@ -14,7 +14,7 @@ for JR, JC in shapes:
     plan.set_series(t, diag, y)
     plan.set_coefficients(*coeffs)
     ref = None
-    for mode in (0, 1, 0, 1):
+    for mode in (0, 1, 2, 0, 2):
         plan.set_summarize_mode(mode)
         plan.enqueue(); plan.synchronize()
         tot, k = plan.run_timed(10)
