@@ -1107,17 +1107,19 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
 }
 
 static bool lazy_eligible(const clr_batch* h) {
-  // |c dx| < 2^-7 at every step: Psi stays within [0.88, 1] over the 16 steps between renormalisations
-  return h->have_series && h->have_coeffs && h->J_real + h->J_comp <= 6 && h->cmax * h->dxmax < 0.0078125;
+  // |c dx| < 2^-7 at every step: Psi stays within [0.88, 1] over the 16 steps between renormalisations;
+  // |d dx| < 2^-5: the per-step rotation of the (cos, sin) pairs uses a short Taylor series
+  return h->have_series && h->have_coeffs && h->cmax * h->dxmax < 0.0078125 && h->dmax * h->dxmax < 0.03125;
 }
 
 static bool split_active(const clr_batch* h) {
-  // explicit modes 1 / 2, or auto (-1): width 8 with at least two complex terms on a densely sampled
-  // series, where the split kernel with the decay factored out of the state (lazy) is the faster one
-  // (profiles/r02h_split_ab.txt, r02r_lazy_ab.txt); real-only kernels and width 7 stay single-wave
+  // explicit modes 1 / 2, or auto (-1): width 8 on a densely sampled series, where the split kernel
+  // with the decay factored out of the state (lazy) is the faster one for every shape (2.6-2.7 ms
+  // against 3.1-3.6: profiles/r02t_lazy_ab.txt); without the lazy decay it only wins with >= 2 complex
+  // terms (r02h_split_ab.txt), so sparse series and width 7 stay single-wave
   if (!(h->launch && h->nchunk > 1 && clr::have_summarize_split(h->J_real, h->J_comp))) return false;
   if (h->summarize_mode > 0) return true;
-  return h->summarize_mode < 0 && h->J == 8 && h->J_comp >= 2 && lazy_eligible(h);
+  return h->summarize_mode < 0 && h->J == 8 && lazy_eligible(h);
 }
 
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {

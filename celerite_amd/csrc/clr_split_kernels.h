@@ -328,13 +328,20 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
   LogProduct lp0;
   lp0.init();
   int flag0 = 0;
-  constexpr int PF = 4;
+  constexpr int PF = 3;
   double tq[PF + 1], dq[PF], yq[PF];
   double tn = src.t(0);
+  double cdv[nz(JC)], sdv[nz(JC)];  // cos / sin of d t at the current sample
+#pragma unroll
+  for (int j = 0; j < JC; ++j) { cdv[j] = 1.0; sdv[j] = 0.0; }
 #pragma unroll
   for (int k = 0; k < PF; ++k) { tq[k] = src.t(1 + k); dq[k] = src.diag(k); yq[k] = src.y(k); }
   for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
     const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
+    // anchor: the full sincos of the absolute phase at the block's first sample (cholesky.h:137); at
+    // most 15 rotations (a few 1e-15 absolute) accumulate before the next anchor
+#pragma unroll
+    for (int j = 0; j < JC; ++j) sincos_phase<FAST>(p.dc[j] * tn, &sdv[j], &cdv[j]);
     for (int i = i0; i < i1; ++i) {
       const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
 #pragma unroll
@@ -347,7 +354,29 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       double* slot = slot0 + (i & 1) * SLOT_STRIDE;
       slot[Lk::F_Y * 64] = y_cur;
       double u[J], v[J];
-      features_uv<JR, JC, FAST>(p, tn, u, v);
+      // U~, V~ (cholesky.h:129-147) from the block's running (cos, sin) pairs
+#pragma unroll
+      for (int j = 0; j < JR; ++j) { u[j] = p.ar[j]; v[j] = 1.0; }
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {
+        const int k = JR + 2 * j;
+        u[k] = p.ac[j] * cdv[j] + p.bc[j] * sdv[j];
+        u[k + 1] = p.ac[j] * sdv[j] - p.bc[j] * cdv[j];
+        v[k] = cdv[j];
+        v[k + 1] = sdv[j];
+      }
+      // ... which advance to the next sample by a ROTATION through the small angle d dx (12 fp64
+      // instructions per term instead of 21 + 14 integer ones: no range reduction, no quadrant
+      // selects); |d dx| < 2^-5 is checked on the host for the whole plan (lazy_eligible)
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {
+        const double dl = p.dc[j] * (t_cur_next - tn), d2 = dl * dl;
+        const double sn = dl * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        const double cs = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+        const double c0 = cdv[j], s0 = sdv[j];
+        cdv[j] = fma(c0, cs, -s0 * sn);
+        sdv[j] = fma(s0, cs, c0 * sn);
+      }
 #pragma unroll
       for (int k = 0; k < J; ++k) {
         u[k] *= psi[phi_index<JR>(k)];                                               // ubar
