@@ -161,6 +161,10 @@ class GP(ModelSet):
         """
         y = self._process_input(y)
         resid = y - self.mean.get_value(self._t)
+        if y.ndim == 1 and not self.computed:
+            # the factorisation is about to run: let it fold resid^T K^-1 resid into the same pass over
+            # the series (dot_solve below then returns it; any other vector takes the ordinary sweep)
+            self.solver._hint_rhs(resid)
         try:
             self._recompute()
         except solver.LinAlgError:

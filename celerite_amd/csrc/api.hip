@@ -260,6 +260,12 @@ struct clr_solver {
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
   DevBuf gradbuf;                       // grad_log_likelihood staging
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
+  // clr_solver_hint_rhs: the right-hand side the caller is about to pass to dot_solve; the next compute
+  // folds b^T K^-1 b into its own pass over the series and dot_solve returns it for that very vector
+  std::vector<double> host_rhs;
+  DevBuf rhs;
+  bool rhs_hint = false, have_quad = false;
+  double cached_quad = 0.0;
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
@@ -433,7 +439,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part, &s->ws_cond, &s->gradbuf})
+                      &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -441,6 +447,8 @@ void clr_solver_destroy(clr_solver* s) {
   }
   delete s;
 }
+
+static void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev);
 
 int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double* a_real,
                        int n_c_real, const double* c_real, int n_a_comp, const double* a_comp,
@@ -450,6 +458,9 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
                        int n_x, const double* x, int n_diag, const double* diag) {
   const int N = n_x;
   s->computed = 0;  // cholesky.h:57
+  s->have_quad = false;
+  const bool use_rhs = s->rhs_hint && (int)s->host_rhs.size() == N;
+  s->rhs_hint = false;  // (one shot)
   if (N != n_diag) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
   int st = check_coeff_dims(n_a_real, n_c_real, n_a_comp, n_b_comp, n_c_comp, n_d_comp, n_A,
                             U_rows, U_cols, V_rows, V_cols, N);
@@ -523,7 +534,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
     // row-major arrays; with more than one chunk the kernels stage them through LDS
-    P.t = s->t.p; P.diag = s->scratch.p; P.y = s->t.p;  // y is irrelevant for compute
+    if (use_rhs && (st = upload(s->rhs, s->host_rhs.data(), (size_t)N, stream)) != CLR_OK) return st;
+    P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
     P.lane_is = 1; P.lane_cs = P.L;
     P.staged = P.nchunk > 1 ? 1 : 0;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
@@ -533,7 +545,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
-    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = 1;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
     L->summarize(P, stream);
     L->prefix(P, stream);
     L->correct(P, stream);        // flags + conditioning record (its sums are overwritten by the replay)
@@ -547,8 +559,65 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     h_logdet = back[1];
     memcpy(&h_status, &back[3], sizeof(int));
     h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
+    if (use_rhs && !h_status) { s->cached_quad = back[2]; s->have_quad = true; }
+  } else if (!has_general && J >= 9 && J <= clr::wide_max_width()) {
+    // widths 9..64 without general terms: the batched wide kernels on one problem -- one wave per
+    // chunk with S distributed over the lanes, up to 16 chunks chained by the scan (widths <= 32),
+    // the replay writing the factor in the reference's storage (instead of factor_generic_kernel:
+    // one workgroup, five barriers per step)
+    if ((st = upload(s->scratch, diag, (size_t)N, stream)) != CLR_OK) return st;
+    if ((st = upload(s->scratch2, &jitter, 1, stream)) != CLR_OK) return st;
+    clr::BatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.B = 1;
+    P.N = N;
+    {
+      double dmax = 0.0;
+      for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
+      P.fast_trig = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+    }
+    int nchunk = 1;
+    if (J <= clr::wide_scan_max_width()) {
+      nchunk = N / 1024;
+      if (nchunk > 16) nchunk = 16;
+      if (nchunk < 2) nchunk = 1;
+    }
+    P.L = (N + nchunk - 1) / nchunk;
+    P.nchunk = (N + P.L - 1) / P.L;
+    const size_t pc = (size_t)P.nchunk, JP = J <= 16 ? 16 : 32, SZP = JP * (JP + 1) / 2;
+    if ((st = s->ws_elems.reserve(pc * (JP * JP + JP + SZP + JP + SZP))) != CLR_OK) return st;
+    if ((st = s->ws_starts.reserve(pc * (SZP + JP))) != CLR_OK) return st;
+    if ((st = s->ws_part.reserve(pc * 4)) != CLR_OK) return st;
+    if ((st = s->ws_cond.reserve(pc * 3)) != CLR_OK) return st;
+    if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, 2 * pc + 1)) != CLR_OK) return st;
+    const clr::GenericProblem g = generic_view(s);
+    P.jitter = s->scratch2.p;
+    P.a_real = g.a_real; P.c_real = g.c_real;
+    P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
+    if (use_rhs && (st = upload(s->rhs, s->host_rhs.data(), (size_t)N, stream)) != CLR_OK) return st;
+    P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
+    P.lane_is = 1; P.lane_cs = P.L;
+    P.elems = s->ws_elems.p; P.starts = s->ws_starts.p;
+    P.part = s->ws_part.p; P.partx = s->ws_part.p + pc * 2;
+    P.flags = s->ws_flags; P.flagsx = s->ws_flags + pc; P.need_exact = s->ws_flags + 2 * pc;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    P.force_exact = 1;       // the factor is wanted: every chunk is replayed (and checked against the scan)
+    P.wide_materialize = 1;
+    P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
+    P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
+    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    HIP_TRY(hipMemsetAsync(P.need_exact, 0, sizeof(int), stream));  // (one chunk: no prefix kernel clears it)
+    wide_flow(P, J_real, J_comp, stream, nullptr);
+    HIP_TRY(hipGetLastError());
+    double back[4];
+    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, sizeof(back), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    h_logdet = back[1];
+    memcpy(&h_status, &back[3], sizeof(int));
+    h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
+    if (use_rhs && !h_status) { s->cached_quad = back[2]; s->have_quad = true; }
   } else {
-    // any width / general terms: diagonal summed on the host in the reference's
+    // general terms (or widths above 64): diagonal summed on the host in the reference's
     // order (cholesky.h:98-99), recurrence on the device
     double sum_ar = 0.0, sum_ac = 0.0;
     for (int j = 0; j < J_real; ++j) sum_ar += a_real[j];
@@ -647,6 +716,13 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   return CLR_OK;
 }
 
+int clr_solver_hint_rhs(clr_solver* s, int n_b, const double* b) {
+  if (n_b < 0 || (n_b > 0 && !b)) return fail(CLR_INVALID_ARGUMENT, "bad right-hand side");
+  s->host_rhs.assign(b, b + n_b);
+  s->rhs_hint = true;
+  return CLR_OK;
+}
+
 int clr_solver_computed(const clr_solver* s) { return s->computed; }
 
 int clr_solver_log_determinant(const clr_solver* s, double* out) {
@@ -675,6 +751,12 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   clr_solver* s = const_cast<clr_solver*>(cs);
   if (n_b != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // :327
   if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
+  // the vector hinted before compute: its quadratic form came out of compute's own pass
+  if (s->have_quad && (int)s->host_rhs.size() == n_b &&
+      memcmp(s->host_rhs.data(), b, sizeof(double) * (size_t)n_b) == 0) {
+    *out = s->cached_quad;
+    return CLR_OK;
+  }
   int st = ensure_stream(s);
   if (st != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
@@ -1305,28 +1387,31 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
 // start state and check the end states against the scan.  Problems the certificate flagged, or whose
 // replay did not meet the scan, are then walked by the sequential sweep itself (one wave per such
 // problem over all N samples), which overwrites their results: nothing of theirs depends on the scan.
-static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
-  auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
-  const int JP = h->J <= 16 ? 16 : 32;
+static void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev) {
+  auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], stream); };
+  const int JP = J_real + 2 * J_comp <= 16 ? 16 : 32;
   mark(1);
-  if (P.nchunk > 1) clr::launch_wide_summarize(P, h->J_real, h->J_comp, h->stream);
+  if (P.nchunk > 1) clr::launch_wide_summarize(P, J_real, J_comp, stream);
   mark(2);
-  clr::launch_wide_prefix(P, JP, h->stream);
+  clr::launch_wide_prefix(P, JP, stream);
   mark(3);
-  clr::launch_wide_correct(P, JP, h->stream);
+  clr::launch_wide_correct(P, JP, stream);
   mark(4);
   // one chunk: the sweep itself; several: the chunked replay of forced runs and of the problems the
   // conditioning record marked (level 1), with its end states checked against the scan
-  clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+  clr::launch_wide_loglike(P, J_real, J_comp, stream);
   if (P.nchunk > 1) {
-    clr::launch_wide_check_replay(P, h->stream);
-    clr::launch_finalize(P, h->stream);
+    clr::launch_wide_check_replay(P, stream);
+    clr::launch_finalize(P, stream);
     clr::BatchParams S = P;  // the flagged problems, sequentially
     S.nchunk = 1; S.L = P.N; S.seq_only = 1; S.force_exact = 1;
-    clr::launch_wide_loglike(S, h->J_real, h->J_comp, h->stream);
+    clr::launch_wide_loglike(S, J_real, J_comp, stream);
   }
   mark(5);
   mark(6);
+}
+static void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
+  wide_flow(P, h->J_real, h->J_comp, h->stream, ev);
 }
 
 static const int PROF_NK = 6, PROF_MAX_STEPS = 4096;

@@ -54,6 +54,8 @@ struct BatchParams {
   double* partx;   // [B][nchunk][2]
   int* flagsx;     // [B][nchunk]     D_n < 0 (n >= 1) seen: cholesky.h:176
   int force_exact; // materialising runs and clr_batch_set_exact(h, 1)
+  int wide_materialize;  // wide path, MODE 0: also write phi, u, W, D of problem b in the reference's storage
+                         // (cholesky.h:76-78, :703-706; CholeskySolver.compute at widths 9..64)
   int split_lazy;     // role-split summarize with the decay factored out of the state (dense series only)
   int seq_only;       // wide path: this launch only walks the problems with need_exact != 0 (one chunk = all N)
   int logdet_only;    // no right-hand side (CholeskySolver.compute): the quadratic form is not checked

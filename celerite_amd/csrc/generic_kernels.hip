@@ -1,16 +1,16 @@
 // celerite_amd/csrc/generic_kernels.hip -- see clr_generic_kernels.h.
 #include "clr_generic_kernels.h"
+#include "clr_wide.h"
 
 #include <math.h>
 
 namespace clr {
 namespace {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// sum over the 64 lanes, wave-uniform result: DPP butterflies within the 16-lane rows and four
+// v_readlane pairs across them (clr_wide.h) -- a __shfl_xor butterfly is twelve ds_bpermute_b32
+// through the LDS crossbar, ~0.3 us per step for the lone wave of these sequential sweeps
+__device__ __forceinline__ double wave_sum(double v) { return clr::row_sum<1>(v); }
 
 // Row j of (phi, u~, v~) for the move t_prev -> t (cholesky.h:127-152).
 __device__ __forceinline__ void row_features(const GenericProblem& g, int j, int n, double t,
@@ -155,34 +155,46 @@ __global__ void __launch_bounds__(64) dot_solve_kernel(int N, int J, const doubl
                                                        const double* u, const double* W,
                                                        const double* D, const double* b,
                                                        double* out) {
-  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  // rows j0 = lane and j1 = lane + 64; the factor of KB steps is held in registers and the NEXT KB
+  // steps are in flight while they are consumed: one step of look-ahead left the ~0.3 us L2 round trip
+  // on every step's critical path (30 ms at N = 1e5 whatever the width)
+  constexpr int KB = 8;
+  const int lane = threadIdx.x, j0 = lane, j1 = lane + 64;
   const bool h0 = j0 < J, h1 = j1 < J;
   double f0 = 0.0, f1 = 0.0;
   double xm1 = b[0];
   double result = xm1 * (xm1 / D[0]);  // cholesky.h:347
-  // register prefetch of row n = 1
-  double p0 = 0, u0 = 0, w0 = 0, p1 = 0, u1 = 0, w1 = 0, bn = 0, dn = 1;
-  if (N > 1) {
-    if (h0) { p0 = phi[j0]; u0 = u[j0]; w0 = W[j0]; }
-    if (h1) { p1 = phi[j1]; u1 = u[j1]; w1 = W[j1]; }
-    bn = b[1];
-    dn = D[1];
-  }
-  for (int n = 1; n < N; ++n) {
-    const double cp0 = p0, cu0 = u0, cw0 = w0, cp1 = p1, cu1 = u1, cw1 = w1, cb = bn, cd = dn;
-    if (n + 1 < N) {
-      const long base = (long)J * n;
-      if (h0) { p0 = phi[base + j0]; u0 = u[base + j0]; w0 = W[base + j0]; }
-      if (h1) { p1 = phi[base + j1]; u1 = u[base + j1]; w1 = W[base + j1]; }
-      bn = b[n + 1];
-      dn = D[n + 1];
+  double p0[KB], u0[KB], w0[KB], p1[KB], u1[KB], w1[KB], bt = 0.0, dt = 1.0;
+  auto fetch = [&](int n0) {  // steps n0 .. n0 + KB - 1 read row n - 1 of phi, u, W and b[n], D[n]
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int n = n0 + k;
+      const long base = (long)J * (n - 1);
+      const bool ok = n < N;
+      p0[k] = (ok && h0) ? phi[base + j0] : 0.0; u0[k] = (ok && h0) ? u[base + j0] : 0.0; w0[k] = (ok && h0) ? W[base + j0] : 0.0;
+      p1[k] = (ok && h1) ? phi[base + j1] : 0.0; u1[k] = (ok && h1) ? u[base + j1] : 0.0; w1[k] = (ok && h1) ? W[base + j1] : 0.0;
     }
-    double part = 0.0;  // cholesky.h:350-354
-    if (h0) { f0 = cp0 * (f0 + cw0 * xm1); part += cu0 * f0; }
-    if (h1) { f1 = cp1 * (f1 + cw1 * xm1); part += cu1 * f1; }
-    const double x = cb - wave_sum(part);
-    xm1 = x;
-    result += x * x / cd;  // :356
+    bt = (lane < KB && n0 + lane < N) ? b[n0 + lane] : 0.0;
+    dt = (lane < KB && n0 + lane < N) ? D[n0 + lane] : 1.0;
+  };
+  fetch(1);
+  for (int n0 = 1; n0 < N; n0 += KB) {
+    double cp0[KB], cu0[KB], cw0[KB], cp1[KB], cu1[KB], cw1[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { cp0[k] = p0[k]; cu0[k] = u0[k]; cw0[k] = w0[k]; cp1[k] = p1[k]; cu1[k] = u1[k]; cw1[k] = w1[k]; }
+    const double cb = bt, cd = dt;
+    if (n0 + KB < N) fetch(n0 + KB);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (n0 + k < N) {
+        double part = 0.0;  // cholesky.h:350-354
+        if (h0) { f0 = cp0[k] * (f0 + cw0[k] * xm1); part += cu0[k] * f0; }
+        if (h1) { f1 = cp1[k] * (f1 + cw1[k] * xm1); part += cu1[k] * f1; }
+        const double x = clr::lane_value(cb, k) - wave_sum(part);
+        xm1 = x;
+        result += x * x / clr::lane_value(cd, k);  // :356
+      }
+    }
   }
   if (threadIdx.x == 0) out[0] = result;
 }

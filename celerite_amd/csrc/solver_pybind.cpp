@@ -251,6 +251,14 @@ PYBIND11_MODULE(solver, m) {
           },
           "b^T K^-1 b (solver.cpp:527-529)");
 
+  cls.def("_hint_rhs",
+          [](Solver& s, const darray& b) {
+            Vec v(b);
+            check(clr_solver_hint_rhs(s.h(), v.n(), v.p()));
+          },
+          "not in the reference: announce the vector of the coming dot_solve so that the next compute folds "
+          "its quadratic form into the factorisation pass (clr_solver_hint_rhs)");
+
   cls.def("dot_L",
           [](Solver& s, const darray& z) {
             Rhs rhs(z);

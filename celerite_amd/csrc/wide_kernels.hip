@@ -207,6 +207,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
         wbuf[row] = phi * w;
         if (MODE == 1) rbuf[row] = r;
       }
+      if (MODE == 0 && P.wide_materialize && writer && row < W) {
+        // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
+        // u[:, n - 1] = U~(t_n), phi[:, n] = decay n -> n + 1 (cholesky.h:131-151, :177-178)
+        const long Wl = W;
+        P.W[(long)b * Wl * N + Wl * n + row] = w;
+        if (row == 0) P.D[(long)b * N + n] = D;
+        if (n >= 1) P.u[(long)b * Wl * (N - 1) + Wl * (n - 1) + row] = u;
+        if (n + 1 < N) P.phi[(long)b * Wl * (N - 1) + Wl * n + row] = phi;
+      }
       {
         const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
     }
     if (lane == 0) {
       double res = (pm > 0.0) ? dp / pm : (dp == 0.0 ? 0.0 : INFINITY);
-      if (fm > 0.0) res = fmax(res, df / fm);
+      if (fm > 0.0 && !P.logdet_only) res = fmax(res, df / fm);
       P.cond[slot * 3 + 2] = (chunk + 1 < P.nchunk) ? res : 0.0;
     }
   }
@@ -480,8 +489,8 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     const double ld = log(det);
     const double err = J * 2.2e-16 / mu;  // rounding-error estimate of the corrections
     if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
-    if (!(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
-    if (!isfinite(q) || !isfinite(ld)) bad = 1;
+    if (!P.logdet_only && !(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
+    if ((!P.logdet_only && !isfinite(q)) || !isfinite(ld)) bad = 1;
     P.part[slot * 2 + 0] = ld0 + ld;
     P.part[slot * 2 + 1] = q0 + q;
     if (P.cond) P.cond[slot * 3 + 1] = mu;

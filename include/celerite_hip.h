@@ -93,6 +93,12 @@ int clr_solver_compute(clr_solver* s, double jitter,
                        int n_x, const double* x,
                        int n_diag, const double* diag);
 
+/* Optional, not in the reference: announce the vector the caller is about to hand to dot_solve (GP.log_likelihood
+ * knows y before it factorises, celerite.py:180-215).  The NEXT clr_solver_compute then folds b^T K^-1 b into its own
+ * pass over the series (widths 1..64 without general terms) and clr_solver_dot_solve returns that value when it is
+ * called with the very same vector (compared byte for byte); any other vector takes the ordinary sweep.  One shot. */
+int clr_solver_hint_rhs(clr_solver* s, int n_b, const double* b);
+
 /* Solver::computed / log_determinant, solver.h:74-81 (solver.cpp:620-634). */
 int clr_solver_computed(const clr_solver* s);
 int clr_solver_log_determinant(const clr_solver* s, double* out);

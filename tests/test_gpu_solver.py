@@ -489,3 +489,62 @@ def test_failed_compute_leaves_solver_not_computed():  # cholesky.h:57
         s.log_determinant()
     with pytest.raises(RuntimeError, match="dimension mismatch"):
         s.compute(0.0, np.ones(1), np.ones(1), e, e, e, e, *NO_GENERAL, t, np.ones(49))
+
+
+@pytest.mark.parametrize("JR,JC,N", [(1, 4, 300), (2, 7, 3000), (4, 11, 5000), (0, 16, 20000), (6, 13, 2500), (10, 15, 700)])
+def test_object_api_wide_widths_through_the_wide_scan(JR, JC, N):
+    """CholeskySolver.compute at widths 9..64 without general terms runs the batched wide kernels on
+    one problem (chunked for widths <= 32 and N >= 2048) and writes the factor in the reference's
+    storage: log_determinant, dot_solve, solve and the pickled state against the oracle."""
+    rng = np.random.RandomState(JR * 100 + JC)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    yerr = rng.uniform(0.3, 0.5, N)
+    y = rng.randn(N)
+    args = (0.0, np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+            0.1 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)),
+            np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t, yerr ** 2)
+    s = celerite_amd.CholeskySolver()
+    r = ref.RefSolver()
+    s.compute(*args)
+    r.compute(*args)
+    assert abs(s.log_determinant() - r.log_determinant()) <= 1e-10 * abs(r.log_determinant())
+    assert abs(s.dot_solve(y) - r.dot_solve(y)) <= 1e-10 * abs(r.dot_solve(y))
+    assert np.allclose(s.solve(y), r.solve(y), rtol=1e-9, atol=1e-12)
+    st, st0 = s.__getstate__(), r.state()
+    assert st[:3] == (True, N, JR + 2 * JC)
+    for a, b in zip(st[4:], st0[4:]):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("JR,JC,N", [(1, 1, 900), (2, 3, 6000), (2, 7, 5000), (0, 16, 4000)])
+def test_hinted_right_hand_side_is_the_same_quadratic_form(JR, JC, N):
+    """GP.log_likelihood announces its residual before the factorisation (solver._hint_rhs): compute then
+    returns resid^T K^-1 resid from its own pass.  Same value as the ordinary dot_solve sweep, only for
+    that very vector, and only once."""
+    rng = np.random.RandomState(JR * 10 + JC)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    yerr = rng.uniform(0.3, 0.5, N)
+    y, y2 = rng.randn(N), rng.randn(N)
+    args = (0.0, np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+            np.zeros(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)),
+            np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t, yerr ** 2)
+    r = ref.RefSolver()
+    r.compute(*args)
+    s = celerite_amd.CholeskySolver()
+    s._hint_rhs(y)
+    s.compute(*args)
+    assert abs(s.dot_solve(y) - r.dot_solve(y)) <= 1e-10 * abs(r.dot_solve(y))        # from compute's pass
+    assert abs(s.dot_solve(y2) - r.dot_solve(y2)) <= 1e-10 * abs(r.dot_solve(y2))     # ordinary sweep
+    assert abs(s.log_determinant() - r.log_determinant()) <= 1e-10 * abs(r.log_determinant())
+    s.compute(*args)                                                                  # the hint is one-shot
+    assert abs(s.dot_solve(y) - r.dot_solve(y)) <= 1e-10 * abs(r.dot_solve(y))
+    # through GP: log_likelihood hints by itself
+    k = terms.RealTerm(log_a=0.1, log_c=-1.0)
+    for j in range(JC):
+        k += terms.ComplexTerm(log_a=-0.5, log_c=-1.0 - 0.1 * j, log_d=0.3 * j)
+    gp = GP(k)
+    gp.compute(t, yerr)
+    ll1 = gp.log_likelihood(y)
+    gp.set_parameter_vector(gp.get_parameter_vector())   # dirty -> recompute with the hint
+    ll2 = gp.log_likelihood(y)
+    assert abs(ll1 - ll2) <= 1e-10 * abs(ll1)

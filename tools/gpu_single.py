@@ -1,48 +1,32 @@
 # -*- coding: utf-8 -*-
-"""Development probe: latency of the single-solver API (the reference's own object API)
-at the sizes of BASELINE config 1 and of the large-N benchmark rows."""
-import os
-import sys
-import time
-
+"""Latency of the reference's object API (one problem per call) across widths and lengths:
+CholeskySolver.compute + dot_solve + log_determinant on the GPU next to the CPU oracle, best of 3
+(celerite/timer.py protocol)."""
+import os, sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import best_of_3
+import celerite_amd
+from oracle import ref
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import celerite_amd  # noqa: E402
-from celerite_amd import GP, terms  # noqa: E402
-from oracle import ref  # noqa: E402
-
-
-def best(fn, reps=5):
-    fn()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-    return min(ts)
-
-
-rng = np.random.RandomState(1)
-for N in (1000, 10000, 100000, 1000000):
-    t = np.sort(rng.rand(N)); yerr = rng.uniform(0.1, 0.2, N); y = np.sin(t)
-    kernel = terms.RealTerm(1.0, 0.1) + terms.RealTerm(1.1, 0.2)
-    for _ in range(3):
-        kernel += terms.ComplexTerm(log_a=0.1, log_c=2.0, log_d=1.6 + 0.1 * rng.randn())
-    gp = GP(kernel)
-    co = kernel.coefficients
-    s = celerite_amd.CholeskySolver()
-    gen = (np.empty(0), np.empty((0, 0)), np.empty((0, 0)))
-    tc = best(lambda: s.compute(0.0, *co, *gen, t, yerr ** 2))
-    td = best(lambda: s.dot_solve(y))
-    ts_ = best(lambda: s.solve(y))
-    tl = best(lambda: s.dot_L(y))
-    tp = best(lambda: s.predict(y, np.linspace(0, 1, 500)))
-    tg = best(lambda: s.grad_log_likelihood(0.0, *co, *gen, t, y, yerr ** 2), reps=2) if N <= 100000 else float("nan")
-    gp.compute(t, yerr)
-    tll = best(lambda: (gp.compute(t, yerr), gp.log_likelihood(y)))
-    r = ref.RefSolver()
-    t0 = time.perf_counter(); r.compute(0.0, *co, *gen, t, yerr ** 2); q0 = r.dot_solve(y); tcpu = time.perf_counter() - t0
-    print("N=%7d width 8: compute %.2f ms dot_solve %.2f solve %.2f dot_L %.2f predict(500) %.2f grad %.1f | GP compute+loglike %.2f ms ; "
-          "CPU oracle compute+dot_solve %.2f ms ; rel err logdet %.1e quad %.1e" % (
-              N, tc * 1e3, td * 1e3, ts_ * 1e3, tl * 1e3, tp * 1e3, tg * 1e3, tll * 1e3, tcpu * 1e3,
-              abs(s.log_determinant() - r.log_determinant()) / abs(r.log_determinant()), abs(s.dot_solve(y) - q0) / abs(q0)), flush=True)
+print("# width | N | GPU ms: compute + dot_solve | GPU ms: hint + compute + dot_solve (GP.log_likelihood) | CPU oracle ms | ratio | parity")
+for JR, JC in [(1, 1), (2, 3), (2, 7), (4, 11), (0, 16)]:
+    for N in (1000, 10000, 100000):
+        rng = np.random.RandomState(JR * 100 + JC)
+        t = np.sort(rng.uniform(0, 0.05 * N, N))
+        yerr = rng.uniform(0.3, 0.5, N)
+        y = rng.randn(N)
+        args = (0.0, np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+                np.zeros(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)),
+                np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t, yerr ** 2)
+        s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+        def gpu():
+            s.compute(*args); return s.dot_solve(y), s.log_determinant()
+        def gpu_hinted():   # what GP.log_likelihood does: the residual is announced before the factorisation
+            s._hint_rhs(y); s.compute(*args); return s.dot_solve(y), s.log_determinant()
+        def cpu():
+            r.compute(*args); return r.dot_solve(y), r.log_determinant()
+        (qg, lg), (qh, lh), (qc, lc) = gpu(), gpu_hinted(), cpu()
+        tg, th, tc = best_of_3(gpu, 0.1), best_of_3(gpu_hinted, 0.1), best_of_3(cpu, 0.1)
+        print("width %2d (%d real + %2d complex)  N=%6d  GPU %8.3f ms  GPU as GP.log_likelihood %8.3f ms  CPU %8.3f ms  CPU/GPU %5.2f  logdet %.1e  dot_solve %.1e / %.1e"
+              % (JR + 2 * JC, JR, JC, N, tg * 1e3, th * 1e3, tc * 1e3, tc / th, abs(lg - lc) / abs(lc), abs(qg - qc) / abs(qc), abs(qh - qc) / abs(qc)), flush=True)
