@@ -56,6 +56,7 @@ def _load():
     lib.clr_batch_set_library_trig.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_summarize_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_summarize_kernel.argtypes = [C.c_void_p, _ip]
+    lib.clr_batch_fp32_probe.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.clr_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
@@ -289,6 +290,14 @@ class BatchedGP(object):
         k = C.c_int()
         _check(_load().clr_batch_get_summarize_kernel(self._h, C.byref(k)))
         return ("single wave", "role split", "role split, lazy decay")[k.value]
+
+    def fp32_probe(self):
+        """``(logdet, quad, ms)`` of the sequential sweep with a float state (widths 9..32;
+        a measurement of the fp32 tolerance, ``clr_batch_fp32_probe``)."""
+        ld, q = np.empty(self.B), np.empty(self.B)
+        ms = C.c_double()
+        _check(_load().clr_batch_fp32_probe(self._h, _ptr(ld), _ptr(q), C.byref(ms)))
+        return ld, q, ms.value
 
     def set_library_trig(self, force=True):
         """Use the library (ocml) sincos instead of the FMA Cody-Waite routine

@@ -1486,6 +1486,36 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   return CLR_OK;
 }
 
+int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (h->launch || h->J > clr::wide_f32_probe_max_width())
+    return fail(CLR_UNSUPPORTED, "the fp32 probe covers widths 9..32");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t B = (size_t)h->B;
+  DevBuf tmp;
+  if ((st = tmp.reserve(2 * B)) != CLR_OK) return st;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  clr::launch_wide_f32_probe(P, h->J_real, h->J_comp, tmp.p, tmp.p + B, h->stream);  // warm-up
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  clr::launch_wide_f32_probe(P, h->J_real, h->J_comp, tmp.p, tmp.p + B, h->stream);
+  HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipGetLastError());
+  if (logdet) HIP_TRY(hipMemcpyAsync(logdet, tmp.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (quad) HIP_TRY(hipMemcpyAsync(quad, tmp.p + B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  if (ms) *ms = t;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  tmp.release();
+  return CLR_OK;
+}
+
 int clr_batch_synchronize(clr_batch* h) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;

@@ -715,6 +715,9 @@ const BatchLaunchers* find_batch_launchers(int JR, int JC);
 // prefix phase at the padded widths of the wide scan (16: 2 problems per wave, 32: one)
 void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s);
 int wide_scan_max_width();
+// fp32-state sequential sweep (a measurement for BASELINE config 5, wide_kernels.hip)
+int wide_f32_probe_max_width();
+void launch_wide_f32_probe(const BatchParams& P, int JR, int JC, double* out_logdet, double* out_quad, hipStream_t s);
 void launch_wide_summarize(const BatchParams& P, int JR, int JC, hipStream_t s);
 void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s);
 // widths 9..wide_max_width(): one wave per problem, sequential in n (wide_kernels.hip)

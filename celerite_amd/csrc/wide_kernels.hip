@@ -501,6 +501,157 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// fp32 probe (BASELINE config 5: "fp32 vs fp64 tolerance"): the sequential sweep of wide_scan_kernel
+// MODE 0 with the STATE and every per-step operation in float -- S, f, q, D, z, w, x, the LDS
+// exchanges and the DPP reductions -- while the features (absolute phases d t, decays) are evaluated
+// in fp64 and rounded, and log det / the quadratic form are accumulated in fp64 from the float pivots
+// (the arrangement tools/fp32_tolerance.py emulates in NumPy).  A measurement, not a product path:
+// it answers on the device what a float state costs in accuracy and buys in time at width <= 32.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+  return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value_f32(float v, int k) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+template <int LPR>
+__device__ __forceinline__ float row_sum_f32(float v) {
+  if (LPR < 2) v = dpp_add_f32<DPP_QUAD_XOR1>(v);
+  if (LPR < 4) v = dpp_add_f32<DPP_QUAD_XOR2>(v);
+  v = dpp_add_f32<DPP_HALF_MIRROR>(v);
+  v = dpp_add_f32<DPP_MIRROR>(v);
+  return (lane_value_f32(v, 0) + lane_value_f32(v, 16)) + (lane_value_f32(v, 32) + lane_value_f32(v, 48));
+}
+
+template <int WMAX, bool FAST>
+__global__ void __launch_bounds__(64) wide_f32_kernel(const BatchParams P, int JR, int JC, double* out_logdet,
+                                                      double* out_quad) {
+  using G = WideGeom<WMAX>;
+  constexpr int LPR = G::LPR, COLS = G::COLS;
+  __shared__ __attribute__((aligned(16))) float ubuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) float pbuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) float wbuf[WMAX];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int row = lane / LPR, seg = lane % LPR;
+  const int W = JR + 2 * JC;
+  const bool writer = seg == 0;
+  RowCoeffs rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (row < JR) {
+    rc.u0 = P.a_real[(long)b * JR + row]; rc.v0 = 1.0; rc.c = P.c_real[(long)b * JR + row];
+  } else if (row < W) {
+    const int j = (row - JR) >> 1;
+    const double a = P.a_comp[(long)b * JC + j], bb = P.b_comp[(long)b * JC + j];
+    if (((row - JR) & 1) == 0) { rc.uc = a; rc.us = bb; rc.vc = 1.0; }
+    else                       { rc.uc = -bb; rc.us = a; rc.vs = 1.0; }
+    rc.c = P.c_comp[(long)b * JC + j];
+    rc.d = P.d_comp[(long)b * JC + j];
+  }
+  double sum_ar = 0.0, sum_ac = 0.0;
+  for (int j = 0; j < JR; ++j) sum_ar += P.a_real[(long)b * JR + j];
+  for (int j = 0; j < JC; ++j) sum_ac += P.a_comp[(long)b * JC + j];
+  const float a0 = (float)((sum_ar + sum_ac) + P.jitter[b]);
+  const double* tp = P.t + b * P.t_stride;
+  const double* dp = P.diag + b * P.diag_stride;
+  const double* yp = P.y + b * P.y_stride;
+  const int N = P.N;
+  float S[COLS], f = 0.0f;
+#pragma unroll
+  for (int c = 0; c < COLS; ++c) S[c] = 0.0f;
+  double quad = 0.0;
+  LogProduct lp;
+  lp.init();
+  double tv, dv, yv, tv2;
+  {
+    const int m = lane;
+    tv = m < N ? tp[m] : 0.0; dv = m < N ? dp[m] : 0.0; yv = m < N ? yp[m] : 0.0;
+    tv2 = m + 64 < N ? tp[m + 64] : 0.0;
+  }
+  auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };
+  double ud, vd, phd;
+  row_features<FAST>(rc, t_at(0), 1 < N ? t_at(1) - t_at(0) : 0.0, &ud, &vd, &phd);
+  float u = (float)ud, v = (float)vd, phi = (float)phd;
+  if (writer) { ubuf[0][row] = u; pbuf[0][row] = phi; }
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int nend = (N - n0 < 64) ? N - n0 : 64;
+    for (int k = 0; k < nend; ++k) {
+      const int n = n0 + k, cur = n & 1;
+      const float diag_n = (float)lane_value(dv, k);
+      const float y_n = (float)lane_value(yv, k);
+      float u1 = 0.0f, v1 = 0.0f, phi1 = 1.0f;
+      if (n + 1 < N) {
+        const double t1 = t_at(k + 1);
+        const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        row_features<FAST>(rc, t1, dx1, &ud, &vd, &phd);
+        u1 = (float)ud; v1 = (float)vd; phi1 = (float)phd;
+        if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
+      }
+      float q = 0.0f;
+      {
+        const float4* uv = reinterpret_cast<const float4*>(&ubuf[cur][seg * COLS]);
+#pragma unroll
+        for (int c = 0; c < COLS / 4; ++c) {
+          const float4 uu = uv[c];
+          q = fmaf(S[4 * c], uu.x, q); q = fmaf(S[4 * c + 1], uu.y, q);
+          q = fmaf(S[4 * c + 2], uu.z, q); q = fmaf(S[4 * c + 3], uu.w, q);
+        }
+      }
+      if (LPR >= 2) q = dpp_add_f32<DPP_QUAD_XOR1>(q);
+      if (LPR >= 4) q = dpp_add_f32<DPP_QUAD_XOR2>(q);
+      const float s = row_sum_f32<LPR>(u * q), ub = row_sum_f32<LPR>(u * f);
+      const float D = (diag_n + a0) - s;
+      const float invD = 1.0f / D;
+      const float x = y_n - ub;
+      lp.mul((double)D);
+      quad += (double)x * (double)x / (double)D;
+      const float z = v - q;
+      const float w = z * invD;
+      if (writer) wbuf[row] = phi * w;
+      {
+        const float4* pv = reinterpret_cast<const float4*>(&pbuf[cur][seg * COLS]);
+        const float4* wv = reinterpret_cast<const float4*>(&wbuf[seg * COLS]);
+        const float zr = phi * z;
+#pragma unroll
+        for (int c = 0; c < COLS / 4; ++c) {
+          const float4 pk = pv[c], pw = wv[c];
+          S[4 * c] = fmaf(zr, pw.x, (phi * pk.x) * S[4 * c]);
+          S[4 * c + 1] = fmaf(zr, pw.y, (phi * pk.y) * S[4 * c + 1]);
+          S[4 * c + 2] = fmaf(zr, pw.z, (phi * pk.z) * S[4 * c + 2]);
+          S[4 * c + 3] = fmaf(zr, pw.w, (phi * pk.w) * S[4 * c + 3]);
+        }
+      }
+      f = phi * (f + w * x);
+      u = u1; v = v1; phi = phi1;
+    }
+    const int m = n0 + 64 + lane;
+    tv = tv2;
+    dv = m < N ? dp[m] : 0.0;
+    yv = m < N ? yp[m] : 0.0;
+    tv2 = m + 64 < N ? tp[m + 64] : 0.0;
+  }
+  if (lane == 0) {
+    out_logdet[b] = lp.log_value();
+    out_quad[b] = quad;
+  }
+}
+
+}  // namespace
+
+int wide_f32_probe_max_width() { return 32; }
+void launch_wide_f32_probe(const BatchParams& P, int JR, int JC, double* out_logdet, double* out_quad, hipStream_t s) {
+  const int W = JR + 2 * JC;
+  const dim3 grid(P.B);
+#define CLR_GO(WM)                                                                                              \
+  do {                                                                                                          \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_f32_kernel<WM, true>), grid, dim3(64), 0, s, P, JR, JC, out_logdet, out_quad);  \
+    else hipLaunchKernelGGL((wide_f32_kernel<WM, false>), grid, dim3(64), 0, s, P, JR, JC, out_logdet, out_quad);             \
+  } while (0)
+  if (W <= 16) CLR_GO(16); else CLR_GO(32);
+#undef CLR_GO
+}
+
+namespace {
 }  // namespace
 
 int wide_max_width() { return 64; }

@@ -306,6 +306,12 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
 int clr_batch_set_profiling(clr_batch* h, int on);
 int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps);
 
+/* A measurement, not a product path (BASELINE config 5 asks for the fp32-vs-fp64 tolerance of the wide
+ * recurrence): the sequential sweep of a width 9..32 plan with the state and every per-step operation in
+ * float (features in fp64, rounded; log det and the quadratic form accumulated in fp64 from the float
+ * pivots).  Returns per-problem log det / quadratic form and the kernel's time for the whole batch. */
+int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms);
+
 /* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,
                              const double* jitter,

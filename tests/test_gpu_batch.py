@@ -597,3 +597,26 @@ def test_config5_full_shape():
     the oracle on a sample of 4 problems (71 ms each), properties over all 256."""
     levels = _full_shape(256, 100000, 0, 16, sample=4, d_spread=True, seed=11)
     assert (levels <= 1).all()   # a few borderline problems take the checked chunked replay; none the sequential sweep
+
+
+def test_fp32_state_tolerance_at_width_32():
+    """BASELINE config 5, "fp32 vs fp64 tolerance": the sequential sweep with the state and all per-step
+    arithmetic in float (features in fp64) against the fp64 path on the same device.  The float state costs
+    five to seven digits -- far above the 1e-10 bar, which is why the product has no fp32 path -- and this
+    test pins the measured envelope: worse than 1e-9 (it really is float), better than 1e-3."""
+    import bench
+    coeffs, t, diag, y = bench.make_inputs(32, 20000, 0, 16, 11, d_spread=True)
+    plan = batch.BatchedGP(32, 20000, 0, 16)
+    try:
+        plan.set_chunks(1)
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs)
+        ll, ld, q, st = plan.log_likelihood()
+        ld32, q32, ms = plan.fp32_probe()
+    finally:
+        plan.close()
+    e_ld = np.abs(ld32 - ld) / np.abs(ld)
+    e_q = np.abs(q32 - q) / np.abs(q)
+    assert (st == 0).all() and np.isfinite(ld32).all() and np.isfinite(q32).all()
+    assert 1e-9 < e_ld.max() < 1e-3, e_ld.max()
+    assert 1e-9 < e_q.max() < 1e-3, e_q.max()
