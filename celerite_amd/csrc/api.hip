@@ -603,6 +603,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
     P.force_exact = 1;       // the factor is wanted: every chunk is replayed (and checked against the scan)
     P.wide_materialize = 1;
+    P.coop_prefix = 1;
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;

@@ -678,11 +678,174 @@ static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
 #undef CLR_GO
 }
 
+// ---------------------------------------------------------------------------
+// prefix at the padded width 32 on the matrix cores.  One wave per problem walks its chunks; per chunk
+// (advance part of chunk_update, clr_core.h):
+//     M^T = I + P Jm ;  [M^T | P] --Gauss-Jordan, partial pivoting--> [I | G] ;  Gs = (G + G^T) / 2
+//     h = f + P eta ; g = h - G (Jm h) ;  P' = C + (A Gs) A^T ;  f' = A g + b
+// All matrices live in LDS (row stride 33 doubles).  The three 32 x 32 x 32 products -- the one dense
+// contraction of the whole path -- run as v_mfma_f64_16x16x4_f64: per product 4
+// output tiles x 8 k-steps = 32 MFMA instructions, operands read from LDS in the instruction's lane
+// layout (A: lane l holds X[m = l & 15][k = l >> 4]; B: Y[k = l >> 4][n = l & 15]; C/D: 4 doubles,
+// row (l >> 4) + 4 r, column l & 15).  The elimination works on the 32 x 64 tableau in LDS, lane =
+// column: per pivot every lane reads the 32 multipliers (broadcast reads) and updates its own column.
+// prefix_coop_kernel<32, 32> did the same algebra with one column per lane in REGISTERS: 512 registers,
+// 1 KB of scratch, a ds_bpermute per broadcast -- 300 us per chunk, 97 % of it moving data between lanes.
+// ---------------------------------------------------------------------------
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+
+struct Prefix32Lds {
+  static constexpr int J = 32, LD = 33, LT = 66;
+  double P[J * LD], Jf[J * LD], A[J * LD], X[J * LD], C[J * LD], T[J * LT];
+  double f[J], h[J], v[J], g[J], eta[J], b[J];
+};
+
+// Z = X Y (+ Z0) for 32 x 32 matrices in LDS; YT: Y is given transposed (Y[k][n] = Yt[n][k]);
+// IDENT: add the identity; Z0 (may alias nothing written here) initialises the accumulators
+template <bool YT, bool IDENT>
+__device__ __forceinline__ void mfma_32x32x32(const double* X, int ldx, const double* Y, int ldy, const double* Z0,
+                                               int ldz0, double* Z, int ldz, int lane) {
+  const int lm = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      mfma_acc_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lm;
+        double init = Z0 ? Z0[row * ldz0 + col] : 0.0;
+        if (IDENT && row == col) init += 1.0;
+        acc[r] = init;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int k = 4 * ks + lk;
+        const double a = X[(16 * ti + lm) * ldx + k];
+        const double bb = YT ? Y[(16 * tj + lm) * ldy + k] : Y[k * ldy + 16 * tj + lm];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Z[(16 * ti + lk + 4 * r) * ldz + 16 * tj + lm] = acc[r];
+    }
+  }
+}
+
+// one wave per workgroup: its LDS operations execute in program order, so phases that exchange data
+// between LANES through LDS only need the compiler not to reorder them and the reads to have landed
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ void __launch_bounds__(64) wide_prefix32_kernel(const BatchParams P_) {
+  constexpr int J = 32, SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
+  constexpr int LD = Prefix32Lds::LD, LT = Prefix32Lds::LT;
+  __shared__ Prefix32Lds L;
+  const int lane = threadIdx.x, prob = blockIdx.x;
+  if (lane == 0) P_.need_exact[prob] = 0;  // raised by wide_correct_kernel / decide_kernel
+  for (int idx = lane; idx < J * J; idx += 64) L.P[(idx / J) * LD + idx % J] = 0.0;
+  if (lane < J) L.f[lane] = 0.0;
+  wave_lds_fence();
+  for (int c = 0; c + 1 < P_.nchunk; ++c) {
+    const double* E = P_.elems + ((long)prob * P_.nchunk + c) * ELEM;
+    const double* Eb = E + J * J;
+    const double* EC = Eb + J;
+    const double* Eeta = EC + SZ;
+    const double* EJm = Eeta + J;
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      L.A[i * LD + j] = E[idx];
+      L.C[i * LD + j] = EC[sym(i, j)];
+      L.Jf[i * LD + j] = EJm[sym(i, j)];
+      L.T[i * LT + J + j] = L.P[i * LD + j];  // right half of the tableau: P
+    }
+    if (lane < J) { L.b[lane] = Eb[lane]; L.eta[lane] = Eeta[lane]; }
+    wave_lds_fence();
+    // M^T = I + P Jm -> left half of the tableau
+    mfma_32x32x32<false, true>(L.P, LD, L.Jf, LD, nullptr, 0, L.T, LT, lane);
+    // h = f + P eta
+    if (lane < J) {
+      double acc = L.f[lane];
+#pragma unroll 8
+      for (int j = 0; j < J; ++j) acc += L.P[lane * LD + j] * L.eta[j];
+      L.h[lane] = acc;
+    }
+    wave_lds_fence();
+    if (lane < J) {  // v = Jm h
+      double acc = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < J; ++j) acc += L.Jf[lane * LD + j] * L.h[j];
+      L.v[lane] = acc;
+    }
+    // Gauss-Jordan with partial pivoting, lane = column of [M^T | P]
+    for (int col = 0; col < J; ++col) {
+      int piv = col;
+      double best = -1.0;
+      for (int i = col; i < J; ++i) {  // (every lane scans the pivot column: broadcast reads)
+        const double cand = fabs(L.T[i * LT + col]);
+        if (cand > best) { best = cand; piv = i; }
+      }
+      const double top = L.T[piv * LT + lane], old = L.T[col * LT + lane];
+      const double pv = L.T[piv * LT + col];
+      wave_lds_fence();
+      const double t = top * (1.0 / pv);
+      L.T[piv * LT + lane] = old;   // row swap (a no-op when piv == col) ...
+      wave_lds_fence();
+      L.T[col * LT + lane] = t;     // ... and the scaled pivot row
+      wave_lds_fence();
+      double m[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i) m[i] = L.T[i * LT + col];
+      wave_lds_fence();
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+        if (i != col) L.T[i * LT + lane] = fma(-m[i], t, L.T[i * LT + lane]);
+      wave_lds_fence();
+    }
+    // Gs = (G + G^T) / 2 -> Jf (Jm is no longer needed); g = h - G v
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      L.Jf[i * LD + j] = 0.5 * (L.T[i * LT + J + j] + L.T[j * LT + J + i]);
+    }
+    if (lane < J) {
+      double acc = L.h[lane];
+#pragma unroll 8
+      for (int j = 0; j < J; ++j) acc -= L.T[lane * LT + J + j] * L.v[j];
+      L.g[lane] = acc;
+    }
+    wave_lds_fence();
+    // X = A Gs ; P' = C + X A^T ; f' = A g + b
+    mfma_32x32x32<false, false>(L.A, LD, L.Jf, LD, nullptr, 0, L.X, LD, lane);
+    if (lane < J) {
+      double acc = L.b[lane];
+#pragma unroll 8
+      for (int j = 0; j < J; ++j) acc += L.A[lane * LD + j] * L.g[j];
+      L.f[lane] = acc;
+    }
+    wave_lds_fence();
+    mfma_32x32x32<true, false>(L.X, LD, L.A, LD, L.C, LD, L.P, LD, lane);
+    wave_lds_fence();
+    // start state of chunk c + 1: packed upper triangle (mirrored into the lower one for the next round) | f
+    double* o = P_.starts + ((long)prob * P_.nchunk + c + 1) * START;
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      if (i <= j) o[tri(i, j)] = L.P[i * LD + j];
+    }
+    if (lane < J) o[SZ + lane] = L.f[lane];
+    wave_lds_fence();
+    for (int idx = lane; idx < J * J; idx += 64) {
+      const int i = idx / J, j = idx % J;
+      if (i > j) L.P[i * LD + j] = L.P[j * LD + i];
+    }
+    wave_lds_fence();
+  }
+}
+
 void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
   if (P.nchunk < 2) return;
   if (width_padded <= 16)
     hipLaunchKernelGGL((prefix_coop_kernel<16, 16>), dim3((P.B + 1) / 2), dim3(64), 0, s, P);
-  else
+  else if (P.coop_prefix)
+    hipLaunchKernelGGL(wide_prefix32_kernel, dim3(P.B), dim3(64), 0, s, P);
+  else  // (clr_batch_set_prefix_mode(h, 0): the register-resident kernel of round 1, kept for A/B)
     hipLaunchKernelGGL((prefix_coop_kernel<32, 32>), dim3(P.B), dim3(64), 0, s, P);
 }
 
