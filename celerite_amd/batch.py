@@ -64,6 +64,7 @@ def _load():
     lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_get_exact_flags.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_get_conditioning.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.clr_batch_get_conditioning_chunkwise.argtypes = [C.c_void_p, _dp]
     lib.clr_batch_set_certificate.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.clr_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.clr_sharded_create.restype = C.c_void_p
@@ -278,6 +279,11 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_conditioning(self._h, _ptr(g), _ptr(m), _ptr(r)))
         self.last_residual = r
         return g, m
+
+    def conditioning_chunkwise(self):
+        r = np.empty(self.B)
+        _check(_load().clr_batch_get_conditioning_chunkwise(self._h, _ptr(r)))
+        return r
 
     def set_summarize_mode(self, mode=-1):
         """summarize kernel of widths 7, 8: 0 single wave, 1 two roles on two waves per

@@ -262,6 +262,8 @@ int clr_batch_get_exact_flags(clr_batch* h, int* level /* [B] */);
  * relative mismatch between a replayed chunk's end state and the scanned start state of the
  * next chunk.  Any pointer may be NULL. */
 int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max);
+/* ... and max over chunks of gamma_c / mu_c taken chunk by chunk (diagnostic). */
+int clr_batch_get_conditioning_chunkwise(clr_batch* h, double* ratio_max);
 /* Routing of ill-conditioned problems.  A problem whose gamma_max / mu_min reaches
  * max_gamma_over_mu (default 1e6; <= 0: never) is not settled from the chunk summaries: the
  * chunked replay (the reference recurrence from the scanned start states, parallel over chunks)
