@@ -1199,13 +1199,13 @@ static bool lazy_eligible(const clr_batch* h) {
 }
 
 static bool split_active(const clr_batch* h) {
-  // explicit modes 1 / 2, or auto (-1): width 8 on a densely sampled series, where the split kernel
+  // explicit modes 1 / 2, or auto (-1): widths 7 and 8 on a densely sampled series, where the split kernel
   // with the decay factored out of the state (lazy) is the faster one for every shape (2.6-2.7 ms
   // against 3.1-3.6: profiles/r02t_lazy_ab.txt); without the lazy decay it only wins with >= 2 complex
-  // terms (r02h_split_ab.txt), so sparse series and width 7 stay single-wave
+  // terms (r02h_split_ab.txt), so sparse series stay single-wave; width 7: 2.16-2.31 against 2.30-2.50 ms
   if (!(h->launch && h->nchunk > 1 && clr::have_summarize_split(h->J_real, h->J_comp))) return false;
   if (h->summarize_mode > 0) return true;
-  return h->summarize_mode < 0 && h->J == 8 && lazy_eligible(h);
+  return h->summarize_mode < 0 && h->J >= 7 && lazy_eligible(h);
 }
 
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
