@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-__all__ = ["BatchedGP", "ShardedBatchedGP", "shard_bounds", "batch_log_likelihood",
+__all__ = ["BatchedGP", "ShardedBatchedGP", "shard_bounds", "batch_log_likelihood", "batch_grad_log_likelihood",
            "kernel_coefficient_table", "LIB_PATH"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcelerite_hip.so")
@@ -473,6 +473,36 @@ def batch_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag
         return plan.log_likelihood()
     finally:
         plan.close()
+
+
+def batch_grad_log_likelihood(a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, jitter=0.0, device=0):
+    """Value and coefficient gradient of B problems at once (``clr_batch_grad_log_likelihood``): returns
+    ``(value[B], grad[B, 1 + 2 J_real + 4 J_comp], status[B])`` with the reference's conventions per
+    problem (``CholeskySolver.grad_log_likelihood``, solver.cpp:347-463; its ``pi log N`` constant)."""
+    lib = _load()
+    a_real = np.atleast_2d(_f64(a_real))
+    B, JR = a_real.shape
+    a_comp = _f64(a_comp).reshape(B, -1)
+    JC = a_comp.shape[1]
+    blocks = [a_real, _f64(c_real, (B, JR)), a_comp, _f64(b_comp, (B, JC)), _f64(c_comp, (B, JC)), _f64(d_comp, (B, JC))]
+    N = np.asarray(t).shape[-1]
+    arrs, strides = [], []
+    for a in (t, diag, y):
+        a = _f64(a)
+        strides.append(0 if a.shape == (N,) else N)
+        if a.shape not in ((N,), (B, N)):
+            raise ValueError("dimension mismatch")
+        arrs.append(a)
+    jit = np.ascontiguousarray(np.broadcast_to(np.asarray(jitter, dtype=np.float64), (B,)))
+    NG = 1 + 2 * JR + 4 * JC
+    value, grad, st = np.empty(B), np.empty((B, NG)), np.empty(B, dtype=np.int32)
+    lib.clr_batch_grad_log_likelihood.argtypes = ([C.c_int] * 4 + [_dp] * 7 + [_dp, C.c_long] * 3 +
+                                                  [_dp, _dp, _ip, C.c_int])
+    _check(lib.clr_batch_grad_log_likelihood(B, N, JR, JC, _ptr(jit), *[_ptr(b) for b in blocks],
+                                             _ptr(arrs[0]), strides[0], _ptr(arrs[1]), strides[1],
+                                             _ptr(arrs[2]), strides[2], _ptr(value), _ptr(grad),
+                                             st.ctypes.data_as(_ip), int(device)))
+    return value, grad, st
 
 
 def kernel_coefficient_table(kernel, parameter_vectors):

@@ -1078,7 +1078,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
       // (4096 / B since the prefix runs on the matrix cores: 0.09 ms per chunk instead of 0.3; the
       //  summarize waves then take two rounds of half the length, the checked replay of borderline
       //  problems is twice as short: config 4 32.3 -> 29.1 ms)
-      nchunk = 4096 / h->B;
+      nchunk = h->B <= 1024 ? 4096 / h->B : 1;  // (above 1024 problems one sweep per problem already fills a round)
       if (nchunk < 2) nchunk = 1;
       if (nchunk > 16) nchunk = 16;
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
@@ -1637,6 +1637,74 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   if (kernel_ms)
     for (int j = 0; j < NK; ++j) kernel_ms[j] = k[j];
   return CLR_OK;
+}
+
+int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,
+                                  const double* a_real, const double* c_real, const double* a_comp,
+                                  const double* b_comp, const double* c_comp, const double* d_comp,
+                                  const double* t, long t_stride, const double* diag, long diag_stride,
+                                  const double* y, long y_stride, double* value, double* grad, int* status,
+                                  int device) {
+  if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) return fail(CLR_INVALID_ARGUMENT, "bad sizes");
+  if (J_real + 2 * J_comp < 1 || J_real + 2 * J_comp > 64) return fail(CLR_UNSUPPORTED, "widths 1..64");
+  for (long sd : {t_stride, diag_stride, y_stride})
+    if (sd != 0 && sd != N) return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
+  int st = require_device(device);
+  if (st != CLR_OK) return st;
+  const size_t Bn = (size_t)B, nr = Bn * J_real, nc = Bn * J_comp, NG = 1 + 2 * (size_t)J_real + 4 * (size_t)J_comp;
+  auto count = [&](long sd) { return (size_t)(sd == 0 ? N : (long)N * B); };
+  hipStream_t stream;
+  HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  DevBuf buf, out;
+  int* dstatus = nullptr;
+  auto done = [&](int code) {
+    buf.release(); out.release();
+    if (dstatus) (void)hipFree(dstatus);
+    (void)hipStreamDestroy(stream);
+    return code;
+  };
+  // one staging vector: coefficients | jitter | t | diag | y
+  std::vector<double> host;
+  auto put = [&](const double* p, size_t n) { const size_t at = host.size(); if (n) host.insert(host.end(), p, p + n); return at; };
+  const size_t o_ar = put(a_real, nr), o_cr = put(c_real, nr), o_ac = put(a_comp, nc), o_bc = put(b_comp, nc),
+               o_cc = put(c_comp, nc), o_dc = put(d_comp, nc), o_j = put(jitter, Bn);
+  const size_t o_t = put(t, count(t_stride)), o_d = put(diag, count(diag_stride)), o_y = put(y, count(y_stride));
+  if ((st = upload(buf, host.data(), host.size(), stream)) != CLR_OK) return done(st);
+  if ((st = out.reserve(Bn * (NG + 1))) != CLR_OK) return done(st);
+  if (hipMalloc(reinterpret_cast<void**>(&dstatus), Bn * sizeof(int)) != hipSuccess) return done(fail(CLR_HIP_ERROR, "hipMalloc failed"));
+  clr::GradParams P;
+  memset(&P, 0, sizeof(P));
+  const double* base = buf.p;
+  P.N = N; P.J_real = J_real; P.J_comp = J_comp; P.J_general = 0;
+  P.a_real = base + o_ar; P.c_real = base + o_cr; P.a_comp = base + o_ac; P.b_comp = base + o_bc;
+  P.c_comp = base + o_cc; P.d_comp = base + o_dc;
+  P.jitter_b = base + o_j;
+  P.t = base + o_t; P.diag = base + o_d; P.y = base + o_y;
+  P.t_stride = t_stride; P.diag_stride = diag_stride; P.y_stride = y_stride;
+  P.B = B;
+  {
+    double dmax = 0.0;
+    for (size_t i = 0; i < nc; ++i) { const double m = fabs(d_comp[i]); if (!(m <= dmax)) dmax = m; }
+    P.fast_trig = (dmax * max_abs(t, (long)count(t_stride)) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+  }
+  P.out_value = out.p; P.out_grad = out.p + Bn; P.out_status = dstatus;
+  clr::launch_grad(P, stream);
+  if (hipGetLastError() != hipSuccess) return done(fail(CLR_HIP_ERROR, "grad kernel launch failed"));
+  std::vector<double> back(Bn * (NG + 1));
+  std::vector<int> hst(Bn);
+  if (hipMemcpyAsync(back.data(), out.p, back.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipMemcpyAsync(hst.data(), dstatus, Bn * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return done(fail(CLR_HIP_ERROR, "copy back failed"));
+  for (size_t b = 0; b < Bn; ++b) {
+    const bool bad = hst[b] != CLR_OK;
+    if (status) status[b] = hst[b];
+    if (value) value[b] = bad ? -INFINITY : back[b];
+    if (grad)
+      for (size_t g = 0; g < NG; ++g) grad[b * NG + g] = bad ? 0.0 : back[Bn + b * NG + g];
+    if (grad && !(jitter[b] > 2.220446049250313e-16)) grad[b * NG] = 0.0;  // solver.cpp:379-389,419-426
+  }
+  return done(CLR_OK);
 }
 
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,

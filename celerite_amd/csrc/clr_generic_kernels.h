@@ -58,6 +58,12 @@ struct GradParams {
   double* out_value;            // [1]  -(quad + log det + pi log N) / 2
   double* out_grad;             // [1 + 2 J_real + 4 J_comp]
   int* out_status;              // [1]
+  // batched form (clr_batch_grad_log_likelihood; no general terms): blockIdx.y = problem b reads its own
+  // coefficient rows ([B][J_real] / [B][J_comp]), jitter_b[b], series b * stride, and writes value[b],
+  // grad[b][...], status[b].  B == 0: the single-problem call above.
+  int B;
+  const double* jitter_b;
+  long t_stride, diag_stride, y_stride;
 };
 void launch_grad(const GradParams& P, hipStream_t s);
 

@@ -32,7 +32,17 @@ namespace clr {
 namespace {
 
 template <int WMAX, bool FAST>
-__global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams P) {
+__global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
+  GradParams P = Pin;
+  if (Pin.B > 0) {  // batched: shift every pointer to problem blockIdx.y (wave-uniform)
+    const long b = blockIdx.y;
+    const int NG = 1 + 2 * Pin.J_real + 4 * Pin.J_comp;
+    P.a_real += b * Pin.J_real; P.c_real += b * Pin.J_real;
+    P.a_comp += b * Pin.J_comp; P.b_comp += b * Pin.J_comp; P.c_comp += b * Pin.J_comp; P.d_comp += b * Pin.J_comp;
+    P.jitter = Pin.jitter_b[b];
+    P.t += b * Pin.t_stride; P.diag += b * Pin.diag_stride; P.y += b * Pin.y_stride;
+    P.out_value += b; P.out_grad += b * NG; P.out_status += b;
+  }
   using G = WideGeom<WMAX>;
   constexpr int LPR = G::LPR, COLS = G::COLS;
   __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX], dubuf[2][WMAX];
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams P) {
 
 void launch_grad(const GradParams& P, hipStream_t s) {
   const int W = P.J_real + 2 * P.J_comp + P.J_general;
-  const dim3 grid(1 + 2 * P.J_real + 4 * P.J_comp);
+  const dim3 grid(1 + 2 * P.J_real + 4 * P.J_comp, P.B > 0 ? P.B : 1);
 #define CLR_GO(WM)                                                                           \
   do {                                                                                       \
     if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<WM, true>), grid, dim3(64), 0, s, P); \

@@ -326,6 +326,20 @@ int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,
                              double* loglike, double* logdet, double* quad,
                              int* status, int device);
 
+/* Batched grad_log_likelihood (celerite/solver.cpp:347-463 per problem; no general terms): one wave per
+ * (problem, partial derivative), the forward-mode tangent recurrence of csrc/grad_kernels.hip.  Host
+ * pointers in and out, one shot.  value[b] = -(y^T K^-1 y + log det K + pi log N) / 2 (the reference's
+ * constant, solver.cpp:415), grad is [B][1 + 2 J_real + 4 J_comp] in the order jitter, a_real, c_real,
+ * a_comp, b_comp, c_comp, d_comp (d/d jitter = 0 where jitter <= DBL_EPSILON, solver.cpp:379-389);
+ * status[b] = CLR_NOT_POSITIVE_DEFINITE gives value -inf and a zero gradient (GP's quiet semantics,
+ * celerite.py:285-291).  Widths 1..64. */
+int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,
+                                  const double* a_real, const double* c_real, const double* a_comp,
+                                  const double* b_comp, const double* c_comp, const double* d_comp,
+                                  const double* t, long t_stride, const double* diag, long diag_stride,
+                                  const double* y, long y_stride, double* value, double* grad, int* status,
+                                  int device);
+
 /* ---- the batch axis over several GPUs (BASELINE config 4) ---------
  * Problems are independent -- every member of the reference solver is per object
  * (cholesky.h:703-706) -- so the batch axis shards embarrassingly: shard s of S owns the

@@ -620,3 +620,38 @@ def test_fp32_state_tolerance_at_width_32():
     assert (st == 0).all() and np.isfinite(ld32).all() and np.isfinite(q32).all()
     assert 1e-9 < e_ld.max() < 1e-3, e_ld.max()
     assert 1e-9 < e_q.max() < 1e-3, e_q.max()
+
+
+@pytest.mark.parametrize("JR,JC,N,shared", [(2, 1, 400, False), (1, 3, 1500, True), (0, 5, 600, False)])
+def test_batched_grad_log_likelihood(JR, JC, N, shared):
+    """clr_batch_grad_log_likelihood: B problems x (1 + 2 J_real + 4 J_comp) partials, one wave each, against
+    the single-problem entry (itself pinned against oracle/grad.py in test_gpu_solver.py) and the oracle."""
+    from oracle import grad as ograd
+    import celerite_amd
+    B = 7
+    case = synthetic(B, N, JR, JC, "accuracy", seed=31 + JR)
+    if shared:
+        case["t"], case["diag"], case["y"] = case["t"][0], case["diag"][0], case["y"][0]
+    jit = np.linspace(0.0, 0.3, B)
+    (case["a_real"] if JR else case["a_comp"])[2:3] *= -50.0   # an indefinite problem in the middle of the batch
+    value, grad, st = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
+    empty, empty2 = np.empty(0), np.empty((0, 0))
+    for b in range(B):
+        tb = case["t"] if shared else case["t"][b]
+        db = case["diag"] if shared else case["diag"][b]
+        yb = case["y"] if shared else case["y"][b]
+        co = [c[b] for c in coeffs_of(case)]
+        s = celerite_amd.CholeskySolver()
+        try:
+            v1, g1 = s.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, tb, yb, db)
+        except celerite_amd.solver.LinAlgError:
+            assert st[b] == 2 and np.isneginf(value[b]) and not grad[b].any()
+            continue
+        assert st[b] == 0
+        assert abs(value[b] - v1) <= 1e-12 * abs(v1)
+        assert np.allclose(grad[b], g1, rtol=1e-11, atol=1e-13)
+        if b in (0, B - 1):
+            v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, tb, yb, db)
+            assert abs(value[b] - v0) <= 1e-10 * abs(v0)
+            assert np.allclose(grad[b], g0, rtol=1e-8, atol=1e-10)
+    assert (st == 2).sum() >= 1
