@@ -340,15 +340,17 @@ def main(argv=None):
     ndev = batch.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: libcelerite_hip has no CPU path")
-    if dist.local_rank >= ndev:
+    if dist.local_rank >= ndev and not os.environ.get("CLR_BENCH_SHARE_GPU"):
         raise SystemExit("rank %d has no GPU of its own (%d visible)" % (dist.local_rank, ndev))
+    # (CLR_BENCH_SHARE_GPU=1: ranks share the visible GPUs -- only to exercise the multi-rank code path
+    #  on a one-GPU box; the numbers of such a run mean nothing)
     B, N, JR, JC = args.batch, args.nsamples, args.jreal, args.jcomp
     W = JR + 2 * JC
     K, Wm = max(args.steps, 1), max(args.warmup, 0)
 
     coeffs, t, diag, y = make_inputs(B, N, JR, JC, seed=42 + dist.rank)
     draws = [coeffs] + fresh_draws(coeffs, 7, seed=1042 + dist.rank)
-    plan = batch.BatchedGP(B, N, JR, JC, device=dist.local_rank)
+    plan = batch.BatchedGP(B, N, JR, JC, device=dist.local_rank % ndev)
     if args.chunks:
         plan.set_chunks(args.chunks)
     plan.set_series(t, diag, y)          # host -> HBM, outside the timed region
