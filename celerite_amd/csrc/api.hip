@@ -1239,6 +1239,9 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   const bool split = split_active(h);
   P.split = split ? 1 : 0;
   P.split_lazy = (split && h->summarize_mode != 1 && lazy_eligible(h)) ? 1 : 0;
+  // wide plans: the lazy-decay flavour of the wide summarize on dense series (mode 0 / 1 switch it off)
+  if (!h->launch && h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h))
+    P.split_lazy = 1;
   if (h->launch && (h->layout == 1 || split) && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
@@ -1390,6 +1393,8 @@ int clr_batch_set_summarize_mode(clr_batch* h, int mode) {
 int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   if (!kind) return fail(CLR_INVALID_ARGUMENT, "kind is null");
   *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
+  if (!h->launch)  // wide plans: plain or lazy flavour of the one-wave-per-chunk summarize
+    *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h)) ? 2 : 0;
   return CLR_OK;
 }
 

@@ -70,8 +70,28 @@ __device__ __forceinline__ void row_features(const RowCoeffs& r, double t, doubl
 //         chain the chunks.  A is held transposed (lane (j, seg) owns A[seg*COLS ..][j]):
 //         r_j = u . A[:, j] is then a lane-local dot product like q, and the update
 //         A[i][j] <- phi_i A[i][j] - (phi w)_i r_j reuses the phi / phi*w reads of the S update.
-template <int WMAX, bool FAST, int MODE>
+// LAZY (summarize on densely sampled series only; host-checked max c dx < 2^-7, max d dx < 2^-5): the decay is
+// factored out of the state exactly as in clr_split_kernels.h -- S = Psi Sbar Psi, A = Psi Abar, f = Psi fbar with Psi
+// the decay accumulated since the last renormalisation (every 16 steps) -- so the S / A updates are one FMA per
+// entry instead of two MULs + FMA and phi is neither published nor read back; and every row's (cos, sin) pair advances
+// by a small-angle rotation, re-anchored with the full sincos every 16 samples.
+template <bool LAZY>
+__device__ __forceinline__ void decay_pair(double x, double* phi, double* phinv) {
+  if (CLR_WAVE_ALL(fabs(x) < 0.0078125)) {
+    const double x2 = x * x;
+    const double ch = fma(x2, fma(x2, fma(x2, 1.0 / 720.0, 1.0 / 24.0), 0.5), 1.0);
+    const double sh = x * fma(x2, fma(x2, 1.0 / 120.0, 1.0 / 6.0), 1.0);
+    *phi = ch + sh;
+    *phinv = ch - sh;
+  } else {
+    *phi = exp(x);
+    *phinv = exp(-x);
+  }
+}
+
+template <int WMAX, bool FAST, int MODE, bool LAZY = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
+  static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
   using G = WideGeom<WMAX>;
   constexpr int LPR = G::LPR, COLS = G::COLS;
   constexpr int J = WMAX, SZ = J * (J + 1) / 2;
@@ -83,6 +103,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX];
   __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
   __shared__ __attribute__((aligned(16))) double rbuf[MODE == 1 ? WMAX : 2];
+  __shared__ __attribute__((aligned(16))) double psibuf[LAZY ? WMAX : 2];
   const int lane = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int row = lane / LPR, seg = lane % LPR;
@@ -154,8 +175,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
 
   // features of the chunk's first sample
   double u, v, phi;
-  row_features<FAST>(rc, t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
-  if (writer) { ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi; }
+  double psi = 1.0, psinv = 1.0, phinv = 1.0, csr = 1.0, sdr = 0.0, tcur = t_at(0);  // (LAZY)
+  if (LAZY) {
+    sincos_phase<FAST>(rc.d * tcur, &sdr, &csr);
+    u = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
+    v = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
+    decay_pair<LAZY>(-rc.c * (n_lo + 1 < N ? t_at(1) - tcur : 0.0), &phi, &phinv);
+    if (writer) ubuf[n_lo & 1][row] = u;  // ubar = psi u with psi = 1
+  } else {
+    row_features<FAST>(rc, t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
+    if (writer) { ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi; }
+  }
 
   for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
     const int nend = (n_hi - n0 < 64) ? n_hi - n0 : 64;
@@ -165,13 +195,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       const double y_n = lane_value(yv, k);
 
       // next sample's features (independent of the state): computed and published now
-      double u1 = 0.0, v1 = 0.0, phi1 = 1.0;
+      double u1 = 0.0, v1 = 0.0, phi1 = 1.0, phinv1 = 1.0;
+      const bool renorm = LAZY && ((((n - n_lo) & 15) == 15) || n + 1 == n_hi);  // wave-uniform
       if (n + 1 < N) {
         const double t1 = t_at(k + 1);
         const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
-        row_features<FAST>(rc, t1, dx1, &u1, &v1, &phi1);
-        if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
+        if (LAZY) {
+          if (((n + 1 - n_lo) & 15) == 0) {
+            sincos_phase<FAST>(rc.d * t1, &sdr, &csr);  // anchor
+          } else {  // rotate the row's (cos, sin) pair through d (t1 - t)
+            const double dl = rc.d * (t1 - tcur), d2 = dl * dl;
+            const double sn = dl * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+            const double cn = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+            const double c0 = csr, s0 = sdr;
+            csr = fma(c0, cn, -s0 * sn);
+            sdr = fma(s0, cn, c0 * sn);
+          }
+          tcur = t1;
+          u1 = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
+          v1 = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
+          decay_pair<LAZY>(-rc.c * dx1, &phi1, &phinv1);
+          // ubar of the next sample: Psi then includes this step's decay -- or is 1 after a renormalisation
+          if (writer) ubuf[cur ^ 1][row] = renorm ? u1 : (psi * phi) * u1;
+        } else {
+          row_features<FAST>(rc, t1, dx1, &u1, &v1, &phi1);
+          if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
+        }
       }
+      const double ueff = LAZY ? psi * u : u;      // this row's entry of ubar (what ubuf[cur] holds)
+      const double veff = LAZY ? psinv * v : v;    // vbar
 
       // q = S u and (summarize) r = A^T u: own columns, then across the row's lanes
       double q = 0.0, r = 0.0;
@@ -190,7 +242,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       }
       if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR1>(r); }
       if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR2>(r); }
-      const double s = row_sum<LPR>(u * q), ub = row_sum<LPR>(u * f);
+      const double s = row_sum<LPR>(ueff * q), ub = row_sum<LPR>(ueff * f);
       const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
       const double invD = 1.0 / D;
       const double x = y_n - ub;
@@ -201,10 +253,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       quad += x * x * invD;
       if (MODE == 1) gam = fmax(gam, fabs(((((diag_n + sum_ar) + sum_ac) + jitter)) * invD));
 
-      const double z = v - q;
+      const double z = veff - q;
       const double w = z * invD;
       if (writer) {
-        wbuf[row] = phi * w;
+        wbuf[row] = LAZY ? w : phi * w;
         if (MODE == 1) rbuf[row] = r;
       }
       if (MODE == 0 && P.wide_materialize && writer && row < W) {
@@ -216,7 +268,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
         if (n >= 1) P.u[(long)b * Wl * (N - 1) + Wl * (n - 1) + row] = u;
         if (n + 1 < N) P.phi[(long)b * Wl * (N - 1) + Wl * n + row] = phi;
       }
-      {
+      if (LAZY) {
+        const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
+        const double2* rv = reinterpret_cast<const double2*>(&rbuf[seg * COLS]);
+        const double rs = r * invD;
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 pw = wv[c], rr = rv[c];
+          S[2 * c] = fma(z, pw.x, S[2 * c]);
+          S[2 * c + 1] = fma(z, pw.y, S[2 * c + 1]);
+          AT[2 * c] = fma(-pw.x, r, AT[2 * c]);
+          AT[2 * c + 1] = fma(-pw.y, r, AT[2 * c + 1]);
+          Jm[2 * c] = fma(-rs, rr.x, Jm[2 * c]);
+          Jm[2 * c + 1] = fma(-rs, rr.y, Jm[2 * c + 1]);
+        }
+      } else {
         const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
         const double2* rv = reinterpret_cast<const double2*>(&rbuf[MODE == 1 ? seg * COLS : 0]);
@@ -236,7 +302,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
         }
       }
       if (MODE == 1) eta = fma(-r, x * invD, eta);
-      f = phi * (f + w * x);
+      if (LAZY) {
+        f = fma(w, x, f);  // fbar
+        psi *= phi;        // Psi now includes this step's decay
+        psinv *= phinv;
+        if (renorm) {      // multiply the accumulated decay out of Sbar, Abar, fbar
+          if (writer) psibuf[row] = psi;
+          const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
+#pragma unroll
+          for (int c = 0; c < COLS / 2; ++c) {
+            const double2 pc = qv[c];
+            S[2 * c] *= psi * pc.x;
+            S[2 * c + 1] *= psi * pc.y;
+            AT[2 * c] *= pc.x;
+            AT[2 * c + 1] *= pc.y;
+          }
+          f *= psi;
+          psi = 1.0;
+          psinv = 1.0;
+        }
+        phinv = phinv1;
+      } else {
+        f = phi * (f + w * x);
+      }
       u = u1; v = v1; phi = phi1;
     }
     // next tile of the series
@@ -667,6 +755,16 @@ template <int MODE>
 static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const int W = JR + 2 * JC;
   const dim3 grid(P.nchunk, P.B);
+  if (MODE == 1 && P.split_lazy) {  // summarize with the decay factored out of the state (dense series)
+#define CLR_GOL(WM)                                                                                                \
+  do {                                                                                                             \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, 1, true>), grid, dim3(64), 0, s, P, JR, JC);  \
+    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true>), grid, dim3(64), 0, s, P, JR, JC);              \
+  } while (0)
+    if (W <= 16) CLR_GOL(16); else CLR_GOL(32);
+#undef CLR_GOL
+    return;
+  }
 #define CLR_GO(WM)                                                                                  \
   do {                                                                                              \
     if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, MODE>), grid, dim3(64), 0, s, P, JR, JC); \

@@ -655,3 +655,30 @@ def test_batched_grad_log_likelihood(JR, JC, N, shared):
             assert abs(value[b] - v0) <= 1e-10 * abs(v0)
             assert np.allclose(grad[b], g0, rtol=1e-8, atol=1e-10)
     assert (st == 2).sum() >= 1
+
+
+@pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13)])
+def test_wide_summarize_with_the_lazy_decay(JR, JC):
+    """Widths 9..32 on a densely sampled series: the wide summarize with the decay factored out of the
+    state and rotated phases (default there) against the plain flavour (mode 0) and the oracle; ragged
+    last chunk, block boundaries of the 16-step renormalisation inside and at the end of a chunk."""
+    for N, nchunk in [(5000, 7), (4097, 4), (1040, 2)]:
+        case = synthetic(3, N, JR, JC, "bench", seed=JR + 3 * JC + N)
+        case["t"] = case["t"] * 0.03         # dense: max c dx < 2^-7, max d dx < 2^-5
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(3, N, JR, JC)
+        plan.set_chunks(nchunk)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        outs = {}
+        for mode in (0, 2):
+            plan.set_summarize_mode(mode)
+            assert plan.summarize_kernel() == ("single wave", "role split, lazy decay")[mode // 2]  # plain / lazy flavour
+            outs[mode] = plan.log_likelihood()
+            ll, ld, q, st = outs[mode]
+            assert np.array_equal(st, s0), (N, mode)
+            assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, (N, mode)
+            assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, (N, mode)
+        plan.close()
+        assert np.max(np.abs(outs[2][1] - outs[0][1]) / np.abs(outs[0][1])) <= 1e-11
+        assert np.max(np.abs(outs[2][2] - outs[0][2]) / np.abs(outs[0][2])) <= 1e-11
