@@ -199,62 +199,136 @@ __global__ void __launch_bounds__(64) dot_solve_kernel(int N, int J, const doubl
   if (threadIdx.x == 0) out[0] = result;
 }
 
+// KB steps of the factor (rows j0 = lane, j1 = lane + 64 of phi, u, W at factor rows r0, r0 + dir, ...) held in
+// registers while the next KB steps are in flight, as in dot_solve_kernel.
+template <int KB>
+struct FactorRows {
+  double p0[KB], u0[KB], w0[KB], p1[KB], u1[KB], w1[KB];
+  __device__ __forceinline__ void fetch(const double* phi, const double* u, const double* W, int J, long r0, int dir,
+                                        long rmin, long rmax, int j0, int j1, bool h0, bool h1) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const long r = r0 + (long)dir * k;
+      const bool ok = r >= rmin && r <= rmax;
+      const long base = (long)J * r;
+      p0[k] = (ok && h0) ? phi[base + j0] : 0.0; u0[k] = (ok && h0) ? u[base + j0] : 0.0; w0[k] = (ok && h0) ? W[base + j0] : 0.0;
+      p1[k] = (ok && h1) ? phi[base + j1] : 0.0; u1[k] = (ok && h1) ? u[base + j1] : 0.0; w1[k] = (ok && h1) ? W[base + j1] : 0.0;
+    }
+  }
+};
+
 __global__ void __launch_bounds__(64) solve_kernel(int N, int J, const double* phi,
                                                    const double* u, const double* W,
                                                    const double* D, const double* b, double* x) {
-  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  constexpr int KB = 8;
+  const int lane = threadIdx.x, j0 = lane, j1 = lane + 64;
   const bool h0 = j0 < J, h1 = j1 < J;
   const double* bk = b + (long)blockIdx.x * N;
   double* xk = x + (long)blockIdx.x * N;
 
-  // forward, cholesky.h:240-248 (x holds the undivided values for now)
+  // forward, cholesky.h:240-248 (x holds the undivided values for now): step n reads factor row n - 1
   double f0 = 0.0, f1 = 0.0;
   double xm1 = bk[0];
-  if (threadIdx.x == 0) xk[0] = xm1;
-  for (int n = 1; n < N; ++n) {
-    const long base = (long)J * (n - 1);
-    double part = 0.0;
-    if (h0) { f0 = phi[base + j0] * (f0 + W[base + j0] * xm1); part += u[base + j0] * f0; }
-    if (h1) { f1 = phi[base + j1] * (f1 + W[base + j1] * xm1); part += u[base + j1] * f1; }
-    xm1 = bk[n] - wave_sum(part);
-    if (threadIdx.x == 0) xk[n] = xm1;
+  if (lane == 0) xk[0] = xm1;
+  {
+    FactorRows<KB> nx, cur;
+    double bt = 0.0;
+    nx.fetch(phi, u, W, J, 0, +1, 0, (long)N - 2, j0, j1, h0, h1);
+    bt = (lane < KB && 1 + lane < N) ? bk[1 + lane] : 0.0;
+    for (int n0 = 1; n0 < N; n0 += KB) {
+      cur = nx;
+      const double cb = bt;
+      if (n0 + KB < N) {
+        nx.fetch(phi, u, W, J, (long)n0 + KB - 1, +1, 0, (long)N - 2, j0, j1, h0, h1);
+        bt = (lane < KB && n0 + KB + lane < N) ? bk[n0 + KB + lane] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        if (n0 + k < N) {
+          double part = 0.0;
+          if (h0) { f0 = cur.p0[k] * (f0 + cur.w0[k] * xm1); part += cur.u0[k] * f0; }
+          if (h1) { f1 = cur.p1[k] * (f1 + cur.w1[k] * xm1); part += cur.u1[k] * f1; }
+          xm1 = clr::lane_value(cb, k) - wave_sum(part);
+          if (lane == 0) xk[n0 + k] = xm1;
+        }
+      }
+    }
   }
   __threadfence_block();
   __syncthreads();
 
-  // backward with the /D of :249 folded in, cholesky.h:251-259
+  // backward with the /D of :249 folded in, cholesky.h:251-259: step n (N - 2 .. 0) reads factor row n
   f0 = 0.0;
   f1 = 0.0;
   double value = xk[N - 1] / D[N - 1];
-  if (threadIdx.x == 0) xk[N - 1] = value;
-  for (int n = N - 2; n >= 0; --n) {
-    const long base = (long)J * n;
-    double part = 0.0;
-    if (h0) { f0 = phi[base + j0] * (f0 + u[base + j0] * value); part += W[base + j0] * f0; }
-    if (h1) { f1 = phi[base + j1] * (f1 + u[base + j1] * value); part += W[base + j1] * f1; }
-    value = xk[n] / D[n] - wave_sum(part);
-    if (threadIdx.x == 0) xk[n] = value;
+  if (lane == 0) xk[N - 1] = value;
+  {
+    FactorRows<KB> nx, cur;
+    double xt = 0.0, dt = 1.0;
+    auto scalars = [&](long top) {  // x and D of steps top, top - 1, ...
+      const long n = top - lane;
+      xt = (lane < KB && n >= 0) ? xk[n] : 0.0;
+      dt = (lane < KB && n >= 0) ? D[n] : 1.0;
+    };
+    nx.fetch(phi, u, W, J, (long)N - 2, -1, 0, (long)N - 2, j0, j1, h0, h1);
+    scalars((long)N - 2);
+    for (long top = (long)N - 2; top >= 0; top -= KB) {
+      cur = nx;
+      const double cx = xt, cd = dt;
+      if (top - KB >= 0) {
+        nx.fetch(phi, u, W, J, top - KB, -1, 0, (long)N - 2, j0, j1, h0, h1);
+        scalars(top - KB);
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const long n = top - k;
+        if (n >= 0) {
+          double part = 0.0;
+          if (h0) { f0 = cur.p0[k] * (f0 + cur.u0[k] * value); part += cur.w0[k] * f0; }
+          if (h1) { f1 = cur.p1[k] * (f1 + cur.u1[k] * value); part += cur.w1[k] * f1; }
+          value = clr::lane_value(cx, k) / clr::lane_value(cd, k) - wave_sum(part);
+          if (lane == 0) xk[n] = value;
+        }
+      }
+    }
   }
 }
 
 __global__ void __launch_bounds__(64) dot_L_kernel(int N, int J, const double* phi,
                                                    const double* u, const double* W,
                                                    const double* D, const double* z, double* y) {
-  const int j0 = threadIdx.x, j1 = threadIdx.x + 64;
+  constexpr int KB = 8;
+  const int lane = threadIdx.x, j0 = lane, j1 = lane + 64;
   const bool h0 = j0 < J, h1 = j1 < J;
   const double* zk = z + (long)blockIdx.x * N;
   double* yk = y + (long)blockIdx.x * N;
   double f0 = 0.0, f1 = 0.0;
   double tmp = zk[0] * sqrt(D[0]);  // cholesky.h:421-422
-  if (threadIdx.x == 0) yk[0] = tmp;
-  for (int n = 1; n < N; ++n) {  // :423-427
-    const long base = (long)J * (n - 1);
-    double part = 0.0;
-    if (h0) { f0 = phi[base + j0] * (f0 + W[base + j0] * tmp); part += u[base + j0] * f0; }
-    if (h1) { f1 = phi[base + j1] * (f1 + W[base + j1] * tmp); part += u[base + j1] * f1; }
-    tmp = sqrt(D[n]) * zk[n];
-    const double yn = tmp + wave_sum(part);
-    if (threadIdx.x == 0) yk[n] = yn;
+  if (lane == 0) yk[0] = tmp;
+  FactorRows<KB> nx, cur;
+  double zt = 0.0, dt = 0.0;
+  nx.fetch(phi, u, W, J, 0, +1, 0, (long)N - 2, j0, j1, h0, h1);
+  zt = (lane < KB && 1 + lane < N) ? zk[1 + lane] : 0.0;
+  dt = (lane < KB && 1 + lane < N) ? D[1 + lane] : 0.0;
+  for (int n0 = 1; n0 < N; n0 += KB) {  // :423-427
+    cur = nx;
+    const double cz = zt, cd = dt;
+    if (n0 + KB < N) {
+      nx.fetch(phi, u, W, J, (long)n0 + KB - 1, +1, 0, (long)N - 2, j0, j1, h0, h1);
+      zt = (lane < KB && n0 + KB + lane < N) ? zk[n0 + KB + lane] : 0.0;
+      dt = (lane < KB && n0 + KB + lane < N) ? D[n0 + KB + lane] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (n0 + k < N) {
+        double part = 0.0;
+        if (h0) { f0 = cur.p0[k] * (f0 + cur.w0[k] * tmp); part += cur.u0[k] * f0; }
+        if (h1) { f1 = cur.p1[k] * (f1 + cur.w1[k] * tmp); part += cur.u1[k] * f1; }
+        tmp = sqrt(clr::lane_value(cd, k)) * clr::lane_value(cz, k);
+        const double yn = tmp + wave_sum(part);
+        if (lane == 0) yk[n0 + k] = yn;
+      }
+    }
   }
 }
 
