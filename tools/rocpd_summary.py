@@ -21,6 +21,9 @@ def main(db, out=None):
         lines.append("%-64s %6d %12.1f %12.1f %12.1f %12.1f %6.2f %5d %5d %5d %7d %8d  (%d,%d) x %d" % (
             r[0][:64], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total,
             r[6], r[7], r[8], r[9], r[10], r[11], r[12], r[13]))
+    lines.append("# vgpr / agpr: rocprofv3's architectural and accumulation register counts as recorded in the trace (for "
+                 "kernels that spill state into AGPRs the trace shows the architectural part only); the unified allocation "
+                 "that sets the waves per SIMD is in the code-object metadata: tools/kernel_resources.py")
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
