@@ -578,9 +578,13 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     }
     int nchunk = 1;
     if (J <= clr::wide_scan_max_width()) {
-      nchunk = N / 1024;
-      if (nchunk > 16) nchunk = 16;
-      if (nchunk < 2) nchunk = 1;
+      // one problem: the chunk waves run side by side (t = a N / nchunk), the prefix walks the chunks
+      // (t = p nchunk): nchunk = sqrt(a N / p).  Measured (profiles/r02y_single_wide_chunks.txt): a = 1.4 us per
+      // sample, p = 15 us per chunk up to width 16; a = 2.0 us, p = 97 us (three 32^3 products on the matrix
+      // cores + a Gauss-Jordan) above.
+      nchunk = (int)lround(sqrt((double)N * (J <= 16 ? 0.096 : 0.0208)));
+      if (nchunk > N / 256) nchunk = N / 256;
+      if (nchunk < 2 || N < 2048) nchunk = 1;  // (short series: the six launches of the chunked flow cost more)
     }
     P.L = (N + nchunk - 1) / nchunk;
     P.nchunk = (N + P.L - 1) / P.L;
@@ -732,19 +736,27 @@ int clr_solver_log_determinant(const clr_solver* s, double* out) {
   return CLR_OK;
 }
 
-// dot_solve / solve as chunked scans for long series of width <= 8 (sweep_kernels.hip)
+// dot_solve / solve as chunked scans for long series: N >= 2048 and width <= 32 one wave per chunk, one lane
+// per column of the chunk's map (wsweep_kernels.hip); 256 <= N < 2048 and width <= 8 one lane per chunk
+// (sweep_kernels.hip); otherwise the sequential sweeps (generic_kernels.hip)
+static bool sweep_scan_ok(const clr_solver* s) {
+  return clr::sweep_scan_supported(s->N, s->J) || clr::wsweep_scan_supported(s->N, s->J);
+}
 static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, double* quad, int backward) {
+  const bool wide = clr::wsweep_scan_supported(s->N, s->J);
   clr::SweepParams P;
   memset(&P, 0, sizeof(P));
   P.N = s->N; P.J = s->J; P.nrhs = nrhs;
-  P.nchunk = clr::sweep_chunks(s->N);
+  P.nchunk = wide ? clr::wsweep_chunks(s->N) : clr::sweep_chunks(s->N);
   P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
   P.nchunk = (s->N - 1 + P.L - 1) / P.L;
   P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
   P.in = in; P.out = out; P.quad = quad; P.backward = backward;
-  int st = s->ws_elems.reserve(clr::sweep_workspace_doubles(s->J, P.nchunk, nrhs));
+  int st = s->ws_elems.reserve(wide ? clr::wsweep_workspace_doubles(s->J, P.nchunk, nrhs)
+                                    : clr::sweep_workspace_doubles(s->J, P.nchunk, nrhs));
   if (st != CLR_OK) return st;
-  clr::launch_sweep_scan(P, s->ws_elems.p, s->stream);
+  if (wide) clr::launch_wsweep_scan(P, s->ws_elems.p, s->stream);
+  else clr::launch_sweep_scan(P, s->ws_elems.p, s->stream);
   return CLR_OK;
 }
 
@@ -762,7 +774,7 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   if (st != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
-  if (clr::sweep_scan_supported(s->N, s->J)) {
+  if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, nullptr, s->scalars.p, 0)) != CLR_OK) return st;
   } else {
     clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
@@ -789,7 +801,7 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
   int st = sweep_common(s, b_rows, nrhs, b);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  if (clr::sweep_scan_supported(s->N, s->J)) {
+  if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, nrhs, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;   // :240-248
     if ((st = sweep_scan(s, nrhs, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;  // :249-259
   } else {
@@ -808,17 +820,19 @@ int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z
   int st = sweep_common(s, z_rows, nrhs, z);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  if (clr::sweep_scan_supported(s->N, s->J)) {
+  const bool wide = clr::wdotl_scan_supported(s->N, s->J);
+  if (wide || clr::sweep_scan_supported(s->N, s->J)) {
     clr::SweepParams P;
     memset(&P, 0, sizeof(P));
     P.N = s->N; P.J = s->J; P.nrhs = nrhs;
-    P.nchunk = clr::sweep_chunks(s->N);
+    P.nchunk = wide ? clr::wdotl_chunks(s->N) : clr::sweep_chunks(s->N);
     P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
     P.nchunk = (s->N - 1 + P.L - 1) / P.L;
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
     P.in = s->scratch.p; P.out = s->scratch2.p;
     if ((st = s->ws_elems.reserve((size_t)nrhs * P.nchunk * 3 * s->J)) != CLR_OK) return st;
-    clr::launch_dot_L_scan(P, s->ws_elems.p, s->stream);
+    if (wide) clr::launch_wdotl_scan(P, s->ws_elems.p, s->stream);
+    else clr::launch_dot_L_scan(P, s->ws_elems.p, s->stream);
   } else {
     clr::launch_dot_L(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
                       s->scratch2.p, s->stream);
@@ -932,7 +946,7 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
                 "state does not carry them (same as the reference, solver.cpp:36-42)");
   hipStream_t stream = s->stream;
   // alpha = K^-1 y  (:608)
-  if (clr::sweep_scan_supported(s->N, s->J)) {
+  if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;
     if ((st = sweep_scan(s, 1, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;
   } else {

@@ -39,6 +39,15 @@ bool sweep_scan_supported(int N, int J);
 int sweep_chunks(int N);
 size_t sweep_workspace_doubles(int J, int nchunk, int nrhs);
 void launch_sweep_scan(SweepParams P, double* workspace, hipStream_t s);
+// N >= 2048, width <= 32 (wsweep_kernels.hip): wave per chunk, lane = column of the chunk's affine map
+bool wsweep_scan_supported(int N, int J);
+int wsweep_chunks(int N);
+size_t wsweep_workspace_doubles(int J, int nchunk, int nrhs);
+void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s);
+// dot_L at N >= 2048, any width: wave per chunk, lane = row; workspace nrhs * nchunk * 3 J doubles
+bool wdotl_scan_supported(int N, int J);
+int wdotl_chunks(int N);
+void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s);
 // dot_L (cholesky.h:409-431) as a chunked diagonal scan; workspace: nrhs * nchunk * 3 J doubles
 void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s);
 // predict (cholesky.h:599-698): chunked diagonal scans + one thread per (sorted) prediction point

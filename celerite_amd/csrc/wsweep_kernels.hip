@@ -1,0 +1,398 @@
+// celerite_amd/csrc/wsweep_kernels.hip -- dot_solve / solve on a stored factor of width <= 32 (and dot_L at any
+// width) as chunked affine scans, one WAVE per chunk (single-solver API, series of N >= 2048).
+//
+// The sweeps (cholesky.h:236-260, :343-357) are f <- p o (f + g x_prev) ; x = in - h . f with
+// (p, g, h, in) = (phi, W, u, b) forward and (phi, u, W, x / D) backward: AFFINE on z = (f, x) in
+// R^(J+1), so a chunk composes into z_end = A z_start + c.  At these widths A ((J+1)^2 <= 1089 doubles)
+// does not fit a lane, but its COLUMNS evolve independently under the same per-step data:
+//   summarize  one WAVE per chunk, one LANE per column of [A | c_1 .. c_nrhs]: every lane applies the
+//              step to its own column (J + 1 doubles in registers); the step's p, g, h are wave-uniform
+//              (scalar loads);
+//   prefix     one wave per right-hand side walks the chunks: lane i owns z_i, z_j is handed round with
+//              v_readlane, the chunk's matrix is read column-major (coalesced);
+//   replay     one wave per (chunk, right-hand side): the reference recurrence from the known start,
+//              lane = row, DPP reductions, factor rows prefetched KB steps ahead (as generic_kernels.hip).
+// A sequential sweep costs 0.23 us per step (25-50 ms at N = 1e5, where the CPU needs 0.6-4 ms); measured here
+// at N = 1e5 (profiles/r02y_sweeps_*): dot_solve 0.29 ms at width 8, 0.49 ms at width 32; solve twice that.
+#include "clr_generic_kernels.h"
+#include "clr_wide.h"
+
+#include <algorithm>
+
+namespace clr {
+
+namespace {
+
+__device__ __forceinline__ double wsum(double v) { return row_sum<1>(v); }
+
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One wave per (chunk, 64 columns).  The step data (p, g, h: 3 J doubles per step) is the same for every
+// lane: the wave copies KB steps at a time into LDS with coalesced vector loads (fetched one tile ahead,
+// in registers) and every lane reads it back with uniform-address (broadcast) LDS reads.  (Through the
+// scalar cache instead -- 96 doubles per step at width 32 against ~100 SGPRs -- a step cost 2.8 us.)
+// The reads are software-pipelined by hand, GS rows ahead of the arithmetic, with scheduling barriers: left
+// alone the compiler keeps ~3 reads in flight and a step pays the LDS latency a dozen times.
+// The tile is padded so that the inner loops have no branch: rows J .. JP-1 are (0, 0, 0), steps past the
+// chunk's end are (1, 0, 0) -- the identity on f -- and keep x through a select.
+template <int JP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+wsweep_summarize_kernel(const SweepParams P) {
+  constexpr int KB = 8, ROUNDS = KB * JP / 64;
+  constexpr int GS = (JP % 16 == 0) ? 16 : 8, NG = JP / GS;
+  __shared__ double tile[KB][3][JP];
+  const int J = P.J, K = J + 1, lane = threadIdx.x;
+  const int c = blockIdx.x;
+  const int id = blockIdx.y * 64 + lane;  // column of [A | c_0 .. c_{nrhs-1}]
+  const bool live = id < K + P.nrhs;
+  const bool affine = live && id >= K;
+  const double* in = affine ? P.in + (long)(id - K) * P.N : nullptr;
+  double f[JP], x = (live && id == J) ? 1.0 : 0.0;  // this lane's column: rows f_0 .. f_{J-1}, then x
+#pragma unroll
+  for (int i = 0; i < JP; ++i) f[i] = (live && i == id) ? 1.0 : 0.0;
+  const int s0 = c * P.L + 1;
+  const int s1 = min(s0 + P.L, P.N);
+  const double* gp = P.backward ? P.u : P.W;
+  const double* hp = P.backward ? P.W : P.u;
+  double np[ROUNDS], ng[ROUNDS], nh[ROUNDS], nin[KB];
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const int r = lane + 64 * q, k = r / JP, i = r % JP, s = sb + k;
+      const bool ok = s < s1 && i < J;
+      const long col = (long)J * (P.backward ? P.N - 1 - s : s - 1);
+      np[q] = ok ? P.phi[col + i] : (i < J ? 1.0 : 0.0);
+      ng[q] = ok ? gp[col + i] : 0.0;
+      nh[q] = ok ? hp[col + i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int s = sb + k, n = P.backward ? P.N - 1 - s : s;
+      nin[k] = 0.0;
+      if (affine && s < s1) nin[k] = P.backward ? in[n] / P.D[n] : in[n];
+    }
+  };
+  fetch(s0);
+  for (int sb = s0; sb < s1; sb += KB) {
+    lds_fence();  // (the previous tile's reads have landed)
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const int r = lane + 64 * q, k = r / JP, i = r % JP;
+      tile[k][0][i] = np[q];
+      tile[k][1][i] = ng[q];
+      tile[k][2][i] = nh[q];
+    }
+    double cin[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) cin[k] = nin[k];
+    lds_fence();
+    if (sb + KB < s1) fetch(sb + KB);
+    double cp[GS], cg[GS], ch[GS];
+#pragma unroll
+    for (int i = 0; i < GS; ++i) { cp[i] = tile[0][0][i]; cg[i] = tile[0][1][i]; ch[i] = tile[0][2][i]; }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        double qp[GS], qg[GS], qh[GS];
+        const int gn = (g + 1) % NG, kn = (g + 1 == NG) ? k + 1 : k;
+        if (kn < KB) {
+#pragma unroll
+          for (int i = 0; i < GS; ++i) {
+            qp[i] = tile[kn][0][gn * GS + i]; qg[i] = tile[kn][1][gn * GS + i]; qh[i] = tile[kn][2][gn * GS + i];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+          f[g * GS + i] = cp[i] * fma(cg[i], x, f[g * GS + i]);
+          acc = fma(ch[i], f[g * GS + i], acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kn < KB) {
+#pragma unroll
+          for (int i = 0; i < GS; ++i) { cp[i] = qp[i]; cg[i] = qg[i]; ch[i] = qh[i]; }
+        }
+      }
+      x = (sb + k < s1) ? cin[k] - acc : x;
+    }
+  }
+  if (!live) return;
+  double* o = P.elems + ((long)c * (K + P.nrhs) + id) * K;  // column-major, K doubles per column
+#pragma unroll
+  for (int i = 0; i < JP; ++i)
+    if (i < J) o[i] = f[i];
+  o[J] = x;
+}
+
+// One workgroup of NW waves per right-hand side.  Lane i (< K) owns row i of a chunk's map; wave w owns the
+// chunks c = w (mod NW) and fetches its next one right after using the current, so a fetch has NW - 1 chunk
+// times to land; z travels from chunk to chunk through LDS (ping-pong, one barrier per chunk) and is read
+// back with broadcast reads.
+template <int JP, int NW>
+__global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParams P) {
+  constexpr int H = (JP + 2) / 2;  // z is read back in two halves of H (columns 0 .. JP+1, the last one padding)
+  __shared__ double zbuf[2][2 * H];
+  const int J = P.J, K = J + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rhs = blockIdx.x;
+  const bool have = lane < K;
+  const double* in = P.in + (long)rhs * P.N;
+  // (no aliasing between the maps and the starts: the fetch must not wait for the store of a start)
+  const double* __restrict__ elems = P.elems;
+  double* __restrict__ starts = P.starts;
+  if (wave == 0 && lane < 2 * H) {
+    // the sweep's first sample: x_0 = b_0 (cholesky.h:238) / x_{N-1} / D_{N-1} (:249,251)
+    double z = 0.0;
+    if (lane == J) z = P.backward ? in[P.N - 1] / P.D[P.N - 1] : in[0];
+    zbuf[0][lane] = z;
+    zbuf[1][lane] = 0.0;
+  }
+  double m[2 * H], aff = 0.0;
+  const int lrow = min(lane, K - 1);
+  // every address in range and no select on the loaded values (a select would wait for them right here):
+  // the padding columns j >= K re-read column K-1 and meet z_j = 0; lanes >= K compute a value nobody stores
+  auto fetch = [&](int c) {
+    const double* M = elems + (long)c * (K + P.nrhs) * K;
+#pragma unroll
+    for (int j = 0; j < 2 * H; ++j) m[j] = M[(long)min(j, K - 1) * K + lrow];
+    aff = M[(long)(K + rhs) * K + lrow];
+  };
+  if (wave < P.nchunk) fetch(wave);
+  __syncthreads();
+  for (int c = 0; c < P.nchunk; ++c) {
+    if (c % NW == wave) {
+      const double* zc = zbuf[c & 1];
+      double z0[H], z1[H];
+#pragma unroll
+      for (int j = 0; j < H; ++j) z0[j] = zc[j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < H; ++j) z1[j] = zc[H + j];
+      const double zmine = zc[min(lane, 2 * H - 1)];
+      double a0 = aff, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // (z_j = 0 for the padding columns j >= K)
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (j % 2 == 0) a0 = fma(m[j], z0[j], a0); else a1 = fma(m[j], z0[j], a1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (j % 2 == 0) a2 = fma(m[H + j], z1[j], a2); else a3 = fma(m[H + j], z1[j], a3);
+      }
+      if (have) zbuf[(c + 1) & 1][lane] = (a0 + a1) + (a2 + a3);
+      // (the store after the arithmetic: issued before it, the wait for this chunk's map -- vmcnt counts
+      // loads and stores in order -- would also wait for the store to be acknowledged)
+      if (have) starts[((long)rhs * P.nchunk + c) * K + lane] = zmine;
+      if (c + NW < P.nchunk) fetch(c + NW);
+    }
+    // LDS traffic only: a plain __syncthreads() would also wait for the fetch just issued (vmcnt(0))
+    lds_fence();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+// one wave per (chunk, right-hand side); lane = row of the state
+__global__ void __launch_bounds__(64) wsweep_replay_kernel(const SweepParams P) {
+  constexpr int KB = 8;
+  const int J = P.J, K = J + 1, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
+  const bool have = lane < J;
+  const double* in = P.in + (long)rhs * P.N;
+  double* out = P.out ? P.out + (long)rhs * P.N : nullptr;
+  const double* st0 = P.starts + ((long)rhs * P.nchunk + c) * K;
+  double f = have ? st0[lane] : 0.0, x = st0[J], quad = 0.0;
+  if (c == 0) {  // the first sample of the sweep belongs to chunk 0
+    const int n0 = P.backward ? P.N - 1 : 0;
+    if (out && lane == 0) out[n0] = x;
+    quad = x * (x / P.D[n0]);  // cholesky.h:347
+  }
+  const int s0 = c * P.L + 1;
+  const int s1 = min(s0 + P.L, P.N);
+  const double* gp = P.backward ? P.u : P.W;
+  const double* hp = P.backward ? P.W : P.u;
+  double np[KB], ng[KB], nh[KB], nin = 0.0, nd = 1.0;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int s = sb + k;
+      const int n = P.backward ? P.N - 1 - s : s;
+      const long col = (long)J * (P.backward ? n : s - 1);
+      const bool ok = s < s1 && have;
+      np[k] = ok ? P.phi[col + lane] : 0.0;
+      ng[k] = ok ? gp[col + lane] : 0.0;
+      nh[k] = ok ? hp[col + lane] : 0.0;
+    }
+    const int s = sb + lane;
+    const int n = P.backward ? P.N - 1 - s : s;
+    const bool ok = lane < KB && s < s1;
+    nd = ok ? P.D[n] : 1.0;
+    nin = ok ? (P.backward ? in[n] / nd : in[n]) : 0.0;
+  };
+  fetch(s0);
+  for (int sb = s0; sb < s1; sb += KB) {
+    double cp[KB], cg[KB], ch[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { cp[k] = np[k]; cg[k] = ng[k]; ch[k] = nh[k]; }
+    const double cin = nin, cd = nd;
+    if (sb + KB < s1) fetch(sb + KB);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int s = sb + k;
+      if (s < s1) {
+        f = cp[k] * fma(cg[k], x, f);            // cholesky.h:243-246 / :255-258 / :350-354
+        x = lane_value(cin, k) - wsum(ch[k] * f);
+        const int n = P.backward ? P.N - 1 - s : s;
+        if (out && lane == 0) out[n] = x;
+        quad += x * x / lane_value(cd, k);       // :356
+      }
+    }
+  }
+  if (P.part && lane == 0) P.part[(long)rhs * P.nchunk + c] = quad;
+}
+
+// dot_solve: chunk partials, one wave per right-hand side (lane-strided sums, then a fixed reduction tree)
+__global__ void __launch_bounds__(64) wsweep_finalize_kernel(const SweepParams P) {
+  const int rhs = blockIdx.x, lane = threadIdx.x;
+  double q = 0.0;
+  for (int c = lane; c < P.nchunk; c += 64) q += P.part[(long)rhs * P.nchunk + c];
+  q = wsum(q);
+  if (lane == 0) P.quad[rhs] = q;
+}
+
+// dot_L (cholesky.h:409-431) at any width: f_j <- phi_j (f_j + W_j sqrt(D_{n-1}) z_{n-1}) is DIAGONAL in j,
+// so a chunk is (a_j, f_j) per row; one wave per (chunk, right-hand side), lane = row.
+template <bool REPLAY>
+__global__ void __launch_bounds__(64) wdotl_kernel(const SweepParams P) {
+  constexpr int KB = 8;
+  const int J = P.J, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
+  const bool have = lane < J;
+  const double* z = P.in + (long)rhs * P.N;
+  double* y = P.out + (long)rhs * P.N;
+  const long slot = (long)rhs * P.nchunk + c;
+  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + lane] : 0.0;
+  const int s0 = c * P.L + 1;
+  const int s1 = min(s0 + P.L, P.N);
+  if (REPLAY && c == 0 && lane == 0) y[0] = sqrt(P.D[0]) * z[0];  // :421-422
+  double np[KB], nw[KB], nu[KB], ntz = 0.0;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int n = sb + k;
+      const long col = (long)J * (n - 1);
+      const bool ok = n < s1 && have;
+      np[k] = ok ? P.phi[col + lane] : 0.0;
+      nw[k] = ok ? P.W[col + lane] : 0.0;
+      nu[k] = (REPLAY && ok) ? P.u[col + lane] : 0.0;
+    }
+    const int n = sb - 1 + lane;  // lanes 0..KB: sqrt(D_n) z_n for n = sb-1 .. sb+KB-1
+    ntz = (lane <= KB && n < s1) ? sqrt(P.D[n]) * z[n] : 0.0;
+  };
+  fetch(s0);
+  for (int sb = s0; sb < s1; sb += KB) {
+    double cp[KB], cw[KB], cu[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { cp[k] = np[k]; cw[k] = nw[k]; cu[k] = nu[k]; }
+    const double ctz = ntz;
+    if (sb + KB < s1) fetch(sb + KB);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int n = sb + k;
+      if (n < s1) {
+        f = cp[k] * (f + cw[k] * lane_value(ctz, k));  // :424-425
+        if (!REPLAY) a *= cp[k];
+        if (REPLAY) {
+          const double v = lane_value(ctz, k + 1) + wsum(cu[k] * f);  // :426
+          if (lane == 0) y[n] = v;
+        }
+      }
+    }
+  }
+  if (!REPLAY && have) {
+    P.elems[slot * 2 * J + lane] = a;
+    P.elems[slot * 2 * J + J + lane] = f;
+  }
+}
+
+__global__ void __launch_bounds__(64) wdotl_prefix_kernel(const SweepParams P) {
+  constexpr int KB = 16;  // chunks fetched ahead
+  const int J = P.J, lane = threadIdx.x, rhs = blockIdx.x;
+  if (lane >= J) return;
+  double f = 0.0, na[KB], ne[KB];
+  auto fetch = [&](int cb) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const long slot = (long)rhs * P.nchunk + cb + k;
+      const bool ok = cb + k < P.nchunk;
+      na[k] = ok ? P.elems[slot * 2 * J + lane] : 1.0;
+      ne[k] = ok ? P.elems[slot * 2 * J + J + lane] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int cb = 0; cb < P.nchunk; cb += KB) {
+    double ca[KB], ce[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { ca[k] = na[k]; ce[k] = ne[k]; }
+    if (cb + KB < P.nchunk) fetch(cb + KB);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (cb + k < P.nchunk) {
+        P.starts[((long)rhs * P.nchunk + cb + k) * J + lane] = f;
+        f = fma(ca[k], f, ce[k]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool wdotl_scan_supported(int N, int J) { return J >= 1 && J <= 64 && N >= 2048; }
+int wdotl_chunks(int N) { return std::max(2, std::min(512, (N - 1) / 128)); }
+
+// workspace: nrhs * nchunk * 3 J doubles
+void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s) {
+  const size_t pc = (size_t)P.nrhs * P.nchunk;
+  P.elems = workspace;
+  P.starts = P.elems + pc * 2 * P.J;
+  const dim3 grid(P.nchunk, P.nrhs);
+  hipLaunchKernelGGL((wdotl_kernel<false>), grid, dim3(64), 0, s, P);
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
+  hipLaunchKernelGGL((wdotl_kernel<true>), grid, dim3(64), 0, s, P);
+}
+
+// (measured at N = 1e5, width 8: 0.29 ms against 1.35 ms for the lane-per-chunk scan of sweep_kernels.hip, which
+// keeps the series of 256 <= N < 2048)
+bool wsweep_scan_supported(int N, int J) { return J >= 1 && J <= 32 && N >= 2048; }
+
+// the sequential prefix costs 0.3-0.6 us per chunk, the parallel phases 0.4-0.8 us per step
+int wsweep_chunks(int N) {
+  long nc = (long)(1.0 * sqrt((double)N));
+  if (nc < 2) nc = 2;
+  const long maxc = std::max<long>(1, (N - 1) / 64);
+  if (nc > maxc) nc = maxc;
+  return (int)nc;
+}
+
+size_t wsweep_workspace_doubles(int J, int nchunk, int nrhs) {
+  const size_t K = (size_t)J + 1;
+  return (size_t)nchunk * (K + nrhs) * K + (size_t)nrhs * nchunk * K + (size_t)nrhs * nchunk;
+}
+
+void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
+  const size_t K = (size_t)P.J + 1;
+  P.elems = workspace;
+  P.starts = P.elems + (size_t)P.nchunk * (K + P.nrhs) * K;
+  P.part = P.starts + (size_t)P.nrhs * P.nchunk * K;
+  const dim3 gsum(P.nchunk, (unsigned)((K + P.nrhs + 63) / 64));
+  if (P.J <= 8) hipLaunchKernelGGL((wsweep_summarize_kernel<8>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 16) hipLaunchKernelGGL((wsweep_summarize_kernel<16>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 24) hipLaunchKernelGGL((wsweep_summarize_kernel<24>), gsum, dim3(64), 0, s, P);
+  else hipLaunchKernelGGL((wsweep_summarize_kernel<32>), gsum, dim3(64), 0, s, P);
+  if (P.J <= 8) hipLaunchKernelGGL((wsweep_prefix_kernel<8, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
+  else if (P.J <= 16) hipLaunchKernelGGL((wsweep_prefix_kernel<16, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
+  else if (P.J <= 24) hipLaunchKernelGGL((wsweep_prefix_kernel<24, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
+  else hipLaunchKernelGGL((wsweep_prefix_kernel<32, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
+  hipLaunchKernelGGL(wsweep_replay_kernel, dim3(P.nchunk, P.nrhs), dim3(64), 0, s, P);
+  if (P.quad) hipLaunchKernelGGL(wsweep_finalize_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
+}
+
+}  // namespace clr

@@ -548,3 +548,40 @@ def test_hinted_right_hand_side_is_the_same_quadratic_form(JR, JC, N):
     gp.set_parameter_vector(gp.get_parameter_vector())   # dirty -> recompute with the hint
     ll2 = gp.log_likelihood(y)
     assert abs(ll1 - ll2) <= 1e-10 * abs(ll1)
+
+
+@pytest.mark.parametrize("JR,JC,N,general", [(1, 4, 2048, False), (3, 5, 4097, True), (0, 8, 30000, False),
+                                              (2, 15, 12345, False), (0, 16, 100000, False), (9, 0, 5000, False),
+                                              (2, 20, 6000, False)])
+def test_wide_sweeps_are_chunked_scans(JR, JC, N, general):
+    """dot_solve / solve (widths 9..32) and dot_L (widths 9..64) on a stored factor of N >= 2048 run as
+    chunked scans (csrc/wsweep_kernels.hip: lane = column of the chunk's affine map / lane = row):
+    same numbers as the oracle's sequential sweeps (cholesky.h:218-431), several right-hand sides."""
+    rng = np.random.RandomState(JR * 100 + JC + N % 7)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    gen = NO_GENERAL
+    if general:
+        U = np.vander((t - t.mean()) / (t.max() - t.min()), 3).T
+        V = U * rng.rand(3)[:, None]
+        gen = (np.sum(U * V, axis=0) + 1e-8, U, V)
+    co = (np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+          0.1 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)))
+    s = celerite_amd.CholeskySolver()
+    r = ref.RefSolver()
+    s.compute(0.0, *co, *gen, t, diag)
+    r.compute(0.0, *co, *gen, t, diag)
+    b = rng.randn(N, 3)
+    for k in range(2):
+        q, q0 = s.dot_solve(b[:, k]), r.dot_solve(b[:, k])
+        assert abs(q - q0) <= 1e-10 * abs(q0)
+    x, x0 = s.solve(b), r.solve(b)
+    assert x.shape == (N, 3)
+    assert np.max(np.abs(x - x0)) <= 1e-10 * np.max(np.abs(x0))
+    yl, yl0 = s.dot_L(b), r.dot_L(b)
+    assert np.max(np.abs(yl - yl0)) <= 1e-11 * np.max(np.abs(yl0))
+    if not general:
+        y = np.sin(t) + 0.1 * b[:, 0]
+        xs = np.linspace(t[0] - 1.0, t[-1] + 1.0, 333)
+        p, p0 = s.predict(y, xs), r.predict(y, xs)
+        assert np.max(np.abs(p - p0)) <= 1e-9 * max(1.0, np.max(np.abs(p0)))
