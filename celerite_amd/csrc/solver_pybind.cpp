@@ -32,7 +32,7 @@ struct linalg_error : public std::exception {
 void check(int status) {
   if (status == CLR_OK) return;
   if (status == CLR_NOT_POSITIVE_DEFINITE) throw linalg_error();
-  if (status == CLR_DIMENSION_MISMATCH || status == CLR_NOT_COMPUTED)
+  if (status == CLR_DIMENSION_MISMATCH || status == CLR_NOT_COMPUTED || status == CLR_CARMA_INSTABILITY)
     throw std::runtime_error(clr_status_string(status));
   std::string msg = clr_status_string(status);
   const char* detail = clr_last_error();
@@ -100,6 +100,18 @@ py::array_t<double> to_numpy_colmajor(const std::vector<double>& v, int rows, in
   if (!v.empty()) std::memcpy(out.mutable_data(), v.data(), sizeof(double) * v.size());
   return out;
 }
+
+struct Carma {
+  clr_carma* h = nullptr;
+  Carma(double log_sigma, const Vec& ar, const Vec& ma) {
+    int st = CLR_OK;
+    h = clr_carma_create(log_sigma, ar.n(), ar.p(), ma.n(), ma.p(), &st);
+    if (!h) check(st == CLR_OK ? (int)CLR_INVALID_ARGUMENT : st);
+  }
+  ~Carma() { clr_carma_destroy(h); }
+  Carma(const Carma&) = delete;
+  Carma& operator=(const Carma&) = delete;
+};
 
 class Solver {
  public:
@@ -188,15 +200,32 @@ PYBIND11_MODULE(solver, m) {
         },
         "Sturm's-theorem check that the PSD is everywhere positive; solver.cpp:165-175");
 
-  // The Kalman-filter comparison solver (carma.h) is outside the hot path
-  // (SURVEY.md section 2 row 7); the name exists so imports keep working.
-  struct CARMAPlaceholder {};
-  py::class_<CARMAPlaceholder>(m, "CARMASolver")
-      .def(py::init([](py::args, py::kwargs) -> CARMAPlaceholder {
-        PyErr_SetString(PyExc_NotImplementedError,
-                        "CARMASolver is not part of the MI355X build (out of scope)");
-        throw py::error_already_set();
-      }));
+  // celerite::carma::CARMASolver (carma.h; solver.cpp:200-235): host model algebra + a one-wave Kalman filter
+  // on the device (csrc/carma.hip) behind clr_carma_*
+  py::class_<Carma>(m, "CARMASolver",
+                    "CARMA(p, q) model in carma_pack's parameterisation (reference: celerite.solver.CARMASolver)")
+      .def(py::init([](double log_sigma, const darray& ar, const darray& ma) {
+        Vec a(ar), b(ma);
+        return std::unique_ptr<Carma>(new Carma(log_sigma, a, b));
+      }))
+      .def("log_likelihood",
+           [](Carma& c, const darray& t, const darray& y, const darray& yerr) {
+             Vec vt(t), vy(y), ve(yerr);
+             double out = 0.0;
+             check(clr_carma_log_likelihood(c.h, vt.n(), vt.p(), vy.n(), vy.p(), ve.n(), ve.p(), &out));
+             return out;
+           },
+           "Compute the log likelihood using a Kalman filter (carma.h:221-239)")
+      .def("get_celerite_coeffs",
+           [](Carma& c) {
+             int nr = 0, nc = 0;
+             check(clr_carma_get_celerite_coeffs(c.h, &nr, &nc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+             py::array_t<double> ar(nr), cr(nr), a(nc), b(nc), cc(nc), d(nc);
+             check(clr_carma_get_celerite_coeffs(c.h, nullptr, nullptr, ar.mutable_data(), cr.mutable_data(),
+                                                 a.mutable_data(), b.mutable_data(), cc.mutable_data(), d.mutable_data()));
+             return py::make_tuple(ar, cr, a, b, cc, d);
+           },
+           "Compute the coefficients of the celerite model for the given CARMA model (carma.h:74-139)");
 
   py::class_<Solver> cls(m, "CholeskySolver",
                          "Device-resident semiseparable Cholesky factorisation "

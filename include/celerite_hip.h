@@ -40,11 +40,13 @@ typedef enum clr_status {
   CLR_NO_DEVICE = 4,             /* no gfx950 GPU visible / HIP runtime unusable    */
   CLR_HIP_ERROR = 5,             /* a HIP call failed; see clr_last_error()          */
   CLR_INVALID_ARGUMENT = 6,
-  CLR_UNSUPPORTED = 7            /* e.g. width above CLR_MAX_WIDTH                   */
+  CLR_UNSUPPORTED = 7,           /* e.g. width above CLR_MAX_WIDTH                   */
+  CLR_CARMA_INSTABILITY = 8      /* celerite::carma_exception     exceptions.h:8-12  */
 } clr_status;
 
 /* Widest semiseparable rank J = J_real + 2 J_comp + J_general accepted. */
 #define CLR_MAX_WIDTH 128
+#define CLR_CARMA_MAX_ORDER 32 /* autoregressive order p of clr_carma (state p, covariance p x p in LDS) */
 
 /* ---- library / device ------------------------------------------------------ */
 
@@ -391,6 +393,25 @@ int clr_batch_log_likelihood_sharded(int B, int N, int J_real, int J_comp, const
                                      const double* t, long t_stride, const double* diag, long diag_stride,
                                      const double* y, long y_stride, double* loglike, double* logdet,
                                      double* quad, int* status, const int* devices, int ndevices);
+
+/* ---- celerite::carma::CARMASolver (cpp/include/celerite/carma.h; solver.cpp:200-235) ----
+ * The reference's comparison solver: a CARMA(p, q) process in carma_pack's parameterisation, its log-likelihood by
+ * a Kalman filter, and the conversion to celerite coefficients (tests/test_celerite.py:22-42 checks that the two
+ * likelihoods agree).  The model algebra runs on the host at creation; the filter -- sequential in n -- runs as one
+ * wave on the device.  Errors: q >= p -> CLR_DIMENSION_MISMATCH (carma.h:59); p > CLR_CARMA_MAX_ORDER ->
+ * CLR_UNSUPPORTED; a negative predicted variance -> CLR_CARMA_INSTABILITY (carma.h:185-186). */
+typedef struct clr_carma clr_carma;
+/* CARMASolver(log_sigma, arparams[p], maparams[q]), carma.h:54-72.  NULL on error (see clr_last_error). */
+clr_carma* clr_carma_create(double log_sigma, int p, const double* arparams, int q, const double* maparams,
+                            int* status);
+void clr_carma_destroy(clr_carma* h);
+/* CARMASolver::log_likelihood(t, y, yerr), carma.h:221-239; host pointers, copied in. */
+int clr_carma_log_likelihood(clr_carma* h, int n_t, const double* t, int n_y, const double* y, int n_yerr,
+                             const double* yerr, double* out);
+/* CARMASolver::get_celerite_coeffs, carma.h:74-139.  Counts first (pass NULL arrays), then the values: a_real,
+ * c_real [n_real]; a_comp, b_comp, c_comp, d_comp [n_comp].  No device work. */
+int clr_carma_get_celerite_coeffs(const clr_carma* h, int* n_real, int* n_comp, double* a_real, double* c_real,
+                                  double* a_comp, double* b_comp, double* c_comp, double* d_comp);
 
 /* ---- O(J) host helpers the Python layer imports (celerite/terms.py:18) --------
  * Plain host C++ (no device work): cpp/include/celerite/utils.h:106-163,27-104. */

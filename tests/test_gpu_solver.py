@@ -585,3 +585,62 @@ def test_wide_sweeps_are_chunked_scans(JR, JC, N, general):
         xs = np.linspace(t[0] - 1.0, t[-1] + 1.0, 333)
         p, p0 = s.predict(y, xs), r.predict(y, xs)
         assert np.max(np.abs(p - p0)) <= 1e-9 * max(1.0, np.max(np.abs(p0)))
+
+
+def test_carma():  # tests/test_celerite.py:22-42
+    """The reference's own CARMA test: the Kalman-filter log-likelihood (csrc/carma.hip) equals the celerite
+    log-likelihood of get_celerite_coeffs() through CholeskySolver."""
+    solver = celerite_amd.CholeskySolver()
+    np.random.seed(42)
+    t = np.sort(np.random.uniform(0, 5, 100))
+    yerr = 0.1 + np.zeros_like(t)
+    y = np.sin(t) + yerr * np.random.randn(len(t))
+    carma_solver = celerite_amd.solver.CARMASolver(-0.5, np.array([0.1, 0.05, 0.01]), np.array([0.2, 0.1]))
+    carma_ll = carma_solver.log_likelihood(t, y, yerr)
+    params = carma_solver.get_celerite_coeffs()
+    solver.compute(0.0, params[0], params[1], params[2], params[3], params[4], params[5],
+                   np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t, yerr ** 2)
+    celerite_ll = -0.5 * (solver.dot_solve(y) + solver.log_determinant() + len(t) * np.log(2 * np.pi))
+    assert np.allclose(carma_ll, celerite_ll)
+    assert abs(carma_ll - celerite_ll) <= 1e-10 * abs(celerite_ll)
+
+
+@pytest.mark.parametrize("log_sigma,ar,ma,N", [(-0.5, [0.1, 0.05, 0.01], [0.2, 0.1], 100), (0.3, [0.5, -0.2], [0.1], 777),
+                                               (0.0, [1.0, 0.3, -0.4, 0.2, 0.05], [0.3, -0.1, 0.2], 2000),
+                                               (-1.0, [0.4], [], 1), (0.2, [0.3, 0.1, -0.2, 0.4, 0.0, 0.2, -0.1, 0.3, 0.1], [0.1, 0.2], 300)])
+def test_carma_filter_vs_oracle(log_sigma, ar, ma, N):
+    """CARMASolver.log_likelihood on the device against oracle/carma.py (carma.h:221-239 restated) at 1e-10,
+    orders 1..9, irregular sampling, heteroscedastic errors; repeated calls on one object."""
+    from oracle import carma
+    rng = np.random.RandomState(N)
+    t = np.sort(rng.uniform(0, 0.05 * N + 1, N))
+    yerr = rng.uniform(0.05, 0.3, N)
+    y = np.sin(t) + yerr * rng.randn(N)
+    s = celerite_amd.solver.CARMASolver(log_sigma, np.array(ar), np.array(ma, dtype=float))
+    o = carma.CARMASolver(log_sigma, ar, ma)
+    want = o.log_likelihood(t, y, yerr)
+    for _ in range(2):
+        got = s.log_likelihood(t, y, yerr)
+        assert abs(got - want) <= 1e-10 * abs(want)
+    got2 = s.log_likelihood(t[: N // 2 + 1], y[: N // 2 + 1], yerr[: N // 2 + 1])
+    want2 = o.log_likelihood(t[: N // 2 + 1], y[: N // 2 + 1], yerr[: N // 2 + 1])
+    assert abs(got2 - want2) <= 1e-10 * abs(want2)
+    with pytest.raises(RuntimeError, match="dimension mismatch"):      # carma.h:223
+        s.log_likelihood(t, y[:-1], yerr)
+
+
+def test_carma_instability_raises():  # carma.h:185-186, exceptions.h:8-12
+    """A predicted variance below zero: the reference throws carma_exception (-> RuntimeError).  Unsorted times
+    (negative dt) make the propagators exceed one and drive P indefinite; the oracle raises at the same input."""
+    from oracle import carma
+    ar, ma = [0.1, 0.05, 0.01], [0.2, 0.1]
+    s = celerite_amd.solver.CARMASolver(-0.5, np.array(ar), np.array(ma))
+    o = carma.CARMASolver(-0.5, ar, ma)
+    t_bad = np.array([0.0, 1.0, 0.5, 3.0, 0.0])
+    with pytest.raises(carma.CarmaInstability):
+        o.log_likelihood(t_bad, np.zeros(5), np.zeros(5))
+    with pytest.raises(RuntimeError, match="CARMA model encountered an instability"):
+        s.log_likelihood(t_bad, np.zeros(5), np.zeros(5))
+    t = np.linspace(0, 1, 5)                                            # the object stays usable
+    got, want = s.log_likelihood(t, np.ones(5), 0.1 + np.zeros(5)), o.log_likelihood(t, np.ones(5), 0.1 + np.zeros(5))
+    assert abs(got - want) <= 1e-10 * abs(want)

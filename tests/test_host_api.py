@@ -105,7 +105,7 @@ def test_host_helpers():
     assert k.shape == tau.shape and np.allclose(k, want, rtol=1e-15)
     assert solver.check_coefficients(a, c, ac, bc, cc, dc) is True
     assert solver.check_coefficients(a, c[:1], ac, bc, cc, dc) is False  # utils.h:41
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="dimension mismatch"):     # q >= p, carma.h:59
         solver.CARMASolver(-0.5, np.array([0.1]), np.array([0.2]))
     assert solver.has_autodiff() is True   # forward-mode gradient kernels (csrc/grad_kernels.hip)
 
@@ -212,3 +212,21 @@ def test_shard_bounds_and_sharded_plan_without_a_gpu():
     if batch.device_count() == 0:
         with pytest.raises(RuntimeError, match="no gfx950"):
             batch.ShardedBatchedGP(8, 100, 1, 1, devices=[0, 0])
+
+
+def test_carma_model_algebra_runs_on_the_host():
+    """CARMASolver's constructor and get_celerite_coeffs are parameter algebra (carma.h:54-165): no device
+    needed, same arrays as the oracle's restatement; log_likelihood is a device kernel and fails loudly."""
+    from oracle import carma
+    for log_sigma, ar, ma in [(-0.5, [0.1, 0.05, 0.01], [0.2, 0.1]), (0.3, [0.5, -0.2], [0.1]),
+                              (0.0, [1.0, 0.3, -0.4, 0.2, 0.05], [0.3, -0.1, 0.2]), (-1.0, [0.4], [])]:
+        s = solver.CARMASolver(log_sigma, np.array(ar), np.array(ma, dtype=float))
+        o = carma.CARMASolver(log_sigma, ar, ma)
+        got, want = s.get_celerite_coeffs(), o.get_celerite_coeffs()
+        assert len(got) == 6
+        for g, w in zip(got, want):
+            assert g.shape == w.shape
+            assert np.allclose(g, w, rtol=1e-12, atol=1e-300)
+    if NO_GPU:
+        with pytest.raises(RuntimeError, match="no gfx950"):
+            s.log_likelihood(np.zeros(3), np.zeros(3), np.ones(3))

@@ -292,3 +292,42 @@ def test_grad_oracle_raises_like_the_reference():
     x = np.linspace(0, 1, 20)
     with pytest.raises(ograd.LinAlgError):
         ograd.grad_log_likelihood(0.0, [-3.0], [0.5], [], [], [], [], *NO_GENERAL, x, np.sin(x), np.zeros(20))
+
+
+@pytest.mark.parametrize("log_sigma,ar,ma", [(-0.5, [0.1, 0.05, 0.01], [0.2, 0.1]), (0.3, [0.5, -0.2], [0.1]),
+                                             (0.0, [1.0, 0.3, -0.4, 0.2, 0.05], [0.3, -0.1, 0.2]), (-1.0, [0.4], [])])
+def test_carma_oracle_pinned_by_the_reference_test_identity_and_dense(log_sigma, ar, ma):
+    """oracle/carma.py (restating carma.h) is pinned by what the reference's own test asserts
+    (tests/test_celerite.py:22-42, first parameter set and its seeded inputs): the Kalman-filter likelihood
+    equals the celerite likelihood of get_celerite_coeffs() -- the latter computed by the (pinned) Cholesky
+    oracle -- and by a dense multivariate normal built from covariance(tau) (carma.h:255-272), which involves
+    neither the filter nor the coefficient conversion."""
+    from oracle import carma
+    np.random.seed(42)
+    t = np.sort(np.random.uniform(0, 5, 100))
+    yerr = 0.1 + np.zeros_like(t)
+    y = np.sin(t) + yerr * np.random.randn(len(t))
+    cs = carma.CARMASolver(log_sigma, ar, ma)
+    ll = cs.log_likelihood(t, y, yerr)
+    params = cs.get_celerite_coeffs()
+    r = ref.RefSolver()
+    r.compute(0.0, *params, *NO_GENERAL, t, yerr ** 2)
+    ll_celerite = -0.5 * (r.dot_solve(y) + r.log_determinant() + len(t) * np.log(2 * np.pi))
+    assert abs(ll - ll_celerite) <= 1e-10 * abs(ll_celerite)          # (the reference asserts np.allclose)
+    tau = np.abs(t[:, None] - t[None, :])
+    K = np.vectorize(cs.covariance)(tau) + np.diag(yerr ** 2)
+    _, ld = np.linalg.slogdet(K)
+    ll_dense = -0.5 * (y.dot(np.linalg.solve(K, y)) + ld + len(t) * np.log(2 * np.pi))
+    assert abs(ll - ll_dense) <= 1e-9 * abs(ll_dense)
+    kv = dense.kernel_value(*params, tau[0]) if hasattr(dense, "kernel_value") else None
+    if kv is not None:
+        assert np.allclose(kv, np.vectorize(cs.covariance)(tau[0]), rtol=1e-9, atol=1e-12)
+
+
+def test_carma_oracle_errors():
+    from oracle import carma
+    with pytest.raises(RuntimeError, match="dimension mismatch"):      # carma.h:59
+        carma.CARMASolver(-0.5, [0.1], [0.2])
+    cs = carma.CARMASolver(-0.5, [0.1, 0.05], [0.2])
+    with pytest.raises(RuntimeError, match="dimension mismatch"):      # carma.h:223
+        cs.log_likelihood(np.zeros(3), np.zeros(2), np.ones(3))
