@@ -644,3 +644,25 @@ def test_carma_instability_raises():  # carma.h:185-186, exceptions.h:8-12
     t = np.linspace(0, 1, 5)                                            # the object stays usable
     got, want = s.log_likelihood(t, np.ones(5), 0.1 + np.zeros(5)), o.log_likelihood(t, np.ones(5), 0.1 + np.zeros(5))
     assert abs(got - want) <= 1e-10 * abs(want)
+
+
+@pytest.mark.parametrize("JR,JC,nrhs", [(0, 16, 40), (2, 3, 70), (1, 7, 64)])
+def test_wide_sweeps_many_right_hand_sides(JR, JC, nrhs):
+    """solve with more right-hand sides than one wave of columns holds (the chunk map's J + 1 columns plus nrhs
+    affine columns spill into further column blocks of wsweep_summarize_kernel; the prefix and replay run one
+    workgroup / wave per right-hand side)."""
+    N = 3000
+    rng = np.random.RandomState(nrhs)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    co = (np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+          0.1 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)))
+    s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+    s.compute(0.0, *co, *NO_GENERAL, t, diag)
+    r.compute(0.0, *co, *NO_GENERAL, t, diag)
+    b = rng.randn(N, nrhs)
+    x, x0 = s.solve(b), r.solve(b)
+    assert x.shape == (N, nrhs)
+    assert np.max(np.abs(x - x0)) <= 1e-10 * np.max(np.abs(x0))
+    yl, yl0 = s.dot_L(b), r.dot_L(b)
+    assert np.max(np.abs(yl - yl0)) <= 1e-11 * np.max(np.abs(yl0))
