@@ -746,19 +746,26 @@ static bool sweep_scan_ok(const clr_solver* s) {
 }
 static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, double* quad, int backward) {
   const bool wide = clr::wsweep_scan_supported(s->N, s->J);
-  clr::SweepParams P;
-  memset(&P, 0, sizeof(P));
-  P.N = s->N; P.J = s->J; P.nrhs = nrhs;
-  P.nchunk = wide ? clr::wsweep_chunks(s->N) : clr::sweep_chunks(s->N);
-  P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
-  P.nchunk = (s->N - 1 + P.L - 1) / P.L;
-  P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
-  P.in = in; P.out = out; P.quad = quad; P.backward = backward;
-  int st = s->ws_elems.reserve(wide ? clr::wsweep_workspace_doubles(s->J, P.nchunk, nrhs)
-                                    : clr::sweep_workspace_doubles(s->J, P.nchunk, nrhs));
-  if (st != CLR_OK) return st;
-  if (wide) clr::launch_wsweep_scan(P, s->ws_elems.p, s->stream);
-  else clr::launch_sweep_scan(P, s->ws_elems.p, s->stream);
+  const int SLICE = 16384;  // right-hand sides per launch (grid.y / workspace bound); stream order keeps the slices apart
+  for (int r0 = 0; r0 < nrhs; r0 += SLICE) {
+    const int nr = std::min(SLICE, nrhs - r0);
+    clr::SweepParams P;
+    memset(&P, 0, sizeof(P));
+    P.N = s->N; P.J = s->J; P.nrhs = nr;
+    P.nchunk = wide ? clr::wsweep_chunks(s->N) : clr::sweep_chunks(s->N);
+    P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
+    P.nchunk = (s->N - 1 + P.L - 1) / P.L;
+    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    P.in = in + (size_t)r0 * s->N;
+    P.out = out ? out + (size_t)r0 * s->N : nullptr;
+    P.quad = quad ? quad + r0 : nullptr;
+    P.backward = backward;
+    int st = s->ws_elems.reserve(wide ? clr::wsweep_workspace_doubles(s->J, P.nchunk, nr)
+                                      : clr::sweep_workspace_doubles(s->J, P.nchunk, nr));
+    if (st != CLR_OK) return st;
+    if (wide) clr::launch_wsweep_scan(P, s->ws_elems.p, s->stream);
+    else clr::launch_sweep_scan(P, s->ws_elems.p, s->stream);
+  }
   return CLR_OK;
 }
 
@@ -824,17 +831,21 @@ int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z
   if (nrhs <= 0) return CLR_OK;
   const bool wide = clr::wdotl_scan_supported(s->N, s->J);
   if (wide || clr::sweep_scan_supported(s->N, s->J)) {
-    clr::SweepParams P;
-    memset(&P, 0, sizeof(P));
-    P.N = s->N; P.J = s->J; P.nrhs = nrhs;
-    P.nchunk = wide ? clr::wdotl_chunks(s->N) : clr::sweep_chunks(s->N);
-    P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
-    P.nchunk = (s->N - 1 + P.L - 1) / P.L;
-    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
-    P.in = s->scratch.p; P.out = s->scratch2.p;
-    if ((st = s->ws_elems.reserve((size_t)nrhs * P.nchunk * 3 * s->J)) != CLR_OK) return st;
-    if (wide) clr::launch_wdotl_scan(P, s->ws_elems.p, s->stream);
-    else clr::launch_dot_L_scan(P, s->ws_elems.p, s->stream);
+    const int SLICE = 16384;  // right-hand sides per launch (grid.y bound)
+    for (int r0 = 0; r0 < nrhs; r0 += SLICE) {
+      const int nr = std::min(SLICE, nrhs - r0);
+      clr::SweepParams P;
+      memset(&P, 0, sizeof(P));
+      P.N = s->N; P.J = s->J; P.nrhs = nr;
+      P.nchunk = wide ? clr::wdotl_chunks(s->N) : clr::sweep_chunks(s->N);
+      P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
+      P.nchunk = (s->N - 1 + P.L - 1) / P.L;
+      P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+      P.in = s->scratch.p + (size_t)r0 * s->N; P.out = s->scratch2.p + (size_t)r0 * s->N;
+      if ((st = s->ws_elems.reserve((size_t)nr * P.nchunk * 3 * s->J)) != CLR_OK) return st;
+      if (wide) clr::launch_wdotl_scan(P, s->ws_elems.p, s->stream);
+      else clr::launch_dot_L_scan(P, s->ws_elems.p, s->stream);
+    }
   } else {
     clr::launch_dot_L(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
                       s->scratch2.p, s->stream);

@@ -598,6 +598,11 @@ summarize_split_kernel(const BatchParams P) {
   const long cell = (long)b * P.nchunk + (store ? c : 0);
   double* elem = P.elems + cell * Wd::ELEM;
   double* slot = ring[set] + lane;
+  // The rider wave gets the issue priority: its step starts with LDS round trips (the published step, then Jm),
+  // so it has the fewer instructions ready at any moment and loses the arbitration to the trajectory's long
+  // fp64 runs -- yet the trajectory cannot run ahead of it by more than one slot.  Measured on one box, same
+  // run: 3.08 ms default, 3.08 ms with T prioritised, 2.85 ms with R prioritised (profiles/r02b_split_notes.txt).
+  if (role == 1) __builtin_amdgcn_s_setprio(3);
   if (role == 0) {
     DirectSeries src = make_direct(P, b, store ? c : 0);
     if (!store) src.nleft = 0;  // lanes past the last chunk / dead sets: padding only
