@@ -44,6 +44,8 @@
 // the gap to the single-wave kernel's 3.5 ms is R idling: its step is shorter than T's.)
 #pragma once
 
+#include <type_traits>
+
 #include "clr_batch_kernels.h"
 
 namespace clr {
@@ -474,54 +476,76 @@ __device__ __forceinline__ void split_riders_lazy(int L, int n0, int N, bool sto
   double q0 = 0.0;
 #pragma unroll
   for (int f = 0; f < LkJ::NJM; ++f) jm[f * 64] = make_double2(0.0, 0.0);
-  for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
-    const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
-    for (int i = i0; i < i1; ++i) {
-      split_barrier();  // B(i)
-      const double* slot = slot0 + (i & 1) * (Lk::NPAY * 64);
-      double u[J], W[J], r[J];
+  // Jm -= r r^T / D is a pure accumulation (never read inside the loop) and its read-modify-write is most of the
+  // riders' LDS traffic (37 of 45 KB per wave and step).  The steps go in PAIRS: the first keeps its (r, 1/D) in
+  // the 18 registers the riders have left, the second folds both rank-one terms in with one pass over the cells.
+  // Steps past the end of the series contribute exact zeros (selects, no branch).  Worth 1.5 % once the riders have
+  // the issue priority (2.53 -> 2.49 ms, same box; nothing before that: profiles/r02b_split_notes.txt).
+  double rp[J], invDp = 0.0;
+  // MODE 0: first of a pair (defer); 1: second of a pair (fold both); 2: a lone last step of the block
+  auto step = [&](int i, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    split_barrier();  // B(i)
+    const double* slot = slot0 + (i & 1) * (Lk::NPAY * 64);
+    double u[J], W[J], r[J];
 #pragma unroll
-      for (int k = 0; k < J; ++k) u[k] = slot[(Lk::F_U + k) * 64];
+    for (int k = 0; k < J; ++k) u[k] = slot[(Lk::F_U + k) * 64];
 #pragma unroll
-      for (int k = 0; k < J; ++k) W[k] = slot[(Lk::F_W + k) * 64];
-      const double invD = slot[Lk::F_INVD * 64];
-      const double y = slot[Lk::F_Y * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const bool valid = n0 + i < N;
-      double ub = 0.0;
+    for (int k = 0; k < J; ++k) W[k] = slot[(Lk::F_W + k) * 64];
+    const double invD = slot[Lk::F_INVD * 64];
+    const double y = slot[Lk::F_Y * 64];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool valid = n0 + i < N;
+    double ub = 0.0;
 #pragma unroll
-      for (int k = 0; k < J; ++k) ub += u[k] * b[k];
-      const double x = y - ub;           // cholesky.h:353-355 from the zero start
-      const double xs = x * invD;
+    for (int k = 0; k < J; ++k) ub += u[k] * b[k];
+    const double x = y - ub;           // cholesky.h:353-355 from the zero start
+    const double xs = x * invD;
 #pragma unroll
-      for (int k = 0; k < J; ++k) b[k] = fma(W[k], x, b[k]);
+    for (int k = 0; k < J; ++k) b[k] = fma(W[k], x, b[k]);
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double racc = 0.0;
+    for (int j = 0; j < J; ++j) {
+      double racc = 0.0;
 #pragma unroll
-        for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
-        r[j] = racc;
+      for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
+      r[j] = valid ? racc : 0.0;
 #pragma unroll
-        for (int k = 0; k < J; ++k) Acol[j * J + k] = fma(-W[k], racc, Acol[j * J + k]);
-      }
-      if (valid) {
-        q0 += x * xs;
-        double rs[J];
+      for (int k = 0; k < J; ++k) Acol[j * J + k] = fma(-W[k], racc, Acol[j * J + k]);
+    }
+    const double vinvD = valid ? invD : 0.0, vxs = valid ? xs : 0.0;
+    q0 += valid ? x * xs : 0.0;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-          rs[j] = r[j] * invD;
-          eta[j] -= r[j] * xs;
+    for (int j = 0; j < J; ++j) eta[j] = fma(-r[j], vxs, eta[j]);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) rp[j] = r[j];
+      invDp = vinvD;
+    } else {
+      double rs[J], rsp[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) { rs[j] = r[j] * vinvD; rsp[j] = (MODE == 1) ? rp[j] * invDp : 0.0; }
+#pragma unroll
+      for (int f = 0; f < LkJ::NJM; ++f) {
+        double2 d = jm[f * 64];
+        if (MODE == 1) d.x = fma(-rp[tri_row(2 * f)], rsp[tri_col(2 * f)], d.x);
+        d.x = fma(-r[tri_row(2 * f)], rs[tri_col(2 * f)], d.x);
+        if (2 * f + 1 < SZ) {
+          if (MODE == 1) d.y = fma(-rp[tri_row(2 * f + 1)], rsp[tri_col(2 * f + 1)], d.y);
+          d.y = fma(-r[tri_row(2 * f + 1)], rs[tri_col(2 * f + 1)], d.y);
         }
-#pragma unroll
-        for (int f = 0; f < LkJ::NJM; ++f) {
-          double2 d = jm[f * 64];
-          d.x -= r[tri_row(2 * f)] * rs[tri_col(2 * f)];
-          if (2 * f + 1 < SZ) d.y -= r[tri_row(2 * f + 1)] * rs[tri_col(2 * f + 1)];
-          jm[f * 64] = d;
-          if ((f % 6) == 5) __builtin_amdgcn_sched_barrier(0);  // (keep the 18 cells from being loaded all at once)
-        }
+        jm[f * 64] = d;
+        if ((f % 6) == 5) __builtin_amdgcn_sched_barrier(0);  // (keep the 18 cells from being loaded all at once)
       }
     }
+  };
+  for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
+    const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+      step(i, std::integral_constant<int, 0>());
+      step(i + 1, std::integral_constant<int, 1>());
+    }
+    if (i < i1) step(i, std::integral_constant<int, 2>());
     {  // the block's accumulated decay (published by T with the block's last step; T rewrites it 16 steps on)
       double psi[nz(M)];
 #pragma unroll
