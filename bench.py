@@ -327,10 +327,17 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         from celerite_amd import batch as _b
 
-        if _b.device_count() < args.gpus:
+        if _b.device_count() < args.gpus and not os.environ.get("CLR_BENCH_SHARE_GPU"):
             raise SystemExit("--gpus %d but only %d MI355X visible" % (args.gpus, _b.device_count()))
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
 
+    # the one JSON line must be the only thing on stdout: gloo's C++ prints its "[Gloo] Rank ..." notices there,
+    # so with several ranks everything else written to fd 1 goes to stderr and rank 0 prints to the saved fd
+    json_fd = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     dist = Dist()
     if dist.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world))
@@ -499,7 +506,11 @@ def main(argv=None):
     dist.barrier()
     dist.close()
     if out is not None:
-        print(json.dumps(out))
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     return out
 
 
