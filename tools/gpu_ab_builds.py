@@ -1,3 +1,6 @@
+"""A/B of two BUILDS of libcelerite_hip.so on one box (box-to-box variation is 5-10 %): copy each build to
+variants/lib<X>.so, then `for v in A B A B; do CLR_LIB=$PWD/variants/lib$v.so python tools/gpu_ab_builds.py; done`
+inside ONE gpurun call.  Headline shape, summarize kernel time + a checksum of the log-determinants."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.getcwd())
