@@ -976,7 +976,7 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
     pchunk = clr::sweep_chunks(s->N);
     pL = (s->N + pchunk - 1) / pchunk;
     pchunk = (s->N + pL - 1) / pL;
-    if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk))) != CLR_OK) return st;
+    if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk, s->J_real + 2 * s->J_comp))) != CLR_OK) return st;
   }
   DevBuf dxs, dpred;
   if ((st = upload(dxs, xs, (size_t)M, stream)) != CLR_OK) return st;

@@ -52,7 +52,7 @@ void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s);
 void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s);
 // predict (cholesky.h:599-698): chunked diagonal scans + one thread per (sorted) prediction point
 bool predict_scan_supported(int N, int J_real, int J_comp);
-size_t predict_workspace_doubles(int nchunk);
+size_t predict_workspace_doubles(int nchunk, int rows);
 void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, const double* xs, double* pred,
                          double* workspace, int nchunk, int L, hipStream_t s);
 

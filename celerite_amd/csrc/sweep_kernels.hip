@@ -256,16 +256,19 @@ struct PredictRows {
   int rows;
 };
 
-__device__ __forceinline__ void load_rows(const GenericProblem& g, PredictRows& r) {
+// rows row0 .. row0 + PJ - 1 of the J_real + 2 J_comp rows (wider kernels go block of PJ rows by block: the
+// recurrences are diagonal, every row is on its own)
+__device__ __forceinline__ void load_rows(const GenericProblem& g, PredictRows& r, int row0 = 0) {
   r.rows = g.J_real + 2 * g.J_comp;
 #pragma unroll
   for (int j = 0; j < PJ; ++j) {
+    const int row = row0 + j;
     r.kind[j] = -1; r.a[j] = r.b[j] = r.c[j] = r.d[j] = 0.0;
-    if (j < g.J_real) {
-      r.kind[j] = 0; r.a[j] = g.a_real[j]; r.c[j] = g.c_real[j];
-    } else if (j < r.rows) {
-      const int jj = (j - g.J_real) >> 1;
-      r.kind[j] = 1 + ((j - g.J_real) & 1);
+    if (row < g.J_real) {
+      r.kind[j] = 0; r.a[j] = g.a_real[row]; r.c[j] = g.c_real[row];
+    } else if (row < r.rows) {
+      const int jj = (row - g.J_real) >> 1;
+      r.kind[j] = 1 + ((row - g.J_real) & 1);
       r.a[j] = g.a_comp[jj]; r.b[j] = g.b_comp[jj]; r.c[j] = g.c_comp[jj]; r.d[j] = g.d_comp[jj];
     }
   }
@@ -295,14 +298,15 @@ __device__ __forceinline__ void predict_step(const PredictRows& r, const double*
   }
 }
 
-// elems: [dir][chunk][2 PJ] = (a, c);  starts: [dir][chunk][PJ]
+// elems: [row block][dir][chunk][2 PJ] = (a, c);  starts: [row block][dir][chunk][PJ]
 __global__ void __launch_bounds__(64) predict_summarize_kernel(GenericProblem g, const double* alpha,
                                                                int nchunk, int L, double* elems) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= nchunk) return;
-  const int dir = blockIdx.y;
+  const int dir = blockIdx.y, blk = blockIdx.z;
+  elems += (long)blk * 2 * nchunk * (2 * PJ);
   PredictRows r;
-  load_rows(g, r);
+  load_rows(g, r, blk * PJ);
   double Q[PJ], A[PJ];
 #pragma unroll
   for (int j = 0; j < PJ; ++j) { Q[j] = 0.0; A[j] = 1.0; }
@@ -315,8 +319,10 @@ __global__ void __launch_bounds__(64) predict_summarize_kernel(GenericProblem g,
 }
 
 __global__ void __launch_bounds__(64) predict_prefix_kernel(int nchunk, const double* elems, double* starts) {
-  const int dir = threadIdx.x;
+  const int dir = threadIdx.x, blk = blockIdx.x;
   if (dir > 1) return;
+  elems += (long)blk * 2 * nchunk * (2 * PJ);
+  starts += (long)blk * 2 * nchunk * PJ;
   double Q[PJ];
 #pragma unroll
   for (int j = 0; j < PJ; ++j) Q[j] = 0.0;
@@ -340,8 +346,6 @@ __global__ void __launch_bounds__(64) predict_points_kernel(GenericProblem g, co
   const int N = g.N;
   const double* t = g.t;
   const double xm = xs[m];
-  PredictRows r;
-  load_rows(g, r);
   // k = number of samples with t_n < x_m  (lower bound)
   int lo = 0, hi = N;
   while (lo < hi) {
@@ -350,54 +354,63 @@ __global__ void __launch_bounds__(64) predict_points_kernel(GenericProblem g, co
   }
   const int k = lo;
   double total = 0.0;
-  if (k >= 1) {  // forward: interval n = k - 1 (t_n < x_m <= t_{n+1}, or beyond the last sample)
-    const int nf = k - 1, c = nf / L;
-    double Q[PJ];
+  const int nblk = (g.J_real + 2 * g.J_comp + PJ - 1) / PJ;
+  for (int blk = 0; blk < nblk; ++blk) {
+    PredictRows r;
+    load_rows(g, r, blk * PJ);
+    const double* bstarts = starts + (long)blk * 2 * nchunk * PJ;
+    if (k >= 1) {  // forward: interval n = k - 1 (t_n < x_m <= t_{n+1}, or beyond the last sample)
+      const int nf = k - 1, c = nf / L;
+      double Q[PJ];
 #pragma unroll
-    for (int j = 0; j < PJ; ++j) Q[j] = starts[((long)0 * nchunk + c) * PJ + j];
-    for (int n = c * L; n <= nf; ++n) predict_step(r, t, alpha, N, n, 0, Q, nullptr);
-    const double tref = nf < N - 1 ? t[nf + 1] : t[N - 1];
-    const double dt = xm - tref;  // :640
+      for (int j = 0; j < PJ; ++j) Q[j] = bstarts[((long)0 * nchunk + c) * PJ + j];
+      for (int n = c * L; n <= nf; ++n) predict_step(r, t, alpha, N, n, 0, Q, nullptr);
+      const double tref = nf < N - 1 ? t[nf + 1] : t[N - 1];
+      const double dt = xm - tref;  // :640
 #pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-      if (r.kind[j] < 0) continue;
-      double u, v;
-      row_uv(r, j, xm, &u, &v);
-      total += u * exp(-r.c[j] * dt) * Q[j];  // :643,649-650
+      for (int j = 0; j < PJ; ++j) {
+        if (r.kind[j] < 0) continue;
+        double u, v;
+        row_uv(r, j, xm, &u, &v);
+        total += u * exp(-r.c[j] * dt) * Q[j];  // :643,649-650
+      }
     }
-  }
-  if (k < N) {  // backward: interval n = k (t_{n-1} < x_m <= t_n, or at / before the first sample)
-    const int nb = k, c = nb / L;
-    double Q[PJ];
+    if (k < N) {  // backward: interval n = k (t_{n-1} < x_m <= t_n, or at / before the first sample)
+      const int nb = k, c = nb / L;
+      double Q[PJ];
 #pragma unroll
-    for (int j = 0; j < PJ; ++j) Q[j] = starts[((long)1 * nchunk + c) * PJ + j];
-    for (int n = min(c * L + L, N) - 1; n >= nb; --n) predict_step(r, t, alpha, N, n, 1, Q, nullptr);
-    const double tref = nb > 0 ? t[nb - 1] : t[0];
-    const double dt = tref - xm;  // :683
-    double pm = 0.0;
+      for (int j = 0; j < PJ; ++j) Q[j] = bstarts[((long)1 * nchunk + c) * PJ + j];
+      for (int n = min(c * L + L, N) - 1; n >= nb; --n) predict_step(r, t, alpha, N, n, 1, Q, nullptr);
+      const double tref = nb > 0 ? t[nb - 1] : t[0];
+      const double dt = tref - xm;  // :683
+      double pm = 0.0;
 #pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-      if (r.kind[j] < 0) continue;
-      double u, v;
-      row_uv(r, j, xm, &u, &v);
-      pm += v * exp(-r.c[j] * dt) * Q[j];  // :686,690-691
+      for (int j = 0; j < PJ; ++j) {
+        if (r.kind[j] < 0) continue;
+        double u, v;
+        row_uv(r, j, xm, &u, &v);
+        pm += v * exp(-r.c[j] * dt) * Q[j];  // :686,690-691
+      }
+      total += pm;
     }
-    total += pm;
   }
   pred[m] = total;
 }
 
 }  // namespace
 
-bool predict_scan_supported(int N, int J_real, int J_comp) { return J_real + 2 * J_comp <= PJ && N >= 256; }
-size_t predict_workspace_doubles(int nchunk) { return (size_t)2 * nchunk * (3 * PJ); }
+// (any width: rows go in blocks of PJ; the sequential kernel took 168 ms at width 16, N = 1e5, M = 2e4 -- the CPU 40)
+bool predict_scan_supported(int N, int J_real, int J_comp) { return J_real + 2 * J_comp >= 1 && N >= 256; }
+static int predict_blocks(const GenericProblem& g) { return (g.J_real + 2 * g.J_comp + PJ - 1) / PJ; }
+size_t predict_workspace_doubles(int nchunk, int rows) { return (size_t)((rows + PJ - 1) / PJ) * 2 * nchunk * (3 * PJ); }
 
 void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, const double* xs, double* pred,
                          double* workspace, int nchunk, int L, hipStream_t s) {
+  const int nblk = predict_blocks(g);
   double* elems = workspace;
-  double* starts = workspace + (size_t)2 * nchunk * 2 * PJ;
-  hipLaunchKernelGGL(predict_summarize_kernel, dim3((nchunk + 63) / 64, 2), dim3(64), 0, s, g, alpha, nchunk, L, elems);
-  hipLaunchKernelGGL(predict_prefix_kernel, dim3(1), dim3(64), 0, s, nchunk, elems, starts);
+  double* starts = workspace + (size_t)nblk * 2 * nchunk * 2 * PJ;
+  hipLaunchKernelGGL(predict_summarize_kernel, dim3((nchunk + 63) / 64, 2, nblk), dim3(64), 0, s, g, alpha, nchunk, L, elems);
+  hipLaunchKernelGGL(predict_prefix_kernel, dim3(nblk), dim3(64), 0, s, nchunk, elems, starts);
   hipLaunchKernelGGL(predict_points_kernel, dim3((M + 63) / 64), dim3(64), 0, s, g, alpha, nchunk, L, starts, M, xs, pred);
 }
 
