@@ -897,9 +897,9 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
   }
 
   // this call must not disturb a previously computed factor: use private buffers
-  DevBuf coeffs, tt, dU, dV, phi, u, v, dg, zin, yout;
+  DevBuf coeffs, tt, dU, dV, phi, u, v, dg, zin, yout, ws;
   auto cleanup = [&]() {
-    for (DevBuf* b : {&coeffs, &tt, &dU, &dV, &phi, &u, &v, &dg, &zin, &yout}) b->release();
+    for (DevBuf* b : {&coeffs, &tt, &dU, &dV, &phi, &u, &v, &dg, &zin, &yout, &ws}) b->release();
   };
   std::vector<double> hc;
   double sum_ar = 0.0, sum_ac = 0.0;
@@ -935,7 +935,24 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
   g.b_comp = g.a_comp + J_comp; g.c_comp = g.b_comp + J_comp; g.d_comp = g.c_comp + J_comp;
   g.U = dU.p; g.V = dV.p; g.t = tt.p;
   clr::launch_dot_setup(g, phi.p, u.p, v.p, stream);
-  clr::launch_dot(N, J, nrhs, phi.p, u.p, v.p, dg.p, zin.p, yout.p, stream);
+  if (clr::wdotl_scan_supported(N, J)) {  // long series: both triangles as chunked diagonal scans
+    const int SLICE = 16384;
+    for (int r0 = 0; r0 < nrhs; r0 += SLICE) {
+      const int nr = std::min(SLICE, nrhs - r0);
+      clr::SweepParams SP;
+      memset(&SP, 0, sizeof(SP));
+      SP.N = N; SP.J = J; SP.nrhs = nr;
+      SP.nchunk = clr::wdotl_chunks(N);
+      SP.L = (N - 1 + SP.nchunk - 1) / SP.nchunk;
+      SP.nchunk = (N - 1 + SP.L - 1) / SP.L;
+      SP.phi = phi.p; SP.u = u.p;
+      SP.in = zin.p + (size_t)r0 * N; SP.out = yout.p + (size_t)r0 * N;
+      DOT_TRY(ws.reserve((size_t)nr * SP.nchunk * 3 * J));
+      clr::launch_wdot_scan(SP, v.p, dg.p, ws.p, stream);
+    }
+  } else {
+    clr::launch_dot(N, J, nrhs, phi.p, u.p, v.p, dg.p, zin.p, yout.p, stream);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess)
     e = hipMemcpyAsync(y, yout.p, sizeof(double) * total, hipMemcpyDeviceToHost, stream);

@@ -48,6 +48,8 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s);
 bool wdotl_scan_supported(int N, int J);
 int wdotl_chunks(int N);
 void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s);
+// dot (cholesky.h:533-560) the same way; P.phi / P.u = dot's own phi, u (J x N), v J x N, dg the diagonal
+void launch_wdot_scan(SweepParams P, const double* v, const double* dg, double* workspace, hipStream_t s);
 // dot_L (cholesky.h:409-431) as a chunked diagonal scan; workspace: nrhs * nchunk * 3 J doubles
 void launch_dot_L_scan(SweepParams P, double* workspace, hipStream_t s);
 // predict (cholesky.h:599-698): chunked diagonal scans + one thread per (sorted) prediction point

@@ -343,7 +343,83 @@ __global__ void __launch_bounds__(64) wdotl_prefix_kernel(const SweepParams P) {
   }
 }
 
+// dot (cholesky.h:533-560): y = K z from phi, u, v (all J x N) and the diagonal dg -- two more diagonal
+// recurrences, PASS 0 the upper triangle walking n down (:536-547), PASS 1 the lower one walking n up (:549-559),
+// each as summarize / prefix (wdotl_prefix_kernel) / replay over chunks of the step index s = 1 .. N-1.
+template <bool REPLAY, int PASS>
+__global__ void __launch_bounds__(64) wdot_kernel(const SweepParams P, const double* __restrict__ v,
+                                                  const double* __restrict__ dg) {
+  constexpr int KB = 8;
+  const int J = P.J, N = P.N, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
+  const bool have = lane < J;
+  const double* z = P.in + (long)rhs * N;
+  double* y = P.out + (long)rhs * N;
+  const long slot = (long)rhs * P.nchunk + c;
+  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + lane] : 0.0;
+  const int s0 = c * P.L + 1;
+  const int s1 = min(s0 + P.L, N);
+  if (REPLAY && PASS == 0 && c == 0 && lane == 0) y[N - 1] = dg[N - 1] * z[N - 1];  // :535
+  const double* wp = PASS == 0 ? P.u : v;   // weight of the incoming z
+  const double* op = PASS == 0 ? v : P.u;   // weight of f in the output
+  double np[KB], nw[KB], no[KB], nzin = 0.0, nbase = 0.0;
+  auto fetch = [&](int sb) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int s = sb + k;
+      const int n = PASS == 0 ? N - 1 - s : s;
+      const long base = (long)J * (PASS == 0 ? n : n - 1);
+      const bool ok = s < s1 && have;
+      np[k] = ok ? P.phi[base + lane] : 0.0;
+      nw[k] = ok ? wp[base + lane] : 0.0;
+      no[k] = (REPLAY && ok) ? op[base + lane] : 0.0;
+    }
+    const int s = sb + lane;  // lanes 0 .. KB-1: the step's scalars
+    const int n = PASS == 0 ? N - 1 - s : s;
+    const bool ok = lane < KB && s < s1;
+    nzin = ok ? z[PASS == 0 ? n + 1 : n - 1] : 0.0;
+    nbase = (REPLAY && ok) ? (PASS == 0 ? dg[n] * z[n] : y[n]) : 0.0;  // (PASS 1 adds to PASS 0's result)
+  };
+  fetch(s0);
+  for (int sb = s0; sb < s1; sb += KB) {
+    double cp[KB], cw[KB], co[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { cp[k] = np[k]; cw[k] = nw[k]; co[k] = no[k]; }
+    const double czin = nzin, cbase = nbase;
+    if (sb + KB < s1) fetch(sb + KB);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int s = sb + k;
+      if (s < s1) {
+        f = cp[k] * (f + cw[k] * lane_value(czin, k));  // :540-542 / :552-554
+        if (!REPLAY) a *= cp[k];
+        if (REPLAY) {
+          const double val = lane_value(cbase, k) + wsum(co[k] * f);  // :543-545 / :555-557
+          if (lane == 0) y[PASS == 0 ? N - 1 - s : s] = val;
+        }
+      }
+    }
+  }
+  if (!REPLAY && have) {
+    P.elems[slot * 2 * J + lane] = a;
+    P.elems[slot * 2 * J + J + lane] = f;
+  }
+}
+
 }  // namespace
+
+// workspace: nrhs * nchunk * 3 J doubles; P.phi, P.u = phi, u of `dot`'s own setup (J x N), P.in = z, P.out = y
+void launch_wdot_scan(SweepParams P, const double* v, const double* dg, double* workspace, hipStream_t s) {
+  const size_t pc = (size_t)P.nrhs * P.nchunk;
+  P.elems = workspace;
+  P.starts = P.elems + pc * 2 * P.J;
+  const dim3 grid(P.nchunk, P.nrhs);
+  hipLaunchKernelGGL((wdot_kernel<false, 0>), grid, dim3(64), 0, s, P, v, dg);
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
+  hipLaunchKernelGGL((wdot_kernel<true, 0>), grid, dim3(64), 0, s, P, v, dg);
+  hipLaunchKernelGGL((wdot_kernel<false, 1>), grid, dim3(64), 0, s, P, v, dg);
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
+  hipLaunchKernelGGL((wdot_kernel<true, 1>), grid, dim3(64), 0, s, P, v, dg);
+}
 
 bool wdotl_scan_supported(int N, int J) { return J >= 1 && J <= 64 && N >= 2048; }
 int wdotl_chunks(int N) { return std::max(2, std::min(512, (N - 1) / 128)); }

@@ -666,3 +666,30 @@ def test_wide_sweeps_many_right_hand_sides(JR, JC, nrhs):
     assert np.max(np.abs(x - x0)) <= 1e-10 * np.max(np.abs(x0))
     yl, yl0 = s.dot_L(b), r.dot_L(b)
     assert np.max(np.abs(yl - yl0)) <= 1e-11 * np.max(np.abs(yl0))
+
+
+@pytest.mark.parametrize("JR,JC,N,general", [(1, 1, 2500, False), (2, 3, 6000, True), (0, 8, 4000, False), (3, 14, 3000, True)])
+def test_dot_long_series_is_a_chunked_scan(JR, JC, N, general):
+    """dot (cholesky.h:444-590) at N >= 2048: both triangles as chunked diagonal scans (wdot_kernel in
+    csrc/wsweep_kernels.hip): against a dense K z and against the oracle's sequential sweeps."""
+    rng = np.random.RandomState(JR * 10 + JC)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    co = (np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+          0.1 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)))
+    gen = NO_GENERAL
+    if general:
+        U = np.vander((t - t.mean()) / (t.max() - t.min()), 3).T
+        V = U * rng.rand(3)[:, None]
+        gen = (np.sum(U * V, axis=0) + 1e-8, U, V)
+    z = rng.randn(N, 3)
+    s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+    y = s.dot(0.3, *co, *gen, t, z)
+    y0 = r.dot(0.3, *co, *gen, t, z)
+    assert y.shape == (N, 3)
+    assert np.max(np.abs(y - y0)) <= 1e-11 * np.max(np.abs(y0))
+    K = get_kernel_value(*co, t[:, None] - t[None, :])
+    K[np.diag_indices_from(K)] += 0.3
+    if general:
+        K[np.diag_indices_from(K)] += gen[0]
+        K += np.tril(np.dot(gen[1].T, gen[2]), -1) + np.triu(np.dot(gen[2].T, gen[1]), 1)
+    assert np.allclose(np.dot(K, z), y, rtol=1e-9, atol=1e-9)
