@@ -557,15 +557,23 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
 // (level 1: chunked replay + end-state check).
 template <int J>
 __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.B || !P.cond || !(P.cert_gamma > 0.0) || P.need_exact[b] != 0) return;
+  // one wave per problem: max / min over the chunks' records are order-independent
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!P.cond || !(P.cert_gamma > 0.0) || P.need_exact[b] != 0) return;
+  // NaN records stick (and then fail the comparison below: ill-conditioned)
+  auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
+  auto nmin = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x < a ? x : a)); };
   double g = 0.0, m = 1.0;
-  for (int c = 0; c < P.nchunk; ++c) {
-    const double gc = P.cond[((long)b * P.nchunk + c) * 3], mc = P.cond[((long)b * P.nchunk + c) * 3 + 1];
-    if (!(gc <= g)) g = gc;
-    if (!(mc >= m)) m = mc;
+  for (int c = lane; c < P.nchunk; c += 64) {
+    g = nmax(g, P.cond[((long)b * P.nchunk + c) * 3]);
+    m = nmin(m, P.cond[((long)b * P.nchunk + c) * 3 + 1]);
   }
-  if (!(g < P.cert_gamma * m)) P.need_exact[b] = 1;  // (NaN records count as ill-conditioned)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    g = nmax(g, __shfl_xor(g, off, 64));
+    m = nmin(m, __shfl_xor(m, off, 64));
+  }
+  if (lane == 0 && !(g < P.cert_gamma * m)) P.need_exact[b] = 1;  // (NaN records count as ill-conditioned)
 }
 
 // ---------------------------------------------------------------------------
@@ -665,7 +673,7 @@ struct BatchImpl {
     const long lanes = (long)P.B * P.nchunk;
     hipLaunchKernelGGL((correct_kernel<JR + 2 * JC>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s,
                        P);
-    hipLaunchKernelGGL((decide_kernel<JR + 2 * JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+    hipLaunchKernelGGL((decide_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
   }
   static void replay(const BatchParams& P, int materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
