@@ -40,8 +40,11 @@
 // slot.  T may overwrite slot i & 1 again in step i + 2, i.e. after B(i + 1), which R only
 // reaches once its reads of step i are done.  (Measured alternatives: two barriers around one
 // slot 3.40 ms; a barrier-free hand-over through a marker in the slot, R polling with s_sleep,
-// 3.31 ms; this 3.20 ms; without any synchronisation -- wrong results -- 2.94 ms.  The rest of
-// the gap to the single-wave kernel's 3.5 ms is R idling: its step is shorter than T's.)
+// 3.31 ms; this 3.20 ms; without any synchronisation -- wrong results -- 2.94 ms.)
+// The two waves of a SIMD share ONE issue port (fp64: 2.46 ns per instruction per SIMD at any wave count), so the
+// step costs about the SUM of both instruction streams; what arbitration there is goes to the RIDERS (s_setprio,
+// see the kernel): their step opens with LDS round trips, and unprioritised they lose the port to T's long fp64
+// runs although T can never be more than one slot ahead (-8 %; profiles/r02b_split_notes.txt has the breakdown).
 #pragma once
 
 #include <type_traits>
