@@ -488,6 +488,22 @@ def main(argv=None):
                                  "kernel's HIP-event time; whole_step_frac = (factor + two passes over the "
                                  "series) over the whole materialising step (summarize runs first)"},
         }
+        # SURVEY.md 8(d) layout (ii): ONE series shared by all B hyper-parameter draws (the MCMC case; t, diag, y with
+        # stride 0: 2.4 MB of series in HBM instead of 2.4 GB).  For information; `value` is layout (i), B distinct series.
+        try:
+            plan.set_series(t[0], diag[0], y[0])
+            plan.set_coefficients(*coeffs)
+            plan.enqueue(); plan.synchronize()
+            sh_ms, sh_k = plan.run_timed(K, relayout_each_step=False)
+            lls, lds, qs, sts = plan.results()
+            out["shared_series"] = {
+                "what": "layout (ii): one series x B draws, device-only step (series stride 0)",
+                "ms_per_step": sh_ms / K, "value": B * dist.world / (sh_ms / K * 1e-3),
+                "kernels_ms": {k: v / K for k, v in sh_k.items()},
+                "problem0_logdet_vs_distinct_series_run": float(abs(lds[0] - ld[0]) / abs(ld[0])),
+            }
+        except Exception as e:  # a failing side leg must not lose the headline line
+            out["shared_series"] = {"error": repr(e)}
         if dist.world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, st, B, N))
     plan.close()
