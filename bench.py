@@ -320,6 +320,7 @@ def main(argv=None):
     ap.add_argument("--chunks", type=int, default=0, help="scan chunks per problem (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 0/1/4 block")
+    ap.add_argument("--no-shared-series", action="store_true", help="skip the layout-(ii) leg (profiling runs: keeps the per-kernel counter averages to the distinct-series launches)")
     ap.add_argument("--steady-seconds", type=float, default=2.5)
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="untimed extra warm-up before the K timed steps")
     args = ap.parse_args(argv)
@@ -491,6 +492,8 @@ def main(argv=None):
         # SURVEY.md 8(d) layout (ii): ONE series shared by all B hyper-parameter draws (the MCMC case; t, diag, y with
         # stride 0: 2.4 MB of series in HBM instead of 2.4 GB).  For information; `value` is layout (i), B distinct series.
         try:
+            if args.no_shared_series:
+                raise RuntimeError("skipped (--no-shared-series)")
             plan.set_series(t[0], diag[0], y[0])
             plan.set_coefficients(*coeffs)
             plan.enqueue(); plan.synchronize()

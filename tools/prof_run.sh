@@ -2,7 +2,7 @@
 # their own passes, every pass under its own timeout (a combined FETCH_SIZE + WRITE_SIZE pass once hung).
 mkdir -p gpurun_out
 R=$PWD
-BENCH="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --steady-seconds 0 --settle-seconds 0"
+BENCH="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --steady-seconds 0 --settle-seconds 0"
 cd /tmp && export TMPDIR=/tmp
 timeout 150 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace -o trace -- $BENCH > $R/gpurun_out/trace.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o pmc -- $BENCH > $R/gpurun_out/pmc_fetch.log 2>&1
