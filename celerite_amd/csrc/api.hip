@@ -277,6 +277,10 @@ struct clr_solver {
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
   int* d_status = nullptr;
+  // pinned staging of compute's inputs and results: copies from pageable memory cost ~15 us of host time each
+  // (six of them per GP.log_likelihood on a short series: profiles/r02zzz_config0_hip_trace.txt)
+  double* pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
 };
 
 struct clr_batch {
@@ -380,6 +384,38 @@ int upload_coeffs(DevBuf& buf, int J_real, const double* a_real, const double* c
   return upload(buf, host.data(), host.size(), stream);
 }
 
+// compute's uploads: through the solver's pinned arena when they fit (reset at the start of every compute,
+// which ends with a stream synchronisation: nothing is in flight when a slice is reused)
+void arena_reset(clr_solver* s, size_t want_doubles) {
+  s->pin_off = 0;
+  const size_t LIMIT = (size_t)1 << 20;  // 8 MB of pinned memory per solver at most
+  if (want_doubles > LIMIT) return;      // (long series: the copies are bandwidth-, not latency-bound)
+  if (want_doubles > s->pin_cap) {
+    if (s->pin) (void)hipHostFree(s->pin);
+    s->pin = nullptr;
+    s->pin_cap = 0;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want_doubles * sizeof(double), hipHostMallocDefault) == hipSuccess) {
+      s->pin = static_cast<double*>(p);
+      s->pin_cap = want_doubles;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+}
+double* arena_take(clr_solver* s, size_t n) {
+  if (!s->pin || s->pin_off + n > s->pin_cap) return nullptr;
+  double* p = s->pin + s->pin_off;
+  s->pin_off += n;
+  return p;
+}
+int stage_upload(clr_solver* s, DevBuf& buf, const double* host, size_t n) {
+  double* p = arena_take(s, n);
+  if (!p) return upload(buf, host, n, s->stream);
+  memcpy(p, host, n * sizeof(double));
+  return upload(buf, p, n, s->stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -452,6 +488,7 @@ void clr_solver_destroy(clr_solver* s) {
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
+    if (s->pin) (void)hipHostFree(s->pin);
     (void)hipStreamDestroy(s->stream);
   }
   delete s;
@@ -499,11 +536,20 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   if ((st = s->D.reserve((size_t)N)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
 
-  HIP_TRY(hipStreamSynchronize(stream));  // (a previous upload may still read host_coeffs)
-  if ((st = upload_coeffs(s->coeffs, J_real, a_real, c_real, J_comp, a_comp, b_comp, c_comp,
-                          d_comp, stream, s->host_coeffs)) != CLR_OK)
-    return st;
-  if ((st = upload(s->t, x, (size_t)N, stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(stream));  // (a previous upload may still read host_coeffs / the pinned arena)
+  arena_reset(s, has_general ? 0 : (size_t)3 * N + 2 * J_real + 4 * J_comp + 16);
+  {
+    std::vector<double>& hc = s->host_coeffs;
+    hc.clear();
+    hc.insert(hc.end(), a_real, a_real + J_real);
+    hc.insert(hc.end(), c_real, c_real + J_real);
+    hc.insert(hc.end(), a_comp, a_comp + J_comp);
+    hc.insert(hc.end(), b_comp, b_comp + J_comp);
+    hc.insert(hc.end(), c_comp, c_comp + J_comp);
+    hc.insert(hc.end(), d_comp, d_comp + J_comp);
+    if ((st = stage_upload(s, s->coeffs, hc.data(), hc.size())) != CLR_OK) return st;
+  }
+  if ((st = stage_upload(s, s->t, x, (size_t)N)) != CLR_OK) return st;
 
   int h_status = 0;
   double h_logdet = 0.0;
@@ -518,8 +564,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   } else if (!has_general && J <= 8 && clr::find_batch_launchers(J_real, J_comp)) {
     // fixed-width chunked scan, materialising the reference-layout factor
     const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
-    if ((st = upload(s->scratch, diag, (size_t)N, stream)) != CLR_OK) return st;
-    if ((st = upload(s->scratch2, &jitter, 1, stream)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->scratch, diag, (size_t)N)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->scratch2, &jitter, 1)) != CLR_OK) return st;
     clr::BatchParams P;
     memset(&P, 0, sizeof(P));
     P.B = 1;
@@ -543,7 +589,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
     // row-major arrays; with more than one chunk the kernels stage them through LDS
-    if (use_rhs && (st = upload(s->rhs, s->host_rhs.data(), (size_t)N, stream)) != CLR_OK) return st;
+    if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
     P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
     P.lane_is = 1; P.lane_cs = P.L;
     P.staged = P.nchunk > 1 ? 1 : 0;
@@ -562,8 +608,10 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     L->sequential(P, 1, stream);  // the whole recurrence in one lane if those cannot be trusted
     clr::launch_finalize(P, stream);
     HIP_TRY(hipGetLastError());
-    double back[4];  // ll | logdet | quad | status (int in the 4th slot): one copy
-    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, sizeof(back), hipMemcpyDeviceToHost, stream));
+    double back_local[4];  // ll | logdet | quad | status (int in the 4th slot): one copy
+    double* pinned_back = arena_take(s, 4);
+    double* back = pinned_back ? pinned_back : back_local;
+    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     h_logdet = back[1];
     memcpy(&h_status, &back[3], sizeof(int));
@@ -574,8 +622,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     // chunk with S distributed over the lanes, up to 16 chunks chained by the scan (widths <= 32),
     // the replay writing the factor in the reference's storage (instead of factor_generic_kernel:
     // one workgroup, five barriers per step)
-    if ((st = upload(s->scratch, diag, (size_t)N, stream)) != CLR_OK) return st;
-    if ((st = upload(s->scratch2, &jitter, 1, stream)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->scratch, diag, (size_t)N)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->scratch2, &jitter, 1)) != CLR_OK) return st;
     clr::BatchParams P;
     memset(&P, 0, sizeof(P));
     P.B = 1;
@@ -607,7 +655,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.jitter = s->scratch2.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
-    if (use_rhs && (st = upload(s->rhs, s->host_rhs.data(), (size_t)N, stream)) != CLR_OK) return st;
+    if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
     P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
     P.lane_is = 1; P.lane_cs = P.L;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p;
@@ -623,8 +671,10 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     HIP_TRY(hipMemsetAsync(P.need_exact, 0, sizeof(int), stream));  // (one chunk: no prefix kernel clears it)
     wide_flow(P, J_real, J_comp, stream, nullptr);
     HIP_TRY(hipGetLastError());
-    double back[4];
-    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, sizeof(back), hipMemcpyDeviceToHost, stream));
+    double back_local[4];
+    double* pinned_back = arena_take(s, 4);
+    double* back = pinned_back ? pinned_back : back_local;
+    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     h_logdet = back[1];
     memcpy(&h_status, &back[3], sizeof(int));
