@@ -115,6 +115,13 @@ def device_info():
     return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=mem.value)
 
 
+def device_memory():
+    """``(free_bytes, total_bytes)`` of the current device's HBM (``clr_device_memory``)."""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(_load().clr_device_memory(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
 def _f64(a, shape=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if shape is not None:
@@ -439,6 +446,12 @@ class ShardedBatchedGP(object):
         ll, ld, q, st = self._out()
         self._ok(_load().clr_sharded_get_results(self._h, _ptr(ll), _ptr(ld), _ptr(q), st.ctypes.data_as(_ip)))
         return ll, ld, q, st
+
+    def log_likelihood(self):
+        """Evaluate all B problems with the coefficients set last; returns ``(loglike, logdet, quad,
+        status)`` (as :meth:`BatchedGP.log_likelihood`)."""
+        self.enqueue()
+        return self.results()
 
     def evaluate(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
         """One optimiser / MCMC evaluation: new coefficients in, ``(loglike, logdet,

@@ -470,6 +470,16 @@ int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm
   return CLR_OK;
 }
 
+int clr_device_memory(size_t* free_bytes, size_t* total_bytes) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return CLR_OK;
+}
+
 /* ---- single-problem solver --------------------------------------------------- */
 clr_solver* clr_solver_create(void) {
   clr_solver* s = new clr_solver();

@@ -66,6 +66,10 @@ int clr_get_device(int* device);
 int clr_device_synchronize(void);
 /* Name + CU count of the current device (for logs). */
 int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm_bytes);
+/* Free / total HBM of the current device right now (hipMemGetInfo): for sizing a batch to the 288 GB of a
+ * GPU -- a plan of B problems x N samples x width J holds about 8 B N (3 + [3 J + 1 when materialising]) bytes
+ * of series and factor plus 8 B nchunk (J^2 + J (J + 1) + 4 J) of scan workspace. */
+int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
 
 /* ---- single-problem solver: celerite::solver::CholeskySolver<double> ----------
  * (cpp/include/celerite/solver/cholesky.h, solver.h), the object behind

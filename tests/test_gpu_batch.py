@@ -682,3 +682,32 @@ def test_wide_summarize_with_the_lazy_decay(JR, JC):
         plan.close()
         assert np.max(np.abs(outs[2][1] - outs[0][1]) / np.abs(outs[0][1])) <= 1e-11
         assert np.max(np.abs(outs[2][2] - outs[0][2]) / np.abs(outs[0][2])) <= 1e-11
+
+
+def test_device_memory_and_plan_lifecycle():
+    """clr_device_memory (hipMemGetInfo) and no leak over create / evaluate / destroy cycles of batch plans,
+    solver objects and CARMA models (tools/gpu_soak.py is the longer version)."""
+    free0, total = batch.device_memory()
+    assert 0 < free0 <= total and total > 200e9        # 288 GB of HBM3E per MI355X
+    import celerite_amd
+    rng = np.random.RandomState(1)
+    def cycle(seed):
+        B, N = 32, 4000
+        t = np.sort(rng.rand(B, N), axis=1); diag = rng.uniform(0.01, 0.04, (B, N)); y = np.sin(t)
+        co = (np.exp(rng.randn(B, 1)), np.exp(rng.randn(B, 1)), np.exp(rng.randn(B, 2)), np.zeros((B, 2)),
+              np.exp(rng.randn(B, 2)), np.exp(1 + rng.randn(B, 2)))
+        plan = batch.BatchedGP(B, N, 1, 2)
+        plan.set_series(t, diag, y); plan.set_coefficients(*co)
+        plan.log_likelihood(); plan.close()
+        s = celerite_amd.CholeskySolver()
+        s.compute(0.0, co[0][0], co[1][0], co[2][0], co[3][0], co[4][0], co[5][0], np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t[0], diag[0])
+        s.solve(y[0]); del s
+    for i in range(3):
+        cycle(i)
+    batch.device_synchronize()
+    used_a = total - batch.device_memory()[0]
+    for i in range(12):
+        cycle(10 + i)
+    batch.device_synchronize()
+    used_b = total - batch.device_memory()[0]
+    assert used_b - used_a < 64 * 2**20                 # (allocator granularity, not a per-cycle leak)

@@ -230,3 +230,12 @@ def test_carma_model_algebra_runs_on_the_host():
     if NO_GPU:
         with pytest.raises(RuntimeError, match="no gfx950"):
             s.log_likelihood(np.zeros(3), np.zeros(3), np.ones(3))
+
+
+def test_device_memory_needs_a_gpu():
+    if NO_GPU:
+        with pytest.raises(RuntimeError, match="no gfx950"):
+            batch.device_memory()
+    else:
+        free, total = batch.device_memory()
+        assert 0 < free <= total
