@@ -335,12 +335,21 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
   int flag0 = 0;
   constexpr int PF = 3;
   double tq[PF + 1], dq[PF], yq[PF];
+  // Steps past the end of the series (the tail of a problem's last chunk, dead lanes) are made HARMLESS instead of
+  // masked: t stays at the last sample (dx = 0: no decay, no rotation) and the diagonal is 1e300, so 1/D ~ 1e-300
+  // and every update of the step -- here and in the rider wave, which therefore needs no selects -- is below the
+  // rounding of what it is added to.  (The sums of this wave are still guarded by n < N below.)
+  auto dd = [&](int i) { return i < src.nleft ? src.dp[src.off(i)] : 1e300; };
   double tn = src.t(0);
   double cdv[nz(JC)], sdv[nz(JC)];  // cos / sin of d t at the current sample
 #pragma unroll
   for (int j = 0; j < JC; ++j) { cdv[j] = 1.0; sdv[j] = 0.0; }
 #pragma unroll
-  for (int k = 0; k < PF; ++k) { tq[k] = src.t(1 + k); dq[k] = src.diag(k); yq[k] = src.y(k); }
+  for (int k = 0; k < PF; ++k) {
+    tq[k] = (1 + k < src.nleft) ? src.tp[src.off(1 + k)] : (k > 0 ? tq[k - 1] : tn);  // (past the end: the last sample's t)
+    dq[k] = dd(k);
+    yq[k] = src.y(k);
+  }
   for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
     const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
     // anchor: the full sincos of the absolute phase at the block's first sample (cholesky.h:137); at
@@ -352,8 +361,8 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
 #pragma unroll
       for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
       if (!(dbg & 2)) {
-        tq[PF - 1] = src.t(i + PF + 1);
-        dq[PF - 1] = src.diag(i + PF);
+        tq[PF - 1] = (i + PF + 1 < src.nleft) ? src.tp[src.off(i + PF + 1)] : tq[PF - 2];
+        dq[PF - 1] = dd(i + PF);
         yq[PF - 1] = src.y(i + PF);
       }
       double* slot = slot0 + (i & 1) * SLOT_STRIDE;
@@ -498,7 +507,6 @@ __device__ __forceinline__ void split_riders_lazy(int L, int n0, int N, bool sto
     const double invD = slot[Lk::F_INVD * 64];
     const double y = slot[Lk::F_Y * 64];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const bool valid = n0 + i < N;
     double ub = 0.0;
 #pragma unroll
     for (int k = 0; k < J; ++k) ub += u[k] * b[k];
@@ -511,12 +519,13 @@ __device__ __forceinline__ void split_riders_lazy(int L, int n0, int N, bool sto
       double racc = 0.0;
 #pragma unroll
       for (int k = 0; k < J; ++k) racc += Acol[j * J + k] * u[k];
-      r[j] = valid ? racc : 0.0;
+      r[j] = racc;
 #pragma unroll
       for (int k = 0; k < J; ++k) Acol[j * J + k] = fma(-W[k], racc, Acol[j * J + k]);
     }
-    const double vinvD = valid ? invD : 0.0, vxs = valid ? xs : 0.0;
-    q0 += valid ? x * xs : 0.0;
+    // (steps past the end of the series arrive with 1/D ~ 1e-300 from the trajectory wave: no masking needed)
+    const double vinvD = invD, vxs = xs;
+    q0 += x * xs;
 #pragma unroll
     for (int j = 0; j < J; ++j) eta[j] = fma(-r[j], vxs, eta[j]);
     if (MODE == 0) {
