@@ -82,17 +82,22 @@ void launch_finalize(const BatchParams& P, hipStream_t s) {
 
 // Tiled transpose through LDS: reads coalesced along i (the time axis), writes
 // coalesced along the chunk axis.  Pure data movement: 8 B in + 8 B out per sample.
+// Cells past the end of the series (the tail of the last chunk) are filled so that a reader may treat them as
+// ordinary samples: pad_kind 1 repeats the series' last value (t: dx = 0), 2 writes 1e300 (the diagonal: 1 / D ~ 0),
+// 0 writes zeros (y).  The lazy role-split summarize reads them unguarded (clr_split_kernels.h); every other reader
+// masks them and never sees the values.
 __global__ void __launch_bounds__(256) relayout_kernel(const double* __restrict__ src,
                                                        long src_stride, double* __restrict__ dst,
-                                                       long dst_stride, int N, int L, int nchunk) {
+                                                       long dst_stride, int N, int L, int nchunk, int pad_kind) {
   __shared__ double tile[32][33];
   const int b = blockIdx.z, i0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const double* in = src + (long)b * src_stride;
   double* out = dst + (long)b * dst_stride;
+  const double pad = pad_kind == 1 ? in[N - 1] : (pad_kind == 2 ? 1e300 : 0.0);
   for (int r = threadIdx.y; r < 32; r += 8) {
     const int c = c0 + r, i = i0 + threadIdx.x;
     const long n = (long)c * L + i;
-    tile[r][threadIdx.x] = (c < nchunk && i < L && n < N) ? in[n] : 0.0;
+    tile[r][threadIdx.x] = (c < nchunk && i < L && n < N) ? in[n] : pad;
   }
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += 8) {
@@ -131,10 +136,10 @@ void launch_deinterleave_factor(const double* phi_i, const double* u_i, const do
 }
 
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
-                     int N, int L, int nchunk, hipStream_t s) {
+                     int N, int L, int nchunk, int pad_kind, hipStream_t s) {
   dim3 grid((L + 31) / 32, (nchunk + 31) / 32, nsrc);
   hipLaunchKernelGGL(relayout_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride,
-                     N, L, nchunk);
+                     N, L, nchunk, pad_kind);
 }
 }  // namespace clr
 
@@ -1393,11 +1398,11 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
 static bool batch_relayout(clr_batch* h) {
   if (!((h->layout == 1 || split_active(h)) && h->nchunk > 1)) return false;
   const long cells = (long)h->nchunk * h->L;
-  struct { DevBuf* src; DevBuf* dst; long stride; } jobs[3] = {
-      {&h->t, &h->tT, h->t_stride}, {&h->diag, &h->dT, h->diag_stride}, {&h->y, &h->yT, h->y_stride}};
+  struct { DevBuf* src; DevBuf* dst; long stride; int pad; } jobs[3] = {
+      {&h->t, &h->tT, h->t_stride, 1}, {&h->diag, &h->dT, h->diag_stride, 2}, {&h->y, &h->yT, h->y_stride, 0}};
   for (auto& j : jobs)
     clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1,
-                         h->N, h->L, h->nchunk, h->stream);
+                         h->N, h->L, h->nchunk, j.pad, h->stream);
   return true;
 }
 

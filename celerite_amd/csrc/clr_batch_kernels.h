@@ -716,7 +716,7 @@ void launch_deinterleave_factor(const double* phi_i, const double* u_i, const do
                                 int N, int J, int L, int nchunk, hipStream_t s);
 // [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api.hip).
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
-                     int N, int L, int nchunk, hipStream_t s);
+                     int N, int L, int nchunk, int pad_kind, hipStream_t s);
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);

@@ -335,21 +335,22 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
   int flag0 = 0;
   constexpr int PF = 3;
   double tq[PF + 1], dq[PF], yq[PF];
-  // Steps past the end of the series (the tail of a problem's last chunk, dead lanes) are made HARMLESS instead of
-  // masked: t stays at the last sample (dx = 0: no decay, no rotation) and the diagonal is 1e300, so 1/D ~ 1e-300
-  // and every update of the step -- here and in the rider wave, which therefore needs no selects -- is below the
-  // rounding of what it is added to.  (The sums of this wave are still guarded by n < N below.)
-  auto dd = [&](int i) { return i < src.nleft ? src.dp[src.off(i)] : 1e300; };
-  double tn = src.t(0);
+  // Steps past the end of the series (the tail of a problem's last chunk) are HARMLESS instead of masked: the
+  // chunk-interleaved copy this kernel reads is padded by relayout_kernel with t = the last sample (dx = 0: no
+  // decay, no rotation), diagonal = 1e300 (1 / D ~ 1e-300) and y = 0, so every update of such a step -- here and
+  // in the rider wave -- is below the rounding of what it is added to, and neither wave needs selects or guarded
+  // loads (the sums of this wave are still restricted to n < N below; reads past the chunk's end land in the next
+  // chunk or, for the last chunk, in rows 1..5 of the copy: only the state after the last step sees them, and the
+  // last chunk's end state is not used).  Dead lanes (no chunk of their own) read chunk 0's samples.
+  auto tt = [&](int i) { return src.tp[src.off(i)]; };
+  auto dd = [&](int i) { return src.dp[src.off(i)]; };
+  auto yy = [&](int i) { return src.yp[src.off(i)]; };
+  double tn = tt(0);
   double cdv[nz(JC)], sdv[nz(JC)];  // cos / sin of d t at the current sample
 #pragma unroll
   for (int j = 0; j < JC; ++j) { cdv[j] = 1.0; sdv[j] = 0.0; }
 #pragma unroll
-  for (int k = 0; k < PF; ++k) {
-    tq[k] = (1 + k < src.nleft) ? src.tp[src.off(1 + k)] : (k > 0 ? tq[k - 1] : tn);  // (past the end: the last sample's t)
-    dq[k] = dd(k);
-    yq[k] = src.y(k);
-  }
+  for (int k = 0; k < PF; ++k) { tq[k] = tt(1 + k); dq[k] = dd(k); yq[k] = yy(k); }
   for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
     const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
     // anchor: the full sincos of the absolute phase at the block's first sample (cholesky.h:137); at
@@ -361,9 +362,9 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
 #pragma unroll
       for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
       if (!(dbg & 2)) {
-        tq[PF - 1] = (i + PF + 1 < src.nleft) ? src.tp[src.off(i + PF + 1)] : tq[PF - 2];
+        tq[PF - 1] = tt(i + PF + 1);
         dq[PF - 1] = dd(i + PF);
-        yq[PF - 1] = src.y(i + PF);
+        yq[PF - 1] = yy(i + PF);
       }
       double* slot = slot0 + (i & 1) * SLOT_STRIDE;
       slot[Lk::F_Y * 64] = y_cur;
