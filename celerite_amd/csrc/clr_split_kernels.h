@@ -351,6 +351,11 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
   for (int j = 0; j < JC; ++j) { cdv[j] = 1.0; sdv[j] = 0.0; }
 #pragma unroll
   for (int k = 0; k < PF; ++k) { tq[k] = tt(1 + k); dq[k] = dd(k); yq[k] = yy(k); }
+  // running (wave-uniform) offsets of the samples fetched next: index i + PF for the diagonal and y, one more for t;
+  // they advance by the sample stride and jump into the next chunk at index L (DirectSeries::off without the
+  // per-step 64-bit multiplies)
+  long od = src.off(PF), ot = src.off(PF + 1);
+  int id = PF;  // the index od stands for
   for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
     const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
     // anchor: the full sincos of the absolute phase at the block's first sample (cholesky.h:137); at
@@ -361,11 +366,12 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
 #pragma unroll
       for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
-      if (!(dbg & 2)) {
-        tq[PF - 1] = tt(i + PF + 1);
-        dq[PF - 1] = dd(i + PF);
-        yq[PF - 1] = yy(i + PF);
-      }
+      tq[PF - 1] = src.tp[ot];
+      dq[PF - 1] = src.dp[od];
+      yq[PF - 1] = src.yp[od];
+      ++id;
+      od = (id == L) ? src.cs : od + src.is;
+      ot = (id + 1 == L) ? src.cs : ot + src.is;
       double* slot = slot0 + (i & 1) * SLOT_STRIDE;
       slot[Lk::F_Y * 64] = y_cur;
       double u[J], v[J];
