@@ -201,6 +201,17 @@ struct LogProduct {
       since = 0;
     }
   }
+  // for callers with their own window of <= 32 factors (the lazy split kernel's 16-step blocks): no counter
+  CLR_HD void mul_window(double d) {
+    int e;
+    mant *= frexp(d, &e);
+    expo += e;
+  }
+  CLR_HD void renorm() {
+    int e;
+    mant = frexp(mant, &e);
+    expo += e;
+  }
   CLR_HD double log_value() const { return log(mant) + expo * 0.693147180559945309417232; }
 };
 

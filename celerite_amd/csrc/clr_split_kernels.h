@@ -424,9 +424,10 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       const double a_n = p.diagonal(diag_cur);
       const double D = a_n - s;
       const double invD = 1.0 / D;
-      if (n0 + i < N) {
-        if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
-        lp0.mul(D);
+      {  // (a padded step has D ~ 1e300 > 0 and a_n / D = 1: only the log-determinant has to leave it out)
+        const int n = n0 + i;
+        flag0 |= (n >= 1 && !(D > 0.0)) ? 1 : 0;
+        lp0.mul_window(n < N ? D : 1.0);
         gamma = fmax(gamma, fabs(a_n * invD));
       }
       double z[J], W[J];
@@ -450,6 +451,7 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       }
       tn = t_cur_next;
     }
+    lp0.renorm();  // (16 factors in [0.5, 1) since the last one)
     {  // multiply the accumulated decay out (the rider does the same to Abar, bbar)
       double pp[nz(M * (M + 1) / 2)];
 #pragma unroll
