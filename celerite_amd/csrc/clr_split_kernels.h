@@ -72,7 +72,7 @@ CLR_HD constexpr int tri_row(int e) { return e - tri_col(e) * (tri_col(e) + 1) /
 // workgroup barrier that waits for nothing of this wave's own (T keeps its series prefetch in
 // flight across it); "memory": the compiler may not move LDS accesses across it
 __device__ __forceinline__ void split_barrier_() { asm volatile("s_barrier" ::: "memory"); }
-#define split_barrier() do { if (!(dbg & 4)) split_barrier_(); } while (0)
+#define split_barrier() split_barrier_()
 
 __device__ __forceinline__ int hw_simd_id() {
   // HW_REG_HW_ID (id 4), SIMD_ID = bits [5:4]
