@@ -711,3 +711,33 @@ def test_device_memory_and_plan_lifecycle():
     batch.device_synchronize()
     used_b = total - batch.device_memory()[0]
     assert used_b - used_a < 64 * 2**20                 # (allocator granularity, not a per-cycle leak)
+
+
+@pytest.mark.parametrize("N,nchunk", [(1025, 64), (8193, 64), (5000, 128), (2049, 2)])
+def test_role_split_tail_padding_and_shared_series(N, nchunk):
+    """The lazy role-split kernels read the chunk-interleaved copy unguarded: its tail past N is padded by the
+    relayout (t held, diagonal 1e300, y = 0) and must not leak into any result -- last chunk nearly empty, more
+    chunks than one wave of lanes, two chunks, and ONE series shared by all problems (stride 0)."""
+    JR, JC = 2, 3
+    case = synthetic(6, N, JR, JC, "bench", seed=N)
+    case["t"] = case["t"] * (0.1 if N >= 4000 else 60.0 / N)   # (dense enough for the lazy kernels: max c dx < 2^-7)
+    for shared in (False, True):
+        t, diag, y = case["t"], case["diag"], case["y"]
+        if shared:
+            t, diag, y = t[0], diag[0], y[0]
+        tt = np.broadcast_to(t, case["t"].shape); dd = np.broadcast_to(diag, case["t"].shape); yy = np.broadcast_to(y, case["t"].shape)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), np.ascontiguousarray(tt), np.ascontiguousarray(dd),
+                                                  np.ascontiguousarray(yy))
+        plan = batch.BatchedGP(6, N, JR, JC)
+        plan.set_chunks(nchunk)
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs_of(case))
+        plan.set_summarize_mode(2)
+        assert "lazy" in plan.summarize_kernel()
+        for _ in range(2):   # (the second evaluation reuses the padded copy)
+            ll, ld, q, st = plan.log_likelihood()
+            assert (plan.exact_levels() == 0).any()   # (settled by the split kernel's summaries, not by a replay)
+            assert np.array_equal(st, s0)
+            assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL
+            assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+        plan.close()
