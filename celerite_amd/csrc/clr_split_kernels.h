@@ -104,18 +104,25 @@ __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, Direc
   // step; an HBM round trip is about one step long, so one step of prefetch is not enough)
   constexpr int PF = 4;
   double tq[PF + 1], dq[PF], yq[PF];  // tq[k] = t(i + 1 + k), dq[k] = diag(i + k), yq[k] = y(i + k)
-  double tn = src.t(0);
+  // The chunk-interleaved copy is padded past the end of the series (relayout_kernel: t held, diagonal 1e300,
+  // y = 0), so the loads are unguarded and a padded step changes nothing above the rounding -- here or in the
+  // rider wave (see split_trajectory_lazy for the argument); running wave-uniform offsets replace
+  // DirectSeries::off per load.
+  double tn = src.tp[src.off(0)];
 #pragma unroll
-  for (int k = 0; k < PF; ++k) { tq[k] = src.t(1 + k); dq[k] = src.diag(k); yq[k] = src.y(k); }
+  for (int k = 0; k < PF; ++k) { tq[k] = src.tp[src.off(1 + k)]; dq[k] = src.dp[src.off(k)]; yq[k] = src.yp[src.off(k)]; }
+  long od = src.off(PF), ot = src.off(PF + 1);
+  int id = PF;  // the index od stands for
   for (int i = 0; i < L; ++i) {
     const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
 #pragma unroll
     for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
-    if (!(dbg & 2)) {  // (reads past the chunk run into the next chunk / padding: masked by nleft)
-      tq[PF - 1] = src.t(i + PF + 1);
-      dq[PF - 1] = src.diag(i + PF);
-      yq[PF - 1] = src.y(i + PF);
-    }
+    tq[PF - 1] = src.tp[ot];
+    dq[PF - 1] = src.dp[od];
+    yq[PF - 1] = src.yp[od];
+    ++id;
+    od = (id == L) ? src.cs : od + src.is;
+    ot = (id + 1 == L) ? src.cs : ot + src.is;
     double* slot = slot0 + (i & 1) * SLOT_STRIDE;
     double u[J], v[J], phid[nz(JR + JC)];
     features_uv<JR, JC, FAST>(p, tn, u, v);
@@ -140,10 +147,11 @@ __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, Direc
     const double D = p.diagonal(diag_cur) - s;
     const double invD = 1.0 / D;
     const double x = y_cur - ub;
-    const bool valid = n0 + i < N;
-    if (valid) {
-      if (n0 + i >= 1 && !(D > 0.0)) flag0 = 1;
-      lp0.mul(D);
+    {  // (a padded step has D ~ 1e300 > 0, a_n / D = 1 and x^2 / D ~ 0: only the log-determinant leaves it out)
+      const int n = n0 + i;
+      flag0 |= (n >= 1 && !(D > 0.0)) ? 1 : 0;
+      lp0.mul_window(n < N ? D : 1.0);
+      if ((i & 31) == 31) lp0.renorm();  // (i is wave-uniform: a scalar branch)
       q0 += x * x * invD;
       gamma = fmax(gamma, fabs(p.diagonal(diag_cur) * invD));
     }
@@ -210,7 +218,6 @@ __device__ __forceinline__ void split_riders(const Problem<JR, JC>& p, int L, in
     const double invD = slot[Lk::F_INVD * 64];
     const double xs = slot[Lk::F_XS * 64];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const bool valid = n0 + i < N;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double racc = 0.0;
@@ -221,7 +228,7 @@ __device__ __forceinline__ void split_riders(const Problem<JR, JC>& p, int L, in
       for (int k = 0; k < J; ++k)
         Acol[j * J + k] = phid[phi_index<JR>(k)] * Acol[j * J + k] - pw[k] * racc;
     }
-    if (valid) {  // (padding steps of the short last chunk must not touch the accumulators)
+    {  // (steps past the end of the series arrive with 1 / D ~ 1e-300 and x / D ~ 0 from the trajectory wave)
       double rs[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
