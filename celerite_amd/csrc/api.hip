@@ -1318,13 +1318,13 @@ static bool split_active(const clr_batch* h) {
   // explicit modes 1 / 2, or auto (-1):
   //  * widths 7 and 8 on a densely sampled series: the split kernel with the decay factored out of the state
   //    (lazy) beats the single-wave kernel for every shape (2.0-2.5 ms against 2.3-3.6, profiles/r02zzz_split_ab_shapes.txt);
-  //  * width 8 with at least two complex terms on any other series: the plain split (3.1-3.2 ms against 3.8-4.2 on
-  //    the paper's sparse family, profiles/r02zzz_sparse_ab.txt).  With fewer complex terms its trajectory wave
-  //    spills ((8,0), (6,1): 5 ms) and at width 7 the two are within 5 %: single wave there.
+  //  * any other series: the plain split at width 7 (2.5-2.7 ms against 2.8-3.0 on the paper's sparse family) and at
+  //    width 8 with at least two complex terms (3.1-3.2 against 3.8-4.2; profiles/r02zzz_sparse_ab.txt).  With
+  //    fewer complex terms at width 8 its trajectory wave spills ((8,0), (6,1): 4.1-4.2 against 3.7): single wave.
   if (!(h->launch && h->nchunk > 1 && clr::have_summarize_split(h->J_real, h->J_comp))) return false;
   if (h->summarize_mode > 0) return true;
   if (h->summarize_mode < 0 && h->J >= 7 && lazy_eligible(h)) return true;
-  return h->summarize_mode < 0 && h->J == 8 && h->J_comp >= 2;
+  return h->summarize_mode < 0 && (h->J == 7 || (h->J == 8 && h->J_comp >= 2));
 }
 
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {

@@ -238,7 +238,8 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
  *      instead of FMA + MUL, renormalised every 16 steps) when the series is densely sampled
  *      (max c * max dx < 2^-7 and max d * max dx < 2^-5: the phases then advance by small-angle
  *      rotations, re-anchored with the full sincos every 16 steps), else as 1;
- *  -1  (default) 2 at widths 7 and 8 on a dense series; otherwise 1 at width 8 with at least two complex terms, else 0. */
+ *  -1  (default) 2 at widths 7 and 8 on a dense series; otherwise 1 at width 7 and at width 8 with at least two
+ *      complex terms, else 0. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
 /* Which one the next evaluation will run (0, 1 or 2 as above), given the series and coefficients set. */
 int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind);
