@@ -60,6 +60,14 @@ def _load():
     lib.clr_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_replay_source.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_prefix_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.clr_batch_get_prefix_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
+    lib.clr_batch_debug_get_starts.argtypes = [C.c_void_p, _dp]
+    lib.clr_batch_debug_compose_check.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    lib.clr_batch_get_selection_bounds.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    lib.clr_batch_set_selection_bounds.argtypes = [C.c_void_p] + [C.c_double] * 4
+    lib.clr_sharded_get_summarize_kernel.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_set_exact.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_get_exact_count.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_get_exact_flags.argtypes = [C.c_void_p, _ip]
@@ -249,9 +257,55 @@ class BatchedGP(object):
         or ``"rowmajor"`` (direct, slow; for A/B measurements)."""
         _check(_load().clr_batch_set_layout(self._h, self.LAYOUTS.get(layout, layout)))
 
-    def set_prefix_mode(self, cooperative=True):
-        """Prefix phase with 16 lanes per problem (default) or one (cross-check)."""
-        _check(_load().clr_batch_set_prefix_mode(self._h, int(bool(cooperative))))
+    PREFIX_MODES = {"single": 0, "walk": 1, "multilevel": 2}
+
+    def set_prefix_mode(self, mode="multilevel"):
+        """Prefix phase (chunk elements -> chunk start states): ``"multilevel"`` (default: groups of
+        elements composed in parallel, the composed ones walked, start states fanned out;
+        csrc/clr_prefix_kernels.h), ``"walk"`` (16 lanes per problem, chunk after chunk) or ``"single"``
+        (one lane: the host-checked form, cross-check).  ``True`` / ``False`` mean walk / single."""
+        if isinstance(mode, bool):
+            mode = 1 if mode else 0
+        _check(_load().clr_batch_set_prefix_mode(self._h, int(self.PREFIX_MODES.get(mode, mode))))
+
+    def set_prefix_plan(self, levels=-1, group=0):
+        """Level structure of the multi-level prefix: ``levels`` levels of groups of ``group`` elements
+        (``levels < 0``: chosen from the chunk count)."""
+        _check(_load().clr_batch_set_prefix_plan(self._h, int(levels), int(group)))
+
+    @property
+    def prefix_plan(self):
+        """``(levels, group sizes, element counts per level)`` of the prefix phase."""
+        lv = C.c_int()
+        g = (C.c_int * 3)()
+        n = (C.c_int * 4)()
+        _check(_load().clr_batch_get_prefix_plan(self._h, C.byref(lv), g, n))
+        return lv.value, list(g)[:max(lv.value, 0)], list(n)[:lv.value + 1]
+
+    def debug_starts(self):
+        """Chunk start states of the last evaluation, ``(B, nchunk, J (J + 1) / 2 + J)`` (widths 1..8)."""
+        out = np.empty((self.B, self.chunks[0], self.J * (self.J + 1) // 2 + self.J))
+        _check(_load().clr_batch_debug_get_starts(self._h, _ptr(out)))
+        return out
+
+    def compose_check(self, group):
+        """Cooperative composition kernel against the single-lane host-checked form on the last
+        evaluation's chunk elements, in groups of ``group``: ``(largest relative difference, largest
+        magnitude)``."""
+        d, m = C.c_double(), C.c_double()
+        _check(_load().clr_batch_debug_compose_check(self._h, int(group), C.byref(d), C.byref(m)))
+        return d.value, m.value
+
+    def selection_bounds(self):
+        """``dict(tmax, dxmax, dmax, cmax, set_series_host_ms)``: what the kernel selection looks at."""
+        v = [C.c_double() for _ in range(5)]
+        _check(_load().clr_batch_get_selection_bounds(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("tmax", "dxmax", "dmax", "cmax", "set_series_host_ms"), [x.value for x in v]))
+
+    def set_replay_source(self, source=-1):
+        """Series view of the replay pass behind the role-split summarize: 0 the chunk-interleaved copy,
+        1 the row-major arrays staged through LDS, -1 auto (``clr_batch_set_replay_source``)."""
+        _check(_load().clr_batch_set_replay_source(self._h, int(source)))
 
     def set_exact(self, force=True):
         """Replay every problem step by step (the reference's recurrence) instead
@@ -352,8 +406,10 @@ class ShardedBatchedGP(object):
     :class:`BatchedGP`-like plan and one host thread per shard, no collective
     (problems are independent: cholesky.h:703-706).  ``devices`` defaults to every
     visible GPU; a device may be listed more than once (shards sharing a GPU), which
-    is how the sharding is tested on one GPU.  Results do not depend on the sharding
-    bit for bit when every shard uses the same chunk count (:meth:`set_chunks`)."""
+    is how the sharding is tested on one GPU.  The kernels are selected once for the whole
+    batch (batch-wide maxima of the series and coefficients), so results do not depend on the
+    sharding bit for bit when the chunk count is the same (:meth:`set_chunks`; the automatic
+    choice looks at the shard size)."""
 
     def __init__(self, B, N, J_real, J_comp, devices=None):
         lib = _load()
@@ -402,6 +458,12 @@ class ShardedBatchedGP(object):
 
     def set_summarize_mode(self, mode=-1):
         self._ok(_load().clr_sharded_set_summarize_mode(self._h, int(mode)))
+
+    def summarize_kernel(self):
+        """The summarize kernel ALL shards run (resolved once for the whole batch)."""
+        k = C.c_int()
+        self._ok(_load().clr_sharded_get_summarize_kernel(self._h, C.byref(k)))
+        return ("single wave", "role split", "role split, lazy decay")[k.value] if k.value >= 0 else "shards disagree"
 
     def set_series(self, t, diag, y):
         arrs, strides = [], []

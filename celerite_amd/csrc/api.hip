@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -302,13 +303,23 @@ struct clr_batch {
   int layout = 2;                     // 0 row-major direct, 1 interleaved copy, 2 staged through LDS
   double tmax = 0.0, dmax = 0.0;      // max |t|, max |d_comp| (host side, O(B))
   double dxmax = 0.0, cmax = 0.0;     // max |t[n+1] - t[n]|, max decay rate: the lazy-decay kernels need cmax * dxmax < 2^-7
+  // floors for the four maxima above (clr_batch_set_selection_bounds): a sharded plan hands every shard the maxima
+  // of the WHOLE batch, so that all shards pick the same kernels whatever the sharding
+  double floor_tmax = 0.0, floor_dxmax = 0.0, floor_dmax = 0.0, floor_cmax = 0.0;
+  double set_series_host_ms = 0.0;    // host time of the last clr_batch_set_series (scan + uploads)
   int force_library_trig = 0;
-  int coop_prefix = 1;
+  int coop_prefix = 2;                // 0 single lane, 1 16 lanes walking the chunks, 2 multi-level (clr_prefix_kernels.h)
+  int plan_levels = -1, plan_g = 0;   // clr_batch_set_prefix_plan: < 0 = chosen by clr::plan_prefix
+  clr::PrefixPlan plan;
+  DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
   double cert_resid = 1e-11;          // end-state mismatch of the chunked replay that still counts as consistent
   double cert_gamma = 1e6;            // conditioning record above which the sequential recurrence settles a problem
   int summarize_mode = -1;            // -1 auto, 0 single wave, 1 role split (widths 7, 8)
+  int replay_source = -1;             // where the replay reads the series when summarize reads the chunk-interleaved
+                                      // copy: 0 the same copy, 1 the row-major arrays staged through LDS, -1 auto
   bool relayout_pending = true;
   bool have_series = false, have_coeffs = false, have_factor = false;
+  bool evaluated = false;             // an evaluation has been enqueued since the plan was (re)chunked
   DevBuf elems, starts, part, partx, cond, out;  // out: ll | logdet | quad | status (B ints)
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int force_exact = 0;
@@ -1173,7 +1184,7 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
-                    &h->fphi, &h->fu, &h->fW, &h->fD})
+                    &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -1210,9 +1221,15 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   h->relayout_pending = true;
   h->have_factor = false;  // its layout depends on the chunking
   const size_t pc = (size_t)h->B * h->nchunk;
+  h->plan = clr::plan_prefix(h->nchunk, 0, 0);
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g);
+    size_t le = 0, ls = 0;
+    clr::multilevel_workspace(h->plan, h->J, &le, &ls);
+    if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
+    if (ls && (st = h->lvl_starts.reserve((size_t)h->B * ls)) != CLR_OK) return st;
   } else if (h->nchunk > 1) {  // elements / start states at the padded width (16 or 32)
     const size_t JP = h->J <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
     if ((st = h->elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
@@ -1225,6 +1242,11 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (h->flags) (void)hipFree(h->flags);
   h->flags = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), (2 * pc + (size_t)h->B) * sizeof(int)));
+  // a single-chunk plan launches no prefix / correct kernel: nothing else would ever clear need_exact or fill
+  // the conditioning record
+  HIP_TRY(hipMemsetAsync(h->flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 3 * sizeof(double), h->stream));
+  h->evaluated = false;
   return CLR_OK;
 }
 
@@ -1243,24 +1265,51 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
     if (sd != 0 && sd != N)
       return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
-  h->tmax = max_abs(t, (long)count(t_stride));  // every sample (sortedness is not assumed)
+  const auto host_t0 = std::chrono::steady_clock::now();
+  // one pass over t: max |t| over every sample (sortedness is not assumed) and the largest step
+  h->tmax = 0.0;
   h->dxmax = 0.0;
   for (long b = 0; b < (t_stride == 0 ? 1 : (long)h->B); ++b) {
     const double* tb = t + b * t_stride;
-    for (long n = 0; n + 1 < N; ++n) {
-      const double d = fabs(tb[n + 1] - tb[n]);
-      if (!(d <= h->dxmax)) h->dxmax = d;
+    double tm = 0.0, dm = 0.0, prev = tb[0];
+    for (long n = 0; n < N; ++n) {
+      const double v = tb[n], a = fabs(v), d = fabs(v - prev);
+      if (!(a <= tm)) tm = a;
+      if (!(d <= dm)) dm = d;
+      prev = v;
     }
+    if (!(tm <= h->tmax)) h->tmax = tm;
+    if (!(dm <= h->dxmax)) h->dxmax = dm;
   }
   if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->set_series_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   h->t_stride = t_stride;
   h->diag_stride = diag_stride;
   h->y_stride = y_stride;
   h->have_series = true;
   h->relayout_pending = true;
+  return CLR_OK;
+}
+
+int clr_batch_get_selection_bounds(const clr_batch* h, double* tmax, double* dxmax, double* dmax, double* cmax,
+                                   double* set_series_host_ms) {
+  if (tmax) *tmax = h->tmax;
+  if (dxmax) *dxmax = h->dxmax;
+  if (dmax) *dmax = h->dmax;
+  if (cmax) *cmax = h->cmax;
+  if (set_series_host_ms) *set_series_host_ms = h->set_series_host_ms;
+  return CLR_OK;
+}
+
+int clr_batch_set_selection_bounds(clr_batch* h, double tmax, double dxmax, double dmax, double cmax) {
+  // negative: leave that floor as it is (NaN counts as "unbounded": the conservative kernels)
+  if (!(tmax < 0.0)) h->floor_tmax = tmax;
+  if (!(dxmax < 0.0)) h->floor_dxmax = dxmax;
+  if (!(dmax < 0.0)) h->floor_dmax = dmax;
+  if (!(cmax < 0.0)) h->floor_cmax = cmax;
   return CLR_OK;
 }
 
@@ -1301,17 +1350,26 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   double* w = h->pin;
   auto put = [&](const double* p, size_t n) { if (n) memcpy(w, p, n * sizeof(double)); w += n; };
   put(a_real, nr); put(c_real, nr); put(a_comp, nc); put(b_comp, nc); put(c_comp, nc); put(d_comp, nc);
-  put(jitter, B);
+  if (jitter) put(jitter, B);
+  else { memset(w, 0, B * sizeof(double)); w += B; }  // NULL: no jitter
   if ((st = h->coeffs.reserve(total)) != CLR_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->coeffs.p, h->pin, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->have_coeffs = true;
   return CLR_OK;
 }
 
+// the maxima the kernel selection looks at: the plan's own, raised to the floors of a sharded parent
+static double sel_max(double own, double floor) {  // (NaN on either side wins: the conservative kernels)
+  if (own != own) return own;
+  if (floor != floor) return floor;
+  return own >= floor ? own : floor;
+}
 static bool lazy_eligible(const clr_batch* h) {
   // |c dx| < 2^-7 at every step: Psi stays within [0.88, 1] over the 16 steps between renormalisations;
   // |d dx| < 2^-5: the per-step rotation of the (cos, sin) pairs uses a short Taylor series
-  return h->have_series && h->have_coeffs && h->cmax * h->dxmax < 0.0078125 && h->dmax * h->dxmax < 0.03125;
+  const double cmax = sel_max(h->cmax, h->floor_cmax), dmax = sel_max(h->dmax, h->floor_dmax),
+               dxmax = sel_max(h->dxmax, h->floor_dxmax);
+  return h->have_series && h->have_coeffs && cmax * dxmax < 0.0078125 && dmax * dxmax < 0.03125;
 }
 
 static bool split_active(const clr_batch* h) {
@@ -1344,8 +1402,12 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   memset(&P, 0, sizeof(P));
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
-  P.fast_trig = (!h->force_library_trig && h->dmax * h->tmax < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+  P.fast_trig = (!h->force_library_trig &&
+                 sel_max(h->dmax, h->floor_dmax) * sel_max(h->tmax, h->floor_tmax) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
   P.coop_prefix = h->coop_prefix;
+  P.plan = h->plan;
+  P.lvl_elems = h->lvl_elems.p;
+  P.lvl_starts = h->lvl_starts.p;
   P.jitter = h->coeffs.p + 2 * nr + 4 * nc;
   P.a_real = h->coeffs.p;
   P.c_real = P.a_real + nr;
@@ -1393,6 +1455,21 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.out_status = reinterpret_cast<int*>(h->out.p + 3 * B);
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
+}
+
+// The replay's view of the series.  The role-split summarize reads the chunk-interleaved copy; the replay is free to
+// read either that copy (one 512-B line per array and step per wave, but a second 2.4 GB stream competing with the
+// factor's stores) or the row-major arrays through the LDS-staged tiles (round 1's path).
+static clr::BatchParams replay_view(const clr_batch* h, const clr::BatchParams& P, int materialize) {
+  clr::BatchParams R = P;
+  const int src = h->replay_source < 0 ? (materialize ? 1 : 0) : h->replay_source;
+  if (src == 1 && !P.staged && P.lane_cs == 1 && h->nchunk > 1 && h->layout == 2) {
+    R.t = h->t.p; R.diag = h->diag.p; R.y = h->y.p;
+    R.t_stride = h->t_stride; R.diag_stride = h->diag_stride; R.y_stride = h->y_stride;
+    R.lane_is = 1; R.lane_cs = h->L;
+    R.staged = 1;
+  }
+  return R;
 }
 
 // Row-major API layout -> chunk-interleaved layout (3 tiled transposes).  Returns whether the copy
@@ -1453,6 +1530,12 @@ int clr_batch_get_conditioning_chunkwise(clr_batch* h, double* ratio_max) {
   // max over chunks of gamma_c / mu_c (both of the SAME chunk), per problem
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if (!ratio_max) return fail(CLR_INVALID_ARGUMENT, "ratio_max is null");
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  if (h->nchunk < 2) {  // one chunk: the recurrence itself ran, there is no record
+    for (int b = 0; b < h->B; ++b) ratio_max[b] = 0.0;
+    return CLR_OK;
+  }
   const size_t pc = (size_t)h->B * h->nchunk;
   std::vector<double> c(pc * 3);
   HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1472,6 +1555,15 @@ int clr_batch_get_conditioning_chunkwise(clr_batch* h, double* ratio_max) {
 int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  if (h->nchunk < 2) {  // one chunk: the recurrence itself ran, there is no record
+    for (int b = 0; b < h->B; ++b) {
+      if (gamma_max) gamma_max[b] = 0.0;
+      if (mu_min) mu_min[b] = 1.0;
+      if (resid_max) resid_max[b] = 0.0;
+    }
+    return CLR_OK;
+  }
   const size_t pc = (size_t)h->B * h->nchunk;
   std::vector<double> c(pc * 3);
   HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1497,8 +1589,76 @@ int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max
   return CLR_OK;
 }
 
-int clr_batch_set_prefix_mode(clr_batch* h, int cooperative) {
-  h->coop_prefix = cooperative ? 1 : 0;
+int clr_batch_set_prefix_mode(clr_batch* h, int mode) {
+  if (mode < 0 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "prefix mode must be 0, 1 or 2");
+  h->coop_prefix = mode;
+  return CLR_OK;
+}
+
+int clr_batch_set_prefix_plan(clr_batch* h, int levels, int group) {
+  if (levels > 3 || (levels > 0 && group < 2)) return fail(CLR_INVALID_ARGUMENT, "prefix plan: levels <= 3, group >= 2");
+  h->plan_levels = levels;
+  h->plan_g = group;
+  return clr_batch_set_chunks(h, h->nchunk);
+}
+
+int clr_batch_get_prefix_plan(const clr_batch* h, int* levels, int* groups /* [3] */, int* counts /* [4] */) {
+  if (levels) *levels = (h->launch && h->coop_prefix == 2) ? h->plan.levels : 0;
+  for (int l = 0; l < 3; ++l) if (groups) groups[l] = h->plan.g[l];
+  for (int l = 0; l < 4; ++l) if (counts) counts[l] = h->plan.n[l];
+  return CLR_OK;
+}
+
+int clr_batch_debug_get_starts(clr_batch* h, double* starts) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch || !starts) return fail(CLR_INVALID_ARGUMENT, "start states are kept for widths 1..8");
+  const size_t n = (size_t)h->B * h->nchunk * h->launch->start_doubles;
+  HIP_TRY(hipMemcpyAsync(starts, h->starts.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_debug_compose_check(clr_batch* h, int group, double* max_abs_diff, double* max_abs_value) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch || group < 2 || !h->evaluated)
+    return fail(CLR_INVALID_ARGUMENT, "compose check: widths 1..8, group >= 2, after an evaluation");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t np = (size_t)(h->nchunk + group - 1) / group, E = (size_t)h->launch->elem_doubles;
+  const size_t n = (size_t)h->B * np * E;
+  DevBuf a, b;
+  if ((st = a.reserve(n)) != CLR_OK || (st = b.reserve(n)) != CLR_OK) return st;
+  h->launch->compose_check(P, group, a.p, b.p, h->stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> ha(n), hb(n);
+  HIP_TRY(hipMemcpyAsync(ha.data(), a.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hb.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  a.release();
+  b.release();
+  // per element (one composed group) and per block of it (A | b | C | eta | Jm): the largest difference against the
+  // block's largest magnitude; the last group of a problem may hold the padded last chunk (never applied): skipped
+  const int J = h->J, SZ = J * (J + 1) / 2;
+  const size_t off[6] = {0, (size_t)J * J, (size_t)J * J + J, (size_t)J * J + J + SZ, (size_t)J * J + 2 * J + SZ, E};
+  double worst = 0.0, big = 0.0;
+  for (size_t e = 0; e < (size_t)h->B * np; ++e) {
+    if (e % np == np - 1) continue;
+    for (int blk = 0; blk < 5; ++blk) {
+      double d = 0.0, m = 0.0;
+      for (size_t i = off[blk]; i < off[blk + 1]; ++i) {
+        const double x = ha[e * E + i], y = hb[e * E + i];
+        if (!(fabs(x - y) <= d)) d = fabs(x - y);
+        if (!(fabs(y) <= m)) m = fabs(y);
+      }
+      const double r = m > 0.0 ? d / m : d;
+      if (!(r <= worst)) worst = r;
+      if (!(m <= big)) big = m;
+    }
+  }
+  if (max_abs_diff) *max_abs_diff = worst;
+  if (max_abs_value) *max_abs_value = big;
   return CLR_OK;
 }
 
@@ -1514,6 +1674,12 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
   if (!h->launch)  // wide plans: plain or lazy flavour of the one-wave-per-chunk summarize
     *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h)) ? 2 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_replay_source(clr_batch* h, int source) {
+  if (source < -1 || source > 1) return fail(CLR_INVALID_ARGUMENT, "replay source must be -1, 0 or 1");
+  h->replay_source = source;
   return CLR_OK;
 }
 
@@ -1608,6 +1774,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     ++h->prof_steps;
   }
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
+  h->evaluated = true;
   if (!h->launch) {
     mark(0);
     wide_launch(h, P, ev);
@@ -1623,7 +1790,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   mark(3);
   h->launch->correct(P, h->stream);  // (also on forced-exact runs: flags + conditioning record)
   mark(4);
-  h->launch->replay(P, materialize ? 2 : 0, h->stream);      // forced-exact / materialising runs only
+  h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);  // forced-exact / materialising runs only
   h->launch->sequential(P, materialize ? 2 : 0, h->stream);  // flagged / ill-conditioned problems only
   mark(5);
   clr::launch_finalize(P, h->stream);
@@ -1716,6 +1883,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   clr::BatchParams P;
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
+  h->evaluated = true;
   if (h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
   // one event per kernel boundary per step, all recorded on the handle's stream
   const int NK = 6;
@@ -1736,7 +1904,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[3], h->stream));
     h->launch->correct(P, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
-    h->launch->replay(P, materialize ? 2 : 0, h->stream);
+    h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);
     h->launch->sequential(P, materialize ? 2 : 0, h->stream);
     HIP_TRY(hipEventRecord(e[5], h->stream));
     clr::launch_finalize(P, h->stream);

@@ -36,7 +36,11 @@ struct BatchParams {
   int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
   int split;      // summarize as two roles on two waves per SIMD (widths 7, 8; clr_split_kernels.h);
                   // needs the chunk-interleaved series (staged == 0, lane_cs == 1)
-  int coop_prefix;  // 16 lanes per problem in the prefix phase (0: one lane, the reference version)
+  int coop_prefix;  // prefix phase: 0 one lane per problem (the reference version), 1 16 lanes per problem walking
+                    // the chunks in order, 2 multi-level (clr_prefix_kernels.h) following `plan`
+  PrefixPlan plan;        // levels of the multi-level prefix (plan.levels == 0: the plain walk)
+  double* lvl_elems;      // composed elements of levels 1..plan.levels, [B][plan.n[l]][ELEM] back to back
+  double* lvl_starts;     // their start states, [B][plan.n[l]][START] back to back
   double* elems;   // [B][nchunk][ELEM]
   double* starts;  // [B][nchunk][START]
   // replay-free path: summarize writes each chunk's ZERO-START sums, correct_kernel
@@ -640,6 +644,10 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
   }
 }
 
+}  // namespace clr
+#include "clr_prefix_kernels.h"
+namespace clr {
+
 // One table entry per (JR, JC): host-callable launchers.
 struct BatchLaunchers {
   void (*summarize)(const BatchParams&, hipStream_t);  // (role-split kernel when P.split > 0, widths 7, 8)
@@ -647,6 +655,9 @@ struct BatchLaunchers {
   void (*correct)(const BatchParams&, hipStream_t);
   void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
   void (*sequential)(const BatchParams&, int materialize, hipStream_t);
+  // cross-check: compose the chunk elements in groups of g with the cooperative kernel (-> coop) and with the
+  // single-lane host-checked form (-> ref); both [B][ceil(nchunk / g)][ELEM]
+  void (*compose_check)(const BatchParams&, int g, double* coop, double* ref, hipStream_t);
   int elem_doubles, start_doubles;
 };
 
@@ -663,7 +674,9 @@ struct BatchImpl {
   }
   static void prefix(const BatchParams& P, hipStream_t s) {
     if (P.nchunk < 2) return;
-    if (P.coop_prefix)
+    if (P.coop_prefix == 2 && P.plan.levels > 0 && P.lvl_elems && P.lvl_starts)
+      launch_multilevel_prefix<JR + 2 * JC>(P, s);
+    else if (P.coop_prefix)
       hipLaunchKernelGGL((prefix_coop_kernel<JR + 2 * JC, 8>), dim3((P.B + 3) / 4), dim3(64), 0, s, P);
     else
       hipLaunchKernelGGL((prefix_kernel<JR, JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
@@ -694,9 +707,18 @@ struct BatchImpl {
 #undef CLR_GO2
 #undef CLR_GO
   }
+  static void compose_check(const BatchParams& P, int g, double* coop, double* ref, hipStream_t s) {
+    constexpr int J = JR + 2 * JC;
+    const int np = (P.nchunk + g - 1) / g;
+    SegParams S{P.elems, nullptr, nullptr, coop, P.B, P.nchunk, g, np, nullptr};
+    const long nseg = (long)P.B * np;
+    hipLaunchKernelGGL((group_compose_kernel<J>), dim3((unsigned)((nseg + 1) / 2)), dim3(64), 0, s, S);
+    S.parents = ref;
+    hipLaunchKernelGGL((group_compose_reference_kernel<J>), dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, s, S);
+  }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, Widths<JR, JC>::ELEM,
-                          Widths<JR, JC>::START};
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check,
+                          Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };
 

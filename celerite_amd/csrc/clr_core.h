@@ -689,6 +689,201 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
 }
 
 // ---------------------------------------------------------------------------
+// compose: the element of "e1, then e2" (the associative operator of the scan; Sarkka &
+// Garcia-Fernandez 2021, Lemma 8, in this file's sign conventions).  With
+// Mi = (I + C1 Jm2)^-1 and w = eta2 - Jm2 b1:
+//   C12 = C2 + A2 (Mi C1) A2^T          b12   = b2 + A2 Mi (b1 + C1 eta2)
+//   A12 = A2 (Mi A1)                    eta12 = eta1 + (Mi A1)^T w
+//   Jm12 = Jm1 + A1^T Jm2 (Mi A1)
+// (C12, b12) is nothing but e2 ADVANCING the state (C1, b1) -- (C, b) of an element is its
+// zero-start trajectory -- so a composition is an advance (chunk_update) whose Gauss-Jordan
+// tableau [I + C1 Jm2 | C1 | h] carries J more right-hand sides, the columns of A1:
+// X1 = Mi A1 feeds the three rider updates.  (Mi^T Jm2 = Jm2 Mi: push-through identity.)
+// Single-lane form: the host check, and the on-device cross-check of the cooperative
+// group_compose_kernel (clr_prefix_kernels.h), which a multi-level prefix is built from.
+// `out` may alias e1 or e2.
+// ---------------------------------------------------------------------------
+template <int J>
+CLR_HD void compose_elements(const double* e1, const double* e2, double* out) {
+  constexpr int SZ = J * (J + 1) / 2;
+  constexpr int NC = 3 * J + 1;  // [ I + C1 Jm2 | C1 | A1 | h ]
+  const double *A1 = e1, *b1 = e1 + J * J, *C1 = b1 + J, *eta1 = C1 + SZ, *Jm1 = eta1 + J;
+  const double *A2 = e2, *b2 = e2 + J * J, *C2 = b2 + J, *eta2 = C2 + SZ, *Jm2 = eta2 + J;
+
+  double T[J][NC];
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    double h = b1[i];
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      double acc = (i == j) ? 1.0 : 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) acc += C1[sym(i, k)] * Jm2[sym(k, j)];
+      T[i][j] = acc;
+      T[i][J + j] = C1[sym(i, j)];
+      T[i][2 * J + j] = A1[i * J + j];
+      h += C1[sym(i, j)] * eta2[j];
+    }
+    T[i][3 * J] = h;
+  }
+  CLR_UNROLL_J
+  for (int col = 0; col < J; ++col) {
+    int piv = col;
+    double best = fabs(T[col][col]);
+    CLR_UNROLL_J
+    for (int i = col + 1; i < J; ++i) {
+      const double cand = fabs(T[i][col]);
+      const bool take = cand > best;
+      best = take ? cand : best;
+      piv = take ? i : piv;
+    }
+    CLR_UNROLL_J
+    for (int c = col; c < NC; ++c) {
+      double top = T[col][c];
+      const double old_top = top;
+      CLR_UNROLL_J
+      for (int i = col + 1; i < J; ++i) {
+        const bool hit = (i == piv);
+        top = hit ? T[i][c] : top;
+        T[i][c] = hit ? old_top : T[i][c];
+      }
+      T[col][c] = top;
+    }
+    const double inv = 1.0 / T[col][col];
+    CLR_UNROLL_J
+    for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      if (i == col) continue;
+      const double m = T[i][col];
+      CLR_UNROLL_J
+      for (int c = col + 1; c < NC; ++c) T[i][c] -= m * T[col][c];
+    }
+  }
+  // T[i][J + j] = X2 = Mi C1 (symmetric up to rounding), T[i][2J + j] = X1 = Mi A1, T[i][3J] = Mi h
+  double w[J], A12[J * J], b12[J], C12[SZ], eta12[J], Jm12[SZ];
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    double acc = eta2[i];
+    CLR_UNROLL_J
+    for (int k = 0; k < J; ++k) acc -= Jm2[sym(i, k)] * b1[k];
+    w[i] = acc;
+  }
+  double Y[J][J];  // A2 X2 (then A2 X2 A2^T), reused for Jm2 X1
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    double bacc = b2[i];
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0, aacc = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) {
+        acc += A2[i * J + k] * (0.5 * (T[k][J + j] + T[j][J + k]));
+        aacc += A2[i * J + k] * T[k][2 * J + j];
+      }
+      Y[i][j] = acc;
+      A12[i * J + j] = aacc;
+      bacc += A2[i * J + j] * T[j][3 * J];
+    }
+    b12[i] = bacc;
+  }
+  CLR_UNROLL_J
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL_J
+    for (int k = 0; k <= j; ++k) {
+      double acc = C2[tri(k, j)];
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) acc += Y[k][i] * A2[j * J + i];
+      C12[tri(k, j)] = acc;
+    }
+  }
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {  // Y <- Jm2 X1
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) acc += Jm2[sym(i, k)] * T[k][2 * J + j];
+      Y[i][j] = acc;
+    }
+  }
+  CLR_UNROLL_J
+  for (int j = 0; j < J; ++j) {
+    double eacc = eta1[j];
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) eacc += T[i][2 * J + j] * w[i];
+    eta12[j] = eacc;
+    CLR_UNROLL_J
+    for (int k = 0; k <= j; ++k) {  // symmetrised: (A1^T Y + Y^T A1) / 2
+      double acc = 0.0;
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) acc += A1[i * J + k] * Y[i][j] + A1[i * J + j] * Y[i][k];
+      Jm12[tri(k, j)] = Jm1[tri(k, j)] + 0.5 * acc;
+    }
+  }
+  double* o = out;
+  CLR_UNROLL_J
+  for (int i = 0; i < J * J; ++i) o[i] = A12[i];
+  o += J * J;
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) o[i] = b12[i];
+  o += J;
+  CLR_UNROLL_J
+  for (int i = 0; i < SZ; ++i) o[i] = C12[i];
+  o += SZ;
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) o[i] = eta12[i];
+  o += J;
+  CLR_UNROLL_J
+  for (int i = 0; i < SZ; ++i) o[i] = Jm12[i];
+}
+
+// ---------------------------------------------------------------------------
+// Schedule of a multi-level prefix over n chunk elements: level 0 = the chunks, level l + 1 =
+// compositions of groups of g[l] consecutive level-l elements; the top level is walked
+// sequentially, then the start states fan out level by level.  Depth in advance-equivalents
+// (a composition costs ~1.2 advances in the cooperative kernel: same Gauss-Jordan, one more
+// product): sum_l 2.2 (g_l - 1) + n_top, against n for the plain walk.  Chosen on the host.
+// ---------------------------------------------------------------------------
+struct PrefixPlan {
+  int levels;     // number of composition levels (0: plain sequential walk)
+  int g[3];       // group sizes, bottom up
+  int n[4];       // element counts per level: n[0] = nchunk, n[l + 1] = ceil(n[l] / g[l])
+  double depth;   // modelled length of the dependent chain, in chunk advances
+};
+// levels < 0: choose; otherwise build the plan with that many levels of groups of g (clamped so that
+// every level still has at least two groups)
+inline PrefixPlan plan_prefix(int nchunk, int levels = -1, int g = 0) {
+  const double per_level = 4.0;  // two more dependent launches per level, in advance-equivalents
+  const double cmp = 1.2;        // a composition against an advance (same Gauss-Jordan, one more product)
+  auto build = [&](int lv, int gg) {
+    PrefixPlan p;
+    p.levels = 0;
+    p.n[0] = nchunk;
+    p.depth = 0.0;
+    for (int l = 0; l < 3; ++l) {
+      const bool use = l < lv && gg >= 2 && p.n[l] >= 2 * gg;
+      p.g[l] = use ? gg : 1;
+      p.n[l + 1] = (p.n[l] + p.g[l] - 1) / p.g[l];
+      if (use) {
+        p.levels = l + 1;
+        p.depth += per_level + (cmp + 1.0) * (gg - 1);
+      }
+    }
+    p.depth += p.n[p.levels];
+    return p;
+  };
+  if (levels >= 0) return build(levels > 3 ? 3 : levels, g);
+  PrefixPlan best = build(0, 0);
+  for (int lv = 1; lv <= 3; ++lv)
+    for (int gg = 2; gg <= 64; ++gg) {
+      const PrefixPlan p = build(lv, gg);
+      if (p.levels == lv && p.depth < best.depth) best = p;
+    }
+  return best;
+}
+
+// ---------------------------------------------------------------------------
 // replay: the reference recurrence over samples [n0, n1) from a known state.
 // Accumulates sum(log D_n) and sum(x_n^2 / D_n); flags the first D_n < 0 with
 // n >= 1 (cholesky.h:176 -- sample 0 is never checked, :100-117).  When

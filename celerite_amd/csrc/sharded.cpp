@@ -3,6 +3,11 @@
 // cholesky.h:703-706), so a sharded plan is nothing but S single-device plans (clr_batch_*)
 // over contiguous slices of the batch axis: no collective, no device-to-device traffic.
 //
+// Kernel selection is resolved ONCE for the whole batch: the maxima the single-device plans look at
+// (max |t|, largest time step, largest decay rate and frequency) are taken over all problems and handed
+// to every shard (clr_batch_set_selection_bounds), and all shards use the first shard's chunk count, so
+// a batch gives bit-identical results under any sharding with the default settings.
+//
 // Each shard has its own host worker thread (which owns the shard's HIP device binding,
 // stream and pinned staging through its clr_batch handle); an API call posts one job to every
 // worker and waits for all of them, so the shards' uploads, launches and downloads overlap.
@@ -170,6 +175,11 @@ clr_sharded* clr_sharded_create(int B, int N, int J_real, int J_comp, const int*
     g_sharded_error = keep;
     return nullptr;
   }
+  // one chunk count for all shards (the automatic choice looks at the shard's own batch size, which differs by
+  // one between shards when B is not a multiple of the shard count)
+  int nchunk = 0;
+  clr_batch_get_chunks(h->plan[0], &nchunk, nullptr);
+  if (nshards > 1) (void)clr_sharded_set_chunks(h, nchunk);
   return h;
 }
 
@@ -198,20 +208,61 @@ int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* ch
 
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
                            long diag_stride, const double* y, long y_stride) {
-  return h->all([=](int s) {
+  int st = h->all([=](int s) {
     const long lo = h->lo[s];
     return clr_batch_set_series(h->plan[s], t + lo * t_stride, t_stride, diag + lo * diag_stride,
                                 diag_stride, y + lo * y_stride, y_stride);
   });
+  if (st != CLR_OK) return st;
+  // the series' maxima over the WHOLE batch (every shard scanned its own slice during the upload)
+  double tmax = 0.0, dxmax = 0.0;
+  for (clr_batch* p : h->plan) {
+    double a = 0.0, b = 0.0;
+    clr_batch_get_selection_bounds(p, &a, &b, nullptr, nullptr, nullptr);
+    if (!(a <= tmax)) tmax = a;
+    if (!(b <= dxmax)) dxmax = b;
+  }
+  for (clr_batch* p : h->plan) clr_batch_set_selection_bounds(p, tmax, dxmax, -1.0, -1.0);
+  return CLR_OK;
+}
+
+// largest |d_comp| and decay rate over the whole batch -> every shard (before it takes its slice)
+static void global_coefficient_bounds(clr_sharded* h, const double* c_real, const double* c_comp, const double* d_comp) {
+  double dmax = 0.0, cmax = 0.0;
+  const size_t nr = (size_t)h->B * h->J_real, nc = (size_t)h->B * h->J_comp;
+  for (size_t i = 0; i < nc; ++i) {
+    const double m = d_comp[i] < 0 ? -d_comp[i] : d_comp[i], c = c_comp[i] < 0 ? -c_comp[i] : c_comp[i];
+    if (!(m <= dmax)) dmax = m;
+    if (!(c <= cmax)) cmax = c;
+  }
+  for (size_t i = 0; i < nr; ++i) {
+    const double c = c_real[i] < 0 ? -c_real[i] : c_real[i];
+    if (!(c <= cmax)) cmax = c;
+  }
+  for (clr_batch* p : h->plan) clr_batch_set_selection_bounds(p, -1.0, -1.0, dmax, cmax);
+}
+
+int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind) {
+  if (!kind) return CLR_INVALID_ARGUMENT;
+  int k0 = 0;
+  int st = clr_batch_get_summarize_kernel(h->plan[0], &k0);
+  for (size_t s = 1; s < h->plan.size() && st == CLR_OK; ++s) {
+    int k = 0;
+    st = clr_batch_get_summarize_kernel(h->plan[s], &k);
+    if (k != k0) k0 = -1;  // (cannot happen once series and coefficients went through this layer)
+  }
+  *kind = k0;
+  return st;
 }
 
 int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const double* a_real,
                                  const double* c_real, const double* a_comp, const double* b_comp,
                                  const double* c_comp, const double* d_comp) {
   const long JR = h->J_real, JC = h->J_comp;
+  global_coefficient_bounds(h, c_real, c_comp, d_comp);
   return h->all([=](int s) {
     const long lo = h->lo[s];
-    return clr_batch_set_coefficients(h->plan[s], jitter + lo, a_real + lo * JR, c_real + lo * JR,
+    return clr_batch_set_coefficients(h->plan[s], jitter ? jitter + lo : nullptr, a_real + lo * JR, c_real + lo * JR,
                                       a_comp + lo * JC, b_comp + lo * JC, c_comp + lo * JC,
                                       d_comp + lo * JC);
   });
@@ -237,10 +288,11 @@ int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_r
                          const double* a_comp, const double* b_comp, const double* c_comp,
                          const double* d_comp, double* loglike, double* logdet, double* quad, int* status) {
   const long JR = h->J_real, JC = h->J_comp;
+  global_coefficient_bounds(h, c_real, c_comp, d_comp);
   return h->all([=](int s) {
     const long lo = h->lo[s];
     clr_batch* p = h->plan[s];
-    int st = clr_batch_set_coefficients(p, jitter + lo, a_real + lo * JR, c_real + lo * JR, a_comp + lo * JC,
+    int st = clr_batch_set_coefficients(p, jitter ? jitter + lo : nullptr, a_real + lo * JR, c_real + lo * JR, a_comp + lo * JC,
                                         b_comp + lo * JC, c_comp + lo * JC, d_comp + lo * JC);
     if (st == CLR_OK) st = clr_batch_enqueue(p, 0);
     if (st == CLR_OK)

@@ -210,6 +210,7 @@ int clr_batch_set_series(clr_batch* h,
                          const double* t, long t_stride,
                          const double* diag, long diag_stride,
                          const double* y, long y_stride);
+/* (jitter may be NULL: no jitter) */
 int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
                                const double* a_real, const double* c_real,
                                const double* a_comp, const double* b_comp,
@@ -241,11 +242,41 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
  *  -1  (default) 2 at widths 7 and 8 on a dense series; otherwise 1 at width 7 and at width 8 with at least two
  *      complex terms, else 0. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
+/* Where the replay pass (materialising / forced-exact runs) reads the series when the summarize kernel reads the
+ * chunk-interleaved copy: 0 that copy, 1 the row-major arrays through LDS-staged tiles, -1 (default) 1 for
+ * materialising runs, else 0 (profiles/r03_materialize_ab.txt). */
+int clr_batch_set_replay_source(clr_batch* h, int source);
 /* Which one the next evaluation will run (0, 1 or 2 as above), given the series and coefficients set. */
 int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind);
-/* Prefix phase: 16 lanes per problem (default) or the single-lane version (kept as
- * the on-device cross-check and for A/B measurements). */
-int clr_batch_set_prefix_mode(clr_batch* h, int cooperative);
+/* Prefix phase of the scan (widths 1..8): how the chunk elements are turned into chunk start states.
+ *   2 (default) multi-level: groups of consecutive elements are composed in parallel (element o element, the
+ *       associative operator of the scan; csrc/clr_prefix_kernels.h), the few composed elements are walked, and the
+ *       start states fan out group by group -- the dependent chain is ~2.2 (g - 1) per level + the top level instead
+ *       of nchunk (the reference's loop being parallelised: cholesky.h:126-179);
+ *   1 16 lanes per problem walking the chunks one after the other;
+ *   0 the single-lane version (the host-checked form; on-device cross-check and A/B). */
+int clr_batch_set_prefix_mode(clr_batch* h, int mode);
+/* Level structure of mode 2: `levels` (0..3) levels of groups of `group` (>= 2) elements; levels < 0 (default):
+ * chosen from the chunk count by a cost model (clr_core.h: plan_prefix).  Re-plans the workspace. */
+int clr_batch_set_prefix_plan(clr_batch* h, int levels, int group);
+/* The plan in force: number of composition levels (0 = plain walk), group size per level [3], element count per
+ * level [4] (counts[0] = chunks). */
+int clr_batch_get_prefix_plan(const clr_batch* h, int* levels, int* groups, int* counts);
+/* Diagnostics (tests): the chunk start states of the last evaluation, [B][nchunk][J(J+1)/2 + J] (packed upper
+ * triangle of P, then f) ... */
+int clr_batch_debug_get_starts(clr_batch* h, double* starts);
+/* ... and the cooperative composition kernel against the single-lane host-checked form on the last evaluation's
+ * chunk elements in groups of `group`: the largest difference relative to the largest entry of the same block
+ * (A, b, C, eta, Jm) of the same composed element, and the largest magnitude seen. */
+int clr_batch_debug_compose_check(clr_batch* h, int group, double* max_rel_diff, double* max_abs_value);
+/* The maxima the kernel selection looks at -- max |t|, largest time step, largest |d_comp|, largest decay rate of the
+ * plan's own series / coefficients -- and the host time of the last clr_batch_set_series (scan + uploads, ms).  Any
+ * pointer may be NULL. */
+int clr_batch_get_selection_bounds(const clr_batch* h, double* tmax, double* dxmax, double* dmax, double* cmax,
+                                   double* set_series_host_ms);
+/* Floors for those maxima (negative: keep): a sharded plan passes the maxima of the WHOLE batch so that every shard
+ * selects the same kernels as the unsharded plan would. */
+int clr_batch_set_selection_bounds(clr_batch* h, double tmax, double dxmax, double dmax, double cmax);
 /* The fused log-likelihood normally needs no second pass over the series: each
  * chunk's true log-det / quadratic contributions follow from its zero-start sums and
  * its start state (determinant lemma + Woodbury), and only
@@ -372,9 +403,11 @@ int clr_sharded_get_shard(const clr_sharded* h, int shard, int* device, int* lo,
  * problems; every shard takes its slice).  The calls return when every shard has. */
 int clr_sharded_set_chunks(clr_sharded* h, int nchunk);
 int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* chunk_len);
-/* (the automatic choice of the summarize kernel looks at the shard's own series and coefficients:
- * pin it too when bit-identical results across shardings are wanted) */
+/* (the automatic choice of the summarize kernel is resolved once for the whole batch: the shards are handed the
+ * batch-wide maxima of the series and coefficients, so the choice does not depend on the sharding) */
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
+/* The summarize kernel all shards will run (clr_batch_get_summarize_kernel; -1 if they disagree). */
+int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind);
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
                            long diag_stride, const double* y, long y_stride);
 int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const double* a_real,

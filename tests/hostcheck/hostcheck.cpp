@@ -6,12 +6,60 @@
 // oracle in the CPU-only test run.  Not linked into libcelerite_hip.so, never
 // used by the product: the shipped library has no CPU implementation.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "../../celerite_amd/csrc/clr_core.h"
 
 using namespace clr;
+
+// prefix schedule of the next hostcheck_batch calls: 0 levels = the plain walk over the chunks;
+// otherwise the multi-level prefix (compose groups bottom-up, walk the top, fan out), group size g
+static int g_prefix_levels = 0, g_prefix_g = 0;
+extern "C" void hostcheck_set_prefix(int levels, int g) { g_prefix_levels = levels; g_prefix_g = g; }
+
+// start states of all `n` elements of one level from the level's elements (ELEM doubles each):
+// recursion over groups of g
+template <int J>
+static void multilevel_starts(const std::vector<double>& elems, int n, int levels, int g,
+                              std::vector<double>& starts) {
+  constexpr int SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
+  starts.assign((size_t)n * START, 0.0);
+  double dld, dq;
+  int sus;
+  if (levels == 0 || n < 2) {
+    double S[SZ] = {0}, f[J] = {0};
+    for (int c = 0; c + 1 < n; ++c) {
+      chunk_update<J>(&elems[(size_t)c * ELEM], S, f, false, true, 0.0, 0.0, &dld, &dq, &sus);
+      memcpy(&starts[(size_t)(c + 1) * START], S, sizeof(S));
+      memcpy(&starts[(size_t)(c + 1) * START + SZ], f, sizeof(f));
+    }
+    return;
+  }
+  const int np = (n + g - 1) / g;
+  std::vector<double> parents((size_t)np * ELEM), pstarts;
+  for (int k = 0; k < np; ++k) {
+    const int first = k * g, len = std::min(g, n - first);
+    double e[ELEM];
+    memcpy(e, &elems[(size_t)first * ELEM], sizeof(e));
+    for (int i = 1; i < len; ++i) compose_elements<J>(e, &elems[(size_t)(first + i) * ELEM], e);
+    memcpy(&parents[(size_t)k * ELEM], e, sizeof(e));
+  }
+  multilevel_starts<J>(parents, np, levels - 1, g, pstarts);
+  for (int k = 0; k < np; ++k) {
+    const int first = k * g, len = std::min(g, n - first);
+    double S[SZ], f[J];
+    memcpy(S, &pstarts[(size_t)k * START], sizeof(S));
+    memcpy(f, &pstarts[(size_t)k * START + SZ], sizeof(f));
+    for (int i = 0; i < len; ++i) {
+      memcpy(&starts[(size_t)(first + i) * START], S, sizeof(S));
+      memcpy(&starts[(size_t)(first + i) * START + SZ], f, sizeof(f));
+      if (i + 1 < len)
+        chunk_update<J>(&elems[(size_t)(first + i) * ELEM], S, f, false, true, 0.0, 0.0, &dld, &dq, &sus);
+    }
+  }
+}
 
 template <int JR, int JC, bool FAST>
 static int run(int B, int N, int nchunk, const double* jitter, const double* a_real,
@@ -62,9 +110,18 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
     double S[Wd::SZ] = {0}, f[J] = {0};
     double ld = 0, qd = 0;
     int need_exact = 0;
+    std::vector<double> mstarts;
+    if (g_prefix_levels > 0) {
+      std::vector<double> real_elems(elems.begin(), elems.begin() + (size_t)nreal * Wd::ELEM);
+      multilevel_starts<J>(real_elems, nreal, g_prefix_levels, g_prefix_g, mstarts);
+    }
     for (int c = 0; c < nreal; ++c) {
       double dld = 0, dq = 0;
       int sus = 0;
+      if (g_prefix_levels > 0) {  // the state this chunk starts from, as the multi-level prefix found it
+        memcpy(S, &mstarts[(size_t)c * Wd::START], sizeof(S));
+        memcpy(f, &mstarts[(size_t)c * Wd::START + Wd::SZ], sizeof(f));
+      }
       // chunk 0 starts from the zero state: no correction (E = I)
       chunk_update<J>(&elems[(size_t)c * Wd::ELEM], S, f, c > 0, c + 1 < nreal, ld0[c], q0[c], &dld,
                       &dq, &sus);
@@ -72,8 +129,13 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       qd += q0[c] + dq;
       need_exact |= sus | fl0[c];
       if (c + 1 < nreal) {
-        memcpy(&starts[(size_t)(c + 1) * Wd::START], S, sizeof(S));
-        memcpy(&starts[(size_t)(c + 1) * Wd::START + Wd::SZ], f, sizeof(f));
+        if (g_prefix_levels > 0) {
+          memcpy(&starts[(size_t)(c + 1) * Wd::START], &mstarts[(size_t)(c + 1) * Wd::START],
+                 sizeof(double) * Wd::START);
+        } else {
+          memcpy(&starts[(size_t)(c + 1) * Wd::START], S, sizeof(S));
+          memcpy(&starts[(size_t)(c + 1) * Wd::START + Wd::SZ], f, sizeof(f));
+        }
       }
     }
     int bad = 0;

@@ -143,6 +143,82 @@ def test_prefix_modes_agree(JR, JC):
 
 
 @pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
+def test_multilevel_prefix_against_the_walk(JR, JC):
+    """Row h of the scope table: the device-side element o element composition (group_compose_kernel)
+    and the multi-level prefix built from it (clr_prefix_kernels.h) against the plain walk over the
+    chunks (prefix mode 1), on every width shape and both input families:
+      * the cooperative composition kernel equals the single-lane host-checked compose_elements on
+        the device (block-relative 1e-11);
+      * chunk start states, log det and the quadratic form agree with the walk to 1e-12 (relative to
+        the problem's largest entry for the states), statuses are identical;
+      * both meet the oracle at 1e-10."""
+    for family, seed in (("bench", 5), ("accuracy", 6)):
+        B, N = 6, 6000
+        case = synthetic(B, N, JR, JC, family, seed=seed + JR + 9 * JC)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(B, N, JR, JC)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        for nchunk, plans in ((64, [(-1, 0), (1, 4), (1, 7), (2, 3)]), (125, [(-1, 0), (1, 8), (2, 4), (3, 3)]),
+                              (13, [(1, 2), (1, 5)])):
+            plan.set_chunks(nchunk)
+            plan.set_prefix_mode("walk")
+            ll1, ld1, q1, st1 = plan.log_likelihood()
+            starts1 = plan.debug_starts()
+            assert np.array_equal(st1, s0)
+            plan.set_prefix_mode("multilevel")
+            for levels, group in plans:
+                plan.set_prefix_plan(levels, group)
+                lv, gs, ns = plan.prefix_plan
+                assert lv >= 1 and ns[0] == plan.chunks[0], (nchunk, levels, group, lv, gs, ns)
+                ll2, ld2, q2, st2 = plan.log_likelihood()
+                starts2 = plan.debug_starts()
+                key = (family, nchunk, levels, group)
+                assert np.array_equal(st2, s0), key
+                scale = np.max(np.abs(starts1[:, 1:]), axis=(1, 2), keepdims=True)
+                assert np.max(np.abs(starts2[:, 1:] - starts1[:, 1:]) / scale) <= 1e-12, key
+                assert np.max(np.abs(ld2 - ld1) / np.abs(ld1)) <= 1e-12, key
+                assert np.max(np.abs(q2 - q1) / np.abs(q1)) <= 1e-12, key
+                assert np.max(np.abs(ld2 - d0) / np.abs(d0)) <= REL, key
+                assert np.max(np.abs(q2 - q0) / np.abs(q0)) <= REL, key
+            for group in (2, 5):
+                diff, big = plan.compose_check(group)
+                assert diff <= 1e-11 and big > 0.0, (family, nchunk, group, diff)
+            plan.set_prefix_plan(-1, 0)
+        plan.close()
+
+
+def test_multilevel_prefix_on_adversarial_problems_and_ragged_groups():
+    """Near-singular / indefinite problems: the multi-level prefix must leave every status word as the walk
+    and the oracle have it (the composed elements of an indefinite problem are garbage, but such a problem is
+    settled by the sequential recurrence, which does not use them)."""
+    shapes = [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 2), (2, 3), (0, 4), (4, 2), (8, 0), (3, 0)]
+    for trial in range(24):
+        JR, JC = shapes[trial % len(shapes)]
+        N = (200, 1000)[trial % 2]
+        case = adversarial(5, N, JR, JC, seed=1000 + trial)   # 5 problems: ragged last wave
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(5, N, JR, JC)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        plan.set_chunks(max(2, N // 8))
+        plan.set_prefix_mode("walk")
+        _, _, _, st1 = plan.log_likelihood()
+        lev1 = plan.exact_levels()
+        plan.set_prefix_mode("multilevel")
+        for levels, group in ((1, 3), (2, 3), (1, 7)):   # 25 / 125 chunks: ragged last groups
+            plan.set_prefix_plan(levels, group)
+            ll, ld, q, st = plan.log_likelihood()
+            assert np.array_equal(st, s0) and np.array_equal(st, st1), (trial, levels, group)
+            lev = plan.exact_levels()
+            for p in range(5):
+                if s0[p] == 0 and lev[p] == 0 and np.isfinite(d0[p]) and np.isfinite(q0[p]):
+                    dev = max(abs(ld[p] - d0[p]) / abs(d0[p]), abs(q[p] - q0[p]) / abs(q0[p]))
+                    assert dev <= REL, (trial, levels, group, p, dev, lev1[p])
+        plan.close()
+
+
+@pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
 def test_replay_free_path_against_exact_replay(JR, JC):
     """The fused log-likelihood is settled from the chunk summaries (determinant
     lemma + Woodbury, chunk_update in clr_core.h) without a second pass; forcing the

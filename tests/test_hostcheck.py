@@ -201,3 +201,43 @@ def test_scan_is_as_close_to_the_exact_answer_as_the_reference_recurrence(lib):
             assert e_scan <= 20.0 * max(e_ref, 1e-13), (seed, b, e_scan, e_ref)
             checked += 1
     assert checked >= 6
+
+
+@pytest.mark.parametrize("family", ["bench", "accuracy"])
+def test_multilevel_prefix_matches_the_sequential_walk(lib, family):
+    """Row h of the scope table: element o element composition (clr_core.h: compose_elements) and the
+    multi-level prefix built from it -- compose groups bottom-up, walk the top level, fan the start
+    states out -- must reproduce the plain walk over the chunks: same statuses, results within 1e-12 of
+    it and within 1e-11 of the oracle, nothing pushed to the exact route."""
+    try:
+        for JR, JC in SHAPES:
+            for N, nchunk in [(1000, 7), (1000, 64), (3000, 100)]:
+                case = synthetic(3, N, JR, JC, family, seed=N + 10 * JR + JC)
+                l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+                lib.hostcheck_set_prefix(0, 0)
+                _, ld, q, st, _ = run(lib, JR, JC, nchunk, case, 1)
+                for levels, g in [(1, 2), (1, 8), (2, 3), (3, 2)]:
+                    lib.hostcheck_set_prefix(levels, g)
+                    _, ld2, q2, st2, _ = run(lib, JR, JC, nchunk, case, 1)
+                    assert np.array_equal(st2, s0) and not run.used_exact.any()
+                    assert np.max(np.abs(ld2 - ld) / np.abs(ld)) < 1e-12
+                    assert np.max(np.abs(q2 - q) / np.abs(q)) < 1e-12
+                    assert np.max(np.abs(ld2 - d0) / np.abs(d0)) < 1e-11
+                    assert np.max(np.abs(q2 - q0) / np.abs(q0)) < 1e-11
+    finally:
+        lib.hostcheck_set_prefix(0, 0)
+
+
+def test_multilevel_prefix_keeps_the_reference_status_on_adversarial_problems(lib):
+    try:
+        for trial in range(36):
+            JR, JC = SHAPES[trial % len(SHAPES)]
+            N = (200, 1000)[trial % 2]
+            case = adversarial(4, N, JR, JC, seed=1000 + trial)
+            l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+            for levels, g in [(1, 4), (2, 3)]:
+                lib.hostcheck_set_prefix(levels, g)
+                ll, ld, q, st, _ = run(lib, JR, JC, max(2, N // 8), case, 1)
+                assert np.array_equal(st, s0), (trial, levels, g)
+    finally:
+        lib.hostcheck_set_prefix(0, 0)
