@@ -230,8 +230,12 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         per = {k: v / max(nrec, 1) for k, v in kms.items()}
         plan.set_coefficients(*coeffs)
         ll, ld, q, st = plan.log_likelihood()
+        levels = np.bincount(plan.exact_levels(), minlength=3)[:3]
+        gam, mu = plan.conditioning()
+        eg = plan.measured_error()
         dev_ms, _ = plan.run_timed(steps, relayout_each_step=False)
         chunks = plan.chunks
+        prefix_plan = plan.prefix_plan if W <= 8 else (0, [], [chunks[0]])
     finally:
         plan.close()
     S = min(sample, B)
@@ -243,6 +247,12 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
     return {
         "workload": name, "batch": B, "N": N, "width": W, "J_real": JR, "J_comp": JC,
         "scan_chunks": chunks[0], "chunk_len": chunks[1], "steps": steps,
+        "prefix_plan": {"levels": prefix_plan[0], "groups": prefix_plan[1], "elements_per_level": prefix_plan[2]},
+        "levels": {"what": "problems by route: 0 settled from the chunk summaries, 1 checked chunked replay, "
+                           "2 sequential recurrence", "histogram": [int(v) for v in levels]},
+        "conditioning": {"gamma_max": float(np.max(gam)), "mu_min": float(np.min(mu)),
+                         "gamma_over_mu_max": float(np.max(gam / mu)), "measured_G_error_max": float(np.max(eg)),
+                         "gamma_times_error_max": float(np.max(gam * eg))},
         "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
         "device_only": {"ms_per_step": dev_ms / steps, "value": B / (dev_ms / steps * 1e-3)},
         "kernels_ms": per, "roofline": roofline_block(per, B, N, W),

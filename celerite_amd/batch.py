@@ -73,7 +73,9 @@ def _load():
     lib.clr_batch_get_exact_flags.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_get_conditioning.argtypes = [C.c_void_p, _dp, _dp, _dp]
     lib.clr_batch_get_conditioning_chunkwise.argtypes = [C.c_void_p, _dp]
+    lib.clr_batch_get_measured_error.argtypes = [C.c_void_p, _dp]
     lib.clr_batch_set_certificate.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.clr_batch_set_certificate_gamma.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.clr_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip]
     lib.clr_sharded_create.restype = C.c_void_p
     lib.clr_sharded_create.argtypes = [C.c_int] * 4 + [_ip, C.c_int]
@@ -329,9 +331,11 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_exact_flags(self._h, f.ctypes.data_as(_ip)))
         return f
 
-    def set_certificate(self, max_gamma_over_mu=1e6, max_residual=1e-11):
-        """Routing of ill-conditioned problems (``clr_batch_set_certificate``)."""
+    def set_certificate(self, max_gamma_over_mu=1e7, max_residual=1e-11, max_gamma=1e4, max_gamma_error=3e-9):
+        """Routing of ill-conditioned problems (``clr_batch_set_certificate``,
+        ``clr_batch_set_certificate_gamma``); a bound <= 0 switches that test off."""
         _check(_load().clr_batch_set_certificate(self._h, float(max_gamma_over_mu), float(max_residual)))
+        _check(_load().clr_batch_set_certificate_gamma(self._h, float(max_gamma), float(max_gamma_error)))
 
     def conditioning(self):
         """``(gamma_max, mu_min)`` per problem of the last run: largest ``a_n / D_n`` over the
@@ -340,6 +344,13 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_conditioning(self._h, _ptr(g), _ptr(m), _ptr(r)))
         self.last_residual = r
         return g, m
+
+    def measured_error(self):
+        """Per problem: the largest measured relative error of the chunks' ``G = (I + P Jm)^-1 P``
+        (``clr_batch_get_measured_error``; the routing tests ``gamma_max * eG_max``)."""
+        e = np.empty(self.B)
+        _check(_load().clr_batch_get_measured_error(self._h, _ptr(e)))
+        return e
 
     def conditioning_chunkwise(self):
         r = np.empty(self.B)

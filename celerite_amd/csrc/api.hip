@@ -228,22 +228,24 @@ double max_abs(const double* x, long n) {
   return m;
 }
 
-// Chunk count for the scan on `B` problems of `N` samples.
-int auto_chunks(int B, int N, bool with_replay = false) {
+// Chunk count for the scan on `B` problems of `N` samples of width `J`.
+int auto_chunks(int B, int N, int J, bool with_replay = false) {
   if (N < 128) return 1;
   // Cost model (measured on MI355X): the big kernels run
   // ceil(B * ceil(nchunk / 64) / 1024) rounds of waves (one per SIMD) over L = N / nchunk
-  // steps at ~2.4 us per step (3.3 us when the replay pass runs too); the prefix phase is
-  // sequential in the chunk count at ~2 us per chunk (4096 problems per round).  Many
-  // problems want exactly one wave per SIMD; a single long series wants ~sqrt(N) chunks.
-  const double c_step = with_replay ? 3.3e-6 : 2.4e-6, c_chunk = 2.0e-6;
+  // steps at ~2.4 us per step at width 8 (3.3 us when the replay pass runs too), less at
+  // smaller widths; the prefix phase costs what its plan says (clr_core.h: plan_prefix --
+  // a walk over the chunks, or a multi-level prefix when the chip has room for it).  Many
+  // problems want exactly one wave per SIMD; a single long series wants many short chunks.
+  const double w = (0.25 + 0.75 * J * J / 64.0);
+  const double c_step = (with_replay ? 3.3e-6 : 2.4e-6) * w;
   const long max_by_len = std::max<long>(1, N / 16);
   auto cost = [&](long nc) {
     long L = (N + nc - 1) / nc;
     if (nc > 1 && L > 8) L = (L + 7) & ~7L;
     const long waves = (long)B * ((nc + 63) / 64);
     const long rounds = (waves + 1023) / 1024;
-    return rounds * L * c_step + nc * c_chunk * ((B + 4095) / 4096);
+    return rounds * L * c_step + clr::plan_prefix((int)nc, -1, 0, B, J).time_us * 1e-6 + (nc > 1 ? 15e-6 : 0.0);
   };
   long best = 1;
   double best_cost = cost(1);
@@ -272,6 +274,7 @@ struct clr_solver {
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
+  DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix
   DevBuf gradbuf;                       // grad_log_likelihood staging
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   // clr_solver_hint_rhs: the right-hand side the caller is about to pass to dot_solve; the next compute
@@ -313,7 +316,9 @@ struct clr_batch {
   clr::PrefixPlan plan;
   DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
   double cert_resid = 1e-11;          // end-state mismatch of the chunked replay that still counts as consistent
-  double cert_gamma = 1e6;            // conditioning record above which the sequential recurrence settles a problem
+  double cert_gamma = 1e7;            // conditioning record gamma_max / mu_min above which a problem leaves the replay-free route
+  double cert_gamma_abs = 1e4;        // ... and gamma_max alone (decide_kernel; calibration: profiles/r03_conditioning_calibration.txt)
+  double cert_eg = 3e-9;              // ... and gamma_max x the largest measured G error of the chunks
   int summarize_mode = -1;            // -1 auto, 0 single wave, 1 role split (widths 7, 8)
   int replay_source = -1;             // where the replay reads the series when summarize reads the chunk-interleaved
                                       // copy: 0 the same copy, 1 the row-major arrays staged through LDS, -1 auto
@@ -510,7 +515,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs})
+                      &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs, &s->ws_lvl_elems, &s->ws_lvl_starts})
       b->release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
@@ -601,14 +606,26 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
       P.fast_trig = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
     }
-    P.coop_prefix = 1;
-    P.nchunk = auto_chunks(1, N, true);
+    P.nchunk = auto_chunks(1, N, J, true);
     P.L = (N + P.nchunk - 1) / P.nchunk;
+    if (P.nchunk > 1 && P.L > 8) P.L = (P.L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
     P.nchunk = (N + P.L - 1) / P.L;  // drop empty trailing chunks
+    // one problem: the whole chip is idle during the prefix, so the chunk elements are composed level by level
+    // (clr_prefix_kernels.h) instead of walked one by one
+    P.coop_prefix = 2;
+    P.plan = clr::plan_prefix(P.nchunk, -1, 0, 1, J);
+    {
+      size_t le = 0, ls = 0;
+      clr::multilevel_workspace(P.plan, J, &le, &ls);
+      if (le && (st = s->ws_lvl_elems.reserve(le)) != CLR_OK) return st;
+      if (ls && (st = s->ws_lvl_starts.reserve(ls)) != CLR_OK) return st;
+      P.lvl_elems = s->ws_lvl_elems.p;
+      P.lvl_starts = s->ws_lvl_starts.p;
+    }
     if ((st = s->ws_elems.reserve((size_t)P.nchunk * L->elem_doubles)) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve((size_t)P.nchunk * L->start_doubles)) != CLR_OK) return st;
     if ((st = s->ws_part.reserve((size_t)P.nchunk * 2)) != CLR_OK) return st;
-    if ((st = s->ws_cond.reserve((size_t)P.nchunk * 3)) != CLR_OK) return st;
+    if ((st = s->ws_cond.reserve((size_t)P.nchunk * 4)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
     P.jitter = s->scratch2.p;
@@ -626,7 +643,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
-    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    if (P.nchunk < 2) HIP_TRY(hipMemsetAsync(P.need_exact, 0, sizeof(int), stream));  // (no prefix kernel clears it)
     L->summarize(P, stream);
     L->prefix(P, stream);
     L->correct(P, stream);        // flags + conditioning record (its sums are overwritten by the replay)
@@ -675,7 +693,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if ((st = s->ws_elems.reserve(pc * (JP * JP + JP + SZP + JP + SZP))) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve(pc * (SZP + JP))) != CLR_OK) return st;
     if ((st = s->ws_part.reserve(pc * 4)) != CLR_OK) return st;
-    if ((st = s->ws_cond.reserve(pc * 3)) != CLR_OK) return st;
+    if ((st = s->ws_cond.reserve(pc * 4)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, 2 * pc + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
     P.jitter = s->scratch2.p;
@@ -687,7 +705,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p;
     P.part = s->ws_part.p; P.partx = s->ws_part.p + pc * 2;
     P.flags = s->ws_flags; P.flagsx = s->ws_flags + pc; P.need_exact = s->ws_flags + 2 * pc;
-    P.cond = s->ws_cond.p; P.cert_gamma = 1e6; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
     P.force_exact = 1;       // the factor is wanted: every chunk is replayed (and checked against the scan)
     P.wide_materialize = 1;
     P.coop_prefix = 1;
@@ -1212,7 +1230,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
     }
     if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
   } else if (nchunk <= 0) {
-    nchunk = auto_chunks(h->B, h->N);
+    nchunk = auto_chunks(h->B, h->N, h->J);
   }
   if (nchunk > h->N) nchunk = h->N;
   h->L = (h->N + nchunk - 1) / nchunk;
@@ -1225,7 +1243,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
-    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g);
+    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, h->B, h->J);
     size_t le = 0, ls = 0;
     clr::multilevel_workspace(h->plan, h->J, &le, &ls);
     if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
@@ -1237,7 +1255,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
-  if ((st = h->cond.reserve(pc * 3)) != CLR_OK) return st;
+  if ((st = h->cond.reserve(pc * 4)) != CLR_OK) return st;  // gamma, mu, residual per chunk | measured G error
   if ((st = h->out.reserve((size_t)h->B * 3 + ((size_t)h->B + 1) / 2)) != CLR_OK) return st;
   if (h->flags) (void)hipFree(h->flags);
   h->flags = nullptr;
@@ -1245,7 +1263,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   // a single-chunk plan launches no prefix / correct kernel: nothing else would ever clear need_exact or fill
   // the conditioning record
   HIP_TRY(hipMemsetAsync(h->flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
-  HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 3 * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 4 * sizeof(double), h->stream));
   h->evaluated = false;
   return CLR_OK;
 }
@@ -1444,6 +1462,9 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
   P.cond = h->cond.p;
   P.cert_gamma = h->cert_gamma;
+  P.cert_gamma_abs = h->cert_gamma_abs;
+  P.cert_eg = h->cert_eg;
+  P.egerr = h->cond.p + (size_t)h->B * h->nchunk * 3;
   P.cert_resid = h->cert_resid;
   {
     const size_t pc = B * (size_t)h->nchunk;
@@ -1462,7 +1483,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
 // factor's stores) or the row-major arrays through the LDS-staged tiles (round 1's path).
 static clr::BatchParams replay_view(const clr_batch* h, const clr::BatchParams& P, int materialize) {
   clr::BatchParams R = P;
-  const int src = h->replay_source < 0 ? (materialize ? 1 : 0) : h->replay_source;
+  const int src = h->replay_source < 0 ? 0 : h->replay_source;  // (measured: profiles/r03a_prefix_ab.txt)
   if (src == 1 && !P.staged && P.lane_cs == 1 && h->nchunk > 1 && h->layout == 2) {
     R.t = h->t.p; R.diag = h->diag.p; R.y = h->y.p;
     R.t_stride = h->t_stride; R.diag_stride = h->diag_stride; R.y_stride = h->y_stride;
@@ -1583,9 +1604,37 @@ int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, 
   return CLR_OK;
 }
 
+int clr_batch_get_measured_error(clr_batch* h, double* eg_max) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!eg_max) return fail(CLR_INVALID_ARGUMENT, "eg_max is null");
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  const size_t pc = (size_t)h->B * h->nchunk;
+  std::vector<double> c(pc);
+  if (h->nchunk >= 2) {
+    HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p + pc * 3, pc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int b = 0; b < h->B; ++b) {
+    double e = 0.0;
+    for (int k = 0; k < h->nchunk && h->nchunk >= 2; ++k) {
+      const double v = c[(size_t)b * h->nchunk + k];
+      if (!(v <= e)) e = v;
+    }
+    eg_max[b] = e;
+  }
+  return CLR_OK;
+}
+
 int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual) {
   h->cert_gamma = max_gamma_over_mu;
   h->cert_resid = max_residual;
+  return CLR_OK;
+}
+
+int clr_batch_set_certificate_gamma(clr_batch* h, double max_gamma, double max_gamma_times_error) {
+  h->cert_gamma_abs = max_gamma;
+  h->cert_eg = max_gamma_times_error;
   return CLR_OK;
 }
 

@@ -50,6 +50,8 @@ struct BatchParams {
                    //                 zero-start pivots (summarize), certificate pivot mu (correct), and
                    //                 the replay's end state against the scanned start of the next chunk
                    //                 (relative residual; replay_kernel)
+  double* egerr;   // [B][nchunk]     measured accuracy of the chunk's G = (I + P Jm)^-1 P (correct kernels; chunk_update's
+                   //                 eg_out: first-order forward error from the residual, relative), may be null
   int* flags;      // [B][nchunk]     zero-start pivot <= 0 seen / chunk suspicious
   int* need_exact; // [B]             0 settled from the chunk summaries; 1 ill-conditioned: chunked replay
                    //                 with its end states checked against the scanned starts; >= 2
@@ -65,6 +67,8 @@ struct BatchParams {
   int logdet_only;    // no right-hand side (CholeskySolver.compute): the quadratic form is not checked
   double cert_gamma;  // a problem whose conditioning record gamma_max / mu_min reaches this leaves the
                       // replay-free route (decide_kernel); <= 0: never
+  double cert_gamma_abs;  // ... or whose gamma_max alone reaches this (<= 0: no such test)
+  double cert_eg;         // ... or whose gamma_max x (largest measured G error of its chunks) reaches this (<= 0: no test)
   double cert_resid;  // largest relative mismatch between a replayed chunk's end state and the scanned
                       // start state of the next chunk that still counts as consistent
   double *out_ll, *out_logdet, *out_quad;
@@ -466,7 +470,10 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   if (slot >= (long)P.B * P.nchunk) return;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
   if (P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
-  if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
+  if (c == 0) {  // the first chunk starts from the zero state: nothing to correct
+    if (P.egerr) P.egerr[slot] = 0.0;
+    return;
+  }
   double S[SZ], f[J];
   const double* st = P.starts + slot * START;
 #pragma unroll
@@ -475,10 +482,11 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   for (int i = 0; i < J; ++i) f[i] = st[SZ + i];
   double dld = 0.0, dq = 0.0;
   int sus = 0;
-  double mu = 1.0;
+  double mu = 1.0, eg = 0.0;
   chunk_update<J>(P.elems + slot * ELEM, S, f, true, false, P.part[slot * 2 + 0], P.part[slot * 2 + 1],
-                  &dld, &dq, &sus, &mu, !P.logdet_only);
+                  &dld, &dq, &sus, &mu, !P.logdet_only, P.egerr ? &eg : nullptr);
   if (P.cond) P.cond[slot * 3 + 1] = mu;
+  if (P.egerr) P.egerr[slot] = eg;
   P.part[slot * 2 + 0] += dld;
   P.part[slot * 2 + 1] += dq;
   if (sus) {
@@ -556,9 +564,20 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   P.flagsx[(long)b * P.nchunk + c] = flag;
 }
 
-// decide: after correct_kernel, one lane per problem: a problem the certificate did not flag but
-// whose conditioning record gamma_max / mu_min reaches cert_gamma leaves the replay-free route
-// (level 1: chunked replay + end-state check).
+// decide: after correct_kernel, one wave per problem: a problem the certificate did not flag but
+// whose conditioning record says the chunk summaries cannot be trusted to 1e-10 leaves the replay-free
+// route (level 1: chunked replay + end-state check).  Round 3 calibration (profiles/r03_conditioning_
+// calibration.txt: 5400 adversarial problem x chunking combinations, widths 1..8 and 32): the deviation
+// from the oracle follows gamma = max a_n / D_n -- the cancellation in the recurrence ITSELF, which any
+// implementation shares (log-log correlation 0.90; with 1 / mu 0.64, with gamma / mu 0.85) -- so the
+// record is tested as gamma_max < cert_gamma_abs (1e4) AND gamma_max / mu_min < cert_gamma (1e7): more
+// problems settled from the summaries than with round 2's gamma / mu < 1e6, at a smaller worst deviation
+// (2.4e-12 against 5e-11), and BASELINE config 4 (gamma ~ 1.3e3, mu 8e-4 .. 2e-2) no longer sends a sixth
+// of its problems through 7 ms of checked replay.  A third test replaces the pessimistic 1 / mu by a MEASUREMENT:
+// the correct kernels compute the first-order forward error eG of every chunk's G = (I + P Jm)^-1 P from its
+// residual (chunk_update, eg_out) and the problem must have gamma_max x eG_max < cert_eg (3e-9); this also catches
+// the one outlier of the calibration set that both gamma tests let through (a 6-chunk N = 50 problem, 1.9e-9):
+// with all three, 2160 of 3488 settled from the summaries, worst 7.6e-12 (round 2: 2109, worst 1.9e-9).
 template <int J>
 __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
   // one wave per problem: max / min over the chunks' records are order-independent
@@ -567,17 +586,22 @@ __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
   // NaN records stick (and then fail the comparison below: ill-conditioned)
   auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
   auto nmin = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x < a ? x : a)); };
-  double g = 0.0, m = 1.0;
+  double g = 0.0, m = 1.0, e = 0.0;
   for (int c = lane; c < P.nchunk; c += 64) {
     g = nmax(g, P.cond[((long)b * P.nchunk + c) * 3]);
     m = nmin(m, P.cond[((long)b * P.nchunk + c) * 3 + 1]);
+    if (P.egerr) e = nmax(e, P.egerr[(long)b * P.nchunk + c]);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     g = nmax(g, __shfl_xor(g, off, 64));
     m = nmin(m, __shfl_xor(m, off, 64));
+    e = nmax(e, __shfl_xor(e, off, 64));
   }
-  if (lane == 0 && !(g < P.cert_gamma * m)) P.need_exact[b] = 1;  // (NaN records count as ill-conditioned)
+  // (NaN records count as ill-conditioned)
+  if (lane == 0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
+                    (P.cert_eg > 0.0 && P.egerr && !(g * e < P.cert_eg))))
+    P.need_exact[b] = 1;
 }
 
 // ---------------------------------------------------------------------------

@@ -557,7 +557,8 @@ CLR_HD double pd_certificate(const double* P /*[SZ]*/, const double* Jm /*[SZ]*/
 template <int J>
 CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]*/, bool correct,
                          bool advance, double ld0, double q0, double* dld, double* dq,
-                         int* suspicious, double* mu_out = nullptr, bool check_quad = true) {
+                         int* suspicious, double* mu_out = nullptr, bool check_quad = true,
+                         double* eg_out = nullptr) {
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int NC = 2 * J + 1;  // [ M^T | P | h ]
   const double* A = elem;
@@ -619,6 +620,57 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
     }
   }
   // now T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
+
+  if (eg_out) {
+    // REALIZED accuracy of G = (I + P Jm)^-1 P, measured instead of bounded by 1 / mu: residual
+    // R = P - G - P Jm G, first-order forward error dG = (I + P Jm)^-1 R = (I - G Jm) R; returned as
+    // max |dG| / max |G| (the floor of this estimate is the rounding of R itself, ~ J eps)
+    double X[J][J], R[J][J];
+    double gmax = 0.0, emax = 0.0;
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * T[k][J + j];
+        X[i][j] = acc;
+      }
+    }
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        double acc = P[sym(i, j)] - T[i][J + j];
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc -= P[sym(i, k)] * X[k][j];
+        R[i][j] = acc;
+      }
+    }
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * R[k][j];
+        X[i][j] = acc;
+      }
+    }
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        double acc = R[i][j];
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc -= T[i][J + k] * X[k][j];
+        emax = fmax(emax, fabs(acc));
+        gmax = fmax(gmax, fabs(T[i][J + j]));
+        if (acc != acc) emax = INFINITY;
+      }
+    }
+    *eg_out = (gmax > 0.0) ? emax / gmax : (emax == 0.0 ? 0.0 : INFINITY);
+  }
 
   if (correct) {
     int bad = 0;
@@ -841,46 +893,65 @@ CLR_HD void compose_elements(const double* e1, const double* e2, double* out) {
 // ---------------------------------------------------------------------------
 // Schedule of a multi-level prefix over n chunk elements: level 0 = the chunks, level l + 1 =
 // compositions of groups of g[l] consecutive level-l elements; the top level is walked
-// sequentially, then the start states fan out level by level.  Depth in advance-equivalents
-// (a composition costs ~1.2 advances in the cooperative kernel: same Gauss-Jordan, one more
-// product): sum_l 2.2 (g_l - 1) + n_top, against n for the plain walk.  Chosen on the host.
+// sequentially, then the start states fan out level by level (clr_prefix_kernels.h).
+// Chosen on the host from a time model fitted on MI355X (profiles/r03a_prefix_ab.txt):
+//   * one advance of a lone wave: t = 0.49 + 0.04 J^2 us (1.13 us at width 4, 3.04 at width 8);
+//     a composition 1.3 t (same Gauss-Jordan on two DPP rows, one more J^3 / 16 product);
+//   * a phase of W waves runs in max(1, W / (1024 SIMDs x k)) rounds, k = min(3, waves the kernel's
+//     registers allow per SIMD) -- lone waves issue one instruction per ~5 cycles, so up to three
+//     resident waves overlap almost for free; beyond that a phase is throughput-bound, which is why
+//     B = 1024 x 64 chunks at width 8 (composition kernel: 308 registers, one wave per SIMD) stays on
+//     the plain walk while 256 x 125 chunks at width 4 runs 2.6x faster multi-level;
+//   * every level adds two dependent launches (~5 us each).
 // ---------------------------------------------------------------------------
 struct PrefixPlan {
   int levels;     // number of composition levels (0: plain sequential walk)
   int g[3];       // group sizes, bottom up
   int n[4];       // element counts per level: n[0] = nchunk, n[l + 1] = ceil(n[l] / g[l])
-  double depth;   // modelled length of the dependent chain, in chunk advances
+  double time_us; // modelled duration of the prefix phase
 };
-// levels < 0: choose; otherwise build the plan with that many levels of groups of g (clamped so that
-// every level still has at least two groups)
-inline PrefixPlan plan_prefix(int nchunk, int levels = -1, int g = 0) {
-  const double per_level = 4.0;  // two more dependent launches per level, in advance-equivalents
-  const double cmp = 1.2;        // a composition against an advance (same Gauss-Jordan, one more product)
+inline double prefix_plan_time_us(const PrefixPlan& p, int B, int J) {
+  static const int occ_compose[9] = {8, 8, 6, 4, 3, 2, 2, 1, 1}, occ_advance[9] = {8, 8, 7, 5, 4, 3, 2, 2, 2};
+  const int j = J < 1 ? 1 : (J > 8 ? 8 : J);
+  const double t = 0.49 + 0.04 * j * j;
+  auto rounds = [](double waves, int occ) {
+    const double r = waves / (1024.0 * (occ < 3 ? occ : 3));
+    return r > 1.0 ? r : 1.0;
+  };
+  double us = rounds(B / 4.0, occ_advance[j]) * p.n[p.levels] * t;
+  for (int l = 0; l < p.levels; ++l) {
+    const double segs = (double)B * p.n[l + 1];
+    us += rounds(segs / 2.0, occ_compose[j]) * (p.g[l] - 1) * 1.3 * t;
+    us += rounds(segs / 4.0, occ_advance[j]) * (p.g[l] - 1) * t;
+    us += 10.0;
+  }
+  return us;
+}
+// levels < 0: choose (multi-level only when the model promises at least 20 % over the walk); otherwise build
+// the plan with that many levels of groups of g (a level is dropped when it would not leave two groups)
+inline PrefixPlan plan_prefix(int nchunk, int levels = -1, int g = 0, int B = 1, int J = 8) {
   auto build = [&](int lv, int gg) {
     PrefixPlan p;
     p.levels = 0;
     p.n[0] = nchunk;
-    p.depth = 0.0;
     for (int l = 0; l < 3; ++l) {
       const bool use = l < lv && gg >= 2 && p.n[l] >= 2 * gg;
       p.g[l] = use ? gg : 1;
       p.n[l + 1] = (p.n[l] + p.g[l] - 1) / p.g[l];
-      if (use) {
-        p.levels = l + 1;
-        p.depth += per_level + (cmp + 1.0) * (gg - 1);
-      }
+      if (use) p.levels = l + 1;
     }
-    p.depth += p.n[p.levels];
+    p.time_us = prefix_plan_time_us(p, B, J);
     return p;
   };
   if (levels >= 0) return build(levels > 3 ? 3 : levels, g);
-  PrefixPlan best = build(0, 0);
+  const PrefixPlan walk = build(0, 0);
+  PrefixPlan best = walk;
   for (int lv = 1; lv <= 3; ++lv)
     for (int gg = 2; gg <= 64; ++gg) {
       const PrefixPlan p = build(lv, gg);
-      if (p.levels == lv && p.depth < best.depth) best = p;
+      if (p.levels == lv && p.time_us < best.time_us) best = p;
     }
-  return best;
+  return best.time_us < 0.8 * walk.time_us ? best : walk;
 }
 
 // ---------------------------------------------------------------------------

@@ -427,7 +427,10 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   const long slot = blockIdx.x;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
   if (lane == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
-  if (c == 0) return;  // the first chunk starts from the zero state: nothing to correct
+  if (c == 0) {  // the first chunk starts from the zero state: nothing to correct
+    if (lane == 0 && P.egerr) P.egerr[slot] = 0.0;
+    return;
+  }
   const double* st = P.starts + slot * START;
   const double* E = P.elems + slot * ELEM;
   const double* eta = E + J * J + J + SZ;
@@ -490,6 +493,48 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     __syncthreads();
   }
   // T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
+
+  // measured accuracy of G (chunk_update's eg_out at this width): R = P - G - P Jm G, dG = (I - G Jm) R; Sm and PF
+  // are free until the certificate
+  double eg = 0.0;
+  if (P.egerr) {
+    for (int idx = lane; idx < J * J; idx += 64) {  // Sm = Jm G
+      const int i = idx / J, j = idx % J;
+      double acc = 0.0;
+      for (int k = 0; k < J; ++k) acc += Jmm[i * LD + k] * T[k * LT + J + j];
+      Sm[i * LD + j] = acc;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < J * J; idx += 64) {  // PF = R
+      const int i = idx / J, j = idx % J;
+      double acc = Pm[i * LD + j] - T[i * LT + J + j];
+      for (int k = 0; k < J; ++k) acc -= Pm[i * LD + k] * Sm[k * LD + j];
+      PF[i * LD + j] = acc;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < J * J; idx += 64) {  // Sm = Jm R
+      const int i = idx / J, j = idx % J;
+      double acc = 0.0;
+      for (int k = 0; k < J; ++k) acc += Jmm[i * LD + k] * PF[k * LD + j];
+      Sm[i * LD + j] = acc;
+    }
+    __syncthreads();
+    double emax = 0.0, gmax = 0.0;
+    for (int idx = lane; idx < J * J; idx += 64) {  // dG = R - G (Jm R)
+      const int i = idx / J, j = idx % J;
+      double acc = PF[i * LD + j];
+      for (int k = 0; k < J; ++k) acc -= T[i * LT + J + k] * Sm[k * LD + j];
+      emax = (acc != acc) ? INFINITY : fmax(emax, fabs(acc));
+      gmax = fmax(gmax, fabs(T[i * LT + J + j]));
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      emax = fmax(emax, __shfl_xor(emax, m, 64));
+      gmax = fmax(gmax, __shfl_xor(gmax, m, 64));
+    }
+    eg = (gmax > 0.0) ? emax / gmax : (emax == 0.0 ? 0.0 : INFINITY);
+    __syncthreads();
+  }
 
   double ef = 0.0, fJf = 0.0, wGw = 0.0;
   if (lane < J) {
@@ -582,6 +627,7 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     P.part[slot * 2 + 0] = ld0 + ld;
     P.part[slot * 2 + 1] = q0 + q;
     if (P.cond) P.cond[slot * 3 + 1] = mu;
+    if (P.egerr) P.egerr[slot] = eg;
     if (bad) {
       P.flags[slot] |= 2;
       atomicOr(P.need_exact + b, 2);

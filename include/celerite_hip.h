@@ -243,8 +243,9 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
  *      complex terms, else 0. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
 /* Where the replay pass (materialising / forced-exact runs) reads the series when the summarize kernel reads the
- * chunk-interleaved copy: 0 that copy, 1 the row-major arrays through LDS-staged tiles, -1 (default) 1 for
- * materialising runs, else 0 (profiles/r03_materialize_ab.txt). */
+ * chunk-interleaved copy: 0 that copy (default, also -1: 4.41 ms = 65 % of HBM for the materialising replay at
+ * B = 1024, N = 1e5, width 8), 1 the row-major arrays through LDS-staged tiles (4.77 ms = 60 %;
+ * profiles/r03a_prefix_ab.txt). */
 int clr_batch_set_replay_source(clr_batch* h, int source);
 /* Which one the next evaluation will run (0, 1 or 2 as above), given the series and coefficients set. */
 int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind);
@@ -300,15 +301,23 @@ int clr_batch_get_exact_flags(clr_batch* h, int* level /* [B] */);
  * relative mismatch between a replayed chunk's end state and the scanned start state of the
  * next chunk.  Any pointer may be NULL. */
 int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max);
+/* ... the largest measured relative error eG of the chunks' G = (I + P Jm)^-1 P, per problem ... */
+int clr_batch_get_measured_error(clr_batch* h, double* eg_max);
 /* ... and max over chunks of gamma_c / mu_c taken chunk by chunk (diagnostic). */
 int clr_batch_get_conditioning_chunkwise(clr_batch* h, double* ratio_max);
 /* Routing of ill-conditioned problems.  A problem whose gamma_max / mu_min reaches
- * max_gamma_over_mu (default 1e6; <= 0: never) is not settled from the chunk summaries: the
+ * max_gamma_over_mu (default 1e7; <= 0: never), or whose gamma_max alone reaches the bound of
+ * clr_batch_set_certificate_gamma (default 1e4), is not settled from the chunk summaries: the
  * chunked replay (the reference recurrence from the scanned start states, parallel over chunks)
  * runs for it and its end states are compared with the scanned start states; a mismatch above
  * max_residual (default 1e-11, relative) sends it to the truly sequential recurrence (one lane
- * walks the whole series; slow, exact).  Calibration: profiles/r02n_adv_probe.txt. */
+ * walks the whole series; slow, exact).  Calibration: profiles/r02n_adv_probe.txt, r03_conditioning_calibration.txt. */
 int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual);
+/* The bound on gamma_max alone (default 1e4; <= 0: no such test) -- gamma = a_n / D_n is the cancellation in the
+ * recurrence itself: it is what the deviation from the reference follows (profiles/r03_conditioning_calibration.txt)
+ * -- and on gamma_max x eG_max (default 3e-9; <= 0: no test), eG = the MEASURED relative accuracy of a chunk's
+ * G = (I + P Jm)^-1 P (first-order forward error from the residual, computed by the correct kernels). */
+int clr_batch_set_certificate_gamma(clr_batch* h, double max_gamma, double max_gamma_times_error);
 /* Number of chunks the N axis is cut into for the scan (0 = auto). */
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);

@@ -17,6 +17,16 @@ using namespace clr;
 // prefix schedule of the next hostcheck_batch calls: 0 levels = the plain walk over the chunks;
 // otherwise the multi-level prefix (compose groups bottom-up, walk the top, fan out), group size g
 static int g_prefix_levels = 0, g_prefix_g = 0;
+// diagnostics of the last hostcheck_batch call, per problem: gamma_max, mu_min, realized G error (max over chunks),
+// and never_replay: report the chunk-summary (route 0) values even for flagged problems
+static std::vector<double> g_diag;
+static int g_never_replay = 0;
+extern "C" void hostcheck_set_never_replay(int on) { g_never_replay = on; }
+extern "C" int hostcheck_get_diag(int B, double* out /* [B][3] */) {
+  if ((int)g_diag.size() < 3 * B) return -1;
+  memcpy(out, g_diag.data(), sizeof(double) * 3 * B);
+  return 0;
+}
 extern "C" void hostcheck_set_prefix(int levels, int g) { g_prefix_levels = levels; g_prefix_g = g; }
 
 // start states of all `n` elements of one level from the level's elements (ELEM doubles each):
@@ -75,6 +85,7 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
   std::vector<double> elems((size_t)nchunk * Wd::ELEM), starts((size_t)nchunk * Wd::START);
   // optional chunk-interleaved copies [i][chunk] (what relayout_kernel writes on the GPU)
   std::vector<double> tT((size_t)L * nchunk), dT((size_t)L * nchunk), yT((size_t)L * nchunk);
+  g_diag.assign((size_t)3 * B, 0.0);
   for (int b = 0; b < B; ++b) {
     Problem<JR, JC> p;
     p.load(a_real + (long)b * JR, c_real + (long)b * JR, a_comp + (long)b * JC,
@@ -103,9 +114,12 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       if ((long)c * L >= N) break;
       nreal = c + 1;
       DirectSeries src = lane(c);
+      double gam = 0.0;
       summarize_chunk<JR, JC, FAST>(p, src, L, c * L, N, true, &elems[(size_t)c * Wd::ELEM], &ld0[c],
-                                    &q0[c], &fl0[c]);
+                                    &q0[c], &fl0[c], &gam);
+      if (!(gam <= g_diag[3 * b])) g_diag[3 * b] = gam;
     }
+    g_diag[3 * b + 1] = 1.0;
     // prefix: corrections with the incoming state, then advance
     double S[Wd::SZ] = {0}, f[J] = {0};
     double ld = 0, qd = 0;
@@ -123,8 +137,11 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
         memcpy(f, &mstarts[(size_t)c * Wd::START + Wd::SZ], sizeof(f));
       }
       // chunk 0 starts from the zero state: no correction (E = I)
+      double mu = 1.0, eg = 0.0;
       chunk_update<J>(&elems[(size_t)c * Wd::ELEM], S, f, c > 0, c + 1 < nreal, ld0[c], q0[c], &dld,
-                      &dq, &sus);
+                      &dq, &sus, &mu, true, c > 0 ? &eg : nullptr);
+      if (c > 0 && !(mu >= g_diag[3 * b + 1])) g_diag[3 * b + 1] = mu;
+      if (!(eg <= g_diag[3 * b + 2])) g_diag[3 * b + 2] = eg;
       ld += ld0[c] + dld;
       qd += q0[c] + dq;
       need_exact |= sus | fl0[c];
@@ -139,6 +156,8 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
       }
     }
     int bad = 0;
+    const int flagged = need_exact;
+    if (g_never_replay) need_exact = 0;
     if (exact || need_exact || materialize) {  // the exact replay (reference semantics)
       ld = 0;
       qd = 0;
@@ -160,7 +179,7 @@ static int run(int B, int N, int nchunk, const double* jitter, const double* a_r
         bad |= fl;
       }
     }
-    used_exact[b] = (exact || need_exact || materialize) ? 1 : 0;
+    used_exact[b] = g_never_replay ? flagged : ((exact || need_exact || materialize) ? 1 : 0);
     status[b] = bad ? 2 : 0;
     logdet[b] = bad ? NAN : ld;
     quad[b] = bad ? NAN : qd;
@@ -190,6 +209,9 @@ extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const d
                                int* used_exact) {
   CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(0, 2) CASE(2, 2)
   CASE(2, 3) CASE(0, 4) CASE(4, 2) CASE(8, 0)
+#ifdef HOSTCHECK_WIDE
+  CASE(0, 16)
+#endif
   return -1;
 }
 

@@ -149,8 +149,9 @@ def test_multilevel_prefix_against_the_walk(JR, JC):
     chunks (prefix mode 1), on every width shape and both input families:
       * the cooperative composition kernel equals the single-lane host-checked compose_elements on
         the device (block-relative 1e-11);
-      * chunk start states, log det and the quadratic form agree with the walk to 1e-12 (relative to
-        the problem's largest entry for the states), statuses are identical;
+      * log det and the quadratic form agree with the walk to 1e-12, the chunk start states to 1e-11
+        relative to the problem's largest entry (near-degenerate real-only kernels reach 1.1e-12 there),
+        statuses are identical;
       * both meet the oracle at 1e-10."""
     for family, seed in (("bench", 5), ("accuracy", 6)):
         B, N = 6, 6000
@@ -176,7 +177,7 @@ def test_multilevel_prefix_against_the_walk(JR, JC):
                 key = (family, nchunk, levels, group)
                 assert np.array_equal(st2, s0), key
                 scale = np.max(np.abs(starts1[:, 1:]), axis=(1, 2), keepdims=True)
-                assert np.max(np.abs(starts2[:, 1:] - starts1[:, 1:]) / scale) <= 1e-12, key
+                assert np.max(np.abs(starts2[:, 1:] - starts1[:, 1:]) / scale) <= 1e-11, key
                 assert np.max(np.abs(ld2 - ld1) / np.abs(ld1)) <= 1e-12, key
                 assert np.max(np.abs(q2 - q1) / np.abs(q1)) <= 1e-12, key
                 assert np.max(np.abs(ld2 - d0) / np.abs(d0)) <= REL, key
@@ -288,7 +289,8 @@ def test_adversarial_problems_keep_the_reference_status():
     bar; the others are handed to the reference recurrence itself -- chunked replay with its end
     states checked against the scan (level 1) or one lane walking the whole series (level 2) --
     where the remaining deviation from the CPU oracle is the problem's own conditioning times the
-    libm / FMA rounding differences (gamma up to 1e10 here: only a loose bound is asserted)."""
+    libm / FMA rounding differences: asserted against a bound that scales with the recorded gamma
+    (10 gamma^2 eps, at least 1e-9, at most 1e-3; gamma reaches 1e10 here)."""
     shapes = [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 2), (2, 3), (0, 4), (4, 2), (8, 0), (3, 0)]
     n_bad = n_total = 0
     n_level = [0, 0, 0]
@@ -307,6 +309,7 @@ def test_adversarial_problems_keep_the_reference_status():
             ll, ld, q, st = plan.log_likelihood()
             assert np.array_equal(st, s0), (trial, nchunk)
             levels = plan.exact_levels()
+            gamma, mu = plan.conditioning()
             n_total += 4
             for p in range(4):
                 if s0[p] != 0 or not (np.isfinite(d0[p]) and np.isfinite(q0[p])):
@@ -317,7 +320,11 @@ def test_adversarial_problems_keep_the_reference_status():
                 if levels[p] == 0:
                     assert dev <= REL, (trial, nchunk, p, dev)
                 else:
-                    assert dev < 1e-3, (trial, nchunk, p, dev)
+                    # the reference recurrence itself, whose distance from the CPU oracle follows the recorded
+                    # cancellation gamma = max a_n / D_n: within 10 gamma^2 eps over the calibration set
+                    # (profiles/r03_conditioning_calibration.txt: dev / (gamma^2 eps) <= 1.3 above gamma = 1e3)
+                    bound = min(1e-3, max(1e-9, 2.2e-15 * gamma[p] ** 2))
+                    assert dev < bound, (trial, nchunk, p, dev, gamma[p], levels[p])
         plan.close()
     assert n_bad >= 6 and n_level[0] > 20 and n_level[1] + n_level[2] > 20, (n_bad, n_level)
 
@@ -672,7 +679,10 @@ def test_config5_full_shape():
     """BASELINE config 5 at full size: batch 256, N = 1e5, width 32 (16 complex terms, log d ~ U(0, 3));
     the oracle on a sample of 4 problems (71 ms each), properties over all 256."""
     levels = _full_shape(256, 100000, 0, 16, sample=4, d_spread=True, seed=11)
-    assert (levels <= 1).all()   # a few borderline problems take the checked chunked replay; none the sequential sweep
+    # round 3: the conditioning record is tested as gamma < 1e4, gamma / mu < 1e7 and gamma x (measured error of G)
+    # < 3e-9 (profiles/r03_conditioning_calibration.txt); this family sits at gamma ~ 1.3e3, mu 8e-4 .. 2e-2, measured
+    # error ~ 3e-13: every problem is settled from the chunk summaries (round 2 sent 45 of 256 through the replay)
+    assert (levels == 0).all(), np.bincount(levels)
 
 
 def test_fp32_state_tolerance_at_width_32():

@@ -20,7 +20,9 @@ for trial in range(trials):
     plan.set_series(case["t"], case["diag"], case["y"])
     plan.set_coefficients(*coeffs_of(case))
     if os.environ.get("CERT") is not None:
-        plan.set_certificate(float(os.environ["CERT"]), float(os.environ.get("RESID", "1e-12")))
+        cert = float(os.environ["CERT"])   # CERT=0: routing by the conditioning record switched off
+        plan.set_certificate(cert, float(os.environ.get("RESID", "1e-12")), max_gamma=float(os.environ.get("GAMMA", "0" if cert == 0 else "1e4")),
+                             max_gamma_error=float(os.environ.get("GAMMAEG", "0" if cert == 0 else "3e-9")))
     for nchunk in (max(2, N // 40), max(2, N // 8)):
         plan.set_chunks(nchunk)
         ll, ld, q, st = plan.log_likelihood()
@@ -64,6 +66,11 @@ for r in worst:
     print(json.dumps(r))
 
 # how the replay-free deviations relate to the conditioning record
+gg = np.array([r["gamma"] for r in free]); ee = np.array([max(r["eld"], r["eq"]) for r in free])
+for lo, hi in [(0, 1e2), (1e2, 1e3), (1e3, 1e4), (1e4, 1e5), (1e5, 1e6), (1e6, 1e300)]:
+    m = (gg >= lo) & (gg < hi)
+    if m.any():
+        print("gamma in [%.0e, %.0e): n=%4d  worst deviation %.2e  median %.2e" % (lo, hi, m.sum(), ee[m].max(), np.median(ee[m])))
 g = np.array([r["gamma"] / max(r["mu"], 1e-300) for r in free])
 e = np.array([max(r["eld"], r["eq"]) for r in free])
 for lo, hi in [(0, 1e3), (1e3, 1e4), (1e4, 1e5), (1e5, 1e6), (1e6, 1e8), (1e8, 1e300)]:
@@ -77,7 +84,7 @@ for fam in ("bench", "accuracy"):
             case = synthetic(8, N, JR, JC, fam, seed=3)
             plan = batch.BatchedGP(8, N, JR, JC); plan.set_chunks(nchunk)
             plan.set_series(case["t"], case["diag"], case["y"]); plan.set_coefficients(*coeffs_of(case))
-            plan.set_certificate(0.0, 1e-12)
+            plan.set_certificate(0.0, 1e-12, max_gamma=0.0, max_gamma_error=0.0)
             ll, ld, q, st = plan.log_likelihood(); gam, mu = plan.conditioning(); plan.close()
             S = 2 if N > 50000 else 8
             l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[:S] for c in coeffs_of(case)], case["t"][:S], case["diag"][:S], case["y"][:S])
