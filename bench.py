@@ -105,6 +105,22 @@ def make_inputs(B, N, J_real, J_comp, seed, d_spread=False):
     return (a_real, c_real, a_comp, b_comp, c_comp, d_comp), t, sig ** 2, y
 
 
+def make_inputs_accuracy(B, N, J_real, J_comp, seed):
+    """The paper's accuracy family (paper/figures/error/error.py:24-25): t = sort(U(0, 0.8 N)) -- mean spacing 0.8 --
+    sigma = U(1, 1.5), y = N(0, 1); coefficients as make_inputs."""
+    rng = np.random.RandomState(seed)
+    t = np.sort(rng.uniform(0, 0.8 * N, (B, N)), axis=1)
+    sig = rng.uniform(1.0, 1.5, (B, N))
+    y = rng.randn(B, N)
+    a_real = np.exp(1.0 + 0.1 * rng.randn(B, J_real))
+    c_real = np.exp(0.1 + 0.1 * rng.randn(B, J_real))
+    a_comp = np.exp(0.1 + 0.1 * rng.randn(B, J_comp))
+    b_comp = np.zeros((B, J_comp))
+    c_comp = np.exp(2.0 + 0.1 * rng.randn(B, J_comp))
+    d_comp = np.exp(1.6 + 0.1 * rng.randn(B, J_comp))
+    return (a_real, c_real, a_comp, b_comp, c_comp, d_comp), t, sig ** 2, y
+
+
 def fresh_draws(coeffs, count, seed):
     """`count` hyper-parameter proposals around `coeffs` (1 % log-normal steps, b_comp kept):
     what an MCMC sampler hands over per iteration."""
@@ -263,6 +279,106 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
     }
 
 
+def accuracy_family_block(B, N, JR, JC, steps, sample, seed):
+    """SURVEY.md 8(d)'s second input family at the headline shape: sparse sampling, the state is forgotten within tens
+    of samples, so the plan runs the warm-started plain recurrence (csrc/clr_batch_kernels.h: warm_kernel) instead of
+    the scan.  Real loop, device-only rate, the scan path on the same inputs for comparison, parity on a sample."""
+    from celerite_amd import batch
+    from oracle import ref
+
+    W = JR + 2 * JC
+    coeffs, t, diag, y = make_inputs_accuracy(B, N, JR, JC, seed)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        draws = [coeffs] + fresh_draws(coeffs, 3, seed + 1)
+        real_loop(plan, draws, 3)
+        plan.set_profiling(True)
+        batch.device_synchronize()
+        t0 = time.perf_counter()
+        real_loop(plan, draws, steps, offset=1)
+        dt = time.perf_counter() - t0
+        kms, nrec = plan.profile()
+        plan.set_profiling(False)
+        per = {k: v / max(nrec, 1) for k, v in kms.items()}
+        plan.set_coefficients(*coeffs)
+        ll, ld, q, st = plan.log_likelihood()
+        warm = plan.warm_start()
+        dev_ms, dev_k = plan.run_timed(steps, relayout_each_step=False)
+        # the scan path on the same inputs (warm start switched off)
+        plan.set_warm_start(0)
+        plan.set_coefficients(*coeffs)
+        ll_s, ld_s, q_s, st_s = plan.log_likelihood()
+        scan_kernel = plan.summarize_kernel()
+        scan_ms, scan_k = plan.run_timed(max(steps // 2, 1), relayout_each_step=False)
+    finally:
+        plan.close()
+    S = min(sample, B)
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[:S] for c in coeffs], t[:S], diag[:S], y[:S], nthreads=1)
+    ok = s0 == 0
+    roof = roofline_block({"warm recurrence + boundary check": per["summarize"]}, B, N, W)
+    return {
+        "workload": "accuracy family (paper/figures/error/error.py:24-25): batch=%d x N=%d, width %d (%d real + %d "
+                    "complex), t = sort(U(0, 0.8 N)), sigma = U(1, 1.5), y = N(0, 1)" % (B, N, W, JR, JC),
+        "path": "warm-started plain recurrence per chunk + boundary check" if warm["active"] else "scan",
+        "warm_start": warm, "steps": steps,
+        "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
+        "device_only": {"ms_per_step": dev_ms / steps, "value": B / (dev_ms / steps * 1e-3),
+                        "kernels_ms": {k: v / steps for k, v in dev_k.items()}},
+        "kernels_ms": per,
+        "kernels_note": "slot `summarize` = warm_kernel + warm_check_kernel (no relayout, prefix, correct or replay "
+                        "kernel runs on this path)",
+        "roofline": roof,
+        "scan_path_same_inputs": {"summarize_kernel": scan_kernel, "ms_per_step": scan_ms / max(steps // 2, 1),
+                                  "kernels_ms": {k: v / max(steps // 2, 1) for k, v in scan_k.items()},
+                                  "vs_warm_logdet_rel": rel_err(ld[st == 0], ld_s[st == 0]),
+                                  "vs_warm_quad_rel": rel_err(q[st == 0], q_s[st == 0])},
+        "parity": {"problems_checked": int(S), "status_equal": bool(np.array_equal(st[:S], s0)),
+                   "logdet_rel_max": rel_err(ld[:S][ok], d0[ok]), "quad_rel_max": rel_err(q[:S][ok], q0[ok]),
+                   "tolerance": 1e-10},
+        "status_not_ok": int((st != 0).sum()),
+    }
+
+
+def sharded_block(B, N, JR, JC, nshards, steps, seed):
+    """The PRODUCT's multi-GPU path (clr_sharded_* / batch.ShardedBatchedGP: one process, one host thread + plan per
+    shard, no collective): `nshards` shards over the visible GPUs (round robin; shards share a GPU when there are
+    fewer GPUs than shards).  Real loop (evaluate = coefficients in, B results out on every shard concurrently)."""
+    from celerite_amd import batch
+
+    ndev = batch.device_count()
+    devices = [s % ndev for s in range(nshards)]
+    coeffs, t, diag, y = make_inputs(B, N, JR, JC, seed)
+    draws = [coeffs] + fresh_draws(coeffs, 3, seed + 1)
+    plan = batch.ShardedBatchedGP(B, N, JR, JC, devices=devices)
+    try:
+        t0 = time.perf_counter()
+        plan.set_series(t, diag, y)
+        set_series_s = time.perf_counter() - t0
+        for k in range(3):
+            out = plan.evaluate(*draws[k % len(draws)])
+        t0 = time.perf_counter()
+        for k in range(steps):
+            out = plan.evaluate(*draws[(k + 1) % len(draws)])
+        dt = time.perf_counter() - t0
+        shard_ms = plan.run_timed(steps)
+        kernel = plan.summarize_kernel()
+        shards = plan.shards
+    finally:
+        plan.close()
+    return {
+        "what": "batch.ShardedBatchedGP / clr_sharded_*: %d shards on %d visible GPU(s), devices %s" % (nshards, ndev, devices),
+        "batch": B, "shards": [{"device": d, "problems": hi - lo} for d, lo, hi in shards],
+        "summarize_kernel_all_shards": kernel,
+        "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
+        "device_only_ms_per_step_per_shard": [float(m) / steps for m in shard_ms],
+        "set_series_seconds": set_series_s,
+        "set_series_note": "host scan of t (max |t|, largest step, warm-up spans) + pageable host->HBM copies of "
+                           "t, diag, y on every shard's own thread, concurrently",
+        "status_not_ok": int((out[3] != 0).sum()),
+    }
+
+
 def object_api_config():
     """BASELINE configs[0]: one series, N = 1000, 1 real + 1 SHO term (width 3) through the
     drop-in object API (GP.compute + GP.log_likelihood), oracle timed the same way."""
@@ -331,6 +447,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 0/1/4 block")
     ap.add_argument("--no-shared-series", action="store_true", help="skip the layout-(ii) leg (profiling runs: keeps the per-kernel counter averages to the distinct-series launches)")
+    ap.add_argument("--no-accuracy-family", action="store_true", help="skip the accuracy-family leg")
+    ap.add_argument("--sharded", type=int, default=2, help="shards of the product's own sharded plan (0: skip the leg)")
     ap.add_argument("--steady-seconds", type=float, default=2.5)
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="untimed extra warm-up before the K timed steps")
     args = ap.parse_args(argv)
@@ -464,6 +582,8 @@ def main(argv=None):
                                       "value": B / (new_ms / max(K // 2, 1) * 1e-3) * dist.world,
                                       "relayout_ms": new_k["relayout"] / max(K // 2, 1)},
             "steady_state": {"seconds": steady_dt, "steps": n_steady, "value": B * n_steady / steady_dt * dist.world},
+            "value_steady": B * n_steady / steady_dt * dist.world,
+            "timed_region_s": dt,
             "status_not_ok": int((st != 0).sum()),
             "roofline": roofline_block(per, B, N, W, pmc_traffic(max(per, key=per.get), B, N, JR, JC, plan.chunks[0])),
             "ab": {
@@ -520,6 +640,16 @@ def main(argv=None):
         if dist.world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, st, B, N))
     plan.close()
+    if dist.rank == 0 and dist.world == 1 and not args.no_accuracy_family:
+        try:
+            out["accuracy_family"] = accuracy_family_block(B, N, JR, JC, max(K // 2, 5), 8, 4242)
+        except Exception as e:  # a failing side leg must not lose the headline line
+            out["accuracy_family"] = {"error": repr(e)}
+    if dist.rank == 0 and dist.world == 1 and args.sharded > 0:
+        try:
+            out["sharded_product_path"] = sharded_block(B, N, JR, JC, args.sharded, max(K // 2, 5), 42)
+        except Exception as e:
+            out["sharded_product_path"] = {"error": repr(e)}
     if dist.rank == 0 and dist.world == 1 and not args.no_configs:
         cfg = {}
         for key, fn in [("config0_object_api", object_api_config),

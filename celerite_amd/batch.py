@@ -61,6 +61,8 @@ def _load():
     lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_replay_source.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_warm_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.clr_batch_get_warm_start.argtypes = [C.c_void_p] + [_ip] * 7
     lib.clr_batch_set_prefix_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.clr_batch_get_prefix_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
     lib.clr_batch_debug_get_starts.argtypes = [C.c_void_p, _dp]
@@ -303,6 +305,19 @@ class BatchedGP(object):
         v = [C.c_double() for _ in range(5)]
         _check(_load().clr_batch_get_selection_bounds(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("tmax", "dxmax", "dmax", "cmax", "set_series_host_ms"), [x.value for x in v]))
+
+    def set_warm_start(self, mode=-1, forced_warmup=0):
+        """Warm-started plain recurrence for series that forget their past (``clr_batch_set_warm_start``):
+        -1 auto, 0 off, 1 forced with ``forced_warmup`` steps.  Takes effect at the next
+        :meth:`set_coefficients`."""
+        _check(_load().clr_batch_set_warm_start(self._h, int(mode), int(forced_warmup)))
+
+    def warm_start(self):
+        """``dict(active, chunks, chunk_len, warmup_min, warmup_max, settled, fallbacks)``."""
+        v = [C.c_int() for _ in range(7)]
+        _check(_load().clr_batch_get_warm_start(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("active", "chunks", "chunk_len", "warmup_min", "warmup_max", "settled", "fallbacks"),
+                        [x.value for x in v]))
 
     def set_replay_source(self, source=-1):
         """Series view of the replay pass behind the role-split summarize: 0 the chunk-interleaved copy,

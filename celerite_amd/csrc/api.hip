@@ -49,6 +49,7 @@ const BatchLaunchers* find_batch_launchers(int JR, int JC) {
 // chunks took 40 us at 125 chunks: a fifth of BASELINE config 1's step.)
 __global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (P.only_pending && P.need_scan[b] == 0) return;  // (settled and written by the warm path)
   // replay-free sums unless the problem was marked for (or the run forces) the exact replay
   const bool exact = P.force_exact || P.need_exact[b] != 0;
   const double* part = exact ? P.partx : P.part;
@@ -320,6 +321,24 @@ struct clr_batch {
   double cert_gamma_abs = 1e4;        // ... and gamma_max alone (decide_kernel; calibration: profiles/r03_conditioning_calibration.txt)
   double cert_eg = 3e-9;              // ... and gamma_max x the largest measured G error of the chunks
   int summarize_mode = -1;            // -1 auto, 0 single wave, 1 role split (widths 7, 8)
+  // warm-started plain recurrence for series that forget their past (clr_batch_kernels.h: warm_kernel)
+  int warm_mode = -1;                 // -1 auto (per problem, from the decay over the samples before the chunk boundaries),
+                                      // 0 off, 1 every problem with warm_forced_K warm-up steps (tests: the boundary check decides)
+  int warm_forced_K = 0;
+  int warm_explicit_chunks = 0;       // chunk count asked for through clr_batch_set_chunks (0: automatic)
+  int wnchunk = 0, wL = 0;            // the warm path's own chunking
+  static const int WARM_NK = 6;
+  int warm_cand[WARM_NK] = {8, 16, 32, 64, 128, 256};
+  std::vector<double> warm_span;      // [B or 1][WARM_NK] shortest time the K samples before a chunk boundary span
+  std::vector<int> warm_K;            // [B] warm-up steps per problem of the current coefficients (0: scan)
+  bool warm_active = false;           // the current (series, coefficients) pair runs the warm path
+  bool warm_inflight = false;         // results of a warm evaluation have not been looked at yet
+  bool in_fallback = false;           // building the parameters of the scan behind the warm path
+  int warm_boost = 0;                 // candidates skipped after an evaluation with many fallbacks
+  int warm_settled = 0, warm_fallbacks = 0;  // of the last evaluation
+  DevBuf wstarts, wends, wpart, wresid;
+  int* wints = nullptr;               // wflags [B * wnchunk] | need_scan [B] | K [B]
+  size_t wints_cap = 0;
   int replay_source = -1;             // where the replay reads the series when summarize reads the chunk-interleaved
                                       // copy: 0 the same copy, 1 the row-major arrays staged through LDS, -1 auto
   bool relayout_pending = true;
@@ -1202,18 +1221,24 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
-                    &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts})
+                    &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
+                    &h->wpart, &h->wresid})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
+  if (h->wints) (void)hipFree(h->wints);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
+static int warm_plan_chunks(clr_batch* h);
+static void warm_scan_spans(clr_batch* h, const double* t, long t_stride);
+
 int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  h->warm_explicit_chunks = nchunk > 0 ? nchunk : 0;
   if (!h->launch) {
     // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
     // unless the batch alone leaves the chip underused: then ~2 waves per SIMD worth of
@@ -1265,7 +1290,65 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   HIP_TRY(hipMemsetAsync(h->flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
   HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 4 * sizeof(double), h->stream));
   h->evaluated = false;
+  if ((st = warm_plan_chunks(h)) != CLR_OK) return st;
   return CLR_OK;
+}
+
+// The warm path's chunking: two waves per SIMD worth of (problem, chunk) lanes (the plain recurrence needs 189
+// registers), chunks of at least 256 samples (the warm-up is at most half a chunk); an explicit chunk count is
+// honoured (results then do not depend on the batch size, i.e. on a sharding).
+static int warm_plan_chunks(clr_batch* h) {
+  h->wnchunk = 0;
+  h->wL = 0;
+  h->warm_active = false;
+  h->warm_span.clear();  // (the spans belong to a chunking: rescanned by the next set_series)
+  if (!h->launch || h->N < 512) return CLR_OK;
+  long want = h->warm_explicit_chunks ? h->warm_explicit_chunks : std::max<long>(1, 131072 / h->B);
+  long L = (h->N + want - 1) / want;
+  if (L < 256) L = 256;
+  L = (L + 7) & ~7L;
+  const long nc = (h->N + L - 1) / L;
+  if (nc < 2) return CLR_OK;
+  h->wL = (int)L;
+  h->wnchunk = (int)nc;
+  const size_t pc = (size_t)h->B * nc, START = (size_t)h->launch->start_doubles;
+  int st;
+  if ((st = h->wstarts.reserve(pc * START)) != CLR_OK) return st;
+  if ((st = h->wends.reserve(pc * START)) != CLR_OK) return st;
+  if ((st = h->wpart.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->wresid.reserve((size_t)h->B)) != CLR_OK) return st;
+  const size_t ints = pc + 2 * (size_t)h->B;
+  if (ints > h->wints_cap) {
+    if (h->wints) (void)hipFree(h->wints);
+    h->wints = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->wints), ints * sizeof(int)));
+    h->wints_cap = ints;
+  }
+  HIP_TRY(hipMemsetAsync(h->wints, 0, ints * sizeof(int), h->stream));
+  return CLR_OK;
+}
+
+// For every problem (or the one shared series) and every candidate K: the shortest time the K samples in front of
+// a chunk boundary of the warm path span.  O(B x chunks) lookups into the host arrays set_series was given.
+static void warm_scan_spans(clr_batch* h, const double* t, long t_stride) {
+  h->warm_span.clear();
+  if (h->wnchunk < 2) return;
+  const long nb = t_stride == 0 ? 1 : h->B;
+  h->warm_span.assign((size_t)nb * clr_batch::WARM_NK, 0.0);
+  for (long b = 0; b < nb; ++b) {
+    const double* tb = t + b * t_stride;
+    for (int k = 0; k < clr_batch::WARM_NK; ++k) {
+      const long K = h->warm_cand[k];
+      double span = INFINITY;
+      if (K > h->wL / 2) span = 0.0;  // (not a usable candidate at this chunk length)
+      for (long c = 1; c < h->wnchunk && span > 0.0; ++c) {
+        const long n = c * (long)h->wL;
+        const double d = tb[n] - tb[n - K];
+        if (!(d >= span)) span = d;  // (NaN sticks: never eligible)
+      }
+      h->warm_span[(size_t)b * clr_batch::WARM_NK + k] = span;
+    }
+  }
 }
 
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len) {
@@ -1299,6 +1382,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
     if (!(tm <= h->tmax)) h->tmax = tm;
     if (!(dm <= h->dxmax)) h->dxmax = dm;
   }
+  warm_scan_spans(h, t, t_stride);
   if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
   if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
@@ -1361,9 +1445,40 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
     const double c = fabs(c_real[i]);
     if (!(c <= h->cmax)) h->cmax = c;
   }
+  // warm-started recurrence: warm-up steps per problem from its slowest decay rate and the time the samples in front
+  // of its chunk boundaries span: exp(-c_min x span) <= exp(-37) = 8.5e-17 -- what is left of ANY start state after
+  // the warm-up is below the rounding of the state (the update by the data only forgets faster); the boundary check
+  // of warm_check_kernel certifies the choice
+  h->warm_active = false;
+  if (h->warm_mode != 0 && h->wnchunk >= 2 && h->have_series && !h->warm_span.empty()) {
+    h->warm_K.assign(B, 0);
+    size_t eligible = 0;
+    const bool shared = h->t_stride == 0;
+    for (size_t b = 0; b < B; ++b) {
+      int K = 0;
+      if (h->warm_mode == 1) {
+        K = std::min(h->warm_forced_K, h->wL / 2);
+      } else {
+        double cmin = INFINITY;
+        for (int j = 0; j < h->J_real; ++j) { const double c = c_real[b * h->J_real + j]; if (!(c >= cmin)) cmin = c; }
+        for (int j = 0; j < h->J_comp; ++j) { const double c = c_comp[b * h->J_comp + j]; if (!(c >= cmin)) cmin = c; }
+        const double* span = &h->warm_span[(shared ? 0 : b) * clr_batch::WARM_NK];
+        for (int k = 0; k < clr_batch::WARM_NK && cmin > 0.0; ++k)
+          if (cmin * span[k] >= 37.0) {
+            K = h->warm_cand[std::min(k + h->warm_boost, clr_batch::WARM_NK - 1)];
+            if (K > h->wL / 2) K = 0;
+            break;
+          }
+      }
+      h->warm_K[b] = K;
+      eligible += K > 0;
+    }
+    // (a batch with only a few eligible problems is not worth a second set of launches)
+    h->warm_active = eligible * 2 >= B;
+  }
   // one pinned staging buffer, one copy: a_real c_real a_comp b_comp c_comp d_comp | jitter
   const size_t total = 2 * nr + 4 * nc + B;
-  if ((st = reserve_pinned(h, std::max(total, 3 * B + (B + 1) / 2))) != CLR_OK) return st;
+  if ((st = reserve_pinned(h, std::max(total, 3 * B + (B + 1) / 2) + (B + 1) / 2)) != CLR_OK) return st;
   HIP_TRY(hipStreamSynchronize(h->stream));  // (a previous upload may still read the staging buffer)
   double* w = h->pin;
   auto put = [&](const double* p, size_t n) { if (n) memcpy(w, p, n * sizeof(double)); w += n; };
@@ -1372,6 +1487,11 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   else { memset(w, 0, B * sizeof(double)); w += B; }  // NULL: no jitter
   if ((st = h->coeffs.reserve(total)) != CLR_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->coeffs.p, h->pin, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->warm_active) {  // K per problem, behind the coefficients in the staging buffer
+    int* kk = reinterpret_cast<int*>(h->pin + std::max(total, 3 * B + (B + 1) / 2));
+    memcpy(kk, h->warm_K.data(), B * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(h->wints + (size_t)h->B * h->wnchunk + B, kk, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
   h->have_coeffs = true;
   return CLR_OK;
 }
@@ -1398,6 +1518,7 @@ static bool split_active(const clr_batch* h) {
   //    width 8 with at least two complex terms (3.1-3.2 against 3.8-4.2; profiles/r02zzz_sparse_ab.txt).  With
   //    fewer complex terms at width 8 its trajectory wave spills ((8,0), (6,1): 4.1-4.2 against 3.7): single wave.
   if (!(h->launch && h->nchunk > 1 && clr::have_summarize_split(h->J_real, h->J_comp))) return false;
+  if (h->in_fallback) return false;  // the scan behind the warm path: single-wave kernels on the row-major arrays
   if (h->summarize_mode > 0) return true;
   if (h->summarize_mode < 0 && h->J >= 7 && lazy_eligible(h)) return true;
   return h->summarize_mode < 0 && (h->J == 7 || (h->J == 8 && h->J_comp >= 2));
@@ -1474,6 +1595,14 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   }
   P.out_ll = h->out.p; P.out_logdet = h->out.p + B; P.out_quad = h->out.p + 2 * B;
   P.out_status = reinterpret_cast<int*>(h->out.p + 3 * B);
+  if (h->wints) {
+    const size_t wpc = B * (size_t)h->wnchunk;
+    P.wflags = h->wints; P.need_scan = h->wints + wpc; P.wK = h->wints + wpc + B;
+    P.wL = h->wL; P.wnchunk = h->wnchunk;
+    P.wstarts = h->wstarts.p; P.wends = h->wends.p; P.wpart = h->wpart.p; P.wresid = h->wresid.p;
+    P.warm_resid = h->cert_resid;
+  }
+  P.only_pending = h->in_fallback ? 1 : 0;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
 }
@@ -1589,13 +1718,29 @@ int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, 
   std::vector<double> c(pc * 3);
   HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  // problems the warm-started recurrence settled have no scan record: gamma 0, mu 1, and the largest boundary
+  // mismatch of the warm path as the residual
+  std::vector<int> scanned;
+  std::vector<double> wres;
+  if (h->warm_active && h->wints && h->warm_settled > 0) {
+    scanned.resize((size_t)h->B);
+    wres.resize((size_t)h->B);
+    HIP_TRY(hipMemcpyAsync(scanned.data(), h->wints + (size_t)h->B * h->wnchunk, scanned.size() * sizeof(int),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(wres.data(), h->wresid.p, wres.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   for (int b = 0; b < h->B; ++b) {
     double g = 0.0, m = 1.0, r = 0.0;
-    for (int k = 0; k < h->nchunk; ++k) {
-      const double* e = &c[((size_t)b * h->nchunk + k) * 3];
-      if (!(e[0] <= g)) g = e[0];
-      if (!(e[1] >= m)) m = e[1];
-      if (!(e[2] <= r)) r = e[2];
+    if (!scanned.empty() && scanned[b] == 0) {
+      r = wres[b];
+    } else {
+      for (int k = 0; k < h->nchunk; ++k) {
+        const double* e = &c[((size_t)b * h->nchunk + k) * 3];
+        if (!(e[0] <= g)) g = e[0];
+        if (!(e[1] >= m)) m = e[1];
+        if (!(e[2] <= r)) r = e[2];
+      }
     }
     if (gamma_max) gamma_max[b] = g;
     if (mu_min) mu_min[b] = m;
@@ -1648,7 +1793,11 @@ int clr_batch_set_prefix_plan(clr_batch* h, int levels, int group) {
   if (levels > 3 || (levels > 0 && group < 2)) return fail(CLR_INVALID_ARGUMENT, "prefix plan: levels <= 3, group >= 2");
   h->plan_levels = levels;
   h->plan_g = group;
-  return clr_batch_set_chunks(h, h->nchunk);
+  const int keep = h->warm_explicit_chunks;  // (re-planning the workspace is not a request for a chunk count)
+  int st = clr_batch_set_chunks(h, h->nchunk);
+  h->warm_explicit_chunks = keep;
+  if (st == CLR_OK) st = warm_plan_chunks(h);
+  return st;
 }
 
 int clr_batch_get_prefix_plan(const clr_batch* h, int* levels, int* groups /* [3] */, int* counts /* [4] */) {
@@ -1723,6 +1872,36 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
   if (!h->launch)  // wide plans: plain or lazy flavour of the one-wave-per-chunk summarize
     *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h)) ? 2 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup) {
+  if (mode < -1 || mode > 1 || (mode == 1 && forced_warmup < 1))
+    return fail(CLR_INVALID_ARGUMENT, "warm start: mode -1 (auto), 0 (off) or 1 (forced, with a warm-up length >= 1)");
+  h->warm_mode = mode;
+  h->warm_forced_K = forced_warmup;
+  h->warm_boost = 0;
+  h->warm_active = false;  // (decided by the next clr_batch_set_coefficients)
+  h->have_coeffs = false;
+  return CLR_OK;
+}
+
+int clr_batch_get_warm_start(const clr_batch* h, int* active, int* nchunk, int* chunk_len, int* warmup_min,
+                             int* warmup_max, int* settled, int* fallbacks) {
+  if (active) *active = h->warm_active ? 1 : 0;
+  if (nchunk) *nchunk = h->wnchunk;
+  if (chunk_len) *chunk_len = h->wL;
+  int lo = 0, hi = 0;
+  if (h->warm_active)
+    for (int k : h->warm_K) {
+      if (k <= 0) continue;
+      lo = (lo == 0 || k < lo) ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+  if (warmup_min) *warmup_min = lo;
+  if (warmup_max) *warmup_max = hi;
+  if (settled) *settled = h->warm_settled;
+  if (fallbacks) *fallbacks = h->warm_fallbacks;
   return CLR_OK;
 }
 
@@ -1805,6 +1984,27 @@ int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps)
   return CLR_OK;
 }
 
+static bool warm_runs(const clr_batch* h, int materialize) {
+  return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
+}
+
+// the scan pipeline for the problems the warm path left pending (single-wave summarize on the row-major arrays)
+static int warm_fallback(clr_batch* h) {
+  clr::BatchParams P;
+  h->in_fallback = true;
+  int st = batch_params(h, 0, P);
+  h->in_fallback = false;
+  if (st != CLR_OK) return st;
+  h->launch->summarize(P, h->stream);
+  h->launch->prefix(P, h->stream);
+  h->launch->correct(P, h->stream);
+  h->launch->replay(P, 0, h->stream);
+  h->launch->sequential(P, 0, h->stream);
+  clr::launch_finalize(P, h->stream);
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
 int clr_batch_enqueue(clr_batch* h, int materialize) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
@@ -1831,6 +2031,22 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     return CLR_OK;
   }
   mark(0);
+  h->warm_inflight = false;
+  if (warm_runs(h, materialize)) {
+    // series that forget: the plain recurrence per chunk with a warm-up + the boundary check; problems it cannot
+    // settle are marked pending and go through the scan pipeline when the results are asked for
+    clr::BatchParams Wp;
+    h->in_fallback = true;  // (the row-major arrays, no role split)
+    st = batch_params(h, 0, Wp);
+    h->in_fallback = false;
+    if (st != CLR_OK) return st;
+    mark(1);
+    h->launch->warm(Wp, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    h->warm_inflight = true;
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
   if (h->relayout_pending && batch_relayout(h)) h->relayout_pending = false;
   mark(1);
   h->launch->summarize(P, h->stream);
@@ -1896,6 +2112,26 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double*
   // one copy into the pinned staging buffer (ll | logdet | quad | status), then host memcpys
   HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->warm_inflight) {
+    // problems the warm path could not settle (boundary mismatch, flagged pivot, not eligible) carry a pending
+    // status: run the scan pipeline for them now and fetch again
+    h->warm_inflight = false;
+    const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
+    int pending = 0;
+    for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
+    h->warm_fallbacks = pending;
+    h->warm_settled = (int)B - pending;
+    if (pending) {
+      if ((st = warm_fallback(h)) != CLR_OK) return st;
+      HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      // many mismatches among the problems that did warm up: longer warm-ups from the next coefficients on
+      size_t eligible = 0;
+      for (int k : h->warm_K) eligible += k > 0;
+      const long failed = (long)pending - (long)(B - eligible);
+      if (h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
+    }
+  }
   if (loglike) memcpy(loglike, h->pin, B * sizeof(double));
   if (logdet) memcpy(logdet, h->pin + B, B * sizeof(double));
   if (quad) memcpy(quad, h->pin + 2 * B, B * sizeof(double));
@@ -1933,7 +2169,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
   h->evaluated = true;
-  if (h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
+  if (!warm_runs(h, materialize) && h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
   // one event per kernel boundary per step, all recorded on the handle's stream
   const int NK = 6;
   std::vector<hipEvent_t> ev((size_t)steps * (NK + 1));
@@ -1943,6 +2179,18 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[0], h->stream));
     if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
       wide_launch(h, P, e);
+      continue;
+    }
+    if (warm_runs(h, materialize)) {  // (the warm path: recurrence + boundary check in the "summarize" slot)
+      clr::BatchParams Wp;
+      h->in_fallback = true;
+      st = batch_params(h, 0, Wp);
+      h->in_fallback = false;
+      if (st != CLR_OK) return st;
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      h->launch->warm(Wp, h->stream);
+      for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      h->warm_inflight = true;
       continue;
     }
     if (relayout_each_step) batch_relayout(h);
@@ -1959,7 +2207,8 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     clr::launch_finalize(P, h->stream);
     HIP_TRY(hipEventRecord(e[6], h->stream));
   }
-  if (relayout_each_step && (h->layout == 1 || split_active(h)) && h->nchunk > 1) h->relayout_pending = false;
+  if (relayout_each_step && !warm_runs(h, materialize) && (h->layout == 1 || split_active(h)) && h->nchunk > 1)
+    h->relayout_pending = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   double k[NK] = {0, 0, 0, 0, 0, 0};

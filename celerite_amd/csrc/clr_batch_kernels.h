@@ -23,6 +23,8 @@
 
 namespace clr {
 
+constexpr int CLR_OK_STATUS = 0;  // (= CLR_OK of include/celerite_hip.h, which this header does not include)
+constexpr int CLR_PENDING_STATUS = -1;  // internal: left to the scan pipeline by the warm path; never handed out
 struct BatchParams {
   int B, N, nchunk, L;
   const double *jitter, *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;
@@ -71,6 +73,17 @@ struct BatchParams {
   double cert_eg;         // ... or whose gamma_max x (largest measured G error of its chunks) reaches this (<= 0: no test)
   double cert_resid;  // largest relative mismatch between a replayed chunk's end state and the scanned
                       // start state of the next chunk that still counts as consistent
+  // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace
+  const int* wK;     // [B] warm-up steps of problem b (wave-uniform per block); <= 0: the problem takes the scan
+  int wL, wnchunk;   // chunk length / count of the warm path
+  double* wstarts;   // [B][wnchunk][START] state after the warm-up = at the chunk's first sample
+  double* wends;     // [B][wnchunk][START] state after the chunk = at the next chunk's first sample
+  double* wpart;     // [B][wnchunk][2]
+  int* wflags;       // [B][wnchunk]
+  double* wresid;    // [B] largest boundary mismatch found by warm_check_kernel
+  int* need_scan;    // [B] warm_check_kernel: 1 = not settled by the warm path (the scan pipeline must run for it)
+  int only_pending;  // the scan pipeline runs behind the warm path: only for problems with need_scan != 0
+  double warm_resid; // largest relative mismatch at a chunk boundary that still counts as consistent
   double *out_ll, *out_logdet, *out_quad;
   int* out_status;
   // factor, only for materialising runs (replay mode 1: reference storage per
@@ -107,20 +120,24 @@ __device__ __forceinline__ void lds_barrier() {
 // lone wave); PRIVATE = true: the wave shares its workgroup with other roles
 // (clr_split_kernels.h) -- the tiles are still written and read by this wave only, LDS
 // operations of one wave complete in order, so a compiler fence + lgkmcnt wait suffices.
-template <bool PRIVATE>
+// WARM = true (warm_kernel): every row starts `shift` samples BEFORE its chunk (the warm-up steps) and runs
+// L + shift steps; samples before the start of the series (the first chunk's warm-up) read as t = 0, y = 0 and a
+// diagonal of 1e300, on which a recurrence step changes nothing above 1e-300 -- the first chunk keeps its zero state.
+template <bool PRIVATE, bool WARM = false>
 struct StagedSeriesT {
   double* lds;  // [2 buffers][3 arrays][64 rows][9]
   const double *g0, *g1, *g2;  // problem bases: t, diag, y (row-major)
   long lim;                    // N
   int L, row0, nchunk, lane;
+  int shift;                   // WARM: warm-up steps in front of every chunk
   double p0, p1, p2;  // loads in flight
   __device__ __forceinline__ void issue(int tile, int group) {
     const int r = group * 8 + (lane >> 3), col = tile * 8 + (lane & 7);
-    const long n = (long)(row0 + r) * L + col;
+    const long n = (long)(row0 + r) * L + col - (WARM ? shift : 0);
     // a row may read up to 2 samples into the next one (t_{n+1}, t_{n+2} of its last steps)
-    const bool ok = (row0 + r < nchunk) && (col < L + 2) && (n < lim);
+    const bool ok = (row0 + r < nchunk) && (col < L + (WARM ? shift : 0) + 2) && (n < lim) && (!WARM || n >= 0);
     p0 = ok ? g0[n] : 0.0;
-    p1 = ok ? g1[n] : 0.0;
+    p1 = ok ? g1[n] : ((WARM && n < 0) ? 1e300 : 0.0);
     p2 = ok ? g2[n] : 0.0;
   }
   __device__ __forceinline__ void commit(int tile, int group) {
@@ -180,6 +197,7 @@ __device__ __forceinline__ StagedSeries make_staged(const BatchParams& P, int b,
   s.row0 = blockIdx.x * 64;
   s.nchunk = P.nchunk;
   s.lane = threadIdx.x;
+  s.shift = 0;
   s.p0 = s.p1 = s.p2 = 0.0;
   return s;
 }
@@ -195,6 +213,7 @@ __global__ void __launch_bounds__(64) summarize_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   __shared__ double tiles[STAGED ? 2 * 3 * 64 * 9 : 1];
   const int b = blockIdx.y;
+  if (P.only_pending && P.need_scan[b] == 0) return;  // (settled by the warm path; wave-uniform)
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool store = c < P.nchunk;
   if (!STAGED && !store) return;  // (staged: every lane helps loading the tiles)
@@ -469,6 +488,7 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   const long slot = (long)blockIdx.x * 64 + threadIdx.x;
   if (slot >= (long)P.B * P.nchunk) return;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
+  if (P.only_pending && P.need_scan[b] == 0) return;  // (settled by the warm path: its workspace holds nothing)
   if (P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
   if (c == 0) {  // the first chunk starts from the zero state: nothing to correct
     if (P.egerr) P.egerr[slot] = 0.0;
@@ -577,11 +597,12 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
 // the correct kernels compute the first-order forward error eG of every chunk's G = (I + P Jm)^-1 P from its
 // residual (chunk_update, eg_out) and the problem must have gamma_max x eG_max < cert_eg (3e-9); this also catches
 // the one outlier of the calibration set that both gamma tests let through (a 6-chunk N = 50 problem, 1.9e-9):
-// with all three, 2160 of 3488 settled from the summaries, worst 7.6e-12 (round 2: 2109, worst 1.9e-9).
+// with all three, 2166 of 3488 settled from the summaries, worst 1.05e-11 (round 2: 2109, worst 1.9e-9).
 template <int J>
 __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
   // one wave per problem: max / min over the chunks' records are order-independent
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (P.only_pending && P.need_scan[b] == 0) return;
   if (!P.cond || !(P.cert_gamma > 0.0) || P.need_exact[b] != 0) return;
   // NaN records stick (and then fail the comparison below: ill-conditioned)
   auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
@@ -668,6 +689,114 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Warm-started plain recurrence: the scan's riders (A, eta, Jm), its prefix and its corrections exist because a
+// chunk's start state depends on everything before it.  On series that FORGET -- the decay between samples is not
+// small, e.g. the paper's accuracy family (paper/figures/error/error.py:24-25: mean spacing 0.8, c >= 1): after a
+// few tens of samples the state no longer depends on where it started -- they are pure overhead: every chunk runs
+// the reference recurrence itself (replay_chunk: ~1x the reference's arithmetic, two waves per SIMD) from the ZERO
+// state K samples before its first sample, counts nothing during those K warm-up steps, and the state it has
+// reached at its first sample is compared with the state the PREVIOUS chunk reaches at that very sample
+// (warm_check_kernel).  Chunk 0 starts from the true zero state, so agreement at every boundary certifies all
+// start states by induction; a problem with a mismatch above warm_resid, a flagged pivot or a non-finite partial
+// is left to the scan pipeline (need_scan).  K is chosen per problem on the host from the slowest decay rate and
+// the time the K samples before every chunk boundary span (api.hip); the check makes that choice safe, not just
+// plausible.  No interleaved copy, no prefix, no corrections.
+// ---------------------------------------------------------------------------
+using WarmSeries = StagedSeriesT<false, true>;
+
+template <int JR, int JC, bool FAST>
+__global__ void __launch_bounds__(64) warm_kernel(const BatchParams P) {
+  using Wd = Widths<JR, JC>;
+  __shared__ double tiles[2 * 3 * 64 * 9];
+  const int b = blockIdx.y;
+  const int K = P.wK[b];
+  if (K <= 0) return;  // this problem takes the scan (wave-uniform)
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const bool mine = c < P.wnchunk;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  WarmSeries src;
+  src.lds = tiles;
+  src.g0 = P.t + b * P.t_stride;
+  src.g1 = P.diag + b * P.diag_stride;
+  src.g2 = P.y + b * P.y_stride;
+  src.lim = P.N;
+  src.L = P.wL;
+  src.row0 = blockIdx.x * 64;
+  src.nchunk = P.wnchunk;
+  src.lane = threadIdx.x;
+  src.shift = K;
+  src.p0 = src.p1 = src.p2 = 0.0;
+  const long slot = (long)b * P.wnchunk + (mine ? c : 0);
+  double ld, qd;
+  int flag;
+  double endst[Wd::START];
+  replay_chunk<JR, JC, 0, FAST>(p, src, P.wL + K, P.N, c * P.wL - K, nullptr, &ld, &qd, &flag, nullptr, nullptr,
+                                nullptr, nullptr, 0, endst, K, mine ? P.wstarts + slot * Wd::START : nullptr);
+  if (!mine) return;
+  double* e = P.wends + slot * Wd::START;
+#pragma unroll
+  for (int i = 0; i < Wd::START; ++i) e[i] = endst[i];
+  P.wpart[slot * 2 + 0] = ld;
+  P.wpart[slot * 2 + 1] = qd;
+  P.wflags[slot] = flag;
+}
+
+// One wave per problem: every boundary's two versions of the same state must agree; then the partial sums are added
+// in a fixed order (as finalize_kernel) and the problem is done.  Otherwise need_scan[b] = 1.
+template <int J>
+__global__ void __launch_bounds__(64) warm_check_kernel(const BatchParams P) {
+  constexpr int SZ = J * (J + 1) / 2, START = SZ + J;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (P.wK[b] <= 0) {
+    if (lane == 0) { P.need_scan[b] = 1; P.out_status[b] = CLR_PENDING_STATUS; if (P.wresid) P.wresid[b] = 0.0; }
+    return;
+  }
+  double res = 0.0, ld = 0.0, qd = 0.0;
+  int bad = 0;
+  for (int c = lane; c < P.wnchunk; c += 64) {
+    const long slot = (long)b * P.wnchunk + c;
+    const double l = P.wpart[slot * 2 + 0], q = P.wpart[slot * 2 + 1];
+    ld += l;
+    qd += q;
+    if (P.wflags[slot] || !isfinite(l) || (!P.logdet_only && !isfinite(q))) bad = 1;
+    if (c + 1 < P.wnchunk) {
+      const double* en = P.wends + slot * START;
+      const double* st = P.wstarts + (slot + 1) * START;
+      double pm = 0.0, dp = 0.0, fm = 0.0, df = 0.0;
+#pragma unroll
+      for (int i = 0; i < SZ; ++i) { pm = fmax(pm, fabs(en[i])); dp = fmax(dp, fabs(en[i] - st[i])); }
+#pragma unroll
+      for (int i = 0; i < J; ++i) { fm = fmax(fm, fabs(en[SZ + i])); df = fmax(df, fabs(en[SZ + i] - st[SZ + i])); }
+      double r = (pm > 0.0) ? dp / pm : (dp == 0.0 ? 0.0 : INFINITY);
+      if (!P.logdet_only && fm > 0.0) r = fmax(r, df / fm);
+      res = (res != res) ? res : ((r != r) ? r : fmax(res, r));  // (NaN sticks)
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(res, off, 64);
+    res = (res != res || o != o) ? NAN : fmax(res, o);
+    ld += __shfl_xor(ld, off, 64);
+    qd += __shfl_xor(qd, off, 64);
+  }
+  bad = __any(bad) ? 1 : 0;
+  if (lane != 0) return;
+  if (P.wresid) P.wresid[b] = res;
+  if (bad || !(res <= P.warm_resid)) {
+    P.need_scan[b] = 1;
+    P.out_status[b] = CLR_PENDING_STATUS;  // the host runs the scan pipeline for it before handing results out
+    return;
+  }
+  P.need_scan[b] = 0;
+  P.need_exact[b] = 0;
+  P.out_status[b] = CLR_OK_STATUS;
+  P.out_logdet[b] = ld;
+  P.out_quad[b] = qd;
+  P.out_ll[b] = combine_loglike(ld, qd, P.N);
+}
+
 }  // namespace clr
 #include "clr_prefix_kernels.h"
 namespace clr {
@@ -682,6 +811,7 @@ struct BatchLaunchers {
   // cross-check: compose the chunk elements in groups of g with the cooperative kernel (-> coop) and with the
   // single-lane host-checked form (-> ref); both [B][ceil(nchunk / g)][ELEM]
   void (*compose_check)(const BatchParams&, int g, double* coop, double* ref, hipStream_t);
+  void (*warm)(const BatchParams&, hipStream_t);  // warm_kernel + warm_check_kernel
   int elem_doubles, start_doubles;
 };
 
@@ -740,8 +870,14 @@ struct BatchImpl {
     S.parents = ref;
     hipLaunchKernelGGL((group_compose_reference_kernel<J>), dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, s, S);
   }
+  static void warm(const BatchParams& P, hipStream_t s) {
+    dim3 grid((P.wnchunk + 63) / 64, P.B);
+    if (P.fast_trig) hipLaunchKernelGGL((warm_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    else hipLaunchKernelGGL((warm_kernel<JR, JC, false>), grid, dim3(64), 0, s, P);
+    hipLaunchKernelGGL((warm_check_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
+  }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check,
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm,
                           Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };

@@ -622,54 +622,55 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
   // now T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
 
   if (eg_out) {
-    // REALIZED accuracy of G = (I + P Jm)^-1 P, measured instead of bounded by 1 / mu: residual
-    // R = P - G - P Jm G, first-order forward error dG = (I + P Jm)^-1 R = (I - G Jm) R; returned as
-    // max |dG| / max |G| (the floor of this estimate is the rounding of R itself, ~ J eps)
-    double X[J][J], R[J][J];
-    double gmax = 0.0, emax = 0.0;
-    CLR_UNROLL_J
-    for (int i = 0; i < J; ++i) {
+    // REALIZED accuracy of G = (I + P Jm)^-1 P, measured instead of bounded by 1 / mu, on two probe vectors
+    // (all ones; alternating signs): residual r = P z - G z - P Jm (G z), first-order forward error
+    // dg = (I + P Jm)^-1 r = (I - G Jm) r; returned as max |dg| / max |G z| over the probes (the floor of
+    // this estimate is the rounding of r itself, ~ J eps).  Vectors only: 12 J^2 flops, no J x J temporaries.
+    double worst = 0.0;
+    CLR_UNROLL
+    for (int probe = 0; probe < 2; ++probe) {
+      double gz[J], t1[J], r[J];
+      double gmax = 0.0, emax = 0.0;
       CLR_UNROLL_J
-      for (int j = 0; j < J; ++j) {
+      for (int i = 0; i < J; ++i) {
         double acc = 0.0;
         CLR_UNROLL_J
-        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * T[k][J + j];
-        X[i][j] = acc;
+        for (int k = 0; k < J; ++k) acc += (probe && (k & 1)) ? -T[i][J + k] : T[i][J + k];
+        gz[i] = acc;
+        gmax = fmax(gmax, fabs(acc));
       }
-    }
-    CLR_UNROLL_J
-    for (int i = 0; i < J; ++i) {
       CLR_UNROLL_J
-      for (int j = 0; j < J; ++j) {
-        double acc = P[sym(i, j)] - T[i][J + j];
-        CLR_UNROLL_J
-        for (int k = 0; k < J; ++k) acc -= P[sym(i, k)] * X[k][j];
-        R[i][j] = acc;
-      }
-    }
-    CLR_UNROLL_J
-    for (int i = 0; i < J; ++i) {
-      CLR_UNROLL_J
-      for (int j = 0; j < J; ++j) {
+      for (int i = 0; i < J; ++i) {
         double acc = 0.0;
         CLR_UNROLL_J
-        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * R[k][j];
-        X[i][j] = acc;
+        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * gz[k];
+        t1[i] = acc;
       }
-    }
-    CLR_UNROLL_J
-    for (int i = 0; i < J; ++i) {
       CLR_UNROLL_J
-      for (int j = 0; j < J; ++j) {
-        double acc = R[i][j];
+      for (int i = 0; i < J; ++i) {
+        double acc = -gz[i];
         CLR_UNROLL_J
-        for (int k = 0; k < J; ++k) acc -= T[i][J + k] * X[k][j];
-        emax = fmax(emax, fabs(acc));
-        gmax = fmax(gmax, fabs(T[i][J + j]));
-        if (acc != acc) emax = INFINITY;
+        for (int k = 0; k < J; ++k) acc += P[sym(i, k)] * (((probe && (k & 1)) ? -1.0 : 1.0) - t1[k]);
+        r[i] = acc;
       }
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) {
+        double acc = 0.0;
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc += Jm[sym(i, k)] * r[k];
+        t1[i] = acc;
+      }
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) {
+        double acc = r[i];
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc -= T[i][J + k] * t1[k];
+        emax = (acc != acc) ? INFINITY : fmax(emax, fabs(acc));
+      }
+      const double e = (gmax > 0.0) ? emax / gmax : (emax == 0.0 ? 0.0 : INFINITY);
+      worst = (e > worst || e != e) ? e : worst;
     }
-    *eg_out = (gmax > 0.0) ? emax / gmax : (emax == 0.0 ? 0.0 : INFINITY);
+    *eg_out = worst;
   }
 
   if (correct) {
@@ -966,7 +967,9 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
                          const double* start /* P[SZ] f[J] or nullptr => zero */,
                          double* logdet_out, double* quad_out, int* flag_out,
                          double* phi_o, double* u_o, double* W_o, double* D_o, long fstride,
-                         double* end_out = nullptr /* state after the chunk: P[SZ] f[J] */) {
+                         double* end_out = nullptr /* state after the chunk: P[SZ] f[J] */,
+                         int warm = 0 /* leading steps that only warm the state up (wave-uniform) */,
+                         double* warm_out = nullptr /* state after them: P[SZ] f[J] */) {
   // MATERIALIZE: 0 = nothing is stored; 1 = the reference's storage (cholesky.h:76-78,
   // :703-706: phi[:, n], u[:, n-1], W[:, n], D[n] with element (j, n) at [j + J n];
   // pointers are the problem's arrays); 2 = chunk-interleaved device layout: the
@@ -1002,7 +1005,13 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
   for (int i = 0; i < L; ++i) {
     src.step_begin(i);
     const int n = n0 + i;
-    const bool valid = n < N;
+    const bool valid = n < N && i >= warm;
+    if (warm_out && i == warm) {  // (wave-uniform branch, taken once: the warmed-up state, stored rather than kept)
+      CLR_UNROLL
+      for (int k = 0; k < SZ; ++k) warm_out[k] = P[k];
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) warm_out[SZ + k] = f[k];
+    }
     const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
     if (i + 1 < L) {
       t_next = src.t(i + 2);

@@ -494,46 +494,53 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   }
   // T[i][J + j] = G[i][j] (symmetrised below), T[i][2J] = g[i]
 
-  // measured accuracy of G (chunk_update's eg_out at this width): R = P - G - P Jm G, dG = (I - G Jm) R; Sm and PF
-  // are free until the certificate
+  // measured accuracy of G (chunk_update's eg_out at this width, same two probe vectors): lane i < J owns row i;
+  // the vectors cross the wave through wv / ev-sized LDS scratch (fv, ev, wv are rewritten below only after use)
   double eg = 0.0;
   if (P.egerr) {
-    for (int idx = lane; idx < J * J; idx += 64) {  // Sm = Jm G
-      const int i = idx / J, j = idx % J;
-      double acc = 0.0;
-      for (int k = 0; k < J; ++k) acc += Jmm[i * LD + k] * T[k * LT + J + j];
-      Sm[i * LD + j] = acc;
-    }
-    __syncthreads();
-    for (int idx = lane; idx < J * J; idx += 64) {  // PF = R
-      const int i = idx / J, j = idx % J;
-      double acc = Pm[i * LD + j] - T[i * LT + J + j];
-      for (int k = 0; k < J; ++k) acc -= Pm[i * LD + k] * Sm[k * LD + j];
-      PF[i * LD + j] = acc;
-    }
-    __syncthreads();
-    for (int idx = lane; idx < J * J; idx += 64) {  // Sm = Jm R
-      const int i = idx / J, j = idx % J;
-      double acc = 0.0;
-      for (int k = 0; k < J; ++k) acc += Jmm[i * LD + k] * PF[k * LD + j];
-      Sm[i * LD + j] = acc;
-    }
-    __syncthreads();
-    double emax = 0.0, gmax = 0.0;
-    for (int idx = lane; idx < J * J; idx += 64) {  // dG = R - G (Jm R)
-      const int i = idx / J, j = idx % J;
-      double acc = PF[i * LD + j];
-      for (int k = 0; k < J; ++k) acc -= T[i * LT + J + k] * Sm[k * LD + j];
-      emax = (acc != acc) ? INFINITY : fmax(emax, fabs(acc));
-      gmax = fmax(gmax, fabs(T[i * LT + J + j]));
-    }
+    __shared__ double pa[J], pb[J];
+    for (int probe = 0; probe < 2; ++probe) {
+      double gz = 0.0, r = 0.0;
+      if (lane < J) {
+        for (int k = 0; k < J; ++k) gz += (probe && (k & 1)) ? -T[lane * LT + J + k] : T[lane * LT + J + k];
+        pa[lane] = gz;
+      }
+      __syncthreads();
+      if (lane < J) {  // t1 = Jm (G z)
+        double acc = 0.0;
+        for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * pa[k];
+        pb[lane] = acc;
+      }
+      __syncthreads();
+      if (lane < J) {  // r = P (z - t1) - G z
+        double acc = -gz;
+        for (int k = 0; k < J; ++k) acc += Pm[lane * LD + k] * (((probe && (k & 1)) ? -1.0 : 1.0) - pb[k]);
+        r = acc;
+        pa[lane] = r;
+      }
+      __syncthreads();
+      if (lane < J) {  // t1 = Jm r
+        double acc = 0.0;
+        for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * pa[k];
+        pb[lane] = acc;
+      }
+      __syncthreads();
+      double dg = 0.0;
+      if (lane < J) {  // dg = r - G t1
+        double acc = r;
+        for (int k = 0; k < J; ++k) acc -= T[lane * LT + J + k] * pb[k];
+        dg = (acc != acc) ? INFINITY : fabs(acc);
+      }
+      double gmax = (lane < J) ? fabs(gz) : 0.0;
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      emax = fmax(emax, __shfl_xor(emax, m, 64));
-      gmax = fmax(gmax, __shfl_xor(gmax, m, 64));
+      for (int m = 1; m < 64; m <<= 1) {
+        dg = fmax(dg, __shfl_xor(dg, m, 64));
+        gmax = fmax(gmax, __shfl_xor(gmax, m, 64));
+      }
+      const double e = (gmax > 0.0) ? dg / gmax : (dg == 0.0 ? 0.0 : INFINITY);
+      eg = (e > eg || e != e) ? e : eg;
+      __syncthreads();
     }
-    eg = (gmax > 0.0) ? emax / gmax : (emax == 0.0 ? 0.0 : INFINITY);
-    __syncthreads();
   }
 
   double ef = 0.0, fJf = 0.0, wGw = 0.0;

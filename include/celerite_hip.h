@@ -242,6 +242,22 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
  *  -1  (default) 2 at widths 7 and 8 on a dense series; otherwise 1 at width 7 and at width 8 with at least two
  *      complex terms, else 0. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
+/* Series that FORGET their past (the decay between samples is not small: e.g. the paper's accuracy family,
+ * paper/figures/error/error.py:24-25, or most real light curves) do not need the scan: every chunk runs the
+ * reference recurrence itself from the zero state `K` samples before its first sample, and the state it has reached
+ * at its first sample is checked against the state the previous chunk reaches there (relative mismatch <= the
+ * max_residual of clr_batch_set_certificate); the first chunk starts from the true zero state, so agreement at every
+ * boundary certifies all of them.  A problem with a mismatch, a flagged pivot or no usable K goes through the scan
+ * pipeline when the results are fetched.  mode -1 (default): per problem, the smallest K of 8, 16, ... 256 with
+ * exp(-c_min x (time the K samples before any chunk boundary span)) <= exp(-37), used when at least half of the batch
+ * has one; 0: off; 1: every problem with `forced_warmup` steps (tests: the check then decides).  Widths 1..8, fused
+ * log-likelihood only (materialising / forced-exact runs take the scan). */
+int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup);
+/* What the current (series, coefficients) pair runs and how the last evaluation went: active, the warm path's chunk
+ * count and length, smallest / largest warm-up in the batch, problems it settled / left to the scan (after the last
+ * clr_batch_get_results).  Any pointer may be NULL. */
+int clr_batch_get_warm_start(const clr_batch* h, int* active, int* nchunk, int* chunk_len, int* warmup_min,
+                             int* warmup_max, int* settled, int* fallbacks);
 /* Where the replay pass (materialising / forced-exact runs) reads the series when the summarize kernel reads the
  * chunk-interleaved copy: 0 that copy (default, also -1: 4.41 ms = 65 % of HBM for the materialising replay at
  * B = 1024, N = 1e5, width 8), 1 the row-major arrays through LDS-staged tiles (4.77 ms = 60 %;

@@ -827,3 +827,112 @@ def test_role_split_tail_padding_and_shared_series(N, nchunk):
             assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL
             assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL
         plan.close()
+
+
+# ---- warm-started plain recurrence (series that forget their past) -------------------------------------------------
+def _oracle(case):
+    return ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+
+
+def test_warm_start_settles_the_accuracy_family_and_matches_the_scan():
+    """The paper's accuracy family (paper/figures/error/error.py:24-25: spacing 0.8, c >= 1) forgets its start state
+    within tens of samples: by default every problem is settled by the warm-started recurrence (no scan, no
+    fallback), within 1e-10 of the oracle and 1e-11 of the scan path; the bench family (dense sampling) never
+    qualifies and keeps the scan."""
+    for JR, JC in ((2, 3), (0, 2), (4, 0), (1, 3)):
+        B, N = 12, 20000
+        case = synthetic(B, N, JR, JC, "accuracy", seed=31 + JR)
+        l0, d0, q0, s0 = _oracle(case)
+        plan = batch.BatchedGP(B, N, JR, JC)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        info = plan.warm_start()
+        assert info["active"] == 1 and 8 <= info["warmup_min"] <= info["warmup_max"] <= info["chunk_len"] // 2, info
+        ll, ld, q, st = plan.log_likelihood()
+        info = plan.warm_start()
+        assert info["settled"] == B and info["fallbacks"] == 0, info
+        assert np.array_equal(st, s0) and (plan.exact_levels() == 0).all()
+        assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL and np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+        assert np.max(np.abs(ll - l0) / np.abs(l0)) <= REL
+        plan.set_warm_start(0)
+        plan.set_coefficients(*coeffs_of(case))
+        assert plan.warm_start()["active"] == 0
+        ll2, ld2, q2, st2 = plan.log_likelihood()
+        assert np.max(np.abs(ld - ld2) / np.abs(ld2)) <= 1e-11 and np.max(np.abs(q - q2) / np.abs(q2)) <= 1e-11
+        plan.close()
+    case = synthetic(8, 20000, 2, 3, "bench", seed=3)
+    plan = batch.BatchedGP(8, 20000, 2, 3)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    assert plan.warm_start()["active"] == 0
+    plan.close()
+
+
+def test_warm_start_boundary_check_sends_unconverged_problems_to_the_scan():
+    """Forced warm-ups that are too short (1, 2, 4 steps): the states at the chunk boundaries do not meet, every
+    problem is left pending and settled by the scan pipeline when the results are fetched -- same numbers.  A warm-up
+    that is long enough settles everything.  On the bench family (which does not forget within a chunk) even the
+    longest warm-up fails the check: the check, not the heuristic, is what certifies."""
+    B, N = 9, 12000
+    case = synthetic(B, N, 2, 3, "accuracy", seed=77)
+    l0, d0, q0, s0 = _oracle(case)
+    plan = batch.BatchedGP(B, N, 2, 3)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    for K, expect_fallback in ((1, True), (2, True), (4, True), (128, False)):
+        plan.set_warm_start(1, K)
+        plan.set_coefficients(*coeffs_of(case))
+        assert plan.warm_start()["active"] == 1
+        ll, ld, q, st = plan.log_likelihood()
+        info = plan.warm_start()
+        assert (info["fallbacks"] == B) if expect_fallback else (info["fallbacks"] == 0), (K, info)
+        assert np.array_equal(st, s0)
+        assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL and np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+    plan.close()
+    case = synthetic(B, N, 2, 3, "bench", seed=78)
+    l0, d0, q0, s0 = _oracle(case)
+    plan = batch.BatchedGP(B, N, 2, 3)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_warm_start(1, 256)
+    plan.set_coefficients(*coeffs_of(case))
+    ll, ld, q, st = plan.log_likelihood()
+    assert plan.warm_start()["fallbacks"] == B
+    assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL and np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+    plan.close()
+
+
+def test_warm_start_mixed_batch_and_indefinite_neighbours():
+    """A batch in which some problems forget (warm path), some have a decay rate so slow that no warm-up qualifies
+    (straight to the scan), and one is not positive definite (flagged during the warm pass -> scan -> status 2):
+    every problem gets the oracle's status and values."""
+    B, N = 10, 16000
+    case = synthetic(B, N, 2, 2, "accuracy", seed=5)
+    case["c_real"][3, 0] = 1e-4          # remembers for ~1e4 time units: not eligible
+    case["c_real"][6, 1] = 3e-4
+    case["a_real"][8, 0] = -40.0         # indefinite
+    case["diag"][8] = 1e-3
+    l0, d0, q0, s0 = _oracle(case)
+    assert s0[8] == 2 and (np.delete(s0, 8) == 0).all()
+    plan = batch.BatchedGP(B, N, 2, 2)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    assert plan.warm_start()["active"] == 1
+    ll, ld, q, st = plan.log_likelihood()
+    info = plan.warm_start()
+    assert info["fallbacks"] == 3 and info["settled"] == B - 3, info
+    assert np.array_equal(st, s0) and np.isneginf(ll[8])
+    ok = s0 == 0
+    assert np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
+    assert np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])) <= REL
+    # shared series (stride 0) through the warm path
+    shared = dict(case)
+    for k in ("t", "diag", "y"):
+        shared[k] = case[k][0]
+    shared["a_real"] = np.array(case["a_real"], copy=True); shared["a_real"][8, 0] = 1.0
+    l1, d1, q1, s1 = ref.batch_log_likelihood(0.0, *coeffs_of(shared), shared["t"], shared["diag"], shared["y"])
+    plan2 = batch.BatchedGP(B, N, 2, 2)
+    plan2.set_series(shared["t"], shared["diag"], shared["y"])
+    plan2.set_coefficients(*coeffs_of(shared))
+    ll, ld, q, st = plan2.log_likelihood()
+    assert np.array_equal(st, s1) and plan2.warm_start()["settled"] == B - 2
+    assert np.max(np.abs(ld - d1) / np.abs(d1)) <= REL and np.max(np.abs(q - q1) / np.abs(q1)) <= REL
+    plan.close(); plan2.close()

@@ -52,6 +52,9 @@ def rep(name, m):
           % (name, m.sum(), len(m), dev[m].max() if m.any() else 0, (dev[m] > 1e-11).sum(), (dev[m] > 1e-10).sum()))
 rep("round 2: gamma/mu < 1e6", gam / mu < 1e6)
 rep("round 3: gamma < 1e4 & gamma/mu < 1e7", (gam < 1e4) & (gam / mu < 1e7))
+rep("round 3, all three: ... & gamma*eG < 3e-9", (gam < 1e4) & (gam / mu < 1e7) & (gam * eg < 3e-9))
+rep("         ... & gamma*eG < 1e-9", (gam < 1e4) & (gam / mu < 1e7) & (gam * eg < 1e-9))
+rep("         ... & gamma*eG < 1e-8", (gam < 1e4) & (gam / mu < 1e7) & (gam * eg < 1e-8))
 rep("         gamma < 2e4 & gamma/mu < 1e7", (gam < 2e4) & (gam / mu < 1e7))
 rep("         gamma < 1e4 & gamma/mu < 3e7", (gam < 1e4) & (gam / mu < 3e7))
 rep("         gamma * eG < 1e-9", gam * eg < 1e-9)
