@@ -137,6 +137,40 @@ void launch_deinterleave_factor(const double* phi_i, const double* u_i, const do
                      D_i, phi, u, W, D, N, J, L, nchunk);
 }
 
+// The warm kernel's copy: [row][chunk] per problem with row r of chunk c = sample n = c L - Kpad + r, rows =
+// Kpad + L + 8 (every chunk's column starts with the Kpad samples in front of it -- its warm-up -- and ends with the
+// look-ahead of its last steps).  Samples outside the series are padding a recurrence step ignores: before the
+// start t = t_0, after the end t = t_{N-1} (a zero time step), the diagonal 1e300 (1 / D ~ 0), y = 0.
+__global__ void __launch_bounds__(256) relayout_warm_kernel(const double* __restrict__ src, long src_stride,
+                                                            double* __restrict__ dst, long dst_stride, int N, int L,
+                                                            int nchunk, int Kpad, int rows, int pad_kind) {
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const double* in = src + (long)b * src_stride;
+  double* out = dst + (long)b * dst_stride;
+  const double pad_lo = pad_kind == 1 ? in[0] : (pad_kind == 2 ? 1e300 : 0.0);
+  const double pad_hi = pad_kind == 1 ? in[N - 1] : (pad_kind == 2 ? 1e300 : 0.0);
+  for (int q = threadIdx.y; q < 32; q += 8) {
+    const int c = c0 + q, r = r0 + threadIdx.x;
+    const long n = (long)c * L - Kpad + r;
+    double v = n < 0 ? pad_lo : pad_hi;
+    if (c < nchunk && r < rows && n >= 0 && n < N) v = in[n];
+    tile[q][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int q = threadIdx.y; q < 32; q += 8) {
+    const int r = r0 + q, c = c0 + threadIdx.x;
+    if (r < rows && c < nchunk) out[(long)r * nchunk + c] = tile[threadIdx.x][q];
+  }
+}
+
+void launch_relayout_warm(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L,
+                          int nchunk, int Kpad, int rows, int pad_kind, hipStream_t s) {
+  dim3 grid((rows + 31) / 32, (nchunk + 31) / 32, nsrc);
+  hipLaunchKernelGGL(relayout_warm_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride, N, L, nchunk,
+                     Kpad, rows, pad_kind);
+}
+
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, int pad_kind, hipStream_t s) {
   dim3 grid((L + 31) / 32, (nchunk + 31) / 32, nsrc);
@@ -327,8 +361,8 @@ struct clr_batch {
   int warm_forced_K = 0;
   int warm_explicit_chunks = 0;       // chunk count asked for through clr_batch_set_chunks (0: automatic)
   int wnchunk = 0, wL = 0;            // the warm path's own chunking
-  static const int WARM_NK = 6;
-  int warm_cand[WARM_NK] = {8, 16, 32, 64, 128, 256};
+  static const int WARM_NK = 5;
+  int warm_cand[WARM_NK] = {8, 16, 32, 64, 128};
   std::vector<double> warm_span;      // [B or 1][WARM_NK] shortest time the K samples before a chunk boundary span
   std::vector<int> warm_K;            // [B] warm-up steps per problem of the current coefficients (0: scan)
   bool warm_active = false;           // the current (series, coefficients) pair runs the warm path
@@ -337,6 +371,9 @@ struct clr_batch {
   int warm_boost = 0;                 // candidates skipped after an evaluation with many fallbacks
   int warm_settled = 0, warm_fallbacks = 0;  // of the last evaluation
   DevBuf wstarts, wends, wpart, wresid;
+  DevBuf wT, wD, wY;                  // the warm kernel's padded chunk-interleaved copy of the series
+  int wKpad = 0, wrows = 0;
+  bool warm_copy_pending = true;
   int* wints = nullptr;               // wflags [B * wnchunk] | need_scan [B] | K [B]
   size_t wints_cap = 0;
   int replay_source = -1;             // where the replay reads the series when summarize reads the chunk-interleaved
@@ -1222,7 +1259,7 @@ void clr_batch_destroy(clr_batch* h) {
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
-                    &h->wpart, &h->wresid})
+                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1311,6 +1348,9 @@ static int warm_plan_chunks(clr_batch* h) {
   if (nc < 2) return CLR_OK;
   h->wL = (int)L;
   h->wnchunk = (int)nc;
+  h->wKpad = std::min(128, h->wL / 2);  // rows of warm-up every chunk's column carries (the largest candidate)
+  h->wrows = h->wKpad + h->wL + 8;
+  h->warm_copy_pending = true;
   const size_t pc = (size_t)h->B * nc, START = (size_t)h->launch->start_doubles;
   int st;
   if ((st = h->wstarts.reserve(pc * START)) != CLR_OK) return st;
@@ -1393,6 +1433,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->y_stride = y_stride;
   h->have_series = true;
   h->relayout_pending = true;
+  h->warm_copy_pending = true;
   return CLR_OK;
 }
 
@@ -1562,7 +1603,8 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   // wide plans: the lazy-decay flavour of the wide summarize on dense series (mode 0 / 1 switch it off)
   if (!h->launch && h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h))
     P.split_lazy = 1;
-  if (h->launch && (h->layout == 1 || split) && h->nchunk > 1) {  // (the wide kernels read the row-major arrays)
+  // (the wide kernels, the warm-started recurrence and the scan behind it read the row-major arrays)
+  if (h->launch && (h->layout == 1 || split) && h->nchunk > 1 && !h->in_fallback) {
     const long cells = (long)h->nchunk * h->L;
     auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
     if ((st = h->tT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
@@ -1578,7 +1620,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
     P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
     P.lane_is = 1; P.lane_cs = h->L;
-    P.staged = (h->layout == 2 && h->nchunk > 1) ? 1 : 0;
+    P.staged = ((h->layout == 2 || h->in_fallback) && h->nchunk > 1) ? 1 : 0;
   }
   P.elems = h->elems.p; P.starts = h->starts.p; P.part = h->part.p; P.flags = h->flags;
   P.cond = h->cond.p;
@@ -1601,6 +1643,10 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.wL = h->wL; P.wnchunk = h->wnchunk;
     P.wstarts = h->wstarts.p; P.wends = h->wends.p; P.wpart = h->wpart.p; P.wresid = h->wresid.p;
     P.warm_resid = h->cert_resid;
+    const long cells = (long)h->wrows * h->wnchunk;
+    P.wt = h->wT.p; P.wdiag = h->wD.p; P.wy = h->wY.p;
+    P.wt_stride = h->t_stride ? cells : 0; P.wdiag_stride = h->diag_stride ? cells : 0; P.wy_stride = h->y_stride ? cells : 0;
+    P.wKpad = h->wKpad; P.wrows = h->wrows;
   }
   P.only_pending = h->in_fallback ? 1 : 0;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
@@ -1988,6 +2034,24 @@ static bool warm_runs(const clr_batch* h, int materialize) {
   return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
 }
 
+// the warm kernel's copy of the series, (re)built when the series or the warm chunking changed
+static int warm_copy(clr_batch* h) {
+  if (!h->warm_copy_pending) return CLR_OK;
+  const size_t cells = (size_t)h->wrows * h->wnchunk;
+  auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
+  int st;
+  if ((st = h->wT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->wD.reserve(nsrc(h->diag_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->wY.reserve(nsrc(h->y_stride) * cells)) != CLR_OK) return st;
+  struct { DevBuf* src; DevBuf* dst; long stride; int pad; } jobs[3] = {
+      {&h->t, &h->wT, h->t_stride, 1}, {&h->diag, &h->wD, h->diag_stride, 2}, {&h->y, &h->wY, h->y_stride, 0}};
+  for (auto& j : jobs)
+    clr::launch_relayout_warm(j.src->p, j.stride, j.dst->p, j.stride ? (long)cells : 0, j.stride ? h->B : 1, h->N,
+                              h->wL, h->wnchunk, h->wKpad, h->wrows, j.pad, h->stream);
+  h->warm_copy_pending = false;
+  return CLR_OK;
+}
+
 // the scan pipeline for the problems the warm path left pending (single-wave summarize on the row-major arrays)
 static int warm_fallback(clr_batch* h) {
   clr::BatchParams P;
@@ -2036,6 +2100,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     // series that forget: the plain recurrence per chunk with a warm-up + the boundary check; problems it cannot
     // settle are marked pending and go through the scan pipeline when the results are asked for
     clr::BatchParams Wp;
+    if ((st = warm_copy(h)) != CLR_OK) return st;
     h->in_fallback = true;  // (the row-major arrays, no role split)
     st = batch_params(h, 0, Wp);
     h->in_fallback = false;
@@ -2183,6 +2248,8 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     }
     if (warm_runs(h, materialize)) {  // (the warm path: recurrence + boundary check in the "summarize" slot)
       clr::BatchParams Wp;
+      if (relayout_each_step) h->warm_copy_pending = true;  // (new series every step: the copy is rebuilt inside it)
+      if ((st = warm_copy(h)) != CLR_OK) return st;
       h->in_fallback = true;
       st = batch_params(h, 0, Wp);
       h->in_fallback = false;

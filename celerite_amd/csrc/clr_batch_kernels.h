@@ -75,6 +75,11 @@ struct BatchParams {
                       // start state of the next chunk that still counts as consistent
   // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace
   const int* wK;     // [B] warm-up steps of problem b (wave-uniform per block); <= 0: the problem takes the scan
+  // the series as the warm kernel reads them: [problem][row][chunk], row r of chunk c = sample c wL - wKpad + r,
+  // wrows = wKpad + wL + 8 rows; samples outside the series are padding a recurrence step ignores (relayout_warm_kernel)
+  const double *wt, *wdiag, *wy;
+  long wt_stride, wdiag_stride, wy_stride;  // per problem (0: one shared series)
+  int wKpad, wrows;
   int wL, wnchunk;   // chunk length / count of the warm path
   double* wstarts;   // [B][wnchunk][START] state after the warm-up = at the chunk's first sample
   double* wends;     // [B][wnchunk][START] state after the chunk = at the next chunk's first sample
@@ -120,24 +125,20 @@ __device__ __forceinline__ void lds_barrier() {
 // lone wave); PRIVATE = true: the wave shares its workgroup with other roles
 // (clr_split_kernels.h) -- the tiles are still written and read by this wave only, LDS
 // operations of one wave complete in order, so a compiler fence + lgkmcnt wait suffices.
-// WARM = true (warm_kernel): every row starts `shift` samples BEFORE its chunk (the warm-up steps) and runs
-// L + shift steps; samples before the start of the series (the first chunk's warm-up) read as t = 0, y = 0 and a
-// diagonal of 1e300, on which a recurrence step changes nothing above 1e-300 -- the first chunk keeps its zero state.
-template <bool PRIVATE, bool WARM = false>
+template <bool PRIVATE>
 struct StagedSeriesT {
   double* lds;  // [2 buffers][3 arrays][64 rows][9]
   const double *g0, *g1, *g2;  // problem bases: t, diag, y (row-major)
   long lim;                    // N
   int L, row0, nchunk, lane;
-  int shift;                   // WARM: warm-up steps in front of every chunk
   double p0, p1, p2;  // loads in flight
   __device__ __forceinline__ void issue(int tile, int group) {
     const int r = group * 8 + (lane >> 3), col = tile * 8 + (lane & 7);
-    const long n = (long)(row0 + r) * L + col - (WARM ? shift : 0);
+    const long n = (long)(row0 + r) * L + col;
     // a row may read up to 2 samples into the next one (t_{n+1}, t_{n+2} of its last steps)
-    const bool ok = (row0 + r < nchunk) && (col < L + (WARM ? shift : 0) + 2) && (n < lim) && (!WARM || n >= 0);
+    const bool ok = (row0 + r < nchunk) && (col < L + 2) && (n < lim);
     p0 = ok ? g0[n] : 0.0;
-    p1 = ok ? g1[n] : ((WARM && n < 0) ? 1e300 : 0.0);
+    p1 = ok ? g1[n] : 0.0;
     p2 = ok ? g2[n] : 0.0;
   }
   __device__ __forceinline__ void commit(int tile, int group) {
@@ -197,7 +198,6 @@ __device__ __forceinline__ StagedSeries make_staged(const BatchParams& P, int b,
   s.row0 = blockIdx.x * 64;
   s.nchunk = P.nchunk;
   s.lane = threadIdx.x;
-  s.shift = 0;
   s.p0 = s.p1 = s.p2 = 0.0;
   return s;
 }
@@ -694,45 +694,72 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
 // chunk's start state depends on everything before it.  On series that FORGET -- the decay between samples is not
 // small, e.g. the paper's accuracy family (paper/figures/error/error.py:24-25: mean spacing 0.8, c >= 1): after a
 // few tens of samples the state no longer depends on where it started -- they are pure overhead: every chunk runs
-// the reference recurrence itself (replay_chunk: ~1x the reference's arithmetic, two waves per SIMD) from the ZERO
+// the reference recurrence itself (replay_chunk: ~1x the reference's arithmetic, two waves per SIMD, reading a padded
+// chunk-interleaved copy of the series that carries every chunk's warm-up rows: relayout_warm_kernel) from the ZERO
 // state K samples before its first sample, counts nothing during those K warm-up steps, and the state it has
 // reached at its first sample is compared with the state the PREVIOUS chunk reaches at that very sample
 // (warm_check_kernel).  Chunk 0 starts from the true zero state, so agreement at every boundary certifies all
 // start states by induction; a problem with a mismatch above warm_resid, a flagged pivot or a non-finite partial
 // is left to the scan pipeline (need_scan).  K is chosen per problem on the host from the slowest decay rate and
 // the time the K samples before every chunk boundary span (api.hip); the check makes that choice safe, not just
-// plausible.  No interleaved copy, no prefix, no corrections.
+// plausible.  No prefix, no corrections, no LDS.
 // ---------------------------------------------------------------------------
-using WarmSeries = StagedSeriesT<false, true>;
+// The warm kernel's view of the series: a lane walks down ITS column of the warm copy (one coalesced 512-B wave
+// load per array and step), rows are prefetched PF steps ahead into registers, every load is unguarded (the copy is
+// padded), the offset is one running wave-uniform value.  No LDS: the kernel's occupancy is set by its registers
+// alone (two waves per SIMD; the LDS-staged tiles of StagedSeries would allow five waves per CU).
+struct WarmQueueSeries {
+  static constexpr int PF = 4;
+  const double *tp, *dp, *yp;  // the lane's column, at the row of its first warm-up step
+  long stride;                 // doubles between rows (= chunks of the warm path)
+  long o;                      // offset of the next row to fetch for diag / y (t: one row further)
+  double tq[PF], dq[PF], yq[PF];  // at step i: tq[k] = t(i + 2 + k), dq[k] = diag(i + 1 + k), yq[k] = y(i + 1 + k)
+  __device__ __forceinline__ void prologue() {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      tq[k] = tp[(2 + k) * stride];
+      dq[k] = dp[(1 + k) * stride];
+      yq[k] = yp[(1 + k) * stride];
+    }
+    o = (1 + PF) * stride;
+  }
+  // (replay_chunk asks for t(0), t(1), diag(0), y(0) once, then for t(i + 2), diag(i + 1), y(i + 1) at step i)
+  __device__ __forceinline__ double t(int idx) const { return idx < 2 ? tp[idx * stride] : tq[0]; }
+  __device__ __forceinline__ double diag(int idx) const { return idx < 1 ? dp[0] : dq[0]; }
+  __device__ __forceinline__ double y(int idx) const { return idx < 1 ? yp[0] : yq[0]; }
+  __device__ __forceinline__ void step_begin(int) {}
+  __device__ __forceinline__ void step_end(int) {
+#pragma unroll
+    for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
+    tq[PF - 1] = tp[o + stride];
+    dq[PF - 1] = dp[o];
+    yq[PF - 1] = yp[o];
+    o += stride;
+  }
+};
 
 template <int JR, int JC, bool FAST>
 __global__ void __launch_bounds__(64) warm_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
-  __shared__ double tiles[2 * 3 * 64 * 9];
   const int b = blockIdx.y;
   const int K = P.wK[b];
   if (K <= 0) return;  // this problem takes the scan (wave-uniform)
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool mine = c < P.wnchunk;
+  const int cc = mine ? c : P.wnchunk - 1;  // (lanes past the last chunk recompute it and store nothing)
   Problem<JR, JC> p;
   load_problem<JR, JC>(P, b, p);
-  WarmSeries src;
-  src.lds = tiles;
-  src.g0 = P.t + b * P.t_stride;
-  src.g1 = P.diag + b * P.diag_stride;
-  src.g2 = P.y + b * P.y_stride;
-  src.lim = P.N;
-  src.L = P.wL;
-  src.row0 = blockIdx.x * 64;
-  src.nchunk = P.wnchunk;
-  src.lane = threadIdx.x;
-  src.shift = K;
-  src.p0 = src.p1 = src.p2 = 0.0;
-  const long slot = (long)b * P.wnchunk + (mine ? c : 0);
+  WarmQueueSeries src;
+  const long first = (long)(P.wKpad - K) * P.wnchunk + cc;
+  src.tp = P.wt + b * P.wt_stride + first;
+  src.dp = P.wdiag + b * P.wdiag_stride + first;
+  src.yp = P.wy + b * P.wy_stride + first;
+  src.stride = P.wnchunk;
+  const long slot = (long)b * P.wnchunk + cc;
   double ld, qd;
   int flag;
   double endst[Wd::START];
-  replay_chunk<JR, JC, 0, FAST>(p, src, P.wL + K, P.N, c * P.wL - K, nullptr, &ld, &qd, &flag, nullptr, nullptr,
+  replay_chunk<JR, JC, 0, FAST>(p, src, P.wL + K, P.N, cc * P.wL - K, nullptr, &ld, &qd, &flag, nullptr, nullptr,
                                 nullptr, nullptr, 0, endst, K, mine ? P.wstarts + slot * Wd::START : nullptr);
   if (!mine) return;
   double* e = P.wends + slot * Wd::START;
@@ -899,6 +926,9 @@ void launch_deinterleave_factor(const double* phi_i, const double* u_i, const do
 // [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api.hip).
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, int pad_kind, hipStream_t s);
+// [problem][n] -> the warm kernel's [problem][row][chunk], row r of chunk c = sample c L - Kpad + r (api.hip)
+void launch_relayout_warm(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L,
+                          int nchunk, int Kpad, int rows, int pad_kind, hipStream_t s);
 
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);
