@@ -171,6 +171,11 @@ class GP(ModelSet):
             if quiet:
                 return -np.inf
             raise
+        except BaseException:
+            # compute() consumes the hint; if the recompute failed before reaching it (a kernel or mean model
+            # raising), withdraw it so that an unrelated later compute() does not fold a stale vector in
+            self.solver._hint_rhs(np.empty(0))
+            raise
         if y.ndim > 1:
             raise ValueError("dimension mismatch")
         logdet = self.solver.log_determinant()

@@ -18,6 +18,7 @@
 #include "clr_batch_kernels.h"
 #include "clr_carma.h"
 #include "clr_generic_kernels.h"
+#include "clr_small.h"
 #include "clr_wide.h"
 
 namespace clr {
@@ -317,6 +318,7 @@ struct clr_solver {
   std::vector<double> host_rhs;
   DevBuf rhs;
   bool rhs_hint = false, have_quad = false;
+  bool coeffs_lazy = false;             // host_coeffs not yet on the device (the one-launch route passes them as arguments)
   double cached_quad = 0.0;
   int* ws_flags = nullptr;
   size_t ws_flags_cap = 0;
@@ -361,8 +363,8 @@ struct clr_batch {
   int warm_forced_K = 0;
   int warm_explicit_chunks = 0;       // chunk count asked for through clr_batch_set_chunks (0: automatic)
   int wnchunk = 0, wL = 0;            // the warm path's own chunking
-  static const int WARM_NK = 5;
-  int warm_cand[WARM_NK] = {8, 16, 32, 64, 128};
+  static const int WARM_NK = 10;
+  int warm_cand[WARM_NK] = {8, 12, 16, 24, 32, 48, 64, 80, 96, 128};
   std::vector<double> warm_span;      // [B or 1][WARM_NK] shortest time the K samples before a chunk boundary span
   std::vector<int> warm_K;            // [B] warm-up steps per problem of the current coefficients (0: scan)
   bool warm_active = false;           // the current (series, coefficients) pair runs the warm path
@@ -634,8 +636,58 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     hc.insert(hc.end(), b_comp, b_comp + J_comp);
     hc.insert(hc.end(), c_comp, c_comp + J_comp);
     hc.insert(hc.end(), d_comp, d_comp + J_comp);
-    if ((st = stage_upload(s, s->coeffs, hc.data(), hc.size())) != CLR_OK) return st;
   }
+  s->coeffs_lazy = false;
+
+  // One short series of a narrow kernel: the whole factorisation in ONE launch and one upload (small_kernels.hip);
+  // it settles the problem itself when every chunk boundary is consistent and no pivot is flagged, and hands it to
+  // the general route below otherwise.
+  if (!has_general && clr::small_compute_supported(J_real, J_comp, N) && !getenv("CLR_NO_SMALL_SOLVER")) {
+    const size_t ELEM = (size_t)J * J + 2 * J + (size_t)J * (J + 1);
+    int threads = 64;
+    while (threads < 256 && threads * 8 < N && (size_t)threads * 2 * ELEM * sizeof(double) <= 60000) threads *= 2;
+    clr::SmallParams S;
+    memset(&S, 0, sizeof(S));
+    S.N = N;
+    S.L = (N + threads - 1) / threads;
+    memcpy(S.coeff, s->host_coeffs.data(), s->host_coeffs.size() * sizeof(double));
+    S.jitter = jitter;
+    // t | diag | right-hand side: one block of the pinned arena, one copy; t stays at the head of s->t (predict)
+    const size_t words = (size_t)N * (use_rhs ? 3 : 2);
+    if ((st = s->t.reserve((size_t)3 * N)) != CLR_OK) return st;
+    double* stage = arena_take(s, words);
+    if (stage) {
+      memcpy(stage, x, (size_t)N * sizeof(double));
+      memcpy(stage + N, diag, (size_t)N * sizeof(double));
+      if (use_rhs) memcpy(stage + 2 * (size_t)N, s->host_rhs.data(), (size_t)N * sizeof(double));
+      HIP_TRY(hipMemcpyAsync(s->t.p, stage, words * sizeof(double), hipMemcpyHostToDevice, stream));
+      S.t = s->t.p; S.diag = s->t.p + N; S.y = use_rhs ? s->t.p + 2 * (size_t)N : nullptr;
+      S.phi = s->phi.p; S.u = s->u.p; S.W = s->W.p; S.D = s->D.p;
+      S.out = s->scalars.p;
+      S.max_residual = 1e-11;
+      double dmax = 0.0;
+      for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
+      const bool fast = dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT;
+      if (clr::launch_small_compute(J_real, J_comp, S, threads, fast, stream)) {
+        HIP_TRY(hipGetLastError());
+        double back_local[4];
+        double* pinned_back = arena_take(s, 4);
+        double* back = pinned_back ? pinned_back : back_local;
+        HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (back[0] == 0.0) {
+          s->coeffs_lazy = true;
+          s->log_det = back[1];
+          if (use_rhs) { s->cached_quad = back[2]; s->have_quad = true; }
+          s->computed = 1;
+          return CLR_OK;
+        }
+        // (not settled: indefinite, ill-conditioned or inconsistent -- the general route decides)
+        arena_reset(s, (size_t)3 * N + 2 * J_real + 4 * J_comp + 16);
+      }
+    }
+  }
+  if ((st = stage_upload(s, s->coeffs, s->host_coeffs.data(), s->host_coeffs.size())) != CLR_OK) return st;
   if ((st = stage_upload(s, s->t, x, (size_t)N)) != CLR_OK) return st;
 
   int h_status = 0;
@@ -1127,6 +1179,10 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
   int st = sweep_common(s, n_y, 1, y);  // also checks N / computed (:600-601)
   if (st != CLR_OK) return st;
   if (M <= 0) return CLR_OK;
+  if (s->coeffs_lazy) {  // (the one-launch compute passed the coefficients as kernel arguments)
+    if ((st = upload(s->coeffs, s->host_coeffs.data(), s->host_coeffs.size(), s->stream)) != CLR_OK) return st;
+    s->coeffs_lazy = false;
+  }
   if (s->t.cap < (size_t)s->N || s->coeffs.p == nullptr)
     return fail(CLR_UNSUPPORTED,
                 "predict needs the inputs of compute(); a solver restored from a pickled "
@@ -1487,9 +1543,9 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
     if (!(c <= h->cmax)) h->cmax = c;
   }
   // warm-started recurrence: warm-up steps per problem from its slowest decay rate and the time the samples in front
-  // of its chunk boundaries span: exp(-c_min x span) <= exp(-37) = 8.5e-17 -- what is left of ANY start state after
-  // the warm-up is below the rounding of the state (the update by the data only forgets faster); the boundary check
-  // of warm_check_kernel certifies the choice
+  // of its chunk boundaries span: exp(-c_min x span) <= exp(-32) = 1.3e-14 -- what is left of ANY start state after
+  // the warm-up by the decay alone, three orders below the tolerance of the boundary check (the update by the data
+  // only forgets faster); the check of warm_check_kernel certifies the choice
   h->warm_active = false;
   if (h->warm_mode != 0 && h->wnchunk >= 2 && h->have_series && !h->warm_span.empty()) {
     h->warm_K.assign(B, 0);
@@ -1505,7 +1561,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
         for (int j = 0; j < h->J_comp; ++j) { const double c = c_comp[b * h->J_comp + j]; if (!(c >= cmin)) cmin = c; }
         const double* span = &h->warm_span[(shared ? 0 : b) * clr_batch::WARM_NK];
         for (int k = 0; k < clr_batch::WARM_NK && cmin > 0.0; ++k)
-          if (cmin * span[k] >= 37.0) {
+          if (cmin * span[k] >= 32.0) {
             K = h->warm_cand[std::min(k + h->warm_boost, clr_batch::WARM_NK - 1)];
             if (K > h->wL / 2) K = 0;
             break;

@@ -102,7 +102,9 @@ int clr_solver_compute(clr_solver* s, double jitter,
 /* Optional, not in the reference: announce the vector the caller is about to hand to dot_solve (GP.log_likelihood
  * knows y before it factorises, celerite.py:180-215).  The NEXT clr_solver_compute then folds b^T K^-1 b into its own
  * pass over the series (widths 1..64 without general terms) and clr_solver_dot_solve returns that value when it is
- * called with the very same vector (compared byte for byte); any other vector takes the ordinary sweep.  One shot. */
+ * called with the very same vector (compared byte for byte); any other vector takes the ordinary sweep.  One shot:
+ * the hint is consumed by the next clr_solver_compute whatever its outcome (a hint of another length is dropped
+ * there); n_b = 0 withdraws a hint that will not be followed by a compute. */
 int clr_solver_hint_rhs(clr_solver* s, int n_b, const double* b);
 
 /* Solver::computed / log_determinant, solver.h:74-81 (solver.cpp:620-634). */
@@ -248,8 +250,8 @@ int clr_batch_set_summarize_mode(clr_batch* h, int mode);
  * at its first sample is checked against the state the previous chunk reaches there (relative mismatch <= the
  * max_residual of clr_batch_set_certificate); the first chunk starts from the true zero state, so agreement at every
  * boundary certifies all of them.  A problem with a mismatch, a flagged pivot or no usable K goes through the scan
- * pipeline when the results are fetched.  mode -1 (default): per problem, the smallest K of 8, 16, ... 256 with
- * exp(-c_min x (time the K samples before any chunk boundary span)) <= exp(-37), used when at least half of the batch
+ * pipeline when the results are fetched.  mode -1 (default): per problem, the smallest K of 8, 12, 16, ... 128 with
+ * exp(-c_min x (time the K samples before any chunk boundary span)) <= exp(-32), used when at least half of the batch
  * has one; 0: off; 1: every problem with `forced_warmup` steps (tests: the check then decides).  Widths 1..8, fused
  * log-likelihood only (materialising / forced-exact runs take the scan). */
 int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup);
