@@ -1,5 +1,5 @@
-// celerite_amd/csrc/wsweep_kernels.hip -- dot_solve / solve on a stored factor of width <= 32 (and dot_L at any
-// width) as chunked affine scans, one WAVE per chunk (single-solver API, series of N >= 2048).
+// celerite_amd/csrc/wsweep_kernels.hip -- dot_solve / solve on a stored factor of width <= 64 (and dot_L at any
+// width) as chunked affine scans, one WAVE per chunk (single-solver API, series of N >= 2048; N >= 512 above width 8).
 //
 // The sweeps (cholesky.h:236-260, :343-357) are f <- p o (f + g x_prev) ; x = in - h . f with
 // (p, g, h, in) = (phi, W, u, b) forward and (phi, u, W, x / D) backward: AFFINE on z = (f, x) in
@@ -133,21 +133,26 @@ wsweep_summarize_kernel(const SweepParams P) {
 template <int JP, int NW>
 __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParams P) {
   constexpr int H = (JP + 2) / 2;  // z is read back in two halves of H (columns 0 .. JP+1, the last one padding)
+  constexpr bool BIG = JP >= 64;   // width 64: K = 65 rows for 64 lanes -- lane 0 also owns row 64 (the x row)
   __shared__ double zbuf[2][2 * H];
   const int J = P.J, K = J + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rhs = blockIdx.x;
   const bool have = lane < K;
+  const bool have2 = BIG && lane == 0 && K > 64;
   const double* in = P.in + (long)rhs * P.N;
   // (no aliasing between the maps and the starts: the fetch must not wait for the store of a start)
   const double* __restrict__ elems = P.elems;
   double* __restrict__ starts = P.starts;
-  if (wave == 0 && lane < 2 * H) {
+  if (wave == 0) {
     // the sweep's first sample: x_0 = b_0 (cholesky.h:238) / x_{N-1} / D_{N-1} (:249,251)
-    double z = 0.0;
-    if (lane == J) z = P.backward ? in[P.N - 1] / P.D[P.N - 1] : in[0];
-    zbuf[0][lane] = z;
-    zbuf[1][lane] = 0.0;
+    for (int i = lane; i < 2 * H; i += 64) {
+      double z = 0.0;
+      if (i == J) z = P.backward ? in[P.N - 1] / P.D[P.N - 1] : in[0];
+      zbuf[0][i] = z;
+      zbuf[1][i] = 0.0;
+    }
   }
   double m[2 * H], aff = 0.0;
+  double m2[BIG ? 2 * H : 1], aff2 = 0.0;
   const int lrow = min(lane, K - 1);
   // every address in range and no select on the loaded values (a select would wait for them right here):
   // the padding columns j >= K re-read column K-1 and meet z_j = 0; lanes >= K compute a value nobody stores
@@ -156,6 +161,11 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
 #pragma unroll
     for (int j = 0; j < 2 * H; ++j) m[j] = M[(long)min(j, K - 1) * K + lrow];
     aff = M[(long)(K + rhs) * K + lrow];
+    if (BIG) {
+#pragma unroll
+      for (int j = 0; j < 2 * H; ++j) m2[j] = M[(long)min(j, K - 1) * K + (K - 1)];
+      aff2 = M[(long)(K + rhs) * K + (K - 1)];
+    }
   };
   if (wave < P.nchunk) fetch(wave);
   __syncthreads();
@@ -169,6 +179,7 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
 #pragma unroll
       for (int j = 0; j < H; ++j) z1[j] = zc[H + j];
       const double zmine = zc[min(lane, 2 * H - 1)];
+      const double zlast = zc[K - 1];
       double a0 = aff, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // (z_j = 0 for the padding columns j >= K)
 #pragma unroll
       for (int j = 0; j < H; ++j) {
@@ -179,10 +190,17 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
       for (int j = 0; j < H; ++j) {
         if (j % 2 == 0) a2 = fma(m[H + j], z1[j], a2); else a3 = fma(m[H + j], z1[j], a3);
       }
+      double b0 = aff2, b1 = 0.0;
+      if (BIG) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) { b0 = fma(m2[j], z0[j], b0); b1 = fma(m2[H + j], z1[j], b1); }
+      }
       if (have) zbuf[(c + 1) & 1][lane] = (a0 + a1) + (a2 + a3);
+      if (have2) zbuf[(c + 1) & 1][K - 1] = b0 + b1;
       // (the store after the arithmetic: issued before it, the wait for this chunk's map -- vmcnt counts
       // loads and stores in order -- would also wait for the store to be acknowledged)
       if (have) starts[((long)rhs * P.nchunk + c) * K + lane] = zmine;
+      if (have2) starts[((long)rhs * P.nchunk + c) * K + K - 1] = zlast;
       if (c + NW < P.nchunk) fetch(c + NW);
     }
     // LDS traffic only: a plain __syncthreads() would also wait for the fetch just issued (vmcnt(0))
@@ -437,7 +455,10 @@ void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s) {
 
 // (measured at N = 1e5, width 8: 0.29 ms against 1.35 ms for the lane-per-chunk scan of sweep_kernels.hip, which
 // keeps the series of 256 <= N < 2048)
-bool wsweep_scan_supported(int N, int J) { return J >= 1 && J <= 32 && N >= 2048; }
+// round 3: widths 33..64 too (summarize: a lane's column is up to 65 doubles, one wave per SIMD; prefix: at width 64 the
+// chunk map has 65 rows, lane 0 owns two), and shorter series at widths above 8 (the lane-per-chunk scan of
+// sweep_kernels.hip stops at width 8; a sequential sweep costs 0.23 us per step)
+bool wsweep_scan_supported(int N, int J) { return J >= 1 && J <= 64 && (N >= 2048 || (J > 8 && N >= 512)); }
 
 // the sequential prefix costs 0.3-0.6 us per chunk, the parallel phases 0.4-0.8 us per step
 int wsweep_chunks(int N) {
@@ -462,11 +483,18 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
   if (P.J <= 8) hipLaunchKernelGGL((wsweep_summarize_kernel<8>), gsum, dim3(64), 0, s, P);
   else if (P.J <= 16) hipLaunchKernelGGL((wsweep_summarize_kernel<16>), gsum, dim3(64), 0, s, P);
   else if (P.J <= 24) hipLaunchKernelGGL((wsweep_summarize_kernel<24>), gsum, dim3(64), 0, s, P);
-  else hipLaunchKernelGGL((wsweep_summarize_kernel<32>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 32) hipLaunchKernelGGL((wsweep_summarize_kernel<32>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 40) hipLaunchKernelGGL((wsweep_summarize_kernel<40>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 48) hipLaunchKernelGGL((wsweep_summarize_kernel<48>), gsum, dim3(64), 0, s, P);
+  else if (P.J <= 56) hipLaunchKernelGGL((wsweep_summarize_kernel<56>), gsum, dim3(64), 0, s, P);
+  else hipLaunchKernelGGL((wsweep_summarize_kernel<64>), gsum, dim3(64), 0, s, P);
   if (P.J <= 8) hipLaunchKernelGGL((wsweep_prefix_kernel<8, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
   else if (P.J <= 16) hipLaunchKernelGGL((wsweep_prefix_kernel<16, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
   else if (P.J <= 24) hipLaunchKernelGGL((wsweep_prefix_kernel<24, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
-  else hipLaunchKernelGGL((wsweep_prefix_kernel<32, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
+  else if (P.J <= 32) hipLaunchKernelGGL((wsweep_prefix_kernel<32, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
+  else if (P.J <= 48) hipLaunchKernelGGL((wsweep_prefix_kernel<48, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
+  else if (P.J <= 62) hipLaunchKernelGGL((wsweep_prefix_kernel<62, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((wsweep_prefix_kernel<64, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
   hipLaunchKernelGGL(wsweep_replay_kernel, dim3(P.nchunk, P.nrhs), dim3(64), 0, s, P);
   if (P.quad) hipLaunchKernelGGL(wsweep_finalize_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
 }

@@ -593,10 +593,10 @@ def test_sharding_with_the_default_kernel_selection_is_bit_identical(spoiler):
     handed the batch-wide maxima), so with the DEFAULT summarize mode the results are bit-identical under any
     sharding -- also on a heterogeneous batch where one problem alone rules out the lazy-decay kernel (a huge
     decay rate) or the fast sincos (a huge frequency), which a shard without that problem would otherwise pick."""
-    B, N, JR, JC, nchunk = 19, 6000, 2, 3, 64
+    B, N, JR, JC, nchunk = 19, 20000, 2, 3, 64
     case = synthetic(B, N, JR, JC, "bench", seed=15)
     if spoiler == "decay":
-        case["c_comp"][17, 1] = 3e3       # c dx ~ 0.5: no lazy decay for the plan that holds it
+        case["c_comp"][17, 1] = 3e3       # c dx ~ 0.15: no lazy decay for the plan that holds it
     if spoiler == "frequency":
         case["d_comp"][2, 0] = 3e9        # d t_max >= 1e9: library sincos for the plan that holds it
     plan = batch.BatchedGP(B, N, JR, JC)

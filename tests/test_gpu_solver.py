@@ -552,10 +552,16 @@ def test_hinted_right_hand_side_is_the_same_quadratic_form(JR, JC, N):
 
 @pytest.mark.parametrize("JR,JC,N,general", [(1, 4, 2048, False), (3, 5, 4097, True), (0, 8, 30000, False),
                                               (2, 15, 12345, False), (0, 16, 100000, False), (9, 0, 5000, False),
-                                              (2, 20, 6000, False)])
+                                              (2, 20, 6000, False),
+                                              # round 3: widths 33..64 (incl. general terms: 37 + 3 = 40, 61 + 3 = 64),
+                                              # the 65-row chunk map of width 64, short wide series (N >= 512)
+                                              (0, 20, 6000, False), (1, 18, 3000, True), (4, 22, 9000, False),
+                                              (0, 28, 2500, False), (1, 30, 4000, True), (0, 32, 5000, False),
+                                              (63, 0, 2100, False), (3, 13, 600, False), (2, 30, 777, False),
+                                              (0, 5, 512, False)])
 def test_wide_sweeps_are_chunked_scans(JR, JC, N, general):
-    """dot_solve / solve (widths 9..32) and dot_L (widths 9..64) on a stored factor of N >= 2048 run as
-    chunked scans (csrc/wsweep_kernels.hip: lane = column of the chunk's affine map / lane = row):
+    """dot_solve / solve / dot_L (widths 9..64) on a stored factor run as chunked scans (csrc/wsweep_kernels.hip:
+    lane = column of the chunk's affine map / lane = row) from N = 2048 (N = 512 above width 8) on:
     same numbers as the oracle's sequential sweeps (cholesky.h:218-431), several right-hand sides."""
     rng = np.random.RandomState(JR * 100 + JC + N % 7)
     t = np.sort(rng.uniform(0, 0.05 * N, N))
