@@ -1624,11 +1624,11 @@ static bool split_active(const clr_batch* h) {
 static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   if (!h->have_series || !h->have_coeffs)
     return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
-  if (materialize && !h->launch)
-    return fail(CLR_UNSUPPORTED, "materialising batched runs support widths 1..8; use CholeskySolver for wider kernels");
   int st = CLR_OK;
   if (materialize && !h->have_factor) {
-    const size_t B = (size_t)h->B, J = (size_t)h->J, cells = (size_t)h->L * h->nchunk;
+    // widths 1..8: chunk-interleaved device layout (replay_chunk, MATERIALIZE == 2); widths 9..64: the wide kernels
+    // write the reference's own storage per problem (wide_scan_kernel, MODE 0: phi, u [N-1][J], W [N][J], D [N])
+    const size_t B = (size_t)h->B, J = (size_t)h->J, cells = h->launch ? (size_t)h->L * h->nchunk : (size_t)h->N;
     if ((st = h->phi.reserve(B * J * cells)) != CLR_OK) return st;
     if ((st = h->u.reserve(B * J * cells)) != CLR_OK) return st;
     if ((st = h->W.reserve(B * J * cells)) != CLR_OK) return st;
@@ -1705,6 +1705,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.wKpad = h->wKpad; P.wrows = h->wrows;
   }
   P.only_pending = h->in_fallback ? 1 : 0;
+  P.wide_materialize = (materialize && !h->launch) ? 1 : 0;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
 }
@@ -2266,6 +2267,14 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   if (!h->have_factor) return fail(CLR_NOT_COMPUTED, "no materialising run has been made");
   if (p < 0 || p >= h->B) return fail(CLR_INVALID_ARGUMENT, "problem index out of range");
   const size_t N = (size_t)h->N, J = (size_t)h->J, Nm1 = N - 1, cells = (size_t)h->L * h->nchunk;
+  if (!h->launch) {  // widths 9..64: already in the reference's storage, problem after problem
+    if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->phi.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->u.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (W) HIP_TRY(hipMemcpyAsync(W, h->W.p + p * J * N, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (D) HIP_TRY(hipMemcpyAsync(D, h->D.p + p * N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CLR_OK;
+  }
   if ((st = h->fphi.reserve(J * Nm1)) != CLR_OK) return st;
   if ((st = h->fu.reserve(J * Nm1)) != CLR_OK) return st;
   if ((st = h->fW.reserve(J * N)) != CLR_OK) return st;

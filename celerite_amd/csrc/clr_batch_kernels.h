@@ -18,6 +18,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "clr_core.h"
 

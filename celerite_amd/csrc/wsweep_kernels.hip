@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
     }
   }
   double m[2 * H], aff = 0.0;
-  double m2[BIG ? 2 * H : 1], aff2 = 0.0;
+  // BIG: row K-1 of the map spread over the lanes (lane j holds its entry in column j), the 65th column and the
+  // affine part wave-uniform; the row's product with z is a wave reduction
+  double m2 = 0.0, m2last = 0.0, aff2 = 0.0;
   const int lrow = min(lane, K - 1);
   // every address in range and no select on the loaded values (a select would wait for them right here):
   // the padding columns j >= K re-read column K-1 and meet z_j = 0; lanes >= K compute a value nobody stores
@@ -162,8 +164,8 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
     for (int j = 0; j < 2 * H; ++j) m[j] = M[(long)min(j, K - 1) * K + lrow];
     aff = M[(long)(K + rhs) * K + lrow];
     if (BIG) {
-#pragma unroll
-      for (int j = 0; j < 2 * H; ++j) m2[j] = M[(long)min(j, K - 1) * K + (K - 1)];
+      m2 = M[(long)min(lane, K - 1) * K + (K - 1)];
+      m2last = M[(long)(K - 1) * K + (K - 1)];
       aff2 = M[(long)(K + rhs) * K + (K - 1)];
     }
   };
@@ -190,13 +192,10 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
       for (int j = 0; j < H; ++j) {
         if (j % 2 == 0) a2 = fma(m[H + j], z1[j], a2); else a3 = fma(m[H + j], z1[j], a3);
       }
-      double b0 = aff2, b1 = 0.0;
-      if (BIG) {
-#pragma unroll
-        for (int j = 0; j < H; ++j) { b0 = fma(m2[j], z0[j], b0); b1 = fma(m2[H + j], z1[j], b1); }
-      }
+      double b0 = 0.0;
+      if (BIG && K > 64) b0 = wsum(m2 * zmine) + fma(m2last, zlast, aff2);  // (lane j: column j < 64; then column 64)
       if (have) zbuf[(c + 1) & 1][lane] = (a0 + a1) + (a2 + a3);
-      if (have2) zbuf[(c + 1) & 1][K - 1] = b0 + b1;
+      if (have2) zbuf[(c + 1) & 1][K - 1] = b0;
       // (the store after the arithmetic: issued before it, the wait for this chunk's map -- vmcnt counts
       // loads and stores in order -- would also wait for the store to be acknowledged)
       if (have) starts[((long)rhs * P.nchunk + c) * K + lane] = zmine;

@@ -201,8 +201,9 @@ typedef struct clr_batch clr_batch;
  *          config 5: 16 complex terms); fused log-likelihood only.  One chunk = the
  *          reference recurrence itself; widths <= 32 are cut into chunks (two-pass
  *          scan) when B alone leaves SIMDs idle (clr_batch_set_chunks(h, 0) picks
- *          2048 / B, at most 16).  Materialising runs, layouts and the exact/replay
- *          switch do not apply;
+ *          2048 / B, at most 16).  Materialising runs write the reference's storage directly
+ *          (every chunk replayed from its scanned start state and checked, as CholeskySolver.compute
+ *          does); layouts do not apply;
  *   else   CLR_UNSUPPORTED. */
 clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device);
 void clr_batch_destroy(clr_batch* h);

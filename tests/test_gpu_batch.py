@@ -608,7 +608,8 @@ def test_sharding_with_the_default_kernel_selection_is_bit_identical(spoiler):
         want = plan.log_likelihood()
     finally:
         plan.close()
-    assert kernel == ("role split, lazy decay" if spoiler != "decay" else "role split")
+    # (a huge decay rate or frequency rules the lazy-decay / rotated-phase kernel out for whoever holds that problem)
+    assert kernel == ("role split, lazy decay" if spoiler == "none" else "role split")
     ndev = batch.device_count()
     for S in (1, 2, 3, 8):
         sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
@@ -1002,3 +1003,30 @@ def test_warm_start_mixed_batch_and_indefinite_neighbours():
     assert np.array_equal(st, s1) and plan2.warm_start()["settled"] == B - 2
     assert np.max(np.abs(ld - d1) / np.abs(d1)) <= REL and np.max(np.abs(q - q1) / np.abs(q1)) <= REL
     plan.close(); plan2.close()
+
+
+@pytest.mark.parametrize("JR,JC,N,nchunk", [(1, 5, 3000, 6), (0, 16, 4000, 8), (2, 19, 1500, 0), (64, 0, 700, 0)])
+def test_wide_materialised_factor_matches_oracle_state(JR, JC, N, nchunk):
+    """Materialising batched runs at widths 9..64 (missing 3): the wide kernels write phi, u, W, D in the
+    reference's storage (solver.cpp:36-42), chunked (widths <= 32) or as one sweep; compared with the oracle's state."""
+    case = synthetic(3, N, JR, JC, "bench", seed=8 + JR)
+    plan = batch.BatchedGP(3, N, JR, JC)
+    if nchunk:
+        plan.set_chunks(nchunk)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case))
+    ll, ld, q, st = plan.log_likelihood(materialize=True)
+    l0, d0, q0, s0 = _oracle(case)
+    assert np.array_equal(st, s0)
+    assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL and np.max(np.abs(q - q0) / np.abs(q0)) <= REL
+    for p in range(3):
+        phi, u, W, D = plan.factor(p)
+        r = ref.RefSolver()
+        r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)),
+                  case["t"][p], case["diag"][p])
+        _, _, _, logdet, rphi, ru, rW, rD = r.state()
+        assert np.allclose(phi, rphi, rtol=1e-13, atol=0)
+        assert np.allclose(u, ru, rtol=1e-12, atol=1e-15)
+        assert np.allclose(W, rW, rtol=1e-8, atol=1e-11)
+        assert np.allclose(D, rD, rtol=1e-10, atol=0)
+    plan.close()
