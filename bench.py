@@ -33,7 +33,14 @@ single-process alternative is the product's `ShardedBatchedGP` /
 
 Rank 0 prints ONE JSON line; `configs` under it carries BASELINE configs
 0, 1 and 4 (object API at N = 1e3; B = 256 x N = 1e4 width 4; B = 256 x N = 1e5
-width 32), each with its own time, rate, roofline and parity on a sample.
+width 32), each with its own time, rate, roofline and parity on a sample (and, for
+the batch configs, the histogram of problems by route and the conditioning record).
+`accuracy_family` is SURVEY.md 8(d)'s second input family at the headline shape
+(sparse sampling: the plan runs the warm-started plain recurrence instead of the
+scan); `sharded_product_path` times the product's own sharding (one process, one
+host thread + plan per shard: batch.ShardedBatchedGP) next to the process-per-GPU
+number `--gpus N` reports; `value_steady` is the 2.5 s steady-state leg of the
+real loop.
 """
 import argparse
 import json
@@ -577,10 +584,14 @@ def main(argv=None):
             "device_only": {"what": "the same kernels back to back, coefficients resident (round 1's `value`)",
                             "ms_per_step": dev_ms / K, "value": B / (dev_ms / K * 1e-3) * dist.world,
                             "kernels_ms": {k: v / K for k, v in dev_k.items()}},
-            "new_series_every_step": {"what": "device-only step including the relayout pass of fresh series",
+            "new_series_every_step": {"what": "device-only step including the relayout pass of series that are ALREADY in "
+                                              "HBM (relayout only: the host scan of t and the host->HBM copies of "
+                                              "clr_batch_set_series are not in it; their time for this batch is "
+                                              "set_series_host_ms, pageable host memory)",
                                       "ms_per_step": new_ms / max(K // 2, 1),
                                       "value": B / (new_ms / max(K // 2, 1) * 1e-3) * dist.world,
-                                      "relayout_ms": new_k["relayout"] / max(K // 2, 1)},
+                                      "relayout_ms": new_k["relayout"] / max(K // 2, 1),
+                                      "set_series_host_ms": plan.selection_bounds()["set_series_host_ms"]},
             "steady_state": {"seconds": steady_dt, "steps": n_steady, "value": B * n_steady / steady_dt * dist.world},
             "value_steady": B * n_steady / steady_dt * dist.world,
             "timed_region_s": dt,

@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(64) seg_advance_kernel(const SegParams S) {
 // its problem, in order, into parents[b][k].  32 lanes per segment: a state row and a
 // rider row (header comment); two segments per wave.
 // ---------------------------------------------------------------------------
-template <int J, int OCC = 1>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC))) group_compose_kernel(const SegParams S) {
+template <int J>
+__global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
   constexpr int HALF = 8, ROW = 16, GROUP = 32, NG = 2;
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int ELEM = J * J + J + SZ + J + SZ;
@@ -494,12 +494,9 @@ void launch_multilevel_prefix(const BatchParams& P, hipStream_t s) {
     SegParams S{elems[l], nullptr, nullptr, const_cast<double*>(elems[l + 1]), P.B, plan.n[l], plan.g[l], plan.n[l + 1],
                 nullptr};
     const long nseg = (long)P.B * S.np;
-    // (A/B switch: CLR_COMPOSE_OCC=2 holds the allocator to two waves per SIMD at widths 7, 8 -- 52 registers spilled)
-    static const int occ = getenv("CLR_COMPOSE_OCC") ? atoi(getenv("CLR_COMPOSE_OCC")) : 1;
-    if (occ == 2 && J >= 7)
-      hipLaunchKernelGGL((group_compose_kernel<J, 2>), dim3((unsigned)((nseg + 1) / 2)), dim3(64), 0, s, S);
-    else
-      hipLaunchKernelGGL((group_compose_kernel<J>), dim3((unsigned)((nseg + 1) / 2)), dim3(64), 0, s, S);
+    // (holding the allocator to two waves per SIMD at width 8 -- 308 -> 256 registers, 52 spilled -- was measured
+    //  slower: plan [8] 0.227 against 0.181 ms, profiles/r03g_compose_occupancy_ab.txt)
+    hipLaunchKernelGGL((group_compose_kernel<J>), dim3((unsigned)((nseg + 1) / 2)), dim3(64), 0, s, S);
   }
   {  // top: one segment per problem
     const int l = plan.levels;

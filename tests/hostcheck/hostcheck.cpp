@@ -215,6 +215,16 @@ extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const d
   return -1;
 }
 
+// The prefix planner (clr_core.h: plan_prefix), as the library calls it.
+extern "C" void hostcheck_plan_prefix(int nchunk, int levels, int g, int B, int J, int* out /* levels, g[3], n[4] */,
+                                      double* time_us) {
+  const PrefixPlan p = plan_prefix(nchunk, levels, g, B, J);
+  out[0] = p.levels;
+  for (int l = 0; l < 3; ++l) out[1 + l] = p.g[l];
+  for (int l = 0; l < 4; ++l) out[4 + l] = p.n[l];
+  *time_us = p.time_us;
+}
+
 // Accuracy probes for the two device math helpers (host instantiation).
 extern "C" void hostcheck_sincos(int n, const double* x, double* s, double* c) {
   for (int i = 0; i < n; ++i) sincos_fast(x[i], s + i, c + i);

@@ -241,3 +241,29 @@ def test_multilevel_prefix_keeps_the_reference_status_on_adversarial_problems(li
                 assert np.array_equal(st, s0), (trial, levels, g)
     finally:
         lib.hostcheck_set_prefix(0, 0)
+
+
+def test_prefix_planner(lib):
+    """clr_core.h: plan_prefix -- the level structure of the multi-level prefix.  Invariants for any request, and
+    the choices the measured time model makes (profiles/r03a_prefix_ab.txt): the headline shape (1024 problems x 64
+    chunks, width 8: the composition kernel is throughput-bound there) keeps the plain walk, BASELINE config 1
+    (256 x 125..250 chunks, width 4) and a single long series go multi-level."""
+    def plan(nchunk, levels=-1, g=0, B=1, J=8):
+        out = np.zeros(8, dtype=np.int32)
+        tm = C.c_double()
+        lib.hostcheck_plan_prefix(nchunk, levels, g, B, J, out.ctypes.data_as(C.POINTER(C.c_int)), C.byref(tm))
+        return int(out[0]), list(out[1:4]), list(out[4:8]), tm.value
+
+    for nchunk in (1, 2, 3, 7, 13, 64, 125, 250, 1000, 4096):
+        for levels, g in ((-1, 0), (0, 0), (1, 2), (1, 8), (2, 3), (3, 2), (3, 5)):
+            lv, gs, ns, tm = plan(nchunk, levels, g, B=7, J=5)
+            assert 0 <= lv <= 3 and ns[0] == nchunk and tm > 0
+            for l in range(3):
+                assert ns[l + 1] == (ns[l] + gs[l] - 1) // gs[l]
+                assert gs[l] >= 2 if l < lv else gs[l] == 1
+                if l < lv:
+                    assert ns[l] >= 2 * gs[l]          # a level keeps at least two groups
+    assert plan(64, B=1024, J=8)[0] == 0               # headline: the walk
+    assert plan(125, B=256, J=4)[0] >= 1 and plan(250, B=256, J=4)[0] >= 1
+    lv, gs, ns, tm = plan(2048, B=1, J=8)
+    assert lv >= 2 and ns[lv] <= 64 and tm < 0.2 * plan(2048, 0, 0, B=1, J=8)[3]
