@@ -555,7 +555,7 @@ def test_hinted_right_hand_side_is_the_same_quadratic_form(JR, JC, N):
                                               (2, 20, 6000, False),
                                               # round 3: widths 33..64 (incl. general terms: 37 + 3 = 40, 61 + 3 = 64),
                                               # the 65-row chunk map of width 64, short wide series (N >= 512)
-                                              (0, 20, 6000, False), (1, 18, 3000, True), (4, 22, 9000, False),
+                                              (0, 20, 6000, False), (3, 17, 3000, True), (4, 22, 9000, False),
                                               (0, 28, 2500, False), (1, 30, 4000, True), (0, 32, 5000, False),
                                               (63, 0, 2100, False), (3, 13, 600, False), (2, 30, 777, False),
                                               (0, 5, 512, False)])
