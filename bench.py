@@ -95,6 +95,19 @@ def pmc_traffic(kernel, B, N, JR, JC, chunks):
     return None
 
 
+def pmc_traffic_other(key_prefix):
+    """HBM bytes per launch of the dominant kernel of one of the other shapes (profiles/pmc_latest.json:
+    other_shapes), by the prefix of its label; None if it was not measured."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        for k, v in rec.get("other_shapes", {}).items():
+            if k.startswith(key_prefix):
+                return v
+    except Exception:
+        pass
+    return None
+
+
 def make_inputs(B, N, J_real, J_comp, seed, d_spread=False):
     rng = np.random.RandomState(seed)
     t = np.sort(rng.rand(B, N), axis=1)
@@ -278,7 +291,8 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
                          "gamma_times_error_max": float(np.max(gam * eg))},
         "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
         "device_only": {"ms_per_step": dev_ms / steps, "value": B / (dev_ms / steps * 1e-3)},
-        "kernels_ms": per, "roofline": roofline_block(per, B, N, W),
+        "kernels_ms": per,
+        "roofline": roofline_block(per, B, N, W, pmc_traffic_other("config4") if (B, N, W) == (256, 100000, 32) else None),
         "cpu_oracle": {"ms_per_loglik": cpu * 1e3, "value": 1.0 / cpu, "cores": 1, "timing": "best of 3 (timer.py)"},
         "parity": {"problems_checked": int(S), "status_equal": bool(np.array_equal(st[:S], s0)),
                    "logdet_rel_max": rel_err(ld[:S][ok], d0[ok]), "quad_rel_max": rel_err(q[:S][ok], q0[ok]),
@@ -323,7 +337,8 @@ def accuracy_family_block(B, N, JR, JC, steps, sample, seed):
     S = min(sample, B)
     l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[:S] for c in coeffs], t[:S], diag[:S], y[:S], nthreads=1)
     ok = s0 == 0
-    roof = roofline_block({"warm recurrence + boundary check": per["summarize"]}, B, N, W)
+    roof = roofline_block({"warm recurrence + boundary check": per["summarize"]}, B, N, W,
+                          pmc_traffic_other("accuracy family") if (B, N, W, bool(warm["active"])) == (1024, 100000, 8, True) else None)
     return {
         "workload": "accuracy family (paper/figures/error/error.py:24-25): batch=%d x N=%d, width %d (%d real + %d "
                     "complex), t = sort(U(0, 0.8 N)), sigma = U(1, 1.5), y = N(0, 1)" % (B, N, W, JR, JC),
