@@ -398,8 +398,9 @@ class BatchedGP(object):
         _check(_load().clr_batch_set_library_trig(self._h, int(bool(force))))
 
     def set_profiling(self, on=True):
-        """Bracket the kernels of every following :meth:`enqueue` with HIP events."""
-        _check(_load().clr_batch_set_profiling(self._h, int(bool(on))))
+        """Bracket the kernels of every following :meth:`enqueue` with HIP events; ``on=2`` brackets the
+        summarize (dominant) kernel only: two event records per evaluation instead of seven."""
+        _check(_load().clr_batch_set_profiling(self._h, 2 if on == 2 else int(bool(on))))
 
     def profile(self):
         """``({kernel name: summed ms}, evaluations recorded)`` since :meth:`set_profiling`."""

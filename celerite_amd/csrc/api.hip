@@ -2064,7 +2064,7 @@ static const int PROF_NK = 6, PROF_MAX_STEPS = 4096;
 int clr_batch_set_profiling(clr_batch* h, int on) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  h->prof_on = on ? 1 : 0;
+  h->prof_on = (on == 2 && h->launch) ? 2 : (on ? 1 : 0);  // 2: only the summarize (dominant) kernel is bracketed (widths 1..8)
   h->prof_steps = 0;
   return CLR_OK;
 }
@@ -2076,6 +2076,7 @@ int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps)
   double k[PROF_NK] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < h->prof_steps; ++i)
     for (int j = 0; j < PROF_NK; ++j) {
+      if (h->prof_on == 2 && j != 1) continue;  // (only events 1 and 2 were recorded)
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, h->prof_events[(size_t)i * (PROF_NK + 1) + j],
                                   h->prof_events[(size_t)i * (PROF_NK + 1) + j + 1]));
@@ -2143,7 +2144,8 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     ev = &h->prof_events[(size_t)h->prof_steps * (PROF_NK + 1)];
     ++h->prof_steps;
   }
-  auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], h->stream); };
+  const bool all_marks = h->prof_on != 2;
+  auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
   h->evaluated = true;
   if (!h->launch) {
     mark(0);

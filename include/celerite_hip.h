@@ -371,6 +371,8 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
  * brackets its kernels with HIP events on the plan's stream (up to 4096 evaluations since
  * the switch); clr_batch_get_profile synchronises and returns the summed milliseconds per
  * kernel (same order as clr_batch_run_timed) and the number of evaluations recorded. */
+/* on = 2: only the summarize kernel (the dominant one; the warm-started recurrence when that runs) is bracketed --
+ * two event records per evaluation instead of seven (an event record costs ~5 us of stream time); widths 1..8. */
 int clr_batch_set_profiling(clr_batch* h, int on);
 int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps);
 
