@@ -61,6 +61,7 @@ def _load():
     lib.clr_batch_get_profile.argtypes = [C.c_void_p, _dp, _ip]
     lib.clr_batch_set_prefix_mode.argtypes = [C.c_void_p, C.c_int]
     lib.clr_batch_set_replay_source.argtypes = [C.c_void_p, C.c_int]
+    lib.clr_batch_set_general.argtypes = [C.c_void_p, C.c_int, _dp, C.c_long, _dp, C.c_long, _dp, C.c_long]
     lib.clr_batch_set_warm_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.clr_batch_get_warm_start.argtypes = [C.c_void_p] + [_ip] * 7
     lib.clr_batch_set_prefix_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -207,6 +208,25 @@ class BatchedGP(object):
             raise ValueError("dimension mismatch")
         jit = np.ascontiguousarray(np.broadcast_to(np.asarray(jitter, dtype=np.float64), (self.B,)))
         _check(_load().clr_batch_set_coefficients(self._h, _ptr(jit), *[_ptr(b) for b in blocks]))
+
+    def set_general(self, A, U, V):
+        """General semiseparable terms (``CholeskySolver.compute``'s ``A, U, V``; cholesky.h:65-72,148-152) for the
+        batch: ``A`` ``(B, N)`` or ``(N,)``, ``U`` and ``V`` ``(B, J_general, N)`` or ``(J_general, N)`` (shared by
+        all problems).  Empty ``U`` removes them.  The plan then runs the any-width sequential kernel."""
+        U, V, A = _f64(U), _f64(V), _f64(A)
+        if U.size == 0:
+            _check(_load().clr_batch_set_general(self._h, 0, None, 0, None, 0, None, 0))
+            return
+        if U.shape != V.shape or U.shape[-1] != self.N or U.ndim not in (2, 3):
+            raise ValueError("dimension mismatch")
+        JG = U.shape[-2]
+        if U.ndim == 3 and U.shape[0] != self.B:
+            raise ValueError("dimension mismatch")
+        if A.shape not in ((self.N,), (self.B, self.N)):
+            raise ValueError("dimension mismatch")
+        _check(_load().clr_batch_set_general(self._h, JG, _ptr(A), self.N if A.ndim == 2 else 0,
+                                             _ptr(U), JG * self.N if U.ndim == 3 else 0,
+                                             _ptr(V), JG * self.N if V.ndim == 3 else 0))
 
     # -- tuning -------------------------------------------------------------
     def set_chunks(self, nchunk):

@@ -378,6 +378,11 @@ struct clr_batch {
   bool warm_copy_pending = true;
   int* wints = nullptr;               // wflags [B * wnchunk] | need_scan [B] | K [B]
   size_t wints_cap = 0;
+  // general terms for the whole batch (clr_batch_set_general): the plan then evaluates through the any-width sequential
+  // kernel, one workgroup per problem (generic_kernels.hip: generic_loglike_batch_kernel)
+  int J_general = 0;
+  DevBuf gA, gU, gV;
+  long gA_stride = 0, gU_stride = 0, gV_stride = 0;
   int replay_source = -1;             // where the replay reads the series when summarize reads the chunk-interleaved
                                       // copy: 0 the same copy, 1 the row-major arrays staged through LDS, -1 auto
   bool relayout_pending = true;
@@ -1315,7 +1320,7 @@ void clr_batch_destroy(clr_batch* h) {
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
-                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY})
+                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1978,6 +1983,30 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   return CLR_OK;
 }
 
+int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
+                          const double* V, long V_stride) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (J_general < 0) return fail(CLR_INVALID_ARGUMENT, "J_general must be >= 0");
+  if (J_general == 0) {  // back to the celerite-terms-only plan
+    h->J_general = 0;
+    return CLR_OK;
+  }
+  if (!A || !U || !V) return fail(CLR_INVALID_ARGUMENT, "general terms need A, U and V");
+  if (h->J + J_general > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  const long N = h->N, UV = (long)J_general * N;
+  if ((A_stride != 0 && A_stride != N) || (U_stride != 0 && U_stride != UV) || (V_stride != 0 && V_stride != UV))
+    return fail(CLR_INVALID_ARGUMENT, "general-term strides must be 0 (shared) or the size of one problem's block");
+  auto count = [&](long sd, long one) { return (size_t)(sd == 0 ? one : one * (long)h->B); };
+  if ((st = upload(h->gA, A, count(A_stride, N), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gU, U, count(U_stride, UV), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gV, V, count(V_stride, UV), h->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->J_general = J_general;
+  h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  return CLR_OK;
+}
+
 int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup) {
   if (mode < -1 || mode > 1 || (mode == 1 && forced_warmup < 1))
     return fail(CLR_INVALID_ARGUMENT, "warm start: mode -1 (auto), 0 (off) or 1 (forced, with a warm-up length >= 1)");
@@ -2147,6 +2176,25 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   const bool all_marks = h->prof_on != 2;
   auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
   h->evaluated = true;
+  if (h->J_general > 0) {  // general terms: the any-width sequential recurrence, one workgroup per problem
+    if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms: use CholeskySolver");
+    h->warm_inflight = false;
+    clr::GenericBatch G;
+    memset(&G, 0, sizeof(G));
+    G.B = h->B; G.N = h->N; G.J_real = h->J_real; G.J_comp = h->J_comp; G.J_general = h->J_general;
+    G.a_real = P.a_real; G.c_real = P.c_real; G.a_comp = P.a_comp; G.b_comp = P.b_comp; G.c_comp = P.c_comp;
+    G.d_comp = P.d_comp; G.jitter = P.jitter;
+    G.t = h->t.p; G.diag = h->diag.p; G.y = h->y.p;
+    G.t_stride = h->t_stride; G.diag_stride = h->diag_stride; G.y_stride = h->y_stride;
+    G.A = h->gA.p; G.U = h->gU.p; G.V = h->gV.p;
+    G.A_stride = h->gA_stride; G.U_stride = h->gU_stride; G.V_stride = h->gV_stride;
+    G.out_ll = P.out_ll; G.out_logdet = P.out_logdet; G.out_quad = P.out_quad; G.out_status = P.out_status;
+    mark(0); mark(1);
+    clr::launch_generic_loglike_batch(G, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
   if (!h->launch) {
     mark(0);
     wide_launch(h, P, ev);

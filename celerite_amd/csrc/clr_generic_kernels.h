@@ -25,6 +25,21 @@ struct GenericProblem {
   const double* t;      // device [N]
 };
 
+// A batch of problems WITH general terms (cholesky.h:65-72,148-152; clr_batch_set_general): one workgroup per
+// problem, sequential in n exactly as the reference, compute (cholesky.h:100-179) fused with dot_solve
+// (:343-357) and log_determinant; nothing is stored but the four results per problem.
+struct GenericBatch {
+  int B, N, J_real, J_comp, J_general;
+  const double *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp, *jitter;  // device, [B][...] / [B]
+  const double *t, *diag, *y;
+  long t_stride, diag_stride, y_stride;  // per problem (0: one shared series)
+  const double *A, *U, *V;               // A [N], U / V row-major [J_general][N] per problem
+  long A_stride, U_stride, V_stride;     // per problem (0: shared)
+  double *out_ll, *out_logdet, *out_quad;
+  int* out_status;
+};
+void launch_generic_loglike_batch(const GenericBatch& G, hipStream_t s);
+
 // dot_solve / solve on a stored factor as chunked scans over n (sweep_kernels.hip).
 struct SweepParams {
   int N, J, nchunk, L, nrhs;

@@ -128,6 +128,137 @@ __global__ void __launch_bounds__(256) factor_generic_kernel(GenericProblem g, d
   if (tid == 0) { status[0] = 0; log_det[0] = ld; }
 }
 
+// ---------------------------------------------------------------------------
+// Batched fused log-likelihood with general terms: factor_generic_kernel's recurrence with the forward sweep of
+// dot_solve (cholesky.h:343-357) carried along -- f <- phi (f + W_{n-1} x_{n-1}), x_n = y_n - u~_n . f -- one
+// workgroup per problem (blockIdx.x), S in LDS.  status 2 = a pivot D_n < 0 with n >= 1 (cholesky.h:176).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) generic_loglike_batch_kernel(const GenericBatch G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, N = G.N, tid = threadIdx.x, nt = blockDim.x;
+  GenericProblem g;
+  g.N = N;
+  g.J_real = G.J_real; g.J_comp = G.J_comp; g.J_general = G.J_general;
+  g.J = G.J_real + 2 * G.J_comp + G.J_general;
+  g.a_real = G.a_real + (long)b * G.J_real; g.c_real = G.c_real + (long)b * G.J_real;
+  g.a_comp = G.a_comp + (long)b * G.J_comp; g.b_comp = G.b_comp + (long)b * G.J_comp;
+  g.c_comp = G.c_comp + (long)b * G.J_comp; g.d_comp = G.d_comp + (long)b * G.J_comp;
+  g.U = G.U ? G.U + (long)b * G.U_stride : nullptr;
+  g.V = G.V ? G.V + (long)b * G.V_stride : nullptr;
+  g.t = G.t + (long)b * G.t_stride;
+  const double* diag = G.diag + (long)b * G.diag_stride;
+  const double* y = G.y + (long)b * G.y_stride;
+  const double* A = G.A ? G.A + (long)b * G.A_stride : nullptr;
+  const int J = g.J;
+  double* S = reinterpret_cast<double*>(smem);
+  double* sphi = S + (long)J * J;
+  double* su = sphi + J;
+  double* sv = su + J;
+  double* swp = sv + J;
+  double* sq = swp + J;
+  double* sp = sq + J;
+  double* sf = sp + J;   // f of dot_solve
+  double* sg = sf + J;   // u~ . f partial products
+  double* sscal = sg + J;  // [0] = D_n, [1] = failure flag, [2] = x_n
+
+  // K(0) summed in the reference's order (cholesky.h:98-99): diag + sum a_real + sum a_comp + jitter (+ A)
+  double sum_ar = 0.0, sum_ac = 0.0;
+  for (int j = 0; j < G.J_real; ++j) sum_ar += g.a_real[j];
+  for (int j = 0; j < G.J_comp; ++j) sum_ac += g.a_comp[j];
+  const double jit = G.jitter[b];
+  auto diagonal = [&](int n) {
+    double d = ((diag[n] + sum_ar) + sum_ac) + jit;
+    if (A) d += A[n];
+    return d;
+  };
+
+  for (int i = tid; i < J * J; i += nt) S[i] = 0.0;
+  for (int j = tid; j < J; j += nt) sf[j] = 0.0;
+  if (tid == 0) sscal[1] = 0.0;
+
+  // sample 0: cholesky.h:100-117, :346-347
+  double Dprev = diagonal(0);
+  double ld = log(Dprev);
+  double xm1 = y[0];
+  double quad = xm1 * (xm1 / Dprev);
+  {
+    const double value = 1.0 / Dprev;
+    for (int j = tid; j < J; j += nt) {
+      double ph, uu, vv;
+      row_features(g, j, 0, g.t[0], 0.0, ph, uu, vv);
+      swp[j] = vv * value;
+    }
+  }
+  __syncthreads();
+
+  for (int n = 1; n < N; ++n) {
+    const double t = g.t[n], dx = t - g.t[n - 1];
+    for (int j = tid; j < J; j += nt) {
+      double ph, uu, vv;
+      row_features(g, j, n, t, dx, ph, uu, vv);
+      sphi[j] = ph;
+      su[j] = uu;
+      sv[j] = vv;
+      const double f = ph * (sf[j] + swp[j] * xm1);  // cholesky.h:350-352
+      sf[j] = f;
+      sg[j] = uu * f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < J * J; idx += nt) {  // cholesky.h:154-160
+      const int k = idx % J, j = idx / J;
+      if (k <= j) {
+        const double xj = Dprev * swp[j];
+        S[idx] = sphi[j] * (sphi[k] * (S[idx] + xj * swp[k]));
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < J; j += nt) {  // q = S u~ ; cholesky.h:163-175
+      double acc = 0.0;
+      for (int k = 0; k < J; ++k) acc += (k <= j ? S[k + (long)J * j] : S[j + (long)J * k]) * su[k];
+      sq[j] = acc;
+      sp[j] = su[j] * acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double part = 0.0, xpart = 0.0;
+      for (int j = tid; j < J; j += 64) { part += sp[j]; xpart += sg[j]; }
+      part = wave_sum(part);
+      xpart = wave_sum(xpart);
+      if (tid == 0) {
+        const double Dn = diagonal(n) - part;
+        if (Dn < 0.0) sscal[1] = 1.0;  // cholesky.h:176
+        sscal[0] = Dn;
+        sscal[2] = y[n] - xpart;       // :353-354
+      }
+    }
+    __syncthreads();
+    if (sscal[1] != 0.0) {
+      if (tid == 0) {
+        G.out_status[b] = 2;
+        G.out_ll[b] = -INFINITY;
+        G.out_logdet[b] = NAN;
+        G.out_quad[b] = NAN;
+      }
+      return;
+    }
+    const double Dn = sscal[0], x = sscal[2];
+    ld += log(Dn);
+    quad += x * x / Dn;  // :356
+    xm1 = x;
+    for (int j = tid; j < J; j += nt) swp[j] = (sv[j] - sq[j]) / Dn;  // cholesky.h:170-178
+    Dprev = Dn;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    G.out_status[b] = 0;
+    G.out_logdet[b] = ld;
+    G.out_quad[b] = quad;
+    double ll = -0.5 * (quad + ld + N * 1.8378770664093453);
+    if (!isfinite(ld) || !isfinite(ll)) ll = -INFINITY;  // celerite.py:211-218
+    G.out_ll[b] = ll;
+  }
+}
+
 // J == 0: cholesky.h:90-95.
 __global__ void __launch_bounds__(256) diag_only_kernel(int N, const double* diag, double jitter,
                                                         double* D, double* log_det) {
@@ -510,6 +641,16 @@ void launch_factor_generic(const GenericProblem& g, double* phi, double* u, doub
   const int threads = g.J <= 8 ? 64 : 256;
   hipLaunchKernelGGL(factor_generic_kernel, dim3(1), dim3(threads), lds, s, g, phi, u, W, D,
                      status, log_det);
+}
+
+void launch_generic_loglike_batch(const GenericBatch& G, hipStream_t s) {
+  const size_t J = (size_t)G.J_real + 2 * (size_t)G.J_comp + (size_t)G.J_general;
+  const size_t lds = sizeof(double) * (J * J + 8 * J + 4);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_loglike_batch_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int threads = J <= 8 ? 64 : 256;
+  hipLaunchKernelGGL(generic_loglike_batch_kernel, dim3(G.B), dim3(threads), lds, s, G);
 }
 
 void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,

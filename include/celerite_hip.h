@@ -195,7 +195,7 @@ int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_d
 typedef struct clr_batch clr_batch;
 
 /* Plans device buffers + workspace for (B, N, J_real, J_comp) on `device`.
- * General terms are not part of the batched path.  Width W = J_real + 2 J_comp:
+ * General terms: clr_batch_set_general.  Width W = J_real + 2 J_comp:
  *   1..8   chunked scan over n, one lane per (problem, chunk)  (the headline path);
  *   9..64  one wave per (problem, chunk), S distributed over the lanes (BASELINE
  *          config 5: 16 complex terms); fused log-likelihood only.  One chunk = the
@@ -218,6 +218,15 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
                                const double* a_real, const double* c_real,
                                const double* a_comp, const double* b_comp,
                                const double* c_comp, const double* d_comp);
+
+/* General semiseparable terms for the whole batch (cholesky.h:65-72,148-152: A added to the diagonal, rows U, V
+ * appended to U~, V~ with phi = 1): A [N], U and V row-major [J_general][N] per problem, *_stride doubles between
+ * problems (N resp. J_general * N) or 0 for one block shared by all problems; J_general = 0 removes them.  A plan
+ * with general terms evaluates through the any-width sequential kernel -- one workgroup per problem, the reference's
+ * step order, compute fused with dot_solve and log_determinant -- at widths J_real + 2 J_comp + J_general <=
+ * CLR_MAX_WIDTH; fused log-likelihood only (materialising runs: CholeskySolver). */
+int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
+                          const double* V, long V_stride);
 
 /* Tuning: how the kernels read the series.
  *   2 (default) staged: each wave loads the row-major arrays in coalesced tiles of

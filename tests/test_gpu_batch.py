@@ -1031,3 +1031,54 @@ def test_wide_materialised_factor_matches_oracle_state(JR, JC, N, nchunk):
         assert np.allclose(W, rW, rtol=1e-8, atol=1e-11)
         assert np.allclose(D, rD, rtol=1e-10, atol=0)
     plan.close()
+
+
+@pytest.mark.parametrize("JR,JC,JG,N,shared", [(2, 1, 3, 700, False), (1, 0, 4, 500, True), (0, 4, 2, 1500, False),
+                                                (3, 10, 3, 400, False)])
+def test_general_terms_in_the_batch(JR, JC, JG, N, shared):
+    """General semiseparable terms (cholesky.h:65-72,148-152) through the batched API (missing 3):
+    clr_batch_set_general + the any-width sequential kernel, against CholeskySolver-style oracle calls problem by
+    problem (compute + dot_solve + log_determinant), incl. an indefinite neighbour and removal of the terms."""
+    B = 5
+    rng = np.random.RandomState(JR + 10 * JC + JG)
+    case = synthetic(B, N, JR, JC, "accuracy", seed=3 + JG)
+    tt = case["t"] if not shared else np.tile(case["t"][0], (B, 1))
+    case["t"] = tt
+    if shared:   # general blocks shared by all problems: (JG, N) / (N,)
+        U = np.vander((tt[0] - tt[0].mean()) / (tt[0].max() - tt[0].min()), JG).T
+        V = U * rng.rand(JG)[:, None]
+        A = np.sum(U * V, axis=0) + 1e-8
+    else:
+        U = np.stack([np.vander((t - t.mean()) / (t.max() - t.min()), JG).T for t in tt])
+        V = U * rng.rand(B, JG)[:, :, None]
+        A = np.sum(U * V, axis=1) + 1e-8
+    if JR:
+        case["a_real"][3, 0] = -30.0      # one indefinite problem
+        case["diag"][3] = 1e-4
+    plan = batch.BatchedGP(B, N, JR, JC)
+    plan.set_series(case["t"], case["diag"], case["y"])
+    plan.set_coefficients(*coeffs_of(case), jitter=0.01)
+    plan.set_general(A, U, V)
+    ll, ld, q, st = plan.log_likelihood()
+    for p in range(B):
+        r = ref.RefSolver()
+        gen = (A, U, V) if shared else (A[p], U[p], V[p])
+        try:
+            r.compute(0.01, *coeffs_of(case, p), *gen, case["t"][p], case["diag"][p])
+        except Exception:
+            assert st[p] == 2 and np.isneginf(ll[p])
+            continue
+        assert st[p] == 0
+        ld0, q0 = r.log_determinant(), r.dot_solve(case["y"][p])
+        assert abs(ld[p] - ld0) <= REL * abs(ld0) and abs(q[p] - q0) <= REL * abs(q0)
+        assert abs(ll[p] - (-0.5 * (q0 + ld0 + N * np.log(2 * np.pi)))) <= REL * abs(ll[p])
+    if JR:
+        assert st[3] == 2
+    # without the general terms the plan is the ordinary one again
+    plan.set_general(np.empty(0), np.empty((0, 0)), np.empty((0, 0)))
+    ll2, ld2, q2, st2 = plan.log_likelihood()
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.01, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    assert np.array_equal(st2, s0)
+    ok = s0 == 0
+    assert np.max(np.abs(ld2[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
+    plan.close()
