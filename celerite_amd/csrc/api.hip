@@ -1343,10 +1343,12 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
     // chunks, at ~1.25x the work per sample (profiles/r01s); widths above 32 stay sequential
     if (h->J > clr::wide_scan_max_width()) nchunk = 1;
     else if (nchunk <= 0) {
-      // (4096 / B since the prefix runs on the matrix cores: 0.09 ms per chunk instead of 0.3; the
-      //  summarize waves then take two rounds of half the length, the checked replay of borderline
-      //  problems is twice as short: config 4 32.3 -> 29.1 ms)
-      nchunk = h->B <= 1024 ? 4096 / h->B : 1;  // (above 1024 problems one sweep per problem already fills a round)
+      // One round of two waves per SIMD: B x nchunk = 2048 waves.  (Round 2 used 4096 / B -- two rounds of half the
+      //  length -- because the checked replay of borderline problems, 7 ms for config 4, got shorter with the chunks;
+      //  with the round-3 routing that family is settled from the chunk summaries and the sequential prefix + the
+      //  correct phase decide: B = 256: 8 chunks 17.1 ms, 16 chunks 18.5, 10 chunks 22.8 (2560 waves = a second,
+      //  nearly empty round), B = 512: 4 chunks 32.2 ms, 8 chunks 32.7; profiles/r03_wide_chunks.txt)
+      nchunk = h->B <= 1024 ? 2048 / h->B : 1;  // (above 1024 problems one sweep per problem already fills a round)
       if (nchunk < 2) nchunk = 1;
       if (nchunk > 16) nchunk = 16;
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
