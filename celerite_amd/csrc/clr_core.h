@@ -183,6 +183,23 @@ CLR_HD void sincos_phase(double x, double* s_out, double* c_out) {
     sincos(x, s_out, c_out);
 }
 
+// 1 / D for the summarize kernels: v_rcp_f64 + two Newton steps (5 fp64 instructions, <= 1 ulp) instead of the
+// IEEE division sequence (div_scale x2, rcp, 5 fma, div_fmas, div_fixup: 12).  D is a pivot of order 1e-6 .. 1e6, or
+// the 1e300 of a padded step; D = 0 or a non-finite D gives NaN here instead of +-inf / 0 -- such a pivot is flagged
+// by its caller (!(D > 0)) and the problem is settled by the reference recurrence, which keeps the IEEE division
+// (replay_chunk writes W = z / D into the factor).  Host build (tests/hostcheck): the plain division.
+CLR_HD double recip_fast(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+#else
+  return 1.0 / d;
+#endif
+}
+
 // sum of log(D_n) without a log per step: keep the product of the mantissas and
 // the sum of the exponents (ocml's fp64 log is 76 fp64 instructions; this is 3).
 // D = 0 -> product 0 -> log = -inf; D < 0 is flagged by the caller; NaN propagates
@@ -377,7 +394,7 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
     CLR_UNROLL
     for (int j = 0; j < J; ++j) { s += u[j] * q[j]; ub += u[j] * b[j]; }
     const double D = p.diagonal(diag_cur) - s;
-    const double invD = 1.0 / D;
+    const double invD = recip_fast(D);
     const double x = y_cur - ub;
     const bool valid = n0 + i < N;
     // zero-start sums of this chunk (corrected for the true start state by

@@ -145,7 +145,7 @@ __device__ __forceinline__ void split_trajectory(const Problem<JR, JC>& p, Direc
 #pragma unroll
     for (int j = 0; j < J; ++j) { s += u[j] * q[j]; ub += u[j] * b[j]; }
     const double D = p.diagonal(diag_cur) - s;
-    const double invD = 1.0 / D;
+    const double invD = recip_fast(D);
     const double x = y_cur - ub;
     {  // (a padded step has D ~ 1e300 > 0, a_n / D = 1 and x^2 / D ~ 0: only the log-determinant leaves it out)
       const int n = n0 + i;
@@ -430,7 +430,7 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       for (int j = 0; j < J; ++j) s += u[j] * q[j];
       const double a_n = p.diagonal(diag_cur);
       const double D = a_n - s;
-      const double invD = 1.0 / D;
+      const double invD = recip_fast(D);
       {  // (a padded step has D ~ 1e300 > 0 and a_n / D = 1: only the log-determinant has to leave it out)
         const int n = n0 + i;
         flag0 |= (n >= 1 && !(D > 0.0)) ? 1 : 0;

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR2>(r); }
       const double s = row_sum<LPR>(ueff * q), ub = row_sum<LPR>(ueff * f);
       const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
-      const double invD = 1.0 / D;
+      const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
       const double x = y_n - ub;
       // replay: the reference's test (cholesky.h:176; sample 0 is never checked); summarize: a
       // zero-start pivot <= 0 sends the problem to the replay (as in summarize_chunk)

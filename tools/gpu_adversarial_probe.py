@@ -10,10 +10,13 @@ from oracle import ref
 from _cases import adversarial, coeffs_of, ALL_WIDTH_SHAPES
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+WIDE = bool(os.environ.get("WIDE"))   # widths 9..32 (the wave-per-chunk scan) instead of 1..8
+WIDE_SHAPES = [(9, 0), (1, 4), (0, 8), (16, 0), (0, 16), (4, 14), (2, 7), (10, 11)]
 rows = []
+mismatch = 0
 for trial in range(trials):
-    JR, JC = ALL_WIDTH_SHAPES[trial % len(ALL_WIDTH_SHAPES)]
-    N = (50, 200, 1000, 3000, 20000)[trial % 5]
+    JR, JC = (WIDE_SHAPES[trial % len(WIDE_SHAPES)] if WIDE else ALL_WIDTH_SHAPES[trial % len(ALL_WIDTH_SHAPES)])
+    N = ((600, 2000, 6000)[trial % 3] if WIDE else (50, 200, 1000, 3000, 20000)[trial % 5])
     case = adversarial(4, N, JR, JC, seed=5000 + trial)
     l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
     plan = batch.BatchedGP(4, N, JR, JC)
@@ -23,9 +26,10 @@ for trial in range(trials):
         cert = float(os.environ["CERT"])   # CERT=0: routing by the conditioning record switched off
         plan.set_certificate(cert, float(os.environ.get("RESID", "1e-12")), max_gamma=float(os.environ.get("GAMMA", "0" if cert == 0 else "1e4")),
                              max_gamma_error=float(os.environ.get("GAMMAEG", "0" if cert == 0 else "3e-9")))
-    for nchunk in (max(2, N // 40), max(2, N // 8)):
+    for nchunk in ((4, 9) if WIDE else (max(2, N // 40), max(2, N // 8))):
         plan.set_chunks(nchunk)
         ll, ld, q, st = plan.log_likelihood()
+        mismatch += int((st != s0).sum())
         fl = plan.exact_levels()
         gam, mu = plan.conditioning()
         plan.set_exact(True)
@@ -42,6 +46,7 @@ for trial in range(trials):
                              eld2=abs(ld2[p] - d0[p]) / abs(d0[p]), eq2=abs(q2[p] - q0[p]) / abs(q0[p]),
                              ld=float(d0[p]), q=float(q0[p])))
     plan.close()
+print("status mismatches against the oracle: %d" % mismatch)
 if os.environ.get("DUMP"):
     json.dump(rows, open(os.environ["DUMP"], "w"))
 free = [r for r in rows if not r["replayed"]]
