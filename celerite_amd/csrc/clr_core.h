@@ -200,6 +200,16 @@ CLR_HD double recip_fast(double d) {
 #endif
 }
 
+// Streaming store for the materialised factor (20 GB per launch at the headline shape, written once and not read
+// back by the kernel): bypasses the caches on the device; a plain store on the host build.
+CLR_HD void store_stream(double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CLR_NO_STREAM_STORES)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // sum of log(D_n) without a log per step: keep the product of the mantissas and
 // the sum of the exponents (ocml's fp64 log is 76 fp64 instructions; this is 3).
 // D = 0 -> product 0 -> log = -inf; D < 0 is flagged by the caller; NaN propagates
@@ -1075,11 +1085,11 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
       }
     }
     if (MATERIALIZE == 2 && valid) {
-      D_o[(long)i * fstride] = D;
+      store_stream(D_o + (long)i * fstride, D);
       CLR_UNROLL
       for (int j = 0; j < J; ++j) {
-        W_o[((long)i * J + j) * fstride] = W[j];
-        u_o[((long)i * J + j) * fstride] = u[j];
+        store_stream(W_o + ((long)i * J + j) * fstride, W[j]);
+        store_stream(u_o + ((long)i * J + j) * fstride, u[j]);
       }
     }
     {
@@ -1091,7 +1101,7 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
       }
       if (MATERIALIZE == 2 && n + 1 < N) {
         CLR_UNROLL
-        for (int j = 0; j < J; ++j) phi_o[((long)i * J + j) * fstride] = phid[phi_index<JR>(j)];
+        for (int j = 0; j < J; ++j) store_stream(phi_o + ((long)i * J + j) * fstride, phid[phi_index<JR>(j)]);
       }
       CLR_UNROLL
       for (int j = 0; j < J; ++j) f[j] = phid[phi_index<JR>(j)] * (f[j] + W[j] * x);
