@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(64) prefix_coop_kernel(const BatchParams P_) {
       double m[J];
 #pragma unroll
       for (int i = 0; i < J; ++i) m[i] = group_bcast<GROUP>(T[i], c0);
-      const double t = T[c0] * (1.0 / m[c0]);
+      const double t = T[c0] * recip_fast(m[c0]);  // (a zero / non-finite pivot gives NaN: the problem is then flagged downstream)
 #pragma unroll
       for (int i = 0; i < J; ++i) T[i] = (i == c0) ? t : (T[i] - m[i] * t);
     }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void gauss_jordan_row16(double (&T)[J]) {
     double m[J];
 #pragma unroll
     for (int i = 0; i < J; ++i) m[i] = row_bcast(T[i], c0);
-    const double t = T[c0] * (1.0 / m[c0]);
+    const double t = T[c0] * recip_fast(m[c0]);  // (a zero / non-finite pivot gives NaN: the problem is then flagged downstream)
 #pragma unroll
     for (int i = 0; i < J; ++i) T[i] = (i == c0) ? t : (T[i] - m[i] * t);
   }
