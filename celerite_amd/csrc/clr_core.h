@@ -635,7 +635,7 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
       T[col][c] = top;
     }
     det *= (piv != col) ? -T[col][col] : T[col][col];
-    const double inv = recip_fast(T[col][col]);
+    const double inv = 1.0 / T[col][col];
     CLR_UNROLL_J
     for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
     CLR_UNROLL_J
@@ -829,7 +829,7 @@ CLR_HD void compose_elements(const double* e1, const double* e2, double* out) {
       }
       T[col][c] = top;
     }
-    const double inv = recip_fast(T[col][col]);
+    const double inv = 1.0 / T[col][col];
     CLR_UNROLL_J
     for (int c = col + 1; c < NC; ++c) T[col][c] *= inv;
     CLR_UNROLL_J
