@@ -215,6 +215,60 @@ extern "C" int hostcheck_batch(int B, int N, int JR, int JC, int nchunk, const d
   return -1;
 }
 
+// The warm-started plain recurrence (clr_batch_kernels.h: warm_kernel + warm_check_kernel) on the host: every chunk
+// runs replay_chunk from the zero state K samples before its first sample (chunk 0: from its first sample), the
+// state after the warm-up is compared with the state the previous chunk ends in.  Returns per problem log det,
+// quadratic form, the largest relative boundary mismatch and whether any pivot was flagged.
+template <int JR, int JC>
+static int run_warm(int B, int N, int nchunk, int K, const double* jitter, const double* a_real, const double* c_real,
+                    const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
+                    const double* t, const double* diag, const double* y, double* logdet, double* quad, double* resid,
+                    int* flagged) {
+  using Wd = Widths<JR, JC>;
+  const int L = (N + nchunk - 1) / nchunk;
+  for (int b = 0; b < B; ++b) {
+    Problem<JR, JC> p;
+    p.load(a_real + (long)b * JR, c_real + (long)b * JR, a_comp + (long)b * JC, b_comp + (long)b * JC,
+           c_comp + (long)b * JC, d_comp + (long)b * JC, jitter[b]);
+    const double *tb = t + (long)b * N, *db = diag + (long)b * N, *yb = y + (long)b * N;
+    double ld = 0, qd = 0, res = 0;
+    int bad = 0;
+    double prev_end[Wd::START];
+    for (int c = 0; c * L < N; ++c) {
+      const int warm = c == 0 ? 0 : K;
+      const long first = (long)c * L - warm;
+      if (first < 0) return -2;
+      DirectSeries src{tb + first, db + first, yb + first, 1, L + warm, L + warm, (long)N - first};
+      double l, q, st[Wd::START], en[Wd::START];
+      int fl;
+      replay_chunk<JR, JC, 0, true>(p, src, L + warm, N, (int)first, nullptr, &l, &q, &fl, nullptr, nullptr, nullptr,
+                                    nullptr, 0, en, warm, st);
+      ld += l; qd += q; bad |= fl;
+      if (c > 0) {
+        double pm = 0, dp = 0, fm = 0, df = 0;
+        for (int i = 0; i < Wd::SZ; ++i) { pm = fmax(pm, fabs(prev_end[i])); dp = fmax(dp, fabs(prev_end[i] - st[i])); }
+        for (int i = Wd::SZ; i < Wd::START; ++i) { fm = fmax(fm, fabs(prev_end[i])); df = fmax(df, fabs(prev_end[i] - st[i])); }
+        double r = pm > 0 ? dp / pm : (dp == 0 ? 0 : INFINITY);
+        if (fm > 0) r = fmax(r, df / fm);
+        if (!(r <= res)) res = r;
+      }
+      memcpy(prev_end, en, sizeof(en));
+    }
+    logdet[b] = ld; quad[b] = qd; resid[b] = res; flagged[b] = bad;
+  }
+  return 0;
+}
+
+extern "C" int hostcheck_warm(int B, int N, int JR, int JC, int nchunk, int K, const double* jitter, const double* a_real,
+                              const double* c_real, const double* a_comp, const double* b_comp, const double* c_comp,
+                              const double* d_comp, const double* t, const double* diag, const double* y, double* logdet,
+                              double* quad, double* resid, int* flagged) {
+#define WCASE(R, C) if (JR == R && JC == C) return run_warm<R, C>(B, N, nchunk, K, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, logdet, quad, resid, flagged);
+  WCASE(2, 3) WCASE(0, 2) WCASE(1, 1) WCASE(4, 0)
+#undef WCASE
+  return -1;
+}
+
 // The prefix planner (clr_core.h: plan_prefix), as the library calls it.
 extern "C" void hostcheck_plan_prefix(int nchunk, int levels, int g, int B, int J, int* out /* levels, g[3], n[4] */,
                                       double* time_us) {

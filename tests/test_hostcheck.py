@@ -267,3 +267,36 @@ def test_prefix_planner(lib):
     assert plan(125, B=256, J=4)[0] >= 1 and plan(250, B=256, J=4)[0] >= 1
     lv, gs, ns, tm = plan(2048, B=1, J=8)
     assert lv >= 2 and ns[lv] <= 64 and tm < 0.2 * plan(2048, 0, 0, B=1, J=8)[3]
+
+
+@pytest.mark.parametrize("JR,JC", [(2, 3), (0, 2), (1, 1), (4, 0)])
+def test_warm_started_recurrence_forgets_or_is_caught(lib, JR, JC):
+    """The claim behind warm_kernel / warm_check_kernel (clr_batch_kernels.h), on the host instantiation of
+    replay_chunk: on the paper's accuracy family a chunk started from the ZERO state 64 samples early reaches the
+    state the previous chunk ends in (mismatch <= 1e-11 at every boundary) and the sums equal the oracle's; with a
+    warm-up that is too short, or on the bench family (which does not forget within a chunk), the boundary mismatch is
+    orders of magnitude above the tolerance -- the check, not the warm-up heuristic, certifies the result."""
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+    def run_warm(case, nchunk, K):
+        B, N = case["t"].shape
+        keep = [np.ascontiguousarray(case[k], dtype=np.float64) for k in
+                ("a_real", "c_real", "a_comp", "b_comp", "c_comp", "d_comp", "t", "diag", "y")]
+        jit = np.zeros(B)
+        ld, q, res = np.empty(B), np.empty(B), np.empty(B)
+        fl = np.zeros(B, dtype=np.int32)
+        rc = lib.hostcheck_warm(B, N, JR, JC, nchunk, K, jit.ctypes.data_as(dp), *[k.ctypes.data_as(dp) for k in keep],
+                                ld.ctypes.data_as(dp), q.ctypes.data_as(dp), res.ctypes.data_as(dp), fl.ctypes.data_as(ip))
+        assert rc == 0
+        return ld, q, res, fl
+
+    case = synthetic(3, 4000, JR, JC, "accuracy", seed=7 + JR)
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    ld, q, res, fl = run_warm(case, 10, 64)
+    assert (fl == 0).all() and np.max(res) <= 1e-11
+    assert np.max(np.abs(ld - d0) / np.abs(d0)) < 1e-11 and np.max(np.abs(q - q0) / np.abs(q0)) < 1e-11
+    ld, q, res, fl = run_warm(case, 10, 2)
+    assert np.min(res) > 1e-6                       # two samples of warm-up: caught at the boundaries
+    case = synthetic(3, 4000, JR, JC, "bench", seed=8 + JR)
+    ld, q, res, fl = run_warm(case, 10, 128)
+    assert np.min(res) > 1e-9                       # dense sampling: no forgetting within 128 samples
