@@ -922,15 +922,17 @@ CLR_HD void compose_elements(const double* e1, const double* e2, double* out) {
 // Schedule of a multi-level prefix over n chunk elements: level 0 = the chunks, level l + 1 =
 // compositions of groups of g[l] consecutive level-l elements; the top level is walked
 // sequentially, then the start states fan out level by level (clr_prefix_kernels.h).
-// Chosen on the host from a time model fitted on MI355X (profiles/r03a_prefix_ab.txt):
+// Chosen on the host from a time model fitted on MI355X (profiles/r03a_prefix_ab.txt, r03p_prefix_ab.txt):
 //   * one advance of a lone wave: t = 0.49 + 0.04 J^2 us (1.13 us at width 4, 3.04 at width 8);
 //     a composition 1.3 t (same Gauss-Jordan on two DPP rows, one more J^3 / 16 product);
-//   * a phase of W waves runs in max(1, W / (1024 SIMDs x k)) rounds, k = min(3, waves the kernel's
-//     registers allow per SIMD) -- lone waves issue one instruction per ~5 cycles, so up to three
-//     resident waves overlap almost for free; beyond that a phase is throughput-bound, which is why
-//     B = 1024 x 64 chunks at width 8 (composition kernel: 308 registers, one wave per SIMD) stays on
-//     the plain walk while 256 x 125 chunks at width 4 runs 2.6x faster multi-level;
-//   * every level adds two dependent launches (~5 us each).
+//   * a phase of W waves runs in max(1, W / (1024 SIMDs x k)) rounds, k = min(waves the kernel's registers
+//     allow per SIMD, overlap): up to width 5 three resident waves overlap almost for free (a lone wave
+//     issues one instruction per ~5 cycles); at widths 6..8 the chains are dense fp64 and a second wave on
+//     the SIMD buys only ~1.3x (fan-out of 2048 waves at width 8: 6.6 us per step against 3.0 alone);
+//   * every level adds two dependent launches (~6 us each).
+// With the running composition in LDS (190 registers, two waves per SIMD at width 8) one level of groups of
+// 8 takes 0.146 ms at B = 1024 x 64 chunks against 0.179 ms for the walk; 256 x 125 chunks at width 4 runs
+// 2.5x faster than the walk.
 // ---------------------------------------------------------------------------
 struct PrefixPlan {
   int levels;     // number of composition levels (0: plain sequential walk)
@@ -939,11 +941,12 @@ struct PrefixPlan {
   double time_us; // modelled duration of the prefix phase
 };
 inline double prefix_plan_time_us(const PrefixPlan& p, int B, int J) {
-  static const int occ_compose[9] = {8, 8, 6, 4, 3, 2, 2, 1, 1}, occ_advance[9] = {8, 8, 7, 5, 4, 3, 2, 2, 2};
+  static const int occ_compose[9] = {8, 8, 7, 5, 4, 4, 3, 2, 2}, occ_advance[9] = {8, 8, 7, 5, 4, 3, 2, 2, 2};
   const int j = J < 1 ? 1 : (J > 8 ? 8 : J);
   const double t = 0.49 + 0.04 * j * j;
-  auto rounds = [](double waves, int occ) {
-    const double r = waves / (1024.0 * (occ < 3 ? occ : 3));
+  const double overlap = j <= 5 ? 3.0 : 1.3;
+  auto rounds = [overlap](double waves, int occ) {
+    const double r = waves / (1024.0 * (occ < overlap ? occ : overlap));
     return r > 1.0 ? r : 1.0;
   };
   double us = rounds(B / 4.0, occ_advance[j]) * p.n[p.levels] * t;
@@ -951,11 +954,11 @@ inline double prefix_plan_time_us(const PrefixPlan& p, int B, int J) {
     const double segs = (double)B * p.n[l + 1];
     us += rounds(segs / 2.0, occ_compose[j]) * (p.g[l] - 1) * 1.3 * t;
     us += rounds(segs / 4.0, occ_advance[j]) * (p.g[l] - 1) * t;
-    us += 10.0;
+    us += 12.0;
   }
   return us;
 }
-// levels < 0: choose (multi-level only when the model promises at least 20 % over the walk); otherwise build
+// levels < 0: choose (multi-level only when the model promises at least 15 % over the walk); otherwise build
 // the plan with that many levels of groups of g (a level is dropped when it would not leave two groups)
 inline PrefixPlan plan_prefix(int nchunk, int levels = -1, int g = 0, int B = 1, int J = 8) {
   auto build = [&](int lv, int gg) {
@@ -979,7 +982,7 @@ inline PrefixPlan plan_prefix(int nchunk, int levels = -1, int g = 0, int B = 1,
       const PrefixPlan p = build(lv, gg);
       if (p.levels == lv && p.time_us < best.time_us) best = p;
     }
-  return best.time_us < 0.8 * walk.time_us ? best : walk;
+  return best.time_us < 0.85 * walk.time_us ? best : walk;
 }
 
 // ---------------------------------------------------------------------------
@@ -1061,6 +1064,8 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
     CLR_UNROLL
     for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
     const double D = p.diagonal(diag_cur) - s;
+    // (the IEEE division also on the warm-started path: v_rcp + two Newton steps there measured no difference,
+    //  2.23-2.25 against 2.21-2.25 ms same box, profiles/r03p_warm_chunks.txt)
     const double invD = 1.0 / D;
     const double x = y_cur - uf;
     if (valid) {

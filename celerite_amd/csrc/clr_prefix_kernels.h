@@ -244,9 +244,14 @@ __global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
   constexpr int HALF = 8, ROW = 16, GROUP = 32, NG = 2;
   constexpr int SZ = J * (J + 1) / 2;
   constexpr int ELEM = J * J + J + SZ + J + SZ;
-  __shared__ double pbuf[NG][HALF][HALF];          // C1: pbuf[g][j][i] = C1[i][j]
-  __shared__ double abuf[NG][J * J + 2];           // A1^T row-major: abuf[g][k * J + a] = A1[a][k]
-  __shared__ double bbuf[NG][HALF];                // b1
+  // The running composition (A1, b1, C1, eta1, Jm1) lives in LDS, double-buffered: an iteration reads buffer p and
+  // writes buffer p ^ 1, so the registers hold only an iteration's temporaries (with the element in registers the
+  // kernel needed 308 of them at width 8: one wave per SIMD and four rounds of waves at the headline shape).
+  __shared__ double pbuf[2][NG][HALF][HALF];   // C1: [j][i] = C1[i][j] (column j contiguous)
+  __shared__ double abuf[2][NG][J * J + 2];    // A1^T row-major: [k * J + a] = A1[a][k] (column k of A1 contiguous)
+  __shared__ double jbuf[2][NG][HALF][HALF];   // Jm1: [j][i] = Jm1[i][j]
+  __shared__ double bbuf[2][NG][HALF];         // b1
+  __shared__ double hbuf[2][NG][HALF];         // eta1
   __shared__ double xbuf[2 * NG][HALF][HALF + 1];  // per row: the exchange of product 1
   constexpr int ESTRIDE = ((ELEM + 15) / 16) * 16 + 2;
   constexpr int EPER = (ELEM + GROUP - 1) / GROUP;
@@ -274,32 +279,26 @@ __global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
       if (lg + GROUP * m < ELEM) ebuf[0][g][lg + GROUP * m] = E0[lg + GROUP * m];
   }
   __syncthreads();
-  // running composition, spread over the right-hand-side lanes of the two rows:
-  //   state row: Sc = C1[:, col], fj = b1[col];  rider row: Sc = A1[:, col], fj = eta1[col], Jc = Jm1[:, col]
-  double Sc[J], Jc[J];
-  double fj;
-  {
+  if (rhs) {  // the group's first element is the initial composition: buffer 0
     const double* E = ebuf[0][g];
     const double* A = E;
     const double* bv = E + J * J;
     const double* C = bv + J;
     const double* eta = C + SZ;
     const double* Jm = eta + J;
+    if (!rider) {
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-      Sc[i] = cv ? (rider ? A[i * J + cc] : C[sym(i, cc)]) : 0.0;
-      Jc[i] = cv ? Jm[sym(i, cc)] : 0.0;
+      for (int i = 0; i < HALF; ++i) pbuf[0][g][col][i] = (cv && i < J) ? C[sym(i < J ? i : 0, cc)] : 0.0;
+      bbuf[0][g][col] = cv ? bv[cc] : 0.0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) jbuf[0][g][col][i] = (cv && i < J) ? Jm[sym(i < J ? i : 0, cc)] : 0.0;
+      hbuf[0][g][col] = cv ? eta[cc] : 0.0;
+      if (cv) {
+#pragma unroll
+        for (int i = 0; i < J; ++i) abuf[0][g][col * J + i] = A[i * J + cc];
+      }
     }
-    fj = cv ? (rider ? eta[cc] : bv[cc]) : 0.0;
-  }
-  if (rhs && !rider) {
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) pbuf[g][col][i] = (i < J) ? Sc[i < J ? i : 0] : 0.0;
-    bbuf[g][col] = fj;
-  }
-  if (rhs && rider && cv) {
-#pragma unroll
-    for (int i = 0; i < J; ++i) abuf[g][col * J + i] = Sc[i];
   }
   {
     const double* E1 = S.elems + (ebase + first + min(1, len - 1)) * ELEM;
@@ -309,7 +308,8 @@ __global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
   }
   __syncthreads();
 
-  for (int c = 1; c < S.g; ++c) {  // wave-uniform trip count; e2 = element first + c
+  int p = 0;  // buffer holding the running composition
+  for (int c = 1; c < S.g; ++c, p ^= 1) {  // wave-uniform trip count; e2 = element first + c
     const bool valid = c < len;
     double nx[EPER];
     const bool more = c + 1 < S.g;
@@ -325,99 +325,85 @@ __global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
     const double* eta = C + SZ;
     const double* Jm = eta + J;
 
-    double jc[J], et[J];
+    double jc[J];
 #pragma unroll
-    for (int i = 0; i < J; ++i) {
-      jc[i] = cv ? Jm[sym(i, cc)] : 0.0;
-      et[i] = eta[i];
-    }
+    for (int i = 0; i < J; ++i) jc[i] = cv ? Jm[sym(i, cc)] : 0.0;
     double T[J];  // column of [I + C1 Jm2 | C1] (state row) / [I + C1 Jm2 | A1] (rider row)
 #pragma unroll
     for (int i = 0; i < J; ++i) {
       double acc = (i == col) ? 1.0 : 0.0;
 #pragma unroll
-      for (int j = 0; j < J; ++j) acc += pbuf[g][j][i] * jc[j];
-      T[i] = rhs ? Sc[i] : acc;
+      for (int j = 0; j < J; ++j) acc += pbuf[p][g][j][i] * jc[j];
+      const double mine = rider ? (cv ? abuf[p][g][cc * J + i] : 0.0) : pbuf[p][g][col][i];
+      T[i] = rhs ? mine : acc;
     }
     // state row: h = b1 + C1 eta2, v = Jm2 h;  rider row: v = Jm2 b1, w = eta2 - v
-    double hj = fj;
+    double hj = bbuf[p][g][col];
+    if (!rider) {
 #pragma unroll
-    for (int i = 0; i < J; ++i) hj += Sc[i] * et[i];
-    if (rider) hj = bbuf[g][col];
+      for (int i = 0; i < J; ++i) hj += T[i] * eta[i];  // (rhs lanes: T = C1[:, col])
+    }
     double vj = 0.0;
 #pragma unroll
     for (int i = 0; i < J; ++i) vj += jc[i] * row_bcast(hj, HALF + i);
-    const double zj = rider ? ((cv ? et[cc] : 0.0) - vj) : vj;
+    const double zj = rider ? ((cv ? eta[cc] : 0.0) - vj) : vj;
 
     gauss_jordan_row16<J>(T);
     // rhs lanes: T = X2[:, col] (= G, symmetric) in the state row, X1[:, col] in the rider row
     double acc1 = 0.0;
 #pragma unroll
     for (int i = 0; i < J; ++i) acc1 += T[i] * row_bcast(zj, HALF + i);
-    const double gj = hj - acc1;    // state row: g = h - G v
-    const double etan = fj + acc1;  // rider row: eta12[col] = eta1[col] + X1[:, col] . w
-    double fn = cv ? bv[cc] : 0.0;  // state row: b12 = A2 g + b2
+    const double gj = hj - acc1;                       // state row: g = h - G v
+    const double etan = hbuf[p][g][col] + acc1;        // rider row: eta12[col] = eta1[col] + X1[:, col] . w
+    double fn = cv ? bv[cc] : 0.0;                     // state row: b12 = A2 g + b2
 #pragma unroll
     for (int i = 0; i < J; ++i) fn += (cv ? A[cc * J + i] : 0.0) * row_bcast(gj, HALF + i);
 
-    double Xr[J];  // A2 T: row `col` of G A2^T (state row) / column `col` of A12 (rider row)
+    // product 1: A2 T = row `col` of G A2^T (state row, exchanged below) / column `col` of A12 (rider row, stored)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double acc = 0.0;
 #pragma unroll
       for (int i = 0; i < J; ++i) acc += T[i] * A[j * J + i];
-      Xr[j] = acc;
+      if (rhs) {
+        if (rider) { if (cv && valid) abuf[p ^ 1][g][cc * J + j] = acc; }
+        else xbuf[row][col][j] = acc;
+      }
     }
-    double yv[J];  // rider row: Jm2 X1[:, col]
+    // rider row: its own Jm2 X1[:, col], stored transposed so that both rows read xbuf[row][a][col] below
+    if (rider) {
 #pragma unroll
-    for (int k = 0; k < J; ++k) {
-      double acc = 0.0;
+      for (int k = 0; k < J; ++k) {
+        double acc = 0.0;
 #pragma unroll
-      for (int a = 0; a < J; ++a) acc += Jm[sym(k, a)] * T[a];
-      yv[k] = acc;
-    }
-    // exchange: the state row hands its rows of G A2^T over (lane a, entry col); the rider row only
-    // needs its OWN Jm2 X1[:, col], stored transposed so that both rows read xbuf[row][a][col]
-    if (rhs) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        if (rider) xbuf[row][j][col] = yv[j];
-        else xbuf[row][col][j] = Xr[j];
+        for (int a = 0; a < J; ++a) acc += Jm[sym(k, a)] * T[a];
+        if (rhs) xbuf[row][k][col] = acc;
       }
     }
     __syncthreads();
-    // product 2: out = add + L1 xbuf[row][:, col];  state row: C2[:, col] + A2 (...) = C12[:, col];
+    // product 2: add + L1 xbuf[row][:, col];  state row: C2[:, col] + A2 (...) = C12[:, col];
     // rider row: Jm1[:, col] + A1^T (Jm2 X1[:, col]) = Jm12[:, col]
-    const double* L1 = rider ? abuf[g] : A;
-    double out[J];
+    const double* L1 = rider ? abuf[p][g] : A;
 #pragma unroll
     for (int k = 0; k < J; ++k) {
-      double acc = rider ? Jc[k] : (cv ? C[sym(k, cc)] : 0.0);
+      double acc = rider ? jbuf[p][g][col][k] : (cv ? C[sym(k, cc)] : 0.0);
 #pragma unroll
       for (int a = 0; a < J; ++a) acc += L1[k * J + a] * xbuf[row][a][col];
-      out[k] = acc;
+      if (rhs) {
+        if (!valid) acc = rider ? jbuf[p][g][col][k] : pbuf[p][g][col][k];  // (a ragged group idles: carry over)
+        if (rider) jbuf[p ^ 1][g][col][k] = cv ? acc : 0.0;
+        else pbuf[p ^ 1][g][col][k] = cv ? acc : 0.0;
+      }
     }
-    __syncthreads();  // (everybody has read the old A1 / C1 / b1 from LDS)
-    if (rhs && valid) {
+    if (rhs) {
       if (rider) {
+        hbuf[p ^ 1][g][col] = valid ? etan : hbuf[p][g][col];
+        if (cv && !valid) {
 #pragma unroll
-        for (int i = 0; i < J; ++i) {
-          Jc[i] = cv ? out[i] : 0.0;
-          Sc[i] = cv ? Xr[i] : 0.0;
-        }
-        fj = etan;
-        if (cv) {
-#pragma unroll
-          for (int i = 0; i < J; ++i) abuf[g][col * J + i] = Sc[i];
+          for (int i = 0; i < J; ++i) abuf[p ^ 1][g][cc * J + i] = abuf[p][g][cc * J + i];
         }
       } else {
-#pragma unroll
-        for (int i = 0; i < J; ++i) {
-          Sc[i] = cv ? out[i] : 0.0;
-          pbuf[g][col][i] = Sc[i];
-        }
-        fj = fn;
-        bbuf[g][col] = fn;
+        bbuf[p ^ 1][g][col] = valid ? fn : bbuf[p][g][col];
       }
     }
     if (more) {
@@ -432,18 +418,18 @@ __global__ void __launch_bounds__(64) group_compose_kernel(const SegParams S) {
     double* o = S.parents + seg * ELEM;
     if (rider) {
 #pragma unroll
-      for (int i = 0; i < J; ++i) o[i * J + cc] = Sc[i];  // A row-major
-      o[J * J + J + SZ + cc] = fj;                        // eta
+      for (int i = 0; i < J; ++i) o[i * J + cc] = abuf[p][g][cc * J + i];  // A row-major
+      o[J * J + J + SZ + cc] = hbuf[p][g][col];                           // eta
       double* oj = o + J * J + J + SZ + J;
 #pragma unroll
       for (int k = 0; k < J; ++k)
-        if (k <= col) oj[tri(k, cc)] = Jc[k];
+        if (k <= col) oj[tri(k, cc)] = jbuf[p][g][col][k];
     } else {
-      o[J * J + cc] = fj;  // b
+      o[J * J + cc] = bbuf[p][g][col];  // b
       double* oc = o + J * J + J;
 #pragma unroll
       for (int k = 0; k < J; ++k)
-        if (k <= col) oc[tri(k, cc)] = Sc[k];
+        if (k <= col) oc[tri(k, cc)] = pbuf[p][g][col][k];
     }
   }
 }
@@ -494,8 +480,6 @@ void launch_multilevel_prefix(const BatchParams& P, hipStream_t s) {
     SegParams S{elems[l], nullptr, nullptr, const_cast<double*>(elems[l + 1]), P.B, plan.n[l], plan.g[l], plan.n[l + 1],
                 nullptr};
     const long nseg = (long)P.B * S.np;
-    // (holding the allocator to two waves per SIMD at width 8 -- 308 -> 256 registers, 52 spilled -- was measured
-    //  slower: plan [8] 0.227 against 0.181 ms, profiles/r03g_compose_occupancy_ab.txt)
     hipLaunchKernelGGL((group_compose_kernel<J>), dim3((unsigned)((nseg + 1) / 2)), dim3(64), 0, s, S);
   }
   {  // top: one segment per problem

@@ -182,7 +182,7 @@ def test_multilevel_prefix_against_the_walk(JR, JC):
                 assert np.max(np.abs(q2 - q1) / np.abs(q1)) <= 1e-12, key
                 assert np.max(np.abs(ld2 - d0) / np.abs(d0)) <= REL, key
                 assert np.max(np.abs(q2 - q0) / np.abs(q0)) <= REL, key
-            for group in (2, 5):
+            for group in (2, 3, 5):
                 diff, big = plan.compose_check(group)
                 assert diff <= 1e-11 and big > 0.0, (family, nchunk, group, diff)
             plan.set_prefix_plan(-1, 0)

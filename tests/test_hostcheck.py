@@ -245,9 +245,10 @@ def test_multilevel_prefix_keeps_the_reference_status_on_adversarial_problems(li
 
 def test_prefix_planner(lib):
     """clr_core.h: plan_prefix -- the level structure of the multi-level prefix.  Invariants for any request, and
-    the choices the measured time model makes (profiles/r03a_prefix_ab.txt): the headline shape (1024 problems x 64
-    chunks, width 8: the composition kernel is throughput-bound there) keeps the plain walk, BASELINE config 1
-    (256 x 125..250 chunks, width 4) and a single long series go multi-level."""
+    the choices the measured time model makes (profiles/r03a_prefix_ab.txt, r03p_prefix_ab.txt): the headline shape
+    (1024 problems x 64 chunks, width 8: throughput-bound, two waves per SIMD) takes ONE level of large groups,
+    four times that batch keeps the plain walk, BASELINE config 1 (256 x 125..250 chunks, width 4) and a single long
+    series go multi-level."""
     def plan(nchunk, levels=-1, g=0, B=1, J=8):
         out = np.zeros(8, dtype=np.int32)
         tm = C.c_double()
@@ -263,7 +264,9 @@ def test_prefix_planner(lib):
                 assert gs[l] >= 2 if l < lv else gs[l] == 1
                 if l < lv:
                     assert ns[l] >= 2 * gs[l]          # a level keeps at least two groups
-    assert plan(64, B=1024, J=8)[0] == 0               # headline: the walk
+    lv, gs, ns, tm = plan(64, B=1024, J=8)             # headline: one level (measured best: groups of 8)
+    assert lv == 1 and 6 <= gs[0] <= 10, (lv, gs)
+    assert plan(64, B=4096, J=8)[0] == 0               # throughput-bound: the walk
     assert plan(125, B=256, J=4)[0] >= 1 and plan(250, B=256, J=4)[0] >= 1
     lv, gs, ns, tm = plan(2048, B=1, J=8)
     assert lv >= 2 and ns[lv] <= 64 and tm < 0.2 * plan(2048, 0, 0, B=1, J=8)[3]
