@@ -65,6 +65,8 @@ def _load():
     lib.clr_batch_set_warm_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.clr_batch_get_warm_start.argtypes = [C.c_void_p] + [_ip] * 7
     lib.clr_batch_set_prefix_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.clr_batch_grad.argtypes = [C.c_void_p, _dp, _dp, _ip]
+    lib.clr_batch_get_grad_fallbacks.argtypes = [C.c_void_p, _ip]
     lib.clr_batch_get_prefix_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
     lib.clr_batch_debug_get_starts.argtypes = [C.c_void_p, _dp]
     lib.clr_batch_debug_compose_check.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -338,6 +340,21 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_warm_start(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("active", "chunks", "chunk_len", "warmup_min", "warmup_max", "settled", "fallbacks"),
                         [x.value for x in v]))
+
+    def grad_log_likelihood(self):
+        """``(value[B], grad[B, 1 + 2 J_real + 4 J_comp], status[B])`` at the coefficients in force, parallel in n
+        (``clr_batch_grad``; the reference's conventions per problem, ``CholeskySolver.grad_log_likelihood``,
+        solver.cpp:347-463)."""
+        NG = 1 + 2 * self.J_real + 4 * self.J_comp
+        value, grad, st = np.empty(self.B), np.empty((self.B, NG)), np.empty(self.B, dtype=np.int32)
+        _check(_load().clr_batch_grad(self._h, _ptr(value), _ptr(grad), st.ctypes.data_as(_ip)))
+        return value, grad, st
+
+    def grad_fallbacks(self):
+        """Problems of the last :meth:`grad_log_likelihood` that took the sequential gradient kernel."""
+        n = C.c_int()
+        _check(_load().clr_batch_get_grad_fallbacks(self._h, C.byref(n)))
+        return n.value
 
     def set_replay_source(self, source=-1):
         """Series view of the replay pass behind the role-split summarize: 0 the chunk-interleaved copy,

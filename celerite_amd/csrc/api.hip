@@ -302,6 +302,11 @@ struct clr_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   bool have_stream = false;
+  // grad_log_likelihood parallel in n (widths 1..8, no general terms): a one-problem plan kept between calls, and
+  // the series it holds (an optimiser calls with the same t, diag, y and new coefficients)
+  struct clr_batch* grad_plan = nullptr;
+  int grad_N = 0, grad_JR = -1, grad_JC = -1;
+  std::vector<double> grad_series;
   int computed = 0, N = 0, J = 0;
   double log_det = 0.0;
   int J_real = 0, J_comp = 0, J_general = 0;
@@ -352,6 +357,10 @@ struct clr_batch {
   int plan_levels = -1, plan_g = 0;   // clr_batch_set_prefix_plan: < 0 = chosen by clr::plan_prefix
   clr::PrefixPlan plan;
   DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
+  DevBuf g_riders, g_out, g_res;      // chunk-parallel gradient (clr_grad_kernels.h): riders, records, result (+ fallback)
+  std::vector<double> host_jitter;    // per problem, as set (the reference zeroes d/d jitter at jitter <= eps)
+  bool grad_scan_only = false;        // the evaluation inside clr_batch_grad: by the scan, its start states are needed
+  int grad_fallbacks = 0;             // problems of the last gradient that took the sequential kernel
   double cert_resid = 1e-11;          // end-state mismatch of the chunked replay that still counts as consistent
   double cert_gamma = 1e7;            // conditioning record gamma_max / mu_min above which a problem leaves the replay-free route
   double cert_gamma_abs = 1e4;        // ... and gamma_max alone (decide_kernel; calibration: profiles/r03_conditioning_calibration.txt)
@@ -573,6 +582,7 @@ clr_solver* clr_solver_create(void) {
 
 void clr_solver_destroy(clr_solver* s) {
   if (!s) return;
+  if (s->grad_plan) clr_batch_destroy(s->grad_plan);
   if (s->have_stream) {
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
@@ -893,6 +903,35 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   if (n_grad != G || !value || !grad) return fail(CLR_INVALID_ARGUMENT, "grad must hold 1 + 2 J_real + 4 J_comp values");
   if ((st = ensure_stream(s)) != CLR_OK) return st;
   hipStream_t stream = s->stream;
+
+  if (!has_general && JG == 0 && JR + 2 * JC >= 1 && JR + 2 * JC <= 8 && N >= 2048 && !getenv("CLR_GRAD_SEQUENTIAL")) {
+    // parallel in n: the scan + the chunk-wise tangents (clr_batch_grad) on a one-problem plan
+    if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC) {
+      if (s->grad_plan) clr_batch_destroy(s->grad_plan);
+      s->grad_plan = clr_batch_create(1, N, JR, JC, s->device);
+      s->grad_series.clear();
+      s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC;
+    }
+    if (s->grad_plan) {
+      const size_t n = (size_t)N;
+      const bool same = s->grad_series.size() == 3 * n && !memcmp(s->grad_series.data(), x, n * sizeof(double)) &&
+                        !memcmp(s->grad_series.data() + n, diag, n * sizeof(double)) &&
+                        !memcmp(s->grad_series.data() + 2 * n, y, n * sizeof(double));
+      if (!same) {
+        if ((st = clr_batch_set_series(s->grad_plan, x, 0, diag, 0, y, 0)) != CLR_OK) return st;
+        s->grad_series.resize(3 * n);
+        memcpy(s->grad_series.data(), x, n * sizeof(double));
+        memcpy(s->grad_series.data() + n, diag, n * sizeof(double));
+        memcpy(s->grad_series.data() + 2 * n, y, n * sizeof(double));
+      }
+      if ((st = clr_batch_set_coefficients(s->grad_plan, &jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp)) != CLR_OK)
+        return st;
+      int pst = CLR_OK;
+      if ((st = clr_batch_grad(s->grad_plan, value, grad, &pst)) != CLR_OK) return st;
+      if (pst != CLR_OK) return fail(CLR_NOT_POSITIVE_DEFINITE, "failed to factorize or solve matrix");
+      return CLR_OK;
+    }
+  }
 
   // one staging buffer: coefficients | A | U | V | t | diag | y | value, grad | status
   std::vector<double> host;
@@ -1320,7 +1359,8 @@ void clr_batch_destroy(clr_batch* h) {
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
-                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV})
+                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
+                    &h->g_res})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1587,8 +1627,8 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   double* w = h->pin;
   auto put = [&](const double* p, size_t n) { if (n) memcpy(w, p, n * sizeof(double)); w += n; };
   put(a_real, nr); put(c_real, nr); put(a_comp, nc); put(b_comp, nc); put(c_comp, nc); put(d_comp, nc);
-  if (jitter) put(jitter, B);
-  else { memset(w, 0, B * sizeof(double)); w += B; }  // NULL: no jitter
+  if (jitter) { put(jitter, B); h->host_jitter.assign(jitter, jitter + B); }
+  else { memset(w, 0, B * sizeof(double)); w += B; h->host_jitter.assign(B, 0.0); }  // NULL: no jitter
   if ((st = h->coeffs.reserve(total)) != CLR_OK) return st;
   HIP_TRY(hipMemcpyAsync(h->coeffs.p, h->pin, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->warm_active) {  // K per problem, behind the coefficients in the staging buffer
@@ -2120,6 +2160,7 @@ int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps)
 }
 
 static bool warm_runs(const clr_batch* h, int materialize) {
+  if (h->grad_scan_only) return false;
   return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
 }
 
@@ -2313,6 +2354,101 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double*
   return CLR_OK;
 }
 
+// Value and gradient of every problem of the plan at the coefficients in force, parallel in n (clr_grad_core.h):
+// the evaluation by the scan, then per chunk the riders and the tangents of every direction group from the scanned
+// start states, then the walk over the chunks.  Problems the scan routed to the sequential recurrence take the
+// sequential gradient kernel (grad_kernels.hip).
+int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch || h->J_general > 0)
+    return fail(CLR_UNSUPPORTED, "the plan gradient covers widths 1..8 without general terms: use clr_batch_grad_log_likelihood");
+  const size_t B = (size_t)h->B, NG = 1 + 2 * (size_t)h->J_real + 4 * (size_t)h->J_comp, J = (size_t)h->J;
+  const size_t SZ = J * (J + 1) / 2, OUT = SZ + J + 2, RID = J * J + J + SZ;
+  h->grad_scan_only = true;
+  st = clr_batch_enqueue(h, 0);
+  h->grad_scan_only = false;
+  if (st != CLR_OK) return st;
+  clr::BatchParams P;
+  h->in_fallback = true;  // (the row-major arrays)
+  st = batch_params(h, 0, P);
+  h->in_fallback = false;
+  if (st != CLR_OK) return st;
+  // gradient chunks: m chunks of the scan each.  Modelled time: rounds of tangent waves x steps per lane (2.7 us per
+  // step of a wave at width 8, ~ J^2) + the walk over the gradient chunks (5 us per chunk, ~ J^3)
+  int m = 1;
+  {
+    const double groups = 1.0 + h->J_real + 2.0 * h->J_comp, w2 = (double)(J * J) / 64.0;
+    double best = INFINITY;
+    for (int k = 1; k <= h->nchunk; ++k) {
+      const int ng = (h->nchunk + k - 1) / k;
+      const double waves = (double)B * ((ng + 63) / 64) * groups;
+      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * (0.3 + 2.4 * w2) + ng * (0.5 + 4.5 * w2 * J / 8.0);
+      if (tm < best) { best = tm; m = k; }
+    }
+  }
+  P.g_m = m;
+  P.g_nchunk = (h->nchunk + m - 1) / m;
+  const size_t pc = B * (size_t)P.g_nchunk;
+  if ((st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
+  if ((st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
+  if ((st = h->g_res.reserve(B * NG + B * (NG + 1) + B)) != CLR_OK) return st;  // result | fallback value, grad | fallback status
+  P.g_riders = h->g_riders.p; P.g_out = h->g_out.p; P.g_res = h->g_res.p;
+  const bool scan_grad = P.fast_trig != 0;  // (only the fast-sincos flavour of the tangent kernels is built)
+  if (scan_grad) {
+    h->launch->grad(P, h->stream);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<double> ll(B), ld(B), qd(B), res(B * NG);
+  std::vector<int> stt(B), lvl(B);
+  if ((st = clr_batch_get_results(h, ll.data(), ld.data(), qd.data(), stt.data())) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(res.data(), h->g_res.p, B * NG * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(lvl.data(), P.need_exact, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  // the sequential gradient for the problems whose scanned start states are not certified
+  int nfb = 0;
+  for (size_t b = 0; b < B; ++b) nfb += (stt[b] == CLR_OK && (lvl[b] >= 2 || !scan_grad));
+  h->grad_fallbacks = nfb;
+  std::vector<double> fb;
+  if (nfb) {
+    clr::GradParams G;
+    memset(&G, 0, sizeof(G));
+    G.N = h->N; G.J_real = h->J_real; G.J_comp = h->J_comp; G.J_general = 0;
+    G.a_real = P.a_real; G.c_real = P.c_real; G.a_comp = P.a_comp; G.b_comp = P.b_comp; G.c_comp = P.c_comp; G.d_comp = P.d_comp;
+    G.jitter_b = P.jitter;
+    G.t = h->t.p; G.diag = h->diag.p; G.y = h->y.p;
+    G.t_stride = h->t_stride; G.diag_stride = h->diag_stride; G.y_stride = h->y_stride;
+    G.B = h->B;
+    G.fast_trig = P.fast_trig;
+    G.only_level = scan_grad ? P.need_exact : nullptr;
+    G.out_value = h->g_res.p + B * NG; G.out_grad = G.out_value + B;
+    G.out_status = reinterpret_cast<int*>(G.out_grad + B * NG);
+    clr::launch_grad(G, h->stream);
+    HIP_TRY(hipGetLastError());
+    fb.resize(B * NG);
+    HIP_TRY(hipMemcpyAsync(fb.data(), G.out_grad, B * NG * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  const double cst = 3.14159265358979323846 * log((double)h->N);  // the reference's constant (solver.cpp:415)
+  for (size_t b = 0; b < B; ++b) {
+    const bool bad = stt[b] != CLR_OK;
+    const bool from_fb = !bad && (lvl[b] >= 2 || !scan_grad);
+    if (status) status[b] = stt[b];
+    if (value) value[b] = bad ? -INFINITY : -0.5 * (qd[b] + ld[b] + cst);
+    if (grad) {
+      for (size_t g = 0; g < NG; ++g) grad[b * NG + g] = bad ? 0.0 : (from_fb ? fb[b * NG + g] : res[b * NG + g]);
+      if (!(h->host_jitter[b] > 2.220446049250313e-16)) grad[b * NG] = 0.0;  // solver.cpp:379-389,419-426
+    }
+  }
+  return CLR_OK;
+}
+
+int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count) {
+  if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
+  *count = h->grad_fallbacks;
+  return CLR_OK;
+}
+
 int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
@@ -2425,6 +2561,17 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
     if (sd != 0 && sd != N) return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   int st = require_device(device);
   if (st != CLR_OK) return st;
+  if (J_real + 2 * J_comp <= 8 && N >= 512 && !getenv("CLR_GRAD_SEQUENTIAL")) {
+    // widths 1..8: parallel in n through a plan (clr_batch_grad); short series and the other widths below
+    clr_batch* h = clr_batch_create(B, N, J_real, J_comp, device);
+    if (h) {
+      st = clr_batch_set_series(h, t, t_stride, diag, diag_stride, y, y_stride);
+      if (st == CLR_OK) st = clr_batch_set_coefficients(h, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+      if (st == CLR_OK) st = clr_batch_grad(h, value, grad, status);
+      clr_batch_destroy(h);
+      return st;
+    }
+  }
   const size_t Bn = (size_t)B, nr = Bn * J_real, nc = Bn * J_comp, NG = 1 + 2 * (size_t)J_real + 4 * (size_t)J_comp;
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : (long)N * B); };
   hipStream_t stream;

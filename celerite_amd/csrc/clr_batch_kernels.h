@@ -74,6 +74,9 @@ struct BatchParams {
   double cert_eg;         // ... or whose gamma_max x (largest measured G error of its chunks) reaches this (<= 0: no test)
   double cert_resid;  // largest relative mismatch between a replayed chunk's end state and the scanned
                       // start state of the next chunk that still counts as consistent
+  // chunk-parallel gradient (clr_grad_kernels.h): riders [B][nchunk][RID], records [B][nchunk][NG][OUT], result [B][NG]
+  double *g_riders, *g_out, *g_res;
+  int g_m, g_nchunk;      // a gradient chunk = g_m chunks of the scan; g_nchunk = ceil(nchunk / g_m)
   // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace
   const int* wK;     // [B] warm-up steps of problem b (wave-uniform per block); <= 0: the problem takes the scan
   // the series as the warm kernel reads them: [problem][row][chunk], row r of chunk c = sample c wL - wKpad + r,
@@ -827,6 +830,7 @@ __global__ void __launch_bounds__(64) warm_check_kernel(const BatchParams P) {
 
 }  // namespace clr
 #include "clr_prefix_kernels.h"
+#include "clr_grad_kernels.h"
 namespace clr {
 
 // One table entry per (JR, JC): host-callable launchers.
@@ -840,6 +844,7 @@ struct BatchLaunchers {
   // single-lane host-checked form (-> ref); both [B][ceil(nchunk / g)][ELEM]
   void (*compose_check)(const BatchParams&, int g, double* coop, double* ref, hipStream_t);
   void (*warm)(const BatchParams&, hipStream_t);  // warm_kernel + warm_check_kernel
+  void (*grad)(const BatchParams&, hipStream_t);  // riders + tangents + walk over the chunks (needs P.fast_trig)
   int elem_doubles, start_doubles;
 };
 
@@ -904,8 +909,16 @@ struct BatchImpl {
     else hipLaunchKernelGGL((warm_kernel<JR, JC, false>), grid, dim3(64), 0, s, P);
     hipLaunchKernelGGL((warm_check_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
   }
+  static void grad(const BatchParams& P, hipStream_t s) {
+    using Sh = GradShape<JR, JC>;
+    const dim3 grid((P.g_nchunk + 63) / 64, P.B);
+    hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    hipLaunchKernelGGL((grad_tangent_kernel<JR, JC, true>), dim3(grid.x, P.B, Sh::GROUPS), dim3(64), 0, s, P);
+    const long n = (long)P.B * Sh::NG;
+    hipLaunchKernelGGL((grad_combine_kernel<JR + 2 * JC>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, Sh::NG);
+  }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm,
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad,
                           Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };

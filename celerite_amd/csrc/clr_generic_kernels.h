@@ -90,6 +90,7 @@ struct GradParams {
   int B;
   const double* jitter_b;
   long t_stride, diag_stride, y_stride;
+  const int* only_level;  // batched, may be null: only the problems with only_level[b] >= 2 are computed
 };
 void launch_grad(const GradParams& P, hipStream_t s);
 

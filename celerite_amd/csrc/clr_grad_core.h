@@ -1,0 +1,458 @@
+// celerite_amd/csrc/clr_grad_core.h -- CholeskySolver.grad_log_likelihood parallel in n (widths 1..8).
+//
+// The reference differentiates compute (cholesky.h:41-210) + dot_solve (:326-401) in forward mode
+// (celerite/solver.cpp:347-463): one tangent recurrence per partial on top of the base recurrence.  A tangent
+// recurrence is LINEAR in the tangent state (dS, df) once the base trajectory is fixed:
+//     dS_{n+1} = F_n dS_n F_n^T + (terms explicit in the direction),   F_n = Phi_n (I - w_n u_n^T)
+//     df_{n+1} = F_n df_n - F_n dS_n u_n x_n / D_n + (explicit terms)
+// so over a chunk of samples [n0, n1) that starts from the TRUE base state (the start states the scan already
+// produced, clr_batch_kernels.h) a tangent splits into
+//   * the tangent from a ZERO tangent start, driven by the direction's explicit terms (grad_chunk: every
+//     (chunk, direction) independently -- this is where the time goes), and
+//   * the homogeneous propagation of the tangent state the chunk starts with, which needs only three riders of
+//     the base trajectory, shared by all directions (grad_riders_chunk):
+//         AA = F_{n1-1} ... F_{n0}          eta = sum_n r_n x_n / D_n        JJ = sum_n r_n r_n^T / D_n,
+//         r_n = (F_{n-1} ... F_{n0})^T u_n:
+//         dS_end = AA dS_0 AA^T            df_end = AA (df_0 - dS_0 eta)
+//         d(log det) = -<JJ, dS_0>         d(quad) = -2 eta . df_0 + eta^T dS_0 eta
+//     (the sum over n of the quad terms telescopes; derivation in DESIGN.md section 8.6).
+// grad_combine walks the chunks of one (problem, direction): a 2 J^3 update per chunk, nothing per sample.
+//
+// Directions in the reference's order (solver.cpp:379-406): jitter | a_real | c_real | a_comp | b_comp | c_comp |
+// d_comp.  A wave carries the TWO directions of one group -- {a_real_j, c_real_j}, {a_comp_j, b_comp_j},
+// {c_comp_j, d_comp_j}, {jitter} -- on one base recurrence, with the group's term swapped to the LAST position of
+// its kind when the coefficients and the start state are loaded: a direction only touches the rows of its own
+// term (U~, V~, phi: cholesky.h:129-147), and with the swap those rows are compile-time constants (the recurrence
+// does not care about the order of the terms; sums change in the last bits only).
+#pragma once
+
+#include "clr_core.h"
+
+namespace clr {
+
+template <int JR, int JC>
+struct GradShape {
+  static constexpr int J = JR + 2 * JC;
+  static constexpr int SZ = J * (J + 1) / 2;
+  static constexpr int NG = 1 + 2 * JR + 4 * JC;   // partials
+  static constexpr int GROUPS = 1 + JR + 2 * JC;   // waves per 64 chunks
+  static constexpr int OUT = SZ + J + 2;           // per (chunk, direction): G[SZ] g[J] d(log det) d(quad), zero tangent start
+  static constexpr int RID = J * J + J + SZ;       // per chunk: AA[J][J] eta[J] JJ[SZ]
+};
+
+// group -> kind (0 jitter, 1 real term, 2 complex a/b, 3 complex c/d), term, the two direction numbers (-1: none)
+template <int JR, int JC>
+CLR_HD void grad_group(int g, int* kind, int* term, int* q0, int* q1) {
+  if (g == 0) { *kind = 0; *term = 0; *q0 = 0; *q1 = -1; return; }
+  g -= 1;
+  if (g < JR) { *kind = 1; *term = g; *q0 = 1 + g; *q1 = 1 + JR + g; return; }
+  g -= JR;
+  if (g < JC) { *kind = 2; *term = g; *q0 = 1 + 2 * JR + g; *q1 = 1 + 2 * JR + JC + g; return; }
+  g -= JC;
+  *kind = 3; *term = g; *q0 = 1 + 2 * JR + 2 * JC + g; *q1 = 1 + 2 * JR + 3 * JC + g;
+}
+
+template <int J, int R>
+CLR_HD void grad_add_col(const double* S, double c, double* y) {
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) y[i] = fma(S[sym(i, R)], c, y[i]);
+}
+
+// ---------------------------------------------------------------------------
+// One chunk, one group: the base recurrence from `start` (packed S[SZ] f[J] in the problem's own row order, or
+// null = zero state) and the two tangents of the group from zero tangent states.  Coefficients are read through
+// the pointers (this problem's rows) with the group's term swapped to the end.  out0 / out1: [OUT] each, row order
+// of the problem (out1 may be null: the jitter group has one direction).
+// ---------------------------------------------------------------------------
+template <int JR, int JC, bool FAST, class Src>
+CLR_HD void grad_chunk(const double* a_real, const double* c_real, const double* a_comp, const double* b_comp,
+                       const double* c_comp, const double* d_comp, double jitter, Src& src, int L, int N, int n0,
+                       const double* start, int group, double* out0, double* out1) {
+  using Sh = GradShape<JR, JC>;
+  constexpr int J = Sh::J, SZ = Sh::SZ, M = JR + JC;
+  constexpr int RR = JR > 0 ? JR - 1 : 0;  // the swapped real term's row
+  constexpr int CR = JC > 0 ? J - 2 : 0;   // the swapped complex term's rows CR, CB = CR + 1
+  constexpr int CB = JC > 0 ? J - 1 : 0;
+  int kind, term, q0, q1;
+  grad_group<JR, JC>(group, &kind, &term, &q0, &q1);
+
+  // the problem with the group's term last, and the row map working row -> problem row
+  Problem<JR, JC> p;
+  int perm[J];
+  {
+    const int sr = kind == 1 ? term : JR - 1, sc = kind >= 2 ? term : JC - 1;
+    p.sum_ar = 0.0;
+    p.sum_ac = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < JR; ++j) {
+      const int o = j == JR - 1 ? sr : (j == sr ? JR - 1 : j);
+      p.ar[j] = a_real[o];
+      p.cr[j] = c_real[o];
+      perm[j] = o;
+    }
+    CLR_UNROLL
+    for (int j = 0; j < JC; ++j) {
+      const int o = j == JC - 1 ? sc : (j == sc ? JC - 1 : j);
+      p.ac[j] = a_comp[o];
+      p.bc[j] = b_comp[o];
+      p.cc[j] = c_comp[o];
+      p.dc[j] = d_comp[o];
+      perm[JR + 2 * j] = JR + 2 * o;
+      perm[JR + 2 * j + 1] = JR + 2 * o + 1;
+    }
+    // K(0) is summed in the problem's own order (cholesky.h:98), whatever the swap
+    CLR_UNROLL
+    for (int j = 0; j < JR; ++j) p.sum_ar += a_real[j];
+    CLR_UNROLL
+    for (int j = 0; j < JC; ++j) p.sum_ac += a_comp[j];
+    p.jitter = jitter;
+  }
+
+  double S[SZ], f[J];
+  CLR_UNROLL
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL
+    for (int k = 0; k <= j; ++k) {
+      const int a = perm[k], b = perm[j];
+      S[tri(k, j)] = start ? start[a <= b ? a + b * (b + 1) / 2 : b + a * (a + 1) / 2] : 0.0;
+    }
+    f[j] = start ? start[SZ + perm[j]] : 0.0;
+  }
+  double dS[2][SZ], df[2][J], dld[2] = {0.0, 0.0}, dqd[2] = {0.0, 0.0};
+  CLR_UNROLL
+  for (int e = 0; e < 2; ++e) {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) dS[e][i] = 0.0;
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) df[e][i] = 0.0;
+  }
+
+  src.prologue();
+  double tn = src.t(0);
+  double t_next = src.t(1);
+  double diag_n = src.diag(0), y_n = src.y(0);
+  for (int i = 0; i < L; ++i) {
+    src.step_begin(i);
+    const int n = n0 + i;
+    const bool valid = n < N;
+    const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
+    if (i + 1 < L) {
+      t_next = src.t(i + 2);
+      diag_n = src.diag(i + 1);
+      y_n = src.y(i + 1);
+    }
+    const double dt = t_cur_next - tn;
+
+    // ---- base step up to w, x (cholesky.h:126-179, :384-398) ----
+    double u[J], v[J];
+    features_uv<JR, JC, FAST>(p, tn, u, v);
+    double q[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += S[sym(k, j)] * u[k];
+      q[j] = acc;
+    }
+    double s = 0.0, uf = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
+    const double D = p.diagonal(diag_cur) - s;
+    const double invD = 1.0 / D;
+    const double x = y_cur - uf;
+    const double xs = x * invD;
+    double z[J], w[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      z[j] = v[j] - q[j];
+      w[j] = z[j] * invD;
+    }
+    double phid[nz(M)], pp[nz(M * (M + 1) / 2)];
+    features_phi_distinct<JR, JC>(p, dt, phid);
+    CLR_UNROLL
+    for (int b = 0; b < M; ++b) {
+      CLR_UNROLL
+      for (int a = 0; a <= b; ++a) pp[tri(a, b)] = phid[a] * phid[b];
+    }
+
+    // ---- the two tangents: everything that reads the state BEFORE this step ----
+    CLR_UNROLL
+    for (int e = 0; e < 2; ++e) {
+      // the direction's explicit terms: d K(0), dU~ / dV~ at the term's rows
+      double da = 0.0, duA = 0.0, duB = 0.0, dvA = 0.0, dvB = 0.0;
+      if (kind == 0) {
+        da = 1.0;                                                        // jitter (cholesky.h:98)
+      } else if (kind == 1) {
+        if (e == 0) { da = 1.0; duA = 1.0; }                             // a_real: U~ = a (cholesky.h:131)
+      } else if (kind == 2) {
+        if (e == 0) { da = 1.0; duA = v[CR]; duB = v[CB]; }          // a_comp: U~ = (a cd + b sd, a sd - b cd)
+        else { duA = v[CB]; duB = -v[CR]; }                          // b_comp
+      } else if (e == 1) {                                               // d_comp: the phase d t
+        duA = -tn * u[CB]; duB = tn * u[CR];
+        dvA = -tn * v[CB]; dvB = tn * v[CR];
+      }
+      double dq[J];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) acc += dS[e][sym(k, j)] * u[k];
+        dq[j] = acc;
+      }
+      double duq = 0.0, duf = 0.0;
+      if (kind == 1) {
+        if (JR > 0) { grad_add_col<J, RR>(S, duA, dq); duq = duA * q[RR]; duf = duA * f[RR]; }
+      } else if (kind >= 2) {
+        if (JC > 0) {
+          grad_add_col<J, CR>(S, duA, dq);
+          grad_add_col<J, CB>(S, duB, dq);
+          duq = duA * q[CR] + duB * q[CB];
+          duf = duA * f[CR] + duB * f[CB];
+        }
+      }
+      double ds = duq, dx = duf;
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) { ds += u[j] * dq[j]; dx += u[j] * df[e][j]; }
+      dx = -dx;
+      const double dD = da - ds;
+      if (valid) {
+        dld[e] = fma(dD, invD, dld[e]);
+        dqd[e] += (2.0 * dx - xs * dD) * xs;
+      }
+      double dz[J], dw[J];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) dz[j] = -dq[j];
+      if (kind == 3 && JC > 0) { dz[CR] += dvA; dz[CB] += dvB; }
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) dw[j] = (dz[j] - w[j] * dD) * invD;
+      // dS <- Phi (dS + dz w^T + z dw^T) Phi ; df <- Phi (df + dw x + w dx)   (the d Phi parts follow the base update)
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        CLR_UNROLL
+        for (int k = 0; k <= j; ++k)
+          dS[e][tri(k, j)] = pp[tri(phi_index<JR>(k), phi_index<JR>(j))] *
+                             fma(dz[k], w[j], fma(z[k], dw[j], dS[e][tri(k, j)]));
+        df[e][j] = phid[phi_index<JR>(j)] * (df[e][j] + fma(dw[j], x, w[j] * dx));
+      }
+    }
+
+    // ---- base update ----
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) f[j] = phid[phi_index<JR>(j)] * (f[j] + w[j] * x);
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k)
+        S[tri(k, j)] = pp[tri(phi_index<JR>(k), phi_index<JR>(j))] * fma(z[k], w[j], S[tri(k, j)]);
+    }
+
+    // ---- d Phi: phi = exp(-c dt) (cholesky.h:130,140) => d phi / dc = -dt phi on the term's rows, i.e.
+    //      dS_ik += -dt ([i in term] + [k in term]) S_ik(new),  df_i += -dt [i in term] f_i(new) ----
+    if (kind == 1) {
+      if (JR > 0) {
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) dS[1][sym(RR, k)] = fma(k == RR ? -2.0 * dt : -dt, S[sym(RR, k)], dS[1][sym(RR, k)]);
+        df[1][RR] = fma(-dt, f[RR], df[1][RR]);
+      }
+    } else if (kind == 3) {
+      if (JC > 0) {
+        CLR_UNROLL
+        for (int k = 0; k < CR; ++k) {
+          dS[0][sym(CR, k)] = fma(-dt, S[sym(CR, k)], dS[0][sym(CR, k)]);
+          dS[0][sym(CB, k)] = fma(-dt, S[sym(CB, k)], dS[0][sym(CB, k)]);
+        }
+        dS[0][tri(CR, CR)] = fma(-2.0 * dt, S[tri(CR, CR)], dS[0][tri(CR, CR)]);
+        dS[0][tri(CR, CB)] = fma(-2.0 * dt, S[tri(CR, CB)], dS[0][tri(CR, CB)]);
+        dS[0][tri(CB, CB)] = fma(-2.0 * dt, S[tri(CB, CB)], dS[0][tri(CB, CB)]);
+        df[0][CR] = fma(-dt, f[CR], df[0][CR]);
+        df[0][CB] = fma(-dt, f[CB], df[0][CB]);
+      }
+    }
+    tn = t_cur_next;
+    src.step_end(i);
+  }
+
+  // ---- store in the problem's row order ----
+  CLR_UNROLL
+  for (int e = 0; e < 2; ++e) {
+    double* o = e == 0 ? out0 : out1;
+    if (!o) continue;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k) {
+        const int a = perm[k], b = perm[j];
+        o[a <= b ? a + b * (b + 1) / 2 : b + a * (a + 1) / 2] = dS[e][tri(k, j)];
+      }
+      o[SZ + perm[j]] = df[e][j];
+    }
+    o[SZ + J] = dld[e];
+    o[SZ + J + 1] = dqd[e];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The riders of one chunk along the base trajectory from `start`: out = AA[J][J] row-major | eta[J] | JJ[SZ].
+// Only samples of the series (n < N) enter eta and JJ; AA of the last chunk is never used.
+// ---------------------------------------------------------------------------
+template <int JR, int JC, bool FAST, class Src>
+CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* start,
+                              double* out) {
+  using Sh = GradShape<JR, JC>;
+  constexpr int J = Sh::J, SZ = Sh::SZ;
+  double S[SZ], f[J], AA[J * J], eta[J], JJ[SZ];
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) { S[i] = start ? start[i] : 0.0; JJ[i] = 0.0; }
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) { f[i] = start ? start[SZ + i] : 0.0; eta[i] = 0.0; }
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) AA[i * J + j] = i == j ? 1.0 : 0.0;
+  }
+  src.prologue();
+  double tn = src.t(0);
+  double t_next = src.t(1);
+  double diag_n = src.diag(0), y_n = src.y(0);
+  for (int i = 0; i < L; ++i) {
+    src.step_begin(i);
+    const bool valid = n0 + i < N;
+    const double t_cur_next = t_next, diag_cur = diag_n, y_cur = y_n;
+    if (i + 1 < L) {
+      t_next = src.t(i + 2);
+      diag_n = src.diag(i + 1);
+      y_n = src.y(i + 1);
+    }
+    double u[J], v[J];
+    features_uv<JR, JC, FAST>(p, tn, u, v);
+    double q[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += S[sym(k, j)] * u[k];
+      q[j] = acc;
+    }
+    double s = 0.0, uf = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
+    const double D = p.diagonal(diag_cur) - s;
+    const double invD = 1.0 / D;
+    const double x = y_cur - uf;
+    double z[J], w[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      z[j] = v[j] - q[j];
+      w[j] = z[j] * invD;
+    }
+    double r[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc += AA[k * J + j] * u[k];
+      r[j] = acc;
+    }
+    if (valid) {
+      const double xs = x * invD;
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        eta[j] = fma(r[j], xs, eta[j]);
+        const double rj = r[j] * invD;
+        CLR_UNROLL
+        for (int k = 0; k <= j; ++k) JJ[tri(k, j)] = fma(r[k], rj, JJ[tri(k, j)]);
+      }
+    }
+    double phid[nz(JR + JC)];
+    features_phi_distinct<JR, JC>(p, t_cur_next - tn, phid);
+    CLR_UNROLL
+    for (int k = 0; k < J; ++k) {
+      const double ph = phid[phi_index<JR>(k)];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) AA[k * J + j] = ph * fma(-w[k], r[j], AA[k * J + j]);
+      f[k] = ph * (f[k] + w[k] * x);
+    }
+    decay_rank1_update<JR, JC>(phid, z, w, S);
+    tn = t_cur_next;
+    src.step_end(i);
+  }
+  CLR_UNROLL
+  for (int i = 0; i < J * J; ++i) out[i] = AA[i];
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) out[J * J + i] = eta[i];
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) out[J * J + J + i] = JJ[i];
+}
+
+// ---------------------------------------------------------------------------
+// One (problem, direction): walk the chunks.  riders: [nchunk][RID]; gout: this direction's record of chunk c at
+// gout + c * stride ([OUT]).  Returns d(log det), d(quad) of the whole series.
+// ---------------------------------------------------------------------------
+template <int J>
+CLR_HD void grad_combine(int nchunk, const double* riders, const double* gout, long stride, double* dld_out,
+                         double* dquad_out) {
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ;
+  double dS[SZ], df[J];
+  CLR_UNROLL_J
+  for (int i = 0; i < SZ; ++i) dS[i] = 0.0;
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) df[i] = 0.0;
+  double dld = 0.0, dqd = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const double* R = riders + (long)c * RID;
+    const double* G = gout + (long)c * stride;
+    const double *AA = R, *eta = R + J * J, *JJ = R + J * J + J;
+    double acc = 0.0;
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL_J
+      for (int k = 0; k <= j; ++k) acc = fma(k == j ? 1.0 : 2.0, JJ[tri(k, j)] * dS[tri(k, j)], acc);
+    }
+    dld += G[SZ + J] - acc;
+    double tmp[J];
+    double e1 = 0.0, e2 = 0.0;
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      double a = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) a = fma(dS[sym(i, k)], eta[k], a);
+      tmp[i] = a;
+      e1 = fma(eta[i], df[i], e1);
+      e2 = fma(eta[i], a, e2);
+    }
+    dqd += G[SZ + J + 1] - 2.0 * e1 + e2;
+    if (c + 1 < nchunk) {
+      double h[J], T[J * J];
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) h[i] = df[i] - tmp[i];
+      CLR_UNROLL_J
+      for (int i = 0; i < J; ++i) {
+        double a = G[SZ + i];
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) a = fma(AA[i * J + k], h[k], a);
+        df[i] = a;
+        CLR_UNROLL_J
+        for (int j = 0; j < J; ++j) {
+          double b = 0.0;
+          CLR_UNROLL_J
+          for (int k = 0; k < J; ++k) b = fma(AA[i * J + k], dS[sym(k, j)], b);
+          T[i * J + j] = b;
+        }
+      }
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        CLR_UNROLL_J
+        for (int i = 0; i <= j; ++i) {
+          double b = G[tri(i, j)];
+          CLR_UNROLL_J
+          for (int k = 0; k < J; ++k) b = fma(T[i * J + k], AA[j * J + k], b);
+          dS[tri(i, j)] = b;
+        }
+      }
+    }
+  }
+  *dld_out = dld;
+  *dquad_out = dqd;
+}
+
+}  // namespace clr

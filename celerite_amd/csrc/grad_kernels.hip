@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
   GradParams P = Pin;
   if (Pin.B > 0) {  // batched: shift every pointer to problem blockIdx.y (wave-uniform)
     const long b = blockIdx.y;
+    if (Pin.only_level && Pin.only_level[b] < 2) return;  // (settled by the chunk-parallel gradient)
     const int NG = 1 + 2 * Pin.J_real + 4 * Pin.J_comp;
     P.a_real += b * Pin.J_real; P.c_real += b * Pin.J_real;
     P.a_comp += b * Pin.J_comp; P.b_comp += b * Pin.J_comp; P.c_comp += b * Pin.J_comp; P.d_comp += b * Pin.J_comp;

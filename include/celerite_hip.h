@@ -417,6 +417,17 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
                                   const double* y, long y_stride, double* value, double* grad, int* status,
                                   int device);
 
+/* The same on a plan (widths 1..8, no general terms): value and gradient of every problem at the coefficients in
+ * force, PARALLEL IN n (csrc/clr_grad_core.h).  The tangent recurrences of solver.cpp:347-463 are linear in the
+ * tangent state once the base trajectory is fixed, so after an evaluation by the scan every (chunk, direction) runs
+ * its tangent from a zero tangent state at the chunk's scanned start state; three riders of the base trajectory per
+ * chunk carry the tangent states across the chunk boundaries in a walk over the chunks per direction.  Problems the
+ * scan routed to the sequential recurrence take the sequential kernel above (count: clr_batch_get_grad_fallbacks).
+ * Synchronous; conventions of value / grad / status as above.  clr_batch_grad_log_likelihood uses this path for
+ * widths 1..8 and N >= 512. */
+int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status);
+int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
+
 /* ---- the batch axis over several GPUs (BASELINE config 4) ---------
  * Problems are independent -- every member of the reference solver is per object
  * (cholesky.h:703-706) -- so the batch axis shards embarrassingly: shard s of S owns the

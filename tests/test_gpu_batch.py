@@ -6,6 +6,8 @@ Tolerance: relative error <= 1e-10 on log_det and on the quadratic form
 (BASELINE.json north_star); integer status words must match exactly.  At the
 full bench size (N = 1e5) the oracle is only run on a sample of problems and
 the rest is covered by size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -809,6 +811,50 @@ def test_batched_grad_log_likelihood(JR, JC, N, shared):
             assert abs(value[b] - v0) <= 1e-10 * abs(v0)
             assert np.allclose(grad[b], g0, rtol=1e-8, atol=1e-10)
     assert (st == 2).sum() >= 1
+
+
+@pytest.mark.parametrize("JR,JC", [(2, 3), (1, 1), (0, 2), (3, 0), (1, 0), (0, 4), (4, 2)])
+@pytest.mark.parametrize("family", ["bench", "accuracy"])
+def test_plan_gradient_parallel_in_n(JR, JC, family):
+    """clr_batch_grad (csrc/clr_grad_core.h): the gradient parallel in n -- tangents per (chunk, direction) from the
+    scanned start states + the walk over the chunks -- against the sequential tangent kernel (one wave per partial,
+    csrc/grad_kernels.hip; itself pinned against oracle/grad.py) at several chunk counts, and against the oracle
+    directly on one problem.  An indefinite problem in the batch keeps the quiet semantics (-inf, zero gradient)."""
+    from oracle import grad as ograd
+    B, N = 5, 2500
+    case = synthetic(B, N, JR, JC, family, seed=77 + JR + 10 * JC)
+    jit = np.array([0.0, 0.01, 0.1, 0.3, 0.0])
+    (case["a_real"] if JR else case["a_comp"])[3:4] *= -50.0
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        v_seq, g_seq, st_seq = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        for nchunk in (0, 1, 5, 40):
+            plan.set_chunks(nchunk)
+            v, g, st = plan.grad_log_likelihood()
+            assert np.array_equal(st, st_seq) and st[3] == 2 and np.isneginf(v[3]) and not g[3].any()
+            ok = st == 0
+            assert np.max(np.abs(v[ok] - v_seq[ok]) / np.abs(v_seq[ok])) <= 1e-11, nchunk
+            scale = np.maximum(np.abs(g_seq[ok]), 1e-6 * np.max(np.abs(g_seq[ok]), axis=1, keepdims=True))
+            assert np.max(np.abs(g[ok] - g_seq[ok]) / scale) <= 1e-8, (nchunk, np.max(np.abs(g[ok] - g_seq[ok]) / scale))
+            assert (g[jit <= 2.3e-16, 0] == 0.0).all()          # solver.cpp:379-389
+            assert plan.grad_fallbacks() == 0
+    finally:
+        plan.close()
+    # the one-shot entry takes the same path (N >= 512) and the oracle agrees
+    v1, g1, st1 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
+    assert np.array_equal(st1, st_seq)
+    empty, empty2 = np.empty(0), np.empty((0, 0))
+    b = 1
+    co = [c[b] for c in coeffs_of(case)]
+    v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, case["t"][b], case["y"][b], case["diag"][b])
+    assert abs(v1[b] - v0) <= 1e-10 * abs(v0)
+    assert np.allclose(g1[b], g0, rtol=1e-8, atol=1e-8 * np.max(np.abs(g0)))
 
 
 @pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13)])

@@ -305,6 +305,42 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
+@pytest.mark.parametrize("JR,JC,N", [(2, 3, 3000), (1, 1, 20000), (0, 4, 6000), (3, 0, 2048)])
+def test_grad_log_likelihood_of_a_long_series_is_parallel_in_n(JR, JC, N):
+    """From N = 2048 on (widths 1..8, no general terms) CholeskySolver.grad_log_likelihood runs the scan + the
+    chunk-wise tangents on a one-problem plan (csrc/clr_grad_core.h): same numbers as the sequential tangent kernel,
+    the oracle on the shortest case, the series kept between calls, LinAlgError for an indefinite matrix."""
+    from oracle import grad as ograd
+    import os
+
+    rng = np.random.RandomState(11 + JR)
+    x = np.sort(rng.uniform(0, 0.6 * N, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    y = rng.randn(N)
+    s = celerite_amd.CholeskySolver()
+    for trial in range(2):   # second call: new coefficients, the plan and its series are reused
+        co = (np.exp(rng.uniform(-1, 1, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0, JC)),
+              0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
+        args = (0.1 * trial,) + co + NO_GENERAL + (x, y, diag)
+        value, g = s.grad_log_likelihood(*args)
+        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        try:
+            v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(*args)
+        finally:
+            del os.environ["CLR_GRAD_SEQUENTIAL"]
+        assert abs(value - v1) <= 1e-11 * abs(v1)
+        assert np.max(np.abs(g - g1)) <= 1e-8 * np.max(np.abs(g1)), np.max(np.abs(g - g1)) / np.max(np.abs(g1))
+        assert (g[0] == 0.0) == (trial == 0)
+        if N <= 3000:
+            v0, g0 = ograd.grad_log_likelihood(*args)
+            assert abs(value - v0) <= 1e-11 * abs(v0)
+            assert np.max(np.abs(g - g0)) <= 1e-8 * np.max(np.abs(g0))
+    bad = list(co)
+    bad[0 if JR else 2] = -50.0 * bad[0 if JR else 2]
+    with pytest.raises(celerite_amd.solver.LinAlgError):
+        s.grad_log_likelihood(0.0, *bad, *NO_GENERAL, x, y, diag)
+
+
 @pytest.mark.parametrize("N", [256, 700, 5000, 40000])
 @pytest.mark.parametrize("shape", ["real", "w4", "w8", "w4+general"])
 def test_long_series_sweeps_are_chunked_scans(N, shape):
