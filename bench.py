@@ -402,6 +402,67 @@ def sharded_block(B, N, JR, JC, nshards, steps, seed):
     }
 
 
+def gradient_block(B, N, JR, JC, seed):
+    """SURVEY.md 8 row f3 at the headline shape: value + gradient (1 + 2 J_real + 4 J_comp partials) of every problem,
+    parallel in n on the resident plan (clr_batch_grad: tangents per (chunk, direction group) from the scanned start
+    states + a walk over the chunks), against the sequential tangent kernel (one wave per (problem, partial)) on a
+    slice, and one series through the object API both ways."""
+    import celerite_amd
+    from celerite_amd import batch
+
+    coeffs, t, diag, y = make_inputs(B, N, JR, JC, seed)
+    NG = 1 + 2 * JR + 4 * JC
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs)
+        v, g, st = plan.grad_log_likelihood()
+        calls = 3
+        batch.device_synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            v, g, st = plan.grad_log_likelihood()
+        dt = (time.perf_counter() - t0) / calls
+        fallbacks, chunks = plan.grad_fallbacks(), plan.chunks
+    finally:
+        plan.close()
+
+    def sequential(fn):
+        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        try:
+            fn()
+            t0 = time.perf_counter()
+            out = fn()
+            return out, time.perf_counter() - t0
+        finally:
+            del os.environ["CLR_GRAD_SEQUENTIAL"]
+
+    S = min(32, B)
+    (vs, gs, sts), dts = sequential(lambda: batch.batch_grad_log_likelihood(*[c[:S] for c in coeffs], t[:S], diag[:S], y[:S]))
+    scale = np.maximum(np.abs(gs), 1e-6 * np.max(np.abs(gs), axis=1, keepdims=True))
+    e, e2 = np.empty(0), np.empty((0, 0))
+    args = (0.0,) + tuple(c[0] for c in coeffs) + (e, e2, e2, t[0], y[0], diag[0])
+    sol = celerite_amd.CholeskySolver()
+    sol.grad_log_likelihood(*args)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        vo, go = sol.grad_log_likelihood(*args)
+    d_obj = (time.perf_counter() - t0) / 5
+    (vq, gq), d_seq = sequential(lambda: celerite_amd.CholeskySolver().grad_log_likelihood(*args))
+    return {
+        "workload": "grad_log_likelihood (solver.cpp:347-463): batch=%d x N=%d, width %d, %d partials per problem" % (B, N, JR + 2 * JC, NG),
+        "path": "clr_batch_grad: evaluation by the scan, then riders + tangents per (chunk, direction group) + walk over the chunks",
+        "scan_chunks": chunks, "ms_per_call": dt * 1e3, "value": B / dt, "unit": "gradients/s",
+        "partials_per_s": B * NG / dt, "sequential_fallbacks": fallbacks, "status_not_ok": int((st != 0).sum()),
+        "sequential_kernel_slice": {"problems": S, "ms_per_problem_incl_upload": dts * 1e3 / S,
+                                    "value_rel_max": rel_err(v[:S], vs), "grad_rel_max": float(np.max(np.abs(g[:S] - gs) / scale)),
+                                    "note": "one wave per (problem, partial), sequential in n (csrc/grad_kernels.hip); pinned "
+                                            "against oracle/grad.py in the tests"},
+        "object_api_one_series": {"N": N, "ms_per_call": d_obj * 1e3, "sequential_ms_per_call": d_seq * 1e3,
+                                  "grad_rel_max": float(np.max(np.abs(go - gq)) / np.max(np.abs(gq)))},
+    }
+
+
 def object_api_config():
     """BASELINE configs[0]: one series, N = 1000, 1 real + 1 SHO term (width 3) through the
     drop-in object API (GP.compute + GP.log_likelihood), oracle timed the same way."""
@@ -471,6 +532,7 @@ def main(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 0/1/4 block")
     ap.add_argument("--no-shared-series", action="store_true", help="skip the layout-(ii) leg (profiling runs: keeps the per-kernel counter averages to the distinct-series launches)")
     ap.add_argument("--no-accuracy-family", action="store_true", help="skip the accuracy-family leg")
+    ap.add_argument("--no-gradient", action="store_true", help="skip the grad_log_likelihood leg")
     ap.add_argument("--sharded", type=int, default=2, help="shards of the product's own sharded plan (0: skip the leg)")
     ap.add_argument("--steady-seconds", type=float, default=2.5)
     ap.add_argument("--settle-seconds", type=float, default=0.5, help="untimed extra warm-up before the K timed steps")
@@ -685,6 +747,11 @@ def main(argv=None):
             out["accuracy_family"] = accuracy_family_block(B, N, JR, JC, max(K // 2, 5), 8, 4242)
         except Exception as e:  # a failing side leg must not lose the headline line
             out["accuracy_family"] = {"error": repr(e)}
+    if dist.rank == 0 and dist.world == 1 and not args.no_gradient:
+        try:
+            out["gradient"] = gradient_block(B, N, JR, JC, 42)
+        except Exception as e:
+            out["gradient"] = {"error": repr(e)}
     if dist.rank == 0 and dist.world == 1 and args.sharded > 0:
         try:
             out["sharded_product_path"] = sharded_block(B, N, JR, JC, args.sharded, max(K // 2, 5), 42)

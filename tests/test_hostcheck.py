@@ -303,3 +303,46 @@ def test_warm_started_recurrence_forgets_or_is_caught(lib, JR, JC):
     case = synthetic(3, 4000, JR, JC, "bench", seed=8 + JR)
     ld, q, res, fl = run_warm(case, 10, 128)
     assert np.min(res) > 1e-9                       # dense sampling: no forgetting within 128 samples
+
+
+@pytest.fixture(scope="module")
+def gradlib():
+    src = os.path.join(HERE, "hostcheck_grad.cpp")
+    so = os.path.join(HERE, "libhostcheck_grad.so")
+    csrc = os.path.join(os.path.dirname(HERE), "..", "celerite_amd", "csrc")
+    deps = [src, os.path.join(csrc, "clr_core.h"), os.path.join(csrc, "clr_grad_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-shared", "-fPIC", "-ffp-contract=off", "-mfma", "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("JR,JC", [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 3), (3, 2)])
+def test_chunk_parallel_gradient_against_the_dual_number_oracle(gradlib, JR, JC):
+    """csrc/clr_grad_core.h on the host: tangents per (chunk, direction group) from a ZERO tangent state at the true
+    start state of the chunk, the three riders of the base trajectory per chunk, the walk over the chunks -- equal to
+    oracle/grad.py (the reference's loops on dual numbers, solver.cpp:347-463) for 1, 3 and 8 chunks: the split of a
+    tangent into its zero-start part and the homogeneous propagation is exact, not an approximation."""
+    from oracle import grad as ograd
+    dp = C.POINTER(C.c_double)
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    rng = np.random.default_rng(100 + JR + 7 * JC)
+    N = 240
+    t = np.sort(rng.uniform(0, 0.5 * N, N))
+    diag = rng.uniform(0.5, 1.0, N)
+    y = rng.normal(size=N)
+    ar, cr = rng.uniform(0.5, 1.5, JR), rng.uniform(0.05, 0.5, JR)
+    ac, bc = rng.uniform(0.5, 1.5, JC), rng.uniform(-0.1, 0.1, JC)
+    cc, dc = rng.uniform(0.05, 0.5, JC), rng.uniform(0.5, 3.0, JC)
+    jitter = 0.05
+    e, e2 = np.empty(0), np.empty((0, 0))
+    v0, g0 = ograd.grad_log_likelihood(jitter, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
+    gradlib.hostcheck_grad.argtypes = [C.c_int] * 4 + [C.c_double] + [dp] * 9 + [C.POINTER(C.c_double)] * 2 + [dp]
+    for nchunk in (1, 3, 8):
+        ld, q = C.c_double(), C.c_double()
+        g = np.zeros(1 + 2 * JR + 4 * JC)
+        rc = gradlib.hostcheck_grad(N, JR, JC, nchunk, jitter, P(ar), P(cr), P(ac), P(bc), P(cc), P(dc), P(t), P(diag),
+                                    P(y), C.byref(ld), C.byref(q), P(g))
+        assert rc == 0
+        v = -0.5 * (q.value + ld.value + np.pi * np.log(N))     # the reference's constant, solver.cpp:415
+        assert abs(v - v0) <= 1e-13 * abs(v0)
+        assert np.max(np.abs(g - g0)) <= 1e-10 * np.max(np.abs(g0)), (nchunk, np.max(np.abs(g - g0)) / np.max(np.abs(g0)))

@@ -1,25 +1,25 @@
 #!/bin/bash
 # Round-3 evidence run on the GPU box (through gpurun): rocprofv3 kernel traces + PMC passes of the headline bench
 # command, of BASELINE config 4 (width 32) and of the accuracy-family leg; summaries land in gpurun_out/prof_r03/.
-# Usage: bash tools/prof_run_r03.sh [headline] [wide] [accuracy] [sweeps]
+# Usage: bash tools/prof_run_r03.sh [headline] [wide] [accuracy] [sweeps] [grad]
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_r03
 mkdir -p "$OUT"
 WHAT="${*:-headline wide accuracy}"
-BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --no-accuracy-family --sharded 0 --steady-seconds 0 --settle-seconds 0"
+BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --no-accuracy-family --no-gradient --sharded 0 --steady-seconds 0 --settle-seconds 0"
 
 trace() {  # name, command...
   local name=$1; shift
   rm -rf "$OUT/$name"
-  rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o trace -- "$@" > "$OUT/$name.log" 2>&1
+  timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o trace -- "$@" > "$OUT/$name.log" 2>&1
   local db; db=$(find "$OUT/$name" -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$OUT/${name}_kernel_trace_stats.txt" > /dev/null
 }
 pmc() {  # name, counters, command...
   local name=$1 counters=$2; shift 2
   rm -rf "$OUT/$name"
-  rocprofv3 --kernel-trace --pmc $counters -d "$OUT/$name" -o pmc -- "$@" > "$OUT/$name.log" 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $counters -d "$OUT/$name" -o pmc -- "$@" > "$OUT/$name.log" 2>&1
   local db; db=$(find "$OUT/$name" -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_pmc.py "$db" > "$OUT/${name}_summary.txt"
 }
@@ -43,6 +43,12 @@ for w in $WHAT; do
       pmc accuracy_fetch "FETCH_SIZE" python tools/gpu_accuracy_profile.py
       pmc accuracy_write "WRITE_SIZE" python tools/gpu_accuracy_profile.py
       pmc accuracy_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" python tools/gpu_accuracy_profile.py
+      ;;
+    grad)
+      trace grad python tools/gpu_grad_profile.py
+      pmc grad_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" python tools/gpu_grad_profile.py
+      pmc grad_fetch "FETCH_SIZE" python tools/gpu_grad_profile.py
+      pmc grad_write "WRITE_SIZE" python tools/gpu_grad_profile.py
       ;;
     sweeps)
       trace sweeps_w64 python tools/gpu_sweep_profile.py 0 32
