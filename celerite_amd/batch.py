@@ -67,6 +67,8 @@ def _load():
     lib.clr_batch_set_prefix_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.clr_batch_grad.argtypes = [C.c_void_p, _dp, _dp, _ip]
     lib.clr_batch_get_grad_fallbacks.argtypes = [C.c_void_p, _ip]
+    lib.clr_batch_set_grad_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    lib.clr_batch_get_grad_info.argtypes = [C.c_void_p, _ip, _ip, _dp]
     lib.clr_batch_get_prefix_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
     lib.clr_batch_debug_get_starts.argtypes = [C.c_void_p, _dp]
     lib.clr_batch_debug_compose_check.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -349,6 +351,18 @@ class BatchedGP(object):
         value, grad, st = np.empty(self.B), np.empty((self.B, NG)), np.empty(self.B, dtype=np.int32)
         _check(_load().clr_batch_grad(self._h, _ptr(value), _ptr(grad), st.ctypes.data_as(_ip)))
         return value, grad, st
+
+    def set_grad_mode(self, mode="reverse", stored_state_distance=0, drift_tolerance=0.0):
+        """``"reverse"`` (default: one sweep for all partials) or ``"forward"`` (one tangent per partial);
+        ``clr_batch_set_grad_mode``."""
+        _check(_load().clr_batch_set_grad_mode(self._h, {"reverse": 0, "forward": 1}[mode], int(stored_state_distance),
+                                               float(drift_tolerance)))
+
+    def grad_info(self):
+        """``dict(reverse, forward_reruns, drift_max)`` of the last :meth:`grad_log_likelihood`."""
+        r, n, d = C.c_int(), C.c_int(), C.c_double()
+        _check(_load().clr_batch_get_grad_info(self._h, C.byref(r), C.byref(n), C.byref(d)))
+        return {"reverse": bool(r.value), "forward_reruns": n.value, "drift_max": d.value}
 
     def grad_fallbacks(self):
         """Problems of the last :meth:`grad_log_likelihood` that took the sequential gradient kernel."""

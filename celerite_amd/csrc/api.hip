@@ -358,6 +358,13 @@ struct clr_batch {
   clr::PrefixPlan plan;
   DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
   DevBuf g_riders, g_out, g_res;      // chunk-parallel gradient (clr_grad_kernels.h): riders, records, result (+ fallback)
+  DevBuf g_rec, g_ck;                 // reverse mode: w, D, x per sample; the state every grad K steps
+  int grad_mode = 0;                  // clr_batch_set_grad_mode: 0 auto (reverse), 1 forward (one tangent per partial)
+  int grad_K = 0;                     // > 0: distance of the stored states (steps), else from c_max dt_max
+  double grad_drift_tol = 1e-9;       // a reverse sweep whose reconstructed states drift further is redone forward
+  double grad_drift_max = 0.0;        // last gradient: largest drift among the problems it settled
+  int grad_forward_reruns = 0;        // ... and the problems redone by the forward-mode kernels
+  bool grad_reverse_used = false;
   std::vector<double> host_jitter;    // per problem, as set (the reference zeroes d/d jitter at jitter <= eps)
   bool grad_scan_only = false;        // the evaluation inside clr_batch_grad: by the scan, its start states are needed
   int grad_fallbacks = 0;             // problems of the last gradient that took the sequential kernel
@@ -1360,7 +1367,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res})
+                    &h->g_res, &h->g_rec, &h->g_ck})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -2374,28 +2381,77 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   st = batch_params(h, 0, P);
   h->in_fallback = false;
   if (st != CLR_OK) return st;
-  // gradient chunks: m chunks of the scan each.  Modelled time: rounds of tangent waves x steps per lane (2.7 us per
-  // step of a wave at width 8, ~ J^2) + the walk over the gradient chunks (5 us per chunk, ~ J^3)
-  int m = 1;
-  {
-    const double groups = 1.0 + h->J_real + 2.0 * h->J_comp, w2 = (double)(J * J) / 64.0;
+  const bool scan_grad = P.fast_trig != 0;  // (only the fast-sincos flavour of the gradient kernels is built)
+  // mode: reverse (one sweep for all partials, needs the per-sample record in HBM) unless asked otherwise or the
+  // record does not fit; forward (one tangent per partial) as the fallback and the cross-check
+  bool reverse = scan_grad && h->grad_mode != 1;
+  const double w2 = (double)(J * J) / 64.0, groups = 1.0 + h->J_real + 2.0 * h->J_comp;
+  auto choose_m = [&](bool rev) {
+    // gradient chunks: m chunks of the scan each.  Modelled time: rounds of waves x steps per lane (forward: 2.7 us
+    // per step of a tangent wave at width 8, ~ J^2, one wave per direction group; reverse: record + sweep, ~ 5 us)
+    // + the walk(s) over the gradient chunks (~ J^3 per chunk)
+    int m = 1;
     double best = INFINITY;
     for (int k = 1; k <= h->nchunk; ++k) {
       const int ng = (h->nchunk + k - 1) / k;
-      const double waves = (double)B * ((ng + 63) / 64) * groups;
-      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * (0.3 + 2.4 * w2) + ng * (0.5 + 4.5 * w2 * J / 8.0);
+      const double waves = (double)B * ((ng + 63) / 64) * (rev ? 1.0 : groups);
+      const double step = rev ? 0.6 + 4.4 * w2 : 0.3 + 2.4 * w2;
+      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * step + ng * (0.5 + 4.5 * w2 * J / 8.0);
       if (tm < best) { best = tm; m = k; }
     }
-  }
-  P.g_m = m;
-  P.g_nchunk = (h->nchunk + m - 1) / m;
-  const size_t pc = B * (size_t)P.g_nchunk;
-  if ((st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
-  if ((st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
+    return m;
+  };
+  auto set_chunks = [&](int m) {
+    P.g_m = m;
+    P.g_nchunk = (h->nchunk + m - 1) / m;
+    return B * (size_t)P.g_nchunk;
+  };
   if ((st = h->g_res.reserve(B * NG + B * (NG + 1) + B)) != CLR_OK) return st;  // result | fallback value, grad | fallback status
-  P.g_riders = h->g_riders.p; P.g_out = h->g_out.p; P.g_res = h->g_res.p;
-  const bool scan_grad = P.fast_trig != 0;  // (only the fast-sincos flavour of the tangent kernels is built)
-  if (scan_grad) {
+  P.g_res = h->g_res.p;
+  h->grad_reverse_used = false;
+  if (reverse) {
+    const size_t pc = set_chunks(choose_m(true));
+    const long Lg = (long)P.g_m * h->L;
+    // stored states every K steps: reconstruction errors grow like exp(2 c T) (clr_grad_core.h); K from a growth
+    // budget of 1e4 per stretch.  The drift the sweep measures at every stored state certifies the choice.
+    const double cdx = sel_max(h->cmax, h->floor_cmax) * sel_max(h->dxmax, h->floor_dxmax);
+    long K = cdx > 0.0 && cdx == cdx ? (long)std::floor(4.6 / cdx) : Lg;
+    if (h->grad_K > 0) K = h->grad_K;
+    K = std::max<long>(1, std::min<long>(K, Lg));
+    const long nck = (Lg + K - 1) / K;
+    P.g_K = (int)K;
+    P.g_rec_stride = Lg * (long)(J + 2) * P.g_nchunk;
+    P.g_ck_stride = nck * (long)(SZ + J) * P.g_nchunk;
+    const size_t small = pc * (RID + 2 * (SZ + J) + NG + 1) + B;
+    if (h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK || h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK ||
+        h->g_riders.reserve(small) != CLR_OK) {
+      h->g_rec.release(); h->g_ck.release();
+      (void)hipGetLastError();
+      reverse = false;  // (the record does not fit: one tangent per partial needs 50x less memory)
+    } else {
+      P.g_rec = h->g_rec.p; P.g_ck = h->g_ck.p;
+      P.g_riders = h->g_riders.p;
+      P.g_ends = P.g_riders + pc * RID;
+      P.g_adj = P.g_ends + pc * (SZ + J);
+      P.g_part = P.g_adj + pc * (SZ + J);
+      P.g_drift = P.g_part + pc * NG;
+      P.g_drift_max = P.g_drift + pc;
+      h->launch->grad_reverse(P, h->stream);
+      HIP_TRY(hipGetLastError());
+      h->grad_reverse_used = true;
+    }
+  }
+  auto forward_buffers = [&]() {
+    const size_t pc = set_chunks(choose_m(false));
+    int e;
+    if ((e = h->g_riders.reserve(pc * RID)) != CLR_OK) return e;
+    if ((e = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return e;
+    P.g_riders = h->g_riders.p; P.g_out = h->g_out.p;
+    P.g_rec = nullptr; P.g_ck = nullptr; P.g_ends = nullptr;
+    return (int)CLR_OK;
+  };
+  if (scan_grad && !reverse) {
+    if ((st = forward_buffers()) != CLR_OK) return st;
     h->launch->grad(P, h->stream);
     HIP_TRY(hipGetLastError());
   }
@@ -2404,7 +2460,38 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   if ((st = clr_batch_get_results(h, ll.data(), ld.data(), qd.data(), stt.data())) != CLR_OK) return st;
   HIP_TRY(hipMemcpyAsync(res.data(), h->g_res.p, B * NG * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(lvl.data(), P.need_exact, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> drift;
+  if (reverse) {
+    drift.resize(B);
+    HIP_TRY(hipMemcpyAsync(drift.data(), P.g_drift_max, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->grad_drift_max = 0.0;
+  h->grad_forward_reruns = 0;
+  if (reverse) {
+    // the reverse sweep's certificate: problems whose reconstructed states drifted from the stored ones (only
+    // meaningful when states are reconstructed over more than one step) are redone by the forward-mode kernels
+    std::vector<int> mask(B, 0);
+    int nre = 0;
+    for (size_t b = 0; b < B; ++b) {
+      if (stt[b] != CLR_OK || lvl[b] >= 2) continue;
+      if (!(drift[b] <= h->grad_drift_max)) h->grad_drift_max = drift[b];
+      if (P.g_K > 1 && !(drift[b] <= h->grad_drift_tol)) { mask[b] = 1; ++nre; }
+    }
+    h->grad_forward_reruns = nre;
+    if (nre) {
+      int* dmask = reinterpret_cast<int*>(h->g_res.p + B * NG + B * (NG + 1));
+      HIP_TRY(hipMemcpyAsync(dmask, mask.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      if ((st = forward_buffers()) != CLR_OK) return st;
+      P.g_mask = dmask;
+      // (the forward-mode result lands in the same g_res rows, only for the masked problems)
+      h->launch->grad(P, h->stream);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(res.data(), h->g_res.p, B * NG * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      P.g_mask = nullptr;
+    }
+  }
   // the sequential gradient for the problems whose scanned start states are not certified
   int nfb = 0;
   for (size_t b = 0; b < B; ++b) nfb += (stt[b] == CLR_OK && (lvl[b] >= 2 || !scan_grad));
@@ -2446,6 +2533,21 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
 int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count) {
   if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
   *count = h->grad_fallbacks;
+  return CLR_OK;
+}
+
+int clr_batch_set_grad_mode(clr_batch* h, int mode, int stored_state_distance, double drift_tolerance) {
+  if (mode < 0 || mode > 1 || stored_state_distance < 0) return fail(CLR_INVALID_ARGUMENT, "bad gradient mode");
+  h->grad_mode = mode;
+  h->grad_K = stored_state_distance;
+  if (drift_tolerance > 0.0) h->grad_drift_tol = drift_tolerance;
+  return CLR_OK;
+}
+
+int clr_batch_get_grad_info(const clr_batch* h, int* reverse_used, int* forward_reruns, double* drift_max) {
+  if (reverse_used) *reverse_used = h->grad_reverse_used ? 1 : 0;
+  if (forward_reruns) *forward_reruns = h->grad_forward_reruns;
+  if (drift_max) *drift_max = h->grad_drift_max;
   return CLR_OK;
 }
 

@@ -77,6 +77,12 @@ struct BatchParams {
   // chunk-parallel gradient (clr_grad_kernels.h): riders [B][nchunk][RID], records [B][nchunk][NG][OUT], result [B][NG]
   double *g_riders, *g_out, *g_res;
   int g_m, g_nchunk;      // a gradient chunk = g_m chunks of the scan; g_nchunk = ceil(nchunk / g_m)
+  // reverse mode: per-sample record w, D, x [B][step][J + 2][chunk], stored states every g_K steps
+  // [B][checkpoint][SZ + J][chunk], state after / adjoint at the end of every chunk, per-chunk partials and drift
+  double *g_rec, *g_ck, *g_ends, *g_adj, *g_part, *g_drift, *g_drift_max;
+  long g_rec_stride, g_ck_stride;  // doubles per problem
+  int g_K;
+  const int* g_mask;      // forward-mode kernels: only the problems with g_mask[b] != 0 (null: all)
   // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace
   const int* wK;     // [B] warm-up steps of problem b (wave-uniform per block); <= 0: the problem takes the scan
   // the series as the warm kernel reads them: [problem][row][chunk], row r of chunk c = sample c wL - wKpad + r,
@@ -845,6 +851,7 @@ struct BatchLaunchers {
   void (*compose_check)(const BatchParams&, int g, double* coop, double* ref, hipStream_t);
   void (*warm)(const BatchParams&, hipStream_t);  // warm_kernel + warm_check_kernel
   void (*grad)(const BatchParams&, hipStream_t);  // riders + tangents + walk over the chunks (needs P.fast_trig)
+  void (*grad_reverse)(const BatchParams&, hipStream_t);  // riders + record, adjoint walk, reverse sweep, reduction
   int elem_doubles, start_doubles;
 };
 
@@ -917,8 +924,17 @@ struct BatchImpl {
     const long n = (long)P.B * Sh::NG;
     hipLaunchKernelGGL((grad_combine_kernel<JR + 2 * JC>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, Sh::NG);
   }
+  static void grad_reverse(const BatchParams& P, hipStream_t s) {
+    using Sh = GradShape<JR, JC>;
+    const dim3 grid((P.g_nchunk + 63) / 64, P.B);
+    hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+    hipLaunchKernelGGL((grad_backward_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    const long n = (long)P.B * Sh::NG;
+    hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, Sh::NG);
+  }
   static BatchLaunchers table() {
-    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad,
+    return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,
                           Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };

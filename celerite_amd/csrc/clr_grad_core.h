@@ -295,9 +295,15 @@ CLR_HD void grad_chunk(const double* a_real, const double* c_real, const double*
 // The riders of one chunk along the base trajectory from `start`: out = AA[J][J] row-major | eta[J] | JJ[SZ].
 // Only samples of the series (n < N) enter eta and JJ; AA of the last chunk is never used.
 // ---------------------------------------------------------------------------
+// rec (may be null): per sample of the chunk w[J], D, x -- element k of local step i at rec[(i (J + 2) + k) rstride] --
+// and end_out = the base state after the chunk's last sample (S[SZ] f[J]): what the reverse sweep
+// (grad_backward_chunk) starts from.  The move after the LAST sample of the series is taken with dt = 0.
+// ck (may be null): the base state BEFORE local step i for i = K, 2K, ... -- checkpoint i / K - 1, element k at
+// ck[((i / K - 1) (SZ + J) + k) rstride] -- which bounds how far the reverse sweep reconstructs states.
 template <int JR, int JC, bool FAST, class Src>
 CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* start,
-                              double* out) {
+                              double* out, double* rec = nullptr, long rstride = 0, double* end_out = nullptr,
+                              double* ck = nullptr, int K = 0) {
   using Sh = GradShape<JR, JC>;
   constexpr int J = Sh::J, SZ = Sh::SZ;
   double S[SZ], f[J], AA[J * J], eta[J], JJ[SZ];
@@ -323,37 +329,50 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
       diag_n = src.diag(i + 1);
       y_n = src.y(i + 1);
     }
-    double u[J], v[J];
-    features_uv<JR, JC, FAST>(p, tn, u, v);
-    double q[J];
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) {
-      double acc = 0.0;
+    if (valid) {  // (the state freezes behind the end of the series: end_out is the state after the last sample)
+      if (ck && i > 0 && i % K == 0) {
+        double* o = ck + (long)(i / K - 1) * (SZ + J) * rstride;
+        CLR_UNROLL
+        for (int k = 0; k < SZ; ++k) o[(long)k * rstride] = S[k];
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) o[(long)(SZ + k) * rstride] = f[k];
+      }
+      double u[J], v[J];
+      features_uv<JR, JC, FAST>(p, tn, u, v);
+      double q[J];
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) acc += S[sym(k, j)] * u[k];
-      q[j] = acc;
-    }
-    double s = 0.0, uf = 0.0;
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
-    const double D = p.diagonal(diag_cur) - s;
-    const double invD = 1.0 / D;
-    const double x = y_cur - uf;
-    double z[J], w[J];
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) {
-      z[j] = v[j] - q[j];
-      w[j] = z[j] * invD;
-    }
-    double r[J];
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) {
-      double acc = 0.0;
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) acc += S[sym(k, j)] * u[k];
+        q[j] = acc;
+      }
+      double s = 0.0, uf = 0.0;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) acc += AA[k * J + j] * u[k];
-      r[j] = acc;
-    }
-    if (valid) {
+      for (int j = 0; j < J; ++j) { s += u[j] * q[j]; uf += u[j] * f[j]; }
+      const double D = p.diagonal(diag_cur) - s;
+      const double invD = 1.0 / D;
+      const double x = y_cur - uf;
+      double z[J], w[J];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        z[j] = v[j] - q[j];
+        w[j] = z[j] * invD;
+      }
+      if (rec) {
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) rec[((long)i * (J + 2) + j) * rstride] = w[j];
+        rec[((long)i * (J + 2) + J) * rstride] = D;
+        rec[((long)i * (J + 2) + J + 1) * rstride] = x;
+      }
+      double r[J];
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) {
+        double acc = 0.0;
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) acc += AA[k * J + j] * u[k];
+        r[j] = acc;
+      }
       const double xs = x * invD;
       CLR_UNROLL
       for (int j = 0; j < J; ++j) {
@@ -362,19 +381,25 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
         CLR_UNROLL
         for (int k = 0; k <= j; ++k) JJ[tri(k, j)] = fma(r[k], rj, JJ[tri(k, j)]);
       }
-    }
-    double phid[nz(JR + JC)];
-    features_phi_distinct<JR, JC>(p, t_cur_next - tn, phid);
-    CLR_UNROLL
-    for (int k = 0; k < J; ++k) {
-      const double ph = phid[phi_index<JR>(k)];
+      double phid[nz(JR + JC)];
+      features_phi_distinct<JR, JC>(p, n0 + i + 1 < N ? t_cur_next - tn : 0.0, phid);
       CLR_UNROLL
-      for (int j = 0; j < J; ++j) AA[k * J + j] = ph * fma(-w[k], r[j], AA[k * J + j]);
-      f[k] = ph * (f[k] + w[k] * x);
+      for (int k = 0; k < J; ++k) {
+        const double ph = phid[phi_index<JR>(k)];
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) AA[k * J + j] = ph * fma(-w[k], r[j], AA[k * J + j]);
+        f[k] = ph * (f[k] + w[k] * x);
+      }
+      decay_rank1_update<JR, JC>(phid, z, w, S);
     }
-    decay_rank1_update<JR, JC>(phid, z, w, S);
     tn = t_cur_next;
     src.step_end(i);
+  }
+  if (end_out) {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) end_out[i] = S[i];
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) end_out[SZ + i] = f[i];
   }
   CLR_UNROLL
   for (int i = 0; i < J * J; ++i) out[i] = AA[i];
@@ -453,6 +478,244 @@ CLR_HD void grad_combine(int nchunk, const double* riders, const double* gout, l
   }
   *dld_out = dld;
   *dquad_out = dqd;
+}
+
+// ---------------------------------------------------------------------------
+// REVERSE mode.  With L = sum_n (log D_n + x_n^2 / D_n) and the chunk maps above, the adjoint of the base state at a
+// chunk's first sample follows from the adjoint at its end (= the first sample of the next chunk) through the same
+// three riders:
+//     Sbar_0 = AA^T Sbar_e AA - sym((AA^T fbar_e) eta^T) - JJ + eta eta^T        fbar_0 = AA^T fbar_e - 2 eta
+// (the transpose of the tangent maps; sym(a b^T) = (a b^T + b a^T) / 2; adjoints of symmetric matrices are kept
+// symmetric, dL = sum over ALL i, k of Sbar_ik dS_ik).  grad_adjoint_walk: one problem, backwards over the chunks,
+// adj[c] = the adjoint at the END of chunk c (Sbar[SZ] fbar[J]); the last chunk ends with zeros.
+// ---------------------------------------------------------------------------
+template <int J>
+CLR_HD void grad_adjoint_walk(int nchunk, const double* riders, double* adj) {
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ADJ = SZ + J;
+  double Sb[SZ], fb[J];
+  CLR_UNROLL_J
+  for (int i = 0; i < SZ; ++i) Sb[i] = 0.0;
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) fb[i] = 0.0;
+  for (int c = nchunk - 1; c >= 0; --c) {
+    double* o = adj + (long)c * ADJ;
+    CLR_UNROLL_J
+    for (int i = 0; i < SZ; ++i) o[i] = Sb[i];
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) o[SZ + i] = fb[i];
+    if (c == 0) break;
+    const double* R = riders + (long)c * RID;
+    const double *AA = R, *eta = R + J * J, *JJ = R + J * J + J;
+    double T[J * J], g[J];
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {    // T = Sbar AA ; g = AA^T fbar
+      double a = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) a = fma(AA[k * J + i], fb[k], a);
+      g[i] = a;
+      CLR_UNROLL_J
+      for (int j = 0; j < J; ++j) {
+        double b = 0.0;
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) b = fma(Sb[sym(i, k)], AA[k * J + j], b);
+        T[i * J + j] = b;
+      }
+    }
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      CLR_UNROLL_J
+      for (int i = 0; i <= j; ++i) {
+        double b = eta[i] * eta[j] - JJ[tri(i, j)] - 0.5 * (g[i] * eta[j] + eta[i] * g[j]);
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) b = fma(AA[k * J + i], T[k * J + j], b);
+        Sb[tri(i, j)] = b;
+      }
+    }
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) fb[i] = g[i] - 2.0 * eta[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One chunk backwards: from the base state after its last sample (end_state, as grad_riders_chunk left it) and the
+// adjoint there (end_adj), over the stored w, D, x of its samples.  Per step the state BEFORE the step is
+// reconstructed from the state after it,
+//     G = S' / (phi phi^T)     S = G - D w w^T        h = f' / phi     f = h - w x
+// and the adjoints follow cholesky.h:154-178 / :384-398 backwards (q = S u, D = a - u.q, z = v - q, w = z / D,
+// x = y - u.f, S' = Phi (S + z w^T) Phi, f' = Phi (f + w x)):
+//     Gbar = phi phi^T o Sbar'   hbar = phi o fbar'   m = Gbar w
+//     wbar = hbar x + D m        xbar = hbar.w + 2 x / D          zbar = m + wbar / D
+//     Dbar = 1 / D - x^2 / D^2 - wbar.w / D            qbar = -zbar - Dbar u          vbar = zbar
+//     ubar = -xbar f - Dbar q + S qbar   (q = v - D w)           fbar = hbar - xbar u
+//     Sbar = Gbar + sym(qbar u^T)
+// every coefficient's partial is accumulated on the way: K(0) (jitter, a_real, a_comp) through Dbar; a_real through
+// ubar; a_comp, b_comp, d_comp through ubar, vbar and the phase; c through d phi / dc = -dt phi:
+//     -dt (2 sum_k Sbar'_jk S'_jk + fbar'_j f'_j) summed over the term's rows j.
+// out[NG]: this chunk's share of dL / d(coefficient) (the caller sums the chunks and applies -1/2); adj0_out
+// (may be null): the adjoint at the chunk's first sample, equal to what grad_adjoint_walk found for the end of the
+// previous chunk -- the built-in consistency check of the tests.
+// The reconstruction inverts a contraction: its rounding errors grow like exp(2 c T) over a time span T (measured on
+// the host instantiation: exact to 1e-13 over c T = 8, lost over c T = 40).  So the forward pass stores the state
+// every K steps (ck), the sweep continues from the stored state there -- and from the scan's start state (`start`,
+// null = the zero state) at the chunk's first sample -- and reports how far its own reconstruction had drifted
+// (mismatch_out: the certificate -- a problem whose drift exceeds the tolerance is handed to the forward-mode kernels
+// above); the host picks K from 2 c_max K dt_max <= log(1e4): K = 1 (every state stored, nothing reconstructed is
+// ever used) on sparse series (api.hip).
+// ---------------------------------------------------------------------------
+template <int JR, int JC, bool FAST, class Src>
+CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* end_state,
+                                const double* end_adj, const double* rec, long rstride, double* out,
+                                double* adj0_out = nullptr, const double* ck = nullptr, int K = 0,
+                                double* mismatch_out = nullptr, const double* start = nullptr) {
+  using Sh = GradShape<JR, JC>;
+  constexpr int J = Sh::J, SZ = Sh::SZ, M = JR + JC, NG = Sh::NG;
+  double S[SZ], f[J], Sb[SZ], fb[J];
+  CLR_UNROLL
+  for (int i = 0; i < SZ; ++i) { S[i] = end_state[i]; Sb[i] = end_adj[i]; }
+  CLR_UNROLL
+  for (int i = 0; i < J; ++i) { f[i] = end_state[SZ + i]; fb[i] = end_adj[SZ + i]; }
+  double g_k0 = 0.0;                       // sum of Dbar: jitter, and every a_real / a_comp
+  double g_ar[nz(JR)], g_cr[nz(JR)], g_ac[nz(JC)], g_bc[nz(JC)], g_cc[nz(JC)], g_dc[nz(JC)];
+  CLR_UNROLL
+  for (int j = 0; j < JR; ++j) { g_ar[j] = 0.0; g_cr[j] = 0.0; }
+  CLR_UNROLL
+  for (int j = 0; j < JC; ++j) { g_ac[j] = 0.0; g_bc[j] = 0.0; g_cc[j] = 0.0; g_dc[j] = 0.0; }
+  const int last = (N - n0 < L ? N - n0 : L) - 1;  // local index of the chunk's last sample
+  double drift = 0.0;
+  for (int i = last; i >= 0; --i) {
+    const int n = n0 + i;
+    const double tn = src.t(i);
+    const double dt = n + 1 < N ? src.t(i + 1) - tn : 0.0;
+    double w[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) w[j] = rec[((long)i * (J + 2) + j) * rstride];
+    const double D = rec[((long)i * (J + 2) + J) * rstride];
+    const double x = rec[((long)i * (J + 2) + J + 1) * rstride];
+    const double invD = 1.0 / D;
+    double u[J], v[J], phid[nz(M)], iphid[nz(M)];
+    features_uv<JR, JC, FAST>(p, tn, u, v);
+    features_phi_distinct<JR, JC>(p, dt, phid);
+    CLR_UNROLL
+    for (int a = 0; a < M; ++a) iphid[a] = 1.0 / phid[a];
+    // d phi / dc from the state AFTER the step, then the state before it
+    double crow[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = fb[j] * f[j];
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc = fma(2.0 * Sb[sym(j, k)], S[sym(j, k)], acc);
+      crow[j] = acc;
+    }
+    CLR_UNROLL
+    for (int j = 0; j < JR; ++j) g_cr[j] = fma(-dt, crow[j], g_cr[j]);
+    CLR_UNROLL
+    for (int j = 0; j < JC; ++j) g_cc[j] = fma(-dt, crow[JR + 2 * j] + crow[JR + 2 * j + 1], g_cc[j]);
+    double Gb[SZ], hb[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      const double pj = phid[phi_index<JR>(j)], ij = iphid[phi_index<JR>(j)];
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k) {
+        const double pk = phid[phi_index<JR>(k)], ik = iphid[phi_index<JR>(k)];
+        Gb[tri(k, j)] = (pj * pk) * Sb[tri(k, j)];
+        S[tri(k, j)] = fma(-D * w[k], w[j], (ij * ik) * S[tri(k, j)]);
+      }
+      hb[j] = pj * fb[j];
+      f[j] = fma(-w[j], x, ij * f[j]);
+    }
+    if ((ck && i > 0 && i % K == 0) || i == 0) {
+      // a state known independently -- stored by the forward pass, or (i = 0) the chunk's start state from the scan:
+      // measure how far the reconstruction has drifted since the last one, then continue from the known state
+      const double* o = i > 0 ? ck + (long)(i / K - 1) * (SZ + J) * rstride : start;
+      const long os = i > 0 ? rstride : 1;
+      double big = 0.0, dev = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < SZ; ++k) {
+        const double e = o ? o[(long)k * os] : 0.0;
+        big = fmax(big, fabs(e));
+        dev = fmax(dev, fabs(e - S[k]));
+        S[k] = e;
+      }
+      double bigf = 0.0, devf = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) {
+        const double e = o ? o[(long)(SZ + k) * os] : 0.0;
+        bigf = fmax(bigf, fabs(e));
+        devf = fmax(devf, fabs(e - f[k]));
+        f[k] = e;
+      }
+      if (o) {  // (the zero state of the first chunk: an absolute deviation has no scale to compare with)
+        double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
+        if (bigf > 0.0) r = fmax(r, devf / bigf);
+        if (!(r <= drift)) drift = r;  // (NaN counts)
+      }
+    }
+    // adjoints of the step
+    double m[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc = fma(Gb[sym(j, k)], w[k], acc);
+      m[j] = acc;
+    }
+    double wb[J], zb[J], xbar = 2.0 * x * invD, wbw = 0.0;
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      wb[j] = fma(hb[j], x, D * m[j]);
+      xbar = fma(hb[j], w[j], xbar);
+      zb[j] = fma(wb[j], invD, m[j]);
+      wbw = fma(wb[j], w[j], wbw);
+    }
+    const double Dbar = invD - (x * invD) * (x * invD) - wbw * invD;
+    g_k0 += Dbar;
+    double qb[J], ub[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) qb[j] = -zb[j] - Dbar * u[j];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      const double q = v[j] - D * w[j];
+      double acc = -xbar * f[j] - Dbar * q;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) acc = fma(S[sym(j, k)], qb[k], acc);
+      ub[j] = acc;
+    }
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      fb[j] = fma(-xbar, u[j], hb[j]);
+      CLR_UNROLL
+      for (int k = 0; k <= j; ++k) Sb[tri(k, j)] = Gb[tri(k, j)] + 0.5 * fma(qb[k], u[j], u[k] * qb[j]);
+    }
+    // coefficients: U~ = a (real), (a cd + b sd, a sd - b cd) and V~ = (cd, sd) (complex), cholesky.h:129-147
+    CLR_UNROLL
+    for (int j = 0; j < JR; ++j) g_ar[j] += ub[j];
+    CLR_UNROLL
+    for (int j = 0; j < JC; ++j) {
+      const int k = JR + 2 * j;
+      const double cd = v[k], sd = v[k + 1];
+      g_ac[j] += fma(ub[k], cd, ub[k + 1] * sd);
+      g_bc[j] += fma(ub[k], sd, -ub[k + 1] * cd);
+      g_dc[j] = fma(tn, (ub[k + 1] * u[k] - ub[k] * u[k + 1]) + (zb[k + 1] * cd - zb[k] * sd), g_dc[j]);
+    }
+  }
+  out[0] = g_k0;
+  CLR_UNROLL
+  for (int j = 0; j < JR; ++j) { out[1 + j] = g_ar[j] + g_k0; out[1 + JR + j] = g_cr[j]; }
+  CLR_UNROLL
+  for (int j = 0; j < JC; ++j) {
+    out[1 + 2 * JR + j] = g_ac[j] + g_k0;
+    out[1 + 2 * JR + JC + j] = g_bc[j];
+    out[1 + 2 * JR + 2 * JC + j] = g_cc[j];
+    out[1 + 2 * JR + 3 * JC + j] = g_dc[j];
+  }
+  (void)NG;
+  if (mismatch_out) *mismatch_out = drift;
+  if (adj0_out) {
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) adj0_out[i] = Sb[i];
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) adj0_out[SZ + i] = fb[i];
+  }
 }
 
 }  // namespace clr

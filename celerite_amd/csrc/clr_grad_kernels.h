@@ -6,8 +6,15 @@
 //   grad_tangent_kernel   lane = chunk, blockIdx.z = direction group: the base recurrence + the group's two
 //                         tangents from zero tangent states                                      [B][nchunk][NG][OUT]
 //   grad_combine_kernel   thread = (problem, direction): walks the chunks                                 [B][NG]
+// Reverse mode (the default, clr_batch_grad): grad_riders_kernel also stores w, D, x per sample, the state every g_K
+// steps and the state after the chunk; then
+//   grad_adjoint_kernel   thread = problem: the adjoint at every chunk end, backwards over the riders      [B][nchunk][ADJ]
+//   grad_backward_kernel  lane = chunk: the reverse sweep, ALL partials at once                             [B][nchunk][NG]
+//   grad_reduce_kernel    thread = (problem, direction): sums the chunks; per problem the largest drift of the
+//                         reconstructed states (grad_backward_chunk's certificate)
 // Problems the scan handed to the sequential recurrence (need_exact >= 2: their scanned start states are not
-// certified) are skipped; the host runs the sequential gradient kernel (grad_kernels.hip) for them.
+// certified) are skipped; the host runs the sequential gradient kernel (grad_kernels.hip) for them.  g_mask (may be
+// null) restricts the forward-mode kernels to the problems whose reverse sweep drifted.
 // The series is read through DirectSeries on the row-major arrays: at ~900 fp64 instructions per step and wave the
 // 24 bytes per lane and step are not what the kernel waits for.
 // A gradient chunk is P.g_m consecutive chunks of the scan (every scan chunk's start state is a valid start): the
@@ -32,6 +39,7 @@ __global__ void __launch_bounds__(64) grad_riders_kernel(const BatchParams P) {
   using Sh = GradShape<JR, JC>;
   const int b = blockIdx.y;
   if (P.need_exact[b] >= 2) return;  // (wave-uniform)
+  if (P.g_mask && !P.g_mask[b]) return;
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= P.g_nchunk) return;
   Problem<JR, JC> p;
@@ -40,7 +48,9 @@ __global__ void __launch_bounds__(64) grad_riders_kernel(const BatchParams P) {
   const long slot = (long)b * P.g_nchunk + c;
   grad_riders_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L,
                                   c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr,
-                                  P.g_riders + slot * Sh::RID);
+                                  P.g_riders + slot * Sh::RID, P.g_rec ? P.g_rec + b * P.g_rec_stride + c : nullptr,
+                                  P.g_nchunk, P.g_rec ? P.g_ends + slot * Wd::START : nullptr,
+                                  P.g_rec ? P.g_ck + b * P.g_ck_stride + c : nullptr, P.g_K);
 }
 
 template <int JR, int JC, bool FAST>
@@ -49,6 +59,7 @@ __global__ void __launch_bounds__(64) grad_tangent_kernel(const BatchParams P) {
   using Sh = GradShape<JR, JC>;
   const int b = blockIdx.y;
   if (P.need_exact[b] >= 2) return;
+  if (P.g_mask && !P.g_mask[b]) return;
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= P.g_nchunk) return;
   const int group = blockIdx.z;
@@ -71,10 +82,61 @@ __global__ void __launch_bounds__(64) grad_combine_kernel(const BatchParams P, i
   if (idx >= (long)P.B * NG) return;
   const int b = (int)(idx / NG), q = (int)(idx % NG);
   if (P.need_exact[b] >= 2) return;
+  if (P.g_mask && !P.g_mask[b]) return;
   double dld, dq;
   grad_combine<J>(P.g_nchunk, P.g_riders + (long)b * P.g_nchunk * RID,
                   P.g_out + ((long)b * P.g_nchunk * NG + q) * OUT, (long)NG * OUT, &dld, &dq);
   P.g_res[idx] = -0.5 * (dq + dld);
+}
+
+template <int J>
+__global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ADJ = SZ + J;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B || P.need_exact[b] >= 2) return;
+  grad_adjoint_walk<J>(P.g_nchunk, P.g_riders + (long)b * P.g_nchunk * RID, P.g_adj + (long)b * P.g_nchunk * ADJ);
+}
+
+template <int JR, int JC, bool FAST>
+__global__ void __launch_bounds__(64) grad_backward_kernel(const BatchParams P) {
+  using Wd = Widths<JR, JC>;
+  using Sh = GradShape<JR, JC>;
+  const int b = blockIdx.y;
+  if (P.need_exact[b] >= 2) return;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= P.g_nchunk) return;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  DirectSeries src = grad_series(P, b, c);
+  const long slot = (long)b * P.g_nchunk + c;
+  double drift = 0.0;
+  grad_backward_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L, P.g_ends + slot * Wd::START,
+                                    P.g_adj + slot * Wd::START, P.g_rec + b * P.g_rec_stride + c, P.g_nchunk,
+                                    P.g_part + slot * Sh::NG, nullptr, P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
+                                    c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr);
+  P.g_drift[slot] = P.g_K > 1 ? drift : 0.0;  // (K = 1: every state is a stored one, no reconstructed state is used)
+}
+
+// thread = (problem, direction): -1/2 of the sum over the chunks; direction 0 also reduces the drift
+// (a template only so that every width's translation unit owns its instantiation)
+template <int J>
+__global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, int NG) {
+  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+  if (idx >= (long)P.B * NG) return;
+  const int b = (int)(idx / NG), q = (int)(idx % NG);
+  if (P.need_exact[b] >= 2) return;
+  const double* part = P.g_part + (long)b * P.g_nchunk * NG + q;
+  double acc = 0.0;
+  for (int c = 0; c < P.g_nchunk; ++c) acc += part[(long)c * NG];
+  P.g_res[idx] = -0.5 * acc;
+  if (q == 0) {
+    double worst = 0.0;
+    for (int c = 0; c < P.g_nchunk; ++c) {
+      const double d = P.g_drift[(long)b * P.g_nchunk + c];
+      if (!(d <= worst)) worst = d;
+    }
+    P.g_drift_max[b] = worst;
+  }
 }
 
 }  // namespace clr

@@ -427,6 +427,18 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
  * widths 1..8 and N >= 512. */
 int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status);
 int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
+/* How clr_batch_grad differentiates.  mode 0 (default): REVERSE mode -- the riders pass also records w, D, x per
+ * sample and the state every K steps, the adjoint at every chunk end follows from the riders in a walk backwards over
+ * the chunks, and ONE reverse sweep per chunk yields all partials (cost ~4x an evaluation instead of ~20x; needs
+ * 8 (J + 2 + (J (J + 3) / 2) / K) bytes per sample of HBM, falls back to mode 1 when that does not fit).  The sweep
+ * reconstructs the states between the stored ones; the drift it measures at every stored state certifies them, and a
+ * problem that drifts beyond `drift_tolerance` (default 1e-9; <= 0 keeps the current one) is redone in mode 1.
+ * mode 1: FORWARD mode, one tangent per partial (the description above).  stored_state_distance: K in steps, 0 = from
+ * the series and coefficients (2 c_max K dt_max <= log 1e4). */
+int clr_batch_set_grad_mode(clr_batch* h, int mode, int stored_state_distance, double drift_tolerance);
+/* Of the last clr_batch_grad: whether the reverse sweep ran, how many problems were redone in forward mode, the
+ * largest drift among the problems the reverse sweep settled. */
+int clr_batch_get_grad_info(const clr_batch* h, int* reverse_used, int* forward_reruns, double* drift_max);
 
 /* ---- the batch axis over several GPUs (BASELINE config 4) ---------
  * Problems are independent -- every member of the reference solver is per object

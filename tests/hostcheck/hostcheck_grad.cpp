@@ -4,6 +4,8 @@
 // GPU grid replaced by plain loops (true start states from a sequential replay of the chunks, then per chunk the
 // riders and every direction group, then the walk over the chunks per direction), so the algebra can be checked
 // against oracle/grad.py in the CPU-only test run.  Not linked into libcelerite_hip.so.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -60,6 +62,84 @@ static int run_grad(int N, int nchunk, double jitter, const double* a_real, cons
   *logdet = ld;
   *quad = qd;
   return bad;
+}
+
+// The reverse-mode path (grad_riders_chunk with its per-sample record, grad_adjoint_walk, grad_backward_chunk).
+// *mismatch: the largest relative difference between the adjoint a chunk's reverse sweep arrives at for its first
+// sample and the one the walk over the riders predicted for the end of the previous chunk.
+template <int JR, int JC>
+static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_real, const double* c_real,
+                            const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
+                            const double* t, const double* diag, const double* y, double* logdet, double* quad,
+                            double* grad, double* mismatch, int K, double* drift) {
+  using Wd = Widths<JR, JC>;
+  using Sh = GradShape<JR, JC>;
+  constexpr int J = Wd::J, ADJ = Wd::START;
+  const int L = (N + nchunk - 1) / nchunk;
+  nchunk = (N + L - 1) / L;
+  Problem<JR, JC> p;
+  p.load(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter);
+  std::vector<double> starts((size_t)nchunk * Wd::START, 0.0), ends((size_t)nchunk * Wd::START), riders((size_t)nchunk * Sh::RID),
+      rec((size_t)N * (J + 2)), adj((size_t)nchunk * ADJ);
+  const int nck = K > 0 ? (L + K - 1) / K : 0;
+  std::vector<double> ck((size_t)nchunk * std::max(nck, 1) * Wd::START, 0.0);
+  double worst_drift = 0.0;
+  double ld = 0.0, qd = 0.0;
+  int bad = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    const long first = (long)c * L;
+    DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+    double l, q, en[Wd::START];
+    int fl;
+    replay_chunk<JR, JC, 0, true>(p, src, L, N, (int)first, c ? &starts[(size_t)c * Wd::START] : nullptr, &l, &q, &fl,
+                                  nullptr, nullptr, nullptr, nullptr, 0, en);
+    ld += l; qd += q; bad |= fl;
+    if (c + 1 < nchunk) memcpy(&starts[(size_t)(c + 1) * Wd::START], en, sizeof(en));
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    const long first = (long)c * L;
+    DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+    grad_riders_chunk<JR, JC, true>(p, src, L, N, (int)first, c ? &starts[(size_t)c * Wd::START] : nullptr,
+                                    &riders[(size_t)c * Sh::RID], &rec[(size_t)first * (J + 2)], 1, &ends[(size_t)c * Wd::START],
+                                    K > 0 ? &ck[(size_t)c * nck * Wd::START] : nullptr, K);
+  }
+  grad_adjoint_walk<J>(nchunk, riders.data(), adj.data());
+  std::vector<double> total(Sh::NG, 0.0);
+  double worst = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const long first = (long)c * L;
+    DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+    double out[Sh::NG], adj0[ADJ], dr = 0.0;
+    grad_backward_chunk<JR, JC, true>(p, src, L, N, (int)first, &ends[(size_t)c * Wd::START], &adj[(size_t)c * ADJ],
+                                      &rec[(size_t)first * (J + 2)], 1, out, adj0,
+                                      K > 0 ? &ck[(size_t)c * nck * Wd::START] : nullptr, K, &dr,
+                                      c ? &starts[(size_t)c * Wd::START] : nullptr);
+    if (!(dr <= worst_drift)) worst_drift = dr;
+    for (int q = 0; q < Sh::NG; ++q) total[q] += out[q];
+    if (c > 0) {
+      const double* want = &adj[(size_t)(c - 1) * ADJ];
+      double mx = 0.0, df = 0.0;
+      for (int i = 0; i < ADJ; ++i) { mx = std::fmax(mx, std::fabs(want[i])); df = std::fmax(df, std::fabs(want[i] - adj0[i])); }
+      if (mx > 0.0) worst = std::fmax(worst, df / mx);
+    }
+  }
+  for (int q = 0; q < Sh::NG; ++q) grad[q] = -0.5 * total[q];
+  *logdet = ld;
+  *quad = qd;
+  *mismatch = worst;
+  *drift = worst_drift;
+  return bad;
+}
+
+extern "C" int hostcheck_grad_reverse(int N, int JR, int JC, int nchunk, double jitter, const double* a_real,
+                                      const double* c_real, const double* a_comp, const double* b_comp,
+                                      const double* c_comp, const double* d_comp, const double* t, const double* diag,
+                                      const double* y, double* logdet, double* quad, double* grad, double* mismatch,
+                                      int K, double* drift) {
+#define GCASE(R, C) if (JR == R && JC == C) return run_grad_reverse<R, C>(N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, logdet, quad, grad, mismatch, K, drift);
+  GCASE(1, 0) GCASE(2, 0) GCASE(0, 1) GCASE(1, 1) GCASE(2, 1) GCASE(0, 2) GCASE(2, 3) GCASE(3, 2) GCASE(8, 0) GCASE(0, 4)
+#undef GCASE
+  return -1;
 }
 
 extern "C" int hostcheck_grad(int N, int JR, int JC, int nchunk, double jitter, const double* a_real,

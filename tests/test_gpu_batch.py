@@ -815,11 +815,14 @@ def test_batched_grad_log_likelihood(JR, JC, N, shared):
 
 @pytest.mark.parametrize("JR,JC", [(2, 3), (1, 1), (0, 2), (3, 0), (1, 0), (0, 4), (4, 2)])
 @pytest.mark.parametrize("family", ["bench", "accuracy"])
-def test_plan_gradient_parallel_in_n(JR, JC, family):
-    """clr_batch_grad (csrc/clr_grad_core.h): the gradient parallel in n -- tangents per (chunk, direction) from the
-    scanned start states + the walk over the chunks -- against the sequential tangent kernel (one wave per partial,
-    csrc/grad_kernels.hip; itself pinned against oracle/grad.py) at several chunk counts, and against the oracle
-    directly on one problem.  An indefinite problem in the batch keeps the quiet semantics (-inf, zero gradient)."""
+@pytest.mark.parametrize("mode", ["reverse", "forward"])
+def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
+    """clr_batch_grad (csrc/clr_grad_core.h): the gradient parallel in n -- reverse mode (riders + per-sample record,
+    adjoint walk over the chunks, one reverse sweep per chunk for all partials) and forward mode (tangents per
+    (chunk, direction) from the scanned start states + the walk over the chunks) -- against the sequential tangent
+    kernel (one wave per partial, csrc/grad_kernels.hip; itself pinned against oracle/grad.py) at several chunk
+    counts, and against the oracle directly on one problem.  An indefinite problem in the batch keeps the quiet
+    semantics (-inf, zero gradient)."""
     from oracle import grad as ograd
     B, N = 5, 2500
     case = synthetic(B, N, JR, JC, family, seed=77 + JR + 10 * JC)
@@ -834,9 +837,12 @@ def test_plan_gradient_parallel_in_n(JR, JC, family):
     try:
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        plan.set_grad_mode(mode)
         for nchunk in (0, 1, 5, 40):
             plan.set_chunks(nchunk)
             v, g, st = plan.grad_log_likelihood()
+            info = plan.grad_info()
+            assert info["reverse"] == (mode == "reverse") and info["forward_reruns"] == 0, info
             assert np.array_equal(st, st_seq) and st[3] == 2 and np.isneginf(v[3]) and not g[3].any()
             ok = st == 0
             assert np.max(np.abs(v[ok] - v_seq[ok]) / np.abs(v_seq[ok])) <= 1e-11, nchunk
@@ -855,6 +861,86 @@ def test_plan_gradient_parallel_in_n(JR, JC, family):
     v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, case["t"][b], case["y"][b], case["diag"][b])
     assert abs(v1[b] - v0) <= 1e-10 * abs(v0)
     assert np.allclose(g1[b], g0, rtol=1e-8, atol=1e-8 * np.max(np.abs(g0)))
+
+
+def test_reverse_gradient_certifies_its_reconstructed_states():
+    """The reverse sweep rebuilds the states between the stored ones by inverting the recurrence, which amplifies
+    rounding errors like exp(2 c T) (csrc/clr_grad_core.h).  With the stored states at the distance the host derives
+    from the series the drift it measures is at rounding level and the result equals forward mode; with the distance
+    forced far too large the drift is caught and those problems are redone by the forward-mode kernels -- the result
+    is right either way."""
+    B, N, JR, JC = 6, 6000, 2, 3
+    case = synthetic(B, N, JR, JC, "accuracy", seed=5)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        plan.set_chunks(8)
+        plan.set_grad_mode("forward")
+        v0, g0, st0 = plan.grad_log_likelihood()
+        assert (st0 == 0).all()
+        scale = np.max(np.abs(g0), axis=1, keepdims=True)
+        plan.set_grad_mode("reverse")                       # stored-state distance chosen by the host
+        v1, g1, st1 = plan.grad_log_likelihood()
+        info = plan.grad_info()
+        assert info["reverse"] and info["forward_reruns"] == 0 and info["drift_max"] <= 1e-9, info
+        assert np.max(np.abs(g1 - g0) / scale) <= 1e-9
+        plan.set_grad_mode("reverse", stored_state_distance=4)     # a few steps between stored states: still fine
+        v4, g4, st4 = plan.grad_log_likelihood()
+        assert np.max(np.abs(g4 - g0) / scale) <= 1e-9
+        plan.set_grad_mode("reverse", stored_state_distance=750)   # one stored state per chunk: far too few here
+        v2, g2, st2 = plan.grad_log_likelihood()
+        info = plan.grad_info()
+        assert info["reverse"] and info["forward_reruns"] >= 1, info
+        assert np.max(np.abs(g2 - g0) / scale) <= 1e-9
+        plan.set_grad_mode("reverse", stored_state_distance=1)     # every state stored: nothing to reconstruct
+        v3, g3, st3 = plan.grad_log_likelihood()
+        assert plan.grad_info()["forward_reruns"] == 0
+        assert np.max(np.abs(g3 - g0) / scale) <= 1e-9
+    finally:
+        plan.close()
+
+
+def test_plan_gradient_full_size_directional_derivative():
+    """The headline shape's series length (N = 1e5, width 8, 17 partials), where no oracle gradient is affordable:
+    the gradient must predict the change of the plan's OWN log-likelihood (pinned to the oracle elsewhere) along a
+    random direction in coefficient space -- central differences, the criterion of the reference's gradient test
+    (tests/test_celerite.py:452-481) -- and agree with the sequential tangent kernel on two problems."""
+    import bench
+    B, N, JR, JC = 16, 100000, 2, 3
+    coeffs, t, diag, y = bench.make_inputs(B, N, JR, JC, 123)
+    jit = np.full(B, 0.05)
+    rng = np.random.default_rng(5)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs, jitter=jit)
+        v, g, st = plan.grad_log_likelihood()
+        assert (st == 0).all() and plan.grad_fallbacks() == 0
+        # direction: relative perturbation of every coefficient and of the jitter
+        d_co = [c * rng.uniform(-1.0, 1.0, c.shape) for c in coeffs]
+        d_jit = jit * rng.uniform(-1.0, 1.0, B)
+        # g is ordered jitter | a_real | c_real | a_comp | b_comp | c_comp | d_comp (solver.cpp:379-406)
+        dvec = np.concatenate([d_jit[:, None]] + d_co, axis=1)
+        pred = np.sum(g * dvec, axis=1)
+        eps = 1e-6
+        lls = []
+        for sgn in (+1.0, -1.0):
+            plan.set_coefficients(*[c + sgn * eps * d for c, d in zip(coeffs, d_co)], jitter=jit + sgn * eps * d_jit)
+            ll, ld, q, s2 = plan.log_likelihood()
+            assert (s2 == 0).all()
+            lls.append(-0.5 * (q + ld))
+        fd = (lls[0] - lls[1]) / (2 * eps)
+        assert np.max(np.abs(fd - pred) / np.abs(pred)) <= 2e-5, np.max(np.abs(fd - pred) / np.abs(pred))
+    finally:
+        plan.close()
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        v2, g2, st2 = batch.batch_grad_log_likelihood(*[c[:2] for c in coeffs], t[:2], diag[:2], y[:2], jitter=jit[:2])
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    assert np.max(np.abs(v[:2] - v2) / np.abs(v2)) <= 1e-11
+    assert np.max(np.abs(g[:2] - g2)) <= 1e-8 * np.max(np.abs(g2))
 
 
 @pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13)])

@@ -346,3 +346,46 @@ def test_chunk_parallel_gradient_against_the_dual_number_oracle(gradlib, JR, JC)
         v = -0.5 * (q.value + ld.value + np.pi * np.log(N))     # the reference's constant, solver.cpp:415
         assert abs(v - v0) <= 1e-13 * abs(v0)
         assert np.max(np.abs(g - g0)) <= 1e-10 * np.max(np.abs(g0)), (nchunk, np.max(np.abs(g - g0)) / np.max(np.abs(g0)))
+
+
+@pytest.mark.parametrize("JR,JC", [(1, 0), (0, 1), (1, 1), (2, 1), (2, 3), (3, 2)])
+def test_reverse_mode_gradient_against_the_dual_number_oracle(gradlib, JR, JC):
+    """csrc/clr_grad_core.h, reverse mode, on the host: the riders pass with its per-sample record, the adjoint walk
+    backwards over the chunks, one reverse sweep per chunk for all partials.  Equal to oracle/grad.py; the adjoint a
+    sweep arrives at for its chunk's first sample equals the one the walk predicted from the riders (1e-13: the two
+    are independent computations of the same quantity); dense and sparse series; and the reason the states are stored
+    every K steps: rebuilding them backwards over a long stretch amplifies rounding errors without bound."""
+    from oracle import grad as ograd
+    dp = C.POINTER(C.c_double)
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    rng = np.random.default_rng(300 + JR + 7 * JC)
+    N = 400
+    diag = rng.uniform(0.5, 1.0, N)
+    y = rng.normal(size=N)
+    ar, cr = rng.uniform(0.5, 1.5, JR), rng.uniform(0.05, 0.5, JR)
+    ac, bc = rng.uniform(0.5, 1.5, JC), rng.uniform(-0.1, 0.1, JC)
+    cc, dc = rng.uniform(0.05, 0.5, JC), rng.uniform(0.5, 3.0, JC)
+    e, e2 = np.empty(0), np.empty((0, 0))
+    gradlib.hostcheck_grad_reverse.argtypes = ([C.c_int] * 4 + [C.c_double] + [dp] * 9 + [C.POINTER(C.c_double)] * 2 +
+                                               [dp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)])
+
+    def run(t, nchunk, K):
+        ld, q, mm, dr = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        g = np.zeros(1 + 2 * JR + 4 * JC)
+        rc = gradlib.hostcheck_grad_reverse(N, JR, JC, nchunk, 0.05, P(ar), P(cr), P(ac), P(bc), P(cc), P(dc), P(t),
+                                            P(diag), P(y), C.byref(ld), C.byref(q), P(g), C.byref(mm), K, C.byref(dr))
+        assert rc == 0
+        return g, mm.value, dr.value
+
+    for span, nchunk, K in ((0.02, 3, 0), (0.02, 1, 50), (0.5, 5, 4), (0.5, 2, 1), (5.0, 4, 1)):
+        t = np.sort(rng.uniform(0, span * N, N))
+        v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
+        g, mismatch, drift = run(t, nchunk, K)
+        assert np.max(np.abs(g - g0)) <= 1e-10 * np.max(np.abs(g0)), (span, nchunk, K)
+        assert mismatch <= 1e-12, (span, nchunk, K, mismatch)
+    # no stored states over 400 samples of a series that forgets: the reconstruction is lost, and the drift says so
+    t = np.sort(rng.uniform(0, 2.0 * N, N))
+    v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
+    g, mismatch, drift = run(t, 2, 0)
+    assert not np.max(np.abs(g - g0)) <= 1e-6 * np.max(np.abs(g0))
+    assert not drift <= 1e-6

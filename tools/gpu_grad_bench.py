@@ -21,14 +21,20 @@ for name, maker in (("bench family", make_inputs), ("accuracy family", make_inpu
     coeffs, t, diag, y = maker(B, N, 2, 3, 42)
     plan = batch.BatchedGP(B, N, 2, 3)
     plan.set_series(t, diag, y); plan.set_coefficients(*coeffs)
-    v, g, st = plan.grad_log_likelihood()
-    batch.device_synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    res = {}
+    for mode in ("forward", "reverse"):
+        plan.set_grad_mode(mode)
         v, g, st = plan.grad_log_likelihood()
-    dt = (time.perf_counter() - t0) / 3
-    print("%s: plan gradient B=%d N=%d: %.2f ms per call (%.1f us per problem), chunks %s, fallbacks %d, ok %d" % (
-        name, B, N, dt * 1e3, dt / B * 1e6, plan.chunks, plan.grad_fallbacks(), int((st == 0).sum())), flush=True)
+        batch.device_synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            v, g, st = plan.grad_log_likelihood()
+        dt = (time.perf_counter() - t0) / 3
+        res[mode] = g
+        print("%s: plan gradient (%s mode) B=%d N=%d: %.2f ms per call (%.1f us per problem), chunks %s, fallbacks %d, ok %d, %s" % (
+            name, mode, B, N, dt * 1e3, dt / B * 1e6, plan.chunks, plan.grad_fallbacks(), int((st == 0).sum()), plan.grad_info()), flush=True)
+    gs_ = np.max(np.abs(res["forward"]), axis=1, keepdims=True)
+    print("   reverse vs forward: %.1e of the largest partial" % np.max(np.abs(res["reverse"] - res["forward"]) / gs_), flush=True)
     plan.close()
     S = 64
     (vs, gs, sts), dts = seq([c[:S] for c in coeffs], t[:S], diag[:S], y[:S])
