@@ -416,14 +416,32 @@ def gradient_block(B, N, JR, JC, seed):
     try:
         plan.set_series(t, diag, y)
         plan.set_coefficients(*coeffs)
-        v, g, st = plan.grad_log_likelihood()
         calls = 3
+        timing = {}
+        for mode in ("forward", "reverse"):      # (reverse last: it is the default and the one reported as `value`)
+            plan.set_grad_mode(mode)
+            v, g, st = plan.grad_log_likelihood()
+            batch.device_synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                v, g, st = plan.grad_log_likelihood()
+            timing[mode] = (time.perf_counter() - t0) / calls
+            if mode == "forward":
+                g_forward = g.copy()
+        dt = timing["reverse"]
+        info = plan.grad_info()
+        fallbacks, chunks = plan.grad_fallbacks(), plan.chunks
+        # the accuracy family (sparse: every state stored) through the same plan shape
+        coeffs_a, t_a, diag_a, y_a = make_inputs_accuracy(B, N, JR, JC, 4242)
+        plan.set_series(t_a, diag_a, y_a)
+        plan.set_coefficients(*coeffs_a)
+        plan.grad_log_likelihood()
         batch.device_synchronize()
         t0 = time.perf_counter()
         for _ in range(calls):
-            v, g, st = plan.grad_log_likelihood()
-        dt = (time.perf_counter() - t0) / calls
-        fallbacks, chunks = plan.grad_fallbacks(), plan.chunks
+            va, ga, sta = plan.grad_log_likelihood()
+        dt_acc = (time.perf_counter() - t0) / calls
+        info_acc = plan.grad_info()
     finally:
         plan.close()
 
@@ -451,9 +469,16 @@ def gradient_block(B, N, JR, JC, seed):
     (vq, gq), d_seq = sequential(lambda: celerite_amd.CholeskySolver().grad_log_likelihood(*args))
     return {
         "workload": "grad_log_likelihood (solver.cpp:347-463): batch=%d x N=%d, width %d, %d partials per problem" % (B, N, JR + 2 * JC, NG),
-        "path": "clr_batch_grad: evaluation by the scan, then riders + tangents per (chunk, direction group) + walk over the chunks",
+        "path": "clr_batch_grad, reverse mode: evaluation by the scan, riders + per-sample record per chunk, adjoint walk "
+                "over the chunks, one reverse sweep per chunk for all partials",
         "scan_chunks": chunks, "ms_per_call": dt * 1e3, "value": B / dt, "unit": "gradients/s",
         "partials_per_s": B * NG / dt, "sequential_fallbacks": fallbacks, "status_not_ok": int((st != 0).sum()),
+        "reverse_sweep": info,
+        "forward_mode": {"what": "one tangent per partial from the scanned start states (two per wave) + walk over the chunks",
+                         "ms_per_call": timing["forward"] * 1e3,
+                         "reverse_vs_forward_rel_max": float(np.max(np.abs(g - g_forward) / np.max(np.abs(g_forward), axis=1, keepdims=True)))},
+        "accuracy_family": {"ms_per_call": dt_acc * 1e3, "reverse_sweep": info_acc, "status_not_ok": int((sta != 0).sum()),
+                            "note": "sparse series: every state is stored (54 doubles per sample instead of ~10)"},
         "sequential_kernel_slice": {"problems": S, "ms_per_problem_incl_upload": dts * 1e3 / S,
                                     "value_rel_max": rel_err(v[:S], vs), "grad_rel_max": float(np.max(np.abs(g[:S] - gs) / scale)),
                                     "note": "one wave per (problem, partial), sequential in n (csrc/grad_kernels.hip); pinned "

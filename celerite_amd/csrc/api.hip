@@ -2376,11 +2376,12 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   st = clr_batch_enqueue(h, 0);
   h->grad_scan_only = false;
   if (st != CLR_OK) return st;
-  clr::BatchParams P;
+  clr::BatchParams P, Pi;
   h->in_fallback = true;  // (the row-major arrays)
   st = batch_params(h, 0, P);
   h->in_fallback = false;
   if (st != CLR_OK) return st;
+  if ((st = batch_params(h, 0, Pi)) != CLR_OK) return st;  // (the evaluation's own view: interleaved copy if it has one)
   const bool scan_grad = P.fast_trig != 0;  // (only the fast-sincos flavour of the gradient kernels is built)
   // mode: reverse (one sweep for all partials, needs the per-sample record in HBM) unless asked otherwise or the
   // record does not fit; forward (one tangent per partial) as the fallback and the cross-check
@@ -2389,14 +2390,15 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   auto choose_m = [&](bool rev) {
     // gradient chunks: m chunks of the scan each.  Modelled time: rounds of waves x steps per lane (forward: 2.7 us
     // per step of a tangent wave at width 8, ~ J^2, one wave per direction group; reverse: record + sweep, ~ 5 us)
-    // + the walk(s) over the gradient chunks (~ J^3 per chunk)
+    // + the walk over the gradient chunks
     int m = 1;
     double best = INFINITY;
     for (int k = 1; k <= h->nchunk; ++k) {
       const int ng = (h->nchunk + k - 1) / k;
       const double waves = (double)B * ((ng + 63) / 64) * (rev ? 1.0 : groups);
       const double step = rev ? 0.6 + 4.4 * w2 : 0.3 + 2.4 * w2;
-      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * step + ng * (0.5 + 4.5 * w2 * J / 8.0);
+      const double walk = rev ? 0.45 : 0.5 + 4.5 * w2 * J / 8.0;  // per chunk: a wave per problem / a thread per (problem, direction)
+      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * step + ng * walk;
       if (tm < best) { best = tm; m = k; }
     }
     return m;
@@ -2404,6 +2406,15 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   auto set_chunks = [&](int m) {
     P.g_m = m;
     P.g_nchunk = (h->nchunk + m - 1) / m;
+    if (m == 1 && Pi.lane_cs == 1 && !Pi.staged) {  // a gradient chunk is a scan chunk: read the interleaved copy
+      P.t = Pi.t; P.diag = Pi.diag; P.y = Pi.y;
+      P.t_stride = Pi.t_stride; P.diag_stride = Pi.diag_stride; P.y_stride = Pi.y_stride;
+      P.lane_is = Pi.lane_is; P.lane_cs = Pi.lane_cs;
+    } else {
+      P.t = h->t.p; P.diag = h->diag.p; P.y = h->y.p;
+      P.t_stride = h->t_stride; P.diag_stride = h->diag_stride; P.y_stride = h->y_stride;
+      P.lane_is = 1; P.lane_cs = h->L;
+    }
     return B * (size_t)P.g_nchunk;
   };
   if ((st = h->g_res.reserve(B * NG + B * (NG + 1) + B)) != CLR_OK) return st;  // result | fallback value, grad | fallback status

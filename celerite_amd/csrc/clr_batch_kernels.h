@@ -928,7 +928,7 @@ struct BatchImpl {
     using Sh = GradShape<JR, JC>;
     const dim3 grid((P.g_nchunk + 63) / 64, P.B);
     hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
-    hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+    hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
     hipLaunchKernelGGL((grad_backward_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
     const long n = (long)P.B * Sh::NG;
     hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, Sh::NG);

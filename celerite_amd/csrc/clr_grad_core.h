@@ -15,8 +15,10 @@
 //         r_n = (F_{n-1} ... F_{n0})^T u_n:
 //         dS_end = AA dS_0 AA^T            df_end = AA (df_0 - dS_0 eta)
 //         d(log det) = -<JJ, dS_0>         d(quad) = -2 eta . df_0 + eta^T dS_0 eta
-//     (the sum over n of the quad terms telescopes; derivation in DESIGN.md section 8.6).
-// grad_combine walks the chunks of one (problem, direction): a 2 J^3 update per chunk, nothing per sample.
+//     (the sum over n of the quad terms telescopes; derivation in DESIGN.md section 3.1).
+// FORWARD mode: grad_combine walks the chunks of one (problem, direction): a 2 J^3 update per chunk, nothing per sample.
+// REVERSE mode (the default, second half of this file): the transposed chunk maps carry the ADJOINT of the base state
+// backwards over the chunks, and one reverse sweep per chunk yields all partials at once.
 //
 // Directions in the reference's order (solver.cpp:379-406): jitter | a_real | c_real | a_comp | b_comp | c_comp |
 // d_comp.  A wave carries the TWO directions of one group -- {a_real_j, c_real_j}, {a_comp_j, b_comp_j},
@@ -333,9 +335,9 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
       if (ck && i > 0 && i % K == 0) {
         double* o = ck + (long)(i / K - 1) * (SZ + J) * rstride;
         CLR_UNROLL
-        for (int k = 0; k < SZ; ++k) o[(long)k * rstride] = S[k];
+        for (int k = 0; k < SZ; ++k) store_stream(o + (long)k * rstride, S[k]);
         CLR_UNROLL
-        for (int k = 0; k < J; ++k) o[(long)(SZ + k) * rstride] = f[k];
+        for (int k = 0; k < J; ++k) store_stream(o + (long)(SZ + k) * rstride, f[k]);
       }
       double u[J], v[J];
       features_uv<JR, JC, FAST>(p, tn, u, v);
@@ -359,11 +361,11 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
         z[j] = v[j] - q[j];
         w[j] = z[j] * invD;
       }
-      if (rec) {
+      if (rec) {  // (written once, read once by the reverse sweep: streaming stores)
         CLR_UNROLL
-        for (int j = 0; j < J; ++j) rec[((long)i * (J + 2) + j) * rstride] = w[j];
-        rec[((long)i * (J + 2) + J) * rstride] = D;
-        rec[((long)i * (J + 2) + J + 1) * rstride] = x;
+        for (int j = 0; j < J; ++j) store_stream(rec + ((long)i * (J + 2) + j) * rstride, w[j]);
+        store_stream(rec + ((long)i * (J + 2) + J) * rstride, D);
+        store_stream(rec + ((long)i * (J + 2) + J + 1) * rstride, x);
       }
       double r[J];
       CLR_UNROLL

@@ -15,8 +15,9 @@
 // Problems the scan handed to the sequential recurrence (need_exact >= 2: their scanned start states are not
 // certified) are skipped; the host runs the sequential gradient kernel (grad_kernels.hip) for them.  g_mask (may be
 // null) restricts the forward-mode kernels to the problems whose reverse sweep drifted.
-// The series is read through DirectSeries on the row-major arrays: at ~900 fp64 instructions per step and wave the
-// 24 bytes per lane and step are not what the kernel waits for.
+// The series is read through DirectSeries: from the chunk-interleaved copy when there is one (one 512-B line per array,
+// step and wave), else from the row-major arrays (8-B reads that re-fetch their 64-B lines: 5x the bytes, measured, but
+// at ~900 fp64 instructions per step and wave not what the forward-mode kernels wait for).
 // A gradient chunk is P.g_m consecutive chunks of the scan (every scan chunk's start state is a valid start): the
 // host balances the tangent pass (steps per lane) against the walk over the gradient chunks (clr_batch_grad) -- one
 // long series is scanned in ~2000 chunks but differentiated in ~250.
@@ -26,8 +27,10 @@
 
 namespace clr {
 
-// gradient chunk c of problem b on the row-major arrays
+// gradient chunk c of problem b: on the chunk-interleaved copy of the series when the plan has one and a gradient
+// chunk IS a scan chunk (the host sets P up that way: lane_cs == 1), else on the row-major arrays
 __device__ __forceinline__ DirectSeries grad_series(const BatchParams& P, int b, int c) {
+  if (P.lane_cs == 1) return make_direct(P, b, c);
   const long Lg = (long)P.g_m * P.L, first = (long)c * Lg;
   return DirectSeries{P.t + b * P.t_stride + first, P.diag + b * P.diag_stride + first, P.y + b * P.y_stride + first,
                       1, Lg, (int)Lg, (long)P.N - first};
@@ -89,12 +92,67 @@ __global__ void __launch_bounds__(64) grad_combine_kernel(const BatchParams P, i
   P.g_res[idx] = -0.5 * (dq + dld);
 }
 
+// grad_adjoint_walk (clr_grad_core.h) with one WAVE per problem: lane (i, j) owns entry (i, j) of the J x J products,
+// operands through LDS, the next chunk's riders prefetched into registers while the current chunk is multiplied.
+// One thread per problem walked a chunk in ~6.6 us (0.42 ms at 64 chunks, the longest phase of a single long series);
+// a wave takes ~0.4 us.
 template <int J>
 __global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
-  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ADJ = SZ + J;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.B || P.need_exact[b] >= 2) return;
-  grad_adjoint_walk<J>(P.g_nchunk, P.g_riders + (long)b * P.g_nchunk * RID, P.g_adj + (long)b * P.g_nchunk * ADJ);
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ADJ = SZ + J, JJN = J * J;
+  __shared__ double AA[JJN], eta[J], JJ[SZ], Sb[JJN], fb[J], g[J], T[JJN];
+  const int b = blockIdx.x, l = threadIdx.x;
+  if (P.need_exact[b] >= 2) return;
+  const int i = l / J, j = l % J;  // (lanes >= J * J idle)
+  const bool mat = l < JJN;
+  const double* riders = P.g_riders + (long)b * P.g_nchunk * RID;
+  double* adj = P.g_adj + (long)b * P.g_nchunk * ADJ;
+  if (mat) Sb[l] = 0.0;
+  if (l < J) fb[l] = 0.0;
+  int c = P.g_nchunk - 1;
+  double r_aa = 0.0, r_eta = 0.0, r_jj = 0.0;
+  auto fetch = [&](int cc) {
+    const double* R = riders + (long)cc * RID;
+    if (mat) r_aa = R[l];
+    if (l < J) r_eta = R[JJN + l];
+    if (l < SZ) r_jj = R[JJN + J + l];
+  };
+  if (c > 0) fetch(c);
+  __syncthreads();
+  for (; c >= 0; --c) {
+    // the adjoint at the end of chunk c
+    if (mat && i <= j) adj[(long)c * ADJ + tri(i, j)] = Sb[l];
+    if (l < J) adj[(long)c * ADJ + SZ + l] = fb[l];
+    if (c == 0) break;
+    if (mat) AA[l] = r_aa;
+    if (l < J) eta[l] = r_eta;
+    if (l < SZ) JJ[l] = r_jj;
+    if (c > 1) fetch(c - 1);
+    __syncthreads();
+    if (l < J) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) a = fma(AA[k * J + l], fb[k], a);
+      g[l] = a;
+    }
+    if (mat) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) t = fma(Sb[i * J + k], AA[k * J + j], t);
+      T[l] = t;
+    }
+    __syncthreads();
+    double s_new = 0.0, f_new = 0.0;
+    if (mat) {
+      s_new = eta[i] * eta[j] - JJ[sym(i, j)] - 0.5 * (g[i] * eta[j] + eta[i] * g[j]);
+#pragma unroll
+      for (int k = 0; k < J; ++k) s_new = fma(AA[k * J + i], T[k * J + j], s_new);
+    }
+    if (l < J) f_new = g[l] - 2.0 * eta[l];
+    __syncthreads();
+    if (mat) Sb[l] = s_new;
+    if (l < J) fb[l] = f_new;
+    __syncthreads();
+  }
 }
 
 template <int JR, int JC, bool FAST>
