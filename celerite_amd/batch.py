@@ -573,6 +573,16 @@ class ShardedBatchedGP(object):
         jit, blocks = self._coeff_blocks(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter)
         self._ok(_load().clr_sharded_set_coefficients(self._h, _ptr(jit), *[_ptr(b) for b in blocks]))
 
+    def grad_log_likelihood(self):
+        """``(value[B], grad[B, 1 + 2 J_real + 4 J_comp], status[B])`` at the coefficients in force: every shard's
+        plan gradient concurrently (``clr_sharded_grad``)."""
+        NG = 1 + 2 * self.J_real + 4 * self.J_comp
+        value, grad, st = np.empty(self.B), np.empty((self.B, NG)), np.empty(self.B, dtype=np.int32)
+        lib = _load()
+        lib.clr_sharded_grad.argtypes = [C.c_void_p, _dp, _dp, _ip]
+        self._ok(lib.clr_sharded_grad(self._h, _ptr(value), _ptr(grad), st.ctypes.data_as(_ip)))
+        return value, grad, st
+
     def enqueue(self):
         self._ok(_load().clr_sharded_enqueue(self._h))
 

@@ -284,6 +284,16 @@ int clr_sharded_get_results(clr_sharded* h, double* loglike, double* logdet, dou
   });
 }
 
+// value + gradient of every problem at the coefficients in force: clr_batch_grad on every shard concurrently
+int clr_sharded_grad(clr_sharded* h, double* value, double* grad, int* status) {
+  const long NG = 1 + 2 * (long)h->J_real + 4 * (long)h->J_comp;
+  return h->all([=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_grad(h->plan[s], value ? value + lo : nullptr, grad ? grad + lo * NG : nullptr,
+                          status ? status + lo : nullptr);
+  });
+}
+
 int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_real, const double* c_real,
                          const double* a_comp, const double* b_comp, const double* c_comp,
                          const double* d_comp, double* loglike, double* logdet, double* quad, int* status) {

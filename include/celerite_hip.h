@@ -478,6 +478,9 @@ int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const dou
 int clr_sharded_enqueue(clr_sharded* h);
 int clr_sharded_synchronize(clr_sharded* h);
 int clr_sharded_get_results(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status);
+/* clr_batch_grad on every shard concurrently (coefficients in force: clr_sharded_set_coefficients); grad is
+ * [B][1 + 2 J_real + 4 J_comp]. */
+int clr_sharded_grad(clr_sharded* h, double* value, double* grad, int* status);
 /* One optimiser / MCMC evaluation: new coefficients in, B log-likelihoods out
  * (set_coefficients + enqueue + get_results on every shard concurrently). */
 int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_real, const double* c_real,

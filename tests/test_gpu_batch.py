@@ -589,6 +589,36 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
             assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), S
 
 
+def test_sharded_gradient_equals_the_unsharded_one():
+    """clr_sharded_grad: every shard's plan gradient concurrently; with the chunk count pinned the numbers are the
+    unsharded plan's bit for bit (per-problem work, batch-wide kernel selection), statuses included."""
+    B, N, JR, JC = 11, 4000, 2, 3
+    case = synthetic(B, N, JR, JC, "bench", seed=8)
+    case["a_real"][4:5] *= -40.0
+    jit = np.linspace(0.0, 0.2, B)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_chunks(16)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        want = plan.grad_log_likelihood()
+    finally:
+        plan.close()
+    assert want[2][4] == 2 and (want[2] == 0).sum() == B - 1
+    ndev = batch.device_count()
+    for S in (2, 3):
+        sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+        try:
+            sp.set_chunks(16)
+            sp.set_series(case["t"], case["diag"], case["y"])
+            sp.set_coefficients(*coeffs_of(case), jitter=jit)
+            got = sp.grad_log_likelihood()
+        finally:
+            sp.close()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b, equal_nan=True), S
+
+
 @pytest.mark.parametrize("spoiler", ["none", "decay", "frequency"])
 def test_sharding_with_the_default_kernel_selection_is_bit_identical(spoiler):
     """ADVICE r2 / VERDICT r2: the automatic kernel selection (role split, lazy decay, fast trigonometry) looks at
@@ -861,6 +891,42 @@ def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
     v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, case["t"][b], case["y"][b], case["diag"][b])
     assert abs(v1[b] - v0) <= 1e-10 * abs(v0)
     assert np.allclose(g1[b], g0, rtol=1e-8, atol=1e-8 * np.max(np.abs(g0)))
+
+
+@pytest.mark.parametrize("mode", ["reverse", "forward"])
+def test_plan_gradient_full_size_against_the_oracle_fixture(mode):
+    """The headline's series length against the ORACLE: tests/golden/grad_n1e5_w8.json holds oracle/grad.py's value
+    and 17 partials for problem 0 of bench.make_inputs(2, 1e5, 2, 3, 42) with jitter 0.25 (75 s of Python loops,
+    generated by tests/golden/make_grad_golden.py); the plan gradient -- 64 chunks of 1568 samples -- must reproduce
+    them to 1e-8 relative per partial, the object API too."""
+    import json
+    import bench
+    import celerite_amd
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grad_n1e5_w8.json")) as f:
+        gold = json.load(f)
+    N, JR, JC = gold["N"], gold["J_real"], gold["J_comp"]
+    coeffs, t, diag, y = bench.make_inputs(2, N, JR, JC, 42)
+    g0 = np.array(gold["grad"])
+    plan = batch.BatchedGP(2, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs, jitter=gold["jitter"])
+        plan.set_chunks(64)
+        plan.set_grad_mode(mode)
+        v, g, st = plan.grad_log_likelihood()
+        assert (st == 0).all() and plan.grad_fallbacks() == 0 and plan.grad_info()["forward_reruns"] == 0
+    finally:
+        plan.close()
+    assert abs(v[0] - gold["value"]) <= 1e-10 * abs(gold["value"])
+    # per partial: 1e-8 relative (the jitter partial is 1.8e5, the others 40 .. 320: a common scale would hide them)
+    tol = 1e-8 * np.abs(g0) + 1e-12 * np.max(np.abs(g0))
+    assert (np.abs(g[0] - g0) <= tol).all(), np.abs(g[0] - g0) / np.abs(g0)
+    if mode == "reverse":
+        e, e2 = np.empty(0), np.empty((0, 0))
+        v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(gold["jitter"], *[c[0] for c in coeffs], e, e2, e2,
+                                                                   t[0], y[0], diag[0])
+        assert abs(v1 - gold["value"]) <= 1e-10 * abs(gold["value"])
+        assert (np.abs(g1 - g0) <= tol).all(), np.abs(g1 - g0) / np.abs(g0)
 
 
 def test_reverse_gradient_certifies_its_reconstructed_states():
