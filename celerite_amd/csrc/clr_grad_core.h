@@ -584,46 +584,70 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
   for (int j = 0; j < JC; ++j) { g_ac[j] = 0.0; g_bc[j] = 0.0; g_cc[j] = 0.0; g_dc[j] = 0.0; }
   const int last = (N - n0 < L ? N - n0 : L) - 1;  // local index of the chunk's last sample
   double drift = 0.0;
+  // the record and the times of a step are fetched one step ahead (one wave per SIMD: nothing else hides the latency)
+  double w_n[J], D_n = 1.0, x_n = 0.0, t_n = 0.0, t_n1 = 0.0;
+  auto fetch = [&](int i) {
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) w_n[j] = rec[((long)i * (J + 2) + j) * rstride];
+    D_n = rec[((long)i * (J + 2) + J) * rstride];
+    x_n = rec[((long)i * (J + 2) + J + 1) * rstride];
+    t_n1 = t_n;          // (going backwards: the time after step i is the time of the step fetched before)
+    t_n = src.t(i);
+  };
+  if (last >= 0) {
+    t_n = src.t(last + 1);
+    fetch(last);
+  }
   for (int i = last; i >= 0; --i) {
     const int n = n0 + i;
-    const double tn = src.t(i);
-    const double dt = n + 1 < N ? src.t(i + 1) - tn : 0.0;
+    const double tn = t_n;
+    const double dt = n + 1 < N ? t_n1 - tn : 0.0;
     double w[J];
     CLR_UNROLL
-    for (int j = 0; j < J; ++j) w[j] = rec[((long)i * (J + 2) + j) * rstride];
-    const double D = rec[((long)i * (J + 2) + J) * rstride];
-    const double x = rec[((long)i * (J + 2) + J + 1) * rstride];
-    const double invD = 1.0 / D;
-    double u[J], v[J], phid[nz(M)], iphid[nz(M)];
+    for (int j = 0; j < J; ++j) w[j] = w_n[j];
+    const double D = D_n, x = x_n;
+    if (i > 0) fetch(i - 1);
+    const double invD = recip_fast(D);
+    double u[J], v[J], phid[nz(M)], iphid[nz(M)], pp[nz(M * (M + 1) / 2)], ipp[nz(M * (M + 1) / 2)];
     features_uv<JR, JC, FAST>(p, tn, u, v);
     features_phi_distinct<JR, JC>(p, dt, phid);
     CLR_UNROLL
-    for (int a = 0; a < M; ++a) iphid[a] = 1.0 / phid[a];
+    for (int a = 0; a < M; ++a) iphid[a] = recip_fast(phid[a]);
+    CLR_UNROLL
+    for (int bb = 0; bb < M; ++bb) {
+      CLR_UNROLL
+      for (int a = 0; a <= bb; ++a) {
+        pp[tri(a, bb)] = phid[a] * phid[bb];
+        ipp[tri(a, bb)] = iphid[a] * iphid[bb];
+      }
+    }
     // d phi / dc from the state AFTER the step, then the state before it
     double crow[J];
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
-      double acc = fb[j] * f[j];
+      double acc = 0.0;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) acc = fma(2.0 * Sb[sym(j, k)], S[sym(j, k)], acc);
-      crow[j] = acc;
+      for (int k = 0; k < J; ++k) acc = fma(Sb[sym(j, k)], S[sym(j, k)], acc);
+      crow[j] = fma(fb[j], f[j], 2.0 * acc);
     }
     CLR_UNROLL
     for (int j = 0; j < JR; ++j) g_cr[j] = fma(-dt, crow[j], g_cr[j]);
     CLR_UNROLL
     for (int j = 0; j < JC; ++j) g_cc[j] = fma(-dt, crow[JR + 2 * j] + crow[JR + 2 * j + 1], g_cc[j]);
-    double Gb[SZ], hb[J];
+    // Gbar = phi phi^T o Sbar' (in place: Sb holds Gbar until the end of the step); S, f before the step
+    double hb[J], mDw[J];
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) mDw[j] = -D * w[j];
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
-      const double pj = phid[phi_index<JR>(j)], ij = iphid[phi_index<JR>(j)];
       CLR_UNROLL
       for (int k = 0; k <= j; ++k) {
-        const double pk = phid[phi_index<JR>(k)], ik = iphid[phi_index<JR>(k)];
-        Gb[tri(k, j)] = (pj * pk) * Sb[tri(k, j)];
-        S[tri(k, j)] = fma(-D * w[k], w[j], (ij * ik) * S[tri(k, j)]);
+        const int e = tri(phi_index<JR>(k), phi_index<JR>(j));
+        Sb[tri(k, j)] = pp[e] * Sb[tri(k, j)];
+        S[tri(k, j)] = fma(mDw[k], w[j], ipp[e] * S[tri(k, j)]);
       }
-      hb[j] = pj * fb[j];
-      f[j] = fma(-w[j], x, ij * f[j]);
+      hb[j] = phid[phi_index<JR>(j)] * fb[j];
+      f[j] = fma(-w[j], x, iphid[phi_index<JR>(j)] * f[j]);
     }
     if ((ck && i > 0 && i % K == 0) || i == 0) {
       // a state known independently -- stored by the forward pass, or (i = 0) the chunk's start state from the scan:
@@ -658,7 +682,7 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
     for (int j = 0; j < J; ++j) {
       double acc = 0.0;
       CLR_UNROLL
-      for (int k = 0; k < J; ++k) acc = fma(Gb[sym(j, k)], w[k], acc);
+      for (int k = 0; k < J; ++k) acc = fma(Sb[sym(j, k)], w[k], acc);
       m[j] = acc;
     }
     double wb[J], zb[J], xbar = 2.0 * x * invD, wbw = 0.0;
@@ -671,12 +695,15 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
     }
     const double Dbar = invD - (x * invD) * (x * invD) - wbw * invD;
     g_k0 += Dbar;
-    double qb[J], ub[J];
-    CLR_UNROLL
-    for (int j = 0; j < J; ++j) qb[j] = -zb[j] - Dbar * u[j];
+    double qb[J], qh[J], ub[J];
     CLR_UNROLL
     for (int j = 0; j < J; ++j) {
-      const double q = v[j] - D * w[j];
+      qb[j] = -zb[j] - Dbar * u[j];
+      qh[j] = 0.5 * qb[j];
+    }
+    CLR_UNROLL
+    for (int j = 0; j < J; ++j) {
+      const double q = fma(mDw[j], 1.0, v[j]);  // q = v - z, z = D w
       double acc = -xbar * f[j] - Dbar * q;
       CLR_UNROLL
       for (int k = 0; k < J; ++k) acc = fma(S[sym(j, k)], qb[k], acc);
@@ -686,7 +713,7 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
     for (int j = 0; j < J; ++j) {
       fb[j] = fma(-xbar, u[j], hb[j]);
       CLR_UNROLL
-      for (int k = 0; k <= j; ++k) Sb[tri(k, j)] = Gb[tri(k, j)] + 0.5 * fma(qb[k], u[j], u[k] * qb[j]);
+      for (int k = 0; k <= j; ++k) Sb[tri(k, j)] = fma(qh[k], u[j], fma(u[k], qh[j], Sb[tri(k, j)]));
     }
     // coefficients: U~ = a (real), (a cd + b sd, a sd - b cd) and V~ = (cd, sd) (complex), cholesky.h:129-147
     CLR_UNROLL
