@@ -353,9 +353,10 @@ class BatchedGP(object):
         return value, grad, st
 
     def set_grad_mode(self, mode="reverse", stored_state_distance=0, drift_tolerance=0.0):
-        """``"reverse"`` (default: one sweep for all partials) or ``"forward"`` (one tangent per partial);
-        ``clr_batch_set_grad_mode``."""
-        _check(_load().clr_batch_set_grad_mode(self._h, {"reverse": 0, "forward": 1}[mode], int(stored_state_distance),
+        """``"reverse"`` (default: one sweep for all partials), ``"forward"`` (one tangent per partial) or
+        ``"reverse-direct-riders"`` (reverse mode with the riders accumulated along the trajectory instead of taken
+        from the scan's elements; A/B runs); ``clr_batch_set_grad_mode``."""
+        _check(_load().clr_batch_set_grad_mode(self._h, {"reverse": 0, "forward": 1, "reverse-direct-riders": 2}[mode], int(stored_state_distance),
                                                float(drift_tolerance)))
 
     def grad_info(self):

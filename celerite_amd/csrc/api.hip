@@ -361,6 +361,7 @@ struct clr_batch {
   DevBuf g_rec, g_ck;                 // reverse mode: w, D, x per sample; the state every grad K steps
   int grad_mode = 0;                  // clr_batch_set_grad_mode: 0 auto (reverse), 1 forward (one tangent per partial)
   int grad_K = 0;                     // > 0: distance of the stored states (steps), else from c_max dt_max
+  int grad_riders_mode = 0;           // 0 auto (from the scan's elements when a gradient chunk is a scan chunk), 1 along the trajectory
   double grad_drift_tol = 1e-9;       // a reverse sweep whose reconstructed states drift further is redone forward
   double grad_drift_max = 0.0;        // last gradient: largest drift among the problems it settled
   int grad_forward_reruns = 0;        // ... and the problems redone by the forward-mode kernels
@@ -2447,6 +2448,7 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       P.g_part = P.g_adj + pc * (SZ + J);
       P.g_drift = P.g_part + pc * NG;
       P.g_drift_max = P.g_drift + pc;
+      P.g_from_elems = (P.g_m == 1 && h->grad_riders_mode != 1) ? 1 : 0;
       h->launch->grad_reverse(P, h->stream);
       HIP_TRY(hipGetLastError());
       h->grad_reverse_used = true;
@@ -2480,14 +2482,15 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   h->grad_drift_max = 0.0;
   h->grad_forward_reruns = 0;
   if (reverse) {
-    // the reverse sweep's certificate: problems whose reconstructed states drifted from the stored ones (only
-    // meaningful when states are reconstructed over more than one step) are redone by the forward-mode kernels
+    // the reverse sweep's certificates (one number per problem: the drift of its reconstructed states -- zero when
+    // every state is stored -- and the mismatch between the adjoint a sweep arrives at and the one predicted from the
+    // riders): problems beyond the tolerance are redone by the forward-mode kernels
     std::vector<int> mask(B, 0);
     int nre = 0;
     for (size_t b = 0; b < B; ++b) {
       if (stt[b] != CLR_OK || lvl[b] >= 2) continue;
       if (!(drift[b] <= h->grad_drift_max)) h->grad_drift_max = drift[b];
-      if (P.g_K > 1 && !(drift[b] <= h->grad_drift_tol)) { mask[b] = 1; ++nre; }
+      if (!(drift[b] <= h->grad_drift_tol)) { mask[b] = 1; ++nre; }
     }
     h->grad_forward_reruns = nre;
     if (nre) {
@@ -2548,7 +2551,9 @@ int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count) {
 }
 
 int clr_batch_set_grad_mode(clr_batch* h, int mode, int stored_state_distance, double drift_tolerance) {
-  if (mode < 0 || mode > 1 || stored_state_distance < 0) return fail(CLR_INVALID_ARGUMENT, "bad gradient mode");
+  if (mode < 0 || mode > 2 || stored_state_distance < 0) return fail(CLR_INVALID_ARGUMENT, "bad gradient mode");
+  h->grad_riders_mode = mode == 2 ? 1 : 0;  // (2: reverse mode with the riders along the trajectory, for A/B runs)
+  if (mode == 2) mode = 0;
   h->grad_mode = mode;
   h->grad_K = stored_state_distance;
   if (drift_tolerance > 0.0) h->grad_drift_tol = drift_tolerance;

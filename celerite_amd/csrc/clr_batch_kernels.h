@@ -82,6 +82,7 @@ struct BatchParams {
   double *g_rec, *g_ck, *g_ends, *g_adj, *g_part, *g_drift, *g_drift_max;
   long g_rec_stride, g_ck_stride;  // doubles per problem
   int g_K;
+  int g_from_elems;       // reverse mode, g_m == 1: riders from the scan's elements (grad_riders_elem_kernel)
   const int* g_mask;      // forward-mode kernels: only the problems with g_mask[b] != 0 (null: all)
   // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace
   const int* wK;     // [B] warm-up steps of problem b (wave-uniform per block); <= 0: the problem takes the scan
@@ -927,7 +928,12 @@ struct BatchImpl {
   static void grad_reverse(const BatchParams& P, hipStream_t s) {
     using Sh = GradShape<JR, JC>;
     const dim3 grid((P.g_nchunk + 63) / 64, P.B);
-    hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    if (P.g_from_elems) {  // (a gradient chunk is a scan chunk: riders from the scan's elements, record by the plain recurrence)
+      hipLaunchKernelGGL((grad_riders_elem_kernel<JR + 2 * JC>), grid, dim3(64), 0, s, P);
+      hipLaunchKernelGGL((grad_record_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    } else {
+      hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
+    }
     hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
     hipLaunchKernelGGL((grad_backward_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
     const long n = (long)P.B * Sh::NG;

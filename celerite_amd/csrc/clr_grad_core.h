@@ -302,21 +302,27 @@ CLR_HD void grad_chunk(const double* a_real, const double* c_real, const double*
 // (grad_backward_chunk) starts from.  The move after the LAST sample of the series is taken with dt = 0.
 // ck (may be null): the base state BEFORE local step i for i = K, 2K, ... -- checkpoint i / K - 1, element k at
 // ck[((i / K - 1) (SZ + J) + k) rstride] -- which bounds how far the reverse sweep reconstructs states.
-template <int JR, int JC, bool FAST, class Src>
+// RIDERS = false: only the record (the riders then come from the scan's element, grad_riders_from_element).
+template <int JR, int JC, bool FAST, class Src, bool RIDERS = true>
 CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* start,
                               double* out, double* rec = nullptr, long rstride = 0, double* end_out = nullptr,
                               double* ck = nullptr, int K = 0) {
   using Sh = GradShape<JR, JC>;
   constexpr int J = Sh::J, SZ = Sh::SZ;
-  double S[SZ], f[J], AA[J * J], eta[J], JJ[SZ];
+  double S[SZ], f[J], AA[RIDERS ? J * J : 1], eta[RIDERS ? J : 1], JJ[RIDERS ? SZ : 1];
   CLR_UNROLL
-  for (int i = 0; i < SZ; ++i) { S[i] = start ? start[i] : 0.0; JJ[i] = 0.0; }
+  for (int i = 0; i < SZ; ++i) S[i] = start ? start[i] : 0.0;
   CLR_UNROLL
-  for (int i = 0; i < J; ++i) { f[i] = start ? start[SZ + i] : 0.0; eta[i] = 0.0; }
-  CLR_UNROLL
-  for (int i = 0; i < J; ++i) {
+  for (int i = 0; i < J; ++i) f[i] = start ? start[SZ + i] : 0.0;
+  if (RIDERS) {
     CLR_UNROLL
-    for (int j = 0; j < J; ++j) AA[i * J + j] = i == j ? 1.0 : 0.0;
+    for (int i = 0; i < SZ; ++i) JJ[i] = 0.0;
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) {
+      eta[i] = 0.0;
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) AA[i * J + j] = i == j ? 1.0 : 0.0;
+    }
   }
   src.prologue();
   double tn = src.t(0);
@@ -368,28 +374,32 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
         store_stream(rec + ((long)i * (J + 2) + J + 1) * rstride, x);
       }
       double r[J];
-      CLR_UNROLL
-      for (int j = 0; j < J; ++j) {
-        double acc = 0.0;
+      if (RIDERS) {
         CLR_UNROLL
-        for (int k = 0; k < J; ++k) acc += AA[k * J + j] * u[k];
-        r[j] = acc;
-      }
-      const double xs = x * invD;
-      CLR_UNROLL
-      for (int j = 0; j < J; ++j) {
-        eta[j] = fma(r[j], xs, eta[j]);
-        const double rj = r[j] * invD;
+        for (int j = 0; j < J; ++j) {
+          double acc = 0.0;
+          CLR_UNROLL
+          for (int k = 0; k < J; ++k) acc += AA[k * J + j] * u[k];
+          r[j] = acc;
+        }
+        const double xs = x * invD;
         CLR_UNROLL
-        for (int k = 0; k <= j; ++k) JJ[tri(k, j)] = fma(r[k], rj, JJ[tri(k, j)]);
+        for (int j = 0; j < J; ++j) {
+          eta[j] = fma(r[j], xs, eta[j]);
+          const double rj = r[j] * invD;
+          CLR_UNROLL
+          for (int k = 0; k <= j; ++k) JJ[tri(k, j)] = fma(r[k], rj, JJ[tri(k, j)]);
+        }
       }
       double phid[nz(JR + JC)];
       features_phi_distinct<JR, JC>(p, n0 + i + 1 < N ? t_cur_next - tn : 0.0, phid);
       CLR_UNROLL
       for (int k = 0; k < J; ++k) {
         const double ph = phid[phi_index<JR>(k)];
-        CLR_UNROLL
-        for (int j = 0; j < J; ++j) AA[k * J + j] = ph * fma(-w[k], r[j], AA[k * J + j]);
+        if (RIDERS) {
+          CLR_UNROLL
+          for (int j = 0; j < J; ++j) AA[k * J + j] = ph * fma(-w[k], r[j], AA[k * J + j]);
+        }
         f[k] = ph * (f[k] + w[k] * x);
       }
       decay_rank1_update<JR, JC>(phid, z, w, S);
@@ -403,12 +413,123 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
     CLR_UNROLL
     for (int i = 0; i < J; ++i) end_out[SZ + i] = f[i];
   }
-  CLR_UNROLL
-  for (int i = 0; i < J * J; ++i) out[i] = AA[i];
-  CLR_UNROLL
-  for (int i = 0; i < J; ++i) out[J * J + i] = eta[i];
-  CLR_UNROLL
-  for (int i = 0; i < SZ; ++i) out[J * J + J + i] = JJ[i];
+  if (RIDERS) {
+    CLR_UNROLL
+    for (int i = 0; i < J * J; ++i) out[i] = AA[i];
+    CLR_UNROLL
+    for (int i = 0; i < J; ++i) out[J * J + i] = eta[i];
+    CLR_UNROLL
+    for (int i = 0; i < SZ; ++i) out[J * J + J + i] = JJ[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The same three riders from the scan's OWN element of the chunk (A, b, C, eta_e, Jm: summarize_chunk, clr_core.h)
+// and the chunk's start state (P, f) -- they are the derivatives of the element's maps at that state (chunk_update:
+// S_end = C + A G A^T, f_end = b + A g, log det += log det(I + P Jm), quad += 2 eta.f - f^T Jm f + w^T G w with
+// Mi = (I + P Jm)^-1, G = Mi P, g = Mi (f + P eta), w = Jm f - eta).  With dG = Mi dP Mi^T:
+//     AA = A Mi          eta = Mi^T (Jm f - eta_e)          JJ = -Jm Mi   (symmetric: Jm Mi = (I + Jm P)^-1 Jm)
+// One J x J Gauss-Jordan with partial pivoting per chunk instead of ~190 FMAs per SAMPLE.  The reverse sweep checks
+// the result: the adjoint it arrives at for the chunk's first sample must equal the one the walk over these riders
+// predicted (grad_backward_chunk: adj0_out).  start == nullptr: the zero state (Mi = I).
+// ---------------------------------------------------------------------------
+template <int J>
+CLR_HD void grad_riders_from_element(const double* elem, const double* start, double* out) {
+  constexpr int SZ = J * (J + 1) / 2;
+  const double* A = elem;
+  const double* eta_e = elem + J * J + J + SZ;
+  const double* Jm = eta_e + J;
+  double T[J][2 * J];  // [ I + P Jm | I ] -> [ I | Mi ]
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      double acc = (i == j) ? 1.0 : 0.0;
+      if (start) {
+        CLR_UNROLL_J
+        for (int k = 0; k < J; ++k) acc = fma(start[sym(i, k)], Jm[sym(k, j)], acc);
+      }
+      T[i][j] = acc;
+      T[i][J + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  CLR_UNROLL_J
+  for (int col = 0; col < J; ++col) {
+    int piv = col;
+    double best = fabs(T[col][col]);
+    CLR_UNROLL_J
+    for (int i = col + 1; i < J; ++i) {
+      const double cand = fabs(T[i][col]);
+      const bool take = cand > best;
+      best = take ? cand : best;
+      piv = take ? i : piv;
+    }
+    CLR_UNROLL_J
+    for (int c = col; c < 2 * J; ++c) {
+      double top = T[col][c];
+      const double old_top = top;
+      CLR_UNROLL_J
+      for (int i = col + 1; i < J; ++i) {
+        const bool hit = (i == piv);
+        top = hit ? T[i][c] : top;
+        T[i][c] = hit ? old_top : T[i][c];
+      }
+      T[col][c] = top;
+    }
+    const double inv = 1.0 / T[col][col];
+    CLR_UNROLL_J
+    for (int c = col + 1; c < 2 * J; ++c) T[col][c] *= inv;
+    CLR_UNROLL_J
+    for (int i = 0; i < J; ++i) {
+      if (i == col) continue;
+      const double m = T[i][col];
+      CLR_UNROLL_J
+      for (int c = col + 1; c < 2 * J; ++c) T[i][c] -= m * T[col][c];
+    }
+  }
+  // AA = A Mi
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    CLR_UNROLL_J
+    for (int j = 0; j < J; ++j) {
+      double acc = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) acc = fma(A[i * J + k], T[k][J + j], acc);
+      out[i * J + j] = acc;
+    }
+  }
+  // eta = Mi^T (Jm f - eta_e)
+  double wv[J];
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    double acc = -eta_e[i];
+    if (start) {
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) acc = fma(Jm[sym(i, k)], start[SZ + k], acc);
+    }
+    wv[i] = acc;
+  }
+  CLR_UNROLL_J
+  for (int i = 0; i < J; ++i) {
+    double acc = 0.0;
+    CLR_UNROLL_J
+    for (int k = 0; k < J; ++k) acc = fma(T[k][J + i], wv[k], acc);
+    out[J * J + i] = acc;
+  }
+  // JJ = -sym(Jm Mi)
+  CLR_UNROLL_J
+  for (int j = 0; j < J; ++j) {
+    CLR_UNROLL_J
+    for (int i = 0; i <= j; ++i) {
+      double a1 = 0.0, a2 = 0.0;
+      CLR_UNROLL_J
+      for (int k = 0; k < J; ++k) {
+        a1 = fma(Jm[sym(i, k)], T[k][J + j], a1);
+        a2 = fma(Jm[sym(j, k)], T[k][J + i], a2);
+      }
+      out[J * J + J + tri(i, j)] = -0.5 * (a1 + a2);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -658,21 +779,24 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
       CLR_UNROLL
       for (int k = 0; k < SZ; ++k) {
         const double e = o ? o[(long)k * os] : 0.0;
+        const double d = fabs(e - S[k]);
         big = fmax(big, fabs(e));
-        dev = fmax(dev, fabs(e - S[k]));
+        if (!(d <= dev)) dev = d;  // (a NaN in the reconstruction sticks: fmax would drop it)
         S[k] = e;
       }
       double bigf = 0.0, devf = 0.0;
       CLR_UNROLL
       for (int k = 0; k < J; ++k) {
         const double e = o ? o[(long)(SZ + k) * os] : 0.0;
+        const double d = fabs(e - f[k]);
         bigf = fmax(bigf, fabs(e));
-        devf = fmax(devf, fabs(e - f[k]));
+        if (!(d <= devf)) devf = d;
         f[k] = e;
       }
       if (o) {  // (the zero state of the first chunk: an absolute deviation has no scale to compare with)
         double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
-        if (bigf > 0.0) r = fmax(r, devf / bigf);
+        const double rf = bigf > 0.0 ? devf / bigf : 0.0;
+        if (!(rf <= r)) r = rf;
         if (!(r <= drift)) drift = r;  // (NaN counts)
       }
     }

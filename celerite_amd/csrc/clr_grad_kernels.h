@@ -56,6 +56,43 @@ __global__ void __launch_bounds__(64) grad_riders_kernel(const BatchParams P) {
                                   P.g_rec ? P.g_ck + b * P.g_ck_stride + c : nullptr, P.g_K);
 }
 
+// Reverse mode when a gradient chunk is a scan chunk: the riders from the scan's own elements (one Gauss-Jordan per
+// chunk, grad_riders_from_element) and the record by the plain recurrence (grad_riders_chunk without its riders).
+template <int J>
+__global__ void __launch_bounds__(64) grad_riders_elem_kernel(const BatchParams P) {
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
+  const int b = blockIdx.y;
+  if (P.need_exact[b] >= 2) return;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= P.nchunk) return;
+  const long slot = (long)b * P.nchunk + c;
+  double* out = P.g_riders + slot * RID;
+  grad_riders_from_element<J>(P.elems + slot * ELEM, c > 0 ? P.starts + slot * START : nullptr, out);
+  if (c == P.nchunk - 1) {
+    // the last chunk's A is never used by the scan and may hold anything behind the end of the series (padding);
+    // its AA only ever multiplies the zero adjoint at the end of the series
+#pragma unroll
+    for (int i = 0; i < J * J; ++i) out[i] = 0.0;
+  }
+}
+
+template <int JR, int JC, bool FAST>
+__global__ void __launch_bounds__(64) grad_record_kernel(const BatchParams P) {
+  using Wd = Widths<JR, JC>;
+  const int b = blockIdx.y;
+  if (P.need_exact[b] >= 2) return;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= P.g_nchunk) return;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  DirectSeries src = grad_series(P, b, c);
+  const long slot = (long)b * P.g_nchunk + c;
+  grad_riders_chunk<JR, JC, FAST, DirectSeries, false>(
+      p, src, P.g_m * P.L, P.N, c * P.g_m * P.L,
+      c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr, nullptr,
+      P.g_rec + b * P.g_rec_stride + c, P.g_nchunk, P.g_ends + slot * Wd::START, P.g_ck + b * P.g_ck_stride + c, P.g_K);
+}
+
 template <int JR, int JC, bool FAST>
 __global__ void __launch_bounds__(64) grad_tangent_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
@@ -167,12 +204,28 @@ __global__ void __launch_bounds__(64) grad_backward_kernel(const BatchParams P) 
   load_problem<JR, JC>(P, b, p);
   DirectSeries src = grad_series(P, b, c);
   const long slot = (long)b * P.g_nchunk + c;
-  double drift = 0.0;
+  double drift = 0.0, adj0[Wd::START];
   grad_backward_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L, P.g_ends + slot * Wd::START,
                                     P.g_adj + slot * Wd::START, P.g_rec + b * P.g_rec_stride + c, P.g_nchunk,
-                                    P.g_part + slot * Sh::NG, nullptr, P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
+                                    P.g_part + slot * Sh::NG, adj0, P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
                                     c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr);
-  P.g_drift[slot] = P.g_K > 1 ? drift : 0.0;  // (K = 1: every state is a stored one, no reconstructed state is used)
+  if (!(P.g_K > 1)) drift = 0.0;  // (K = 1: every state is a stored one, no reconstructed state is used)
+  if (c > 0) {
+    // second certificate: the adjoint this sweep arrives at for the chunk's first sample against the one the walk
+    // over the riders predicted for the end of the previous chunk (two independent computations of one quantity;
+    // it is what vouches for riders taken from the scan's elements)
+    const double* want = P.g_adj + (slot - 1) * Wd::START;
+    double big = 0.0, dev = 0.0;
+#pragma unroll
+    for (int i = 0; i < Wd::START; ++i) {
+      const double a = fabs(want[i]), d = fabs(want[i] - adj0[i]);
+      if (!(a <= big)) big = a;   // (NaN sticks: fmax would drop it)
+      if (!(d <= dev)) dev = d;
+    }
+    const double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
+    if (!(r <= drift)) drift = r;
+  }
+  P.g_drift[slot] = drift;
 }
 
 // thread = (problem, direction): -1/2 of the sum over the chunks; direction 0 also reduces the drift

@@ -434,7 +434,11 @@ int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
  * reconstructs the states between the stored ones; the drift it measures at every stored state certifies them, and a
  * problem that drifts beyond `drift_tolerance` (default 1e-9; <= 0 keeps the current one) is redone in mode 1.
  * mode 1: FORWARD mode, one tangent per partial (the description above).  stored_state_distance: K in steps, 0 = from
- * the series and coefficients (2 c_max K dt_max <= log 1e4). */
+ * the series and coefficients (2 c_max K dt_max <= log 1e4).
+ * In reverse mode the three riders of a chunk come from the scan's own element of that chunk (one J x J solve per chunk
+ * instead of ~190 FMAs per sample) whenever a gradient chunk is a scan chunk; the sweep's second certificate -- the
+ * adjoint it arrives at for the chunk's first sample against the one predicted from the riders -- vouches for them.
+ * mode 2 = reverse mode with the riders accumulated along the trajectory (A/B runs). */
 int clr_batch_set_grad_mode(clr_batch* h, int mode, int stored_state_distance, double drift_tolerance);
 /* Of the last clr_batch_grad: whether the reverse sweep ran, how many problems were redone in forward mode, the
  * largest drift among the problems the reverse sweep settled. */

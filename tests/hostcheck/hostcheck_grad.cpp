@@ -131,6 +131,62 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
   return bad;
 }
 
+// Riders of every chunk two ways: along the base trajectory (grad_riders_chunk) and from the scan's element of the
+// chunk + its start state (summarize_chunk -> grad_riders_from_element).  Returns the largest difference relative to
+// the largest entry of each of AA, eta, JJ over the chunks.
+template <int JR, int JC>
+static int run_riders_check(int N, int nchunk, double jitter, const double* a_real, const double* c_real,
+                            const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
+                            const double* t, const double* diag, const double* y, double* worst /* [3] */) {
+  using Wd = Widths<JR, JC>;
+  using Sh = GradShape<JR, JC>;
+  constexpr int J = Wd::J;
+  const int L = (N + nchunk - 1) / nchunk;
+  nchunk = (N + L - 1) / L;
+  Problem<JR, JC> p;
+  p.load(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter);
+  std::vector<double> start(Wd::START, 0.0);
+  worst[0] = worst[1] = worst[2] = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const long first = (long)c * L;
+    const double* st = c ? start.data() : nullptr;
+    double direct[Sh::RID], fromel[Sh::RID], elem[Wd::ELEM], ld0, q0, en[Wd::START];
+    int fl;
+    {
+      DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+      grad_riders_chunk<JR, JC, true>(p, src, L, N, (int)first, st, direct);
+    }
+    {
+      DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+      summarize_chunk<JR, JC, true>(p, src, L, (int)first, N, true, elem, &ld0, &q0, &fl);
+    }
+    grad_riders_from_element<J>(elem, st, fromel);
+    const int lo[4] = {0, J * J, J * J + J, Sh::RID};
+    for (int part = 0; part < 3; ++part) {
+      if (part == 0 && c == nchunk - 1) continue;  // (AA of the last chunk is never used)
+      double big = 0.0, dev = 0.0;
+      for (int i = lo[part]; i < lo[part + 1]; ++i) { big = std::fmax(big, std::fabs(direct[i])); dev = std::fmax(dev, std::fabs(direct[i] - fromel[i])); }
+      if (big > 0.0) worst[part] = std::fmax(worst[part], dev / big);
+    }
+    {
+      DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
+      double l, q;
+      replay_chunk<JR, JC, 0, true>(p, src, L, N, (int)first, st, &l, &q, &fl, nullptr, nullptr, nullptr, nullptr, 0, en);
+      memcpy(start.data(), en, sizeof(en));
+    }
+  }
+  return 0;
+}
+
+extern "C" int hostcheck_riders(int N, int JR, int JC, int nchunk, double jitter, const double* a_real,
+                                const double* c_real, const double* a_comp, const double* b_comp, const double* c_comp,
+                                const double* d_comp, const double* t, const double* diag, const double* y, double* worst) {
+#define GCASE(R, C) if (JR == R && JC == C) return run_riders_check<R, C>(N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, worst);
+  GCASE(1, 0) GCASE(2, 0) GCASE(0, 1) GCASE(1, 1) GCASE(2, 1) GCASE(0, 2) GCASE(2, 3) GCASE(3, 2) GCASE(8, 0) GCASE(0, 4)
+#undef GCASE
+  return -1;
+}
+
 extern "C" int hostcheck_grad_reverse(int N, int JR, int JC, int nchunk, double jitter, const double* a_real,
                                       const double* c_real, const double* a_comp, const double* b_comp,
                                       const double* c_comp, const double* d_comp, const double* t, const double* diag,

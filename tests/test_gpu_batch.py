@@ -845,10 +845,11 @@ def test_batched_grad_log_likelihood(JR, JC, N, shared):
 
 @pytest.mark.parametrize("JR,JC", [(2, 3), (1, 1), (0, 2), (3, 0), (1, 0), (0, 4), (4, 2)])
 @pytest.mark.parametrize("family", ["bench", "accuracy"])
-@pytest.mark.parametrize("mode", ["reverse", "forward"])
+@pytest.mark.parametrize("mode", ["reverse", "reverse-direct-riders", "forward"])
 def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
-    """clr_batch_grad (csrc/clr_grad_core.h): the gradient parallel in n -- reverse mode (riders + per-sample record,
-    adjoint walk over the chunks, one reverse sweep per chunk for all partials) and forward mode (tangents per
+    """clr_batch_grad (csrc/clr_grad_core.h): the gradient parallel in n -- reverse mode (riders from the scan's
+    elements or accumulated along the trajectory, per-sample record, adjoint walk over the chunks, one reverse sweep
+    per chunk for all partials) and forward mode (tangents per
     (chunk, direction) from the scanned start states + the walk over the chunks) -- against the sequential tangent
     kernel (one wave per partial, csrc/grad_kernels.hip; itself pinned against oracle/grad.py) at several chunk
     counts, and against the oracle directly on one problem.  An indefinite problem in the batch keeps the quiet
@@ -872,7 +873,7 @@ def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
             plan.set_chunks(nchunk)
             v, g, st = plan.grad_log_likelihood()
             info = plan.grad_info()
-            assert info["reverse"] == (mode == "reverse") and info["forward_reruns"] == 0, info
+            assert info["reverse"] == (mode != "forward") and info["forward_reruns"] == 0, info
             assert np.array_equal(st, st_seq) and st[3] == 2 and np.isneginf(v[3]) and not g[3].any()
             ok = st == 0
             assert np.max(np.abs(v[ok] - v_seq[ok]) / np.abs(v_seq[ok])) <= 1e-11, nchunk

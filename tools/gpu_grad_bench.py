@@ -22,7 +22,7 @@ for name, maker in (("bench family", make_inputs), ("accuracy family", make_inpu
     plan = batch.BatchedGP(B, N, 2, 3)
     plan.set_series(t, diag, y); plan.set_coefficients(*coeffs)
     res = {}
-    for mode in ("forward", "reverse"):
+    for mode in ("forward", "reverse-direct-riders", "reverse"):
         plan.set_grad_mode(mode)
         v, g, st = plan.grad_log_likelihood()
         batch.device_synchronize()
