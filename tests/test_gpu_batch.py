@@ -930,6 +930,49 @@ def test_plan_gradient_full_size_against_the_oracle_fixture(mode):
         assert (np.abs(g1 - g0) <= tol).all(), np.abs(g1 - g0) / np.abs(g0)
 
 
+@pytest.mark.parametrize("JR,JC", [(2, 3), (1, 1), (0, 2), (4, 0)])
+def test_plan_gradient_on_the_adversarial_family(JR, JC):
+    """Near-singular and indefinite problems (tests/_cases.py: adversarial): statuses as the sequential tangent kernel
+    reports them; problems the scan hands to the sequential recurrence (level 2: their scanned start states are not
+    certified) take the sequential tangent kernel and are bit-identical to it; problems settled by the scan agree
+    with it within the conditioning they have (both sides evaluate the same ill-conditioned recurrence in a different
+    order: 1e-6 of the largest partial covers gamma up to ~1e9, the measured worst is printed by -s)."""
+    worst, nfb, nre = 0.0, 0, 0
+    for trial in range(10):
+        B, N = 6, 3000
+        case = adversarial(B, N, JR, JC, seed=4000 + trial)
+        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        try:
+            v0, g0, st0 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"])
+        finally:
+            del os.environ["CLR_GRAD_SEQUENTIAL"]
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            v, g, st = plan.grad_log_likelihood()
+            levels = plan.exact_levels()
+            fb, info = plan.grad_fallbacks(), plan.grad_info()
+        finally:
+            plan.close()
+        assert np.array_equal(st, st0), (trial, st, st0)
+        ok = st == 0
+        assert fb == int((ok & (levels >= 2)).sum()), (trial, fb, levels, st)
+        nfb += fb
+        nre += info["forward_reruns"]
+        for b in np.nonzero(ok)[0]:
+            if levels[b] >= 2:
+                assert np.array_equal(g[b], g0[b]) or np.allclose(g[b], g0[b], rtol=1e-13, atol=0.0), (trial, b)
+            else:
+                scale = np.max(np.abs(g0[b]))
+                err = np.max(np.abs(g[b] - g0[b])) / scale
+                worst = max(worst, err)
+                assert err <= 1e-6, (trial, b, err, levels[b])
+                assert abs(v[b] - v0[b]) <= 1e-8 * abs(v0[b]), (trial, b)
+    print("adversarial gradient: worst %.2e of the largest partial among scan-settled problems; %d sequential "
+          "fallbacks, %d forward-mode reruns" % (worst, nfb, nre))
+
+
 def test_reverse_gradient_certifies_its_reconstructed_states():
     """The reverse sweep rebuilds the states between the stored ones by inverting the recurrence, which amplifies
     rounding errors like exp(2 c T) (csrc/clr_grad_core.h).  With the stored states at the distance the host derives
