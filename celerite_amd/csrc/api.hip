@@ -2434,7 +2434,7 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
     P.g_K = (int)K;
     P.g_rec_stride = Lg * (long)(J + 2) * P.g_nchunk;
     P.g_ck_stride = nck * (long)(SZ + J) * P.g_nchunk;
-    const size_t small = pc * (RID + 2 * (SZ + J) + NG + 1) + B;
+    const size_t small = pc * (RID + 3 * (SZ + J) + NG + 1) + B;
     if (h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK || h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK ||
         h->g_riders.reserve(small) != CLR_OK) {
       h->g_rec.release(); h->g_ck.release();
@@ -2445,7 +2445,8 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       P.g_riders = h->g_riders.p;
       P.g_ends = P.g_riders + pc * RID;
       P.g_adj = P.g_ends + pc * (SZ + J);
-      P.g_part = P.g_adj + pc * (SZ + J);
+      P.g_adj0 = P.g_adj + pc * (SZ + J);
+      P.g_part = P.g_adj0 + pc * (SZ + J);
       P.g_drift = P.g_part + pc * NG;
       P.g_drift_max = P.g_drift + pc;
       P.g_from_elems = (P.g_m == 1 && h->grad_riders_mode != 1) ? 1 : 0;

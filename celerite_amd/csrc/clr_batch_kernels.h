@@ -79,7 +79,7 @@ struct BatchParams {
   int g_m, g_nchunk;      // a gradient chunk = g_m chunks of the scan; g_nchunk = ceil(nchunk / g_m)
   // reverse mode: per-sample record w, D, x [B][step][J + 2][chunk], stored states every g_K steps
   // [B][checkpoint][SZ + J][chunk], state after / adjoint at the end of every chunk, per-chunk partials and drift
-  double *g_rec, *g_ck, *g_ends, *g_adj, *g_part, *g_drift, *g_drift_max;
+  double *g_rec, *g_ck, *g_ends, *g_adj, *g_adj0, *g_part, *g_drift, *g_drift_max;
   long g_rec_stride, g_ck_stride;  // doubles per problem
   int g_K;
   int g_from_elems;       // reverse mode, g_m == 1: riders from the scan's elements (grad_riders_elem_kernel)
@@ -936,8 +936,7 @@ struct BatchImpl {
     }
     hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
     hipLaunchKernelGGL((grad_backward_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
-    const long n = (long)P.B * Sh::NG;
-    hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, Sh::NG);
+    hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P, Sh::NG);
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,

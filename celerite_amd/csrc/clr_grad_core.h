@@ -779,25 +779,22 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
       CLR_UNROLL
       for (int k = 0; k < SZ; ++k) {
         const double e = o ? o[(long)k * os] : 0.0;
-        const double d = fabs(e - S[k]);
         big = fmax(big, fabs(e));
-        if (!(d <= dev)) dev = d;  // (a NaN in the reconstruction sticks: fmax would drop it)
+        dev = fmax(dev, fabs(e - S[k]));  // (fmax drops a NaN; a NaN reconstruction shows in the partials instead)
         S[k] = e;
       }
       double bigf = 0.0, devf = 0.0;
       CLR_UNROLL
       for (int k = 0; k < J; ++k) {
         const double e = o ? o[(long)(SZ + k) * os] : 0.0;
-        const double d = fabs(e - f[k]);
         bigf = fmax(bigf, fabs(e));
-        if (!(d <= devf)) devf = d;
+        devf = fmax(devf, fabs(e - f[k]));
         f[k] = e;
       }
       if (o) {  // (the zero state of the first chunk: an absolute deviation has no scale to compare with)
         double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
-        const double rf = bigf > 0.0 ? devf / bigf : 0.0;
-        if (!(rf <= r)) r = rf;
-        if (!(r <= drift)) drift = r;  // (NaN counts)
+        if (bigf > 0.0) r = fmax(r, devf / bigf);
+        if (!(r <= drift)) drift = r;
       }
     }
     // adjoints of the step

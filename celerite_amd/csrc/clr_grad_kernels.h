@@ -204,50 +204,60 @@ __global__ void __launch_bounds__(64) grad_backward_kernel(const BatchParams P) 
   load_problem<JR, JC>(P, b, p);
   DirectSeries src = grad_series(P, b, c);
   const long slot = (long)b * P.g_nchunk + c;
-  double drift = 0.0, adj0[Wd::START];
+  double drift = 0.0;
   grad_backward_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L, P.g_ends + slot * Wd::START,
                                     P.g_adj + slot * Wd::START, P.g_rec + b * P.g_rec_stride + c, P.g_nchunk,
-                                    P.g_part + slot * Sh::NG, adj0, P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
+                                    P.g_part + slot * Sh::NG, P.g_adj0 + slot * Wd::START,
+                                    P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
                                     c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr);
   if (!(P.g_K > 1)) drift = 0.0;  // (K = 1: every state is a stored one, no reconstructed state is used)
-  if (c > 0) {
-    // second certificate: the adjoint this sweep arrives at for the chunk's first sample against the one the walk
-    // over the riders predicted for the end of the previous chunk (two independent computations of one quantity;
-    // it is what vouches for riders taken from the scan's elements)
-    const double* want = P.g_adj + (slot - 1) * Wd::START;
-    double big = 0.0, dev = 0.0;
-#pragma unroll
-    for (int i = 0; i < Wd::START; ++i) {
-      const double a = fabs(want[i]), d = fabs(want[i] - adj0[i]);
-      if (!(a <= big)) big = a;   // (NaN sticks: fmax would drop it)
-      if (!(d <= dev)) dev = d;
-    }
-    const double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
-    if (!(r <= drift)) drift = r;
-  }
   P.g_drift[slot] = drift;
 }
 
-// thread = (problem, direction): -1/2 of the sum over the chunks; direction 0 also reduces the drift
-// (a template only so that every width's translation unit owns its instantiation)
+// One wave per problem.  Lane q < NG: -1/2 of the sum over the chunks of partial q (in chunk order).  All lanes,
+// striding over the chunks: the two certificates of the reverse sweep reduced to one number per problem --
+//   * the drift of the reconstructed states (g_drift, zero when every state is stored), and
+//   * the adjoint a sweep arrived at for its chunk's first sample (g_adj0) against the one the walk over the riders
+//     predicted for the end of the previous chunk (g_adj): two independent computations of one quantity -- it is what
+//     vouches for riders taken from the scan's elements;
+// a non-finite partial or a NaN anywhere is a failed certificate (reported as +inf).
 template <int J>
 __global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, int NG) {
-  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-  if (idx >= (long)P.B * NG) return;
-  const int b = (int)(idx / NG), q = (int)(idx % NG);
+  constexpr int ADJ = J * (J + 1) / 2 + J;
+  const int b = blockIdx.x, l = threadIdx.x;
   if (P.need_exact[b] >= 2) return;
-  const double* part = P.g_part + (long)b * P.g_nchunk * NG + q;
-  double acc = 0.0;
-  for (int c = 0; c < P.g_nchunk; ++c) acc += part[(long)c * NG];
-  P.g_res[idx] = -0.5 * acc;
-  if (q == 0) {
-    double worst = 0.0;
-    for (int c = 0; c < P.g_nchunk; ++c) {
-      const double d = P.g_drift[(long)b * P.g_nchunk + c];
-      if (!(d <= worst)) worst = d;
-    }
-    P.g_drift_max[b] = worst;
+  const int ng = P.g_nchunk;
+  for (int q = l; q < NG; q += 64) {
+    const double* part = P.g_part + (long)b * ng * NG + q;
+    double acc = 0.0;
+    for (int c = 0; c < ng; ++c) acc += part[(long)c * NG];
+    P.g_res[(long)b * NG + q] = -0.5 * acc;
   }
+  double worst = 0.0;
+  bool bad = false;
+  for (int c = l; c < ng; c += 64) {
+    const long slot = (long)b * ng + c;
+    const double d = P.g_drift[slot];
+    if (d != d) bad = true;
+    worst = fmax(worst, d);
+    for (int k = 0; k < NG; ++k)
+      if (!(fabs(P.g_part[slot * NG + k]) <= 1.79e308)) bad = true;
+    if (c > 0) {
+      const double *want = P.g_adj + (slot - 1) * ADJ, *got = P.g_adj0 + slot * ADJ;
+      double big = 0.0, dev = 0.0;
+      for (int i = 0; i < ADJ; ++i) {
+        const double a = fabs(want[i]), e = fabs(want[i] - got[i]);
+        if (a != a || e != e) bad = true;
+        big = fmax(big, a);
+        dev = fmax(dev, e);
+      }
+      worst = fmax(worst, big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY));
+    }
+  }
+  if (bad) worst = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
+  if (l == 0) P.g_drift_max[b] = worst;
 }
 
 }  // namespace clr
