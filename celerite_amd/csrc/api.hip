@@ -358,7 +358,12 @@ struct clr_batch {
   clr::PrefixPlan plan;
   DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
   DevBuf g_riders, g_out, g_res;      // chunk-parallel gradient (clr_grad_kernels.h): riders, records, result (+ fallback)
-  DevBuf g_rec, g_ck;                 // reverse mode: w, D, x per sample; the state every grad K steps
+  DevBuf g_rec, g_ck;                 // reverse mode: w, D, x per sample; stored states (GradStore, clr_grad_core.h)
+  unsigned char* g_ckflag = nullptr;  // what the forward pass did before each step, per wave of 64 chunks
+  size_t g_ckflag_cap = 0;
+  std::vector<double> host_cmax;      // per problem: largest decay rate (sizes the stored states)
+  std::vector<double> grad_span;      // per problem (one entry when the series is shared): longest time a scan chunk spans
+  bool grad_span_valid = false;
   int grad_mode = 0;                  // clr_batch_set_grad_mode: 0 auto (reverse), 1 forward (one tangent per partial)
   int grad_K = 0;                     // > 0: distance of the stored states (steps), else from c_max dt_max
   int grad_riders_mode = 0;           // 0 auto (from the scan's elements when a gradient chunk is a scan chunk), 1 along the trajectory
@@ -1372,6 +1377,7 @@ void clr_batch_destroy(clr_batch* h) {
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
+  if (h->g_ckflag) (void)hipFree(h->g_ckflag);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1410,6 +1416,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->relayout_pending = true;
+  h->grad_span_valid = false;
   h->have_factor = false;  // its layout depends on the chunking
   const size_t pc = (size_t)h->B * h->nchunk;
   h->plan = clr::plan_prefix(h->nchunk, 0, 0);
@@ -1543,6 +1550,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->diag_stride = diag_stride;
   h->y_stride = y_stride;
   h->have_series = true;
+  h->grad_span_valid = false;
   h->relayout_pending = true;
   h->warm_copy_pending = true;
   return CLR_OK;
@@ -1596,6 +1604,13 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   for (size_t i = 0; i < nr; ++i) {
     const double c = fabs(c_real[i]);
     if (!(c <= h->cmax)) h->cmax = c;
+  }
+  h->host_cmax.assign(B, 0.0);
+  for (size_t b = 0; b < B; ++b) {
+    double m = 0.0;
+    for (int j = 0; j < h->J_real; ++j) m = std::max(m, fabs(c_real[b * h->J_real + j]));
+    for (int j = 0; j < h->J_comp; ++j) m = std::max(m, fabs(c_comp[b * h->J_comp + j]));
+    h->host_cmax[b] = m;
   }
   // warm-started recurrence: warm-up steps per problem from its slowest decay rate and the time the samples in front
   // of its chunk boundaries span: exp(-c_min x span) <= exp(-32) = 1.3e-14 -- what is left of ANY start state after
@@ -2362,6 +2377,42 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double*
   return CLR_OK;
 }
 
+// time spanned by every scan chunk (its samples and the move to the next chunk's first sample), one thread per chunk
+__global__ void chunk_span_kernel(const double* t, long t_stride, int N, int L, int nchunk, int nsrc, double* out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)nsrc * nchunk) return;
+  const long b = idx / nchunk, c = idx % nchunk;
+  const long first = c * (long)L, last = std::min<long>((c + 1) * (long)L, N - 1);
+  out[idx] = first < N ? t[b * t_stride + last] - t[b * t_stride + first] : 0.0;
+}
+
+// per problem (one entry for a shared series): the longest time any scan chunk spans; cached until the series or the
+// chunking changes
+static int grad_chunk_spans(clr_batch* h) {
+  if (h->grad_span_valid) return CLR_OK;
+  const int nsrc = h->t_stride == 0 ? 1 : h->B;
+  const size_t n = (size_t)nsrc * h->nchunk;
+  DevBuf tmp;
+  int st = tmp.reserve(n);
+  if (st != CLR_OK) return st;
+  hipLaunchKernelGGL(chunk_span_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->t.p, h->t_stride,
+                     h->N, h->L, h->nchunk, nsrc, tmp.p);
+  std::vector<double> spans(n);
+  const bool ok = hipGetLastError() == hipSuccess &&
+                  hipMemcpyAsync(spans.data(), tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                  hipStreamSynchronize(h->stream) == hipSuccess;
+  tmp.release();
+  if (!ok) return fail(CLR_HIP_ERROR, "chunk span kernel failed");
+  h->grad_span.assign(nsrc, 0.0);
+  for (int b = 0; b < nsrc; ++b)
+    for (int c = 0; c < h->nchunk; ++c) {
+      const double v = spans[(size_t)b * h->nchunk + c];
+      if (!(v <= h->grad_span[b])) h->grad_span[b] = v;  // (NaN sticks: as many slots as steps)
+    }
+  h->grad_span_valid = true;
+  return CLR_OK;
+}
+
 // Value and gradient of every problem of the plan at the coefficients in force, parallel in n (clr_grad_core.h):
 // the evaluation by the scan, then per chunk the riders and the tangents of every direction group from the scanned
 // start states, then the walk over the chunks.  Problems the scan routed to the sequential recurrence take the
@@ -2424,17 +2475,39 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   if (reverse) {
     const size_t pc = set_chunks(choose_m(true));
     const long Lg = (long)P.g_m * h->L;
-    // stored states every K steps: reconstruction errors grow like exp(2 c T) (clr_grad_core.h); K from a growth
-    // budget of 1e4 per stretch.  The drift the sweep measures at every stored state certifies the choice.
-    const double cdx = sel_max(h->cmax, h->floor_cmax) * sel_max(h->dxmax, h->floor_dxmax);
-    long K = cdx > 0.0 && cdx == cdx ? (long)std::floor(4.6 / cdx) : Lg;
-    if (h->grad_K > 0) K = h->grad_K;
-    K = std::max<long>(1, std::min<long>(K, Lg));
-    const long nck = (Lg + K - 1) / K;
-    P.g_K = (int)K;
+    // stored states (GradStore, clr_grad_core.h): every grad_K steps when forced, else wherever the decay accumulated
+    // since the last one reaches the growth budget -- sized from the problems' largest decay rates and the longest
+    // time a chunk spans, with a factor 2 for the wave-wide trigger (a chunk that runs out of slots fails its
+    // certificate and is redone in forward mode)
+    long nalloc;
+    if (h->grad_K > 0) {
+      P.g_K = (int)std::min<long>(h->grad_K, Lg);
+      nalloc = (Lg + P.g_K - 1) / P.g_K;
+    } else {
+      P.g_K = 0;
+      if ((st = grad_chunk_spans(h)) != CLR_OK) return st;
+      double need = 0.0;
+      for (size_t b = 0; b < B; ++b) {
+        const double v = h->host_cmax[b] * h->grad_span[h->t_stride == 0 ? 0 : b] * P.g_m / CLR_GRAD_GROWTH_BUDGET;
+        if (!(v <= need)) need = v;
+      }
+      nalloc = (need == need && need < (double)Lg) ? (long)(2.0 * std::ceil(need)) + 8 : Lg;
+      nalloc = std::min<long>(nalloc, Lg);
+    }
+    P.g_nalloc = (int)nalloc;
     P.g_rec_stride = Lg * (long)(J + 2) * P.g_nchunk;
-    P.g_ck_stride = nck * (long)(SZ + J) * P.g_nchunk;
-    const size_t small = pc * (RID + 3 * (SZ + J) + NG + 1) + B;
+    P.g_ck_stride = nalloc * (long)(SZ + J) * P.g_nchunk;
+    const size_t nflag = B * (size_t)((P.g_nchunk + 63) / 64) * (size_t)Lg;
+    if (nflag > h->g_ckflag_cap) {
+      if (h->g_ckflag) (void)hipFree(h->g_ckflag);
+      h->g_ckflag = nullptr;
+      h->g_ckflag_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_ckflag), nflag));
+      h->g_ckflag_cap = nflag;
+    }
+    HIP_TRY(hipMemsetAsync(h->g_ckflag, 0, nflag, h->stream));
+    P.g_ckflag = h->g_ckflag;
+    const size_t small = pc * (RID + 3 * (SZ + J) + NG + 2) + B;
     if (h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK || h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK ||
         h->g_riders.reserve(small) != CLR_OK) {
       h->g_rec.release(); h->g_ck.release();
@@ -2448,7 +2521,8 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       P.g_adj0 = P.g_adj + pc * (SZ + J);
       P.g_part = P.g_adj0 + pc * (SZ + J);
       P.g_drift = P.g_part + pc * NG;
-      P.g_drift_max = P.g_drift + pc;
+      P.g_count = P.g_drift + pc;
+      P.g_drift_max = P.g_count + pc;
       P.g_from_elems = (P.g_m == 1 && h->grad_riders_mode != 1) ? 1 : 0;
       h->launch->grad_reverse(P, h->stream);
       HIP_TRY(hipGetLastError());

@@ -81,7 +81,10 @@ struct BatchParams {
   // [B][checkpoint][SZ + J][chunk], state after / adjoint at the end of every chunk, per-chunk partials and drift
   double *g_rec, *g_ck, *g_ends, *g_adj, *g_adj0, *g_part, *g_drift, *g_drift_max;
   long g_rec_stride, g_ck_stride;  // doubles per problem
-  int g_K;
+  int g_K;                // stored states: every g_K steps (> 0), or where the accumulated decay asks for one (0: GradStore)
+  int g_nalloc;           // slots per chunk in g_ck
+  unsigned char* g_ckflag;  // [B][waves of 64 chunks][steps]: what the forward pass did before each step (GradStore)
+  double* g_count;        // [B][g_nchunk]: slots each chunk used
   int g_from_elems;       // reverse mode, g_m == 1: riders from the scan's elements (grad_riders_elem_kernel)
   const int* g_mask;      // forward-mode kernels: only the problems with g_mask[b] != 0 (null: all)
   // warm-started plain recurrence (warm_kernel; series that forget their past): its own chunking and workspace

@@ -42,6 +42,44 @@ struct GradShape {
   static constexpr int RID = J * J + J + SZ;       // per chunk: AA[J][J] eta[J] JJ[SZ]
 };
 
+// Wave-level "some lane wants" / "this lane is the first active one" (host: the single lane itself).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CLR_WAVE_ANY(cond) (__any(cond) != 0)
+#define CLR_FIRST_ACTIVE_LANE() ((int)threadIdx.x == __ffsll((unsigned long long)__ballot(1)) - 1)
+#else
+#define CLR_WAVE_ANY(cond) (cond)
+#define CLR_FIRST_ACTIVE_LANE() (true)
+#endif
+
+// Where the reverse mode's forward pass stores base states for the sweep to continue from (clr_grad_core.h, second
+// half).  Slots are handed out in step order, the same for all lanes of a wave; flag[i] says what happened before local
+// step i (0 nothing, 1 state stored in the next slot, 2 wanted but no slot left) -- one byte per step and wave, written
+// by the wave's first active lane, read back by the sweep.
+//   K > 0:  every K steps.
+//   K == 0: adaptive -- a state is stored as soon as, for SOME lane of the wave, the decay accumulated over the moves
+//           since the last stored state would exceed the growth budget: scale x (t - t_stored) > 1, scale = (largest
+//           decay rate of the problem) / CLR_GRAD_GROWTH_BUDGET.  Reconstruction errors grow like exp(2 c T): the
+//           budget 3 bounds the growth over any stretch the sweep rebuilds and uses by 4e2, and over the stretch plus
+//           the stored state's own move -- what the drift check at that state sees -- by 2e5.  Dense series store a
+//           handful of states per chunk, sparse ones one every few samples, a lone long gap exactly where it is.
+#define CLR_GRAD_GROWTH_BUDGET 3.0
+struct GradStore {
+  double* ck = nullptr;           // [slot][SZ + J], element k of a slot at ck[(slot (SZ + J) + k) rstride]
+  unsigned char* flag = nullptr;  // [L]
+  int K = 0;
+  int nalloc = 0;                 // slots
+  double* count = nullptr;        // (forward pass) out: slots this lane's chunk used; (sweep) in
+};
+template <int JR, int JC>
+CLR_HD double grad_store_scale(const Problem<JR, JC>& p) {
+  double cm = 0.0;
+  CLR_UNROLL
+  for (int j = 0; j < JR; ++j) cm = fmax(cm, fabs(p.cr[j]));
+  CLR_UNROLL
+  for (int j = 0; j < JC; ++j) cm = fmax(cm, fabs(p.cc[j]));
+  return cm / CLR_GRAD_GROWTH_BUDGET;
+}
+
 // group -> kind (0 jitter, 1 real term, 2 complex a/b, 3 complex c/d), term, the two direction numbers (-1: none)
 template <int JR, int JC>
 CLR_HD void grad_group(int g, int* kind, int* term, int* q0, int* q1) {
@@ -300,13 +338,13 @@ CLR_HD void grad_chunk(const double* a_real, const double* c_real, const double*
 // rec (may be null): per sample of the chunk w[J], D, x -- element k of local step i at rec[(i (J + 2) + k) rstride] --
 // and end_out = the base state after the chunk's last sample (S[SZ] f[J]): what the reverse sweep
 // (grad_backward_chunk) starts from.  The move after the LAST sample of the series is taken with dt = 0.
-// ck (may be null): the base state BEFORE local step i for i = K, 2K, ... -- checkpoint i / K - 1, element k at
-// ck[((i / K - 1) (SZ + J) + k) rstride] -- which bounds how far the reverse sweep reconstructs states.
+// store (GradStore, ck may be null): base states BEFORE selected local steps, which bounds how far the reverse sweep
+// reconstructs states.
 // RIDERS = false: only the record (the riders then come from the scan's element, grad_riders_from_element).
 template <int JR, int JC, bool FAST, class Src, bool RIDERS = true>
 CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* start,
                               double* out, double* rec = nullptr, long rstride = 0, double* end_out = nullptr,
-                              double* ck = nullptr, int K = 0) {
+                              GradStore store = GradStore()) {
   using Sh = GradShape<JR, JC>;
   constexpr int J = Sh::J, SZ = Sh::SZ;
   double S[SZ], f[J], AA[RIDERS ? J * J : 1], eta[RIDERS ? J : 1], JJ[RIDERS ? SZ : 1];
@@ -324,6 +362,9 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
       for (int j = 0; j < J; ++j) AA[i * J + j] = i == j ? 1.0 : 0.0;
     }
   }
+  const double store_scale = grad_store_scale<JR, JC>(p);
+  double store_acc = 0.0;
+  int store_used = 0;
   src.prologue();
   double tn = src.t(0);
   double t_next = src.t(1);
@@ -338,12 +379,30 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
       y_n = src.y(i + 1);
     }
     if (valid) {  // (the state freezes behind the end of the series: end_out is the state after the last sample)
-      if (ck && i > 0 && i % K == 0) {
-        double* o = ck + (long)(i / K - 1) * (SZ + J) * rstride;
-        CLR_UNROLL
-        for (int k = 0; k < SZ; ++k) store_stream(o + (long)k * rstride, S[k]);
-        CLR_UNROLL
-        for (int k = 0; k < J; ++k) store_stream(o + (long)(SZ + k) * rstride, f[k]);
+      if (store.ck) {
+        const double sdt = n0 + i + 1 < N ? store_scale * (t_cur_next - tn) : 0.0;
+        bool fire;
+        if (store.K > 0) {
+          fire = i > 0 && i % store.K == 0;
+        } else {
+          const bool want = i > 0 && store_acc + sdt > 1.0;
+          fire = CLR_WAVE_ANY(want);
+        }
+        if (fire) {
+          const bool room = store_used < store.nalloc;
+          if (room) {
+            double* o = store.ck + (long)store_used * (SZ + J) * rstride;
+            CLR_UNROLL
+            for (int k = 0; k < SZ; ++k) store_stream(o + (long)k * rstride, S[k]);
+            CLR_UNROLL
+            for (int k = 0; k < J; ++k) store_stream(o + (long)(SZ + k) * rstride, f[k]);
+            ++store_used;
+          }
+          if (store.flag && CLR_FIRST_ACTIVE_LANE()) store.flag[i] = room ? 1 : 2;
+          store_acc = 0.0;  // (the stored state's own move does not count: nothing is rebuilt across it)
+        } else {
+          store_acc += sdt;
+        }
       }
       double u[J], v[J];
       features_uv<JR, JC, FAST>(p, tn, u, v);
@@ -413,6 +472,7 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
     CLR_UNROLL
     for (int i = 0; i < J; ++i) end_out[SZ + i] = f[i];
   }
+  if (store.count) *store.count = (double)store_used;
   if (RIDERS) {
     CLR_UNROLL
     for (int i = 0; i < J * J; ++i) out[i] = AA[i];
@@ -678,17 +738,16 @@ CLR_HD void grad_adjoint_walk(int nchunk, const double* riders, double* adj) {
 // (may be null): the adjoint at the chunk's first sample, equal to what grad_adjoint_walk found for the end of the
 // previous chunk -- the built-in consistency check of the tests.
 // The reconstruction inverts a contraction: its rounding errors grow like exp(2 c T) over a time span T (measured on
-// the host instantiation: exact to 1e-13 over c T = 8, lost over c T = 40).  So the forward pass stores the state
-// every K steps (ck), the sweep continues from the stored state there -- and from the scan's start state (`start`,
-// null = the zero state) at the chunk's first sample -- and reports how far its own reconstruction had drifted
-// (mismatch_out: the certificate -- a problem whose drift exceeds the tolerance is handed to the forward-mode kernels
-// above); the host picks K from 2 c_max K dt_max <= log(1e4): K = 1 (every state stored, nothing reconstructed is
-// ever used) on sparse series (api.hip).
+// the host instantiation: exact to 1e-13 over c T = 8, lost over c T = 40).  So the forward pass stores states
+// (GradStore: wherever the accumulated decay since the last stored one reaches the growth budget), the sweep continues
+// from the stored state there -- and from the scan's start state (`start`, null = the zero state) at the chunk's first
+// sample -- and reports how far its own reconstruction had drifted (mismatch_out: the certificate -- a problem whose
+// drift exceeds the tolerance is handed to the forward-mode kernels above).
 // ---------------------------------------------------------------------------
 template <int JR, int JC, bool FAST, class Src>
 CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n0, const double* end_state,
                                 const double* end_adj, const double* rec, long rstride, double* out,
-                                double* adj0_out = nullptr, const double* ck = nullptr, int K = 0,
+                                double* adj0_out = nullptr, GradStore store = GradStore(),
                                 double* mismatch_out = nullptr, const double* start = nullptr) {
   using Sh = GradShape<JR, JC>;
   constexpr int J = Sh::J, SZ = Sh::SZ, M = JR + JC, NG = Sh::NG;
@@ -705,6 +764,8 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
   for (int j = 0; j < JC; ++j) { g_ac[j] = 0.0; g_bc[j] = 0.0; g_cc[j] = 0.0; g_dc[j] = 0.0; }
   const int last = (N - n0 < L ? N - n0 : L) - 1;  // local index of the chunk's last sample
   double drift = 0.0;
+  const double store_scale = grad_store_scale<JR, JC>(p);
+  int store_left = store.count ? (int)*store.count : 0;  // slots this chunk's forward pass filled, taken from the top
   // the record and the times of a step are fetched one step ahead (one wave per SIMD: nothing else hides the latency)
   double w_n[J], D_n = 1.0, x_n = 0.0, t_n = 0.0, t_n1 = 0.0;
   auto fetch = [&](int i) {
@@ -770,12 +831,24 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
       hb[j] = phid[phi_index<JR>(j)] * fb[j];
       f[j] = fma(-w[j], x, iphid[phi_index<JR>(j)] * f[j]);
     }
-    if ((ck && i > 0 && i % K == 0) || i == 0) {
+    const int stored = (store.ck && store.flag && i > 0) ? store.flag[i] : 0;
+    if (stored == 2) drift = INFINITY;  // (the forward pass ran out of slots: the rebuilt states are not certified)
+    if (stored == 1 || i == 0) {
       // a state known independently -- stored by the forward pass, or (i = 0) the chunk's start state from the scan:
-      // measure how far the reconstruction has drifted since the last one, then continue from the known state
-      const double* o = i > 0 ? ck + (long)(i / K - 1) * (SZ + J) * rstride : start;
+      // measure how far the reconstruction has drifted since the last one, then continue from the known state.
+      // (A stored state whose own move is a long one -- beyond the growth budget by itself -- is not measured: the
+      //  one reconstruction across that move is never used; the adjoint mismatch still covers the chunk.)
+      if (stored == 1) --store_left;
+      const double* o = i > 0 ? store.ck + (long)store_left * (SZ + J) * rstride : start;
       const long os = i > 0 ? rstride : 1;
-      double big = 0.0, dev = 0.0;
+      const bool measure = store.K > 0 || !(store_scale * dt > 1.0);
+      // scale of the comparison: the state before the step is the DIFFERENCE S = G - D w w^T, f = h - w x; where the
+      // series has forgotten its past S is tiny next to the terms it is the difference of, and it is their rounding
+      // (and the dynamics' natural scale), not S's own size, that an error must be held against
+      double wmax = 0.0;
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) wmax = fmax(wmax, fabs(w[k]));
+      double big = fabs(D) * wmax * wmax, dev = 0.0;
       CLR_UNROLL
       for (int k = 0; k < SZ; ++k) {
         const double e = o ? o[(long)k * os] : 0.0;
@@ -783,7 +856,7 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
         dev = fmax(dev, fabs(e - S[k]));  // (fmax drops a NaN; a NaN reconstruction shows in the partials instead)
         S[k] = e;
       }
-      double bigf = 0.0, devf = 0.0;
+      double bigf = wmax * fabs(x), devf = 0.0;
       CLR_UNROLL
       for (int k = 0; k < J; ++k) {
         const double e = o ? o[(long)(SZ + k) * os] : 0.0;
@@ -791,7 +864,7 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
         devf = fmax(devf, fabs(e - f[k]));
         f[k] = e;
       }
-      if (o) {  // (the zero state of the first chunk: an absolute deviation has no scale to compare with)
+      if (o && measure) {  // (the zero state of the first chunk: an absolute deviation has no scale to compare with)
         double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
         if (bigf > 0.0) r = fmax(r, devf / bigf);
         if (!(r <= drift)) drift = r;

@@ -6,8 +6,8 @@
 //   grad_tangent_kernel   lane = chunk, blockIdx.z = direction group: the base recurrence + the group's two
 //                         tangents from zero tangent states                                      [B][nchunk][NG][OUT]
 //   grad_combine_kernel   thread = (problem, direction): walks the chunks                                 [B][NG]
-// Reverse mode (the default, clr_batch_grad): grad_riders_kernel also stores w, D, x per sample, the state every g_K
-// steps and the state after the chunk; then
+// Reverse mode (the default, clr_batch_grad): grad_riders_kernel also stores w, D, x per sample, the state wherever the
+// accumulated decay asks for one (GradStore, clr_grad_core.h) and the state after the chunk; then
 //   grad_adjoint_kernel   thread = problem: the adjoint at every chunk end, backwards over the riders      [B][nchunk][ADJ]
 //   grad_backward_kernel  lane = chunk: the reverse sweep, ALL partials at once                             [B][nchunk][NG]
 //   grad_reduce_kernel    thread = (problem, direction): sums the chunks; per problem the largest drift of the
@@ -36,6 +36,19 @@ __device__ __forceinline__ DirectSeries grad_series(const BatchParams& P, int b,
                       1, Lg, (int)Lg, (long)P.N - first};
 }
 
+// the stored states of gradient chunk c of problem b (reverse mode; null when nothing is recorded)
+__device__ __forceinline__ GradStore grad_store(const BatchParams& P, int b, int c) {
+  GradStore st;
+  if (P.g_rec) {
+    st.ck = P.g_ck + b * P.g_ck_stride + c;
+    st.flag = P.g_ckflag + ((long)b * gridDim.x + blockIdx.x) * ((long)P.g_m * P.L);
+    st.K = P.g_K;
+    st.nalloc = P.g_nalloc;
+    st.count = P.g_count + (long)b * P.g_nchunk + c;
+  }
+  return st;
+}
+
 template <int JR, int JC, bool FAST>
 __global__ void __launch_bounds__(64) grad_riders_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
@@ -52,8 +65,7 @@ __global__ void __launch_bounds__(64) grad_riders_kernel(const BatchParams P) {
   grad_riders_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L,
                                   c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr,
                                   P.g_riders + slot * Sh::RID, P.g_rec ? P.g_rec + b * P.g_rec_stride + c : nullptr,
-                                  P.g_nchunk, P.g_rec ? P.g_ends + slot * Wd::START : nullptr,
-                                  P.g_rec ? P.g_ck + b * P.g_ck_stride + c : nullptr, P.g_K);
+                                  P.g_nchunk, P.g_rec ? P.g_ends + slot * Wd::START : nullptr, grad_store(P, b, c));
 }
 
 // Reverse mode when a gradient chunk is a scan chunk: the riders from the scan's own elements (one Gauss-Jordan per
@@ -90,7 +102,7 @@ __global__ void __launch_bounds__(64) grad_record_kernel(const BatchParams P) {
   grad_riders_chunk<JR, JC, FAST, DirectSeries, false>(
       p, src, P.g_m * P.L, P.N, c * P.g_m * P.L,
       c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr, nullptr,
-      P.g_rec + b * P.g_rec_stride + c, P.g_nchunk, P.g_ends + slot * Wd::START, P.g_ck + b * P.g_ck_stride + c, P.g_K);
+      P.g_rec + b * P.g_rec_stride + c, P.g_nchunk, P.g_ends + slot * Wd::START, grad_store(P, b, c));
 }
 
 template <int JR, int JC, bool FAST>
@@ -207,10 +219,9 @@ __global__ void __launch_bounds__(64) grad_backward_kernel(const BatchParams P) 
   double drift = 0.0;
   grad_backward_chunk<JR, JC, FAST>(p, src, P.g_m * P.L, P.N, c * P.g_m * P.L, P.g_ends + slot * Wd::START,
                                     P.g_adj + slot * Wd::START, P.g_rec + b * P.g_rec_stride + c, P.g_nchunk,
-                                    P.g_part + slot * Sh::NG, P.g_adj0 + slot * Wd::START,
-                                    P.g_ck + b * P.g_ck_stride + c, P.g_K, &drift,
+                                    P.g_part + slot * Sh::NG, P.g_adj0 + slot * Wd::START, grad_store(P, b, c), &drift,
                                     c > 0 ? P.starts + ((long)b * P.nchunk + (long)c * P.g_m) * Wd::START : nullptr);
-  if (!(P.g_K > 1)) drift = 0.0;  // (K = 1: every state is a stored one, no reconstructed state is used)
+  if (P.g_K == 1) drift = 0.0;  // (every state is a stored one: no reconstructed state is used)
   P.g_drift[slot] = drift;
 }
 

@@ -430,11 +430,12 @@ int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
 /* How clr_batch_grad differentiates.  mode 0 (default): REVERSE mode -- the riders pass also records w, D, x per
  * sample and the state every K steps, the adjoint at every chunk end follows from the riders in a walk backwards over
  * the chunks, and ONE reverse sweep per chunk yields all partials (cost ~4x an evaluation instead of ~20x; needs
- * 8 (J + 2 + (J (J + 3) / 2) / K) bytes per sample of HBM, falls back to mode 1 when that does not fit).  The sweep
+ * 8 (J + 2) bytes per sample of HBM plus the stored states, falls back to mode 1 when that does not fit).  The sweep
  * reconstructs the states between the stored ones; the drift it measures at every stored state certifies them, and a
  * problem that drifts beyond `drift_tolerance` (default 1e-9; <= 0 keeps the current one) is redone in mode 1.
- * mode 1: FORWARD mode, one tangent per partial (the description above).  stored_state_distance: K in steps, 0 = from
- * the series and coefficients (2 c_max K dt_max <= log 1e4).
+ * mode 1: FORWARD mode, one tangent per partial (the description above).  stored_state_distance: a state every K steps;
+ * 0 (default) = wherever the decay accumulated since the last stored state reaches the growth budget (c T <= 3 over any
+ * rebuilt stretch: a few states per chunk on dense series, one every few samples on sparse ones).
  * In reverse mode the three riders of a chunk come from the scan's own element of that chunk (one J x J solve per chunk
  * instead of ~190 FMAs per sample) whenever a gradient chunk is a scan chunk; the sweep's second certificate -- the
  * adjoint it arrives at for the chunk's first sample against the one predicted from the riders -- vouches for them.

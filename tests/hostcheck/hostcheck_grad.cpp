@@ -71,7 +71,7 @@ template <int JR, int JC>
 static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_real, const double* c_real,
                             const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
                             const double* t, const double* diag, const double* y, double* logdet, double* quad,
-                            double* grad, double* mismatch, int K, double* drift) {
+                            double* grad, double* mismatch, int K, double* drift, double* stored_fraction) {
   using Wd = Widths<JR, JC>;
   using Sh = GradShape<JR, JC>;
   constexpr int J = Wd::J, ADJ = Wd::START;
@@ -81,8 +81,21 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
   p.load(a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter);
   std::vector<double> starts((size_t)nchunk * Wd::START, 0.0), ends((size_t)nchunk * Wd::START), riders((size_t)nchunk * Sh::RID),
       rec((size_t)N * (J + 2)), adj((size_t)nchunk * ADJ);
-  const int nck = K > 0 ? (L + K - 1) / K : 0;
-  std::vector<double> ck((size_t)nchunk * std::max(nck, 1) * Wd::START, 0.0);
+  // stored states: K > 0 every K steps, K == 0 where the accumulated decay reaches the growth budget, K < 0 none
+  const int nck = K < 0 ? 0 : L;
+  std::vector<double> ck((size_t)nchunk * std::max(nck, 1) * Wd::START, 0.0), counts(nchunk, 0.0);
+  std::vector<unsigned char> flags((size_t)nchunk * L, 0);
+  auto store_of = [&](int c) {
+    GradStore st;
+    if (K >= 0) {
+      st.ck = &ck[(size_t)c * nck * Wd::START];
+      st.flag = &flags[(size_t)c * L];
+      st.K = K;
+      st.nalloc = nck;
+      st.count = &counts[c];
+    }
+    return st;
+  };
   double worst_drift = 0.0;
   double ld = 0.0, qd = 0.0;
   int bad = 0;
@@ -101,7 +114,7 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
     DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
     grad_riders_chunk<JR, JC, true>(p, src, L, N, (int)first, c ? &starts[(size_t)c * Wd::START] : nullptr,
                                     &riders[(size_t)c * Sh::RID], &rec[(size_t)first * (J + 2)], 1, &ends[(size_t)c * Wd::START],
-                                    K > 0 ? &ck[(size_t)c * nck * Wd::START] : nullptr, K);
+                                    store_of(c));
   }
   grad_adjoint_walk<J>(nchunk, riders.data(), adj.data());
   std::vector<double> total(Sh::NG, 0.0);
@@ -111,8 +124,7 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
     DirectSeries src{t + first, diag + first, y + first, 1, L, L, (long)N - first};
     double out[Sh::NG], adj0[ADJ], dr = 0.0;
     grad_backward_chunk<JR, JC, true>(p, src, L, N, (int)first, &ends[(size_t)c * Wd::START], &adj[(size_t)c * ADJ],
-                                      &rec[(size_t)first * (J + 2)], 1, out, adj0,
-                                      K > 0 ? &ck[(size_t)c * nck * Wd::START] : nullptr, K, &dr,
+                                      &rec[(size_t)first * (J + 2)], 1, out, adj0, store_of(c), &dr,
                                       c ? &starts[(size_t)c * Wd::START] : nullptr);
     if (!(dr <= worst_drift)) worst_drift = dr;
     for (int q = 0; q < Sh::NG; ++q) total[q] += out[q];
@@ -128,6 +140,11 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
   *quad = qd;
   *mismatch = worst;
   *drift = worst_drift;
+  if (stored_fraction) {
+    double total = 0.0;
+    for (double x : counts) total += x;
+    *stored_fraction = total / N;
+  }
   return bad;
 }
 
@@ -191,8 +208,8 @@ extern "C" int hostcheck_grad_reverse(int N, int JR, int JC, int nchunk, double 
                                       const double* c_real, const double* a_comp, const double* b_comp,
                                       const double* c_comp, const double* d_comp, const double* t, const double* diag,
                                       const double* y, double* logdet, double* quad, double* grad, double* mismatch,
-                                      int K, double* drift) {
-#define GCASE(R, C) if (JR == R && JC == C) return run_grad_reverse<R, C>(N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, logdet, quad, grad, mismatch, K, drift);
+                                      int K, double* drift, double* stored_fraction) {
+#define GCASE(R, C) if (JR == R && JC == C) return run_grad_reverse<R, C>(N, nchunk, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, logdet, quad, grad, mismatch, K, drift, stored_fraction);
   GCASE(1, 0) GCASE(2, 0) GCASE(0, 1) GCASE(1, 1) GCASE(2, 1) GCASE(0, 2) GCASE(2, 3) GCASE(3, 2) GCASE(8, 0) GCASE(0, 4)
 #undef GCASE
   return -1;

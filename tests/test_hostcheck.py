@@ -367,25 +367,34 @@ def test_reverse_mode_gradient_against_the_dual_number_oracle(gradlib, JR, JC):
     cc, dc = rng.uniform(0.05, 0.5, JC), rng.uniform(0.5, 3.0, JC)
     e, e2 = np.empty(0), np.empty((0, 0))
     gradlib.hostcheck_grad_reverse.argtypes = ([C.c_int] * 4 + [C.c_double] + [dp] * 9 + [C.POINTER(C.c_double)] * 2 +
-                                               [dp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)])
+                                               [dp, C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 2)
 
-    def run(t, nchunk, K):
-        ld, q, mm, dr = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    def run(t, nchunk, K):   # K > 0: a state stored every K steps; 0: where the accumulated decay asks for one; < 0: none
+        ld, q, mm, dr, sf = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
         g = np.zeros(1 + 2 * JR + 4 * JC)
         rc = gradlib.hostcheck_grad_reverse(N, JR, JC, nchunk, 0.05, P(ar), P(cr), P(ac), P(bc), P(cc), P(dc), P(t),
-                                            P(diag), P(y), C.byref(ld), C.byref(q), P(g), C.byref(mm), K, C.byref(dr))
+                                            P(diag), P(y), C.byref(ld), C.byref(q), P(g), C.byref(mm), K, C.byref(dr),
+                                            C.byref(sf))
         assert rc == 0
-        return g, mm.value, dr.value
+        return g, mm.value, dr.value, sf.value
 
-    for span, nchunk, K in ((0.02, 3, 0), (0.02, 1, 50), (0.5, 5, 4), (0.5, 2, 1), (5.0, 4, 1)):
+    fractions = {}
+    for span, nchunk, K in ((0.02, 3, -1), (0.02, 1, 50), (0.5, 5, 4), (0.5, 2, 1), (5.0, 4, 1),
+                            (0.02, 2, 0), (0.5, 3, 0), (5.0, 4, 0), (50.0, 2, 0)):
         t = np.sort(rng.uniform(0, span * N, N))
         v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
-        g, mismatch, drift = run(t, nchunk, K)
+        g, mismatch, drift, stored = run(t, nchunk, K)
         assert np.max(np.abs(g - g0)) <= 1e-10 * np.max(np.abs(g0)), (span, nchunk, K)
         assert mismatch <= 1e-12, (span, nchunk, K, mismatch)
+        if K == 0:
+            assert drift <= 1e-9, (span, drift)      # the adaptive rule keeps every rebuilt stretch inside the budget
+            fractions[span] = stored
+    # the adaptive rule stores a few states on a dense series and (almost) every one on a very sparse series
+    assert fractions[0.02] <= fractions[0.5] < fractions[5.0] < fractions[50.0] <= 1.0, fractions
+    assert fractions[0.02] < 0.02 and fractions[50.0] > 0.5, fractions
     # no stored states over 400 samples of a series that forgets: the reconstruction is lost, and the drift says so
     t = np.sort(rng.uniform(0, 2.0 * N, N))
     v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
-    g, mismatch, drift = run(t, 2, 0)
+    g, mismatch, drift, stored = run(t, 2, -1)
     assert not np.max(np.abs(g - g0)) <= 1e-6 * np.max(np.abs(g0))
     assert not drift <= 1e-6
