@@ -13,6 +13,10 @@
 
 using namespace clr;
 
+// slots per chunk for the stored states of the reverse-mode runs (<= 0: as many as steps)
+static int g_slot_limit = 0;
+extern "C" void hostcheck_grad_set_slot_limit(int n) { g_slot_limit = n; }
+
 template <int JR, int JC>
 static int run_grad(int N, int nchunk, double jitter, const double* a_real, const double* c_real, const double* a_comp,
                     const double* b_comp, const double* c_comp, const double* d_comp, const double* t,
@@ -91,7 +95,7 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
       st.ck = &ck[(size_t)c * nck * Wd::START];
       st.flag = &flags[(size_t)c * L];
       st.K = K;
-      st.nalloc = nck;
+      st.nalloc = g_slot_limit > 0 ? std::min(g_slot_limit, nck) : nck;
       st.count = &counts[c];
     }
     return st;

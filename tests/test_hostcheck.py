@@ -392,6 +392,14 @@ def test_reverse_mode_gradient_against_the_dual_number_oracle(gradlib, JR, JC):
     # the adaptive rule stores a few states on a dense series and (almost) every one on a very sparse series
     assert fractions[0.02] <= fractions[0.5] < fractions[5.0] < fractions[50.0] <= 1.0, fractions
     assert fractions[0.02] < 0.02 and fractions[50.0] > 0.5, fractions
+    # fewer slots than the rule asks for: the sweep reports it (infinite drift = a failed certificate, the problem is
+    # then redone in forward mode by the library)
+    gradlib.hostcheck_grad_set_slot_limit(3)
+    try:
+        g, mismatch, drift, stored = run(np.sort(rng.uniform(0, 5.0 * N, N)), 2, 0)
+    finally:
+        gradlib.hostcheck_grad_set_slot_limit(0)
+    assert np.isinf(drift) and stored <= 2 * 3 / N + 1e-12
     # no stored states over 400 samples of a series that forgets: the reconstruction is lost, and the drift says so
     t = np.sort(rng.uniform(0, 2.0 * N, N))
     v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
