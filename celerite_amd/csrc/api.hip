@@ -917,7 +917,7 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   if ((st = ensure_stream(s)) != CLR_OK) return st;
   hipStream_t stream = s->stream;
 
-  if (!has_general && JG == 0 && JR + 2 * JC >= 1 && JR + 2 * JC <= 8 && N >= 2048 && !getenv("CLR_GRAD_SEQUENTIAL")) {
+  if (!has_general && JG == 0 && JR + 2 * JC >= 1 && JR + 2 * JC <= 8 && N >= 1024 && !getenv("CLR_GRAD_SEQUENTIAL")) {
     // parallel in n: the scan + the chunk-wise tangents (clr_batch_grad) on a one-problem plan
     if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC) {
       if (s->grad_plan) clr_batch_destroy(s->grad_plan);

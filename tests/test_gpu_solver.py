@@ -307,7 +307,7 @@ def test_grad_log_likelihood_wide_and_long():
 
 @pytest.mark.parametrize("JR,JC,N", [(2, 3, 3000), (1, 1, 20000), (0, 4, 6000), (3, 0, 2048)])
 def test_grad_log_likelihood_of_a_long_series_is_parallel_in_n(JR, JC, N):
-    """From N = 2048 on (widths 1..8, no general terms) CholeskySolver.grad_log_likelihood runs the scan + the
+    """From N = 1024 on (widths 1..8, no general terms) CholeskySolver.grad_log_likelihood runs the scan + the
     chunk-wise tangents on a one-problem plan (csrc/clr_grad_core.h): same numbers as the sequential tangent kernel,
     the oracle on the shortest case, the series kept between calls, LinAlgError for an indefinite matrix."""
     from oracle import grad as ograd
