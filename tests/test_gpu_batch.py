@@ -973,6 +973,31 @@ def test_plan_gradient_on_the_adversarial_family(JR, JC):
           "fallbacks, %d forward-mode reruns" % (worst, nfb, nre))
 
 
+def test_full_size_gradient_reverse_against_forward_on_both_families():
+    """At the headline's series length both input families of SURVEY.md 8(d): the reverse sweep (stored states where
+    the accumulated decay asks for one: a handful per chunk on the bench family, every one on the sparse family) against
+    forward mode (no reconstruction at all), certificates at rounding level, no problem redone."""
+    import bench
+    B, N, JR, JC = 8, 100000, 2, 3
+    for maker, seed in ((bench.make_inputs, 9), (bench.make_inputs_accuracy, 10)):
+        coeffs, t, diag, y = maker(B, N, JR, JC, seed)
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_series(t, diag, y)
+            plan.set_coefficients(*coeffs, jitter=0.05)
+            plan.set_grad_mode("forward")
+            v0, g0, st0 = plan.grad_log_likelihood()
+            plan.set_grad_mode("reverse")
+            v1, g1, st1 = plan.grad_log_likelihood()
+            info = plan.grad_info()
+        finally:
+            plan.close()
+        assert (st0 == 0).all() and (st1 == 0).all()
+        assert info["reverse"] and info["forward_reruns"] == 0 and info["drift_max"] <= 1e-10, info
+        assert np.max(np.abs(g1 - g0) / np.max(np.abs(g0), axis=1, keepdims=True)) <= 1e-10
+        assert np.array_equal(v0, v1)
+
+
 def test_reverse_gradient_certifies_its_reconstructed_states():
     """The reverse sweep rebuilds the states between the stored ones by inverting the recurrence, which amplifies
     rounding errors like exp(2 c T) (csrc/clr_grad_core.h).  With the stored states at the distance the host derives
