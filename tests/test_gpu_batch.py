@@ -973,6 +973,35 @@ def test_plan_gradient_on_the_adversarial_family(JR, JC):
           "fallbacks, %d forward-mode reruns" % (worst, nfb, nre))
 
 
+@pytest.mark.parametrize("JR,JC", ALL_WIDTH_SHAPES)
+def test_plan_gradient_every_width_shape(JR, JC):
+    """All 24 (J_real, J_comp) shapes of widths 1..8 (each its own instantiation of the record / reverse-sweep / riders
+    kernels): the default plan gradient against the sequential tangent kernel, a series length that is no multiple of
+    the chunk length, one shared series for the whole batch, jitter from zero up."""
+    B, N = 4, 1777
+    case = synthetic(B, N, JR, JC, "accuracy" if (JR + JC) % 2 else "bench", seed=200 + 10 * JR + JC)
+    t, diag, y = case["t"][0], case["diag"][0], case["y"][0]
+    jit = np.array([0.0, 1e-3, 0.05, 0.4])
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        v0, g0, st0 = batch.batch_grad_log_likelihood(*coeffs_of(case), t, diag, y, jitter=jit)
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(t, diag, y)
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        v, g, st = plan.grad_log_likelihood()
+        info = plan.grad_info()
+    finally:
+        plan.close()
+    assert np.array_equal(st, st0) and (st == 0).all()
+    assert info["reverse"] and info["forward_reruns"] == 0, info
+    assert np.max(np.abs(v - v0) / np.abs(v0)) <= 1e-11
+    assert np.max(np.abs(g - g0) / np.max(np.abs(g0), axis=1, keepdims=True)) <= 1e-9
+    assert g[0, 0] == 0.0 and (g[1:, 0] != 0.0).all()       # d / d jitter is zeroed at jitter = 0 only (solver.cpp:379-389)
+
+
 def test_full_size_gradient_reverse_against_forward_on_both_families():
     """At the headline's series length both input families of SURVEY.md 8(d): the reverse sweep (stored states where
     the accumulated decay asks for one: a handful per chunk on the bench family, every one on the sparse family) against
