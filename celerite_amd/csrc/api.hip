@@ -339,6 +339,8 @@ struct clr_batch {
   hipStream_t stream = nullptr;
   int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
   int nchunk = 1, L = 0;
+  int L0 = 0;                      // wide plans: samples of the first chunk when it is longer than L (0: uniform)
+  double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk
   const clr::BatchLaunchers* launch = nullptr;
   DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout
   double* pin = nullptr;              // pinned host staging: coefficient uploads, result downloads
@@ -1415,6 +1417,18 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   h->L = (h->N + nchunk - 1) / nchunk;
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
+  h->L0 = 0;
+  if (const char* e = getenv("CLR_WIDE_FIRST_RATIO")) h->wide_first_ratio = atof(e);  // (tuning runs only)
+  if (!h->launch && h->nchunk > 1 && h->wide_first_ratio > 1.0) {
+    // wide scan: the first chunk's summarize carries no riders (wide_scan_body, RIDERS == false) and costs
+    // ~1 / wide_first_ratio of a later chunk's per sample: it gets that many more samples, so that all waves of the
+    // one round finish together.  Chunks 1.. have exactly L samples, the first one the rest.
+    const int nc = h->nchunk;
+    int L = (int)ceil(h->N / (nc - 1 + h->wide_first_ratio));
+    L = (L + 7) & ~7;
+    const long first = (long)h->N - (long)(nc - 1) * L;
+    if (L >= 64 && first >= L) { h->L = L; h->L0 = (int)first; }
+  }
   h->relayout_pending = true;
   h->grad_span_valid = false;
   h->have_factor = false;  // its layout depends on the chunking
@@ -1707,7 +1721,7 @@ static int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   }
   memset(&P, 0, sizeof(P));
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
-  P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L;
+  P.B = h->B; P.N = h->N; P.nchunk = h->nchunk; P.L = h->L; P.L0 = h->L0;
   P.fast_trig = (!h->force_library_trig &&
                  sel_max(h->dmax, h->floor_dmax) * sel_max(h->tmax, h->floor_tmax) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
   P.coop_prefix = h->coop_prefix;
@@ -2143,7 +2157,7 @@ static void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t s
     clr::launch_wide_check_replay(P, stream);
     clr::launch_finalize(P, stream);
     clr::BatchParams S = P;  // the flagged problems, sequentially
-    S.nchunk = 1; S.L = P.N; S.seq_only = 1; S.force_exact = 1;
+    S.nchunk = 1; S.L = P.N; S.L0 = 0; S.seq_only = 1; S.force_exact = 1;
     clr::launch_wide_loglike(S, J_real, J_comp, stream);
   }
   mark(5);

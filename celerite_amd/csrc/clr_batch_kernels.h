@@ -28,6 +28,8 @@ constexpr int CLR_OK_STATUS = 0;  // (= CLR_OK of include/celerite_hip.h, which 
 constexpr int CLR_PENDING_STATUS = -1;  // internal: left to the scan pipeline by the warm path; never handed out
 struct BatchParams {
   int B, N, nchunk, L;
+  int L0;  // wide path: samples of the FIRST chunk when it differs from L (its summarize carries no riders and is
+           // given more samples in return); 0: uniform chunks
   const double *jitter, *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;
   // series as the kernels read them.  staged == 0 (DirectSeries): element (chunk c,
   // local i) of problem b is at base[b * stride + c * lane_cs + i * lane_is].

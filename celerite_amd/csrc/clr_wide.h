@@ -47,4 +47,22 @@ __device__ __forceinline__ double row_sum(double v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+constexpr int DPP_ROW_ROR4 = 0x124;     // row_ror:4: lane i <- lane (i + 4) mod 16 of its 16-lane row
+constexpr int DPP_ROW_ROR8 = 0x128;     // row_ror:8
+
+// Two such sums with ONE butterfly tree (rows of LPR >= 2 lanes): the first lane of every row brings the first
+// sum's term, the second lane the second sum's (the caller passes seg == 0 ? a : b); further lanes of a row bring
+// nothing.  Every stage (xor 2, rotate by 4, rotate by 8) keeps the lane parity, so even lanes end with sum a and odd
+// lanes with sum b of their 16-lane group.
+template <int LPR>
+__device__ __forceinline__ void row_sum2(double mine, int seg, double* sa, double* sb) {
+  static_assert(LPR >= 2, "needs two lanes per row");
+  double v = (LPR > 2 && seg >= 2) ? 0.0 : mine;
+  v = dpp_add<DPP_QUAD_XOR2>(v);
+  v = dpp_add<DPP_ROW_ROR4>(v);
+  v = dpp_add<DPP_ROW_ROR8>(v);
+  *sa = (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+  *sb = (lane_value(v, 1) + lane_value(v, 17)) + (lane_value(v, 33) + lane_value(v, 49));
+}
+
 }  // namespace clr

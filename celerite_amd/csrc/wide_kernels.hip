@@ -37,9 +37,22 @@
 #include "clr_batch_kernels.h"
 #include "clr_wide.h"
 
+// Round-4 build switches (A/B builds: -DCLR_WIDE_JM_MFMA=0 etc.; profiles/r04b_wide_ab.txt)
+#ifndef CLR_WIDE_JM_MFMA
+#define CLR_WIDE_JM_MFMA 1   // width 32 lazy summarize: Jm -= R D^-1 R^T as rank-16 updates on v_mfma_f64_16x16x4
+#endif
+#ifndef CLR_WIDE_PACKED_SUMS
+#define CLR_WIDE_PACKED_SUMS 1  // u.q and u.f reduced together (even / odd lanes), one DPP tree instead of two
+#endif
+#ifndef CLR_WIDE_LOGPROD_WINDOW
+#define CLR_WIDE_LOGPROD_WINDOW 1  // lazy summarize: plain product of a block's 16 pivots, one frexp per block
+#endif
+
 namespace clr {
 
 namespace {
+
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 
 // One row's features: u~, v~ (cholesky.h:129-147) at t and the decay to t + dx, without
 // selects: u = u0 + uc cos(d t) + us sin(d t), v = v0 + vc cos + vs sin with per-row
@@ -89,20 +102,42 @@ __device__ __forceinline__ void decay_pair(double x, double* phi, double* phinv)
   }
 }
 
-template <int WMAX, bool FAST, int MODE, bool LAZY = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
+// first sample of chunk c (c == nchunk: N).  Uniform chunks of L samples, or (L0 > 0) a first chunk of L0 samples
+// followed by chunks of L
+__device__ __forceinline__ int wide_chunk_begin(const BatchParams& P, int c) {
+  const long n = (P.L0 > 0 && c > 0) ? (long)P.L0 + (long)(c - 1) * P.L : (long)c * P.L;
+  return n < P.N ? (int)n : P.N;
+}
+
+// RIDERS == false (summarize only): the chunk that starts at sample 0.  Its start state IS the zero state, so the
+// prefix takes (C, b) of its element as they are and nothing ever reads A, Jm, eta: the riders -- half of a
+// summarize step's state FMAs -- are not carried, and the host makes that chunk longer in return (BatchParams::L0).
+template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS>
+__device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int JC) {
   static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
+  constexpr bool RID = MODE == 1 && RIDERS;
   using G = WideGeom<WMAX>;
   constexpr int LPR = G::LPR, COLS = G::COLS;
   constexpr int J = WMAX, SZ = J * (J + 1) / 2;
   constexpr int ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
+  // Jm on the matrix cores (width 32, lazy summarize): the r of a 16-step block and -r / D are parked in LDS
+  // [step][row]; at the block's end Jm += R (-D^-1 R)^T is 3 output tiles ((0,0), (0,1), (1,1): Jm is symmetric) x 4
+  // k-steps = 12 v_mfma_f64_16x16x4, operands read from LDS in the instruction's lane layout.  Replaces 16 FMAs and
+  // eight b128 LDS reads per lane and STEP.  (A and r stay on the VALU: r_n needs the up-to-date A, and a blocked
+  // WY form costs R0 = A0^T U, G = W^T U and a forward substitution on top -- 40 MFMA + 120 FMA per block against
+  // 32 FMA per step, with fp64 MFMA only 1.28x the VALU's FMA rate and not overlapping it: profiles/r04a_mfma_overlap.txt.)
+  constexpr bool JMM = RID && LAZY && WMAX == 32 && CLR_WIDE_JM_MFMA;
+  constexpr bool PACKED = LPR >= 2 && CLR_WIDE_PACKED_SUMS;
+  constexpr bool LPWIN = LAZY && CLR_WIDE_LOGPROD_WINDOW;
+  __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * 32 : 2];
+  __shared__ __attribute__((aligned(16))) double rsblk[JMM ? 16 * 32 : 2];
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
   __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX];
   __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX];
   __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
-  __shared__ __attribute__((aligned(16))) double rbuf[MODE == 1 ? WMAX : 2];
+  __shared__ __attribute__((aligned(16))) double rbuf[(RID && !JMM) ? WMAX : 2];
   __shared__ __attribute__((aligned(16))) double psibuf[LAZY ? WMAX : 2];
   const int lane = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -137,8 +172,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
   // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
   if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] != 1) return;
   if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
-  const int n_lo = chunk * P.L;
-  const int n_hi = (n_lo + P.L < N) ? n_lo + P.L : N;
+  const int n_lo = wide_chunk_begin(P, chunk);
+  const int n_hi = wide_chunk_begin(P, chunk + 1);
   const long slot = (long)b * P.nchunk + chunk;
 
   double S[COLS];
@@ -151,10 +186,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
     for (int c = 0; c < COLS; ++c) S[c] = st[sym(row, seg * COLS + c)];
     f = st[SZ + row];
   }
-  double AT[MODE == 1 ? COLS : 1], Jm[MODE == 1 ? COLS : 1], eta = 0.0;
-  if (MODE == 1) {
+  double AT[RID ? COLS : 1], Jm[(RID && !JMM) ? COLS : 1], eta = 0.0;
+  mfma_acc_t Jacc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};  // (JMM) tiles (0,0), (0,1), (1,1)
+  double dprod = 1.0;  // (LPWIN) product of the current block's pivots
+  if (RID) {
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) { AT[c] = (seg * COLS + c == row) ? 1.0 : 0.0; Jm[c] = 0.0; }
+    for (int c = 0; c < COLS; ++c) AT[c] = (seg * COLS + c == row) ? 1.0 : 0.0;
+    if (!JMM) {
+#pragma unroll
+      for (int c = 0; c < COLS; ++c) Jm[c] = 0.0;
+    }
   }
   LogProduct lp;
   lp.init();
@@ -234,22 +275,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
           const double2 uu = uv[c];
           q = fma(S[2 * c], uu.x, q);
           q = fma(S[2 * c + 1], uu.y, q);
-          if (MODE == 1) {
+          if (RID) {
             r = fma(AT[2 * c], uu.x, r);
             r = fma(AT[2 * c + 1], uu.y, r);
           }
         }
       }
-      if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR1>(r); }
-      if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (MODE == 1) r = dpp_add<DPP_QUAD_XOR2>(r); }
-      const double s = row_sum<LPR>(ueff * q), ub = row_sum<LPR>(ueff * f);
+      if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); if (RID) r = dpp_add<DPP_QUAD_XOR1>(r); }
+      if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (RID) r = dpp_add<DPP_QUAD_XOR2>(r); }
+      double s, ub;
+      if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
+      else { s = row_sum<LPR>(ueff * q); ub = row_sum<LPR>(ueff * f); }
       const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
       const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
       const double x = y_n - ub;
       // replay: the reference's test (cholesky.h:176; sample 0 is never checked); summarize: a
       // zero-start pivot <= 0 sends the problem to the replay (as in summarize_chunk)
       if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
-      lp.mul(D);
+      if (LPWIN) dprod *= D; else lp.mul(D);
       quad += x * x * invD;
       if (MODE == 1) gam = fmax(gam, fabs(((((diag_n + sum_ar) + sum_ac) + jitter)) * invD));
 
@@ -257,7 +300,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       const double w = z * invD;
       if (writer) {
         wbuf[row] = LAZY ? w : phi * w;
-        if (MODE == 1) rbuf[row] = r;
+        if (RID && !JMM) rbuf[row] = r;
+      }
+      if (JMM) {  // this step's r (first lane of the row) and -r / D (second lane), for the block's rank-16 update
+        double* dst = (seg == 0 ? rblk : rsblk) + ((n - n_lo) & 15) * 32 + row;
+        *dst = seg == 0 ? r : -(r * invD);
       }
       if (MODE == 0 && P.wide_materialize && writer && row < W) {
         // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
@@ -270,29 +317,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       }
       if (LAZY) {
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
-        const double2* rv = reinterpret_cast<const double2*>(&rbuf[seg * COLS]);
+        const double2* rv = reinterpret_cast<const double2*>(&rbuf[(RID && !JMM) ? seg * COLS : 0]);
         const double rs = r * invD;
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
-          const double2 pw = wv[c], rr = rv[c];
+          const double2 pw = wv[c];
           S[2 * c] = fma(z, pw.x, S[2 * c]);
           S[2 * c + 1] = fma(z, pw.y, S[2 * c + 1]);
-          AT[2 * c] = fma(-pw.x, r, AT[2 * c]);
-          AT[2 * c + 1] = fma(-pw.y, r, AT[2 * c + 1]);
-          Jm[2 * c] = fma(-rs, rr.x, Jm[2 * c]);
-          Jm[2 * c + 1] = fma(-rs, rr.y, Jm[2 * c + 1]);
+          if (RID) {
+            AT[2 * c] = fma(-pw.x, r, AT[2 * c]);
+            AT[2 * c + 1] = fma(-pw.y, r, AT[2 * c + 1]);
+          }
+          if (RID && !JMM) {
+            const double2 rr = rv[c];
+            Jm[2 * c] = fma(-rs, rr.x, Jm[2 * c]);
+            Jm[2 * c + 1] = fma(-rs, rr.y, Jm[2 * c + 1]);
+          }
         }
       } else {
         const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
-        const double2* rv = reinterpret_cast<const double2*>(&rbuf[MODE == 1 ? seg * COLS : 0]);
+        const double2* rv = reinterpret_cast<const double2*>(&rbuf[(RID && !JMM) ? seg * COLS : 0]);
         const double zr = phi * z, rs = r * invD;
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
           const double2 pk = pv[c], pw = wv[c];
           S[2 * c] = fma(zr, pw.x, (phi * pk.x) * S[2 * c]);
           S[2 * c + 1] = fma(zr, pw.y, (phi * pk.y) * S[2 * c + 1]);
-          if (MODE == 1) {
+          if (RID) {
             const double2 rr = rv[c];
             AT[2 * c] = fma(-pw.x, r, pk.x * AT[2 * c]);
             AT[2 * c + 1] = fma(-pw.y, r, pk.y * AT[2 * c + 1]);
@@ -301,12 +353,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
           }
         }
       }
-      if (MODE == 1) eta = fma(-r, x * invD, eta);
+      if (RID) eta = fma(-r, x * invD, eta);
       if (LAZY) {
         f = fma(w, x, f);  // fbar
         psi *= phi;        // Psi now includes this step's decay
         psinv *= phinv;
         if (renorm) {      // multiply the accumulated decay out of Sbar, Abar, fbar
+          if (LPWIN) {     // the block's pivots: one frexp for (at most) 16 of them
+            if (!(dprod > 1e-250 && dprod < 1e250)) flag = 1;  // (a pivot <= 0 is flagged above; this is over/underflow)
+            lp.mul_window(dprod);
+            lp.renorm();
+            dprod = 1.0;
+          }
+          if (JMM) {       // Jm += R (-D^-1 R)^T over the block's steps
+            const int cnt = ((n - n_lo) & 15) + 1;
+            if (cnt < 16)  // the chunk's last, shorter block: the unused steps contribute nothing
+              for (int idx = cnt * 32 + lane; idx < 16 * 32; idx += 64) { rblk[idx] = 0.0; rsblk[idx] = 0.0; }
+            const int lm = lane & 15, lk = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double a0 = rblk[(4 * ks + lk) * 32 + lm], a1 = rblk[(4 * ks + lk) * 32 + 16 + lm];
+              const double b0 = rsblk[(4 * ks + lk) * 32 + lm], b1 = rsblk[(4 * ks + lk) * 32 + 16 + lm];
+              Jacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, Jacc[0], 0, 0, 0);
+              Jacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, Jacc[1], 0, 0, 0);
+              Jacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, Jacc[2], 0, 0, 0);
+            }
+          }
           if (writer) psibuf[row] = psi;
           const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
 #pragma unroll
@@ -314,8 +386,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
             const double2 pc = qv[c];
             S[2 * c] *= psi * pc.x;
             S[2 * c + 1] *= psi * pc.y;
-            AT[2 * c] *= pc.x;
-            AT[2 * c + 1] *= pc.y;
+            if (RID) {
+              AT[2 * c] *= pc.x;
+              AT[2 * c + 1] *= pc.y;
+            }
           }
           f *= psi;
           psi = 1.0;
@@ -340,10 +414,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
 #pragma unroll
     for (int c = 0; c < COLS; ++c) {
       const int col = seg * COLS + c;
-      e[col * J + row] = AT[c];                                  // A[col][row] = AT[row][col]
+      e[col * J + row] = RID ? AT[c] : 0.0;                      // A[col][row] = AT[row][col]
       if (row <= col) {
         e[J * J + J + tri(row, col)] = S[c];                     // C, packed upper triangle
-        e[J * J + J + SZ + J + tri(row, col)] = Jm[c];           // Jm
+        if (!JMM) e[J * J + J + SZ + J + tri(row, col)] = RID ? Jm[c] : 0.0;  // Jm
+      }
+    }
+    if (JMM) {  // accumulator layout of v_mfma_f64_16x16x4: register r of tile (ti, tj) is entry (16 ti + (lane >> 4) + 4 r, 16 tj + (lane & 15))
+      const int lm = lane & 15, lk = lane >> 4;
+#pragma unroll
+      for (int tile = 0; tile < 3; ++tile) {
+        const int ti = tile == 2 ? 1 : 0, tj = tile == 0 ? 0 : 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + lk + 4 * r, j = 16 * tj + lm;
+          if (i <= j) e[J * J + J + SZ + J + tri(i, j)] = Jacc[tile][r];
+        }
       }
     }
     if (writer) {
@@ -401,6 +487,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wi
       P.out_ll[b] = combine_loglike(ld, quad, N);
     }
   }
+}
+
+template <int WMAX, bool FAST, int MODE, bool LAZY = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false>(P, JR, JC);
+  else wide_scan_body<WMAX, FAST, MODE, LAZY, true>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -843,8 +935,6 @@ static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
 // prefix_coop_kernel<32, 32> did the same algebra with one column per lane in REGISTERS: 512 registers,
 // 1 KB of scratch, a ds_bpermute per broadcast -- 300 us per chunk, 97 % of it moving data between lanes.
 // ---------------------------------------------------------------------------
-typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
-
 struct Prefix32Lds {
   static constexpr int J = 32, LD = 33, LT = 66;
   double P[J * LD], Jf[J * LD], A[J * LD], X[J * LD], C[J * LD], T[J * LT];
