@@ -287,11 +287,14 @@ class BatchedGP(object):
 
     PREFIX_MODES = {"single": 0, "walk": 1, "multilevel": 2}
 
-    def set_prefix_mode(self, mode="multilevel"):
+    def set_prefix_mode(self, mode="multilevel", cooperative=None):
         """Prefix phase (chunk elements -> chunk start states): ``"multilevel"`` (default: groups of
         elements composed in parallel, the composed ones walked, start states fanned out;
         csrc/clr_prefix_kernels.h), ``"walk"`` (16 lanes per problem, chunk after chunk) or ``"single"``
-        (one lane: the host-checked form, cross-check).  ``True`` / ``False`` mean walk / single."""
+        (one lane: the host-checked form, cross-check).  ``True`` / ``False`` mean walk / single
+        (also accepted as the keyword ``cooperative`` of earlier releases)."""
+        if cooperative is not None:
+            mode = bool(cooperative)
         if isinstance(mode, bool):
             mode = 1 if mode else 0
         _check(_load().clr_batch_set_prefix_mode(self._h, int(self.PREFIX_MODES.get(mode, mode))))
@@ -398,11 +401,14 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_exact_flags(self._h, f.ctypes.data_as(_ip)))
         return f
 
-    def set_certificate(self, max_gamma_over_mu=1e7, max_residual=1e-11, max_gamma=1e4, max_gamma_error=3e-9):
+    def set_certificate(self, max_gamma_over_mu=1e7, max_residual=1e-11, max_gamma=None, max_gamma_error=None):
         """Routing of ill-conditioned problems (``clr_batch_set_certificate``,
-        ``clr_batch_set_certificate_gamma``); a bound <= 0 switches that test off."""
+        ``clr_batch_set_certificate_gamma``); a bound <= 0 switches that test off.  The two gamma bounds
+        (defaults of a new plan: 1e4 and 3e-9) are only touched when one of them is passed."""
         _check(_load().clr_batch_set_certificate(self._h, float(max_gamma_over_mu), float(max_residual)))
-        _check(_load().clr_batch_set_certificate_gamma(self._h, float(max_gamma), float(max_gamma_error)))
+        if max_gamma is not None or max_gamma_error is not None:
+            _check(_load().clr_batch_set_certificate_gamma(self._h, float(1e4 if max_gamma is None else max_gamma),
+                                                           float(3e-9 if max_gamma_error is None else max_gamma_error)))
 
     def conditioning(self):
         """``(gamma_max, mu_min)`` per problem of the last run: largest ``a_n / D_n`` over the
@@ -488,7 +494,8 @@ class ShardedBatchedGP(object):
     is how the sharding is tested on one GPU.  The kernels are selected once for the whole
     batch (batch-wide maxima of the series and coefficients), so results do not depend on the
     sharding bit for bit when the chunk count is the same (:meth:`set_chunks`; the automatic
-    choice looks at the shard size)."""
+    choice looks at the shard size) and the warm-started recurrence is not in play (it adapts per
+    plan: see :meth:`set_warm_start`)."""
 
     def __init__(self, B, N, J_real, J_comp, devices=None):
         lib = _load()
@@ -537,6 +544,14 @@ class ShardedBatchedGP(object):
 
     def set_summarize_mode(self, mode=-1):
         self._ok(_load().clr_sharded_set_summarize_mode(self._h, int(mode)))
+
+    def set_warm_start(self, mode=-1, forced_warmup=0):
+        """``clr_batch_set_warm_start`` on every shard.  The warm-started recurrence adapts per plan, so a batch
+        may take different (equally certified) routes under different shardings -- results then agree to the scan's
+        rounding, not bit for bit; ``mode=0`` switches it off."""
+        lib = _load()
+        lib.clr_sharded_set_warm_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._ok(lib.clr_sharded_set_warm_start(self._h, int(mode), int(forced_warmup)))
 
     def summarize_kernel(self):
         """The summarize kernel ALL shards run (resolved once for the whole batch)."""

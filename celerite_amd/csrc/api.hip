@@ -391,10 +391,13 @@ struct clr_batch {
   int warm_cand[WARM_NK] = {8, 12, 16, 24, 32, 48, 64, 80, 96, 128};
   std::vector<double> warm_span;      // [B or 1][WARM_NK] shortest time the K samples before a chunk boundary span
   std::vector<int> warm_K;            // [B] warm-up steps per problem of the current coefficients (0: scan)
+  std::vector<double> host_cmin;      // [B] slowest decay rate of problem b (last set_coefficients)
+  bool warm_K_dirty = false;          // warm_K changed on the host after the last upload (set_series re-selected it)
   bool warm_active = false;           // the current (series, coefficients) pair runs the warm path
   bool warm_inflight = false;         // results of a warm evaluation have not been looked at yet
   bool in_fallback = false;           // building the parameters of the scan behind the warm path
   int warm_boost = 0;                 // candidates skipped after an evaluation with many fallbacks
+  int warm_clean = 0;                 // consecutive warm evaluations without a fallback (decays warm_boost)
   int warm_settled = 0, warm_fallbacks = 0;  // of the last evaluation
   DevBuf wstarts, wends, wpart, wresid;
   DevBuf wT, wD, wY;                  // the warm kernel's padded chunk-interleaved copy of the series
@@ -1387,11 +1390,13 @@ void clr_batch_destroy(clr_batch* h) {
 }
 
 static int warm_plan_chunks(clr_batch* h);
+static int warm_resolve(clr_batch* h, bool* pin_current);
 static void warm_scan_spans(clr_batch* h, const double* t, long t_stride);
 
 int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
   h->warm_explicit_chunks = nchunk > 0 ? nchunk : 0;
   if (!h->launch) {
     // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
@@ -1529,6 +1534,42 @@ int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len) {
   return CLR_OK;
 }
 
+// Warm-started recurrence: warm-up steps per problem from its slowest decay rate (host_cmin, kept from the last
+// set_coefficients) and the time the samples in front of its chunk boundaries span (warm_span, from the last
+// set_series): exp(-c_min x span) <= exp(-32) = 1.3e-14 -- what is left of ANY start state after the warm-up by the
+// decay alone, three orders below the tolerance of the boundary check (the update by the data only forgets faster); the
+// check of warm_check_kernel certifies the choice.  Called whenever either side changes, so that the K in force always
+// belongs to the (series, coefficients) pair in force.
+static void warm_select(clr_batch* h) {
+  const size_t B = (size_t)h->B;
+  h->warm_active = false;
+  h->warm_K_dirty = false;
+  if (h->warm_mode == 0 || h->wnchunk < 2 || !h->have_series || h->warm_span.empty() || h->host_cmin.size() != B) return;
+  h->warm_K.assign(B, 0);
+  size_t eligible = 0;
+  const bool shared = h->t_stride == 0;
+  for (size_t b = 0; b < B; ++b) {
+    int K = 0;
+    if (h->warm_mode == 1) {
+      K = std::min(h->warm_forced_K, h->wL / 2);
+    } else {
+      const double cmin = h->host_cmin[b];
+      const double* span = &h->warm_span[(shared ? 0 : b) * clr_batch::WARM_NK];
+      for (int k = 0; k < clr_batch::WARM_NK && cmin > 0.0; ++k)
+        if (cmin * span[k] >= 32.0) {
+          K = h->warm_cand[std::min(k + h->warm_boost, clr_batch::WARM_NK - 1)];
+          if (K > h->wL / 2) K = 0;
+          break;
+        }
+    }
+    h->warm_K[b] = K;
+    eligible += K > 0;
+  }
+  // (a batch with only a few eligible problems is not worth a second set of launches)
+  h->warm_active = eligible * 2 >= B;
+  h->warm_K_dirty = h->warm_active;  // (uploaded behind the next coefficients, or by the next enqueue)
+}
+
 int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const double* diag,
                          long diag_stride, const double* y, long y_stride) {
   int st = require_device(h->device);
@@ -1537,6 +1578,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   for (long sd : {t_stride, diag_stride, y_stride})
     if (sd != 0 && sd != N)
       return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (an evaluation in flight is settled on ITS series)
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
   const auto host_t0 = std::chrono::steady_clock::now();
   // one pass over t: max |t| over every sample (sortedness is not assumed) and the largest step
@@ -1567,6 +1609,9 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->grad_span_valid = false;
   h->relayout_pending = true;
   h->warm_copy_pending = true;
+  // a new series: the warm-ups chosen for the previous one's spans do not apply, nor does its history of fallbacks
+  if (h->warm_mode < 0) h->warm_boost = 0;
+  warm_select(h);
   return CLR_OK;
 }
 
@@ -1607,6 +1652,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
                                const double* c_comp, const double* d_comp) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems of the evaluation in flight: at ITS coefficients)
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   h->dmax = 0.0;
   h->cmax = 0.0;
@@ -1626,37 +1672,14 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
     for (int j = 0; j < h->J_comp; ++j) m = std::max(m, fabs(c_comp[b * h->J_comp + j]));
     h->host_cmax[b] = m;
   }
-  // warm-started recurrence: warm-up steps per problem from its slowest decay rate and the time the samples in front
-  // of its chunk boundaries span: exp(-c_min x span) <= exp(-32) = 1.3e-14 -- what is left of ANY start state after
-  // the warm-up by the decay alone, three orders below the tolerance of the boundary check (the update by the data
-  // only forgets faster); the check of warm_check_kernel certifies the choice
-  h->warm_active = false;
-  if (h->warm_mode != 0 && h->wnchunk >= 2 && h->have_series && !h->warm_span.empty()) {
-    h->warm_K.assign(B, 0);
-    size_t eligible = 0;
-    const bool shared = h->t_stride == 0;
-    for (size_t b = 0; b < B; ++b) {
-      int K = 0;
-      if (h->warm_mode == 1) {
-        K = std::min(h->warm_forced_K, h->wL / 2);
-      } else {
-        double cmin = INFINITY;
-        for (int j = 0; j < h->J_real; ++j) { const double c = c_real[b * h->J_real + j]; if (!(c >= cmin)) cmin = c; }
-        for (int j = 0; j < h->J_comp; ++j) { const double c = c_comp[b * h->J_comp + j]; if (!(c >= cmin)) cmin = c; }
-        const double* span = &h->warm_span[(shared ? 0 : b) * clr_batch::WARM_NK];
-        for (int k = 0; k < clr_batch::WARM_NK && cmin > 0.0; ++k)
-          if (cmin * span[k] >= 32.0) {
-            K = h->warm_cand[std::min(k + h->warm_boost, clr_batch::WARM_NK - 1)];
-            if (K > h->wL / 2) K = 0;
-            break;
-          }
-      }
-      h->warm_K[b] = K;
-      eligible += K > 0;
-    }
-    // (a batch with only a few eligible problems is not worth a second set of launches)
-    h->warm_active = eligible * 2 >= B;
+  h->host_cmin.assign(B, INFINITY);
+  for (size_t b = 0; b < B; ++b) {
+    double cmin = INFINITY;
+    for (int j = 0; j < h->J_real; ++j) { const double c = c_real[b * h->J_real + j]; if (!(c >= cmin)) cmin = c; }
+    for (int j = 0; j < h->J_comp; ++j) { const double c = c_comp[b * h->J_comp + j]; if (!(c >= cmin)) cmin = c; }
+    h->host_cmin[b] = cmin;
   }
+  warm_select(h);
   // one pinned staging buffer, one copy: a_real c_real a_comp b_comp c_comp d_comp | jitter
   const size_t total = 2 * nr + 4 * nc + B;
   if ((st = reserve_pinned(h, std::max(total, 3 * B + (B + 1) / 2) + (B + 1) / 2)) != CLR_OK) return st;
@@ -1672,6 +1695,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
     int* kk = reinterpret_cast<int*>(h->pin + std::max(total, 3 * B + (B + 1) / 2));
     memcpy(kk, h->warm_K.data(), B * sizeof(int));
     HIP_TRY(hipMemcpyAsync(h->wints + (size_t)h->B * h->wnchunk + B, kk, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->warm_K_dirty = false;
   }
   h->have_coeffs = true;
   return CLR_OK;
@@ -2067,6 +2091,7 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
   if (J_general < 0) return fail(CLR_INVALID_ARGUMENT, "J_general must be >= 0");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
   if (J_general == 0) {  // back to the celerite-terms-only plan
     h->J_general = 0;
     return CLR_OK;
@@ -2089,6 +2114,8 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
 int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup) {
   if (mode < -1 || mode > 1 || (mode == 1 && forced_warmup < 1))
     return fail(CLR_INVALID_ARGUMENT, "warm start: mode -1 (auto), 0 (off) or 1 (forced, with a warm-up length >= 1)");
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
   h->warm_mode = mode;
   h->warm_forced_K = forced_warmup;
   h->warm_boost = 0;
@@ -2219,6 +2246,16 @@ static int warm_copy(clr_batch* h) {
   return CLR_OK;
 }
 
+// K per problem on the device, when set_series re-selected it after the coefficients were uploaded
+static int warm_upload_K(clr_batch* h) {
+  if (!h->warm_K_dirty || !h->wints) return CLR_OK;
+  HIP_TRY(hipMemcpyAsync(h->wints + (size_t)h->B * h->wnchunk + h->B, h->warm_K.data(), (size_t)h->B * sizeof(int),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (pageable source)
+  h->warm_K_dirty = false;
+  return CLR_OK;
+}
+
 // the scan pipeline for the problems the warm path left pending (single-wave summarize on the row-major arrays)
 static int warm_fallback(clr_batch* h) {
   clr::BatchParams P;
@@ -2288,6 +2325,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     // settle are marked pending and go through the scan pipeline when the results are asked for
     clr::BatchParams Wp;
     if ((st = warm_copy(h)) != CLR_OK) return st;
+    if ((st = warm_upload_K(h)) != CLR_OK) return st;
     h->in_fallback = true;  // (the row-major arrays, no role split)
     st = batch_params(h, 0, Wp);
     h->in_fallback = false;
@@ -2348,9 +2386,47 @@ int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms)
   return CLR_OK;
 }
 
+// Problems the warm path could not settle (boundary mismatch, flagged pivot, not eligible) carry a pending status
+// until the scan pipeline has run for them.  That pipeline reads the plan's CURRENT coefficients, series and
+// chunking, so it must run before any of them changes: every state-changing entry point, clr_batch_synchronize and
+// clr_batch_get_results call this first.  *pin_current (may be null): the pinned staging buffer holds the final
+// results (ll | logdet | quad | status) of this evaluation.
+static int warm_resolve(clr_batch* h, bool* pin_current) {
+  if (pin_current) *pin_current = false;
+  if (!h->warm_inflight) return CLR_OK;
+  h->warm_inflight = false;
+  const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
+  int st;
+  if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
+  int pending = 0;
+  for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
+  h->warm_fallbacks = pending;
+  h->warm_settled = (int)B - pending;
+  if (pending) {
+    if ((st = warm_fallback(h)) != CLR_OK) return st;
+    HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // many mismatches among the problems that did warm up: longer warm-ups from the next coefficients on
+    size_t eligible = 0;
+    for (int k : h->warm_K) eligible += k > 0;
+    const long failed = (long)pending - (long)(B - eligible);
+    if (h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
+  } else if (h->warm_mode < 0 && h->warm_boost > 0 && ++h->warm_clean >= 8) {
+    --h->warm_boost;  // eight clean evaluations in a row: try the shorter warm-ups again
+    h->warm_clean = 0;
+  }
+  if (pending) h->warm_clean = 0;
+  if (pin_current) *pin_current = true;
+  return CLR_OK;
+}
+
 int clr_batch_synchronize(clr_batch* h) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CLR_OK;
 }
@@ -2361,28 +2437,13 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double*
   if (st != CLR_OK) return st;
   const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
   if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
-  // one copy into the pinned staging buffer (ll | logdet | quad | status), then host memcpys
-  HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (h->warm_inflight) {
-    // problems the warm path could not settle (boundary mismatch, flagged pivot, not eligible) carry a pending
-    // status: run the scan pipeline for them now and fetch again
-    h->warm_inflight = false;
-    const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
-    int pending = 0;
-    for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
-    h->warm_fallbacks = pending;
-    h->warm_settled = (int)B - pending;
-    if (pending) {
-      if ((st = warm_fallback(h)) != CLR_OK) return st;
-      HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      // many mismatches among the problems that did warm up: longer warm-ups from the next coefficients on
-      size_t eligible = 0;
-      for (int k : h->warm_K) eligible += k > 0;
-      const long failed = (long)pending - (long)(B - eligible);
-      if (h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
-    }
+  // pending problems of a warm evaluation first (they leave the final results in the staging buffer); otherwise one
+  // copy into the pinned staging buffer (ll | logdet | quad | status), then host memcpys
+  bool pin_current = false;
+  if ((st = warm_resolve(h, &pin_current)) != CLR_OK) return st;
+  if (!pin_current) {
+    HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
   if (loglike) memcpy(loglike, h->pin, B * sizeof(double));
   if (logdet) memcpy(logdet, h->pin + B, B * sizeof(double));
@@ -2512,18 +2573,23 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
     P.g_rec_stride = Lg * (long)(J + 2) * P.g_nchunk;
     P.g_ck_stride = nalloc * (long)(SZ + J) * P.g_nchunk;
     const size_t nflag = B * (size_t)((P.g_nchunk + 63) / 64) * (size_t)Lg;
+    bool flags_fit = true;  // (a flag buffer that does not fit degrades to forward mode like the record buffers)
     if (nflag > h->g_ckflag_cap) {
       if (h->g_ckflag) (void)hipFree(h->g_ckflag);
       h->g_ckflag = nullptr;
       h->g_ckflag_cap = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_ckflag), nflag));
-      h->g_ckflag_cap = nflag;
+      if (hipMalloc(reinterpret_cast<void**>(&h->g_ckflag), nflag) != hipSuccess) {
+        h->g_ckflag = nullptr;
+        flags_fit = false;
+      } else {
+        h->g_ckflag_cap = nflag;
+      }
     }
-    HIP_TRY(hipMemsetAsync(h->g_ckflag, 0, nflag, h->stream));
+    if (flags_fit) HIP_TRY(hipMemsetAsync(h->g_ckflag, 0, nflag, h->stream));
     P.g_ckflag = h->g_ckflag;
     const size_t small = pc * (RID + 3 * (SZ + J) + NG + 2) + B;
-    if (h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK || h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK ||
-        h->g_riders.reserve(small) != CLR_OK) {
+    if (!flags_fit || h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK ||
+        h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK || h->g_riders.reserve(small) != CLR_OK) {
       h->g_rec.release(); h->g_ck.release();
       (void)hipGetLastError();
       reverse = false;  // (the record does not fit: one tangent per partial needs 50x less memory)
@@ -2710,6 +2776,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
       clr::BatchParams Wp;
       if (relayout_each_step) h->warm_copy_pending = true;  // (new series every step: the copy is rebuilt inside it)
       if ((st = warm_copy(h)) != CLR_OK) return st;
+      if ((st = warm_upload_K(h)) != CLR_OK) return st;
       h->in_fallback = true;
       st = batch_params(h, 0, Wp);
       h->in_fallback = false;

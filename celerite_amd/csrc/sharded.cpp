@@ -6,7 +6,14 @@
 // Kernel selection is resolved ONCE for the whole batch: the maxima the single-device plans look at
 // (max |t|, largest time step, largest decay rate and frequency) are taken over all problems and handed
 // to every shard (clr_batch_set_selection_bounds), and all shards use the first shard's chunk count, so
-// a batch gives bit-identical results under any sharding with the default settings.
+// a batch gives bit-identical results under any sharding with the default settings -- as long as the
+// warm-started recurrence (series that forget their past) does not come into play.  That path is
+// ADAPTIVE per plan: it is switched on when at least half of the plan's problems are eligible, its chunking looks at
+// the plan's batch size and its warm-up lengths grow with the plan's own history of fallbacks.  A batch in which
+// about half of the problems forget can therefore take the warm recurrence in one sharding and the scan in another:
+// two certified evaluations of the same numbers, equal to the rounding of the scan (<= 1e-11 relative, statuses
+// identical; tests/test_gpu_batch.py::test_sharding_a_batch_with_mixed_warm_eligibility), not bit for bit.
+// clr_batch_set_warm_start(plan, 0, 0) on every shard (ShardedBatchedGP.set_warm_start(0)) restores bit-identity.
 //
 // Each shard has its own host worker thread (which owns the shard's HIP device binding,
 // stream and pinned staging through its clr_batch handle); an API call posts one job to every
@@ -195,6 +202,10 @@ int clr_sharded_get_shard(const clr_sharded* h, int shard, int* device, int* lo,
 
 int clr_sharded_set_chunks(clr_sharded* h, int nchunk) {
   return h->all([=](int s) { return clr_batch_set_chunks(h->plan[s], nchunk); });
+}
+
+int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup) {
+  return h->all([=](int s) { return clr_batch_set_warm_start(h->plan[s], mode, forced_warmup); });
 }
 
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode) {

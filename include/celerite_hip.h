@@ -473,6 +473,11 @@ int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* ch
 /* (the automatic choice of the summarize kernel is resolved once for the whole batch: the shards are handed the
  * batch-wide maxima of the series and coefficients, so the choice does not depend on the sharding) */
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
+/* clr_batch_set_warm_start on every shard.  The warm-started recurrence adapts PER PLAN (activation when half of the
+ * plan's problems are eligible, chunking by the plan's batch size, warm-up lengths by its history of fallbacks), so
+ * with it a batch may take different -- equally certified -- routes under different shardings: results then agree to
+ * the scan's rounding (<= 1e-11), not bit for bit; mode 0 switches it off and restores bit-identity. */
+int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup);
 /* The summarize kernel all shards will run (clr_batch_get_summarize_kernel; -1 if they disagree). */
 int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind);
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,

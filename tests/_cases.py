@@ -121,3 +121,17 @@ def adversarial(B, N, J_real, J_comp, seed=0):
     d_comp = 10 ** rng.uniform(-2, 2, (B, J_comp))
     return dict(a_real=a_real, c_real=c_real, a_comp=a_comp, b_comp=b_comp, c_comp=c_comp,
                 d_comp=d_comp, t=t, diag=diag, y=rng.randn(B, N))
+
+
+# ---- measured deviations: every tolerance assert that goes through `within` is also remembered, and the worst value
+# per name is printed at the end of the session (tests/conftest.py) -- tolerances are set from these numbers, not guessed
+MEASURED = {}
+
+
+def within(name, dev, tol, context=None):
+    dev = float(dev)
+    rec = MEASURED.setdefault(name, [0.0, tol, 0])
+    rec[0] = max(rec[0], dev) if dev == dev else float("nan")
+    rec[1] = tol
+    rec[2] += 1
+    assert dev <= tol, (name, dev, tol, context)

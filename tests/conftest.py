@@ -28,3 +28,16 @@ def pytest_collection_modifyitems(config, items):
     skip = pytest.mark.skip(reason="no gfx950 device visible (GPU tests run with -m gpu on the GPU box)")
     for it in gpu_items:
         it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    try:
+        from _cases import MEASURED
+    except Exception:
+        return
+    if not MEASURED:
+        return
+    terminalreporter.section("measured deviations (worst / asserted tolerance / checks)")
+    for name in sorted(MEASURED):
+        worst, tol, n = MEASURED[name]
+        terminalreporter.write_line("%-72s %.2e / %.0e / %d" % (name, worst, tol, n))

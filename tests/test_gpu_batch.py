@@ -13,7 +13,7 @@ import pytest
 
 from celerite_amd import batch
 from oracle import ref
-from _cases import ALL_WIDTH_SHAPES, synthetic, adversarial, coeffs_of
+from _cases import ALL_WIDTH_SHAPES, synthetic, adversarial, coeffs_of, within
 
 pytestmark = pytest.mark.gpu
 REL = 1e-10
@@ -292,7 +292,9 @@ def test_adversarial_problems_keep_the_reference_status():
     states checked against the scan (level 1) or one lane walking the whole series (level 2) --
     where the remaining deviation from the CPU oracle is the problem's own conditioning times the
     libm / FMA rounding differences: asserted against a bound that scales with the recorded gamma
-    (10 gamma^2 eps, at least 1e-9, at most 1e-3; gamma reaches 1e10 here)."""
+    (gamma^2 eps / 20, at least the 1e-10 bar itself, at most 1e-3; gamma reaches 1e10 here; round 4: 220x tighter than
+    round 3's 10 gamma^2 eps, set from the measured worst ratio 1.4e-5 of that bound -- the end-of-session report of
+    tests/conftest.py prints the worst deviation / bound per route)."""
     shapes = [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (2, 2), (2, 3), (0, 4), (4, 2), (8, 0), (3, 0)]
     n_bad = n_total = 0
     n_level = [0, 0, 0]
@@ -320,13 +322,15 @@ def test_adversarial_problems_keep_the_reference_status():
                 n_level[levels[p]] += 1
                 worst[levels[p]] = max(worst[levels[p]], dev)
                 if levels[p] == 0:
-                    assert dev <= REL, (trial, nchunk, p, dev)
+                    within("adversarial family, route 0 (chunk summaries): deviation from the oracle", dev, REL,
+                           (trial, nchunk, p))
                 else:
                     # the reference recurrence itself, whose distance from the CPU oracle follows the recorded
                     # cancellation gamma = max a_n / D_n: within 10 gamma^2 eps over the calibration set
                     # (profiles/r03_conditioning_calibration.txt: dev / (gamma^2 eps) <= 1.3 above gamma = 1e3)
-                    bound = min(1e-3, max(1e-9, 2.2e-15 * gamma[p] ** 2))
-                    assert dev < bound, (trial, nchunk, p, dev, gamma[p], levels[p])
+                    bound = min(1e-3, max(1e-10, 1e-17 * gamma[p] ** 2))
+                    within("adversarial family, route %d: deviation / gamma-scaled bound" % levels[p], dev / bound,
+                           1.0, (trial, nchunk, p, dev, gamma[p]))
         plan.close()
     assert n_bad >= 6 and n_level[0] > 20 and n_level[1] + n_level[2] > 20, (n_bad, n_level)
 
@@ -589,6 +593,79 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
             assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), S
 
 
+def test_sharding_a_batch_with_mixed_warm_eligibility():
+    """The warm-started recurrence adapts per plan (activation when half of the plan's problems are eligible), so a
+    batch in which half of the series forget their past may take it in one sharding and the scan in another: statuses
+    must be identical and values equal to the scan's rounding; with the warm start switched off on every shard the
+    results are bit-identical again (csrc/sharded.cpp header)."""
+    B, N, JR, JC = 12, 6000, 2, 3
+    a, b = synthetic(B, N, JR, JC, "accuracy", seed=21), synthetic(B, N, JR, JC, "bench", seed=22)
+    case = dict(a)
+    for k in ("t", "diag", "y"):
+        case[k] = np.where((np.arange(B) % 3 == 0)[:, None], b[k], a[k])      # every third series is dense
+    case["a_real"][5] *= -30.0
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    ndev = batch.device_count()
+    outs = {}
+    for warm in (-1, 0):
+        for S in (1, 2, 3, 4):
+            sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+            try:
+                sp.set_chunks(16)
+                sp.set_warm_start(warm)
+                sp.set_series(case["t"], case["diag"], case["y"])
+                outs[warm, S] = sp.evaluate(*coeffs_of(case))
+            finally:
+                sp.close()
+            ll, ld, q, st = outs[warm, S]
+            ok = s0 == 0
+            assert np.array_equal(st, s0), (warm, S)
+            within("mixed warm eligibility, %s: vs oracle" % ("warm auto" if warm else "warm off"),
+                   max(np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok]))), REL)
+            ref_out = outs[warm, 1]
+            if warm == 0:
+                for x, y_ in zip(outs[warm, S], ref_out):
+                    assert np.array_equal(x, y_, equal_nan=True), S
+            else:
+                within("mixed warm eligibility, warm auto: sharded vs unsharded",
+                       max(np.max(np.abs(ld[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])),
+                           np.max(np.abs(q[ok] - ref_out[2][ok]) / np.abs(ref_out[2][ok]))), 1e-11)
+
+
+def test_state_changes_settle_a_warm_evaluation_in_flight_first():
+    """enqueue(k); set_coefficients(k + 1) / set_series / set_chunks; results(): the problems the warm path left
+    pending are resolved by the scan pipeline BEFORE the plan's state changes, i.e. at draw k's coefficients and
+    series (round 3 resolved them at fetch time, with whatever the plan then held: a silent mix of two draws)."""
+    B, N, JR, JC = 8, 6000, 2, 3
+    a, b = synthetic(B, N, JR, JC, "accuracy", seed=31), synthetic(B, N, JR, JC, "bench", seed=32)
+    case = dict(a)
+    for k in ("t", "diag", "y"):
+        case[k] = np.where((np.arange(B) % 4 == 0)[:, None], b[k], a[k])      # two dense series: never warm-eligible
+    other = synthetic(B, N, JR, JC, "accuracy", seed=33)
+    want = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    for change in ("coefficients", "series", "synchronize"):
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_chunks(16)
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            plan.enqueue()
+            info = plan.warm_start()
+            assert info["active"], info          # the warm path ran; the dense series are pending
+            if change == "coefficients":
+                plan.set_coefficients(*coeffs_of(other))
+            elif change == "series":
+                plan.set_series(other["t"], other["diag"], other["y"])
+            else:
+                plan.synchronize()
+            ll, ld, q, st = plan.results()
+        finally:
+            plan.close()
+        assert np.array_equal(st, want[3]), change
+        within("warm evaluation settled before a state change: vs oracle",
+               max(np.max(np.abs(ld - want[1]) / np.abs(want[1])), np.max(np.abs(q - want[2]) / np.abs(want[2]))), REL, change)
+
+
 def test_sharded_gradient_equals_the_unsharded_one():
     """clr_sharded_grad: every shard's plan gradient concurrently; with the chunk count pinned the numbers are the
     unsharded plan's bit for bit (per-problem work, batch-wide kernel selection), statuses included."""
@@ -760,25 +837,77 @@ def _full_shape(B, N, JR, JC, sample, d_spread=False, seed=11):
         assert np.array_equal(ll, ll2) and np.array_equal(ld, ld2) and np.array_equal(q, q2)
     finally:
         plan.close()
-    S = sample
-    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[:S] for c in coeffs], t[:S], diag[:S], y[:S])
+    # the oracle on `sample` problems (None: ALL of them, one oracle thread per host core: 11 ms per problem at
+    # width 8, 71 ms at width 32 -- under a second of wall clock on the GPU box's 256 threads)
+    S = B if sample is None else sample
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[:S] for c in coeffs], t[:S], diag[:S], y[:S],
+                                              nthreads=os.cpu_count() or 1)
     assert np.array_equal(st[:S], s0)
-    assert np.max(np.abs(ld[:S] - d0) / np.abs(d0)) <= REL
-    assert np.max(np.abs(q[:S] - q0) / np.abs(q0)) <= REL
+    e_ld = float(np.max(np.abs(ld[:S] - d0) / np.abs(d0)))
+    e_q = float(np.max(np.abs(q[:S] - q0) / np.abs(q0)))
+    print("full shape B=%d N=%d width %d: %d problems against the oracle, log det %.2e, quadratic form %.2e"
+          % (B, N, JR + 2 * JC, S, e_ld, e_q))
+    assert e_ld <= REL and e_q <= REL
     return levels
 
 
 def test_config3_full_shape():
     """BASELINE config 3 per GPU at full size: batch 1024, N = 1e5, width 8 (2 real + 3 complex);
-    the oracle on a sample of 8 problems, properties over all 1024."""
-    levels = _full_shape(1024, 100000, 2, 3, sample=8, seed=42)
+    the oracle on ALL 1024 problems, properties over all 1024."""
+    levels = _full_shape(1024, 100000, 2, 3, sample=None, seed=42)
     assert (levels == 0).all()   # the headline family is settled from the chunk summaries alone
+
+
+def test_config4_b8192_as_eight_shards():
+    """BASELINE configs[3] at ITS size: batch 8192 (8 hyper-parameter draws x 1024 series), N = 1e5, width 8, as the
+    eight 1024-problem shards of the 8-GPU run -- on however many MI355X are visible (shard s on device s mod ndev; on a
+    one-GPU box all eight share it: 20 GB of series + 20 GB of chunk-interleaved copies + workspaces in HBM).  Every
+    1024-slice must equal the unsharded 1024-problem plan bit for bit (per-problem work, batch-wide kernel selection,
+    chunking of a 1024-problem shard; state per problem: cholesky.h:703-706), a sample of every shard the oracle, and
+    the whole batch the size-independent properties of `_full_shape`."""
+    import bench
+    B1, S, N, JR, JC = 1024, 8, 100000, 2, 3
+    coeffs, t1, diag1, y1 = bench.make_inputs(B1, N, JR, JC, 42)
+    draws = [coeffs] + bench.fresh_draws(coeffs, S - 1, seed=1042)
+    big = [np.concatenate([d[i] for d in draws], axis=0) for i in range(6)]
+    t, diag, y = (np.tile(a, (S, 1)) for a in (t1, diag1, y1))
+    ndev = batch.device_count()
+    sp = batch.ShardedBatchedGP(S * B1, N, JR, JC, devices=[s % ndev for s in range(S)])
+    try:
+        assert [(lo, hi) for _, lo, hi in sp.shards] == [(s * B1, (s + 1) * B1) for s in range(S)]
+        sp.set_series(t, diag, y)
+        del t, diag, y
+        ll, ld, q, st = sp.evaluate(*big)
+        ll2, ld2, q2, st2 = sp.evaluate(*big)
+        kernel = sp.summarize_kernel()
+    finally:
+        sp.close()
+    assert (st == 0).all() and np.isfinite(ll).all() and (q > 0).all()
+    assert np.allclose(ll, -0.5 * (q + ld + N * np.log(2 * np.pi)), rtol=1e-14, atol=0)
+    assert np.array_equal(ll, ll2) and np.array_equal(ld, ld2) and np.array_equal(q, q2)
+    plan = batch.BatchedGP(B1, N, JR, JC)
+    try:
+        plan.set_series(t1, diag1, y1)
+        for s in range(S):
+            plan.set_coefficients(*draws[s])
+            want = plan.log_likelihood()
+            sl = slice(s * B1, (s + 1) * B1)
+            for a, b in zip(want, (ll[sl], ld[sl], q[sl], st[sl])):
+                assert np.array_equal(a, b), s
+        assert plan.summarize_kernel() == kernel
+    finally:
+        plan.close()
+    idx = np.concatenate([s * B1 + np.arange(0, B1, 64) for s in range(S)])   # 16 problems of every shard
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *[c[idx] for c in big], t1[idx % B1], diag1[idx % B1], y1[idx % B1],
+                                              nthreads=os.cpu_count() or 1)
+    assert np.array_equal(st[idx], s0)
+    assert np.max(np.abs(ld[idx] - d0) / np.abs(d0)) <= REL and np.max(np.abs(q[idx] - q0) / np.abs(q0)) <= REL
 
 
 def test_config5_full_shape():
     """BASELINE config 5 at full size: batch 256, N = 1e5, width 32 (16 complex terms, log d ~ U(0, 3));
-    the oracle on a sample of 4 problems (71 ms each), properties over all 256."""
-    levels = _full_shape(256, 100000, 0, 16, sample=4, d_spread=True, seed=11)
+    the oracle on ALL 256 problems (71 ms each on one core), properties over all 256."""
+    levels = _full_shape(256, 100000, 0, 16, sample=None, d_spread=True, seed=11)
     # round 3: the conditioning record is tested as gamma < 1e4, gamma / mu < 1e7 and gamma x (measured error of G)
     # < 3e-9 (profiles/r03_conditioning_calibration.txt); this family sits at gamma ~ 1.3e3, mu 8e-4 .. 2e-2, measured
     # error ~ 3e-13: every problem is settled from the chunk summaries (round 2 sent 45 of 256 through the replay)
@@ -838,8 +967,9 @@ def test_batched_grad_log_likelihood(JR, JC, N, shared):
         assert np.allclose(grad[b], g1, rtol=1e-11, atol=1e-13)
         if b in (0, B - 1):
             v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, tb, yb, db)
-            assert abs(value[b] - v0) <= 1e-10 * abs(v0)
-            assert np.allclose(grad[b], g0, rtol=1e-8, atol=1e-10)
+            within("one-shot gradient: value vs oracle", abs(value[b] - v0) / abs(v0), 1e-10)
+            within("one-shot gradient: partials vs oracle (of the largest partial)",
+                   np.max(np.abs(grad[b] - g0)) / np.max(np.abs(g0)), 1e-10)
     assert (st == 2).sum() >= 1
 
 
@@ -876,9 +1006,11 @@ def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
             assert info["reverse"] == (mode != "forward") and info["forward_reruns"] == 0, info
             assert np.array_equal(st, st_seq) and st[3] == 2 and np.isneginf(v[3]) and not g[3].any()
             ok = st == 0
-            assert np.max(np.abs(v[ok] - v_seq[ok]) / np.abs(v_seq[ok])) <= 1e-11, nchunk
-            scale = np.maximum(np.abs(g_seq[ok]), 1e-6 * np.max(np.abs(g_seq[ok]), axis=1, keepdims=True))
-            assert np.max(np.abs(g[ok] - g_seq[ok]) / scale) <= 1e-8, (nchunk, np.max(np.abs(g[ok] - g_seq[ok]) / scale))
+            within("plan gradient %s: value vs sequential kernel" % mode,
+                   np.max(np.abs(v[ok] - v_seq[ok]) / np.abs(v_seq[ok])), 1e-11, nchunk)
+            scale = np.max(np.abs(g_seq[ok]), axis=1, keepdims=True)
+            within("plan gradient %s / %s: partials vs sequential kernel (of the largest partial)" % (mode, family),
+                   np.max(np.abs(g[ok] - g_seq[ok]) / scale), 1e-10, nchunk)
             assert (g[jit <= 2.3e-16, 0] == 0.0).all()          # solver.cpp:379-389
             assert plan.grad_fallbacks() == 0
     finally:
@@ -890,8 +1022,9 @@ def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
     b = 1
     co = [c[b] for c in coeffs_of(case)]
     v0, g0 = ograd.grad_log_likelihood(jit[b], *co, empty, empty2, empty2, case["t"][b], case["y"][b], case["diag"][b])
-    assert abs(v1[b] - v0) <= 1e-10 * abs(v0)
-    assert np.allclose(g1[b], g0, rtol=1e-8, atol=1e-8 * np.max(np.abs(g0)))
+    within("plan gradient: value vs oracle", abs(v1[b] - v0) / abs(v0), 1e-10)
+    within("plan gradient %s / %s: partials vs oracle (of the largest partial)" % (mode, family),
+           np.max(np.abs(g1[b] - g0)) / np.max(np.abs(g0)), 1e-10)
 
 
 @pytest.mark.parametrize("mode", ["reverse", "forward"])
@@ -919,14 +1052,17 @@ def test_plan_gradient_full_size_against_the_oracle_fixture(mode):
     finally:
         plan.close()
     assert abs(v[0] - gold["value"]) <= 1e-10 * abs(gold["value"])
-    # per partial: 1e-8 relative (the jitter partial is 1.8e5, the others 40 .. 320: a common scale would hide them)
-    tol = 1e-8 * np.abs(g0) + 1e-12 * np.max(np.abs(g0))
+    # per partial, relative (the jitter partial is 1.8e5, the others 40 .. 320: a common scale would hide them)
+    tol = 1e-10 * np.abs(g0) + 1e-13 * np.max(np.abs(g0))
+    within("N = 1e5 gradient %s: worst partial vs oracle fixture (relative to that partial)" % mode,
+           np.max(np.abs(g[0] - g0) / np.abs(g0)), 1e-10)
     assert (np.abs(g[0] - g0) <= tol).all(), np.abs(g[0] - g0) / np.abs(g0)
     if mode == "reverse":
         e, e2 = np.empty(0), np.empty((0, 0))
         v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(gold["jitter"], *[c[0] for c in coeffs], e, e2, e2,
                                                                    t[0], y[0], diag[0])
         assert abs(v1 - gold["value"]) <= 1e-10 * abs(gold["value"])
+        within("N = 1e5 gradient, object API: worst partial vs oracle fixture", np.max(np.abs(g1 - g0) / np.abs(g0)), 1e-10)
         assert (np.abs(g1 - g0) <= tol).all(), np.abs(g1 - g0) / np.abs(g0)
 
 
@@ -997,8 +1133,9 @@ def test_plan_gradient_every_width_shape(JR, JC):
         plan.close()
     assert np.array_equal(st, st0) and (st == 0).all()
     assert info["reverse"] and info["forward_reruns"] == 0, info
-    assert np.max(np.abs(v - v0) / np.abs(v0)) <= 1e-11
-    assert np.max(np.abs(g - g0) / np.max(np.abs(g0), axis=1, keepdims=True)) <= 1e-9
+    within("shared-series gradient: value", np.max(np.abs(v - v0) / np.abs(v0)), 1e-11)
+    within("shared-series gradient: partials (of the largest partial)",
+           np.max(np.abs(g - g0) / np.max(np.abs(g0), axis=1, keepdims=True)), 1e-10)
     assert g[0, 0] == 0.0 and (g[1:, 0] != 0.0).all()       # d / d jitter is zeroed at jitter = 0 only (solver.cpp:379-389)
 
 
@@ -1048,19 +1185,20 @@ def test_reverse_gradient_certifies_its_reconstructed_states():
         v1, g1, st1 = plan.grad_log_likelihood()
         info = plan.grad_info()
         assert info["reverse"] and info["forward_reruns"] == 0 and info["drift_max"] <= 1e-9, info
-        assert np.max(np.abs(g1 - g0) / scale) <= 1e-9
+        within("reverse vs forward gradient, host-chosen stored states", np.max(np.abs(g1 - g0) / scale), 1e-10)
+        within("reverse gradient: reported drift", info["drift_max"], 1e-9)
         plan.set_grad_mode("reverse", stored_state_distance=4)     # a few steps between stored states: still fine
         v4, g4, st4 = plan.grad_log_likelihood()
-        assert np.max(np.abs(g4 - g0) / scale) <= 1e-9
+        within("reverse vs forward gradient, stored states every 4 steps", np.max(np.abs(g4 - g0) / scale), 1e-10)
         plan.set_grad_mode("reverse", stored_state_distance=750)   # one stored state per chunk: far too few here
         v2, g2, st2 = plan.grad_log_likelihood()
         info = plan.grad_info()
         assert info["reverse"] and info["forward_reruns"] >= 1, info
-        assert np.max(np.abs(g2 - g0) / scale) <= 1e-9
+        within("reverse vs forward gradient, too few stored states (forward reruns)", np.max(np.abs(g2 - g0) / scale), 1e-10)
         plan.set_grad_mode("reverse", stored_state_distance=1)     # every state stored: nothing to reconstruct
         v3, g3, st3 = plan.grad_log_likelihood()
         assert plan.grad_info()["forward_reruns"] == 0
-        assert np.max(np.abs(g3 - g0) / scale) <= 1e-9
+        within("reverse vs forward gradient, every state stored", np.max(np.abs(g3 - g0) / scale), 1e-10)
     finally:
         plan.close()
 
@@ -1103,8 +1241,9 @@ def test_plan_gradient_full_size_directional_derivative():
         v2, g2, st2 = batch.batch_grad_log_likelihood(*[c[:2] for c in coeffs], t[:2], diag[:2], y[:2], jitter=jit[:2])
     finally:
         del os.environ["CLR_GRAD_SEQUENTIAL"]
-    assert np.max(np.abs(v[:2] - v2) / np.abs(v2)) <= 1e-11
-    assert np.max(np.abs(g[:2] - g2)) <= 1e-8 * np.max(np.abs(g2))
+    within("full-size gradient vs sequential kernel: value", np.max(np.abs(v[:2] - v2) / np.abs(v2)), 1e-11)
+    within("full-size gradient vs sequential kernel: partials (of the largest)",
+           np.max(np.abs(g[:2] - g2)) / np.max(np.abs(g2)), 1e-10)
 
 
 @pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13)])
