@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 __all__ = ["BatchedGP", "ShardedBatchedGP", "shard_bounds", "batch_log_likelihood", "batch_grad_log_likelihood",
-           "kernel_coefficient_table", "LIB_PATH"]
+           "kernel_coefficient_table", "kernel_coefficient_jacobian_table", "chain_gradient", "LIB_PATH"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcelerite_hip.so")
 
@@ -706,3 +706,37 @@ def kernel_coefficient_table(kernel, parameter_vectors):
         raise ValueError("the draws do not share one (J_real, J_comp) shape")
     blocks = [np.array([r[i] for r in rows]).reshape(len(rows), -1) for i in range(6)]
     return tuple(blocks) + (np.array(jit),)
+
+
+def kernel_coefficient_jacobian_table(kernel, parameter_vectors):
+    """The chain rule's other half for :func:`kernel_coefficient_table`: for every draw the Jacobian of the
+    coefficients with respect to the kernel's (unfrozen) parameters.
+
+    Returns ``(jac, jitter_jac)``: ``jac[b, p, c]`` = d coefficient ``c`` / d parameter ``p`` with the coefficients
+    in the order of the batched gradient's columns 1.. (``a_real, c_real, a_comp, b_comp, c_comp, d_comp``, each
+    block contiguous: ``Term.get_coeffs_jacobian``, terms.py:206-215) and ``jitter_jac[b, p]`` = d jitter / d
+    parameter (``get_jitter_jacobian``, :197-204).  Built-in terms need no autograd (their formulas are evaluated
+    on dual numbers, ``terms._dual_coefficients``)."""
+    saved = kernel.get_parameter_vector()
+    jac, jit = [], []
+    try:
+        for p in np.atleast_2d(parameter_vectors):
+            kernel.set_parameter_vector(p)
+            if kernel._has_coeffs:
+                jac.append(np.asarray(kernel.get_coeffs_jacobian(), dtype=np.float64))
+            else:
+                jac.append(np.zeros((len(p), 0)))
+            jit.append(np.asarray(kernel.get_jitter_jacobian(), dtype=np.float64) if kernel._has_jitter
+                       else np.zeros(len(p)))
+    finally:
+        kernel.set_parameter_vector(saved)
+    return np.array(jac), np.array(jit)
+
+
+def chain_gradient(grad, jac, jitter_jac):
+    """``d loglike / d parameters`` of every draw, ``[B, P]``, from the batched coefficient gradient ``grad``
+    (``[B, 1 + 2 J_real + 4 J_comp]``: column 0 the jitter partial, as ``BatchedGP.grad_log_likelihood`` returns
+    it) and the tables of :func:`kernel_coefficient_jacobian_table` (what ``GP.grad_log_likelihood`` does for one
+    problem, celerite.py:286-305)."""
+    grad = np.asarray(grad, dtype=np.float64)
+    return np.einsum("bpc,bc->bp", jac, grad[:, 1:]) + jitter_jac * grad[:, :1]

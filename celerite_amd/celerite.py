@@ -191,9 +191,10 @@ class GP(ModelSet):
         the coefficients runs on the device (``solver.has_autodiff()`` is True:
         csrc/grad_kernels.hip, the counterpart of solver.cpp:347-463, including
         its ``pi * log(N)`` constant).  The chain rule through the term
-        parameters needs ``autograd`` for ``get_coeffs_jacobian`` /
-        ``get_jitter_jacobian`` exactly as the reference does (terms.py:197-215):
-        without it those raise ``ImportError`` (tests/test_celerite.py:441-446).
+        parameters (``get_coeffs_jacobian`` / ``get_jitter_jacobian``, terms.py:197-215)
+        needs no ``autograd`` for the built-in terms and their sums / products -- their
+        formulas are evaluated on dual numbers (``terms._dual_coefficients``); a
+        user-defined term needs it exactly as in the reference (``ImportError`` without).
         """
         if not solver.has_autodiff():
             raise RuntimeError("celerite must be compiled with autodiff "

@@ -609,37 +609,42 @@ __device__ __forceinline__ void split_riders_lazy(int L, int n0, int N, bool sto
   }
 }
 
-// 8 waves: 4 sets (problem b, block x of 64 chunks), one T and one R wave per set.
-template <int JR, int JC, bool FAST, bool LAZY>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// SETS == 4: 8 waves = 4 sets (problem b, block x of 64 chunks), one T and one R wave per set, the per-step barrier
+// spans all 8 waves.  SETS == 1 (round 4 A/B, profiles/r04g_split_wg_ab.txt): one set per 128-thread workgroup -- the
+// barrier couples only the T and R wave that actually exchange data; four workgroups per CU.
+template <int JR, int JC, bool FAST, bool LAZY, int SETS = 4>
+__global__ void __launch_bounds__(128 * SETS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 summarize_split_kernel(const BatchParams P) {
   using Wd = Widths<JR, JC>;
   using Lk = SplitLink<JR, JC>;
   using LkL = SplitLinkLazy<JR, JC>;
   constexpr int NPAY = LAZY ? LkL::NPAY : Lk::NPAY;
-  __shared__ double ring[4][2 * NPAY * 64];  // two slots per set: T fills one while R reads the other
-  __shared__ double psibuf[LAZY ? 4 : 1][(LAZY ? LkL::M : 1) * 64];  // Psi of the renormalisation steps
-  __shared__ double2 jmbuf[4][Lk::NJM * 64];
-  int* placed = reinterpret_cast<int*>(&jmbuf[0][0]);  // (LDS is full: borrowed until the roles are fixed)
+  __shared__ double ring[SETS][2 * NPAY * 64];  // two slots per set: T fills one while R reads the other
+  __shared__ double psibuf[LAZY ? SETS : 1][(LAZY ? LkL::M : 1) * 64];  // Psi of the renormalisation steps
+  __shared__ double2 jmbuf[SETS][Lk::NJM * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (threadIdx.x < 4) placed[threadIdx.x] = 0;
-  __syncthreads();
-  // role from the SIMD this wave actually runs on: first arrival = trajectory, second = riders
-  const int simd = hw_simd_id();
-  int slot_id = 0;
-  if (lane == 0) slot_id = atomicAdd(&placed[simd], 1);
-  slot_id = __builtin_amdgcn_readfirstlane(slot_id);
-  __syncthreads();
-  const int balanced = __builtin_amdgcn_readfirstlane(
-      (placed[0] == 2 && placed[1] == 2 && placed[2] == 2 && placed[3] == 2) ? 1 : 0);
-  // (everything below is wave-uniform: keep it in SGPRs so that the hyper-parameters are scalar loads)
-  const int set = __builtin_amdgcn_readfirstlane(balanced ? simd : (wave & 3));
-  const int role = __builtin_amdgcn_readfirstlane(balanced ? slot_id : (wave >> 2));  // 0 = T, 1 = R
-  __syncthreads();  // (everybody has read `placed`: the riders may now clear their Jm cells)
+  int set = 0, role = wave;  // (SETS == 1: the first wave is the trajectory, the second the riders)
+  if (SETS == 4) {
+    int* placed = reinterpret_cast<int*>(&jmbuf[0][0]);  // (LDS is full: borrowed until the roles are fixed)
+    if (threadIdx.x < 4) placed[threadIdx.x] = 0;
+    __syncthreads();
+    // role from the SIMD this wave actually runs on: first arrival = trajectory, second = riders
+    const int simd = hw_simd_id();
+    int slot_id = 0;
+    if (lane == 0) slot_id = atomicAdd(&placed[simd], 1);
+    slot_id = __builtin_amdgcn_readfirstlane(slot_id);
+    __syncthreads();
+    const int balanced = __builtin_amdgcn_readfirstlane(
+        (placed[0] == 2 && placed[1] == 2 && placed[2] == 2 && placed[3] == 2) ? 1 : 0);
+    // (everything below is wave-uniform: keep it in SGPRs so that the hyper-parameters are scalar loads)
+    set = __builtin_amdgcn_readfirstlane(balanced ? simd : (wave & 3));
+    role = __builtin_amdgcn_readfirstlane(balanced ? slot_id : (wave >> 2));  // 0 = T, 1 = R
+    __syncthreads();  // (everybody has read `placed`: the riders may now clear their Jm cells)
+  }
 
   const int nblk = (P.nchunk + 63) / 64;
-  const long g = (long)blockIdx.x * 4 + set;
+  const long g = (long)blockIdx.x * SETS + set;
   const bool live = g < (long)P.B * nblk;
   const int b = live ? (int)(g / nblk) : 0;
   const int xblk = live ? (int)(g % nblk) : 0;
@@ -687,8 +692,11 @@ template <int JR, int JC>
 inline void launch_split_shape(const BatchParams& P, hipStream_t s) {
   const int nblk = (P.nchunk + 63) / 64;
   const long sets = (long)P.B * nblk;
-  const dim3 grid((unsigned)((sets + 3) / 4)), block(512);
-#define CLR_GO(F, Z) hipLaunchKernelGGL((summarize_split_kernel<JR, JC, F, Z>), grid, block, 0, s, P)
+#ifndef CLR_SPLIT_SETS
+#define CLR_SPLIT_SETS 4
+#endif
+  const dim3 grid((unsigned)((sets + CLR_SPLIT_SETS - 1) / CLR_SPLIT_SETS)), block(128 * CLR_SPLIT_SETS);
+#define CLR_GO(F, Z) hipLaunchKernelGGL((summarize_split_kernel<JR, JC, F, Z, CLR_SPLIT_SETS>), grid, block, 0, s, P)
   if (P.split_lazy) { if (P.fast_trig) CLR_GO(true, true); else CLR_GO(false, true); }
   else              { if (P.fast_trig) CLR_GO(true, false); else CLR_GO(false, false); }
 #undef CLR_GO

@@ -37,6 +37,89 @@ _EMPTY2 = lambda: (np.empty(0), np.empty(0))
 _EMPTY4 = lambda: (np.empty(0), np.empty(0), np.empty(0), np.empty(0))
 
 
+# ---- forward-mode derivatives of the coefficient formulas -----------------------------------------------------
+# The reference obtains d(coefficients) / d(parameters) from autograd (terms.py:197-215) and raises ImportError
+# without it.  autograd is not part of the MI355X image, and the device gradient (clr_batch_grad /
+# CholeskySolver.grad_log_likelihood) is with respect to the COEFFICIENTS: the chain rule to the kernel's
+# log-parameters is closed here, by evaluating the built-in terms' own formulas on dual numbers (value + gradient
+# with respect to the full parameter vector) -- exact to rounding, no finite differences.  User-defined terms still
+# go through autograd, exactly as in the reference.
+import numpy as _np
+
+
+class _Dual(object):
+    """value + gradient (1-D array over the full parameter vector); just the arithmetic the term formulas use"""
+    __slots__ = ("v", "g")
+    __array_priority__ = 1000.0
+
+    def __init__(self, v, g):
+        self.v = float(v)
+        self.g = g
+
+    @staticmethod
+    def lift(x, n):
+        return x if isinstance(x, _Dual) else _Dual(x, _np.zeros(n))
+
+    def _o(self, other):
+        return other if isinstance(other, _Dual) else _Dual(other, _np.zeros_like(self.g))
+
+    def __add__(self, o):
+        o = self._o(o)
+        return _Dual(self.v + o.v, self.g + o.g)
+    __radd__ = __add__
+
+    def __neg__(self):
+        return _Dual(-self.v, -self.g)
+
+    def __sub__(self, o):
+        o = self._o(o)
+        return _Dual(self.v - o.v, self.g - o.g)
+
+    def __rsub__(self, o):
+        return self._o(o) - self
+
+    def __mul__(self, o):
+        o = self._o(o)
+        return _Dual(self.v * o.v, self.v * o.g + o.v * self.g)
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        o = self._o(o)
+        return _Dual(self.v / o.v, (self.g - (self.v / o.v) * o.g) / o.v)
+
+    def __rtruediv__(self, o):
+        return self._o(o) / self
+
+
+def _dexp(x):
+    e = _np.exp(x.v)
+    return _Dual(e, e * x.g)
+
+
+def _dsqrt(x):
+    r = _np.sqrt(x.v)
+    return _Dual(r, x.g / (2.0 * r))
+
+
+def _dual_params(values):
+    n = len(values)
+    eye = _np.eye(n)
+    return [_Dual(values[i], eye[i]) for i in range(n)]
+
+
+def _embed(blocks, offset, total):
+    """gradients of a sub-term's coefficients (w.r.t. its own parameters) inside the parent's parameter vector"""
+    out = []
+    for blk in blocks:
+        row = []
+        for x in blk:
+            g = _np.zeros(total)
+            g[offset:offset + len(x.g)] = x.g
+            row.append(_Dual(x.v, g))
+        out.append(row)
+    return out
+
+
 class Term(Model):
     """Base class: an empty kernel.  Subclasses override
     :meth:`get_real_coefficients` and/or :meth:`get_complex_coefficients`."""
@@ -114,19 +197,45 @@ class Term(Model):
     def jitter(self):
         return self.get_jitter(self.get_parameter_vector(include_frozen=True))
 
-    # -- Jacobians (autograd-gated exactly like the reference, terms.py:197-215) ---------
+    # -- Jacobians (terms.py:197-215) --------------------------------------------------------
+    # Built-in terms (and sums / products of them): their formulas on dual numbers, no dependency.  Anything else:
+    # autograd, exactly like the reference -- ImportError without it.
+    def _dual_coefficients(self, p):
+        """The six coefficient blocks as lists of ``_Dual`` and the jitter as a ``_Dual``, for the parameter duals
+        ``p`` -- or None when this term's formulas are not known here (user-defined terms)."""
+        return None
+
+    def _dual_all(self):
+        vec = _np.asarray(self.get_parameter_vector(include_frozen=True), dtype=float)
+        return self._dual_coefficients(_dual_params(vec)), len(vec)
+
     def get_jitter_jacobian(self, include_frozen=False):
-        if not HAS_AUTOGRAD:
-            raise ImportError("'autograd' must be installed to compute gradients")
-        jac = elementwise_grad(self.get_jitter)(self.get_parameter_vector(include_frozen=True))
+        res, n = self._dual_all()
+        if res is not None:
+            jac = _np.array(_Dual.lift(res[1], n).g, dtype=float)
+        else:
+            if not HAS_AUTOGRAD:
+                raise ImportError("'autograd' must be installed to compute gradients")
+            jac = elementwise_grad(self.get_jitter)(self.get_parameter_vector(include_frozen=True))
         return jac if include_frozen else jac[self.unfrozen_mask]
 
     def get_coeffs_jacobian(self, include_frozen=False):
-        if not HAS_AUTOGRAD:
-            raise ImportError("'autograd' must be installed to compute gradients")
-        flat = lambda p: np.concatenate(self.get_all_coefficients(p))
-        jac = jacobian(flat)(self.get_parameter_vector(include_frozen=True)).T
+        res, n = self._dual_all()
+        if res is not None:
+            flat = [x for blk in res[0] for x in blk]
+            jac = _np.array([x.g for x in flat], dtype=float).reshape(len(flat), n).T
+        else:
+            if not HAS_AUTOGRAD:
+                raise ImportError("'autograd' must be installed to compute gradients")
+            flat = lambda p: np.concatenate(self.get_all_coefficients(p))
+            jac = jacobian(flat)(self.get_parameter_vector(include_frozen=True)).T
         return jac if include_frozen else jac[self.unfrozen_mask]
+
+    def _formulas_are(self, cls):
+        """True when this object's coefficient formulas are the ones `cls` defines (not overridden by a subclass)."""
+        t = type(self)
+        return all(getattr(t, m) is getattr(cls, m)
+                   for m in ("get_real_coefficients", "get_complex_coefficients", "get_all_coefficients", "get_jitter"))
 
 
 class TermSum(Term, ModelSet):
@@ -173,6 +282,22 @@ class TermSum(Term, ModelSet):
         for term, p in self._split(params):
             total += term.get_jitter(p)
         return total
+
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(TermSum):
+            return None
+        n = len(p)
+        blocks, jitter, start = [[] for _ in range(6)], _Dual(0.0, _np.zeros(n)), 0
+        for term in self.models.values():
+            m = term.full_size
+            sub = term._dual_coefficients(_dual_params([x.v for x in p[start:start + m]]))
+            if sub is None:
+                return None
+            for dst, src in zip(blocks, _embed(sub[0], start, n)):
+                dst.extend(src)
+            jitter = jitter + _embed([[_Dual.lift(sub[1], m)]], start, n)[0][0]
+            start += m
+        return blocks, jitter
 
 
 class TermProduct(Term, ModelSet):
@@ -230,6 +355,40 @@ class TermProduct(Term, ModelSet):
 
         return [np.array(block) for block in (ar, cr, ac, bc, cc, dc)]
 
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(TermProduct):
+            return None
+        k1, k2 = self.models["k1"], self.models["k2"]
+        n, n1 = len(p), k1.full_size
+        s1 = k1._dual_coefficients(_dual_params([x.v for x in p[:n1]]))
+        s2 = k2._dual_coefficients(_dual_params([x.v for x in p[n1:]]))
+        if s1 is None or s2 is None:
+            return None
+        ar1, cr1, ac1, bc1, cc1, dc1 = _embed(s1[0], 0, n)
+        ar2, cr2, ac2, bc2, cc2, dc2 = _embed(s2[0], n1, n)
+        reals1, reals2 = list(zip(ar1, cr1)), list(zip(ar2, cr2))
+        comps1, comps2 = list(zip(ac1, bc1, cc1, dc1)), list(zip(ac2, bc2, cc2, dc2))
+        ar, cr, ac, bc, cc, dc = [], [], [], [], [], []
+        for a1, c1 in reals1:                       # (the algebra of get_all_coefficients, on duals)
+            for a2, c2 in reals2:
+                ar.append(a1 * a2)
+                cr.append(c1 + c2)
+        for rs, cs in ((reals1, comps2), (reals2, comps1)):
+            for a1, c1 in rs:
+                for a2, b2, c2, d2 in cs:
+                    ac.append(a1 * a2)
+                    bc.append(a1 * b2)
+                    cc.append(c1 + c2)
+                    dc.append(d2)
+        for a1, b1, c1, d1 in comps1:
+            for a2, b2, c2, d2 in comps2:
+                for sign in (-1.0, 1.0):
+                    ac.append(0.5 * (a1 * a2 - sign * (b1 * b2)))
+                    bc.append(0.5 * (b1 * a2 + sign * (a1 * b2)))
+                    cc.append(c1 + c2)
+                    dc.append(d1 + sign * d2)
+        return [ar, cr, ac, bc, cc, dc], _Dual(0.0, _np.zeros(n))
+
 
 class JitterTerm(Term):
     """White noise ``sigma^2 delta_nm``; parameter ``log_sigma``."""
@@ -244,6 +403,11 @@ class JitterTerm(Term):
     def get_jitter(self, params):
         return np.exp(2.0 * params[0])
 
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(JitterTerm):
+            return None
+        return [[] for _ in range(6)], _dexp(2.0 * p[0])
+
 
 class RealTerm(Term):
     """``a exp(-c tau)``; parameters ``log_a``, ``log_c``."""
@@ -255,6 +419,11 @@ class RealTerm(Term):
 
     def get_real_coefficients(self, params):
         return np.exp(params[0]), np.exp(params[1])
+
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(RealTerm):
+            return None
+        return [[_dexp(p[0])], [_dexp(p[1])], [], [], [], []], 0.0
 
 
 class ComplexTerm(Term):
@@ -284,6 +453,14 @@ class ComplexTerm(Term):
             return np.exp(log_a), np.exp(log_b), np.exp(log_c), np.exp(log_d)
         log_a, log_c, log_d = params
         return np.exp(log_a), 0.0, np.exp(log_c), np.exp(log_d)
+
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(ComplexTerm):
+            return None
+        n = len(p)
+        if self.fit_b:
+            return [[], [], [_dexp(p[0])], [_dexp(p[1])], [_dexp(p[2])], [_dexp(p[3])]], 0.0
+        return [[], [], [_dexp(p[0])], [_Dual(0.0, _np.zeros(n))], [_dexp(p[1])], [_dexp(p[2])]], 0.0
 
     def log_prior(self):
         if self.fit_b and self.log_a + self.log_c < self.log_b + self.log_d:
@@ -323,6 +500,19 @@ class SHOTerm(Term):
         f = np.sqrt(4.0 * Q**2 - 1)
         return (S0 * w0 * Q, S0 * w0 * Q / f, 0.5 * w0 / Q, 0.5 * w0 / Q * f)
 
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(SHOTerm):
+            return None
+        S0, Q, w0 = _dexp(p[0]), _dexp(p[1]), _dexp(p[2])
+        if Q.v < 0.5:       # (the formulas of get_real_coefficients)
+            f = _dsqrt(1.0 - 4.0 * (Q * Q))
+            pre, rate = 0.5 * (S0 * w0 * Q), 0.5 * (w0 / Q)
+            return [[pre * (1.0 + 1.0 / f), pre * (1.0 - 1.0 / f)], [rate * (1.0 - f), rate * (1.0 + f)],
+                    [], [], [], []], 0.0
+        f = _dsqrt(4.0 * (Q * Q) - 1.0)   # (get_complex_coefficients)
+        a = S0 * w0 * Q
+        return [[], [], [a], [a / f], [0.5 * (w0 / Q)], [0.5 * (w0 / Q) * f]], 0.0
+
 
 class Matern32Term(Term):
     """Approximate Matern-3/2: a complex term with ``d = eps`` -> 0.
@@ -345,3 +535,10 @@ class Matern32Term(Term):
         w0 = np.sqrt(3.0) * np.exp(-log_rho)
         S0 = np.exp(2.0 * log_sigma) / w0
         return (w0 * S0, w0 * w0 * S0 / self.eps, w0, self.eps)
+
+    def _dual_coefficients(self, p):
+        if not self._formulas_are(Matern32Term):
+            return None
+        w0 = _np.sqrt(3.0) * _dexp(-p[1])
+        S0 = _dexp(2.0 * p[0]) / w0
+        return [[], [], [w0 * S0], [w0 * w0 * S0 / self.eps], [w0], [_Dual(self.eps, _np.zeros(len(p)))]], 0.0

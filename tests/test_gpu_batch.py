@@ -405,6 +405,54 @@ def test_one_shot_helper_and_coefficient_table():
 WIDE_SHAPES = [(9, 0), (1, 4), (0, 8), (2, 7), (16, 0), (0, 16), (4, 14), (10, 11), (1, 16), (0, 20), (64, 0), (2, 31)]
 
 
+def test_batched_gradient_reaches_the_kernel_parameters():
+    """The optimiser loop without autograd (celerite.py:221-305 for B draws at once): coefficient tables and
+    their Jacobians from a `terms` kernel (batch.kernel_coefficient_table / kernel_coefficient_jacobian_table), the
+    coefficient gradient of all draws from the plan (clr_batch_grad), the chain rule on the host -- against central
+    differences of the plan's own log-likelihood in PARAMETER space, and against GP.grad_log_likelihood."""
+    from celerite_amd import terms, GP
+
+    kernel = (terms.RealTerm(0.1, 0.5) + terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5)
+              + terms.JitterTerm(log_sigma=-2.0))
+    rng = np.random.RandomState(3)
+    N, B = 3000, 6
+    t = np.sort(rng.uniform(0, 150, N))
+    yerr = rng.uniform(0.1, 0.3, N)
+    y = np.sin(t) + yerr * rng.randn(N)
+    draws = kernel.get_parameter_vector()[None, :] + 0.05 * rng.randn(B, 6)
+    plan = batch.BatchedGP(B, N, 1, 1)
+    try:
+        plan.set_series(t, yerr ** 2, y)
+
+        def loglike(d):
+            tab = batch.kernel_coefficient_table(kernel, d)
+            plan.set_coefficients(*tab[:6], jitter=tab[6])
+            return plan.log_likelihood()[0]
+
+        tab = batch.kernel_coefficient_table(kernel, draws)
+        plan.set_coefficients(*tab[:6], jitter=tab[6])
+        value, grad, st = plan.grad_log_likelihood()
+        assert (st == 0).all()
+        g = batch.chain_gradient(grad, *batch.kernel_coefficient_jacobian_table(kernel, draws))
+        assert g.shape == (B, 6)
+        eps = 1e-6
+        for p in range(6):
+            hi, lo = draws.copy(), draws.copy()
+            hi[:, p] += eps
+            lo[:, p] -= eps
+            fd = (loglike(hi) - loglike(lo)) / (2 * eps)
+            within("batched gradient in parameter space vs central differences (of the largest partial)",
+                   np.max(np.abs(g[:, p] - fd) / np.max(np.abs(g), axis=1)), 1e-6)
+    finally:
+        plan.close()
+    gp = GP(kernel)
+    gp.compute(t, yerr)
+    for b in (0, B - 1):
+        gp.set_parameter_vector(draws[b])
+        _, g1 = gp.grad_log_likelihood(y)
+        within("batched gradient in parameter space vs GP.grad_log_likelihood", np.max(np.abs(g[b] - g1)) / np.max(np.abs(g1)), 1e-10)
+
+
 @pytest.mark.parametrize("JR,JC", WIDE_SHAPES)
 def test_wide_kernels_every_layout_class(JR, JC):
     """Widths 9..64 (wide_kernels.hip: one wave per problem, S distributed over the

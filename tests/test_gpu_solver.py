@@ -247,8 +247,8 @@ GRAD_KERNELS = [  # tests/test_celerite.py:407-423
 @pytest.mark.parametrize("with_general", [False, True])
 def test_grad_log_likelihood(make_kernel, with_general):  # tests/test_celerite.py:425-446
     """The solver-level gradient (value + d/d(jitter, coefficients), solver.cpp:347-463)
-    against the dual-number oracle on the reference test's inputs; the GP-level call
-    then stops where the reference's does without autograd (ImportError, :441-446)."""
+    against the dual-number oracle on the reference test's inputs; then the GP-level gradient
+    against central differences of the GP's own log-likelihood (:448-465)."""
     from oracle import grad as ograd
 
     kernel = make_kernel()
@@ -271,10 +271,28 @@ def test_grad_log_likelihood(make_kernel, with_general):  # tests/test_celerite.
     # the value is the log-likelihood up to the reference's odd constant (solver.cpp:415)
     ll = gp.log_likelihood(y)
     assert np.isclose(value + 0.5 * np.pi * np.log(len(x)), ll + 0.5 * len(x) * np.log(2 * np.pi), rtol=1e-12)
-    if not terms.HAS_AUTOGRAD:
-        if kernel.vector_size:
-            with pytest.raises(ImportError):
-                gp.grad_log_likelihood(y)
+    # the GP-level gradient (celerite.py:221-305): the reference needs autograd for the chain rule to the kernel's
+    # log-parameters; here the built-in terms carry their own Jacobians (terms._dual_coefficients), so the branch the
+    # reference only runs WITH autograd (tests/test_celerite.py:448-465: central differences of log_likelihood, with and
+    # without a fitted mean) runs always
+    eps = 1.34e-7
+    for fit_mean in (True, False):
+        gp = GP(kernel, fit_mean=fit_mean)
+        gp.compute(x, yerr, A=A, U=U, V=V)
+        _, grad = gp.grad_log_likelihood(y)
+        grad0 = np.empty_like(grad)
+        v = gp.get_parameter_vector()
+        for i, pval in enumerate(v):
+            v[i] = pval + eps
+            gp.set_parameter_vector(v)
+            ll = gp.log_likelihood(y)
+            v[i] = pval - eps
+            gp.set_parameter_vector(v)
+            ll -= gp.log_likelihood(y)
+            grad0[i] = 0.5 * ll / eps
+            v[i] = pval
+        gp.set_parameter_vector(v)
+        assert np.allclose(grad, grad0), (fit_mean, grad, grad0)
 
 
 def test_grad_log_likelihood_wide_and_long():

@@ -198,6 +198,36 @@ def test_batch_front_end_validation():
         batch.kernel_coefficient_table(sho, np.array([[0.1, 1.0, 0.5], [0.1, -1.0, 0.5]]))
 
 
+def test_coefficient_jacobian_table_and_chain_rule():
+    """batch.kernel_coefficient_jacobian_table / chain_gradient (host arithmetic): shapes, the order of the
+    coefficient columns (that of the batched gradient: jitter | a_real c_real a_comp b_comp c_comp d_comp), restored
+    parameters, and the chain rule on a linear test functional of the coefficients."""
+    k = terms.RealTerm(0.1, 0.5) + terms.ComplexTerm(0.6, 0.7, 1.0) + terms.JitterTerm(log_sigma=-1.0)
+    rng = np.random.RandomState(5)
+    draws = k.get_parameter_vector()[None, :] + 0.1 * rng.randn(7, 6)
+    jac, jit_jac = batch.kernel_coefficient_jacobian_table(k, draws)
+    assert jac.shape == (7, 6, 6) and jit_jac.shape == (7, 6)
+    assert np.allclose(k.get_parameter_vector(), [0.1, 0.5, 0.6, 0.7, 1.0, -1.0])
+    tab = batch.kernel_coefficient_table(k, draws)
+    # every coefficient is exp(one parameter): the Jacobian is a permutation of diag(coefficients); b_comp = 0
+    for b in range(7):
+        coeffs = np.concatenate([tab[i][b] for i in range(6)])
+        assert np.allclose(jac[b].sum(axis=0), coeffs) and np.count_nonzero(jac[b]) == 5
+        assert np.allclose(jit_jac[b], [0, 0, 0, 0, 0, 2 * tab[6][b]])
+    w = rng.randn(7, 7)     # a functional f = w0 jitter + w[1:] . coefficients has d f / d coefficients = w
+    g = batch.chain_gradient(w, jac, jit_jac)
+    eps = 1e-6
+    for p in range(6):
+        hi, lo = draws.copy(), draws.copy()
+        hi[:, p] += eps
+        lo[:, p] -= eps
+        f = []
+        for d in (hi, lo):
+            t = batch.kernel_coefficient_table(k, d)
+            f.append(w[:, 0] * t[6] + np.sum(w[:, 1:] * np.concatenate([t[i] for i in range(6)], axis=1), axis=1))
+        assert np.allclose(g[:, p], (f[0] - f[1]) / (2 * eps), rtol=1e-6, atol=1e-8)
+
+
 def test_shard_bounds_and_sharded_plan_without_a_gpu():
     """clr_shard_bounds is host arithmetic; a sharded plan fails loudly without a device."""
     from celerite_amd import batch

@@ -94,13 +94,100 @@ def test_bounds():  # tests/test_terms.py:37-46
         terms.RealTerm(log_a=0.5, log_c=0.5, bounds=bounds)  # outside => non-finite prior
 
 
-def test_jacobians_need_autograd():  # tests/test_terms.py:64-68, 101-104
+JAC_KERNELS = [  # tests/test_terms.py:49-63 (+ a Matern-3/2 product, a frozen parameter and a nested product)
+    lambda: terms.RealTerm(log_a=0.1, log_c=0.5),
+    lambda: terms.RealTerm(log_a=0.1, log_c=0.5) + terms.RealTerm(log_a=-0.1, log_c=0.7),
+    lambda: terms.ComplexTerm(log_a=0.1, log_c=0.5, log_d=0.1),
+    lambda: terms.ComplexTerm(log_a=0.1, log_b=-0.2, log_c=0.5, log_d=0.1),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=-1, log_omega0=0.5),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5) + terms.RealTerm(log_a=0.1, log_c=0.4),
+    lambda: terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5) * terms.RealTerm(log_a=0.1, log_c=0.4),
+    lambda: terms.Matern32Term(log_sigma=0.3, log_rho=-0.2) * terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5)
+    + terms.JitterTerm(log_sigma=0.1),
+    lambda: (terms.SHOTerm(log_S0=0.1, log_Q=-1, log_omega0=0.5) + terms.RealTerm(log_a=0.1, log_c=0.4))
+    * terms.ComplexTerm(log_a=0.1, log_b=-0.2, log_c=0.5, log_d=0.1),
+]
+
+
+def _central(fn, k, eps=1.34e-7):
+    """Richardson-extrapolated central differences of fn() with respect to k's parameter vector (h and h / 2)."""
+    v = k.get_parameter_vector()
+    rows = []
+    for i, pval in enumerate(v):
+        d = []
+        for h in (eps, 0.5 * eps):
+            v[i] = pval + h
+            k.set_parameter_vector(v)
+            hi = fn()
+            v[i] = pval - h
+            k.set_parameter_vector(v)
+            d.append((hi - fn()) / (2.0 * h))
+            v[i] = pval
+        rows.append((4.0 * d[1] - d[0]) / 3.0)
+    k.set_parameter_vector(v)
+    return np.array(rows)
+
+
+@pytest.mark.parametrize("make", JAC_KERNELS)
+def test_jacobian(make):  # tests/test_terms.py:64-84 -- here WITHOUT autograd: the built-in formulas on dual numbers
+    k = make()
+    v = k.get_parameter_vector()
+    c = np.concatenate(k.coefficients)
+    jac = k.get_coeffs_jacobian()
+    assert jac.shape == (len(v), len(c))
+    jac0 = _central(lambda: np.concatenate(k.coefficients), k)
+    assert np.allclose(jac, jac0, rtol=1e-6, atol=1e-7 * max(1.0, np.max(np.abs(c))))
+    # a frozen parameter drops its row (terms.py:214-215); include_frozen keeps it
+    name = k.get_parameter_names()[0]
+    k.freeze_parameter(name)
+    assert np.array_equal(k.get_coeffs_jacobian(), jac[1:]) and np.array_equal(k.get_coeffs_jacobian(include_frozen=True), jac)
+
+
+@pytest.mark.parametrize("make", [  # tests/test_terms.py:87-94
+    lambda: terms.JitterTerm(log_sigma=0.5),
+    lambda: terms.RealTerm(log_a=0.5, log_c=0.1),
+    lambda: terms.RealTerm(log_a=0.5, log_c=0.1) + terms.JitterTerm(log_sigma=0.3),
+    lambda: terms.JitterTerm(log_sigma=0.5) + terms.JitterTerm(log_sigma=0.1),
+])
+def test_jitter_jacobian(make):  # tests/test_terms.py:95-119
+    k = make()
+    jac = k.get_jitter_jacobian()
+    assert len(jac) == len(k.get_parameter_vector())
+    assert np.allclose(jac, _central(lambda: k.jitter, k), rtol=1e-7, atol=1e-9)
+
+
+def test_jacobian_matches_the_golden_coefficients():
+    """The dual-number evaluation returns the very coefficients tests/golden/terms_golden.json pins (generated from the
+    reference's terms.py): value parts bit-identical to get_all_coefficients, whose parity test_reference_coefficients
+    asserts -- so the Jacobian differentiates the golden-pinned function, not a restatement of it."""
+    for make in JAC_KERNELS:
+        k = make()
+        res, n = k._dual_all()
+        assert res is not None
+        vals = np.array([x.v for blk in res[0] for x in blk])
+        assert np.allclose(vals, np.concatenate(k.coefficients), rtol=1e-15, atol=0.0)
+        assert np.isclose(terms._Dual.lift(res[1], n).v, k.jitter, rtol=1e-15, atol=0.0)
+
+
+def test_user_defined_terms_still_need_autograd():  # terms.py:197-215: the reference's behaviour for everything else
+    class Custom(terms.Term):
+        parameter_names = ("log_a", )
+
+        def get_real_coefficients(self, params):
+            return np.exp(params[0]), 1.0
+
+    class Tweaked(terms.RealTerm):
+        def get_real_coefficients(self, params):
+            return 2.0 * np.exp(params[0]), np.exp(params[1])
+
     if terms.HAS_AUTOGRAD:
         pytest.skip("autograd present")
-    with pytest.raises(ImportError):
-        terms.RealTerm(log_a=0.1, log_c=0.5).get_coeffs_jacobian()
-    with pytest.raises(ImportError):
-        terms.JitterTerm(log_sigma=0.5).get_jitter_jacobian()
+    for k in (Custom(log_a=0.1), Tweaked(log_a=0.1, log_c=0.2), Custom(log_a=0.1) + terms.RealTerm(log_a=0.1, log_c=0.5)):
+        with pytest.raises(ImportError):
+            k.get_coeffs_jacobian()
+        with pytest.raises(ImportError):
+            k.get_jitter_jacobian()
 
 
 def test_quiet():  # tests/test_terms.py:122-139
