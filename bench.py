@@ -607,6 +607,8 @@ def main(argv=None):
     if args.chunks:
         plan.set_chunks(args.chunks)
     plan.set_series(t, diag, y)          # host -> HBM, outside the timed region
+    set_series_first_ms = plan.selection_bounds()["set_series_host_ms"]   # (device buffers + pinned staging allocated)
+    plan.set_series(t, diag, y)          # ... and again: what every later batch of series costs
     real_loop(plan, draws, Wm)
     # untimed settling beyond the W warm-up steps: a few steps are not enough for the clocks of an idle
     # device (and the host's pinned-copy path) to reach their steady state; reported as settle_steps
@@ -714,7 +716,13 @@ def main(argv=None):
                                       "ms_per_step": new_ms / max(K // 2, 1),
                                       "value": B / (new_ms / max(K // 2, 1) * 1e-3) * dist.world,
                                       "relayout_ms": new_k["relayout"] / max(K // 2, 1),
-                                      "set_series_host_ms": plan.selection_bounds()["set_series_host_ms"]},
+                                      "set_series_host_ms": plan.selection_bounds()["set_series_host_ms"],
+                                      "set_series_first_call_ms": set_series_first_ms,
+                                      "set_series_note": "clr_batch_set_series of 2.46 GB of pageable NumPy arrays: 8 host "
+                                                         "threads staging through pinned buffers + device-side scans of t "
+                                                         "(csrc/series_io.hip); the first call also allocates",
+                                      "step_including_set_series_ms": new_ms / max(K // 2, 1)
+                                                                      + plan.selection_bounds()["set_series_host_ms"]},
             "steady_state": {"seconds": steady_dt, "steps": n_steady, "value": B * n_steady / steady_dt * dist.world},
             "value_steady": B * n_steady / steady_dt * dist.world,
             "timed_region_s": dt,
@@ -829,6 +837,10 @@ def promote(out):
     r, c = out["roofline"], out["config"]
     r["value_steady"] = out.get("value_steady")
     c["value_steady"] = out.get("value_steady")
+    ns = out.get("new_series_every_step") or {}
+    if "set_series_host_ms" in ns:
+        r["set_series_ms"] = {"steady": ns["set_series_host_ms"], "first_call": ns.get("set_series_first_call_ms"),
+                              "GBps": 3 * 8e-9 * c["batch_per_gpu"] * c["N"] / (ns["set_series_host_ms"] * 1e-3)}
     m = out.get("materialize")
     if m and "roofline" in m:
         mr = m["roofline"]

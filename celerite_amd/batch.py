@@ -197,10 +197,18 @@ class BatchedGP(object):
             else:
                 raise ValueError("dimension mismatch")
             arrs.append(a)
-        if np.any(np.diff(arrs[0], axis=-1) < 0.0):
+        lib = _load()
+        _check(lib.clr_batch_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
+                                        strides[1], _ptr(arrs[2]), strides[2]))
+        # sortedness from the device-side scan of the uploaded t (np.diff over 0.8 GB of times costs more than the
+        # whole transfer): an unsorted batch is dropped again
+        dtmin = C.c_double()
+        lib.clr_batch_get_series_order.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _check(lib.clr_batch_get_series_order(self._h, C.byref(dtmin)))
+        if dtmin.value < 0.0:
+            lib.clr_batch_clear_series.argtypes = [C.c_void_p]
+            _check(lib.clr_batch_clear_series(self._h))
             raise ValueError("the input coordinates must be sorted")
-        _check(_load().clr_batch_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
-                                            strides[1], _ptr(arrs[2]), strides[2]))
 
     def set_coefficients(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
         """Coefficient tables ``(B, J_real)`` / ``(B, J_comp)``; ``jitter`` scalar or ``(B,)``."""
@@ -570,10 +578,16 @@ class ShardedBatchedGP(object):
             else:
                 raise ValueError("dimension mismatch")
             arrs.append(a)
-        if np.any(np.diff(arrs[0], axis=-1) < 0.0):
+        lib = _load()
+        self._ok(lib.clr_sharded_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
+                                            strides[1], _ptr(arrs[2]), strides[2]))
+        dtmin = C.c_double()
+        lib.clr_sharded_get_series_order.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._ok(lib.clr_sharded_get_series_order(self._h, C.byref(dtmin)))
+        if dtmin.value < 0.0:       # (the device-side scans of the shards: see BatchedGP.set_series)
+            lib.clr_sharded_clear_series.argtypes = [C.c_void_p]
+            self._ok(lib.clr_sharded_clear_series(self._h))
             raise ValueError("the input coordinates must be sorted")
-        self._ok(_load().clr_sharded_set_series(self._h, _ptr(arrs[0]), strides[0], _ptr(arrs[1]),
-                                                strides[1], _ptr(arrs[2]), strides[2]))
 
     def _coeff_blocks(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter):
         try:

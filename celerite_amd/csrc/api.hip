@@ -18,6 +18,7 @@
 #include "clr_batch_kernels.h"
 #include "clr_carma.h"
 #include "clr_generic_kernels.h"
+#include "clr_series_io.h"
 #include "clr_small.h"
 #include "clr_wide.h"
 
@@ -354,6 +355,9 @@ struct clr_batch {
   // of the WHOLE batch, so that all shards pick the same kernels whatever the sharding
   double floor_tmax = 0.0, floor_dxmax = 0.0, floor_dmax = 0.0, floor_cmax = 0.0;
   double set_series_host_ms = 0.0;    // host time of the last clr_batch_set_series (scan + uploads)
+  double dtmin = 0.0;                 // smallest step of t over the plan's series (negative: not sorted; NaN: a NaN time)
+  clr::UploadStaging staging;         // pinned staging + copy streams of clr_batch_set_series (large series only)
+  DevBuf scan;                        // results of the device-side scans of t
   int force_library_trig = 0;
   int coop_prefix = 2;                // 0 single lane, 1 16 lanes walking the chunks, 2 multi-level (clr_prefix_kernels.h)
   int plan_levels = -1, plan_g = 0;   // clr_batch_set_prefix_plan: < 0 = chosen by clr::plan_prefix
@@ -1385,13 +1389,16 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->g_ckflag) (void)hipFree(h->g_ckflag);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->pin) (void)hipHostFree(h->pin);
+  clr::staging_destroy(h->staging);
+  h->scan.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 static int warm_plan_chunks(clr_batch* h);
 static int warm_resolve(clr_batch* h, bool* pin_current);
-static void warm_scan_spans(clr_batch* h, const double* t, long t_stride);
+static int warm_scan_spans(clr_batch* h);
+static void warm_select(clr_batch* h);
 
 int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   int st = require_device(h->device);
@@ -1502,30 +1509,31 @@ static int warm_plan_chunks(clr_batch* h) {
     h->wints_cap = ints;
   }
   HIP_TRY(hipMemsetAsync(h->wints, 0, ints * sizeof(int), h->stream));
+  if (h->have_series) {  // the spans and the warm-ups follow the new chunking (the series are resident)
+    if ((st = warm_scan_spans(h)) != CLR_OK) return st;
+    warm_select(h);
+  }
   return CLR_OK;
 }
 
 // For every problem (or the one shared series) and every candidate K: the shortest time the K samples in front of
-// a chunk boundary of the warm path span.  O(B x chunks) lookups into the host arrays set_series was given.
-static void warm_scan_spans(clr_batch* h, const double* t, long t_stride) {
+// a chunk boundary of the warm path span.  O(B x chunks) lookups into the series resident in HBM (warm_spans_kernel),
+// so the spans follow the chunking too (clr_batch_set_chunks after clr_batch_set_series).
+static int warm_scan_spans(clr_batch* h) {
   h->warm_span.clear();
-  if (h->wnchunk < 2) return;
-  const long nb = t_stride == 0 ? 1 : h->B;
-  h->warm_span.assign((size_t)nb * clr_batch::WARM_NK, 0.0);
-  for (long b = 0; b < nb; ++b) {
-    const double* tb = t + b * t_stride;
-    for (int k = 0; k < clr_batch::WARM_NK; ++k) {
-      const long K = h->warm_cand[k];
-      double span = INFINITY;
-      if (K > h->wL / 2) span = 0.0;  // (not a usable candidate at this chunk length)
-      for (long c = 1; c < h->wnchunk && span > 0.0; ++c) {
-        const long n = c * (long)h->wL;
-        const double d = tb[n] - tb[n - K];
-        if (!(d >= span)) span = d;  // (NaN sticks: never eligible)
-      }
-      h->warm_span[(size_t)b * clr_batch::WARM_NK + k] = span;
-    }
-  }
+  if (h->wnchunk < 2 || !h->have_series) return CLR_OK;
+  const int nb = h->t_stride == 0 ? 1 : h->B;
+  const size_t n = (size_t)nb * clr_batch::WARM_NK;
+  int st;
+  if ((st = h->scan.reserve(std::max(n, (size_t)nb * 4))) != CLR_OK) return st;
+  clr::WarmCands cands;
+  cands.nk = clr_batch::WARM_NK;
+  for (int k = 0; k < clr_batch::WARM_NK; ++k) cands.K[k] = h->warm_cand[k];
+  clr::launch_warm_spans(h->t.p, h->t_stride, nb, h->wL, h->wnchunk, cands, h->scan.p, h->stream);
+  h->warm_span.assign(n, 0.0);
+  HIP_TRY(hipMemcpyAsync(h->warm_span.data(), h->scan.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
 }
 
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len) {
@@ -1581,37 +1589,69 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (an evaluation in flight is settled on ITS series)
   auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
   const auto host_t0 = std::chrono::steady_clock::now();
-  // one pass over t: max |t| over every sample (sortedness is not assumed) and the largest step
-  h->tmax = 0.0;
-  h->dxmax = 0.0;
-  for (long b = 0; b < (t_stride == 0 ? 1 : (long)h->B); ++b) {
-    const double* tb = t + b * t_stride;
-    double tm = 0.0, dm = 0.0, prev = tb[0];
-    for (long n = 0; n < N; ++n) {
-      const double v = tb[n], a = fabs(v), d = fabs(v - prev);
-      if (!(a <= tm)) tm = a;
-      if (!(d <= dm)) dm = d;
-      prev = v;
-    }
-    if (!(tm <= h->tmax)) h->tmax = tm;
-    if (!(dm <= h->dxmax)) h->dxmax = dm;
+  if ((st = h->t.reserve(count(t_stride))) != CLR_OK) return st;
+  if ((st = h->diag.reserve(count(diag_stride))) != CLR_OK) return st;
+  if ((st = h->y.reserve(count(y_stride))) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (kernels of an earlier evaluation may still be reading the old series)
+  const clr::CopyJob jobs[3] = {{h->t.p, t, count(t_stride)}, {h->diag.p, diag, count(diag_stride)}, {h->y.p, y, count(y_stride)}};
+  const size_t total = (jobs[0].n + jobs[1].n + jobs[2].n) * sizeof(double);
+  if (total >= ((size_t)32 << 20)) {
+    // large series: NT host threads stage pieces through pinned buffers, their DMAs share the link (clr_series_io.h)
+    int e = clr::staging_create(h->staging, h->device);
+    if (e == 0) e = clr::upload_parallel(h->staging, jobs, 3);
+    if (e != 0) return fail(CLR_HIP_ERROR, hipGetErrorString((hipError_t)e));
+  } else {
+    for (const clr::CopyJob& j : jobs)
+      if (j.n) HIP_TRY(hipMemcpyAsync(j.dst, j.src, j.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  warm_scan_spans(h, t, t_stride);
-  if ((st = upload(h->t, t, count(t_stride), h->stream)) != CLR_OK) return st;
-  if ((st = upload(h->diag, diag, count(diag_stride), h->stream)) != CLR_OK) return st;
-  if ((st = upload(h->y, y, count(y_stride), h->stream)) != CLR_OK) return st;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->set_series_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   h->t_stride = t_stride;
   h->diag_stride = diag_stride;
   h->y_stride = y_stride;
   h->have_series = true;
+  // one pass over t ON THE DEVICE: max |t| over every sample (sortedness is not assumed), the largest and the smallest
+  // step, NaN times; then the warm path's spans
+  {
+    const int nb = t_stride == 0 ? 1 : h->B;
+    if ((st = h->scan.reserve((size_t)nb * std::max(4, (int)clr_batch::WARM_NK))) != CLR_OK) return st;
+    clr::launch_series_stats(h->t.p, t_stride, nb, (int)N, h->scan.p, h->stream);
+    std::vector<double> stats((size_t)nb * 4);
+    HIP_TRY(hipMemcpyAsync(stats.data(), h->scan.p, stats.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double tm = 0.0, dm = 0.0, dmin = INFINITY;
+    bool nan = false;
+    for (int b = 0; b < nb; ++b) {
+      tm = std::max(tm, stats[4 * b]); dm = std::max(dm, stats[4 * b + 1]); dmin = std::min(dmin, stats[4 * b + 2]);
+      nan = nan || stats[4 * b + 3] != 0.0;
+    }
+    // (a NaN time: NaN bounds select the conservative kernels, sel_max)
+    h->tmax = nan ? NAN : tm;
+    h->dxmax = nan ? NAN : dm;
+    h->dtmin = nan ? NAN : (N > 1 ? dmin : 0.0);
+  }
+  if ((st = warm_scan_spans(h)) != CLR_OK) return st;
+  h->set_series_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   h->grad_span_valid = false;
   h->relayout_pending = true;
   h->warm_copy_pending = true;
   // a new series: the warm-ups chosen for the previous one's spans do not apply, nor does its history of fallbacks
   if (h->warm_mode < 0) h->warm_boost = 0;
   warm_select(h);
+  return CLR_OK;
+}
+
+int clr_batch_get_series_order(const clr_batch* h, double* dtmin) {
+  if (!h->have_series) return fail(CLR_INVALID_ARGUMENT, "no series set");
+  if (dtmin) *dtmin = h->dtmin;
+  return CLR_OK;
+}
+
+int clr_batch_clear_series(clr_batch* h) {
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->have_series = false;
+  h->warm_active = false;
+  h->warm_span.clear();
   return CLR_OK;
 }
 

@@ -237,6 +237,22 @@ int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const
   return CLR_OK;
 }
 
+int clr_sharded_get_series_order(const clr_sharded* h, double* dtmin) {
+  double m = 1.0 / 0.0;
+  for (clr_batch* p : h->plan) {
+    double d = 0.0;
+    const int st = clr_batch_get_series_order(p, &d);
+    if (st != CLR_OK) return st;
+    if (!(d >= m)) m = d;  // (NaN sticks)
+  }
+  if (dtmin) *dtmin = m;
+  return CLR_OK;
+}
+
+int clr_sharded_clear_series(clr_sharded* h) {
+  return h->all([=](int s) { return clr_batch_clear_series(h->plan[s]); });
+}
+
 // largest |d_comp| and decay rate over the whole batch -> every shard (before it takes its slice)
 static void global_coefficient_bounds(clr_sharded* h, const double* c_real, const double* c_comp, const double* d_comp) {
   double dmax = 0.0, cmax = 0.0;

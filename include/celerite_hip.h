@@ -213,6 +213,11 @@ int clr_batch_set_series(clr_batch* h,
                          const double* t, long t_stride,
                          const double* diag, long diag_stride,
                          const double* y, long y_stride);
+/* The smallest step t[n + 1] - t[n] over the plan's series, found by the device-side scan of clr_batch_set_series
+ * (negative: some series is not sorted -- GP.compute's check, celerite.py:126-129, without a host pass over t; NaN: a
+ * NaN time).  clr_batch_clear_series drops the series (a front end that rejects unsorted input calls it). */
+int clr_batch_get_series_order(const clr_batch* h, double* dtmin);
+int clr_batch_clear_series(clr_batch* h);
 /* (jitter may be NULL: no jitter) */
 int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
                                const double* a_real, const double* c_real,
@@ -480,6 +485,9 @@ int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
 int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup);
 /* The summarize kernel all shards will run (clr_batch_get_summarize_kernel; -1 if they disagree). */
 int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind);
+/* clr_batch_get_series_order / clr_batch_clear_series over all shards (the smallest step of the whole batch) */
+int clr_sharded_get_series_order(const clr_sharded* h, double* dtmin);
+int clr_sharded_clear_series(clr_sharded* h);
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
                            long diag_stride, const double* y, long y_stride);
 int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const double* a_real,

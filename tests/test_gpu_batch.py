@@ -641,6 +641,47 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
             assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), S
 
 
+def test_set_series_checks_the_order_on_the_device_and_follows_the_chunking():
+    """clr_batch_set_series: large batches go through the pinned multi-threaded staging (>= 32 MB), the scans of t
+    (max |t|, largest / smallest step, warm-path spans) run on the device.  An unsorted series anywhere in the batch is
+    rejected as GP.compute does (celerite.py:126-129) and dropped; the result of a staged upload equals the plain
+    copy's bit for bit; the warm path's spans are rescanned when the chunking changes after the series."""
+    B, N, JR, JC = 48, 30000, 2, 3                       # 3 x 11.5 MB: staged
+    case = synthetic(B, N, JR, JC, "accuracy", seed=41)
+    small = {k: (v[:4] if k in ("t", "diag", "y") else v[:4]) for k, v in case.items()}   # 2.9 MB: plain copies
+    plan, plan4 = batch.BatchedGP(B, N, JR, JC), batch.BatchedGP(4, N, JR, JC)
+    try:
+        bad = case["t"].copy()
+        bad[B - 1, N // 2] = bad[B - 1, N // 2 - 1] - 1e-9
+        with pytest.raises(ValueError, match="sorted"):
+            plan.set_series(bad, case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        with pytest.raises(RuntimeError):                 # the unsorted batch was dropped
+            plan.log_likelihood()
+        for p, c in ((plan, case), (plan4, small)):
+            p.set_chunks(32)
+            p.set_series(c["t"], c["diag"], c["y"])
+            p.set_coefficients(*coeffs_of(c))
+        want = plan.log_likelihood()
+        got4 = plan4.log_likelihood()
+        for a, b in zip(want, got4):
+            assert np.array_equal(a[:4], b)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"],
+                                                  nthreads=os.cpu_count() or 1)
+        assert np.array_equal(want[3], s0)
+        within("staged set_series: vs oracle", max(np.max(np.abs(want[1] - d0) / np.abs(d0)), np.max(np.abs(want[2] - q0) / np.abs(q0))), REL)
+        assert plan.warm_start()["active"]
+        plan.set_chunks(24)                               # chunking after the series: the spans follow
+        plan.set_coefficients(*coeffs_of(case))
+        again = plan.log_likelihood()
+        assert plan.warm_start()["active"] and plan.warm_start()["fallbacks"] == 0
+        within("staged set_series, re-chunked: vs oracle",
+               max(np.max(np.abs(again[1] - d0) / np.abs(d0)), np.max(np.abs(again[2] - q0) / np.abs(q0))), REL)
+    finally:
+        plan.close()
+        plan4.close()
+
+
 def test_sharding_a_batch_with_mixed_warm_eligibility():
     """The warm-started recurrence adapts per plan (activation when half of the plan's problems are eligible), so a
     batch in which half of the series forget their past may take it in one sharding and the scan in another: statuses
