@@ -347,6 +347,21 @@ class BatchedGP(object):
         :meth:`set_coefficients`."""
         _check(_load().clr_batch_set_warm_start(self._h, int(mode), int(forced_warmup)))
 
+    def set_small_mode(self, mode=-1):
+        """One-launch evaluation of short narrow problems (``clr_batch_set_small_mode``): -1 automatic, 0 off,
+        1 whenever supported (widths 1..4, 512 <= N <= 32768)."""
+        lib = _load()
+        lib.clr_batch_set_small_mode.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.clr_batch_set_small_mode(self._h, int(mode)))
+
+    def small_mode_active(self):
+        """Whether the next evaluation runs as one launch (series and coefficients must be set)."""
+        a = C.c_int()
+        lib = _load()
+        lib.clr_batch_get_small_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _check(lib.clr_batch_get_small_mode(self._h, C.byref(a)))
+        return bool(a.value)
+
     def warm_start(self):
         """``dict(active, chunks, chunk_len, warmup_min, warmup_max, settled, fallbacks)``."""
         v = [C.c_int() for _ in range(7)]

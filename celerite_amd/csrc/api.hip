@@ -341,6 +341,8 @@ struct clr_batch {
   int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
   int nchunk = 1, L = 0;
   int L0 = 0;                      // wide plans: samples of the first chunk when it is longer than L (0: uniform)
+  int small_mode = -1;             // one-launch evaluation of short narrow problems: -1 auto, 0 off, 1 whenever supported
+  bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
   double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk
   const clr::BatchLaunchers* launch = nullptr;
   DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout
@@ -1405,6 +1407,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (st != CLR_OK) return st;
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
   h->warm_explicit_chunks = nchunk > 0 ? nchunk : 0;
+  if (nchunk > 0) h->pipeline_pinned = true;
   if (!h->launch) {
     // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
     // unless the batch alone leaves the chip underused: then ~2 waves per SIMD worth of
@@ -2025,6 +2028,7 @@ int clr_batch_get_measured_error(clr_batch* h, double* eg_max) {
 int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual) {
   h->cert_gamma = max_gamma_over_mu;
   h->cert_resid = max_residual;
+  h->pipeline_pinned = true;
   return CLR_OK;
 }
 
@@ -2037,6 +2041,7 @@ int clr_batch_set_certificate_gamma(clr_batch* h, double max_gamma, double max_g
 int clr_batch_set_prefix_mode(clr_batch* h, int mode) {
   if (mode < 0 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "prefix mode must be 0, 1 or 2");
   h->coop_prefix = mode;
+  h->pipeline_pinned = true;
   return CLR_OK;
 }
 
@@ -2115,6 +2120,7 @@ int clr_batch_set_summarize_mode(clr_batch* h, int mode) {
   if (mode < -1 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "summarize mode must be -1, 0, 1 or 2");
   if (mode != h->summarize_mode) h->relayout_pending = true;
   h->summarize_mode = mode;
+  if (mode >= 0) h->pipeline_pinned = true;
   return CLR_OK;
 }
 
@@ -2148,6 +2154,22 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->J_general = J_general;
   h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  return CLR_OK;
+}
+
+static bool warm_runs(const clr_batch* h, int materialize);
+static bool small_runs(const clr_batch* h, int materialize);
+
+int clr_batch_set_small_mode(clr_batch* h, int mode) {
+  if (mode < -1 || mode > 1) return fail(CLR_INVALID_ARGUMENT, "small mode: -1 (auto), 0 (off) or 1 (whenever supported)");
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->small_mode = mode;
+  return CLR_OK;
+}
+
+int clr_batch_get_small_mode(const clr_batch* h, int* active) {
+  if (active) *active = (!warm_runs(h, 0) && small_runs(h, 0)) ? 1 : 0;
   return CLR_OK;
 }
 
@@ -2186,6 +2208,7 @@ int clr_batch_get_warm_start(const clr_batch* h, int* active, int* nchunk, int* 
 int clr_batch_set_replay_source(clr_batch* h, int source) {
   if (source < -1 || source > 1) return fail(CLR_INVALID_ARGUMENT, "replay source must be -1, 0 or 1");
   h->replay_source = source;
+  h->pipeline_pinned = true;
   return CLR_OK;
 }
 
@@ -2198,6 +2221,7 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
   if (layout < 0 || layout > 2) return fail(CLR_INVALID_ARGUMENT, "layout must be 0, 1 or 2");
   h->layout = layout;
   h->relayout_pending = true;
+  h->pipeline_pinned = true;
   return CLR_OK;
 }
 
@@ -2261,6 +2285,21 @@ int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps)
     for (int j = 0; j < PROF_NK; ++j) kernel_ms[j] = k[j];
   if (steps) *steps = h->prof_steps;
   return CLR_OK;
+}
+
+// a batch of short, narrow problems: the whole fused evaluation in ONE launch, one workgroup per problem
+// (small_batch_kernel, small_kernels.hip); problems it cannot certify stay pending for the scan pipeline
+static bool small_runs(const clr_batch* h, int materialize) {
+  if (h->grad_scan_only || h->small_mode == 0) return false;
+  if (!h->launch || materialize || h->force_exact || !h->wints || h->J_general > 0) return false;
+  if (!clr::small_batch_supported(h->J_real, h->J_comp, h->N)) return false;
+  // (automatic: while a workgroup per problem still fits one round of the chip -- above that the scan pipeline's
+  //  throughput wins, profiles/r04i_small_batch.txt)
+  if (h->small_mode == 1) return true;
+  // automatic: not when the caller tuned the scan pipeline explicitly, and only while a workgroup per problem fits
+  // one round of the chip (widths 3, 4: one workgroup per CU by registers and LDS; narrower: four) -- above that the
+  // pipeline's throughput wins (profiles/r04i_small_batch.txt: 1024 x 1e4 x width 4 0.29 ms against 0.34)
+  return !h->pipeline_pinned && h->B <= (h->J >= 3 ? 256 : 1024);
 }
 
 static bool warm_runs(const clr_batch* h, int materialize) {
@@ -2360,6 +2399,19 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   }
   mark(0);
   h->warm_inflight = false;
+  if (!warm_runs(h, materialize) && small_runs(h, materialize)) {
+    clr::BatchParams Sp;
+    h->in_fallback = true;  // (the row-major arrays)
+    st = batch_params(h, 0, Sp);
+    h->in_fallback = false;
+    if (st != CLR_OK) return st;
+    mark(1);
+    clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    h->warm_inflight = true;  // (pending problems are settled like the warm path's: warm_resolve)
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
   if (warm_runs(h, materialize)) {
     // series that forget: the plain recurrence per chunk with a warm-up + the boundary check; problems it cannot
     // settle are marked pending and go through the scan pipeline when the results are asked for
@@ -2810,6 +2862,18 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[0], h->stream));
     if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
       wide_launch(h, P, e);
+      continue;
+    }
+    if (!warm_runs(h, materialize) && small_runs(h, materialize)) {  // (one launch, in the "summarize" slot)
+      clr::BatchParams Sp;
+      h->in_fallback = true;
+      st = batch_params(h, 0, Sp);
+      h->in_fallback = false;
+      if (st != CLR_OK) return st;
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
+      for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      h->warm_inflight = true;
       continue;
     }
     if (warm_runs(h, materialize)) {  // (the warm path: recurrence + boundary check in the "summarize" slot)

@@ -14,6 +14,12 @@ struct SmallParams {
   double max_residual;          // largest relative end-state / start-state mismatch that counts as consistent
 };
 
+struct BatchParams;
+// a batch of short problems (widths 1..4, 512 <= N <= 32768), one workgroup of `threads` (64, 128 or 256) lanes per
+// problem, one launch; needs P.need_scan (problems it could not certify are left pending for the scan pipeline)
+bool small_batch_supported(int JR, int JC, int N);
+bool launch_small_batch(int JR, int JC, const BatchParams& P, int threads, hipStream_t s);
+
 bool small_compute_supported(int JR, int JC, int N);
 // threads: 64, 128 or 256 (a power of two), with threads * L >= N
 bool launch_small_compute(int JR, int JC, const SmallParams& P, int threads, bool fast, hipStream_t s);

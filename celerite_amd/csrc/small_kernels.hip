@@ -17,7 +17,8 @@
 // Coefficients and jitter travel as kernel arguments; t, diag and the hinted right-hand side in one upload.
 #include <hip/hip_runtime.h>
 
-#include "clr_core.h"
+#include "../../include/celerite_hip.h"
+#include "clr_batch_kernels.h"
 #include "clr_small.h"
 
 namespace clr {
@@ -129,6 +130,124 @@ __global__ void __launch_bounds__(256) small_compute_kernel(const SmallParams P)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same idea for a BATCH of short problems (BASELINE configs[1]: 256 problems x N = 1e4 x width 4): ONE workgroup
+// per problem, one launch for the whole fused log-likelihood instead of the six launches of the scan pipeline
+// (summarize, prefix, correct, replay, sequential, finalize: 0.17 ms of device time at that shape, the prefix over 250
+// chunks longer than the summarize).  Lane = chunk of L = ceil(N / T) samples: (1) summarize_chunk, (2) Kogge-Stone scan
+// of the composed elements through LDS -- (C, b) of the element of chunks 0 .. c - 1 IS the state at chunk c's first
+// sample --, (3) the chunk's true contributions from its zero-start sums and that state (chunk_update: determinant
+// lemma, Woodbury, positivity certificate -- what correct_kernel does; a replay of the chunk instead was measured at
+// 41 of 117 us), (4) the problem's conditioning record tested as decide_kernel does.  Certified and benign => the
+// problem's results are written by this kernel; anything else => status "pending" and need_scan[b] = 1: the host
+// runs the scan pipeline (with all its routes) for those problems before it hands results out, as behind the
+// warm-started recurrence (clr_batch_kernels.h).
+// ---------------------------------------------------------------------------------------------------------------
+template <int JR, int JC, bool FAST>
+__global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, int L) {
+  using Wd = Widths<JR, JC>;
+  constexpr int J = Wd::J, SZ = Wd::SZ, ELEM = Wd::ELEM, START = Wd::START;
+  extern __shared__ double lds[];  // [ELEM][T]
+  const int T = blockDim.x, c = threadIdx.x, b = blockIdx.x;
+  const int N = P.N;
+  const int nreal = (N + L - 1) / L;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  // 1. the chunk's element and zero-start sums; eta and Jm of the chunk's OWN element are what the corrections need
+  double e[ELEM], own[ELEM];
+  double ld0 = 0.0, q0 = 0.0, gamma = 0.0;
+  int flag0 = 0;
+  {
+    DirectSeries src{P.t + (long)b * P.t_stride + (long)c * L, P.diag + (long)b * P.diag_stride + (long)c * L,
+                     P.y + (long)b * P.y_stride + (long)c * L, 1, L, L, (long)N - (long)c * L};
+    summarize_chunk<JR, JC, FAST>(p, src, L, c * L, N, true, e, &ld0, &q0, &flag0, &gamma);
+  }
+#pragma unroll
+  for (int k = 0; k < ELEM; ++k) own[k] = (k >= J * J + J + SZ) ? e[k] : 0.0;  // (eta | Jm; the rest is never read)
+  // 2. inclusive Kogge-Stone scan over the lanes (chunk order) with the composition
+  for (int d = 1; d < nreal; d <<= 1) {
+#pragma unroll
+    for (int k = 0; k < ELEM; ++k) lds[k * T + c] = e[k];
+    __syncthreads();
+    if (c >= d && c < nreal) {
+      double left[ELEM];
+#pragma unroll
+      for (int k = 0; k < ELEM; ++k) left[k] = lds[k * T + c - d];
+      compose_elements<J>(left, e, e);
+    }
+    __syncthreads();
+  }
+  // the state at the first sample of chunk c = (C, b) of the element of chunks 0 .. c - 1
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) lds[k * T + c] = e[J * J + J + k];
+#pragma unroll
+  for (int k = 0; k < J; ++k) lds[(SZ + k) * T + c] = e[J * J + k];
+  __syncthreads();
+  double S[SZ], f[J];
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) S[k] = (c > 0) ? lds[k * T + c - 1] : 0.0;
+#pragma unroll
+  for (int k = 0; k < J; ++k) f[k] = (c > 0) ? lds[(SZ + k) * T + c - 1] : 0.0;
+  __syncthreads();
+  // 3. the chunk's true contributions from its zero-start sums and its start state (chunk_update, clr_core.h:
+  //    determinant lemma + Woodbury + the positivity certificate), as correct_kernel does -- no second pass
+  double dld = 0.0, dq = 0.0, mu = 1.0, eg = 0.0;
+  int sus = 0;
+  if (c >= 1 && c < nreal) chunk_update<J>(own, S, f, true, false, ld0, q0, &dld, &dq, &sus, &mu, true, &eg);
+  const double ld = ld0 + dld, qd = q0 + dq;
+  int bad = 0;
+  if (c < nreal && (flag0 || sus || !isfinite(ld) || !isfinite(qd))) bad = 1;
+  // 4. sums in chunk order (a fixed tree over the lanes) and the problem's conditioning record (decide_kernel's test)
+  auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
+  auto nmin = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x < a ? x : a)); };
+  const bool real = c < nreal;
+  lds[c] = real ? ld : 0.0;
+  lds[T + c] = real ? qd : 0.0;
+  lds[2 * T + c] = (double)bad;
+  lds[3 * T + c] = real ? gamma : 0.0;
+  lds[4 * T + c] = real ? mu : 1.0;
+  lds[5 * T + c] = real ? eg : 0.0;
+  __syncthreads();
+  for (int s = T / 2; s >= 1; s >>= 1) {
+    if (c < s) {
+      lds[c] += lds[c + s];
+      lds[T + c] += lds[T + c + s];
+      lds[2 * T + c] += lds[2 * T + c + s];
+      lds[3 * T + c] = nmax(lds[3 * T + c], lds[3 * T + c + s]);
+      lds[4 * T + c] = nmin(lds[4 * T + c], lds[4 * T + c + s]);
+      lds[5 * T + c] = nmax(lds[5 * T + c], lds[5 * T + c + s]);
+    }
+    __syncthreads();
+  }
+  if (c == 0) {
+    const double g = lds[3 * T], m = lds[4 * T], er = lds[5 * T];
+    bool pending = lds[2 * T] > 0.0;
+    if (P.cert_gamma > 0.0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
+                               (P.cert_eg > 0.0 && !(g * er < P.cert_eg))))
+      pending = true;  // ill-conditioned: the scan pipeline routes it (checked replay / sequential recurrence)
+    if (pending) {
+      P.need_scan[b] = 1;
+      P.out_status[b] = CLR_PENDING_STATUS;
+    } else {
+      P.need_scan[b] = 0;
+      P.out_status[b] = CLR_OK;
+      P.out_logdet[b] = lds[0];
+      P.out_quad[b] = lds[T];
+      P.out_ll[b] = combine_loglike(lds[0], lds[T], N);
+    }
+  }
+}
+
+template <int JR, int JC>
+bool go_batch(const BatchParams& P, int threads, hipStream_t s) {
+  constexpr int ELEM = Widths<JR, JC>::ELEM;
+  const int L = (P.N + threads - 1) / threads;
+  const size_t lds = (size_t)(ELEM > 6 ? ELEM : 6) * threads * sizeof(double);
+  if (P.fast_trig) hipLaunchKernelGGL((small_batch_kernel<JR, JC, true>), dim3(P.B), dim3(threads), lds, s, P, L);
+  else hipLaunchKernelGGL((small_batch_kernel<JR, JC, false>), dim3(P.B), dim3(threads), lds, s, P, L);
+  return true;
+}
+
 template <int JR, int JC>
 bool go(const SmallParams& P, int threads, bool fast, hipStream_t s) {
   constexpr int ELEM = Widths<JR, JC>::ELEM;
@@ -143,6 +262,19 @@ bool go(const SmallParams& P, int threads, bool fast, hipStream_t s) {
 bool small_compute_supported(int JR, int JC, int N) {
   const int J = JR + 2 * JC;
   return J >= 1 && J <= 4 && N >= 64 && N <= 4096;
+}
+
+bool small_batch_supported(int JR, int JC, int N) {
+  const int J = JR + 2 * JC;
+  return J >= 1 && J <= 4 && N >= 512 && N <= 32768;
+}
+
+bool launch_small_batch(int JR, int JC, const BatchParams& P, int threads, hipStream_t s) {
+#define CLR_SMALLB(R, C) if (JR == R && JC == C) return go_batch<R, C>(P, threads, s);
+  CLR_SMALLB(1, 0) CLR_SMALLB(2, 0) CLR_SMALLB(3, 0) CLR_SMALLB(4, 0)
+  CLR_SMALLB(0, 1) CLR_SMALLB(1, 1) CLR_SMALLB(2, 1) CLR_SMALLB(0, 2)
+#undef CLR_SMALLB
+  return false;
 }
 
 bool launch_small_compute(int JR, int JC, const SmallParams& P, int threads, bool fast, hipStream_t s) {

@@ -213,6 +213,13 @@ int clr_batch_set_series(clr_batch* h,
                          const double* t, long t_stride,
                          const double* diag, long diag_stride,
                          const double* y, long y_stride);
+/* Short narrow problems (widths 1..4, 512 <= N <= 32768; BASELINE configs[1]: 256 x 1e4 x width 4): the whole fused
+ * evaluation in ONE launch, one workgroup per problem -- chunk elements composed by a Kogge-Stone scan in LDS, the
+ * reference recurrence per chunk from the scanned states, every chunk boundary checked; a problem that fails the check
+ * (or has a flagged pivot) goes through the scan pipeline before results are handed out.  mode: -1 automatic (up to
+ * 1024 problems), 0 off, 1 whenever supported.  clr_batch_get_small_mode: whether the next evaluation takes it. */
+int clr_batch_set_small_mode(clr_batch* h, int mode);
+int clr_batch_get_small_mode(const clr_batch* h, int* active);
 /* The smallest step t[n + 1] - t[n] over the plan's series, found by the device-side scan of clr_batch_set_series
  * (negative: some series is not sorted -- GP.compute's check, celerite.py:126-129, without a host pass over t; NaN: a
  * NaN time).  clr_batch_clear_series drops the series (a front end that rejects unsorted input calls it). */

@@ -160,6 +160,7 @@ def test_multilevel_prefix_against_the_walk(JR, JC):
         case = synthetic(B, N, JR, JC, family, seed=seed + JR + 9 * JC)
         l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
         plan = batch.BatchedGP(B, N, JR, JC)
+        plan.set_warm_start(0)       # (the scan's own start states are what is compared: no warm-started recurrence)
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case))
         for nchunk, plans in ((64, [(-1, 0), (1, 4), (1, 7), (2, 3)]), (125, [(-1, 0), (1, 8), (2, 4), (3, 3)]),
@@ -639,6 +640,61 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
             sp.close()
         for a, b, c in zip(want, got, got2):
             assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), S
+
+
+@pytest.mark.parametrize("JR,JC", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (1, 1), (2, 1), (0, 2)])
+def test_short_narrow_problems_in_one_launch(JR, JC):
+    """small_batch_kernel (BASELINE configs[1]'s route: one workgroup per problem, Kogge-Stone scan of the composed chunk
+    elements in LDS, corrections and certificate in the same launch) against the oracle and against the scan pipeline:
+    ragged lengths, the shortest and the longest supported series, both input families, a shared series, an indefinite
+    problem and a near-singular one (left pending and settled by the pipeline with the reference's status)."""
+    for N, family in ((512, "bench"), (1000, "accuracy"), (10000, "bench"), (4099, "accuracy"), (32768, "bench")):
+        B = 5
+        case = synthetic(B, N, JR, JC, family, seed=3 * JR + 5 * JC + N)
+        (case["a_real"] if JR else case["a_comp"])[1] *= -30.0     # indefinite: linalg_exception in the reference
+        case["diag"] = np.array(case["diag"], copy=True)
+        case["diag"][3] = 1e-14                                    # near-singular: gamma far above the bound
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        outs = {}
+        for mode in (1, 0):
+            plan = batch.BatchedGP(B, N, JR, JC)
+            try:
+                plan.set_small_mode(mode)
+                plan.set_warm_start(0)
+                plan.set_series(case["t"], case["diag"], case["y"])
+                plan.set_coefficients(*coeffs_of(case))
+                assert plan.small_mode_active() == bool(mode)
+                outs[mode] = plan.log_likelihood()
+                if mode:
+                    again = plan.log_likelihood()
+                    for a, b_ in zip(outs[mode], again):
+                        assert np.array_equal(a, b_, equal_nan=True)
+            finally:
+                plan.close()
+            ll, ld, q, st = outs[mode]
+            assert np.array_equal(st, s0), (N, mode, st, s0)
+            ok = (s0 == 0) & (np.arange(B) != 3)
+            within("one-launch batch (mode %d): vs oracle" % mode,
+                   max(np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok]))), REL, (N, JR, JC))
+            assert np.all(np.isneginf(ll[s0 != 0]))
+        # the near-singular problem: whichever route its conditioning record sends it on, both modes agree
+        if s0[3] == 0:
+            assert abs(outs[1][1][3] - outs[0][1][3]) <= 1e-9 * abs(outs[0][1][3])
+    # one shared series, many draws (stride 0); automatic selection at this size
+    case = synthetic(40, 3000, JR, JC, "bench", seed=9)
+    plan = batch.BatchedGP(40, 3000, JR, JC)
+    try:
+        plan.set_series(case["t"][0], case["diag"][0], case["y"][0])
+        plan.set_coefficients(*coeffs_of(case))
+        assert plan.small_mode_active()
+        ll, ld, q, st = plan.log_likelihood()
+        plan.set_chunks(24)                      # an explicit chunk count asks for the scan pipeline
+        assert not plan.small_mode_active()
+    finally:
+        plan.close()
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"][0], case["diag"][0], case["y"][0])
+    assert np.array_equal(st, s0)
+    within("one-launch batch, shared series: vs oracle", max(np.max(np.abs(ld - d0) / np.abs(d0)), np.max(np.abs(q - q0) / np.abs(q0))), REL)
 
 
 def test_set_series_checks_the_order_on_the_device_and_follows_the_chunking():
