@@ -224,7 +224,9 @@ class BatchedGP(object):
     def set_general(self, A, U, V):
         """General semiseparable terms (``CholeskySolver.compute``'s ``A, U, V``; cholesky.h:65-72,148-152) for the
         batch: ``A`` ``(B, N)`` or ``(N,)``, ``U`` and ``V`` ``(B, J_general, N)`` or ``(J_general, N)`` (shared by
-        all problems).  Empty ``U`` removes them.  The plan then runs the any-width sequential kernel."""
+        all problems).  Empty ``U`` removes them.  Up to a total width of 64 the plan then runs the wave-per-(problem,
+        chunk) kernels with the general rows as one more row class, above that the any-width sequential kernel
+        (:meth:`set_general_route`)."""
         U, V, A = _f64(U), _f64(V), _f64(A)
         if U.size == 0:
             _check(_load().clr_batch_set_general(self._h, 0, None, 0, None, 0, None, 0))
@@ -239,6 +241,13 @@ class BatchedGP(object):
         _check(_load().clr_batch_set_general(self._h, JG, _ptr(A), self.N if A.ndim == 2 else 0,
                                              _ptr(U), JG * self.N if U.ndim == 3 else 0,
                                              _ptr(V), JG * self.N if V.ndim == 3 else 0))
+
+    def set_general_route(self, route=-1):
+        """Plans with general terms: -1 the wide kernels when the total width allows (default), 1 the any-width
+        sequential kernel (one workgroup per problem; the cross-check)."""
+        lib = _load()
+        lib.clr_batch_set_general_route.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.clr_batch_set_general_route(self._h, int(route)))
 
     # -- tuning -------------------------------------------------------------
     def set_chunks(self, nchunk):

@@ -341,7 +341,12 @@ struct clr_batch {
   int B = 0, N = 0, J_real = 0, J_comp = 0, J = 0;
   int nchunk = 1, L = 0;
   int L0 = 0;                      // wide plans: samples of the first chunk when it is longer than L (0: uniform)
+  int general_route = -1;          // plans with general terms: -1 the wide kernels when the total width allows, 1 the any-width sequential kernel
   int small_mode = -1;             // one-launch evaluation of short narrow problems: -1 auto, 0 off, 1 whenever supported
+  // general terms through the wide kernels (widths J + J_general <= 64): their own chunking and workspace
+  int gen_nchunk = 0, gen_L = 0, gen_L0 = 0;
+  DevBuf gen_elems, gen_starts, gen_part, gen_cond;
+  int* gen_flags = nullptr;
   bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
   double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk
   const clr::BatchLaunchers* launch = nullptr;
@@ -1393,6 +1398,8 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   clr::staging_destroy(h->staging);
   h->scan.release();
+  for (DevBuf* b : {&h->gen_elems, &h->gen_starts, &h->gen_part, &h->gen_cond}) b->release();
+  if (h->gen_flags) (void)hipFree(h->gen_flags);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -2154,11 +2161,50 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->J_general = J_general;
   h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  // Total widths up to 64 run on the wave-per-(problem, chunk) kernels (wide_kernels.hip, GEN flavour): the general rows
+  // are one more row class there.  Chunks as for any wide plan: one round of two waves per SIMD, the scan up to width 32.
+  h->gen_nchunk = 0;
+  const int Wt = h->J + J_general;
+  if (Wt <= clr::wide_max_width()) {
+    int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
+    if (nchunk > 16) nchunk = 16;
+    while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    if (nchunk < 1) nchunk = 1;
+    int L = (h->N + nchunk - 1) / nchunk;
+    if (nchunk > 1) L = (L + 7) & ~7;
+    nchunk = (h->N + L - 1) / L;
+    int L0 = 0;
+    if (nchunk > 1 && h->wide_first_ratio > 1.0) {  // (the riderless, longer first chunk: clr_batch_set_chunks)
+      int L2 = (int)ceil(h->N / (nchunk - 1 + h->wide_first_ratio));
+      L2 = (L2 + 7) & ~7;
+      const long first = (long)h->N - (long)(nchunk - 1) * L2;
+      if (L2 >= 64 && first >= L2) { L = L2; L0 = (int)first; }
+    }
+    const size_t pc = (size_t)h->B * nchunk, JP = Wt <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    if (nchunk > 1) {
+      if ((st = h->gen_elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
+      if ((st = h->gen_starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
+    }
+    if ((st = h->gen_part.reserve(pc * 4)) != CLR_OK) return st;
+    if ((st = h->gen_cond.reserve(pc * 4)) != CLR_OK) return st;
+    if (h->gen_flags) (void)hipFree(h->gen_flags);
+    h->gen_flags = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->gen_flags), (2 * pc + (size_t)h->B) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->gen_flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->gen_cond.p, 0, pc * 4 * sizeof(double), h->stream));
+    h->gen_nchunk = nchunk; h->gen_L = L; h->gen_L0 = L0;
+  }
   return CLR_OK;
 }
 
 static bool warm_runs(const clr_batch* h, int materialize);
 static bool small_runs(const clr_batch* h, int materialize);
+
+int clr_batch_set_general_route(clr_batch* h, int route) {
+  if (route != -1 && route != 1) return fail(CLR_INVALID_ARGUMENT, "general route: -1 (automatic) or 1 (sequential kernel)");
+  h->general_route = route;
+  return CLR_OK;
+}
 
 int clr_batch_set_small_mode(clr_batch* h, int mode) {
   if (mode < -1 || mode > 1) return fail(CLR_INVALID_ARGUMENT, "small mode: -1 (auto), 0 (off) or 1 (whenever supported)");
@@ -2233,7 +2279,7 @@ int clr_batch_set_layout(clr_batch* h, int layout) {
 // problem over all N samples), which overwrites their results: nothing of theirs depends on the scan.
 static void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev) {
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], stream); };
-  const int JP = J_real + 2 * J_comp <= 16 ? 16 : 32;
+  const int JP = J_real + 2 * J_comp + P.J_general <= 16 ? 16 : 32;
   mark(1);
   if (P.nchunk > 1) clr::launch_wide_summarize(P, J_real, J_comp, stream);
   mark(2);
@@ -2375,6 +2421,30 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (h->J_general > 0) {  // general terms: the any-width sequential recurrence, one workgroup per problem
     if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms: use CholeskySolver");
     h->warm_inflight = false;
+    if (h->gen_nchunk > 0 && h->general_route != 1) {
+      // the wide kernels with the general rows as a third row class (chunked scan up to total width 32)
+      clr::BatchParams W = P;
+      const size_t pc = (size_t)h->B * h->gen_nchunk;
+      W.nchunk = h->gen_nchunk; W.L = h->gen_L; W.L0 = h->gen_L0;
+      W.t = h->t.p; W.diag = h->diag.p; W.y = h->y.p;
+      W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
+      W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
+      W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;
+      W.coop_prefix = 1;
+      W.J_general = h->J_general;
+      W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;
+      W.gen_A_stride = h->gA_stride; W.gen_U_stride = h->gU_stride; W.gen_V_stride = h->gV_stride;
+      W.elems = h->gen_elems.p; W.starts = h->gen_starts.p;
+      W.part = h->gen_part.p; W.partx = h->gen_part.p + pc * 2;
+      W.cond = h->gen_cond.p; W.egerr = h->gen_cond.p + pc * 3;
+      W.flags = h->gen_flags; W.flagsx = h->gen_flags + pc; W.need_exact = h->gen_flags + 2 * pc;
+      W.force_exact = (h->force_exact || W.nchunk < 2) ? 1 : 0;
+      W.wide_materialize = 0;
+      mark(0);
+      wide_flow(W, h->J_real, h->J_comp, h->stream, ev);
+      HIP_TRY(hipGetLastError());
+      return CLR_OK;
+    }
     clr::GenericBatch G;
     memset(&G, 0, sizeof(G));
     G.B = h->B; G.N = h->N; G.J_real = h->J_real; G.J_comp = h->J_comp; G.J_general = h->J_general;

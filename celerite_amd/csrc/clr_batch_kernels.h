@@ -28,6 +28,12 @@ constexpr int CLR_OK_STATUS = 0;  // (= CLR_OK of include/celerite_hip.h, which 
 constexpr int CLR_PENDING_STATUS = -1;  // internal: left to the scan pipeline by the warm path; never handed out
 struct BatchParams {
   int B, N, nchunk, L;
+  // general semiseparable terms (cholesky.h:65-72,114-116,148-152), wide path only: J_general extra rows behind the
+  // celerite rows with phi = 1 and per-sample features U[j][n], V[j][n] (row-major [J_general][N] per problem), A[n]
+  // added to the diagonal; strides in doubles between problems (0: shared)
+  int J_general;
+  const double *gen_A, *gen_U, *gen_V;
+  long gen_A_stride, gen_U_stride, gen_V_stride;
   int L0;  // wide path: samples of the FIRST chunk when it differs from L (its summarize carries no riders and is
            // given more samples in return); 0: uniform chunks
   const double *jitter, *a_real, *c_real, *a_comp, *b_comp, *c_comp, *d_comp;

@@ -133,45 +133,6 @@ struct DirectSeries {
   CLR_HD void step_end(int) {}
 };
 
-// DirectSeries behind a register pipeline: the chunk loops ask for t(i + 2), diag(i + 1), y(i + 1) once per step in
-// increasing order, one step ahead of their use -- with a lone wave per SIMD (small_batch_kernel) that is a full
-// memory round trip per step (measured: 1.0 us per replay step of which 0.4 us are instructions).  Here every call
-// hands out the front of a PF-deep queue and issues the load PF samples further on, so PF loads per array are always
-// in flight.  Only valid for the access order of summarize_chunk / replay_chunk (t from 0, diag and y from 0, each
-// index once, ascending).
-template <int PF>
-struct QueuedSeries {
-  DirectSeries d;
-  double tq[PF], dq[PF], yq[PF];
-  CLR_HD void prologue() {
-    CLR_UNROLL
-    for (int k = 0; k < PF; ++k) { tq[k] = d.t(k); dq[k] = d.diag(k); yq[k] = d.y(k); }
-  }
-  CLR_HD double t(int i) {
-    const double v = tq[0];
-    CLR_UNROLL
-    for (int k = 0; k + 1 < PF; ++k) tq[k] = tq[k + 1];
-    tq[PF - 1] = d.t(i + PF);
-    return v;
-  }
-  CLR_HD double diag(int i) {
-    const double v = dq[0];
-    CLR_UNROLL
-    for (int k = 0; k + 1 < PF; ++k) dq[k] = dq[k + 1];
-    dq[PF - 1] = d.diag(i + PF);
-    return v;
-  }
-  CLR_HD double y(int i) {
-    const double v = yq[0];
-    CLR_UNROLL
-    for (int k = 0; k + 1 < PF; ++k) yq[k] = yq[k + 1];
-    yq[PF - 1] = d.y(i + PF);
-    return v;
-  }
-  CLR_HD void step_begin(int) {}
-  CLR_HD void step_end(int) {}
-};
-
 // ---------------------------------------------------------------------------
 // sin and cos of the absolute phase d * t.  ocml's fp64 sincos spends 108 fp64
 // instructions per call (double-double reduction and polynomial tails) to be

@@ -112,7 +112,12 @@ __device__ __forceinline__ int wide_chunk_begin(const BatchParams& P, int c) {
 // RIDERS == false (summarize only): the chunk that starts at sample 0.  Its start state IS the zero state, so the
 // prefix takes (C, b) of its element as they are and nothing ever reads A, Jm, eta: the riders -- half of a
 // summarize step's state FMAs -- are not carried, and the host makes that chunk longer in return (BatchParams::L0).
-template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS>
+// GEN: general semiseparable terms (cholesky.h:65-72,114-116,148-152): rows W_c .. W_c + J_general - 1 behind the
+// celerite rows carry phi = 1 and per-sample features u = U[j][n], v = V[j][n]; A[n] joins the diagonal.  A general
+// row is a "real" row (d = 0: cos = 1, sin = 0, c = 0: phi = 1) whose constants u0, v0 are REPLACED every step by
+// the row's next sample, fetched GEN_PF steps ahead through a register queue -- nothing else in the step changes.
+constexpr int GEN_PF = 6;
+template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN>
 __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int JC) {
   static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
   constexpr bool RID = MODE == 1 && RIDERS;
@@ -142,7 +147,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   const int lane = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int row = lane / LPR, seg = lane % LPR;
-  const int W = JR + 2 * JC;
+  const int Wc = JR + 2 * JC;                       // celerite rows
+  const int W = Wc + (GEN ? P.J_general : 0);       // + general rows
   const bool writer = seg == 0;
 
   RowCoeffs rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -150,7 +156,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     rc.u0 = P.a_real[(long)b * JR + row];
     rc.v0 = 1.0;
     rc.c = P.c_real[(long)b * JR + row];
-  } else if (row < W) {
+  } else if (row < Wc) {
     const int j = (row - JR) >> 1;
     const double a = P.a_comp[(long)b * JC + j], bb = P.b_comp[(long)b * JC + j];
     if (((row - JR) & 1) == 0) { rc.uc = a; rc.us = bb; rc.vc = 1.0; }   // cholesky.h:143,145
@@ -169,6 +175,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   const double* dp = P.diag + b * P.diag_stride;
   const double* yp = P.y + b * P.y_stride;
   const int N = P.N;
+  const bool gen = GEN && row >= Wc && row < W;
+  const double* Ug = gen ? P.gen_U + b * P.gen_U_stride + (long)(row - Wc) * N : nullptr;
+  const double* Vg = gen ? P.gen_V + b * P.gen_V_stride + (long)(row - Wc) * N : nullptr;
+  const double* Ap = GEN ? P.gen_A + b * P.gen_A_stride : nullptr;
   // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
   if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] != 1) return;
   if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
@@ -209,10 +219,32 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const int m = n_lo + lane;
     tv = m < N ? tp[m] : 0.0;
     dv = m < N ? dp[m] : 0.0;
+    if (GEN && m < N) dv += Ap[m];  // (the reference adds A last, cholesky.h:99: a difference in the last bit)
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
   }
   auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };  // k < 66
+  // (GEN) the general rows' features of samples base .. base + GEN_PF - 1; gen_next() hands out the front one as the
+  // row's constants and fetches the sample GEN_PF further on
+  double gu[GEN ? GEN_PF : 1], gv[GEN ? GEN_PF : 1];
+  int gbase = n_lo;
+  if (GEN) {
+#pragma unroll
+    for (int k = 0; k < GEN_PF; ++k) {
+      gu[k] = (gen && n_lo + k < N) ? Ug[n_lo + k] : 0.0;
+      gv[k] = (gen && n_lo + k < N) ? Vg[n_lo + k] : 0.0;
+    }
+  }
+  auto gen_next = [&]() {
+    if (gen) { rc.u0 = gu[0]; rc.v0 = gv[0]; }
+#pragma unroll
+    for (int k = 0; k + 1 < GEN_PF; ++k) { gu[k] = gu[k + 1]; gv[k] = gv[k + 1]; }
+    const int m = gbase + GEN_PF;
+    gu[GEN_PF - 1] = (gen && m < N) ? Ug[m] : 0.0;
+    gv[GEN_PF - 1] = (gen && m < N) ? Vg[m] : 0.0;
+    ++gbase;
+  };
+  if (GEN) gen_next();  // the chunk's first sample
 
   // features of the chunk's first sample
   double u, v, phi;
@@ -241,6 +273,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       if (n + 1 < N) {
         const double t1 = t_at(k + 1);
         const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        if (GEN) gen_next();  // the general rows' u0, v0 of sample n + 1
         if (LAZY) {
           if (((n + 1 - n_lo) & 15) == 0) {
             sincos_phase<FAST>(rc.d * t1, &sdr, &csr);  // anchor
@@ -405,6 +438,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const int m = n0 + 64 + lane;
     tv = tv2;
     dv = m < N ? dp[m] : 0.0;
+    if (GEN && m < N) dv += Ap[m];
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
   }
@@ -489,10 +523,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   }
 }
 
-template <int WMAX, bool FAST, int MODE, bool LAZY = false>
+template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
-  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false>(P, JR, JC);
-  else wide_scan_body<WMAX, FAST, MODE, LAZY, true>(P, JR, JC);
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN>(P, JR, JC);
+  else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -890,35 +924,42 @@ namespace {
 int wide_max_width() { return 64; }
 int wide_scan_max_width() { return 32; }  // the chunk algebra runs in prefix_coop_kernel<16 | 32>
 
+template <bool GEN>
 static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const dim3 grid(P.nchunk, P.B);
-  if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0>), grid, dim3(64), 0, s, P, JR, JC);
-  else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0>), grid, dim3(64), 0, s, P, JR, JC);
+  if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+  else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
 }
 
-template <int MODE>
-static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
-  const int W = JR + 2 * JC;
+template <int MODE, bool GEN>
+static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
+  const int W = JR + 2 * JC + (GEN ? P.J_general : 0);
   const dim3 grid(P.nchunk, P.B);
   if (MODE == 1 && P.split_lazy) {  // summarize with the decay factored out of the state (dense series)
-#define CLR_GOL(WM)                                                                                                \
-  do {                                                                                                             \
-    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, 1, true>), grid, dim3(64), 0, s, P, JR, JC);  \
-    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true>), grid, dim3(64), 0, s, P, JR, JC);              \
+#define CLR_GOL(WM)                                                                                                     \
+  do {                                                                                                                  \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);  \
+    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);              \
   } while (0)
     if (W <= 16) CLR_GOL(16); else CLR_GOL(32);
 #undef CLR_GOL
     return;
   }
-#define CLR_GO(WM)                                                                                  \
-  do {                                                                                              \
-    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, MODE>), grid, dim3(64), 0, s, P, JR, JC); \
-    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, MODE>), grid, dim3(64), 0, s, P, JR, JC);            \
+#define CLR_GO(WM)                                                                                                        \
+  do {                                                                                                                    \
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, MODE, false, GEN>), grid, dim3(64), 0, s, P, JR, JC); \
+    else hipLaunchKernelGGL((wide_scan_kernel<WM, false, MODE, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);            \
   } while (0)
   if (W <= 16) CLR_GO(16);
   else if (W <= 32 || MODE == 1) CLR_GO(32);
-  else launch_wide64(P, JR, JC, s);
+  else launch_wide64<GEN>(P, JR, JC, s);
 #undef CLR_GO
+}
+
+template <int MODE>
+static void launch_wide(const BatchParams& P, int JR, int JC, hipStream_t s) {
+  if (P.J_general > 0) launch_wide_g<MODE, true>(P, JR, JC, s);
+  else launch_wide_g<MODE, false>(P, JR, JC, s);
 }
 
 // ---------------------------------------------------------------------------

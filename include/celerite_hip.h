@@ -234,11 +234,15 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
 /* General semiseparable terms for the whole batch (cholesky.h:65-72,148-152: A added to the diagonal, rows U, V
  * appended to U~, V~ with phi = 1): A [N], U and V row-major [J_general][N] per problem, *_stride doubles between
  * problems (N resp. J_general * N) or 0 for one block shared by all problems; J_general = 0 removes them.  A plan
- * with general terms evaluates through the any-width sequential kernel -- one workgroup per problem, the reference's
- * step order, compute fused with dot_solve and log_determinant -- at widths J_real + 2 J_comp + J_general <=
- * CLR_MAX_WIDTH; fused log-likelihood only (materialising runs: CholeskySolver). */
+ * with general terms evaluates, up to a total width J_real + 2 J_comp + J_general of 64, on the wave-per-(problem,
+ * chunk) kernels of the widths 9..64 with the general rows as a third row class (per-sample features fetched a few
+ * steps ahead; chunked scan up to total width 32, as clr_batch_set_chunks(h, 0) would pick for a wide plan), above
+ * that -- or after clr_batch_set_general_route(h, 1) -- through the any-width sequential kernel (one workgroup per
+ * problem, the reference's step order) up to CLR_MAX_WIDTH; fused log-likelihood only (materialising runs:
+ * CholeskySolver). */
 int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
                           const double* V, long V_stride);
+int clr_batch_set_general_route(clr_batch* h, int route);
 
 /* Tuning: how the kernels read the series.
  *   2 (default) staged: each wave loads the row-major arrays in coalesced tiles of

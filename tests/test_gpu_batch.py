@@ -642,6 +642,58 @@ def test_sharding_does_not_change_a_single_bit(JR, JC, N, nchunk):
             assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), S
 
 
+def test_general_terms_in_the_chunked_scan_at_length():
+    """General terms at N >= 1e4 through the chunked wide scan (summarize with the general rows, prefix, corrections):
+    parity with the oracle problem by problem, the dense-series (lazy) and the sparse flavour, and the cost against a
+    celerite-only plan of the SAME total width (the bar: within 3x)."""
+    import time
+    B, N = 64, 12000
+    for (JR, JC, JG), family in (((2, 3, 4), "bench"), ((1, 2, 3), "accuracy"), ((0, 6, 4), "bench"), ((4, 8, 6), "bench")):
+        rng = np.random.RandomState(JR + 7 * JC + JG)
+        case = synthetic(B, N, JR, JC, family, seed=5 + JG)
+        t = case["t"]
+        z = (t - t.mean(axis=1, keepdims=True)) / (t.max(axis=1, keepdims=True) - t.min(axis=1, keepdims=True))
+        U = np.stack([np.vander(zz, JG).T for zz in z])
+        V = U * rng.rand(B, JG)[:, :, None]
+        A = np.sum(U * V, axis=1) + 1e-8
+        plan = batch.BatchedGP(B, N, JR, JC)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case), jitter=0.01)
+        plan.set_general(A, U, V)
+        ll, ld, q, st = plan.log_likelihood()
+        for _ in range(3):
+            plan.log_likelihood()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            plan.log_likelihood()
+        ms_gen = (time.perf_counter() - t0) / 5 * 1e3
+        plan.close()
+        for p in range(0, B, 7):
+            r = ref.RefSolver()
+            r.compute(0.01, *coeffs_of(case, p), A[p], U[p], V[p], case["t"][p], case["diag"][p])
+            assert st[p] == 0
+            ld0, q0 = r.log_determinant(), r.dot_solve(case["y"][p])
+            within("general terms, chunked wide scan: vs oracle", max(abs(ld[p] - ld0) / abs(ld0), abs(q[p] - q0) / abs(q0)), REL,
+                   (JR, JC, JG, p))
+        # a celerite-only plan of the same total width: JG more real terms
+        W = JR + 2 * JC + JG
+        if W >= 9:
+            ref_case = synthetic(B, N, JR + JG, JC, family, seed=5 + JG)
+            plan = batch.BatchedGP(B, N, JR + JG, JC)
+            plan.set_series(ref_case["t"], ref_case["diag"], ref_case["y"])
+            plan.set_coefficients(*coeffs_of(ref_case), jitter=0.01)
+            for _ in range(3):
+                plan.log_likelihood()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                plan.log_likelihood()
+            ms_ref = (time.perf_counter() - t0) / 5 * 1e3
+            plan.close()
+            print("general terms (%d, %d) + %d at N = %d, B = %d: %.2f ms per evaluation; celerite-only width %d: %.2f ms"
+                  % (JR, JC, JG, N, B, ms_gen, W, ms_ref))
+            within("general terms: cost / celerite-only plan of the same width", ms_gen / ms_ref, 3.0, (JR, JC, JG))
+
+
 @pytest.mark.parametrize("JR,JC", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (1, 1), (2, 1), (0, 2)])
 def test_short_narrow_problems_in_one_launch(JR, JC):
     """small_batch_kernel (BASELINE configs[1]'s route: one workgroup per problem, Kogge-Stone scan of the composed chunk
@@ -1639,7 +1691,15 @@ def test_general_terms_in_the_batch(JR, JC, JG, N, shared):
     plan.set_series(case["t"], case["diag"], case["y"])
     plan.set_coefficients(*coeffs_of(case), jitter=0.01)
     plan.set_general(A, U, V)
-    ll, ld, q, st = plan.log_likelihood()
+    ll, ld, q, st = plan.log_likelihood()       # (total width <= 64: the wide kernels, general rows as a row class)
+    plan.set_general_route(1)                   # the any-width sequential kernel: the same numbers to rounding
+    ll_s, ld_s, q_s, st_s = plan.log_likelihood()
+    plan.set_general_route(-1)
+    assert np.array_equal(st, st_s)
+    oks = st == 0
+    if oks.any():
+        within("general terms in the batch: wide kernels vs sequential kernel",
+               max(np.max(np.abs(ld[oks] - ld_s[oks]) / np.abs(ld_s[oks])), np.max(np.abs(q[oks] - q_s[oks]) / np.abs(q_s[oks]))), 1e-11)
     for p in range(B):
         r = ref.RefSolver()
         gen = (A, U, V) if shared else (A[p], U[p], V[p])
