@@ -756,6 +756,7 @@ def main(argv=None):
                          "achieved": (factor_bytes + bytes_) / mat_replay_s / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": (factor_bytes + bytes_) / mat_replay_s / 1e9 / PEAK_HBM_GBS,
                          "bytes_per_launch": factor_bytes + bytes_,
+                         "traffic": pmc_traffic("replay (materialising)", B, N, JR, JC, plan.chunks[0]),
                          "whole_step_frac": (factor_bytes + 2 * bytes_) / mat_step_s / 1e9 / PEAK_HBM_GBS,
                          "note": "factor written (8 N (3W+1) B per problem) + t, diag, y read, over the replay "
                                  "kernel's HIP-event time; whole_step_frac = (factor + two passes over the "
