@@ -307,6 +307,7 @@ struct clr_solver {
   // the series it holds (an optimiser calls with the same t, diag, y and new coefficients)
   struct clr_batch* grad_plan = nullptr;
   int grad_N = 0, grad_JR = -1, grad_JC = -1;
+  bool grad_wide = false, grad_had_general = false;
   std::vector<double> grad_series;
   int computed = 0, N = 0, J = 0;
   double log_det = 0.0;
@@ -933,13 +934,23 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   if ((st = ensure_stream(s)) != CLR_OK) return st;
   hipStream_t stream = s->stream;
 
-  if (!has_general && JG == 0 && JR + 2 * JC >= 1 && JR + 2 * JC <= 8 && N >= 1024 && !getenv("CLR_GRAD_SEQUENTIAL")) {
+  const int Wc = JR + 2 * JC, Wt = Wc + JG;
+  const bool narrow_plan = !has_general && JG == 0 && Wc >= 1 && Wc <= 8 && N >= 1024;
+  // widths 9..32, and general terms up to a total width of 32: the wide scan + chunk-wise forward-mode tangents
+  // (wide_batch_grad); chunk count for ONE problem from profiles/r04k_wide_grad_chunks.txt
+  const bool wide_plan = !narrow_plan && Wc >= 1 && Wt <= 32 && (Wc >= 9 || JG > 0) && N >= 4096;
+  if ((narrow_plan || wide_plan) && !getenv("CLR_GRAD_SEQUENTIAL")) {
     // parallel in n: the scan + the chunk-wise tangents (clr_batch_grad) on a one-problem plan
-    if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC) {
+    if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC || s->grad_wide != wide_plan) {
       if (s->grad_plan) clr_batch_destroy(s->grad_plan);
       s->grad_plan = clr_batch_create(1, N, JR, JC, s->device);
       s->grad_series.clear();
-      s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC;
+      s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC; s->grad_wide = wide_plan;
+      if (s->grad_plan && wide_plan) {
+        int nc = (int)lround(sqrt((double)N / (Wt <= 16 ? 40.0 : 170.0)));
+        nc = std::max(Wt <= 16 ? 8 : 16, std::min(nc, Wt <= 16 ? 64 : 32));
+        if ((st = clr_batch_set_chunks(s->grad_plan, nc)) != CLR_OK) return st;
+      }
     }
     if (s->grad_plan) {
       const size_t n = (size_t)N;
@@ -952,6 +963,10 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
         memcpy(s->grad_series.data(), x, n * sizeof(double));
         memcpy(s->grad_series.data() + n, diag, n * sizeof(double));
         memcpy(s->grad_series.data() + 2 * n, y, n * sizeof(double));
+      }
+      if (wide_plan && (JG > 0 || s->grad_had_general)) {  // (general terms are arguments of every call)
+        if ((st = clr_batch_set_general(s->grad_plan, JG, A, 0, U, 0, V, 0)) != CLR_OK) return st;
+        s->grad_had_general = JG > 0;
       }
       if ((st = clr_batch_set_coefficients(s->grad_plan, &jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp)) != CLR_OK)
         return st;
@@ -2169,6 +2184,8 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
     if (nchunk > 16) nchunk = 16;
     while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)
+      nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
     if (nchunk < 1) nchunk = 1;
     int L = (h->N + nchunk - 1) / nchunk;
     if (nchunk > 1) L = (L + 7) & ~7;
@@ -2348,6 +2365,27 @@ static bool small_runs(const clr_batch* h, int materialize) {
   return !h->pipeline_pinned && h->B <= (h->J >= 3 ? 256 : 1024);
 }
 
+// a plan with general terms on the wide kernels: its own chunking and workspace (clr_batch_set_general)
+static void general_wide_params(const clr_batch* h, const clr::BatchParams& P, clr::BatchParams& W) {
+  W = P;
+  const size_t pc = (size_t)h->B * h->gen_nchunk;
+  W.nchunk = h->gen_nchunk; W.L = h->gen_L; W.L0 = h->gen_L0;
+  W.t = h->t.p; W.diag = h->diag.p; W.y = h->y.p;
+  W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
+  W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
+  W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;
+  W.coop_prefix = 1;
+  W.J_general = h->J_general;
+  W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;
+  W.gen_A_stride = h->gA_stride; W.gen_U_stride = h->gU_stride; W.gen_V_stride = h->gV_stride;
+  W.elems = h->gen_elems.p; W.starts = h->gen_starts.p;
+  W.part = h->gen_part.p; W.partx = h->gen_part.p + pc * 2;
+  W.cond = h->gen_cond.p; W.egerr = h->gen_cond.p + pc * 3;
+  W.flags = h->gen_flags; W.flagsx = h->gen_flags + pc; W.need_exact = h->gen_flags + 2 * pc;
+  W.force_exact = (h->force_exact || W.nchunk < 2) ? 1 : 0;
+  W.wide_materialize = 0;
+}
+
 static bool warm_runs(const clr_batch* h, int materialize) {
   if (h->grad_scan_only) return false;
   return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
@@ -2423,23 +2461,8 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     h->warm_inflight = false;
     if (h->gen_nchunk > 0 && h->general_route != 1) {
       // the wide kernels with the general rows as a third row class (chunked scan up to total width 32)
-      clr::BatchParams W = P;
-      const size_t pc = (size_t)h->B * h->gen_nchunk;
-      W.nchunk = h->gen_nchunk; W.L = h->gen_L; W.L0 = h->gen_L0;
-      W.t = h->t.p; W.diag = h->diag.p; W.y = h->y.p;
-      W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
-      W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
-      W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;
-      W.coop_prefix = 1;
-      W.J_general = h->J_general;
-      W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;
-      W.gen_A_stride = h->gA_stride; W.gen_U_stride = h->gU_stride; W.gen_V_stride = h->gV_stride;
-      W.elems = h->gen_elems.p; W.starts = h->gen_starts.p;
-      W.part = h->gen_part.p; W.partx = h->gen_part.p + pc * 2;
-      W.cond = h->gen_cond.p; W.egerr = h->gen_cond.p + pc * 3;
-      W.flags = h->gen_flags; W.flagsx = h->gen_flags + pc; W.need_exact = h->gen_flags + 2 * pc;
-      W.force_exact = (h->force_exact || W.nchunk < 2) ? 1 : 0;
-      W.wide_materialize = 0;
+      clr::BatchParams W;
+      general_wide_params(h, P, W);
       mark(0);
       wide_flow(W, h->J_real, h->J_comp, h->stream, ev);
       HIP_TRY(hipGetLastError());
@@ -2654,11 +2677,89 @@ static int grad_chunk_spans(clr_batch* h) {
 // the evaluation by the scan, then per chunk the riders and the tangents of every direction group from the scanned
 // start states, then the walk over the chunks.  Problems the scan routed to the sequential recurrence take the
 // sequential gradient kernel (grad_kernels.hip).
+// The plan gradient at widths 9..32 and with general terms (total width <= 32): the wide scan's evaluation, then the
+// riders of every chunk from its element, one tangent wave per (direction, chunk) from the scanned start states, and a
+// walk over the chunks per direction (wide_grad_kernels.hip); problems the evaluation sent to the sequential recurrence
+// take the sequential tangent kernel.
+static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
+  const bool general = h->J_general > 0;
+  const int Wt = h->J + h->J_general;
+  if (general && (h->gen_nchunk < 2 || h->general_route == 1))
+    return fail(CLR_UNSUPPORTED, "the plan gradient with general terms needs the chunked wide scan (total width <= 32, N >= 1024)");
+  if (!general && (h->launch || h->nchunk < 2))
+    return fail(CLR_UNSUPPORTED, "the plan gradient at widths 9..32 needs a chunked plan: use clr_batch_grad_log_likelihood");
+  if (Wt > clr::wide_scan_max_width())
+    return fail(CLR_UNSUPPORTED, "the plan gradient covers total widths up to 32: use clr_batch_grad_log_likelihood");
+  int st = clr_batch_enqueue(h, 0);
+  if (st != CLR_OK) return st;
+  clr::BatchParams P0, P;
+  if ((st = batch_params(h, 0, P0)) != CLR_OK) return st;
+  if (general) general_wide_params(h, P0, P); else P = P0;
+  const size_t B = (size_t)h->B, NG = 1 + 2 * (size_t)h->J_real + 4 * (size_t)h->J_comp;
+  const int JP = Wt <= 16 ? 16 : 32;
+  const size_t pc = B * (size_t)P.nchunk, RID = 2 * (size_t)JP * JP + JP, OUT = (size_t)JP * JP + JP + 2;
+  if ((st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
+  if ((st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
+  if ((st = h->g_res.reserve(B * (NG + 2))) != CLR_OK) return st;  // value | grad | status (ints in the last B doubles)
+  double* d_value = h->g_res.p;
+  double* d_grad = h->g_res.p + B;
+  int* d_status = reinterpret_cast<int*>(h->g_res.p + B + B * NG);
+
+  clr::WideGradWalk W;
+  memset(&W, 0, sizeof(W));
+  W.B = h->B; W.NG = (int)NG; W.nchunk = P.nchunk; W.JP = JP; W.N = h->N;
+  W.elems = P.elems; W.starts = P.starts; W.riders = h->g_riders.p; W.rec = h->g_out.p;
+  W.level = P.need_exact; W.ll = P.out_ll; W.ll_status = P.out_status; W.jitter = P.jitter;
+  W.out_value = d_value; W.out_grad = d_grad; W.out_status = d_status;
+
+  clr::GradParams G;
+  memset(&G, 0, sizeof(G));
+  G.N = h->N; G.J_real = h->J_real; G.J_comp = h->J_comp; G.J_general = h->J_general;
+  G.a_real = P.a_real; G.c_real = P.c_real; G.a_comp = P.a_comp; G.b_comp = P.b_comp; G.c_comp = P.c_comp; G.d_comp = P.d_comp;
+  G.jitter_b = P.jitter;
+  if (general) {
+    G.A = h->gA.p; G.U = h->gU.p; G.V = h->gV.p;
+    G.A_stride = h->gA_stride; G.U_stride = h->gU_stride; G.V_stride = h->gV_stride;
+  }
+  G.t = h->t.p; G.diag = h->diag.p; G.y = h->y.p;
+  G.t_stride = h->t_stride; G.diag_stride = h->diag_stride; G.y_stride = h->y_stride;
+  G.fast_trig = P.fast_trig;
+  G.B = h->B;
+  G.only_level = P.need_exact;
+  G.nchunk = P.nchunk; G.L = P.L; G.L0 = P.L0; G.JP = JP;
+  G.starts = P.starts; G.rec = h->g_out.p;
+  G.out_value = d_value; G.out_grad = d_grad; G.out_status = d_status;
+
+  clr::launch_wide_grad_riders(W, h->stream);
+  clr::launch_grad_chunked(G, h->stream);
+  clr::launch_wide_grad_walk(W, h->stream);
+  clr::launch_grad(G, h->stream);  // (sequential form: only the problems with level >= 2)
+  HIP_TRY(hipGetLastError());
+  std::vector<double> back(B * (NG + 2));
+  HIP_TRY(hipMemcpyAsync(back.data(), h->g_res.p, back.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int* hst = reinterpret_cast<const int*>(back.data() + B + B * NG);
+  int nfb = 0;
+  std::vector<int> levels(B);
+  HIP_TRY(hipMemcpy(levels.data(), P.need_exact, B * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; ++b) {
+    nfb += levels[b] >= 2;
+    const bool ok = hst[b] == CLR_OK;
+    if (value) value[b] = ok ? back[b] : -INFINITY;
+    if (status) status[b] = hst[b];
+    if (grad)
+      for (size_t g = 0; g < NG; ++g) grad[b * NG + g] = ok ? back[B + b * NG + g] : 0.0;
+    if (ok && grad && !(h->host_jitter[b] > 2.220446049250313e-16)) grad[b * NG] = 0.0;  // solver.cpp:379-389 (sequential form too)
+  }
+  h->grad_fallbacks = nfb;
+  h->grad_reverse_used = false;
+  return CLR_OK;
+}
+
 int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  if (!h->launch || h->J_general > 0)
-    return fail(CLR_UNSUPPORTED, "the plan gradient covers widths 1..8 without general terms: use clr_batch_grad_log_likelihood");
+  if (!h->launch || h->J_general > 0) return wide_batch_grad(h, value, grad, status);
   const size_t B = (size_t)h->B, NG = 1 + 2 * (size_t)h->J_real + 4 * (size_t)h->J_comp, J = (size_t)h->J;
   const size_t SZ = J * (J + 1) / 2, OUT = SZ + J + 2, RID = J * J + J + SZ;
   h->grad_scan_only = true;

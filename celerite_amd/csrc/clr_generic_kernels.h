@@ -91,8 +91,37 @@ struct GradParams {
   const double* jitter_b;
   long t_stride, diag_stride, y_stride;
   const int* only_level;  // batched, may be null: only the problems with only_level[b] >= 2 are computed
+  // CHUNKED mode (the gradient parallel in n at widths 9..32 and with general terms, wide_grad_kernels.hip):
+  // blockIdx.z = chunk c.  The wave runs samples [chunk c) only, from the TRUE base state at the chunk's first sample
+  // (starts: [B][nchunk][JP (JP + 1) / 2 + JP] from the wide scan, packed upper triangle at the padded width JP | f)
+  // and a ZERO tangent state, and writes the record of (problem b, chunk c, direction p) to
+  // rec + ((b nchunk + c) NG + p) (JP JP + JP + 2):  dS_end [JP][JP] | df_end [JP] | d log det | d quad.
+  // only_level (if given): only the problems with only_level[b] < 2 (the scan's start states are certified for them).
+  int nchunk, L, L0, JP;
+  const double* starts;
+  double* rec;
+  long A_stride, U_stride, V_stride;  // general terms per problem (0: shared)
 };
 void launch_grad(const GradParams& P, hipStream_t s);
+void launch_grad_chunked(const GradParams& P, hipStream_t s);  // (the batched form, P.nchunk >= 2)
+
+// The other two kernels of the chunk-parallel gradient at the padded widths JP = 16 / 32 (wide_grad_kernels.hip):
+struct WideGradWalk {
+  int B, NG, nchunk, JP, N;
+  const double* elems;    // [B][nchunk][ELEM(JP)]  the wide scan's chunk elements (A | b | C | eta | Jm)
+  const double* starts;   // [B][nchunk][START(JP)]
+  double* riders;         // [B][nchunk][JP JP (AA) + JP (eta) + JP JP (JJ)]
+  const double* rec;      // [B][nchunk][NG][JP JP + JP + 2]
+  const int* level;       // [B] route of the evaluation (may be null); problems with level >= 2 are skipped
+  const double* ll;       // [B] log-likelihood of the evaluation
+  const int* ll_status;   // [B]
+  const double* jitter;   // [B]
+  double* out_value;      // [B]  -(quad + log det + pi log N) / 2   (solver.cpp:415)
+  double* out_grad;       // [B][NG]
+  int* out_status;        // [B]
+};
+void launch_wide_grad_riders(const WideGradWalk& W, hipStream_t s);  // riders of every (problem, chunk) from element + start
+void launch_wide_grad_walk(const WideGradWalk& W, hipStream_t s);    // one wave per (problem, direction): walk the chunks
 
 // cholesky.h:41-210.  D must arrive initialised to the full diagonal
 // (diag + sum a_real + sum a_comp + jitter [+ A], cholesky.h:98-99).

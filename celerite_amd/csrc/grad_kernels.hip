@@ -31,13 +31,16 @@ namespace clr {
 
 namespace {
 
-template <int WMAX, bool FAST>
+template <int WMAX, bool FAST, bool CHUNKED = false>
 __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
   GradParams P = Pin;
   if (Pin.B > 0) {  // batched: shift every pointer to problem blockIdx.y (wave-uniform)
     const long b = blockIdx.y;
-    if (Pin.only_level && Pin.only_level[b] < 2) return;  // (settled by the chunk-parallel gradient)
+    if (!CHUNKED && Pin.only_level && Pin.only_level[b] < 2) return;  // (settled by the chunk-parallel gradient)
+    if (CHUNKED && Pin.only_level && Pin.only_level[b] >= 2) return;  // (left to the sequential form)
     const int NG = 1 + 2 * Pin.J_real + 4 * Pin.J_comp;
+    if (P.A) P.A += b * Pin.A_stride;   // (general terms per problem; strides 0: shared blocks)
+    if (P.U) { P.U += b * Pin.U_stride; P.V += b * Pin.V_stride; }
     P.a_real += b * Pin.J_real; P.c_real += b * Pin.J_real;
     P.a_comp += b * Pin.J_comp; P.b_comp += b * Pin.J_comp; P.c_comp += b * Pin.J_comp; P.d_comp += b * Pin.J_comp;
     P.jitter = Pin.jitter_b[b];
@@ -121,35 +124,53 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
     *dv = tt * (vs * cs - vc * sd);
   };
 
+  // the samples of this wave: the whole series, or (CHUNKED) chunk blockIdx.z of the wide scan's chunking
+  int n_lo = 0, n_hi = N;
+  if (CHUNKED) {
+    const int c = blockIdx.z;
+    auto begin = [&](int k) {
+      const long n = (P.L0 > 0 && k > 0) ? (long)P.L0 + (long)(k - 1) * P.L : (long)k * P.L;
+      return n < N ? (int)n : N;
+    };
+    n_lo = begin(c);
+    n_hi = begin(c + 1);
+  }
   double S[COLS], dS[COLS];
 #pragma unroll
   for (int c = 0; c < COLS; ++c) { S[c] = 0.0; dS[c] = 0.0; }
   double f = 0.0, df = 0.0, quad = 0.0, dquad = 0.0, dld = 0.0;
+  if (CHUNKED && blockIdx.z > 0) {  // the true base state at the chunk's first sample (packed upper triangle | f)
+    constexpr int SZP = WMAX * (WMAX + 1) / 2;
+    const double* st = P.starts + ((long)blockIdx.y * P.nchunk + blockIdx.z) * (SZP + WMAX);
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) S[c] = st[sym(row, seg * COLS + c)];
+    f = st[SZP + row];
+  }
   LogProduct lp;
   lp.init();
   int flag = 0;
 
   // 64-sample register tiles (t with two samples of look-ahead)
-  double tv = lane < N ? P.t[lane] : 0.0;
-  double tv2 = lane + 64 < N ? P.t[lane + 64] : 0.0;
-  double dv_ = lane < N ? P.diag[lane] : 0.0;
-  double yv = lane < N ? P.y[lane] : 0.0;
-  double av = (has_general && lane < N) ? P.A[lane] : 0.0;
+  double tv = n_lo + lane < N ? P.t[n_lo + lane] : 0.0;
+  double tv2 = n_lo + lane + 64 < N ? P.t[n_lo + lane + 64] : 0.0;
+  double dv_ = n_lo + lane < N ? P.diag[n_lo + lane] : 0.0;
+  double yv = n_lo + lane < N ? P.y[n_lo + lane] : 0.0;
+  double av = (has_general && n_lo + lane < N) ? P.A[n_lo + lane] : 0.0;
   auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };
 
   // general rows: u, v of sample n are fetched during step n - 2
   double ug1 = 0.0, vg1 = 0.0, ug2 = 0.0, vg2 = 0.0;
   if (ug) {
-    ug1 = N > 1 ? ug[1] : 0.0; vg1 = N > 1 ? vg[1] : 0.0;
-    ug2 = N > 2 ? ug[2] : 0.0; vg2 = N > 2 ? vg[2] : 0.0;
+    ug1 = n_lo + 1 < N ? ug[n_lo + 1] : 0.0; vg1 = n_lo + 1 < N ? vg[n_lo + 1] : 0.0;
+    ug2 = n_lo + 2 < N ? ug[n_lo + 2] : 0.0; vg2 = n_lo + 2 < N ? vg[n_lo + 2] : 0.0;
   }
   double u, du, v, dv, phi, dphi;
-  features(t_at(0), N > 1 ? t_at(1) - t_at(0) : 0.0, ug ? ug[0] : 0.0, ug ? vg[0] : 0.0, &u, &du, &v,
-           &dv, &phi, &dphi);
-  if (writer) { ubuf[0][row] = u; dubuf[0][row] = du; pbuf[0][row] = phi; dpbuf[0][row] = dphi; }
+  features(t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, (ug && n_lo < N) ? ug[n_lo] : 0.0, (ug && n_lo < N) ? vg[n_lo] : 0.0,
+           &u, &du, &v, &dv, &phi, &dphi);
+  if (writer) { ubuf[n_lo & 1][row] = u; dubuf[n_lo & 1][row] = du; pbuf[n_lo & 1][row] = phi; dpbuf[n_lo & 1][row] = dphi; }
 
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int nend = (N - n0 < 64) ? N - n0 : 64;
+  for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
+    const int nend = (n_hi - n0 < 64) ? n_hi - n0 : 64;
     for (int k = 0; k < nend; ++k) {
       const int n = n0 + k, cur = n & 1;
       const double diag_n = lane_value(dv_, k), y_n = lane_value(yv, k);
@@ -239,6 +260,15 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
     yv = m < N ? P.y[m] : 0.0;
     av = (has_general && m < N) ? P.A[m] : 0.0;
   }
+  if (CHUNKED) {  // the chunk's record for this direction: dS_end | df_end | d log det | d quad (zero tangent start)
+    const int NGc = 1 + 2 * JR + 4 * JC;
+    double* o = P.rec + (((long)blockIdx.y * P.nchunk + blockIdx.z) * NGc + blockIdx.x) * ((long)WMAX * WMAX + WMAX + 2);
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) o[row * WMAX + seg * COLS + c] = dS[c];
+    if (writer) o[WMAX * WMAX + row] = df;
+    if (lane == 0) { o[WMAX * WMAX + WMAX] = dld; o[WMAX * WMAX + WMAX + 1] = dquad; }
+    return;
+  }
   if (lane == 0) {
     P.out_grad[blockIdx.x] = -0.5 * (dquad + dld);
     if (blockIdx.x == 0) {
@@ -250,6 +280,17 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
 }
 
 }  // namespace
+
+void launch_grad_chunked(const GradParams& P, hipStream_t s) {
+  const dim3 grid(1 + 2 * P.J_real + 4 * P.J_comp, P.B, P.nchunk);
+  if (P.JP == 16) {
+    if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<16, true, true>), grid, dim3(64), 0, s, P);
+    else hipLaunchKernelGGL((wide_grad_kernel<16, false, true>), grid, dim3(64), 0, s, P);
+  } else {
+    if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<32, true, true>), grid, dim3(64), 0, s, P);
+    else hipLaunchKernelGGL((wide_grad_kernel<32, false, true>), grid, dim3(64), 0, s, P);
+  }
+}
 
 void launch_grad(const GradParams& P, hipStream_t s) {
   const int W = P.J_real + 2 * P.J_comp + P.J_general;

@@ -406,6 +406,59 @@ def test_one_shot_helper_and_coefficient_table():
 WIDE_SHAPES = [(9, 0), (1, 4), (0, 8), (2, 7), (16, 0), (0, 16), (4, 14), (10, 11), (1, 16), (0, 20), (64, 0), (2, 31)]
 
 
+@pytest.mark.parametrize("JR,JC,JG", [(4, 4, 0), (0, 8, 0), (0, 16, 0), (6, 13, 0), (2, 3, 4), (0, 8, 3)])
+def test_wide_plan_gradient_parallel_in_n(JR, JC, JG):
+    """clr_batch_grad on plans of widths 9..32 and with general terms (wide_grad_kernels.hip): riders of every chunk from
+    the wide scan's elements, one tangent wave per (direction, chunk) from the scanned start states, the walk over the
+    chunks per direction -- against the sequential tangent kernel problem by problem at several chunk counts, an indefinite
+    problem keeping the quiet semantics (-inf, zero gradient), the zero-jitter rule."""
+    import celerite_amd
+    B, N = 4, 6000
+    case = synthetic(B, N, JR, JC, "bench", seed=17 + JR + 5 * JC + JG)
+    jit = np.array([0.0, 0.02, 0.1, 0.05])
+    (case["a_real"] if JR else case["a_comp"])[2] *= -40.0
+    rng = np.random.RandomState(JG + 1)
+    if JG:
+        t = case["t"]
+        z = (t - t.mean(axis=1, keepdims=True)) / (t.max(axis=1, keepdims=True) - t.min(axis=1, keepdims=True))
+        U = np.stack([np.vander(zz, JG).T for zz in z])
+        V = U * rng.rand(B, JG)[:, :, None]
+        A = np.sum(U * V, axis=1) + 1e-8
+    empty, empty2 = np.empty(0), np.empty((0, 0))
+    want = []
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        for b in range(B):
+            gen = (A[b], U[b], V[b]) if JG else (empty, empty2, empty2)
+            try:
+                want.append(celerite_amd.CholeskySolver().grad_log_likelihood(
+                    jit[b], *[c[b] for c in coeffs_of(case)], *gen, case["t"][b], case["y"][b], case["diag"][b]))
+            except celerite_amd.solver.LinAlgError:
+                want.append(None)
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    assert want[2] is None and all(w is not None for i, w in enumerate(want) if i != 2)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        for nchunk in (4, 11):
+            plan.set_chunks(nchunk)
+            if JG:
+                plan.set_general(A, U, V)
+            plan.set_coefficients(*coeffs_of(case), jitter=jit)
+            v, g, st = plan.grad_log_likelihood()
+            assert st[2] == 2 and np.isneginf(v[2]) and not g[2].any()
+            for b in (0, 1, 3):
+                v0, g0 = want[b]
+                assert st[b] == 0
+                within("wide plan gradient: value vs sequential kernel", abs(v[b] - v0) / abs(v0), 1e-12, (nchunk, b))
+                within("wide plan gradient: partials vs sequential kernel (of the largest)",
+                       np.max(np.abs(g[b] - g0)) / np.max(np.abs(g0)), 1e-10, (nchunk, b))
+            assert g[0, 0] == 0.0 and g[1, 0] != 0.0
+    finally:
+        plan.close()
+
+
 def test_batched_gradient_reaches_the_kernel_parameters():
     """The optimiser loop without autograd (celerite.py:221-305 for B draws at once): coefficient tables and
     their Jacobians from a `terms` kernel (batch.kernel_coefficient_table / kernel_coefficient_jacobian_table), the

@@ -323,6 +323,54 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
+@pytest.mark.parametrize("JR,JC,JG,N", [(4, 4, 0, 4200), (0, 8, 0, 20000), (2, 5, 0, 9000), (0, 16, 0, 8000), (6, 13, 0, 5000),
+                                        (2, 3, 4, 6000), (0, 8, 3, 5000), (1, 0, 2, 4096)])
+def test_grad_log_likelihood_at_widths_9_to_32_and_with_general_terms_is_parallel_in_n(JR, JC, JG, N):
+    """From N = 4096 on, widths 9..32 -- and any celerite width with general terms up to a total width of 32 -- run
+    the wide scan + chunk-wise forward-mode tangents on a one-problem plan (csrc/wide_grad_kernels.hip; the reference's AD
+    handles any width and J_general, solver.cpp:347-463, general rows :393-399): same numbers as the sequential tangent
+    kernel, the dual-number oracle on the shortest cases, the zero-jitter rule, LinAlgError for an indefinite matrix."""
+    from oracle import grad as ograd
+    import os
+    from _cases import within
+
+    rng = np.random.RandomState(7 + JR + 3 * JC + JG)
+    x = np.sort(rng.uniform(0, 0.05 * N, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    y = rng.randn(N)
+    if JG:
+        z = (x - x.mean()) / (x.max() - x.min())
+        U = np.vander(z, JG).T.copy()
+        V = U * rng.rand(JG)[:, None]
+        gen = (np.sum(U * V, axis=0) + 1e-8, U, V)
+    else:
+        gen = NO_GENERAL
+    s = celerite_amd.CholeskySolver()
+    for trial in range(2):   # second call: new coefficients, the plan and its series are reused
+        co = (np.exp(rng.uniform(-1, 1, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0, JC)),
+              0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
+        args = (0.1 * trial,) + co + gen + (x, y, diag)
+        value, g = s.grad_log_likelihood(*args)
+        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        try:
+            v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(*args)
+        finally:
+            del os.environ["CLR_GRAD_SEQUENTIAL"]
+        within("wide / general gradient, object API: value vs sequential kernel", abs(value - v1) / abs(v1), 1e-12, (JR, JC, JG))
+        within("wide / general gradient, object API: partials vs sequential kernel (of the largest)",
+               np.max(np.abs(g - g1)) / np.max(np.abs(g1)), 1e-10, (JR, JC, JG))
+        assert (g[0] == 0.0) == (trial == 0)
+        if N <= 4200:
+            v0, g0 = ograd.grad_log_likelihood(*args)
+            within("wide / general gradient, object API: value vs oracle", abs(value - v0) / abs(v0), 1e-11)
+            within("wide / general gradient, object API: partials vs oracle (of the largest)",
+                   np.max(np.abs(g - g0)) / np.max(np.abs(g0)), 1e-10)
+    bad = list(co)
+    bad[0 if JR else 2] = -50.0 * bad[0 if JR else 2]
+    with pytest.raises(celerite_amd.solver.LinAlgError):
+        s.grad_log_likelihood(0.0, *bad, *gen, x, y, diag)
+
+
 @pytest.mark.parametrize("JR,JC,N", [(2, 3, 3000), (1, 1, 20000), (0, 4, 6000), (3, 0, 2048)])
 def test_grad_log_likelihood_of_a_long_series_is_parallel_in_n(JR, JC, N):
     """From N = 1024 on (widths 1..8, no general terms) CholeskySolver.grad_log_likelihood runs the scan + the
