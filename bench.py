@@ -473,7 +473,23 @@ def gradient_block(B, N, JR, JC, seed):
         vo, go = sol.grad_log_likelihood(*args)
     d_obj = (time.perf_counter() - t0) / 5
     (vq, gq), d_seq = sequential(lambda: celerite_amd.CholeskySolver().grad_log_likelihood(*args))
+    # widths 16 and 32 through the object API (one series of N samples): the wide scan + chunk-wise forward-mode
+    # tangents (csrc/wide_grad_kernels.hip) against the sequential tangent kernel
+    wide = {}
+    for name, jc in (("width16", 8), ("width32", 16)):
+        wc, wt, wd, wy = make_inputs(1, N, 0, jc, seed + 5, d_spread=(jc == 16))
+        wargs = (0.01,) + tuple(c[0] for c in wc) + (e, e2, e2, wt[0], wy[0], wd[0])
+        ws = celerite_amd.CholeskySolver()
+        ws.grad_log_likelihood(*wargs)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vw, gw = ws.grad_log_likelihood(*wargs)
+        d_w = (time.perf_counter() - t0) / 3
+        (vws, gws), d_ws = sequential(lambda: celerite_amd.CholeskySolver().grad_log_likelihood(*wargs))
+        wide[name] = {"N": N, "partials": 1 + 4 * jc, "ms_per_call": d_w * 1e3, "sequential_ms_per_call": d_ws * 1e3,
+                      "value_rel": abs(vw - vws) / abs(vws), "grad_rel_max": float(np.max(np.abs(gw - gws)) / np.max(np.abs(gws)))}
     return {
+        "object_api_wide": wide,
         "workload": "grad_log_likelihood (solver.cpp:347-463): batch=%d x N=%d, width %d, %d partials per problem" % (B, N, JR + 2 * JC, NG),
         "path": "clr_batch_grad, reverse mode: evaluation by the scan, riders + per-sample record per chunk, adjoint walk "
                 "over the chunks, one reverse sweep per chunk for all partials",
@@ -873,6 +889,8 @@ def promote(out):
     g = out.get("gradient")
     if g and "ms_per_call" in g:
         r["gradient_ms_per_call"] = g["ms_per_call"]
+        if "object_api_wide" in g:
+            r["gradient_object_api_ms"] = {k: v["ms_per_call"] for k, v in g["object_api_wide"].items()}
     a = out.get("accuracy_family")
     if a and "ms_per_step" in a:
         r["accuracy_family_ms_per_step"] = a["ms_per_step"]

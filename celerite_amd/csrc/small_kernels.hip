@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
       P.out_status[b] = CLR_PENDING_STATUS;
     } else {
       P.need_scan[b] = 0;
+      P.need_exact[b] = 0;  // (route 0 for clr_batch_get_exact_flags: settled without the reference recurrence)
       P.out_status[b] = CLR_OK;
       P.out_logdet[b] = lds[0];
       P.out_quad[b] = lds[T];

@@ -802,6 +802,44 @@ def test_short_narrow_problems_in_one_launch(JR, JC):
     within("one-launch batch, shared series: vs oracle", max(np.max(np.abs(ld - d0) / np.abs(d0)), np.max(np.abs(q - q0) / np.abs(q0))), REL)
 
 
+def test_one_launch_path_on_the_adversarial_family():
+    """Near-singular and indefinite problems through small_batch_kernel: whatever it cannot certify (flagged pivot, failed
+    certificate, conditioning record above the bounds) is left pending and settled by the scan pipeline, so the status
+    words equal the oracle's and the numbers obey the same bars as the pipeline's own routes."""
+    shapes = [(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (4, 0), (3, 0)]
+    n_bad = n_ok = 0
+    for trial in range(24):
+        JR, JC = shapes[trial % len(shapes)]
+        N = (600, 1500, 4000)[trial % 3]
+        case = adversarial(4, N, JR, JC, seed=2000 + trial)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(4, N, JR, JC)
+        try:
+            plan.set_small_mode(1)
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            assert plan.small_mode_active()
+            ll, ld, q, st = plan.log_likelihood()
+            levels = plan.exact_levels()
+            gamma, mu = plan.conditioning()
+        finally:
+            plan.close()
+        assert np.array_equal(st, s0), (trial, st, s0)
+        n_bad += int((s0 != 0).sum())
+        for p in range(4):
+            if s0[p] != 0 or not (np.isfinite(d0[p]) and np.isfinite(q0[p])):
+                continue
+            n_ok += 1
+            dev = max(abs(ld[p] - d0[p]) / abs(d0[p]), abs(q[p] - q0[p]) / abs(q0[p]))
+            if levels[p] == 0:
+                within("one-launch path, adversarial family, settled without the reference recurrence", dev, REL, (trial, p))
+            else:
+                bound = min(1e-3, max(1e-10, 1e-17 * gamma[p] ** 2))
+                within("one-launch path, adversarial family, route %d: deviation / gamma-scaled bound" % levels[p],
+                       dev / bound, 1.0, (trial, p, dev, gamma[p]))
+    assert n_bad >= 4 and n_ok >= 40, (n_bad, n_ok)
+
+
 def test_set_series_checks_the_order_on_the_device_and_follows_the_chunking():
     """clr_batch_set_series: large batches go through the pinned multi-threaded staging (>= 32 MB), the scans of t
     (max |t|, largest / smallest step, warm-path spans) run on the device.  An unsorted series anywhere in the batch is
