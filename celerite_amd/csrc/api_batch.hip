@@ -1,0 +1,1221 @@
+// celerite_amd/csrc/api_batch.hip -- C ABI of the batched plans (clr_batch_*): HBM residency, path selection
+// (scan pipeline, warm-started recurrence, one-launch path, wide kernels, general terms), evaluation and results.
+#include "api_internal.h"
+
+extern "C" {
+
+/* ---- batched log-likelihood ---------------------------------------------------- */
+clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
+  if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) {
+    fail(CLR_INVALID_ARGUMENT, "clr_batch_create: bad sizes");
+    return nullptr;
+  }
+  const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
+  const int width = J_real + 2 * J_comp;
+  if (!L && (width < 1 || width > clr::wide_max_width())) {
+    fail(CLR_UNSUPPORTED, "batched path supports widths 1..64 (J_real + 2 J_comp)");
+    return nullptr;
+  }
+  if (require_device(device) != CLR_OK) return nullptr;
+  clr_batch* h = new clr_batch();
+  h->device = device;
+  h->B = B;
+  h->N = N;
+  h->J_real = J_real;
+  h->J_comp = J_comp;
+  h->J = J_real + 2 * J_comp;
+  h->launch = L;  // null: widths 9..64, one wave per problem (wide_kernels.hip)
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(CLR_HIP_ERROR, "hipStreamCreate failed");
+    delete h;
+    return nullptr;
+  }
+  if (clr_batch_set_chunks(h, 0) != CLR_OK) {
+    clr_batch_destroy(h);
+    return nullptr;
+  }
+  return h;
+}
+
+void clr_batch_destroy(clr_batch* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
+                    &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
+                    &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
+                    &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
+                    &h->g_res, &h->g_rec, &h->g_ck})
+    b->release();
+  if (h->flags) (void)hipFree(h->flags);
+  if (h->wints) (void)hipFree(h->wints);
+  if (h->g_ckflag) (void)hipFree(h->g_ckflag);
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  if (h->pin) (void)hipHostFree(h->pin);
+  clr::staging_destroy(h->staging);
+  h->scan.release();
+  for (DevBuf* b : {&h->gen_elems, &h->gen_starts, &h->gen_part, &h->gen_cond}) b->release();
+  if (h->gen_flags) (void)hipFree(h->gen_flags);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int warm_plan_chunks(clr_batch* h);
+static int warm_resolve(clr_batch* h, bool* pin_current);
+static int warm_scan_spans(clr_batch* h);
+static void warm_select(clr_batch* h);
+
+int clr_batch_set_chunks(clr_batch* h, int nchunk) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  h->warm_explicit_chunks = nchunk > 0 ? nchunk : 0;
+  if (nchunk > 0) h->pipeline_pinned = true;
+  if (!h->launch) {
+    // wide path: one wave per (problem, chunk).  One chunk (the plain sequential sweep)
+    // unless the batch alone leaves the chip underused: then ~2 waves per SIMD worth of
+    // chunks, at ~1.25x the work per sample (profiles/r01s); widths above 32 stay sequential
+    if (h->J > clr::wide_scan_max_width()) nchunk = 1;
+    else if (nchunk <= 0) {
+      // One round of two waves per SIMD: B x nchunk = 2048 waves.  (Round 2 used 4096 / B -- two rounds of half the
+      //  length -- because the checked replay of borderline problems, 7 ms for config 4, got shorter with the chunks;
+      //  with the round-3 routing that family is settled from the chunk summaries and the sequential prefix + the
+      //  correct phase decide: B = 256: 8 chunks 17.1 ms, 16 chunks 18.5, 10 chunks 22.8 (2560 waves = a second,
+      //  nearly empty round), B = 512: 4 chunks 32.2 ms, 8 chunks 32.7; profiles/r03_wide_chunks.txt)
+      nchunk = h->B <= 1024 ? 2048 / h->B : 1;  // (above 1024 problems one sweep per problem already fills a round)
+      if (nchunk < 2) nchunk = 1;
+      if (nchunk > 16) nchunk = 16;
+      while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    }
+    if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
+  } else if (nchunk <= 0) {
+    nchunk = auto_chunks(h->B, h->N, h->J);
+  }
+  if (nchunk > h->N) nchunk = h->N;
+  h->L = (h->N + nchunk - 1) / nchunk;
+  if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
+  h->nchunk = (h->N + h->L - 1) / h->L;
+  h->L0 = 0;
+  if (const char* e = getenv("CLR_WIDE_FIRST_RATIO")) h->wide_first_ratio = atof(e);  // (tuning runs only)
+  if (!h->launch && h->nchunk > 1 && h->wide_first_ratio > 1.0) {
+    // wide scan: the first chunk's summarize carries no riders (wide_scan_body, RIDERS == false) and costs
+    // ~1 / wide_first_ratio of a later chunk's per sample: it gets that many more samples, so that all waves of the
+    // one round finish together.  Chunks 1.. have exactly L samples, the first one the rest.
+    const int nc = h->nchunk;
+    int L = (int)ceil(h->N / (nc - 1 + h->wide_first_ratio));
+    L = (L + 7) & ~7;
+    const long first = (long)h->N - (long)(nc - 1) * L;
+    if (L >= 64 && first >= L) { h->L = L; h->L0 = (int)first; }
+  }
+  h->relayout_pending = true;
+  h->grad_span_valid = false;
+  h->have_factor = false;  // its layout depends on the chunking
+  const size_t pc = (size_t)h->B * h->nchunk;
+  h->plan = clr::plan_prefix(h->nchunk, 0, 0);
+  if (h->launch) {
+    if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
+    if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
+    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, h->B, h->J);
+    size_t le = 0, ls = 0;
+    clr::multilevel_workspace(h->plan, h->J, &le, &ls);
+    if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
+    if (ls && (st = h->lvl_starts.reserve((size_t)h->B * ls)) != CLR_OK) return st;
+  } else if (h->nchunk > 1) {  // elements / start states at the padded width (16 or 32)
+    const size_t JP = h->J <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    if ((st = h->elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
+    if ((st = h->starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
+  }
+  if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->cond.reserve(pc * 4)) != CLR_OK) return st;  // gamma, mu, residual per chunk | measured G error
+  if ((st = h->out.reserve((size_t)h->B * 3 + ((size_t)h->B + 1) / 2)) != CLR_OK) return st;
+  if (h->flags) (void)hipFree(h->flags);
+  h->flags = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->flags), (2 * pc + (size_t)h->B) * sizeof(int)));
+  // a single-chunk plan launches no prefix / correct kernel: nothing else would ever clear need_exact or fill
+  // the conditioning record
+  HIP_TRY(hipMemsetAsync(h->flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 4 * sizeof(double), h->stream));
+  h->evaluated = false;
+  if ((st = warm_plan_chunks(h)) != CLR_OK) return st;
+  return CLR_OK;
+}
+
+// The warm path's chunking: two waves per SIMD worth of (problem, chunk) lanes (the plain recurrence needs 189
+// registers), chunks of at least 256 samples (the warm-up is at most half a chunk); an explicit chunk count is
+// honoured (results then do not depend on the batch size, i.e. on a sharding).
+static int warm_plan_chunks(clr_batch* h) {
+  h->wnchunk = 0;
+  h->wL = 0;
+  h->warm_active = false;
+  h->warm_span.clear();  // (the spans belong to a chunking: rescanned by the next set_series)
+  if (!h->launch || h->N < 512) return CLR_OK;
+  long want = h->warm_explicit_chunks ? h->warm_explicit_chunks : std::max<long>(1, 131072 / h->B);
+  long L = (h->N + want - 1) / want;
+  if (L < 256) L = 256;
+  L = (L + 7) & ~7L;
+  const long nc = (h->N + L - 1) / L;
+  if (nc < 2) return CLR_OK;
+  h->wL = (int)L;
+  h->wnchunk = (int)nc;
+  h->wKpad = std::min(128, h->wL / 2);  // rows of warm-up every chunk's column carries (the largest candidate)
+  h->wrows = h->wKpad + h->wL + 8;
+  h->warm_copy_pending = true;
+  const size_t pc = (size_t)h->B * nc, START = (size_t)h->launch->start_doubles;
+  int st;
+  if ((st = h->wstarts.reserve(pc * START)) != CLR_OK) return st;
+  if ((st = h->wends.reserve(pc * START)) != CLR_OK) return st;
+  if ((st = h->wpart.reserve(pc * 2)) != CLR_OK) return st;
+  if ((st = h->wresid.reserve((size_t)h->B)) != CLR_OK) return st;
+  const size_t ints = pc + 2 * (size_t)h->B;
+  if (ints > h->wints_cap) {
+    if (h->wints) (void)hipFree(h->wints);
+    h->wints = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->wints), ints * sizeof(int)));
+    h->wints_cap = ints;
+  }
+  HIP_TRY(hipMemsetAsync(h->wints, 0, ints * sizeof(int), h->stream));
+  if (h->have_series) {  // the spans and the warm-ups follow the new chunking (the series are resident)
+    if ((st = warm_scan_spans(h)) != CLR_OK) return st;
+    warm_select(h);
+  }
+  return CLR_OK;
+}
+
+// For every problem (or the one shared series) and every candidate K: the shortest time the K samples in front of
+// a chunk boundary of the warm path span.  O(B x chunks) lookups into the series resident in HBM (warm_spans_kernel),
+// so the spans follow the chunking too (clr_batch_set_chunks after clr_batch_set_series).
+static int warm_scan_spans(clr_batch* h) {
+  h->warm_span.clear();
+  if (h->wnchunk < 2 || !h->have_series) return CLR_OK;
+  const int nb = h->t_stride == 0 ? 1 : h->B;
+  const size_t n = (size_t)nb * clr_batch::WARM_NK;
+  int st;
+  if ((st = h->scan.reserve(std::max(n, (size_t)nb * 4))) != CLR_OK) return st;
+  clr::WarmCands cands;
+  cands.nk = clr_batch::WARM_NK;
+  for (int k = 0; k < clr_batch::WARM_NK; ++k) cands.K[k] = h->warm_cand[k];
+  clr::launch_warm_spans(h->t.p, h->t_stride, nb, h->wL, h->wnchunk, cands, h->scan.p, h->stream);
+  h->warm_span.assign(n, 0.0);
+  HIP_TRY(hipMemcpyAsync(h->warm_span.data(), h->scan.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len) {
+  if (nchunk) *nchunk = h->nchunk;
+  if (chunk_len) *chunk_len = h->L;
+  return CLR_OK;
+}
+
+// Warm-started recurrence: warm-up steps per problem from its slowest decay rate (host_cmin, kept from the last
+// set_coefficients) and the time the samples in front of its chunk boundaries span (warm_span, from the last
+// set_series): exp(-c_min x span) <= exp(-32) = 1.3e-14 -- what is left of ANY start state after the warm-up by the
+// decay alone, three orders below the tolerance of the boundary check (the update by the data only forgets faster); the
+// check of warm_check_kernel certifies the choice.  Called whenever either side changes, so that the K in force always
+// belongs to the (series, coefficients) pair in force.
+static void warm_select(clr_batch* h) {
+  const size_t B = (size_t)h->B;
+  h->warm_active = false;
+  h->warm_K_dirty = false;
+  if (h->warm_mode == 0 || h->wnchunk < 2 || !h->have_series || h->warm_span.empty() || h->host_cmin.size() != B) return;
+  h->warm_K.assign(B, 0);
+  size_t eligible = 0;
+  const bool shared = h->t_stride == 0;
+  for (size_t b = 0; b < B; ++b) {
+    int K = 0;
+    if (h->warm_mode == 1) {
+      K = std::min(h->warm_forced_K, h->wL / 2);
+    } else {
+      const double cmin = h->host_cmin[b];
+      const double* span = &h->warm_span[(shared ? 0 : b) * clr_batch::WARM_NK];
+      for (int k = 0; k < clr_batch::WARM_NK && cmin > 0.0; ++k)
+        if (cmin * span[k] >= 32.0) {
+          K = h->warm_cand[std::min(k + h->warm_boost, clr_batch::WARM_NK - 1)];
+          if (K > h->wL / 2) K = 0;
+          break;
+        }
+    }
+    h->warm_K[b] = K;
+    eligible += K > 0;
+  }
+  // (a batch with only a few eligible problems is not worth a second set of launches)
+  h->warm_active = eligible * 2 >= B;
+  h->warm_K_dirty = h->warm_active;  // (uploaded behind the next coefficients, or by the next enqueue)
+}
+
+int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const double* diag,
+                         long diag_stride, const double* y, long y_stride) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const long N = h->N;
+  for (long sd : {t_stride, diag_stride, y_stride})
+    if (sd != 0 && sd != N)
+      return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (an evaluation in flight is settled on ITS series)
+  auto count = [&](long sd) { return (size_t)(sd == 0 ? N : N * (long)h->B); };
+  const auto host_t0 = std::chrono::steady_clock::now();
+  if ((st = h->t.reserve(count(t_stride))) != CLR_OK) return st;
+  if ((st = h->diag.reserve(count(diag_stride))) != CLR_OK) return st;
+  if ((st = h->y.reserve(count(y_stride))) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (kernels of an earlier evaluation may still be reading the old series)
+  const clr::CopyJob jobs[3] = {{h->t.p, t, count(t_stride)}, {h->diag.p, diag, count(diag_stride)}, {h->y.p, y, count(y_stride)}};
+  const size_t total = (jobs[0].n + jobs[1].n + jobs[2].n) * sizeof(double);
+  if (total >= ((size_t)32 << 20)) {
+    // large series: NT host threads stage pieces through pinned buffers, their DMAs share the link (clr_series_io.h)
+    int e = clr::staging_create(h->staging, h->device);
+    if (e == 0) e = clr::upload_parallel(h->staging, jobs, 3);
+    if (e != 0) return fail(CLR_HIP_ERROR, hipGetErrorString((hipError_t)e));
+  } else {
+    for (const clr::CopyJob& j : jobs)
+      if (j.n) HIP_TRY(hipMemcpyAsync(j.dst, j.src, j.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  h->t_stride = t_stride;
+  h->diag_stride = diag_stride;
+  h->y_stride = y_stride;
+  h->have_series = true;
+  // one pass over t ON THE DEVICE: max |t| over every sample (sortedness is not assumed), the largest and the smallest
+  // step, NaN times; then the warm path's spans
+  {
+    const int nb = t_stride == 0 ? 1 : h->B;
+    if ((st = h->scan.reserve((size_t)nb * std::max(4, (int)clr_batch::WARM_NK))) != CLR_OK) return st;
+    clr::launch_series_stats(h->t.p, t_stride, nb, (int)N, h->scan.p, h->stream);
+    std::vector<double> stats((size_t)nb * 4);
+    HIP_TRY(hipMemcpyAsync(stats.data(), h->scan.p, stats.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double tm = 0.0, dm = 0.0, dmin = INFINITY;
+    bool nan = false;
+    for (int b = 0; b < nb; ++b) {
+      tm = std::max(tm, stats[4 * b]); dm = std::max(dm, stats[4 * b + 1]); dmin = std::min(dmin, stats[4 * b + 2]);
+      nan = nan || stats[4 * b + 3] != 0.0;
+    }
+    // (a NaN time: NaN bounds select the conservative kernels, sel_max)
+    h->tmax = nan ? NAN : tm;
+    h->dxmax = nan ? NAN : dm;
+    h->dtmin = nan ? NAN : (N > 1 ? dmin : 0.0);
+  }
+  if ((st = warm_scan_spans(h)) != CLR_OK) return st;
+  h->set_series_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+  h->grad_span_valid = false;
+  h->relayout_pending = true;
+  h->warm_copy_pending = true;
+  // a new series: the warm-ups chosen for the previous one's spans do not apply, nor does its history of fallbacks
+  if (h->warm_mode < 0) h->warm_boost = 0;
+  warm_select(h);
+  return CLR_OK;
+}
+
+int clr_batch_get_series_order(const clr_batch* h, double* dtmin) {
+  if (!h->have_series) return fail(CLR_INVALID_ARGUMENT, "no series set");
+  if (dtmin) *dtmin = h->dtmin;
+  return CLR_OK;
+}
+
+int clr_batch_clear_series(clr_batch* h) {
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->have_series = false;
+  h->warm_active = false;
+  h->warm_span.clear();
+  return CLR_OK;
+}
+
+int clr_batch_get_selection_bounds(const clr_batch* h, double* tmax, double* dxmax, double* dmax, double* cmax,
+                                   double* set_series_host_ms) {
+  if (tmax) *tmax = h->tmax;
+  if (dxmax) *dxmax = h->dxmax;
+  if (dmax) *dmax = h->dmax;
+  if (cmax) *cmax = h->cmax;
+  if (set_series_host_ms) *set_series_host_ms = h->set_series_host_ms;
+  return CLR_OK;
+}
+
+int clr_batch_set_selection_bounds(clr_batch* h, double tmax, double dxmax, double dmax, double cmax) {
+  // negative: leave that floor as it is (NaN counts as "unbounded": the conservative kernels)
+  if (!(tmax < 0.0)) h->floor_tmax = tmax;
+  if (!(dxmax < 0.0)) h->floor_dxmax = dxmax;
+  if (!(dmax < 0.0)) h->floor_dmax = dmax;
+  if (!(cmax < 0.0)) h->floor_cmax = cmax;
+  return CLR_OK;
+}
+
+static int reserve_pinned(clr_batch* h, size_t doubles) {
+  if (doubles <= h->pin_cap && h->pin) return CLR_OK;
+  if (h->pin) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+  }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin), doubles * sizeof(double), hipHostMallocDefault));
+  h->pin_cap = doubles;
+  return CLR_OK;
+}
+
+int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double* a_real,
+                               const double* c_real, const double* a_comp, const double* b_comp,
+                               const double* c_comp, const double* d_comp) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems of the evaluation in flight: at ITS coefficients)
+  const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
+  h->dmax = 0.0;
+  h->cmax = 0.0;
+  for (size_t i = 0; i < nc; ++i) {
+    const double m = fabs(d_comp[i]), c = fabs(c_comp[i]);
+    if (!(m <= h->dmax)) h->dmax = m;
+    if (!(c <= h->cmax)) h->cmax = c;
+  }
+  for (size_t i = 0; i < nr; ++i) {
+    const double c = fabs(c_real[i]);
+    if (!(c <= h->cmax)) h->cmax = c;
+  }
+  h->host_cmax.assign(B, 0.0);
+  for (size_t b = 0; b < B; ++b) {
+    double m = 0.0;
+    for (int j = 0; j < h->J_real; ++j) m = std::max(m, fabs(c_real[b * h->J_real + j]));
+    for (int j = 0; j < h->J_comp; ++j) m = std::max(m, fabs(c_comp[b * h->J_comp + j]));
+    h->host_cmax[b] = m;
+  }
+  h->host_cmin.assign(B, INFINITY);
+  for (size_t b = 0; b < B; ++b) {
+    double cmin = INFINITY;
+    for (int j = 0; j < h->J_real; ++j) { const double c = c_real[b * h->J_real + j]; if (!(c >= cmin)) cmin = c; }
+    for (int j = 0; j < h->J_comp; ++j) { const double c = c_comp[b * h->J_comp + j]; if (!(c >= cmin)) cmin = c; }
+    h->host_cmin[b] = cmin;
+  }
+  warm_select(h);
+  // one pinned staging buffer, one copy: a_real c_real a_comp b_comp c_comp d_comp | jitter
+  const size_t total = 2 * nr + 4 * nc + B;
+  if ((st = reserve_pinned(h, std::max(total, 3 * B + (B + 1) / 2) + (B + 1) / 2)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (a previous upload may still read the staging buffer)
+  double* w = h->pin;
+  auto put = [&](const double* p, size_t n) { if (n) memcpy(w, p, n * sizeof(double)); w += n; };
+  put(a_real, nr); put(c_real, nr); put(a_comp, nc); put(b_comp, nc); put(c_comp, nc); put(d_comp, nc);
+  if (jitter) { put(jitter, B); h->host_jitter.assign(jitter, jitter + B); }
+  else { memset(w, 0, B * sizeof(double)); w += B; h->host_jitter.assign(B, 0.0); }  // NULL: no jitter
+  if ((st = h->coeffs.reserve(total)) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->coeffs.p, h->pin, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->warm_active) {  // K per problem, behind the coefficients in the staging buffer
+    int* kk = reinterpret_cast<int*>(h->pin + std::max(total, 3 * B + (B + 1) / 2));
+    memcpy(kk, h->warm_K.data(), B * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(h->wints + (size_t)h->B * h->wnchunk + B, kk, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->warm_K_dirty = false;
+  }
+  h->have_coeffs = true;
+  return CLR_OK;
+}
+
+int clr_batch_set_exact(clr_batch* h, int force) {
+  h->force_exact = force ? 1 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_get_exact_count(clr_batch* h, int* count) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
+  if (h->nchunk < 2 || h->force_exact) {  // every problem went through the reference recurrence
+    *count = h->B;
+    return CLR_OK;
+  }
+  std::vector<int> need((size_t)h->B);
+  const size_t pc = (size_t)h->B * h->nchunk;
+  HIP_TRY(hipMemcpyAsync(need.data(), h->flags + 2 * pc, need.size() * sizeof(int),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int n = 0;
+  for (int v : need) n += v != 0;
+  *count = n;
+  return CLR_OK;
+}
+
+int clr_batch_get_exact_flags(clr_batch* h, int* flags) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!flags) return fail(CLR_INVALID_ARGUMENT, "flags is null");
+  if (h->nchunk < 2) {
+    for (int b = 0; b < h->B; ++b) flags[b] = 2;  // one chunk: the replay from the zero state is the recurrence
+    return CLR_OK;
+  }
+  const size_t pc = (size_t)h->B * h->nchunk;
+  HIP_TRY(hipMemcpyAsync(flags, h->flags + 2 * pc, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->force_exact)
+    for (int b = 0; b < h->B; ++b) flags[b] = flags[b] < 1 ? 1 : flags[b];
+  return CLR_OK;
+}
+
+int clr_batch_get_conditioning_chunkwise(clr_batch* h, double* ratio_max) {
+  // max over chunks of gamma_c / mu_c (both of the SAME chunk), per problem
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!ratio_max) return fail(CLR_INVALID_ARGUMENT, "ratio_max is null");
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  if (h->nchunk < 2) {  // one chunk: the recurrence itself ran, there is no record
+    for (int b = 0; b < h->B; ++b) ratio_max[b] = 0.0;
+    return CLR_OK;
+  }
+  const size_t pc = (size_t)h->B * h->nchunk;
+  std::vector<double> c(pc * 3);
+  HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; ++b) {
+    double r = 0.0;
+    for (int k = 0; k < h->nchunk; ++k) {
+      const double* e = &c[((size_t)b * h->nchunk + k) * 3];
+      const double q = e[0] / e[1];
+      if (!(q <= r)) r = q;
+    }
+    ratio_max[b] = r;
+  }
+  return CLR_OK;
+}
+
+int clr_batch_get_conditioning(clr_batch* h, double* gamma_max, double* mu_min, double* resid_max) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  if (h->nchunk < 2) {  // one chunk: the recurrence itself ran, there is no record
+    for (int b = 0; b < h->B; ++b) {
+      if (gamma_max) gamma_max[b] = 0.0;
+      if (mu_min) mu_min[b] = 1.0;
+      if (resid_max) resid_max[b] = 0.0;
+    }
+    return CLR_OK;
+  }
+  const size_t pc = (size_t)h->B * h->nchunk;
+  std::vector<double> c(pc * 3);
+  HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  // problems the warm-started recurrence settled have no scan record: gamma 0, mu 1, and the largest boundary
+  // mismatch of the warm path as the residual
+  std::vector<int> scanned;
+  std::vector<double> wres;
+  if (h->warm_active && h->wints && h->warm_settled > 0) {
+    scanned.resize((size_t)h->B);
+    wres.resize((size_t)h->B);
+    HIP_TRY(hipMemcpyAsync(scanned.data(), h->wints + (size_t)h->B * h->wnchunk, scanned.size() * sizeof(int),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(wres.data(), h->wresid.p, wres.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int b = 0; b < h->B; ++b) {
+    double g = 0.0, m = 1.0, r = 0.0;
+    if (!scanned.empty() && scanned[b] == 0) {
+      r = wres[b];
+    } else {
+      for (int k = 0; k < h->nchunk; ++k) {
+        const double* e = &c[((size_t)b * h->nchunk + k) * 3];
+        if (!(e[0] <= g)) g = e[0];
+        if (!(e[1] >= m)) m = e[1];
+        if (!(e[2] <= r)) r = e[2];
+      }
+    }
+    if (gamma_max) gamma_max[b] = g;
+    if (mu_min) mu_min[b] = m;
+    if (resid_max) resid_max[b] = r;
+  }
+  return CLR_OK;
+}
+
+int clr_batch_get_measured_error(clr_batch* h, double* eg_max) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!eg_max) return fail(CLR_INVALID_ARGUMENT, "eg_max is null");
+  if (!h->evaluated) return fail(CLR_NOT_COMPUTED, "no evaluation has been enqueued on this plan");
+  const size_t pc = (size_t)h->B * h->nchunk;
+  std::vector<double> c(pc);
+  if (h->nchunk >= 2) {
+    HIP_TRY(hipMemcpyAsync(c.data(), h->cond.p + pc * 3, pc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int b = 0; b < h->B; ++b) {
+    double e = 0.0;
+    for (int k = 0; k < h->nchunk && h->nchunk >= 2; ++k) {
+      const double v = c[(size_t)b * h->nchunk + k];
+      if (!(v <= e)) e = v;
+    }
+    eg_max[b] = e;
+  }
+  return CLR_OK;
+}
+
+int clr_batch_set_certificate(clr_batch* h, double max_gamma_over_mu, double max_residual) {
+  h->cert_gamma = max_gamma_over_mu;
+  h->cert_resid = max_residual;
+  h->pipeline_pinned = true;
+  return CLR_OK;
+}
+
+int clr_batch_set_certificate_gamma(clr_batch* h, double max_gamma, double max_gamma_times_error) {
+  h->cert_gamma_abs = max_gamma;
+  h->cert_eg = max_gamma_times_error;
+  return CLR_OK;
+}
+
+int clr_batch_set_prefix_mode(clr_batch* h, int mode) {
+  if (mode < 0 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "prefix mode must be 0, 1 or 2");
+  h->coop_prefix = mode;
+  h->pipeline_pinned = true;
+  return CLR_OK;
+}
+
+int clr_batch_set_prefix_plan(clr_batch* h, int levels, int group) {
+  if (levels > 3 || (levels > 0 && group < 2)) return fail(CLR_INVALID_ARGUMENT, "prefix plan: levels <= 3, group >= 2");
+  h->plan_levels = levels;
+  h->plan_g = group;
+  const int keep = h->warm_explicit_chunks;  // (re-planning the workspace is not a request for a chunk count)
+  int st = clr_batch_set_chunks(h, h->nchunk);
+  h->warm_explicit_chunks = keep;
+  if (st == CLR_OK) st = warm_plan_chunks(h);
+  return st;
+}
+
+int clr_batch_get_prefix_plan(const clr_batch* h, int* levels, int* groups /* [3] */, int* counts /* [4] */) {
+  if (levels) *levels = (h->launch && h->coop_prefix == 2) ? h->plan.levels : 0;
+  for (int l = 0; l < 3; ++l) if (groups) groups[l] = h->plan.g[l];
+  for (int l = 0; l < 4; ++l) if (counts) counts[l] = h->plan.n[l];
+  return CLR_OK;
+}
+
+int clr_batch_debug_get_starts(clr_batch* h, double* starts) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch || !starts) return fail(CLR_INVALID_ARGUMENT, "start states are kept for widths 1..8");
+  const size_t n = (size_t)h->B * h->nchunk * h->launch->start_doubles;
+  HIP_TRY(hipMemcpyAsync(starts, h->starts.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_debug_compose_check(clr_batch* h, int group, double* max_abs_diff, double* max_abs_value) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch || group < 2 || !h->evaluated)
+    return fail(CLR_INVALID_ARGUMENT, "compose check: widths 1..8, group >= 2, after an evaluation");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t np = (size_t)(h->nchunk + group - 1) / group, E = (size_t)h->launch->elem_doubles;
+  const size_t n = (size_t)h->B * np * E;
+  DevBuf a, b;
+  if ((st = a.reserve(n)) != CLR_OK || (st = b.reserve(n)) != CLR_OK) return st;
+  h->launch->compose_check(P, group, a.p, b.p, h->stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> ha(n), hb(n);
+  HIP_TRY(hipMemcpyAsync(ha.data(), a.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hb.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  a.release();
+  b.release();
+  // per element (one composed group) and per block of it (A | b | C | eta | Jm): the largest difference against the
+  // block's largest magnitude; the last group of a problem may hold the padded last chunk (never applied): skipped
+  const int J = h->J, SZ = J * (J + 1) / 2;
+  const size_t off[6] = {0, (size_t)J * J, (size_t)J * J + J, (size_t)J * J + J + SZ, (size_t)J * J + 2 * J + SZ, E};
+  double worst = 0.0, big = 0.0;
+  for (size_t e = 0; e < (size_t)h->B * np; ++e) {
+    if (e % np == np - 1) continue;
+    for (int blk = 0; blk < 5; ++blk) {
+      double d = 0.0, m = 0.0;
+      for (size_t i = off[blk]; i < off[blk + 1]; ++i) {
+        const double x = ha[e * E + i], y = hb[e * E + i];
+        if (!(fabs(x - y) <= d)) d = fabs(x - y);
+        if (!(fabs(y) <= m)) m = fabs(y);
+      }
+      const double r = m > 0.0 ? d / m : d;
+      if (!(r <= worst)) worst = r;
+      if (!(m <= big)) big = m;
+    }
+  }
+  if (max_abs_diff) *max_abs_diff = worst;
+  if (max_abs_value) *max_abs_value = big;
+  return CLR_OK;
+}
+
+int clr_batch_set_summarize_mode(clr_batch* h, int mode) {
+  if (mode < -1 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "summarize mode must be -1, 0, 1 or 2");
+  if (mode != h->summarize_mode) h->relayout_pending = true;
+  h->summarize_mode = mode;
+  if (mode >= 0) h->pipeline_pinned = true;
+  return CLR_OK;
+}
+
+int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
+  if (!kind) return fail(CLR_INVALID_ARGUMENT, "kind is null");
+  *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
+  if (!h->launch)  // wide plans: plain or lazy flavour of the one-wave-per-chunk summarize
+    *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h)) ? 2 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
+                          const double* V, long V_stride) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (J_general < 0) return fail(CLR_INVALID_ARGUMENT, "J_general must be >= 0");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (J_general == 0) {  // back to the celerite-terms-only plan
+    h->J_general = 0;
+    return CLR_OK;
+  }
+  if (!A || !U || !V) return fail(CLR_INVALID_ARGUMENT, "general terms need A, U and V");
+  if (h->J + J_general > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  const long N = h->N, UV = (long)J_general * N;
+  if ((A_stride != 0 && A_stride != N) || (U_stride != 0 && U_stride != UV) || (V_stride != 0 && V_stride != UV))
+    return fail(CLR_INVALID_ARGUMENT, "general-term strides must be 0 (shared) or the size of one problem's block");
+  auto count = [&](long sd, long one) { return (size_t)(sd == 0 ? one : one * (long)h->B); };
+  if ((st = upload(h->gA, A, count(A_stride, N), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gU, U, count(U_stride, UV), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gV, V, count(V_stride, UV), h->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->J_general = J_general;
+  h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  // Total widths up to 64 run on the wave-per-(problem, chunk) kernels (wide_kernels.hip, GEN flavour): the general rows
+  // are one more row class there.  Chunks as for any wide plan: one round of two waves per SIMD, the scan up to width 32.
+  h->gen_nchunk = 0;
+  const int Wt = h->J + J_general;
+  if (Wt <= clr::wide_max_width()) {
+    int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
+    if (nchunk > 16) nchunk = 16;
+    while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)
+      nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
+    if (nchunk < 1) nchunk = 1;
+    int L = (h->N + nchunk - 1) / nchunk;
+    if (nchunk > 1) L = (L + 7) & ~7;
+    nchunk = (h->N + L - 1) / L;
+    int L0 = 0;
+    if (nchunk > 1 && h->wide_first_ratio > 1.0) {  // (the riderless, longer first chunk: clr_batch_set_chunks)
+      int L2 = (int)ceil(h->N / (nchunk - 1 + h->wide_first_ratio));
+      L2 = (L2 + 7) & ~7;
+      const long first = (long)h->N - (long)(nchunk - 1) * L2;
+      if (L2 >= 64 && first >= L2) { L = L2; L0 = (int)first; }
+    }
+    const size_t pc = (size_t)h->B * nchunk, JP = Wt <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    if (nchunk > 1) {
+      if ((st = h->gen_elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
+      if ((st = h->gen_starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
+    }
+    if ((st = h->gen_part.reserve(pc * 4)) != CLR_OK) return st;
+    if ((st = h->gen_cond.reserve(pc * 4)) != CLR_OK) return st;
+    if (h->gen_flags) (void)hipFree(h->gen_flags);
+    h->gen_flags = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->gen_flags), (2 * pc + (size_t)h->B) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->gen_flags, 0, (2 * pc + (size_t)h->B) * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->gen_cond.p, 0, pc * 4 * sizeof(double), h->stream));
+    h->gen_nchunk = nchunk; h->gen_L = L; h->gen_L0 = L0;
+  }
+  return CLR_OK;
+}
+
+static bool warm_runs(const clr_batch* h, int materialize);
+static bool small_runs(const clr_batch* h, int materialize);
+
+int clr_batch_set_general_route(clr_batch* h, int route) {
+  if (route != -1 && route != 1) return fail(CLR_INVALID_ARGUMENT, "general route: -1 (automatic) or 1 (sequential kernel)");
+  h->general_route = route;
+  return CLR_OK;
+}
+
+int clr_batch_set_small_mode(clr_batch* h, int mode) {
+  if (mode < -1 || mode > 1) return fail(CLR_INVALID_ARGUMENT, "small mode: -1 (auto), 0 (off) or 1 (whenever supported)");
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->small_mode = mode;
+  return CLR_OK;
+}
+
+int clr_batch_get_small_mode(const clr_batch* h, int* active) {
+  if (active) *active = (!warm_runs(h, 0) && small_runs(h, 0)) ? 1 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_warm_start(clr_batch* h, int mode, int forced_warmup) {
+  if (mode < -1 || mode > 1 || (mode == 1 && forced_warmup < 1))
+    return fail(CLR_INVALID_ARGUMENT, "warm start: mode -1 (auto), 0 (off) or 1 (forced, with a warm-up length >= 1)");
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->warm_mode = mode;
+  h->warm_forced_K = forced_warmup;
+  h->warm_boost = 0;
+  h->warm_active = false;  // (decided by the next clr_batch_set_coefficients)
+  h->have_coeffs = false;
+  return CLR_OK;
+}
+
+int clr_batch_get_warm_start(const clr_batch* h, int* active, int* nchunk, int* chunk_len, int* warmup_min,
+                             int* warmup_max, int* settled, int* fallbacks) {
+  if (active) *active = h->warm_active ? 1 : 0;
+  if (nchunk) *nchunk = h->wnchunk;
+  if (chunk_len) *chunk_len = h->wL;
+  int lo = 0, hi = 0;
+  if (h->warm_active)
+    for (int k : h->warm_K) {
+      if (k <= 0) continue;
+      lo = (lo == 0 || k < lo) ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+  if (warmup_min) *warmup_min = lo;
+  if (warmup_max) *warmup_max = hi;
+  if (settled) *settled = h->warm_settled;
+  if (fallbacks) *fallbacks = h->warm_fallbacks;
+  return CLR_OK;
+}
+
+int clr_batch_set_replay_source(clr_batch* h, int source) {
+  if (source < -1 || source > 1) return fail(CLR_INVALID_ARGUMENT, "replay source must be -1, 0 or 1");
+  h->replay_source = source;
+  h->pipeline_pinned = true;
+  return CLR_OK;
+}
+
+int clr_batch_set_library_trig(clr_batch* h, int force) {
+  h->force_library_trig = force ? 1 : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_layout(clr_batch* h, int layout) {
+  if (layout < 0 || layout > 2) return fail(CLR_INVALID_ARGUMENT, "layout must be 0, 1 or 2");
+  h->layout = layout;
+  h->relayout_pending = true;
+  h->pipeline_pinned = true;
+  return CLR_OK;
+}
+
+// wide path.  One chunk: the sequential sweep (one wave per problem).  Several chunks: summarize ->
+// prefix -> correct (+ conditioning decision) -> finalize from the chunk summaries.  Forced-exact runs
+// and the problems whose conditioning record is above the bound replay every chunk from its scanned
+// start state and check the end states against the scan.  Problems the certificate flagged, or whose
+// replay did not meet the scan, are then walked by the sequential sweep itself (one wave per such
+// problem over all N samples), which overwrites their results: nothing of theirs depends on the scan.
+int clr_batch_set_profiling(clr_batch* h, int on) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  h->prof_on = (on == 2 && h->launch) ? 2 : (on ? 1 : 0);  // 2: only the summarize (dominant) kernel is bracketed (widths 1..8)
+  h->prof_steps = 0;
+  return CLR_OK;
+}
+
+int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double k[PROF_NK] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < h->prof_steps; ++i)
+    for (int j = 0; j < PROF_NK; ++j) {
+      if (h->prof_on == 2 && j != 1) continue;  // (only events 1 and 2 were recorded)
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, h->prof_events[(size_t)i * (PROF_NK + 1) + j],
+                                  h->prof_events[(size_t)i * (PROF_NK + 1) + j + 1]));
+      k[j] += ms;
+    }
+  if (kernel_ms)
+    for (int j = 0; j < PROF_NK; ++j) kernel_ms[j] = k[j];
+  if (steps) *steps = h->prof_steps;
+  return CLR_OK;
+}
+
+// a batch of short, narrow problems: the whole fused evaluation in ONE launch, one workgroup per problem
+// (small_batch_kernel, small_kernels.hip); problems it cannot certify stay pending for the scan pipeline
+static bool small_runs(const clr_batch* h, int materialize) {
+  if (h->grad_scan_only || h->small_mode == 0) return false;
+  if (!h->launch || materialize || h->force_exact || !h->wints || h->J_general > 0) return false;
+  if (!clr::small_batch_supported(h->J_real, h->J_comp, h->N)) return false;
+  // (automatic: while a workgroup per problem still fits one round of the chip -- above that the scan pipeline's
+  //  throughput wins, profiles/r04i_small_batch.txt)
+  if (h->small_mode == 1) return true;
+  // automatic: not when the caller tuned the scan pipeline explicitly, and only while a workgroup per problem fits
+  // one round of the chip (widths 3, 4: one workgroup per CU by registers and LDS; narrower: four) -- above that the
+  // pipeline's throughput wins (profiles/r04i_small_batch.txt: 1024 x 1e4 x width 4 0.29 ms against 0.34)
+  return !h->pipeline_pinned && h->B <= (h->J >= 3 ? 256 : 1024);
+}
+
+static bool warm_runs(const clr_batch* h, int materialize) {
+  if (h->grad_scan_only) return false;
+  return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
+}
+
+// the warm kernel's copy of the series, (re)built when the series or the warm chunking changed
+static int warm_copy(clr_batch* h) {
+  if (!h->warm_copy_pending) return CLR_OK;
+  const size_t cells = (size_t)h->wrows * h->wnchunk;
+  auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
+  int st;
+  if ((st = h->wT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->wD.reserve(nsrc(h->diag_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->wY.reserve(nsrc(h->y_stride) * cells)) != CLR_OK) return st;
+  struct { DevBuf* src; DevBuf* dst; long stride; int pad; } jobs[3] = {
+      {&h->t, &h->wT, h->t_stride, 1}, {&h->diag, &h->wD, h->diag_stride, 2}, {&h->y, &h->wY, h->y_stride, 0}};
+  for (auto& j : jobs)
+    clr::launch_relayout_warm(j.src->p, j.stride, j.dst->p, j.stride ? (long)cells : 0, j.stride ? h->B : 1, h->N,
+                              h->wL, h->wnchunk, h->wKpad, h->wrows, j.pad, h->stream);
+  h->warm_copy_pending = false;
+  return CLR_OK;
+}
+
+// K per problem on the device, when set_series re-selected it after the coefficients were uploaded
+static int warm_upload_K(clr_batch* h) {
+  if (!h->warm_K_dirty || !h->wints) return CLR_OK;
+  HIP_TRY(hipMemcpyAsync(h->wints + (size_t)h->B * h->wnchunk + h->B, h->warm_K.data(), (size_t)h->B * sizeof(int),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // (pageable source)
+  h->warm_K_dirty = false;
+  return CLR_OK;
+}
+
+// the scan pipeline for the problems the warm path left pending (single-wave summarize on the row-major arrays)
+static int warm_fallback(clr_batch* h) {
+  clr::BatchParams P;
+  h->in_fallback = true;
+  int st = batch_params(h, 0, P);
+  h->in_fallback = false;
+  if (st != CLR_OK) return st;
+  h->launch->summarize(P, h->stream);
+  h->launch->prefix(P, h->stream);
+  h->launch->correct(P, h->stream);
+  h->launch->replay(P, 0, h->stream);
+  h->launch->sequential(P, 0, h->stream);
+  clr::launch_finalize(P, h->stream);
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
+int clr_batch_enqueue(clr_batch* h, int materialize) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  clr::BatchParams P;
+  if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  // profiling: one event per kernel boundary of this evaluation, on the plan's stream
+  hipEvent_t* ev = nullptr;
+  if (h->prof_on && h->prof_steps < PROF_MAX_STEPS) {
+    const size_t need = (size_t)(h->prof_steps + 1) * (PROF_NK + 1);
+    while (h->prof_events.size() < need) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      h->prof_events.push_back(e);
+    }
+    ev = &h->prof_events[(size_t)h->prof_steps * (PROF_NK + 1)];
+    ++h->prof_steps;
+  }
+  const bool all_marks = h->prof_on != 2;
+  auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
+  h->evaluated = true;
+  if (h->J_general > 0) {  // general terms: the any-width sequential recurrence, one workgroup per problem
+    if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms: use CholeskySolver");
+    h->warm_inflight = false;
+    if (h->gen_nchunk > 0 && h->general_route != 1) {
+      // the wide kernels with the general rows as a third row class (chunked scan up to total width 32)
+      clr::BatchParams W;
+      general_wide_params(h, P, W);
+      mark(0);
+      wide_flow(W, h->J_real, h->J_comp, h->stream, ev);
+      HIP_TRY(hipGetLastError());
+      return CLR_OK;
+    }
+    clr::GenericBatch G;
+    memset(&G, 0, sizeof(G));
+    G.B = h->B; G.N = h->N; G.J_real = h->J_real; G.J_comp = h->J_comp; G.J_general = h->J_general;
+    G.a_real = P.a_real; G.c_real = P.c_real; G.a_comp = P.a_comp; G.b_comp = P.b_comp; G.c_comp = P.c_comp;
+    G.d_comp = P.d_comp; G.jitter = P.jitter;
+    G.t = h->t.p; G.diag = h->diag.p; G.y = h->y.p;
+    G.t_stride = h->t_stride; G.diag_stride = h->diag_stride; G.y_stride = h->y_stride;
+    G.A = h->gA.p; G.U = h->gU.p; G.V = h->gV.p;
+    G.A_stride = h->gA_stride; G.U_stride = h->gU_stride; G.V_stride = h->gV_stride;
+    G.out_ll = P.out_ll; G.out_logdet = P.out_logdet; G.out_quad = P.out_quad; G.out_status = P.out_status;
+    mark(0); mark(1);
+    clr::launch_generic_loglike_batch(G, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
+  if (!h->launch) {
+    mark(0);
+    wide_launch(h, P, ev);
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
+  mark(0);
+  h->warm_inflight = false;
+  if (!warm_runs(h, materialize) && small_runs(h, materialize)) {
+    clr::BatchParams Sp;
+    h->in_fallback = true;  // (the row-major arrays)
+    st = batch_params(h, 0, Sp);
+    h->in_fallback = false;
+    if (st != CLR_OK) return st;
+    mark(1);
+    clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    h->warm_inflight = true;  // (pending problems are settled like the warm path's: warm_resolve)
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
+  if (warm_runs(h, materialize)) {
+    // series that forget: the plain recurrence per chunk with a warm-up + the boundary check; problems it cannot
+    // settle are marked pending and go through the scan pipeline when the results are asked for
+    clr::BatchParams Wp;
+    if ((st = warm_copy(h)) != CLR_OK) return st;
+    if ((st = warm_upload_K(h)) != CLR_OK) return st;
+    h->in_fallback = true;  // (the row-major arrays, no role split)
+    st = batch_params(h, 0, Wp);
+    h->in_fallback = false;
+    if (st != CLR_OK) return st;
+    mark(1);
+    h->launch->warm(Wp, h->stream);
+    mark(2); mark(3); mark(4); mark(5); mark(6);
+    h->warm_inflight = true;
+    HIP_TRY(hipGetLastError());
+    return CLR_OK;
+  }
+  if (h->relayout_pending && batch_relayout(h)) h->relayout_pending = false;
+  mark(1);
+  h->launch->summarize(P, h->stream);
+  mark(2);
+  h->launch->prefix(P, h->stream);
+  mark(3);
+  h->launch->correct(P, h->stream);  // (also on forced-exact runs: flags + conditioning record)
+  mark(4);
+  h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);  // forced-exact / materialising runs only
+  h->launch->sequential(P, materialize ? 2 : 0, h->stream);  // flagged / ill-conditioned problems only
+  mark(5);
+  clr::launch_finalize(P, h->stream);
+  mark(6);
+  // (capturing these five launches in a hipGraph was measured: no gain -- the gaps between
+  //  dependent kernels are on the device side; profiles/r01r_small_batches.log)
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
+int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (h->launch || h->J > clr::wide_f32_probe_max_width())
+    return fail(CLR_UNSUPPORTED, "the fp32 probe covers widths 9..32");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t B = (size_t)h->B;
+  DevBuf tmp;
+  if ((st = tmp.reserve(2 * B)) != CLR_OK) return st;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  clr::launch_wide_f32_probe(P, h->J_real, h->J_comp, tmp.p, tmp.p + B, h->stream);  // warm-up
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  clr::launch_wide_f32_probe(P, h->J_real, h->J_comp, tmp.p, tmp.p + B, h->stream);
+  HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipGetLastError());
+  if (logdet) HIP_TRY(hipMemcpyAsync(logdet, tmp.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (quad) HIP_TRY(hipMemcpyAsync(quad, tmp.p + B, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  if (ms) *ms = t;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  tmp.release();
+  return CLR_OK;
+}
+
+// Problems the warm path could not settle (boundary mismatch, flagged pivot, not eligible) carry a pending status
+// until the scan pipeline has run for them.  That pipeline reads the plan's CURRENT coefficients, series and
+// chunking, so it must run before any of them changes: every state-changing entry point, clr_batch_synchronize and
+// clr_batch_get_results call this first.  *pin_current (may be null): the pinned staging buffer holds the final
+// results (ll | logdet | quad | status) of this evaluation.
+static int warm_resolve(clr_batch* h, bool* pin_current) {
+  if (pin_current) *pin_current = false;
+  if (!h->warm_inflight) return CLR_OK;
+  h->warm_inflight = false;
+  const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
+  int st;
+  if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
+  HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
+  int pending = 0;
+  for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
+  h->warm_fallbacks = pending;
+  h->warm_settled = (int)B - pending;
+  if (pending) {
+    if ((st = warm_fallback(h)) != CLR_OK) return st;
+    HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // many mismatches among the problems that did warm up: longer warm-ups from the next coefficients on
+    size_t eligible = 0;
+    for (int k : h->warm_K) eligible += k > 0;
+    const long failed = (long)pending - (long)(B - eligible);
+    if (h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
+  } else if (h->warm_mode < 0 && h->warm_boost > 0 && ++h->warm_clean >= 8) {
+    --h->warm_boost;  // eight clean evaluations in a row: try the shorter warm-ups again
+    h->warm_clean = 0;
+  }
+  if (pending) h->warm_clean = 0;
+  if (pin_current) *pin_current = true;
+  return CLR_OK;
+}
+
+int clr_batch_synchronize(clr_batch* h) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet, double* quad,
+                          int* status) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
+  if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
+  // pending problems of a warm evaluation first (they leave the final results in the staging buffer); otherwise one
+  // copy into the pinned staging buffer (ll | logdet | quad | status), then host memcpys
+  bool pin_current = false;
+  if ((st = warm_resolve(h, &pin_current)) != CLR_OK) return st;
+  if (!pin_current) {
+    HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (loglike) memcpy(loglike, h->pin, B * sizeof(double));
+  if (logdet) memcpy(logdet, h->pin + B, B * sizeof(double));
+  if (quad) memcpy(quad, h->pin + 2 * B, B * sizeof(double));
+  if (status) memcpy(status, h->pin + 3 * B, B * sizeof(int));
+  return CLR_OK;
+}
+
+int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->have_factor) return fail(CLR_NOT_COMPUTED, "no materialising run has been made");
+  if (p < 0 || p >= h->B) return fail(CLR_INVALID_ARGUMENT, "problem index out of range");
+  const size_t N = (size_t)h->N, J = (size_t)h->J, Nm1 = N - 1, cells = (size_t)h->L * h->nchunk;
+  if (!h->launch) {  // widths 9..64: already in the reference's storage, problem after problem
+    if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->phi.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->u.p + p * J * Nm1, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (W) HIP_TRY(hipMemcpyAsync(W, h->W.p + p * J * N, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (D) HIP_TRY(hipMemcpyAsync(D, h->D.p + p * N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CLR_OK;
+  }
+  if ((st = h->fphi.reserve(J * Nm1)) != CLR_OK) return st;
+  if ((st = h->fu.reserve(J * Nm1)) != CLR_OK) return st;
+  if ((st = h->fW.reserve(J * N)) != CLR_OK) return st;
+  if ((st = h->fD.reserve(N)) != CLR_OK) return st;
+  clr::launch_deinterleave_factor(h->phi.p + p * J * cells, h->u.p + p * J * cells,
+                                  h->W.p + p * J * cells, h->D.p + p * cells, h->fphi.p, h->fu.p,
+                                  h->fW.p, h->fD.p, h->N, h->J, h->L, h->nchunk, h->stream);
+  HIP_TRY(hipGetLastError());
+  if (phi && J * Nm1) HIP_TRY(hipMemcpyAsync(phi, h->fphi.p, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (u && J * Nm1) HIP_TRY(hipMemcpyAsync(u, h->fu.p, J * Nm1 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (W) HIP_TRY(hipMemcpyAsync(W, h->fW.p, J * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (D) HIP_TRY(hipMemcpyAsync(D, h->fD.p, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CLR_OK;
+}
+
+int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
+                        double* total_ms, double* kernel_ms) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  clr::BatchParams P;
+  if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
+  if (steps < 1) steps = 1;
+  h->evaluated = true;
+  if (!warm_runs(h, materialize) && h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
+  // one event per kernel boundary per step, all recorded on the handle's stream
+  const int NK = 6;
+  std::vector<hipEvent_t> ev((size_t)steps * (NK + 1));
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < steps; ++i) {
+    hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
+    HIP_TRY(hipEventRecord(e[0], h->stream));
+    if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
+      wide_launch(h, P, e);
+      continue;
+    }
+    if (!warm_runs(h, materialize) && small_runs(h, materialize)) {  // (one launch, in the "summarize" slot)
+      clr::BatchParams Sp;
+      h->in_fallback = true;
+      st = batch_params(h, 0, Sp);
+      h->in_fallback = false;
+      if (st != CLR_OK) return st;
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
+      for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      h->warm_inflight = true;
+      continue;
+    }
+    if (warm_runs(h, materialize)) {  // (the warm path: recurrence + boundary check in the "summarize" slot)
+      clr::BatchParams Wp;
+      if (relayout_each_step) h->warm_copy_pending = true;  // (new series every step: the copy is rebuilt inside it)
+      if ((st = warm_copy(h)) != CLR_OK) return st;
+      if ((st = warm_upload_K(h)) != CLR_OK) return st;
+      h->in_fallback = true;
+      st = batch_params(h, 0, Wp);
+      h->in_fallback = false;
+      if (st != CLR_OK) return st;
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      h->launch->warm(Wp, h->stream);
+      for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      h->warm_inflight = true;
+      continue;
+    }
+    if (relayout_each_step) batch_relayout(h);
+    HIP_TRY(hipEventRecord(e[1], h->stream));
+    h->launch->summarize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[2], h->stream));
+    h->launch->prefix(P, h->stream);
+    HIP_TRY(hipEventRecord(e[3], h->stream));
+    h->launch->correct(P, h->stream);
+    HIP_TRY(hipEventRecord(e[4], h->stream));
+    h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);
+    h->launch->sequential(P, materialize ? 2 : 0, h->stream);
+    HIP_TRY(hipEventRecord(e[5], h->stream));
+    clr::launch_finalize(P, h->stream);
+    HIP_TRY(hipEventRecord(e[6], h->stream));
+  }
+  if (relayout_each_step && !warm_runs(h, materialize) && (h->layout == 1 || split_active(h)) && h->nchunk > 1)
+    h->relayout_pending = false;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double k[NK] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < steps; ++i) {
+    hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
+    for (int j = 0; j < NK; ++j) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e[j], e[j + 1]));
+      k[j] += ms;
+    }
+  }
+  float tot = 0.f;
+  HIP_TRY(hipEventElapsedTime(&tot, ev.front(), ev.back()));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (total_ms) *total_ms = tot;
+  if (kernel_ms)
+    for (int j = 0; j < NK; ++j) kernel_ms[j] = k[j];
+  return CLR_OK;
+}
+
+int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,
+                             const double* a_real, const double* c_real, const double* a_comp,
+                             const double* b_comp, const double* c_comp, const double* d_comp,
+                             const double* t, long t_stride, const double* diag,
+                             long diag_stride, const double* y, long y_stride, double* loglike,
+                             double* logdet, double* quad, int* status, int device) {
+  clr_batch* h = clr_batch_create(B, N, J_real, J_comp, device);
+  if (!h) {
+    // clr_batch_create recorded why (message in clr_last_error)
+    if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) return CLR_INVALID_ARGUMENT;
+    const int width = J_real + 2 * J_comp;
+    if (width < 1 || width > clr::wide_max_width()) return CLR_UNSUPPORTED;
+    return visible_gfx950() > 0 ? CLR_HIP_ERROR : CLR_NO_DEVICE;
+  }
+  int st = clr_batch_set_series(h, t, t_stride, diag, diag_stride, y, y_stride);
+  if (st == CLR_OK)
+    st = clr_batch_set_coefficients(h, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+  if (st == CLR_OK) st = clr_batch_enqueue(h, 0);
+  if (st == CLR_OK) st = clr_batch_get_results(h, loglike, logdet, quad, status);
+  clr_batch_destroy(h);
+  return st;
+}
+
+}  // extern "C"

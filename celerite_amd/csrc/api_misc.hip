@@ -1,0 +1,164 @@
+// celerite_amd/csrc/api_misc.hip -- C ABI: library / device entries and the CARMA handle (clr_carma_*).
+#include "api_internal.h"
+
+thread_local std::string clr_api_last_error;
+thread_local int clr_api_device = 0;
+
+extern "C" {
+
+/* ---- library / device ------------------------------------------------------ */
+const char* clr_version(void) { return "0.3.0"; }
+const char* clr_last_error(void) { return g_last_error.c_str(); }
+
+const char* clr_status_string(int status) {
+  switch (status) {
+    case CLR_OK: return "ok";
+    case CLR_DIMENSION_MISMATCH: return "dimension mismatch";
+    case CLR_NOT_POSITIVE_DEFINITE: return "failed to factorize or solve matrix";
+    case CLR_NOT_COMPUTED: return "you must call 'compute' first";
+    case CLR_NO_DEVICE: return "no gfx950 device available (libcelerite_hip has no CPU path)";
+    case CLR_HIP_ERROR: return "HIP runtime error";
+    case CLR_INVALID_ARGUMENT: return "invalid argument";
+    case CLR_UNSUPPORTED: return "unsupported configuration";
+    case CLR_CARMA_INSTABILITY: return "CARMA model encountered an instability";
+    default: return "unknown status";
+  }
+}
+
+int clr_device_count(void) { return visible_gfx950(); }
+
+int clr_set_device(int device) {
+  int st = require_device(device);
+  if (st == CLR_OK) g_device = device;
+  return st;
+}
+
+int clr_get_device(int* device) {
+  *device = g_device;
+  return CLR_OK;
+}
+
+int clr_device_synchronize(void) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  HIP_TRY(hipDeviceSynchronize());
+  return CLR_OK;
+}
+
+int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm_bytes) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return CLR_OK;
+}
+
+int clr_device_memory(size_t* free_bytes, size_t* total_bytes) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return CLR_OK;
+}
+
+
+/* ======================================================================== */
+/* CARMASolver (carma.h): host model + one-wave Kalman filter (carma.hip)    */
+/* ======================================================================== */
+struct clr_carma {
+  clr::CarmaModel model;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf dmodel, dt, dy, dyerr, dout;  // dout: [ll | status as int bits]
+  bool model_resident = false;
+};
+
+clr_carma* clr_carma_create(double log_sigma, int p, const double* arparams, int q, const double* maparams,
+                            int* status) {
+  int st = CLR_OK;
+  clr_carma* h = nullptr;
+  if (p < 0 || q < 0 || (p > 0 && !arparams) || (q > 0 && !maparams)) {
+    st = fail(CLR_INVALID_ARGUMENT, "bad CARMA parameter arrays");
+  } else {
+    h = new clr_carma();
+    std::string err;
+    st = clr::carma_setup(log_sigma, p, arparams, q, maparams, h->model, err);
+    if (st != CLR_OK) {
+      fail(st, err);
+      delete h;
+      h = nullptr;
+    } else {
+      h->device = g_device;
+    }
+  }
+  if (status) *status = st;
+  return h;
+}
+
+void clr_carma_destroy(clr_carma* h) {
+  if (!h) return;
+  if (h->stream || h->dmodel.p) {
+    (void)hipSetDevice(h->device);
+    for (DevBuf* b : {&h->dmodel, &h->dt, &h->dy, &h->dyerr, &h->dout}) b->release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+}
+
+int clr_carma_get_celerite_coeffs(const clr_carma* h, int* n_real, int* n_comp, double* a_real, double* c_real,
+                                  double* a_comp, double* b_comp, double* c_comp, double* d_comp) {
+  std::vector<double> v[6];
+  clr::carma_celerite_coeffs(h->model, v);
+  if (n_real) *n_real = (int)v[0].size();
+  if (n_comp) *n_comp = (int)v[2].size();
+  double* dst[6] = {a_real, c_real, a_comp, b_comp, c_comp, d_comp};
+  for (int i = 0; i < 6; ++i)
+    if (dst[i]) std::copy(v[i].begin(), v[i].end(), dst[i]);
+  return CLR_OK;
+}
+
+int clr_carma_log_likelihood(clr_carma* h, int n_t, const double* t, int n_y, const double* y, int n_yerr,
+                             const double* yerr, double* out) {
+  if (n_y != n_t || n_yerr != n_t) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // carma.h:223
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->stream) HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const int p = h->model.p, n = n_t;
+  if (n == 0 || p == 0) {
+    // (an empty series: the filter loop does not run; p = 0 cannot happen, q < p)
+    *out = -0.5 * (double)n * 1.8378770664093453;
+    return CLR_OK;
+  }
+  if (!h->model_resident) {
+    std::vector<double> pk;
+    auto push = [&](const std::vector<std::complex<double>>& a) {
+      for (const std::complex<double>& c : a) { pk.push_back(c.real()); pk.push_back(c.imag()); }
+    };
+    push(h->model.b); push(h->model.V); push(h->model.loglam);
+    if ((st = upload(h->dmodel, pk.data(), pk.size(), h->stream)) != CLR_OK) return st;
+    HIP_TRY(hipStreamSynchronize(h->stream));  // (pk is a local)
+    h->model_resident = true;
+  }
+  if ((st = upload(h->dt, t, (size_t)n, h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->dy, y, (size_t)n, h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->dyerr, yerr, (size_t)n, h->stream)) != CLR_OK) return st;
+  if ((st = h->dout.reserve(2)) != CLR_OK) return st;
+  clr::launch_carma_filter(n, p, h->dmodel.p, h->dt.p, h->dy.p, h->dyerr.p, h->dout.p,
+                           reinterpret_cast<int*>(h->dout.p + 1), h->stream);
+  HIP_TRY(hipGetLastError());
+  double host[2] = {0.0, 0.0};
+  HIP_TRY(hipMemcpyAsync(host, h->dout.p, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int bad = 0;
+  memcpy(&bad, &host[1], sizeof(int));
+  if (bad) return fail(CLR_CARMA_INSTABILITY, "CARMA model encountered an instability");  // exceptions.h:8-12
+  *out = host[0];
+  return CLR_OK;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@
 // in L1/L2 (measured: replay 2x slower at 2 waves/SIMD), so the series are read
 // either through StagedSeries (default: cooperative coalesced tiles transposed in
 // LDS, no extra pass) or from a chunk-interleaved copy [problem][i][chunk] made by
-// relayout_kernel (api.hip; one coalesced 512-B wave load per array per step).
+// relayout_kernel (api_kernels.hip; one coalesced 512-B wave load per array per step).
 // The workspace (elements, start states, partial sums) is O(nchunk) per problem.
 #pragma once
 
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
 // (warm_check_kernel).  Chunk 0 starts from the true zero state, so agreement at every boundary certifies all
 // start states by induction; a problem with a mismatch above warm_resid, a flagged pivot or a non-finite partial
 // is left to the scan pipeline (need_scan).  K is chosen per problem on the host from the slowest decay rate and
-// the time the K samples before every chunk boundary span (api.hip); the check makes that choice safe, not just
+// the time the K samples before every chunk boundary span (api_batch.hip); the check makes that choice safe, not just
 // plausible.  No prefix, no corrections, no LDS.
 // ---------------------------------------------------------------------------
 // The warm kernel's view of the series: a lane walks down ITS column of the warm copy (one coalesced 512-B wave
@@ -963,16 +963,16 @@ bool have_summarize_split(int JR, int JC);
 // decide_kernel at the padded widths of the wide scan
 void launch_wide_decide(const BatchParams& P, hipStream_t s);
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s);
-// Per-problem reduction of the chunk partials + the -inf rules (api.hip).
+// Per-problem reduction of the chunk partials + the -inf rules (api_kernels.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
-// One problem's interleaved factor -> the reference's storage (api.hip).
+// One problem's interleaved factor -> the reference's storage (api_kernels.hip).
 void launch_deinterleave_factor(const double* phi_i, const double* u_i, const double* W_i,
                                 const double* D_i, double* phi, double* u, double* W, double* D,
                                 int N, int J, int L, int nchunk, hipStream_t s);
-// [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api.hip).
+// [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api_kernels.hip).
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, int pad_kind, hipStream_t s);
-// [problem][n] -> the warm kernel's [problem][row][chunk], row r of chunk c = sample c L - Kpad + r (api.hip)
+// [problem][n] -> the warm kernel's [problem][row][chunk], row r of chunk c = sample c L - Kpad + r (api_kernels.hip)
 void launch_relayout_warm(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L,
                           int nchunk, int Kpad, int rows, int pad_kind, hipStream_t s);
 

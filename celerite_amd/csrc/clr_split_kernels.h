@@ -32,7 +32,7 @@
 // the roles does not matter (they share one issue port); the total instruction count does.
 // LDS is then full (slots 4 x 2 x 10.8 KB + Jm 4 x 18.4 KB = 160 KB), so T reads the series from the
 // chunk-interleaved copy [problem][i][chunk] (one coalesced 512-B load per array and step,
-// relayout_kernel in api.hip, made once per set_series) instead of staging tiles.
+// relayout_kernel in api_kernels.hip, made once per set_series) instead of staging tiles.
 //
 // Synchronisation: R runs one step behind T, through TWO slots and one workgroup barrier per
 // step: T fills slot i & 1 during step i and then meets R at barrier B(i); R, after B(i), reads

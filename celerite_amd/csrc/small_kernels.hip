@@ -1,7 +1,7 @@
 // celerite_amd/csrc/small_kernels.hip -- CholeskySolver.compute of ONE short series (N <= 4096, widths 1..4) in ONE
 // launch (BASELINE configs[0]: N = 1000, a real + an SHO term, through the object API).
 //
-// The general object-API route (api.hip: summarize -> prefix -> correct -> replay -> sequential -> finalize) is seven
+// The general object-API route (api_solver.hip: summarize -> prefix -> correct -> replay -> sequential -> finalize) is seven
 // launches and five uploads for one problem: ~100 us of device time and as much host time at N = 1000, where a CPU core
 // needs 55 us.  Here the whole factorisation is one workgroup:
 //   1. lane = chunk of L = ceil(N / T) samples: summarize_chunk (clr_core.h) folds the chunk into its transfer

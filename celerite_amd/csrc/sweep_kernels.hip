@@ -246,7 +246,7 @@ void run_dotl(const SweepParams& P, hipStream_t s) {
 // data, :657,681).  Chunk starts of both recurrences come from a chunked scan; then ONE
 // THREAD PER PREDICTION POINT walks from its chunk start to its interval (<= L steps)
 // and evaluates both sums.  Needs the prediction points sorted (the reference's while
-// loops assume it); api.hip checks and otherwise uses the sequential kernel.
+// loops assume it); api_solver.hip checks and otherwise uses the sequential kernel.
 // ---------------------------------------------------------------------------
 constexpr int PJ = 8;  // rows (J_real + 2 J_comp) handled per thread
 

@@ -235,13 +235,14 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       gv[k] = (gen && n_lo + k < N) ? Vg[n_lo + k] : 0.0;
     }
   }
+  constexpr int GQ = GEN ? GEN_PF : 1;
   auto gen_next = [&]() {
     if (gen) { rc.u0 = gu[0]; rc.v0 = gv[0]; }
 #pragma unroll
-    for (int k = 0; k + 1 < GEN_PF; ++k) { gu[k] = gu[k + 1]; gv[k] = gv[k + 1]; }
-    const int m = gbase + GEN_PF;
-    gu[GEN_PF - 1] = (gen && m < N) ? Ug[m] : 0.0;
-    gv[GEN_PF - 1] = (gen && m < N) ? Vg[m] : 0.0;
+    for (int k = 0; k + 1 < GQ; ++k) { gu[k] = gu[k + 1]; gv[k] = gv[k + 1]; }
+    const int m = gbase + GQ;
+    gu[GQ - 1] = (gen && m < N) ? Ug[m] : 0.0;
+    gv[GQ - 1] = (gen && m < N) ? Vg[m] : 0.0;
     ++gbase;
   };
   if (GEN) gen_next();  // the chunk's first sample
