@@ -219,11 +219,22 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const int m = n_lo + lane;
     tv = m < N ? tp[m] : 0.0;
     dv = m < N ? dp[m] : 0.0;
-    if (GEN && m < N) dv += Ap[m];  // (the reference adds A last, cholesky.h:99: a difference in the last bit)
+    dv = ((dv + sum_ar) + sum_ac) + jitter;  // K(0) of the tile's samples: the reference's summation order, once per tile
+    if (GEN && m < N) dv += Ap[m];  // (the reference adds A last, cholesky.h:99)
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
   }
   auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };  // k < 66
+  // (LAZY) the steps of the tile, prepared once per 64 samples: lane k holds t(n0 + k + 2) - t(n0 + k + 1), the one
+  // scalar a step still has to fetch (the rotation's step is the previous step's decay step; t itself is only needed
+  // at the anchors) -- instead of two wave-uniform reads of t with their tile selects per step
+  auto tile_steps = [&](int n0) {
+    const int i1 = (lane + 1) & 63, i2 = (lane + 2) & 63;
+    const double a1 = __shfl(tv, i1, 64), b1 = __shfl(tv2, i1, 64), a2 = __shfl(tv, i2, 64), b2 = __shfl(tv2, i2, 64);
+    const double t1v = lane + 1 < 64 ? a1 : b1, t2v = lane + 2 < 64 ? a2 : b2;
+    return (n0 + lane + 2 < N) ? t2v - t1v : 0.0;
+  };
+  double dxt = LAZY ? tile_steps(n_lo) : 0.0, dxprev = 0.0;
   // (GEN) the general rows' features of samples base .. base + GEN_PF - 1; gen_next() hands out the front one as the
   // row's constants and fetches the sample GEN_PF further on
   double gu[GEN ? GEN_PF : 1], gv[GEN ? GEN_PF : 1];
@@ -254,7 +265,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     sincos_phase<FAST>(rc.d * tcur, &sdr, &csr);
     u = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
     v = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
-    decay_pair<LAZY>(-rc.c * (n_lo + 1 < N ? t_at(1) - tcur : 0.0), &phi, &phinv);
+    dxprev = n_lo + 1 < N ? t_at(1) - tcur : 0.0;
+    decay_pair<LAZY>(-rc.c * dxprev, &phi, &phinv);
     if (writer) ubuf[n_lo & 1][row] = u;  // ubar = psi u with psi = 1
   } else {
     row_features<FAST>(rc, t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, &u, &v, &phi);
@@ -272,21 +284,21 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       double u1 = 0.0, v1 = 0.0, phi1 = 1.0, phinv1 = 1.0;
       const bool renorm = LAZY && ((((n - n_lo) & 15) == 15) || n + 1 == n_hi);  // wave-uniform
       if (n + 1 < N) {
-        const double t1 = t_at(k + 1);
-        const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        const double t1 = LAZY ? 0.0 : t_at(k + 1);
+        const double dx1 = LAZY ? lane_value(dxt, k) : ((n + 2 < N) ? t_at(k + 2) - t1 : 0.0);
         if (GEN) gen_next();  // the general rows' u0, v0 of sample n + 1
         if (LAZY) {
           if (((n + 1 - n_lo) & 15) == 0) {
-            sincos_phase<FAST>(rc.d * t1, &sdr, &csr);  // anchor
+            sincos_phase<FAST>(rc.d * t_at(k + 1), &sdr, &csr);  // anchor
           } else {  // rotate the row's (cos, sin) pair through d (t1 - t)
-            const double dl = rc.d * (t1 - tcur), d2 = dl * dl;
+            const double dl = rc.d * dxprev, d2 = dl * dl;
             const double sn = dl * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
             const double cn = fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
             const double c0 = csr, s0 = sdr;
             csr = fma(c0, cn, -s0 * sn);
             sdr = fma(s0, cn, c0 * sn);
           }
-          tcur = t1;
+          dxprev = dx1;
           u1 = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
           v1 = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
           decay_pair<LAZY>(-rc.c * dx1, &phi1, &phinv1);
@@ -320,15 +332,16 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       double s, ub;
       if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
       else { s = row_sum<LPR>(ueff * q); ub = row_sum<LPR>(ueff * f); }
-      const double D = (((diag_n + sum_ar) + sum_ac) + jitter) - s;
+      const double D = diag_n - s;  // (diag_n: the tile already holds K(0) = ((diag + sum a_real) + sum a_comp) + jitter)
       const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
       const double x = y_n - ub;
       // replay: the reference's test (cholesky.h:176; sample 0 is never checked); summarize: a
       // zero-start pivot <= 0 sends the problem to the replay (as in summarize_chunk)
       if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
       if (LPWIN) dprod *= D; else lp.mul(D);
-      quad += x * x * invD;
-      if (MODE == 1) gam = fmax(gam, fabs(((((diag_n + sum_ar) + sum_ac) + jitter)) * invD));
+      const double xs = x * invD;
+      quad = fma(x, xs, quad);
+      if (MODE == 1) gam = fmax(gam, fabs(diag_n * invD));
 
       const double z = veff - q;
       const double w = z * invD;
@@ -387,7 +400,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           }
         }
       }
-      if (RID) eta = fma(-r, x * invD, eta);
+      if (RID) eta = fma(-r, xs, eta);
       if (LAZY) {
         f = fma(w, x, f);  // fbar
         psi *= phi;        // Psi now includes this step's decay
@@ -439,9 +452,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const int m = n0 + 64 + lane;
     tv = tv2;
     dv = m < N ? dp[m] : 0.0;
+    dv = ((dv + sum_ar) + sum_ac) + jitter;
     if (GEN && m < N) dv += Ap[m];
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
+    if (LAZY) dxt = tile_steps(n0 + 64);
   }
 
   if (MODE == 1) {  // the element, in the narrow kernels' layout at width J = WMAX
