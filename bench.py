@@ -287,9 +287,10 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         "prefix_plan": {"levels": prefix_plan[0], "groups": prefix_plan[1], "elements_per_level": prefix_plan[2]},
         "levels": {"what": "problems by route: 0 settled from the chunk summaries, 1 checked chunked replay, "
                            "2 sequential recurrence", "histogram": [int(v) for v in levels]},
+        # (the one-launch path of short narrow problems settles them without leaving a per-chunk record: zeros)
         "conditioning": {"gamma_max": float(np.max(gam)), "mu_min": float(np.min(mu)),
-                         "gamma_over_mu_max": float(np.max(gam / mu)), "measured_G_error_max": float(np.max(eg)),
-                         "gamma_times_error_max": float(np.max(gam * eg))},
+                         "gamma_over_mu_max": float(np.max(gam / np.where(mu > 0, mu, np.inf))),
+                         "measured_G_error_max": float(np.max(eg)), "gamma_times_error_max": float(np.max(gam * eg))},
         "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "log-likelihoods/s",
         "device_only": {"ms_per_step": dev_ms / steps, "value": B / (dev_ms / steps * 1e-3)},
         "kernels_ms": per,
