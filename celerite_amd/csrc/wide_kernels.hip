@@ -561,42 +561,46 @@ __device__ __forceinline__ double wave_sum64(double v) {
 }
 
 template <int J>
-__global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
+// (round 4: 256 threads per (problem, chunk) -- the tableau / matrix sweeps are strided over four waves, the wave-uniform
+//  scalars (pivot search, determinants, certificate pivots) are computed by every wave from the same LDS data, and the
+//  per-row sections and the final reduction belong to the first wave: 0.83 -> 0.3 ms for BASELINE config 4)
+__global__ void __launch_bounds__(256) wide_correct_kernel(const BatchParams P) {
   constexpr int SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
   constexpr int NC = 2 * J + 1, LD = J + 1, LT = NC + 1;  // padded leading dimensions
   __shared__ double Pm[J * LD], Jmm[J * LD], Sm[J * LD], PF[J * LD], T[J * LT], fv[J], ev[J], wv[J];
-  const int lane = threadIdx.x;
+  constexpr int NT = 256;
+  const int tid = threadIdx.x, lane = tid & 63;  // lane: position in the wave (wave-uniform searches); tid < J: row owner
   const long slot = blockIdx.x;
   const int b = (int)(slot / P.nchunk), c = (int)(slot % P.nchunk);
-  if (lane == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
+  if (tid == 0 && P.flags[slot]) atomicOr(P.need_exact + b, 2);  // a zero-start pivot <= 0 (summarize)
   if (c == 0) {  // the first chunk starts from the zero state: nothing to correct
-    if (lane == 0 && P.egerr) P.egerr[slot] = 0.0;
+    if (tid == 0 && P.egerr) P.egerr[slot] = 0.0;
     return;
   }
   const double* st = P.starts + slot * START;
   const double* E = P.elems + slot * ELEM;
   const double* eta = E + J * J + J + SZ;
   const double* Jm = eta + J;
-  for (int idx = lane; idx < J * J; idx += 64) {
+  for (int idx = tid; idx < J * J; idx += NT) {
     const int i = idx / J, j = idx % J;
     Pm[i * LD + j] = st[sym(i, j)];
     Jmm[i * LD + j] = Jm[sym(i, j)];
   }
-  if (lane < J) { fv[lane] = st[SZ + lane]; ev[lane] = eta[lane]; }
+  if (tid < J) { fv[tid] = st[SZ + lane]; ev[tid] = eta[tid]; }
   __syncthreads();
 
   // T = [ I + P Jm | P | f + P eta ]
-  for (int idx = lane; idx < J * J; idx += 64) {
+  for (int idx = tid; idx < J * J; idx += NT) {
     const int i = idx / J, j = idx % J;
     double acc = (i == j) ? 1.0 : 0.0;
     for (int k = 0; k < J; ++k) acc += Pm[i * LD + k] * Jmm[k * LD + j];
     T[i * LT + j] = acc;
     T[i * LT + J + j] = Pm[i * LD + j];
   }
-  if (lane < J) {
-    double h = fv[lane];
-    for (int j = 0; j < J; ++j) h += Pm[lane * LD + j] * ev[j];
-    T[lane * LT + 2 * J] = h;
+  if (tid < J) {
+    double h = fv[tid];
+    for (int j = 0; j < J; ++j) h += Pm[tid * LD + j] * ev[j];
+    T[tid * LT + 2 * J] = h;
   }
   __syncthreads();
 
@@ -613,8 +617,9 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
       best = take ? ob : best;
       piv = take ? op : piv;
     }
+    __syncthreads();  // (every wave has finished its search of column `col`)
     if (piv != col) {
-      for (int cc = lane; cc < NC; cc += 64) {
+      for (int cc = tid; cc < NC; cc += NT) {
         const double a = T[col * LT + cc], bb = T[piv * LT + cc];
         T[col * LT + cc] = bb;
         T[piv * LT + cc] = a;
@@ -625,10 +630,10 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     det *= (piv != col) ? -p : p;
     const double inv = 1.0 / p;
     __syncthreads();
-    for (int cc = lane; cc < NC; cc += 64)
+    for (int cc = tid; cc < NC; cc += NT)
       if (cc > col) T[col * LT + cc] *= inv;
     __syncthreads();
-    for (int idx = lane; idx < J * NC; idx += 64) {
+    for (int idx = tid; idx < J * NC; idx += NT) {
       const int i = idx / NC, cc = idx % NC;
       if (i != col && cc > col) T[i * LT + cc] -= T[i * LT + col] * T[col * LT + cc];
     }
@@ -643,37 +648,37 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     __shared__ double pa[J], pb[J];
     for (int probe = 0; probe < 2; ++probe) {
       double gz = 0.0, r = 0.0;
-      if (lane < J) {
-        for (int k = 0; k < J; ++k) gz += (probe && (k & 1)) ? -T[lane * LT + J + k] : T[lane * LT + J + k];
-        pa[lane] = gz;
+      if (tid < J) {
+        for (int k = 0; k < J; ++k) gz += (probe && (k & 1)) ? -T[tid * LT + J + k] : T[tid * LT + J + k];
+        pa[tid] = gz;
       }
       __syncthreads();
-      if (lane < J) {  // t1 = Jm (G z)
+      if (tid < J) {  // t1 = Jm (G z)
         double acc = 0.0;
-        for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * pa[k];
-        pb[lane] = acc;
+        for (int k = 0; k < J; ++k) acc += Jmm[tid * LD + k] * pa[k];
+        pb[tid] = acc;
       }
       __syncthreads();
-      if (lane < J) {  // r = P (z - t1) - G z
+      if (tid < J) {  // r = P (z - t1) - G z
         double acc = -gz;
-        for (int k = 0; k < J; ++k) acc += Pm[lane * LD + k] * (((probe && (k & 1)) ? -1.0 : 1.0) - pb[k]);
+        for (int k = 0; k < J; ++k) acc += Pm[tid * LD + k] * (((probe && (k & 1)) ? -1.0 : 1.0) - pb[k]);
         r = acc;
-        pa[lane] = r;
+        pa[tid] = r;
       }
       __syncthreads();
-      if (lane < J) {  // t1 = Jm r
+      if (tid < J) {  // t1 = Jm r
         double acc = 0.0;
-        for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * pa[k];
-        pb[lane] = acc;
+        for (int k = 0; k < J; ++k) acc += Jmm[tid * LD + k] * pa[k];
+        pb[tid] = acc;
       }
       __syncthreads();
       double dg = 0.0;
-      if (lane < J) {  // dg = r - G t1
+      if (tid < J) {  // dg = r - G t1
         double acc = r;
-        for (int k = 0; k < J; ++k) acc -= T[lane * LT + J + k] * pb[k];
+        for (int k = 0; k < J; ++k) acc -= T[tid * LT + J + k] * pb[k];
         dg = (acc != acc) ? INFINITY : fabs(acc);
       }
-      double gmax = (lane < J) ? fabs(gz) : 0.0;
+      double gmax = (tid < J) ? fabs(gz) : 0.0;
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) {
         dg = fmax(dg, __shfl_xor(dg, m, 64));
@@ -686,29 +691,29 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   }
 
   double ef = 0.0, fJf = 0.0, wGw = 0.0;
-  if (lane < J) {
+  if (tid < J) {
     double acc = 0.0;
-    for (int k = 0; k < J; ++k) acc += Jmm[lane * LD + k] * fv[k];
-    wv[lane] = acc - ev[lane];
-    ef = ev[lane] * fv[lane];
-    fJf = fv[lane] * acc;
+    for (int k = 0; k < J; ++k) acc += Jmm[tid * LD + k] * fv[k];
+    wv[tid] = acc - ev[tid];
+    ef = ev[tid] * fv[tid];
+    fJf = fv[tid] * acc;
   }
   __syncthreads();
-  if (lane < J) {
+  if (tid < J) {
     double acc = 0.0;
-    for (int k = 0; k < J; ++k) acc += 0.5 * (T[lane * LT + J + k] + T[k * LT + J + lane]) * wv[k];
-    wGw = wv[lane] * acc;
+    for (int k = 0; k < J; ++k) acc += 0.5 * (T[tid * LT + J + k] + T[k * LT + J + lane]) * wv[k];
+    wGw = wv[tid] * acc;
   }
   ef = wave_sum64(ef);
   fJf = wave_sum64(fJf);
   wGw = wave_sum64(wGw);
 
   // certificate: F F^T = N + delta I (N = -Jm), then the Cholesky pivots of I - F^T P F
-  double nmax = (lane < J) ? -Jmm[lane * LD + lane] : 0.0;
+  double nmax = (lane < J) ? -Jmm[lane * LD + lane] : 0.0;  // (every wave: delta is needed by all threads)
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) nmax = fmax(nmax, __shfl_xor(nmax, m, 64));
   const double delta = 4e-13 * nmax;
-  for (int idx = lane; idx < J * J; idx += 64) {
+  for (int idx = tid; idx < J * J; idx += NT) {
     const int i = idx / J, j = idx % J;
     Sm[i * LD + j] = -Jmm[i * LD + j] + ((i == j) ? delta : 0.0);
   }
@@ -716,9 +721,9 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   for (int k = 0; k < J; ++k) {  // in place: column k of F replaces column k of S (rows >= k)
     const double rs = 1.0 / sqrt(Sm[k * LD + k]);
     __syncthreads();
-    if (lane < J) Sm[lane * LD + k] = (lane >= k) ? Sm[lane * LD + k] * rs : 0.0;
+    if (tid < J) Sm[tid * LD + k] = (tid >= k) ? Sm[tid * LD + k] * rs : 0.0;
     __syncthreads();
-    for (int idx = lane; idx < J * J; idx += 64) {
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       if (j > k && i >= j) {
         Sm[i * LD + j] -= Sm[i * LD + k] * Sm[j * LD + k];
@@ -727,7 +732,7 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     __syncthreads();
   }
   // (F is the lower triangle of Sm; the strict upper triangle still holds N)
-  for (int idx = lane; idx < J * J; idx += 64) {  // PF = P F
+  for (int idx = tid; idx < J * J; idx += NT) {  // PF = P F
     const int i = idx / J, k = idx % J;
     double acc = 0.0;
     for (int m = k; m < J; ++m) acc += Pm[i * LD + m] * Sm[m * LD + k];
@@ -735,7 +740,7 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   }
   __syncthreads();
   double* Em = T;  // T is no longer needed: E = I - F^T (P F), lower triangle, leading dimension LT
-  for (int idx = lane; idx < J * J; idx += 64) {
+  for (int idx = tid; idx < J * J; idx += NT) {
     const int j = idx / J, k = idx % J;
     if (k <= j) {
       double acc = (j == k) ? 1.0 : 0.0;
@@ -752,9 +757,9 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
     mu = (d < mu) ? d : mu;
     const double rs = 1.0 / sqrt(d);
     __syncthreads();
-    if (lane < J && lane >= k) Em[lane * LT + k] *= rs;
+    if (tid < J && tid >= k) Em[tid * LT + k] *= rs;
     __syncthreads();
-    for (int idx = lane; idx < J * J; idx += 64) {
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       if (j > k && i >= j) Em[i * LT + j] -= Em[i * LT + k] * Em[j * LT + k];
     }
@@ -762,7 +767,7 @@ __global__ void __launch_bounds__(64) wide_correct_kernel(const BatchParams P) {
   }
   if (broke) mu = -1.0;
 
-  if (lane == 0) {
+  if (tid == 0) {
     int bad = 0;
     if (!(mu > 1e-5)) bad = 1;
     if (!(det > 0.0)) bad = 1;
@@ -1151,8 +1156,8 @@ void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
 void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) {
   if (P.nchunk < 2) return;
   const dim3 grid((unsigned)((long)P.B * P.nchunk));
-  if (width_padded <= 16) hipLaunchKernelGGL((wide_correct_kernel<16>), grid, dim3(64), 0, s, P);
-  else hipLaunchKernelGGL((wide_correct_kernel<32>), grid, dim3(64), 0, s, P);
+  if (width_padded <= 16) hipLaunchKernelGGL((wide_correct_kernel<16>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((wide_correct_kernel<32>), grid, dim3(256), 0, s, P);
   launch_wide_decide(P, s);
 }
 
