@@ -1038,47 +1038,76 @@ __device__ __forceinline__ void mfma_32x32x32(const double* X, int ldx, const do
 // between LANES through LDS only need the compiler not to reorder them and the reads to have landed
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ void __launch_bounds__(64) wide_prefix32_kernel(const BatchParams P_) {
+// Round 4: FOUR waves per problem.  The walk over the chunks stays sequential, but inside a chunk the element loads are
+// strided over 256 threads, every wave computes ONE of the four 16 x 16 output tiles of a product (8 MFMA instead of 32), and
+// the elimination is split by rows: wave w owns rows 8 w .. 8 w + 7 of the tableau (lane = column as before), so a pivot
+// costs 8 instead of 32 multiplier reads and row updates per lane.  The pivot search and the scaled pivot row belong to
+// every wave / the first wave; phases are separated by workgroup barriers.
+template <bool YT, bool IDENT>
+__device__ __forceinline__ void mfma_tile_32(const double* X, int ldx, const double* Y, int ldy, const double* Z0, int ldz0,
+                                             double* Z, int ldz, int lane, int ti, int tj) {
+  const int lm = lane & 15, lk = lane >> 4;
+  mfma_acc_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * ti + lk + 4 * r, col = 16 * tj + lm;
+    double init = Z0 ? Z0[row * ldz0 + col] : 0.0;
+    if (IDENT && row == col) init += 1.0;
+    acc[r] = init;
+  }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int k = 4 * ks + lk;
+    const double a = X[(16 * ti + lm) * ldx + k];
+    const double bb = YT ? Y[(16 * tj + lm) * ldy + k] : Y[k * ldy + 16 * tj + lm];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Z[(16 * ti + lk + 4 * r) * ldz + 16 * tj + lm] = acc[r];
+}
+
+__global__ void __launch_bounds__(256) wide_prefix32_kernel(const BatchParams P_) {
   constexpr int J = 32, SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
-  constexpr int LD = Prefix32Lds::LD, LT = Prefix32Lds::LT;
+  constexpr int LD = Prefix32Lds::LD, LT = Prefix32Lds::LT, NT = 256;
   __shared__ Prefix32Lds L;
-  const int lane = threadIdx.x, prob = blockIdx.x;
-  if (lane == 0) P_.need_exact[prob] = 0;  // raised by wide_correct_kernel / decide_kernel
-  for (int idx = lane; idx < J * J; idx += 64) L.P[(idx / J) * LD + idx % J] = 0.0;
-  if (lane < J) L.f[lane] = 0.0;
-  wave_lds_fence();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, prob = blockIdx.x;
+  const int ti = wave >> 1, tj = wave & 1;  // this wave's output tile of the 32 x 32 products
+  if (tid == 0) P_.need_exact[prob] = 0;  // raised by wide_correct_kernel / decide_kernel
+  for (int idx = tid; idx < J * J; idx += NT) L.P[(idx / J) * LD + idx % J] = 0.0;
+  if (tid < J) L.f[tid] = 0.0;
+  __syncthreads();
   for (int c = 0; c + 1 < P_.nchunk; ++c) {
     const double* E = P_.elems + ((long)prob * P_.nchunk + c) * ELEM;
     const double* Eb = E + J * J;
     const double* EC = Eb + J;
     const double* Eeta = EC + SZ;
     const double* EJm = Eeta + J;
-    for (int idx = lane; idx < J * J; idx += 64) {
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       L.A[i * LD + j] = E[idx];
       L.C[i * LD + j] = EC[sym(i, j)];
       L.Jf[i * LD + j] = EJm[sym(i, j)];
       L.T[i * LT + J + j] = L.P[i * LD + j];  // right half of the tableau: P
     }
-    if (lane < J) { L.b[lane] = Eb[lane]; L.eta[lane] = Eeta[lane]; }
-    wave_lds_fence();
+    if (tid < J) { L.b[tid] = Eb[tid]; L.eta[tid] = Eeta[tid]; }
+    __syncthreads();
     // M^T = I + P Jm -> left half of the tableau
-    mfma_32x32x32<false, true>(L.P, LD, L.Jf, LD, nullptr, 0, L.T, LT, lane);
+    mfma_tile_32<false, true>(L.P, LD, L.Jf, LD, nullptr, 0, L.T, LT, lane, ti, tj);
     // h = f + P eta
-    if (lane < J) {
-      double acc = L.f[lane];
+    if (tid < J) {
+      double acc = L.f[tid];
 #pragma unroll 8
-      for (int j = 0; j < J; ++j) acc += L.P[lane * LD + j] * L.eta[j];
-      L.h[lane] = acc;
+      for (int j = 0; j < J; ++j) acc += L.P[tid * LD + j] * L.eta[j];
+      L.h[tid] = acc;
     }
-    wave_lds_fence();
-    if (lane < J) {  // v = Jm h
+    __syncthreads();
+    if (tid < J) {  // v = Jm h
       double acc = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < J; ++j) acc += L.Jf[lane * LD + j] * L.h[j];
-      L.v[lane] = acc;
+      for (int j = 0; j < J; ++j) acc += L.Jf[tid * LD + j] * L.h[j];
+      L.v[tid] = acc;
     }
-    // Gauss-Jordan with partial pivoting, lane = column of [M^T | P]
+    // Gauss-Jordan with partial pivoting, lane = column of [M^T | P], wave = block of 8 rows
     for (int col = 0; col < J; ++col) {
       int piv = col;
       double best = -1.0;
@@ -1088,57 +1117,61 @@ __global__ void __launch_bounds__(64) wide_prefix32_kernel(const BatchParams P_)
       }
       const double top = L.T[piv * LT + lane], old = L.T[col * LT + lane];
       const double pv = L.T[piv * LT + col];
-      wave_lds_fence();
+      __syncthreads();  // (every wave has read the column and the two rows)
       const double t = top * (1.0 / pv);
-      L.T[piv * LT + lane] = old;   // row swap (a no-op when piv == col) ...
-      wave_lds_fence();
-      L.T[col * LT + lane] = t;     // ... and the scaled pivot row
-      wave_lds_fence();
-      double m[J];
+      if (wave == 0) {
+        L.T[piv * LT + lane] = old;   // row swap (a no-op when piv == col) ...
+        wave_lds_fence();
+        L.T[col * LT + lane] = t;     // ... and the scaled pivot row
+      }
+      __syncthreads();
+      double m[8];
 #pragma unroll
-      for (int i = 0; i < J; ++i) m[i] = L.T[i * LT + col];
-      wave_lds_fence();
+      for (int r = 0; r < 8; ++r) m[r] = L.T[(8 * wave + r) * LT + col];
+      wave_lds_fence();  // (a wave's own rows: no other wave writes them)
 #pragma unroll
-      for (int i = 0; i < J; ++i)
-        if (i != col) L.T[i * LT + lane] = fma(-m[i], t, L.T[i * LT + lane]);
-      wave_lds_fence();
+      for (int r = 0; r < 8; ++r) {
+        const int i = 8 * wave + r;
+        if (i != col) L.T[i * LT + lane] = fma(-m[r], t, L.T[i * LT + lane]);
+      }
+      __syncthreads();
     }
     // Gs = (G + G^T) / 2 -> Jf (Jm is no longer needed); g = h - G v
-    for (int idx = lane; idx < J * J; idx += 64) {
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       L.Jf[i * LD + j] = 0.5 * (L.T[i * LT + J + j] + L.T[j * LT + J + i]);
     }
-    if (lane < J) {
-      double acc = L.h[lane];
+    if (tid < J) {
+      double acc = L.h[tid];
 #pragma unroll 8
-      for (int j = 0; j < J; ++j) acc -= L.T[lane * LT + J + j] * L.v[j];
-      L.g[lane] = acc;
+      for (int j = 0; j < J; ++j) acc -= L.T[tid * LT + J + j] * L.v[j];
+      L.g[tid] = acc;
     }
-    wave_lds_fence();
+    __syncthreads();
     // X = A Gs ; P' = C + X A^T ; f' = A g + b
-    mfma_32x32x32<false, false>(L.A, LD, L.Jf, LD, nullptr, 0, L.X, LD, lane);
-    if (lane < J) {
-      double acc = L.b[lane];
+    mfma_tile_32<false, false>(L.A, LD, L.Jf, LD, nullptr, 0, L.X, LD, lane, ti, tj);
+    if (tid < J) {
+      double acc = L.b[tid];
 #pragma unroll 8
-      for (int j = 0; j < J; ++j) acc += L.A[lane * LD + j] * L.g[j];
-      L.f[lane] = acc;
+      for (int j = 0; j < J; ++j) acc += L.A[tid * LD + j] * L.g[j];
+      L.f[tid] = acc;
     }
-    wave_lds_fence();
-    mfma_32x32x32<true, false>(L.X, LD, L.A, LD, L.C, LD, L.P, LD, lane);
-    wave_lds_fence();
+    __syncthreads();
+    mfma_tile_32<true, false>(L.X, LD, L.A, LD, L.C, LD, L.P, LD, lane, ti, tj);
+    __syncthreads();
     // start state of chunk c + 1: packed upper triangle (mirrored into the lower one for the next round) | f
     double* o = P_.starts + ((long)prob * P_.nchunk + c + 1) * START;
-    for (int idx = lane; idx < J * J; idx += 64) {
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       if (i <= j) o[tri(i, j)] = L.P[i * LD + j];
     }
-    if (lane < J) o[SZ + lane] = L.f[lane];
-    wave_lds_fence();
-    for (int idx = lane; idx < J * J; idx += 64) {
+    if (tid < J) o[SZ + tid] = L.f[tid];
+    __syncthreads();
+    for (int idx = tid; idx < J * J; idx += NT) {
       const int i = idx / J, j = idx % J;
       if (i > j) L.P[i * LD + j] = L.P[j * LD + i];
     }
-    wave_lds_fence();
+    __syncthreads();
   }
 }
 
@@ -1147,7 +1180,7 @@ void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
   if (width_padded <= 16)
     hipLaunchKernelGGL((prefix_coop_kernel<16, 16>), dim3((P.B + 1) / 2), dim3(64), 0, s, P);
   else if (P.coop_prefix)
-    hipLaunchKernelGGL(wide_prefix32_kernel, dim3(P.B), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(wide_prefix32_kernel, dim3(P.B), dim3(256), 0, s, P);
   else  // (clr_batch_set_prefix_mode(h, 0): the register-resident kernel of round 1, kept for A/B)
     hipLaunchKernelGGL((prefix_coop_kernel<32, 32>), dim3(P.B), dim3(64), 0, s, P);
 }
