@@ -199,7 +199,7 @@ struct clr_batch {
   DevBuf gen_elems, gen_starts, gen_part, gen_cond;
   int* gen_flags = nullptr;
   bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
-  double wide_first_ratio = 1.18;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk (1.1-1.2 flat, 1.25 already long: profiles/r04c, r04p)
+  double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk (1.1-1.25 within 2 %: profiles/r04c, r04p)
   const clr::BatchLaunchers* launch = nullptr;
   DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout
   double* pin = nullptr;              // pinned host staging: coefficient uploads, result downloads

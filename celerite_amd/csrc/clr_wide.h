@@ -65,4 +65,44 @@ __device__ __forceinline__ void row_sum2(double mine, int seg, double* sa, doubl
   *sb = (lane_value(v, 1) + lane_value(v, 17)) + (lane_value(v, 33) + lane_value(v, 49));
 }
 
+// v + the value of the lane 16 (32) lanes away: gfx950's v_permlane16_swap / v_permlane32_swap exchange odd and even
+// 16-lane rows (the two 32-lane halves) of two registers -- with both operands copies of v, the two results are v of
+// the own row and v of the partner row in EVERY lane, lane positions inside the rows unchanged.  No LDS, no SGPR trip.
+__device__ __forceinline__ double swap_add16(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap_add32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_EVEN = 0xA0;  // quad_perm:[0,0,2,2]: both lanes of a pair read the even one
+constexpr int DPP_QUAD_ODD = 0xF5;   // quad_perm:[1,1,3,3]
+
+// row_sum2 with both sums delivered to EVERY lane as vector values (no v_readlane / SGPR round trip): the butterfly is
+// completed across the four 16-lane rows with the permlane swaps, then the even lane's total (sum a) and the odd
+// lane's (sum b) are copied to their pair.  The consumers (D, 1 / D, x ...) are per-lane fp64 operations anyway.
+template <int LPR>
+__device__ __forceinline__ void row_sum2_all(double mine, int seg, double* sa, double* sb) {
+  static_assert(LPR >= 2, "needs two lanes per row");
+  double v = (LPR > 2 && seg >= 2) ? 0.0 : mine;
+  v = dpp_add<DPP_QUAD_XOR2>(v);
+  v = dpp_add<DPP_ROW_ROR4>(v);
+  v = dpp_add<DPP_ROW_ROR8>(v);
+  v = swap_add16(v);
+  v = swap_add32(v);
+  *sa = dpp_mov<DPP_QUAD_EVEN>(v);
+  *sb = dpp_mov<DPP_QUAD_ODD>(v);
+}
+
 }  // namespace clr

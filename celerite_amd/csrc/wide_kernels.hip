@@ -330,7 +330,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); if (RID) r = dpp_add<DPP_QUAD_XOR1>(r); }
       if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); if (RID) r = dpp_add<DPP_QUAD_XOR2>(r); }
       double s, ub;
-      if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
+#ifndef CLR_WIDE_PERMLANE_SUMS
+#define CLR_WIDE_PERMLANE_SUMS 1  // the sums completed with v_permlane16/32_swap and kept in vector registers
+#endif
+      if constexpr (PACKED && CLR_WIDE_PERMLANE_SUMS) row_sum2_all<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
+      else if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
       else { s = row_sum<LPR>(ueff * q); ub = row_sum<LPR>(ueff * f); }
       const double D = diag_n - s;  // (diag_n: the tile already holds K(0) = ((diag + sum a_real) + sum a_comp) + jitter)
       const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
