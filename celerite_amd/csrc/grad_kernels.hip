@@ -206,8 +206,16 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
       }
       if (LPR >= 2) { q = dpp_add<DPP_QUAD_XOR1>(q); dq = dpp_add<DPP_QUAD_XOR1>(dq); }
       if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); dq = dpp_add<DPP_QUAD_XOR2>(dq); }
-      const double s = row_sum<LPR>(u * q), ds = row_sum<LPR>(fma(du, q, u * dq));
-      const double ub = row_sum<LPR>(u * f), dub = row_sum<LPR>(fma(du, f, u * df));
+      double s, ds, ub, dub;
+      if constexpr (LPR >= 2) {
+        // two sums per butterfly tree (first lane of a row: the q-terms, second lane: the f-terms), completed across the
+        // 16-lane rows with the permlane swaps and delivered to every lane as vector values (clr_wide.h: row_sum2_all)
+        row_sum2_all<LPR>(u * (seg == 0 ? q : f), seg, &s, &ub);
+        row_sum2_all<LPR>(seg == 0 ? fma(du, q, u * dq) : fma(du, f, u * df), seg, &ds, &dub);
+      } else {
+        s = row_sum<LPR>(u * q); ds = row_sum<LPR>(fma(du, q, u * dq));
+        ub = row_sum<LPR>(u * f); dub = row_sum<LPR>(fma(du, f, u * df));
+      }
       const double D = a_n - s, dD = da - ds;
       const double invD = 1.0 / D;
       const double x = y_n - ub, dx = -dub;
