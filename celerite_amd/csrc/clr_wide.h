@@ -89,6 +89,16 @@ __device__ __forceinline__ double dpp_mov(double v) {
 constexpr int DPP_QUAD_EVEN = 0xA0;  // quad_perm:[0,0,2,2]: both lanes of a pair read the even one
 constexpr int DPP_QUAD_ODD = 0xF5;   // quad_perm:[1,1,3,3]
 
+// row_sum with the total delivered to every lane as a vector value: the in-row butterfly, then the permlane swaps
+template <int LPR>
+__device__ __forceinline__ double row_sum_all(double v) {
+  if (LPR < 2) v = dpp_add<DPP_QUAD_XOR1>(v);
+  if (LPR < 4) v = dpp_add<DPP_QUAD_XOR2>(v);
+  v = dpp_add<DPP_HALF_MIRROR>(v);
+  v = dpp_add<DPP_MIRROR>(v);
+  return swap_add32(swap_add16(v));
+}
+
 // row_sum2 with both sums delivered to EVERY lane as vector values (no v_readlane / SGPR round trip): the butterfly is
 // completed across the four 16-lane rows with the permlane swaps, then the even lane's total (sum a) and the odd
 // lane's (sum b) are copied to their pair.  The consumers (D, 1 / D, x ...) are per-lane fp64 operations anyway.

@@ -213,8 +213,8 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
         row_sum2_all<LPR>(u * (seg == 0 ? q : f), seg, &s, &ub);
         row_sum2_all<LPR>(seg == 0 ? fma(du, q, u * dq) : fma(du, f, u * df), seg, &ds, &dub);
       } else {
-        s = row_sum<LPR>(u * q); ds = row_sum<LPR>(fma(du, q, u * dq));
-        ub = row_sum<LPR>(u * f); dub = row_sum<LPR>(fma(du, f, u * df));
+        s = row_sum_all<LPR>(u * q); ds = row_sum_all<LPR>(fma(du, q, u * dq));
+        ub = row_sum_all<LPR>(u * f); dub = row_sum_all<LPR>(fma(du, f, u * df));
       }
       const double D = a_n - s, dD = da - ds;
       const double invD = 1.0 / D;

@@ -335,7 +335,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 #endif
       if constexpr (PACKED && CLR_WIDE_PERMLANE_SUMS) row_sum2_all<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
       else if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
-      else { s = row_sum<LPR>(ueff * q); ub = row_sum<LPR>(ueff * f); }
+      else { s = row_sum_all<LPR>(ueff * q); ub = row_sum_all<LPR>(ueff * f); }  // (one lane per row: width 64)
       const double D = diag_n - s;  // (diag_n: the tile already holds K(0) = ((diag + sum a_real) + sum a_comp) + jitter)
       const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
       const double x = y_n - ub;
