@@ -450,8 +450,11 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
       s->grad_series.clear();
       s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC; s->grad_wide = wide_plan;
       if (s->grad_plan && wide_plan) {
-        int nc = (int)lround(sqrt((double)N / (Wt <= 16 ? 40.0 : 170.0)));
-        nc = std::max(Wt <= 16 ? 8 : 16, std::min(nc, Wt <= 16 ? 64 : 32));
+        // chunks: the tangent pass dominates (one wave per (partial, chunk), 0.55-1.3 us per step): exactly two resident
+        // waves per SIMD -- G x nc <= 2048 -- as long as a chunk keeps >= 768 samples (profiles/r04r_wide_grad_trace.txt:
+        // 65 x 24 = 1560 waves left a third of the SIMDs with two waves and the rest waiting for them)
+        int nc = std::min(2048 / G, N / 768);
+        nc = std::max(4, std::min(nc, 64));
         if ((st = clr_batch_set_chunks(s->grad_plan, nc)) != CLR_OK) return st;
       }
     }

@@ -54,6 +54,9 @@ for w in $WHAT; do
       trace small python tools/gpu_small_profile.py
       pmc small_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" python tools/gpu_small_profile.py
       ;;
+    widegrad)
+      trace widegrad python tools/gpu_wide_grad_profile.py
+      ;;
     general)
       trace general python tools/gpu_general_profile.py
       ;;
