@@ -455,6 +455,18 @@ def test_wide_plan_gradient_parallel_in_n(JR, JC, JG):
                 within("wide plan gradient: partials vs sequential kernel (of the largest)",
                        np.max(np.abs(g[b] - g0)) / np.max(np.abs(g0)), 1e-10, (nchunk, b))
             assert g[0, 0] == 0.0 and g[1, 0] != 0.0
+        # every problem pushed off the scan's routes (no conditioning record passes, no replay residual either): the
+        # evaluation settles them sequentially and the gradient takes the sequential tangent kernel in its batched form
+        # (general terms per problem through their strides)
+        plan.set_certificate(max_gamma_over_mu=1e-30, max_residual=1e-30)
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        v, g, st = plan.grad_log_likelihood()
+        assert plan.grad_fallbacks() == B and st[2] == 2
+        for b in (0, 1, 3):
+            v0, g0 = want[b]
+            within("wide plan gradient, sequential fallback: value", abs(v[b] - v0) / abs(v0), 1e-13, b)
+            within("wide plan gradient, sequential fallback: partials (of the largest)",
+                   np.max(np.abs(g[b] - g0)) / np.max(np.abs(g0)), 1e-12, b)
     finally:
         plan.close()
 
