@@ -450,11 +450,12 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
       s->grad_series.clear();
       s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC; s->grad_wide = wide_plan;
       if (s->grad_plan && wide_plan) {
-        // chunks: the tangent pass dominates (one wave per (partial, chunk), 0.55-1.3 us per step): exactly two resident
-        // waves per SIMD -- G x nc <= 2048 -- as long as a chunk keeps >= 768 samples (profiles/r04r_wide_grad_trace.txt:
-        // 65 x 24 = 1560 waves left a third of the SIMDs with two waves and the rest waiting for them)
-        int nc = std::min(2048 / G, N / 768);
-        nc = std::max(4, std::min(nc, 64));
+        // chunks: the tangent pass dominates (one wave per (pair of partials, chunk), ~1.2 us per step whatever else the
+        // SIMD holds): exactly one wave per SIMD -- ceil(G / 2) x nc <= 1024 -- as long as a chunk keeps >= 768 samples
+        // (profiles/r04s_wide_grad_two_directions.txt: 17 x 60 = 1020 waves 4.04 ms, 17 x 64 = 1088 waves 4.72 ms -- the 64
+        // SIMDs with a second wave finish last)
+        int nc = std::min(1024 / ((G + 1) / 2), N / 768);
+        nc = std::max(4, std::min(nc, 128));
         if ((st = clr_batch_set_chunks(s->grad_plan, nc)) != CLR_OK) return st;
       }
     }

@@ -287,10 +287,289 @@ __global__ void __launch_bounds__(64) wide_grad_kernel(const GradParams Pin) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The chunked tangent pass with TWO directions per wave (round 4): a wave of the kernel above spends ~40 % of a step on
+// the base recurrence (features, q, the S update, the pivot) that every direction of the chunk repeats.  Here a wave
+// carries directions 2 x and 2 x + 1 on ONE base recurrence: NG / 2 waves per (problem, chunk) instead of NG, three
+// packed reduction trees per step instead of four, the base's LDS exchanges shared.  Same arithmetic per direction.
+// blockIdx = (pair of directions, problem, chunk); record layout as wide_grad_kernel<.., CHUNKED>.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WMAX, bool FAST>
+__global__ void __launch_bounds__(64) wide_grad2_kernel(const GradParams Pin) {
+  GradParams P = Pin;
+  const long b = blockIdx.y;
+  if (Pin.only_level && Pin.only_level[b] >= 2) return;  // (left to the sequential form)
+  const int NG = 1 + 2 * Pin.J_real + 4 * Pin.J_comp;
+  if (P.A) P.A += b * Pin.A_stride;
+  if (P.U) { P.U += b * Pin.U_stride; P.V += b * Pin.V_stride; }
+  P.a_real += b * Pin.J_real; P.c_real += b * Pin.J_real;
+  P.a_comp += b * Pin.J_comp; P.b_comp += b * Pin.J_comp; P.c_comp += b * Pin.J_comp; P.d_comp += b * Pin.J_comp;
+  P.jitter = Pin.jitter_b[b];
+  P.t += b * Pin.t_stride; P.diag += b * Pin.diag_stride; P.y += b * Pin.y_stride;
+  using G = WideGeom<WMAX>;
+  constexpr int LPR = G::LPR, COLS = G::COLS;
+  static_assert(LPR >= 2, "the chunked gradient covers the padded widths 16 and 32");
+  __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX], pbuf[2][WMAX], wbuf[WMAX];
+  __shared__ __attribute__((aligned(16))) double dubuf[2][2][WMAX], dpbuf[2][2][WMAX], dwbuf[2][WMAX];  // [direction]...
+  const int lane = threadIdx.x;
+  const int row = lane / LPR, seg = lane % LPR;
+  const bool writer = seg == 0;
+  const int JR = P.J_real, JC = P.J_comp, JG = P.J_general, N = P.N;
+  const int Wc = JR + 2 * JC;
+
+  double u0 = 0.0, uc = 0.0, us = 0.0, v0 = 0.0, vc = 0.0, vs = 0.0, cdec = 0.0, dfreq = 0.0;
+  int pair = -1;
+  bool cosrow = false;
+  const double *ug = nullptr, *vg = nullptr;
+  if (row < JR) {
+    u0 = P.a_real[row]; v0 = 1.0; cdec = P.c_real[row];
+  } else if (row < Wc) {
+    pair = (row - JR) >> 1;
+    cosrow = ((row - JR) & 1) == 0;
+    const double a = P.a_comp[pair], bb = P.b_comp[pair];
+    if (cosrow) { uc = a; us = bb; vc = 1.0; } else { uc = -bb; us = a; vs = 1.0; }
+    cdec = P.c_comp[pair];
+    dfreq = P.d_comp[pair];
+  } else if (row < Wc + JG) {
+    ug = P.U + (long)(row - Wc) * N;
+    vg = P.V + (long)(row - Wc) * N;
+  }
+  // the two directions (solver.cpp:379-406: jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp); a direction past
+  // the last one is the zero direction
+  double du0[2] = {0.0, 0.0}, duc[2] = {0.0, 0.0}, dus[2] = {0.0, 0.0}, dcf[2] = {0.0, 0.0}, ddf[2] = {0.0, 0.0}, da[2] = {0.0, 0.0};
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    int q = 2 * blockIdx.x + d;
+    if (q >= NG) continue;
+    if (q == 0) {
+      da[d] = 1.0;
+    } else if ((q -= 1) < JR) {
+      da[d] = 1.0;
+      if (row == q) du0[d] = 1.0;
+    } else if ((q -= JR) < JR) {
+      if (row == q) dcf[d] = 1.0;
+    } else if ((q -= JR) < JC) {
+      da[d] = 1.0;
+      if (pair == q) { if (cosrow) duc[d] = 1.0; else dus[d] = 1.0; }
+    } else if ((q -= JC) < JC) {
+      if (pair == q) { if (cosrow) dus[d] = 1.0; else duc[d] = -1.0; }
+    } else if ((q -= JC) < JC) {
+      if (pair == q) dcf[d] = 1.0;
+    } else {
+      q -= JC;
+      if (pair == q) ddf[d] = 1.0;
+    }
+  }
+  double sum_ar = 0.0, sum_ac = 0.0;  // cholesky.h:98
+  for (int j = 0; j < JR; ++j) sum_ar += P.a_real[j];
+  for (int j = 0; j < JC; ++j) sum_ac += P.a_comp[j];
+  const double jitter = P.jitter;
+  const bool has_general = P.A != nullptr;
+
+  auto features = [&](double t, double dx, double ugen, double vgen, double* u, double* du, double* v, double* dv,
+                      double* phi, double* dphi) {
+    double sd, cs;
+    sincos_phase<FAST>(dfreq * t, &sd, &cs);
+    const double x = -cdec * dx;
+    const double e = CLR_WAVE_ALL(fabs(x) < 0.0078125) ? exp_small(x) : exp(x);
+    *phi = e;
+    *u = fma(uc, cs, fma(us, sd, u0)) + ugen;
+    *v = fma(vc, cs, fma(vs, sd, v0)) + vgen;
+    const double ru = us * cs - uc * sd, rv = vs * cs - vc * sd;  // d u / d(phase), d v / d(phase)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      dphi[d] = -(dcf[d] * dx) * e;
+      const double tt = ddf[d] * t;
+      du[d] = fma(duc[d], cs, fma(dus[d], sd, du0[d])) + tt * ru;
+      dv[d] = tt * rv;
+    }
+  };
+
+  const int c = blockIdx.z;
+  auto begin = [&](int k) {
+    const long n = (P.L0 > 0 && k > 0) ? (long)P.L0 + (long)(k - 1) * P.L : (long)k * P.L;
+    return n < N ? (int)n : N;
+  };
+  const int n_lo = begin(c), n_hi = begin(c + 1);
+  double S[COLS], dS[2][COLS];
+#pragma unroll
+  for (int k = 0; k < COLS; ++k) { S[k] = 0.0; dS[0][k] = 0.0; dS[1][k] = 0.0; }
+  double f = 0.0, df[2] = {0.0, 0.0}, dquad[2] = {0.0, 0.0}, dld[2] = {0.0, 0.0};
+  if (c > 0) {  // the true base state at the chunk's first sample (packed upper triangle | f)
+    constexpr int SZP = WMAX * (WMAX + 1) / 2;
+    const double* st = P.starts + ((long)b * P.nchunk + c) * (SZP + WMAX);
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) S[k] = st[sym(row, seg * COLS + k)];
+    f = st[SZP + row];
+  }
+
+  double tv = n_lo + lane < N ? P.t[n_lo + lane] : 0.0;
+  double tv2 = n_lo + lane + 64 < N ? P.t[n_lo + lane + 64] : 0.0;
+  double dv_ = n_lo + lane < N ? P.diag[n_lo + lane] : 0.0;
+  dv_ = ((dv_ + sum_ar) + sum_ac) + jitter;                       // K(0) of the tile's samples (cholesky.h:98-99)
+  if (has_general && n_lo + lane < N) dv_ += P.A[n_lo + lane];
+  double yv = n_lo + lane < N ? P.y[n_lo + lane] : 0.0;
+  auto t_at = [&](int k) { return k < 64 ? lane_value(tv, k) : lane_value(tv2, k - 64); };
+
+  double ug1 = 0.0, vg1 = 0.0, ug2 = 0.0, vg2 = 0.0;
+  if (ug) {
+    ug1 = n_lo + 1 < N ? ug[n_lo + 1] : 0.0; vg1 = n_lo + 1 < N ? vg[n_lo + 1] : 0.0;
+    ug2 = n_lo + 2 < N ? ug[n_lo + 2] : 0.0; vg2 = n_lo + 2 < N ? vg[n_lo + 2] : 0.0;
+  }
+  double u, v, phi, du[2], dv[2], dphi[2];
+  features(t_at(0), n_lo + 1 < N ? t_at(1) - t_at(0) : 0.0, (ug && n_lo < N) ? ug[n_lo] : 0.0, (ug && n_lo < N) ? vg[n_lo] : 0.0,
+           &u, du, &v, dv, &phi, dphi);
+  if (writer) {
+    ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) { dubuf[d][n_lo & 1][row] = du[d]; dpbuf[d][n_lo & 1][row] = dphi[d]; }
+  }
+
+  for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
+    const int nend = (n_hi - n0 < 64) ? n_hi - n0 : 64;
+    for (int k = 0; k < nend; ++k) {
+      const int n = n0 + k, cur = n & 1;
+      const double a_n = lane_value(dv_, k), y_n = lane_value(yv, k);
+
+      double u1 = 0.0, v1 = 0.0, phi1 = 1.0, du1[2] = {0.0, 0.0}, dv1[2] = {0.0, 0.0}, dphi1[2] = {0.0, 0.0};
+      if (n + 1 < N) {
+        const double t1 = t_at(k + 1);
+        const double dx1 = (n + 2 < N) ? t_at(k + 2) - t1 : 0.0;
+        features(t1, dx1, ug1, vg1, &u1, du1, &v1, dv1, &phi1, dphi1);
+        if (writer) {
+          ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1;
+#pragma unroll
+          for (int d = 0; d < 2; ++d) { dubuf[d][cur ^ 1][row] = du1[d]; dpbuf[d][cur ^ 1][row] = dphi1[d]; }
+        }
+        ug1 = ug2; vg1 = vg2;
+        if (ug && n + 3 < N) { ug2 = ug[n + 3]; vg2 = vg[n + 3]; }
+      }
+
+      double q = 0.0, dq[2] = {0.0, 0.0};
+      {
+        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+        const double2* duv0 = reinterpret_cast<const double2*>(&dubuf[0][cur][seg * COLS]);
+        const double2* duv1 = reinterpret_cast<const double2*>(&dubuf[1][cur][seg * COLS]);
+#pragma unroll
+        for (int j = 0; j < COLS / 2; ++j) {
+          const double2 uu = uv[j], d0 = duv0[j], d1 = duv1[j];
+          q = fma(S[2 * j], uu.x, q);
+          q = fma(S[2 * j + 1], uu.y, q);
+          dq[0] = fma(dS[0][2 * j], uu.x, fma(S[2 * j], d0.x, dq[0]));
+          dq[0] = fma(dS[0][2 * j + 1], uu.y, fma(S[2 * j + 1], d0.y, dq[0]));
+          dq[1] = fma(dS[1][2 * j], uu.x, fma(S[2 * j], d1.x, dq[1]));
+          dq[1] = fma(dS[1][2 * j + 1], uu.y, fma(S[2 * j + 1], d1.y, dq[1]));
+        }
+      }
+      q = dpp_add<DPP_QUAD_XOR1>(q); dq[0] = dpp_add<DPP_QUAD_XOR1>(dq[0]); dq[1] = dpp_add<DPP_QUAD_XOR1>(dq[1]);
+      if (LPR >= 4) { q = dpp_add<DPP_QUAD_XOR2>(q); dq[0] = dpp_add<DPP_QUAD_XOR2>(dq[0]); dq[1] = dpp_add<DPP_QUAD_XOR2>(dq[1]); }
+      double s, ub, ds[2], dub[2];
+      row_sum2_all<LPR>(u * (seg == 0 ? q : f), seg, &s, &ub);
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        row_sum2_all<LPR>(seg == 0 ? fma(du[d], q, u * dq[d]) : fma(du[d], f, u * df[d]), seg, &ds[d], &dub[d]);
+      const double D = a_n - s;
+      const double invD = 1.0 / D;
+      const double x = y_n - ub;
+      const double xs = x * invD;
+      const double z = v - q;
+      const double w = z * invD;
+      double dz[2], dw[2], dxx[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const double dD = da[d] - ds[d];
+        dxx[d] = -dub[d];
+        dld[d] = fma(dD, invD, dld[d]);
+        dquad[d] += (2.0 * dxx[d] - xs * dD) * xs;
+        dz[d] = dv[d] - dq[d];
+        dw[d] = (dz[d] - w * dD) * invD;
+      }
+      if (writer) {
+        wbuf[row] = phi * w;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) dwbuf[d][row] = fma(dphi[d], w, phi * dw[d]);
+      }
+      {
+        const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
+        const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
+        const double2* dpv0 = reinterpret_cast<const double2*>(&dpbuf[0][cur][seg * COLS]);
+        const double2* dpv1 = reinterpret_cast<const double2*>(&dpbuf[1][cur][seg * COLS]);
+        const double2* dwv0 = reinterpret_cast<const double2*>(&dwbuf[0][seg * COLS]);
+        const double2* dwv1 = reinterpret_cast<const double2*>(&dwbuf[1][seg * COLS]);
+#pragma unroll
+        for (int j = 0; j < COLS / 2; ++j) {
+          const double2 pk = pv[j], pw = wv[j], dpk0 = dpv0[j], dpk1 = dpv1[j], dpw0 = dwv0[j], dpw1 = dwv1[j];
+          {
+            const double inner = fma(z, pw.x, pk.x * S[2 * j]);
+            const double di0 = fma(dpk0.x, S[2 * j], fma(pk.x, dS[0][2 * j], fma(dz[0], pw.x, z * dpw0.x)));
+            const double di1 = fma(dpk1.x, S[2 * j], fma(pk.x, dS[1][2 * j], fma(dz[1], pw.x, z * dpw1.x)));
+            dS[0][2 * j] = fma(dphi[0], inner, phi * di0);
+            dS[1][2 * j] = fma(dphi[1], inner, phi * di1);
+            S[2 * j] = phi * inner;
+          }
+          {
+            const double inner = fma(z, pw.y, pk.y * S[2 * j + 1]);
+            const double di0 = fma(dpk0.y, S[2 * j + 1], fma(pk.y, dS[0][2 * j + 1], fma(dz[0], pw.y, z * dpw0.y)));
+            const double di1 = fma(dpk1.y, S[2 * j + 1], fma(pk.y, dS[1][2 * j + 1], fma(dz[1], pw.y, z * dpw1.y)));
+            dS[0][2 * j + 1] = fma(dphi[0], inner, phi * di0);
+            dS[1][2 * j + 1] = fma(dphi[1], inner, phi * di1);
+            S[2 * j + 1] = phi * inner;
+          }
+        }
+      }
+      {
+        const double g = fma(w, x, f);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const double dg = df[d] + fma(dw[d], x, w * dxx[d]);
+          df[d] = fma(dphi[d], g, phi * dg);
+        }
+        f = phi * g;
+      }
+      u = u1; v = v1; phi = phi1;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) { du[d] = du1[d]; dv[d] = dv1[d]; dphi[d] = dphi1[d]; }
+    }
+    const int m = n0 + 64 + lane;
+    tv = tv2;
+    tv2 = m + 64 < N ? P.t[m + 64] : 0.0;
+    dv_ = m < N ? P.diag[m] : 0.0;
+    dv_ = ((dv_ + sum_ar) + sum_ac) + jitter;
+    if (has_general && m < N) dv_ += P.A[m];
+    yv = m < N ? P.y[m] : 0.0;
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int q = 2 * blockIdx.x + d;
+    if (q >= NG) continue;
+    double* o = P.rec + (((long)b * P.nchunk + c) * NG + q) * ((long)WMAX * WMAX + WMAX + 2);
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) o[row * WMAX + seg * COLS + k] = dS[d][k];
+    if (writer) o[WMAX * WMAX + row] = df[d];
+    if (lane == 0) { o[WMAX * WMAX + WMAX] = dld[d]; o[WMAX * WMAX + WMAX + 1] = dquad[d]; }
+  }
+}
+
 }  // namespace
 
 void launch_grad_chunked(const GradParams& P, hipStream_t s) {
-  const dim3 grid(1 + 2 * P.J_real + 4 * P.J_comp, P.B, P.nchunk);
+#ifndef CLR_GRAD_TWO_DIRECTIONS
+#define CLR_GRAD_TWO_DIRECTIONS 1
+#endif
+  const int NG = 1 + 2 * P.J_real + 4 * P.J_comp;
+  if (CLR_GRAD_TWO_DIRECTIONS) {  // two directions per wave on one base recurrence
+    const dim3 grid2((NG + 1) / 2, P.B, P.nchunk);
+    if (P.JP == 16) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_grad2_kernel<16, true>), grid2, dim3(64), 0, s, P);
+      else hipLaunchKernelGGL((wide_grad2_kernel<16, false>), grid2, dim3(64), 0, s, P);
+    } else {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_grad2_kernel<32, true>), grid2, dim3(64), 0, s, P);
+      else hipLaunchKernelGGL((wide_grad2_kernel<32, false>), grid2, dim3(64), 0, s, P);
+    }
+    return;
+  }
+  const dim3 grid(NG, P.B, P.nchunk);
   if (P.JP == 16) {
     if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<16, true, true>), grid, dim3(64), 0, s, P);
     else hipLaunchKernelGGL((wide_grad_kernel<16, false, true>), grid, dim3(64), 0, s, P);

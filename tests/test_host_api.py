@@ -269,36 +269,3 @@ def test_device_memory_needs_a_gpu():
     else:
         free, total = batch.device_memory()
         assert 0 < free <= total
-
-
-def test_element_composition_prototype():
-    """tools/prototypes/compose.py (groundwork for a two-level prefix, not product code): the closed-form
-    composition of two chunk elements equals applying them one after the other, and the two-level start states
-    equal the sequential ones -- on a celerite-like random recurrence (positive definite, decaying)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location(
-        "compose", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "prototypes", "compose.py"))
-    cp = importlib.util.module_from_spec(spec); spec.loader.exec_module(cp)
-    rng = np.random.RandomState(5)
-    J, nchunk, L = 5, 12, 7
-    elems = []
-    for c in range(nchunk):
-        us = rng.randn(L, J) * 0.3; vs = rng.randn(L, J) * 0.3
-        phis = np.exp(-rng.uniform(0.01, 0.3, (L, J))); a_s = rng.uniform(2.0, 3.0, L); ys = rng.randn(L)
-        elems.append(cp.chunk_element(us, vs, phis, a_s, ys))
-    # sequential start states
-    P, f = np.zeros((J, J)), np.zeros(J)
-    seq = []
-    for e in elems:
-        seq.append((P, f))
-        P, f = cp.advance(e, P, f)
-    # pairwise composition == two advances
-    P0 = np.cov(rng.randn(J, 40)) * 0.1; f0 = rng.randn(J)
-    Pa, fa = cp.advance(elems[4], *cp.advance(elems[3], P0, f0))
-    Pb, fb = cp.advance(cp.compose(elems[3], elems[4]), P0, f0)
-    assert np.allclose(Pa, Pb, rtol=1e-11, atol=1e-13) and np.allclose(fa, fb, rtol=1e-11, atol=1e-13)
-    for g in (2, 3, 4, 5):
-        two = cp.two_level_starts(elems, g)
-        assert len(two) == nchunk
-        for (Ps, fs), (Pt, ft) in zip(seq, two):
-            assert np.allclose(Ps, Pt, rtol=1e-10, atol=1e-12) and np.allclose(fs, ft, rtol=1e-10, atol=1e-12)
