@@ -501,7 +501,7 @@ def gradient_block(B, N, JR, JC, seed):
                          "ms_per_call": timing["forward"] * 1e3,
                          "reverse_vs_forward_rel_max": float(np.max(np.abs(g - g_forward) / np.max(np.abs(g_forward), axis=1, keepdims=True)))},
         "accuracy_family": {"ms_per_call": dt_acc * 1e3, "reverse_sweep": info_acc, "status_not_ok": int((sta != 0).sum()),
-                            "note": "sparse series: every state is stored (54 doubles per sample instead of ~10)"},
+                            "note": "sparse series: every step asks for a stored state; every 4th is stored, the others are rebuilt forwards by the sweep (GradStore::span; 21 doubles per sample instead of 54)"},
         "sequential_kernel_slice": {"problems": S, "ms_per_problem_incl_upload": dts * 1e3 / S,
                                     "value_rel_max": rel_err(v[:S], vs), "grad_rel_max": float(np.max(np.abs(g[:S] - gs) / scale)),
                                     "note": "one wave per (problem, partial), sequential in n (csrc/grad_kernels.hip); pinned "

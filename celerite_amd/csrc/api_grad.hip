@@ -186,11 +186,16 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
     // time a chunk spans, with a factor 2 for the wave-wide trigger (a chunk that runs out of slots fails its
     // certificate and is redone in forward mode)
     long nalloc;
+    P.g_span = 1;
     if (h->grad_K > 0) {
       P.g_K = (int)std::min<long>(h->grad_K, Lg);
       nalloc = (Lg + P.g_K - 1) / P.g_K;
     } else {
       P.g_K = 0;
+      // states the rule asks for fewer than g_span steps after a stored one are rebuilt forwards by the sweep
+      // (GradStore::span; profiles/r04t_grad_rebuild_span.txt); CLR_GRAD_REBUILD_SPAN: the tools' A/B knob
+      P.g_span = h->grad_rebuild_span;
+      if (const char* e = getenv("CLR_GRAD_REBUILD_SPAN")) P.g_span = std::max(1, std::min(atoi(e), 200));
       if ((st = grad_chunk_spans(h)) != CLR_OK) return st;
       double need = 0.0;
       for (size_t b = 0; b < B; ++b) {
@@ -199,6 +204,7 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       }
       nalloc = (need == need && need < (double)Lg) ? (long)(2.0 * std::ceil(need)) + 8 : Lg;
       nalloc = std::min<long>(nalloc, Lg);
+      if (P.g_span > 1) nalloc = std::min<long>(nalloc, Lg / P.g_span + 2);
     }
     P.g_nalloc = (int)nalloc;
     P.g_rec_stride = Lg * (long)(J + 2) * P.g_nchunk;

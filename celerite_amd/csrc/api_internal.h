@@ -222,6 +222,7 @@ struct clr_batch {
   clr::PrefixPlan plan;
   DevBuf lvl_elems, lvl_starts;       // composed elements / start states of the upper levels
   DevBuf g_riders, g_out, g_res;      // chunk-parallel gradient (clr_grad_kernels.h): riders, records, result (+ fallback)
+  int grad_rebuild_span = 4;          // reverse mode, adaptive rule: stored states at least this many steps apart (GradStore::span)
   DevBuf g_rec, g_ck;                 // reverse mode: w, D, x per sample; stored states (GradStore, clr_grad_core.h)
   unsigned char* g_ckflag = nullptr;  // what the forward pass did before each step, per wave of 64 chunks
   size_t g_ckflag_cap = 0;

@@ -91,6 +91,7 @@ struct BatchParams {
   long g_rec_stride, g_ck_stride;  // doubles per problem
   int g_K;                // stored states: every g_K steps (> 0), or where the accumulated decay asks for one (0: GradStore)
   int g_nalloc;           // slots per chunk in g_ck
+  int g_span;             // (adaptive rule) stored states at least this many steps apart, the rest rebuilt forwards (GradStore::span)
   unsigned char* g_ckflag;  // [B][waves of 64 chunks][steps]: what the forward pass did before each step (GradStore)
   double* g_count;        // [B][g_nchunk]: slots each chunk used
   int g_from_elems;       // reverse mode, g_m == 1: riders from the scan's elements (grad_riders_elem_kernel)

@@ -62,13 +62,21 @@ struct GradShape {
 //           budget 3 bounds the growth over any stretch the sweep rebuilds and uses by 4e2, and over the stretch plus
 //           the stored state's own move -- what the drift check at that state sees -- by 2e5.  Dense series store a
 //           handful of states per chunk, sparse ones one every few samples, a lone long gap exactly where it is.
+//   span > 1 (adaptive rule only; round 4): a state the rule asks for fewer than `span` steps after the last STORED one
+//           is not stored but marked flag[i] = 16 + m (m = steps since that stored state): the sweep rebuilds it FORWARDS
+//           from the stored state over the m recorded steps, S <- Phi (S + D w w^T) Phi, f <- Phi (f + w x) -- the
+//           forward recurrence itself (a contraction: stable whatever the gaps), from w, D, x of the record and the
+//           times.  A series that forgets between any two samples then stores every span-th state (44 / span instead
+//           of 44 doubles per sample through HBM, twice) for (span - 1) / 2 rebuilt steps per step on average.
 #define CLR_GRAD_GROWTH_BUDGET 3.0
+#define CLR_GRAD_FLAG_REBUILD 16
 struct GradStore {
   double* ck = nullptr;           // [slot][SZ + J], element k of a slot at ck[(slot (SZ + J) + k) rstride]
   unsigned char* flag = nullptr;  // [L]
   int K = 0;
   int nalloc = 0;                 // slots
   double* count = nullptr;        // (forward pass) out: slots this lane's chunk used; (sweep) in
+  int span = 1;                   // (adaptive rule) stored states at least this many steps apart; 1: every one the rule asks for
 };
 template <int JR, int JC>
 CLR_HD double grad_store_scale(const Problem<JR, JC>& p) {
@@ -364,7 +372,7 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
   }
   const double store_scale = grad_store_scale<JR, JC>(p);
   double store_acc = 0.0;
-  int store_used = 0;
+  int store_used = 0, store_last = -(1 << 20);  // (local step of the last stored state)
   src.prologue();
   double tn = src.t(0);
   double t_next = src.t(1);
@@ -388,8 +396,13 @@ CLR_HD void grad_riders_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, 
           const bool want = i > 0 && store_acc + sdt > 1.0;
           fire = CLR_WAVE_ANY(want);
         }
-        if (fire) {
+        if (fire && store.K == 0 && i - store_last < store.span) {
+          // rebuilt by the sweep from the stored state i - store_last steps back (wave-uniform, like `fire`)
+          if (store.flag && CLR_FIRST_ACTIVE_LANE()) store.flag[i] = (unsigned char)(CLR_GRAD_FLAG_REBUILD + (i - store_last));
+          store_acc = 0.0;
+        } else if (fire) {
           const bool room = store_used < store.nalloc;
+          store_last = i;
           if (room) {
             double* o = store.ck + (long)store_used * (SZ + J) * rstride;
             CLR_UNROLL
@@ -868,6 +881,31 @@ CLR_HD void grad_backward_chunk(const Problem<JR, JC>& p, Src& src, int L, int N
         double r = big > 0.0 ? dev / big : (dev == 0.0 ? 0.0 : INFINITY);
         if (bigf > 0.0) r = fmax(r, devf / bigf);
         if (!(r <= drift)) drift = r;
+      }
+    }
+    if (stored >= CLR_GRAD_FLAG_REBUILD) {
+      // the state before this step, forwards from the last stored state (GradStore: span): steps i - nb .. i - 1
+      const int nb = stored - CLR_GRAD_FLAG_REBUILD;
+      const double* o = store.ck + (long)(store_left - 1) * (SZ + J) * rstride;
+      CLR_UNROLL
+      for (int k = 0; k < SZ; ++k) S[k] = o[(long)k * rstride];
+      CLR_UNROLL
+      for (int k = 0; k < J; ++k) f[k] = o[(long)(SZ + k) * rstride];
+      double tp = src.t(i - nb);
+      for (int s = i - nb; s < i; ++s) {
+        const double tq = src.t(s + 1);
+        double ph[nz(M)], ww[J], zz[J];
+        features_phi_distinct<JR, JC>(p, tq - tp, ph);
+        tp = tq;
+        const double Ds = rec[((long)s * (J + 2) + J) * rstride], xs_ = rec[((long)s * (J + 2) + J + 1) * rstride];
+        CLR_UNROLL
+        for (int j = 0; j < J; ++j) {
+          ww[j] = rec[((long)s * (J + 2) + j) * rstride];
+          zz[j] = Ds * ww[j];
+        }
+        CLR_UNROLL
+        for (int k = 0; k < J; ++k) f[k] = ph[phi_index<JR>(k)] * fma(ww[k], xs_, f[k]);
+        decay_rank1_update<JR, JC>(ph, zz, ww, S);
       }
     }
     // adjoints of the step

@@ -44,6 +44,7 @@ __device__ __forceinline__ GradStore grad_store(const BatchParams& P, int b, int
     st.flag = P.g_ckflag + ((long)b * gridDim.x + blockIdx.x) * ((long)P.g_m * P.L);
     st.K = P.g_K;
     st.nalloc = P.g_nalloc;
+    st.span = P.g_span > 1 ? P.g_span : 1;
     st.count = P.g_count + (long)b * P.g_nchunk + c;
   }
   return st;

@@ -16,6 +16,9 @@ using namespace clr;
 // slots per chunk for the stored states of the reverse-mode runs (<= 0: as many as steps)
 static int g_slot_limit = 0;
 extern "C" void hostcheck_grad_set_slot_limit(int n) { g_slot_limit = n; }
+// stored states at least this many steps apart, the ones in between rebuilt forwards by the sweep (GradStore::span)
+static int g_span = 1;
+extern "C" void hostcheck_grad_set_span(int n) { g_span = n > 1 ? n : 1; }
 
 template <int JR, int JC>
 static int run_grad(int N, int nchunk, double jitter, const double* a_real, const double* c_real, const double* a_comp,
@@ -97,6 +100,7 @@ static int run_grad_reverse(int N, int nchunk, double jitter, const double* a_re
       st.K = K;
       st.nalloc = g_slot_limit > 0 ? std::min(g_slot_limit, nck) : nck;
       st.count = &counts[c];
+      st.span = g_span;
     }
     return st;
   };

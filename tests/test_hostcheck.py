@@ -392,6 +392,21 @@ def test_reverse_mode_gradient_against_the_dual_number_oracle(gradlib, JR, JC):
     # the adaptive rule stores a few states on a dense series and (almost) every one on a very sparse series
     assert fractions[0.02] <= fractions[0.5] < fractions[5.0] < fractions[50.0] <= 1.0, fractions
     assert fractions[0.02] < 0.02 and fractions[50.0] > 0.5, fractions
+    # stored states at least `span` steps apart, the ones in between rebuilt FORWARDS from the stored state (GradStore::span):
+    # same partials, same certificate, 1 / span of the states on a series that forgets between any two samples
+    for span_steps in (2, 3, 4, 7):
+        gradlib.hostcheck_grad_set_span(span_steps)
+        try:
+            for span, nchunk in ((0.02, 2), (0.5, 3), (5.0, 4), (50.0, 2), (50.0, 5)):
+                t = np.sort(rng.uniform(0, span * N, N))
+                v0, g0 = ograd.grad_log_likelihood(0.05, ar, cr, ac, bc, cc, dc, e, e2, e2, t, y, diag)
+                g, mismatch, drift, stored = run(t, nchunk, 0)
+                assert np.max(np.abs(g - g0)) <= 1e-10 * np.max(np.abs(g0)), (span_steps, span, nchunk)
+                assert mismatch <= 1e-12 and drift <= 1e-9, (span_steps, span, nchunk, mismatch, drift)
+                if span == 50.0:
+                    assert 0.5 / span_steps <= stored <= 1.0 / span_steps + 0.02, (span_steps, stored)
+        finally:
+            gradlib.hostcheck_grad_set_span(1)
     # fewer slots than the rule asks for: the sweep reports it (infinite drift = a failed certificate, the problem is
     # then redone in forward mode by the library)
     gradlib.hostcheck_grad_set_slot_limit(3)
