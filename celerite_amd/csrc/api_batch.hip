@@ -261,12 +261,20 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   HIP_TRY(hipStreamSynchronize(h->stream));  // (kernels of an earlier evaluation may still be reading the old series)
   const clr::CopyJob jobs[3] = {{h->t.p, t, count(t_stride)}, {h->diag.p, diag, count(diag_stride)}, {h->y.p, y, count(y_stride)}};
   const size_t total = (jobs[0].n + jobs[1].n + jobs[2].n) * sizeof(double);
+  bool staged = false;
   if (total >= ((size_t)32 << 20)) {
-    // large series: NT host threads stage pieces through pinned buffers, their DMAs share the link (clr_series_io.h)
-    int e = clr::staging_create(h->staging, h->device);
-    if (e == 0) e = clr::upload_parallel(h->staging, jobs, 3);
-    if (e != 0) return fail(CLR_HIP_ERROR, hipGetErrorString((hipError_t)e));
-  } else {
+    // large series: NT host threads stage pieces through pinned buffers, their DMAs share the link (clr_series_io.h);
+    // no pinned memory to be had (64 MB): the plain copies below
+    if (clr::staging_create(h->staging, h->device) == 0) {
+      const int e = clr::upload_parallel(h->staging, jobs, 3);
+      if (e != 0) return fail(CLR_HIP_ERROR, hipGetErrorString((hipError_t)e));
+      staged = true;
+    } else {
+      clr::staging_destroy(h->staging);
+      (void)hipGetLastError();
+    }
+  }
+  if (!staged) {
     for (const clr::CopyJob& j : jobs)
       if (j.n) HIP_TRY(hipMemcpyAsync(j.dst, j.src, j.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
