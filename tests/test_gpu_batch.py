@@ -1503,6 +1503,46 @@ def test_reverse_gradient_certifies_its_reconstructed_states():
         plan.close()
 
 
+def test_reverse_gradient_rebuilds_thinned_states_forwards():
+    """GradStore::span (round 4): on series that forget between any two samples the growth rule asks for a stored state
+    at every step; only every span-th one is stored and the sweep rebuilds the others FORWARDS from it over the recorded
+    steps.  Every span gives the forward-mode partials (and span 1 -- every state stored -- the round-3 behaviour), at
+    every width 1..8 shape class, with dense and sparse problems mixed in one wave."""
+    import os
+    for (JR, JC) in ((1, 0), (0, 1), (2, 1), (0, 3), (2, 3), (4, 2), (0, 4)):
+        B, N = 5, 5000
+        case = synthetic(B, N, JR, JC, "accuracy", seed=11 + JR + 3 * JC)
+        dense = synthetic(B, N, JR, JC, "bench", seed=12 + JR)
+        for k in ("t", "diag", "y"):
+            case[k][1] = dense[k][1]                       # one dense series among the sparse ones
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            plan.set_chunks(6)
+            plan.set_grad_mode("forward")
+            v0, g0, st0 = plan.grad_log_likelihood()
+            assert (st0 == 0).all()
+            scale = np.max(np.abs(g0), axis=1, keepdims=True)
+            plan.set_grad_mode("reverse")
+            for span in (None, 1, 2, 3, 7):
+                if span is None:
+                    os.environ.pop("CLR_GRAD_REBUILD_SPAN", None)
+                else:
+                    os.environ["CLR_GRAD_REBUILD_SPAN"] = str(span)
+                try:
+                    v, g, st = plan.grad_log_likelihood()
+                finally:
+                    os.environ.pop("CLR_GRAD_REBUILD_SPAN", None)
+                info = plan.grad_info()
+                assert (st == 0).all() and info["reverse"] and info["forward_reruns"] == 0, (JR, JC, span, info)
+                within("reverse gradient with thinned stored states vs forward mode", np.max(np.abs(g - g0) / scale), 1e-10)
+                within("reverse gradient with thinned stored states: value", np.max(np.abs(v - v0) / np.abs(v0)), 1e-12)
+                within("reverse gradient with thinned stored states: reported drift", info["drift_max"], 1e-9)
+        finally:
+            plan.close()
+
+
 def test_plan_gradient_full_size_directional_derivative():
     """The headline shape's series length (N = 1e5, width 8, 17 partials), where no oracle gradient is affordable:
     the gradient must predict the change of the plan's OWN log-likelihood (pinned to the oracle elsewhere) along a
