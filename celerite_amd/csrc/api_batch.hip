@@ -54,7 +54,7 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->pin) (void)hipHostFree(h->pin);
   clr::staging_destroy(h->staging);
   h->scan.release();
-  for (DevBuf* b : {&h->gen_elems, &h->gen_starts, &h->gen_part, &h->gen_cond}) b->release();
+  for (DevBuf* b : {&h->gen_elems, &h->gen_starts, &h->gen_part, &h->gen_cond, &h->gen_scan}) b->release();
   if (h->gen_flags) (void)hipFree(h->gen_flags);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -86,6 +86,10 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
       if (nchunk < 2) nchunk = 1;
       if (nchunk > 16) nchunk = 16;
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+      // few problems: the prefix is a parallel scan (wide_prefix_scan.hip) as long as B x nchunk <= 512 -- chunks of
+      // >= 256 samples instead of 16 long ones (one series of 1e5 samples: 390 chunks)
+      const int cap = clr::wide_prefix_scan_cap(h->J <= 16 ? 16 : 32);
+      if (h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / 256) > nchunk) nchunk = std::min(cap / h->B, h->N / 256);
     }
     if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
   } else if (nchunk <= 0) {
@@ -112,6 +116,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   h->have_factor = false;  // its layout depends on the chunking
   const size_t pc = (size_t)h->B * h->nchunk;
   h->plan = clr::plan_prefix(h->nchunk, 0, 0);
+  h->scan_ws_doubles = 0;
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
@@ -124,6 +129,9 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
     const size_t JP = h->J <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
     if ((st = h->elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
+    // few problems with many chunks: the prefix as a parallel scan (wide_prefix_scan.hip); its level buffers
+    h->scan_ws_doubles = clr::wide_prefix_scan_workspace(h->B, h->nchunk, (int)JP);
+    if (h->scan_ws_doubles && (st = h->lvl_elems.reserve(h->scan_ws_doubles)) != CLR_OK) return st;
   }
   if ((st = h->part.reserve(pc * 2)) != CLR_OK) return st;
   if ((st = h->partx.reserve(pc * 2)) != CLR_OK) return st;
@@ -687,6 +695,9 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
     if (nchunk > 16) nchunk = 16;
     while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    const int cap = clr::wide_prefix_scan_cap(Wt <= 16 ? 16 : 32);
+    if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / 256) > nchunk)
+      nchunk = std::min(cap / h->B, h->N / 256);  // (few problems: the parallel prefix, clr_batch_set_chunks)
     if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)
       nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
     if (nchunk < 1) nchunk = 1;
@@ -704,6 +715,10 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     if (nchunk > 1) {
       if ((st = h->gen_elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
       if ((st = h->gen_starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
+      h->gen_scan_ws_doubles = clr::wide_prefix_scan_workspace(h->B, nchunk, (int)JP);
+      if (h->gen_scan_ws_doubles && (st = h->gen_scan.reserve(h->gen_scan_ws_doubles)) != CLR_OK) return st;
+    } else {
+      h->gen_scan_ws_doubles = 0;
     }
     if ((st = h->gen_part.reserve(pc * 4)) != CLR_OK) return st;
     if ((st = h->gen_cond.reserve(pc * 4)) != CLR_OK) return st;

@@ -167,7 +167,7 @@ struct clr_solver {
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
-  DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix
+  DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix; level buffers of the wide parallel prefix
   DevBuf gradbuf;                       // grad_log_likelihood staging
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   // clr_solver_hint_rhs: the right-hand side the caller is about to pass to dot_solve; the next compute
@@ -196,7 +196,8 @@ struct clr_batch {
   int small_mode = -1;             // one-launch evaluation of short narrow problems: -1 auto, 0 off, 1 whenever supported
   // general terms through the wide kernels (widths J + J_general <= 64): their own chunking and workspace
   int gen_nchunk = 0, gen_L = 0, gen_L0 = 0;
-  DevBuf gen_elems, gen_starts, gen_part, gen_cond;
+  DevBuf gen_elems, gen_starts, gen_part, gen_cond, gen_scan;
+  size_t gen_scan_ws_doubles = 0, scan_ws_doubles = 0;  // workspace of the wide parallel prefix (0: sequential walk)
   int* gen_flags = nullptr;
   bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
   double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk (1.1-1.25 within 2 %: profiles/r04c, r04p)
@@ -342,6 +343,7 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.coop_prefix = h->coop_prefix;
   P.plan = h->plan;
   P.lvl_elems = h->lvl_elems.p;
+  P.scan_ws = (!h->launch && h->scan_ws_doubles) ? h->lvl_elems.p : nullptr;
   P.lvl_starts = h->lvl_starts.p;
   P.jitter = h->coeffs.p + 2 * nr + 4 * nc;
   P.a_real = h->coeffs.p;
@@ -478,11 +480,12 @@ void general_wide_params(const clr_batch* h, const clr::BatchParams& P, clr::Bat
   W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
   W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
   W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;
-  W.coop_prefix = 1;
+  W.coop_prefix = h->coop_prefix == 2 ? 2 : 1;  // (2: the parallel prefix where its workspace exists, else the walk)
   W.J_general = h->J_general;
   W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;
   W.gen_A_stride = h->gA_stride; W.gen_U_stride = h->gU_stride; W.gen_V_stride = h->gV_stride;
   W.elems = h->gen_elems.p; W.starts = h->gen_starts.p;
+  W.scan_ws = h->gen_scan_ws_doubles ? h->gen_scan.p : nullptr;
   W.part = h->gen_part.p; W.partx = h->gen_part.p + pc * 2;
   W.cond = h->gen_cond.p; W.egerr = h->gen_cond.p + pc * 3;
   W.flags = h->gen_flags; W.flagsx = h->gen_flags + pc; W.need_exact = h->gen_flags + 2 * pc;

@@ -340,6 +340,13 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       // sample, p = 15 us per chunk up to width 16; a = 2.0 us, p = 97 us (three 32^3 products on the matrix
       // cores + a Gauss-Jordan) above.
       nchunk = (int)lround(sqrt((double)N * (J <= 16 ? 0.096 : 0.0208)));
+      // round 4: the prefix is a parallel scan (wide_prefix_scan.hip: ceil(log2 nchunk) launches of 25 / 50 us instead
+      // of nchunk steps of 14 / 50 us), so the chunks only have to stay long enough to amortise their own set-up:
+      // 256 samples, at most 1024 / 512 chunks (profiles/r04v_single_wide_chunks.txt: N = 1e5 width 16 3.0 -> 1.0 ms,
+      // width 32 6.9 -> 1.9 ms)
+      const int cap = clr::wide_prefix_scan_cap(J <= 16 ? 16 : 32);
+      if (std::min(N / 256, cap) >= 8 && !getenv("CLR_WIDE_PREFIX_WALK")) nchunk = std::min(N / 256, cap);
+      if (const char* e = getenv("CLR_SOLVER_WIDE_CHUNKS")) nchunk = atoi(e);  // (tools/gpu_single_wide_chunks.py)
       if (nchunk > N / 256) nchunk = N / 256;
       if (nchunk < 2 || N < 2048) nchunk = 1;  // (short series: the six launches of the chunked flow cost more)
     }
@@ -348,6 +355,9 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     const size_t pc = (size_t)P.nchunk, JP = J <= 16 ? 16 : 32, SZP = JP * (JP + 1) / 2;
     if ((st = s->ws_elems.reserve(pc * (JP * JP + JP + SZP + JP + SZP))) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve(pc * (SZP + JP))) != CLR_OK) return st;
+    const size_t scan_ws = getenv("CLR_WIDE_PREFIX_WALK") ? 0 : clr::wide_prefix_scan_workspace(1, P.nchunk, (int)JP);  // the prefix as a parallel scan
+    if (scan_ws && (st = s->ws_lvl_elems.reserve(scan_ws)) != CLR_OK) return st;
+    P.scan_ws = scan_ws ? s->ws_lvl_elems.p : nullptr;
     if ((st = s->ws_part.reserve(pc * 4)) != CLR_OK) return st;
     if ((st = s->ws_cond.reserve(pc * 4)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, 2 * pc + 1)) != CLR_OK) return st;
@@ -364,7 +374,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
     P.force_exact = 1;       // the factor is wanted: every chunk is replayed (and checked against the scan)
     P.wide_materialize = 1;
-    P.coop_prefix = 1;
+    P.coop_prefix = P.scan_ws ? 2 : 1;  // (2: the parallel prefix, wide_prefix_scan.hip)
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;

@@ -47,6 +47,7 @@ struct BatchParams {
   int fast_trig;  // host-verified: max|d_comp| * max|t| < CLR_FAST_TRIG_LIMIT
   int split;      // summarize as two roles on two waves per SIMD (widths 7, 8; clr_split_kernels.h);
                   // needs the chunk-interleaved series (staged == 0, lane_cs == 1)
+  double* scan_ws;  // wide layout: workspace of the parallel prefix (wide_prefix_scan.hip), null = the sequential walk
   int coop_prefix;  // prefix phase: 0 one lane per problem (the reference version), 1 16 lanes per problem walking
                     // the chunks in order, 2 multi-level (clr_prefix_kernels.h) following `plan`
   PrefixPlan plan;        // levels of the multi-level prefix (plan.levels == 0: the plain walk)
@@ -981,6 +982,10 @@ void launch_relayout_warm(const double* src, long src_stride, double* dst, long 
 const BatchLaunchers* find_batch_launchers(int JR, int JC);
 // prefix phase at the padded widths of the wide scan (16: 2 problems per wave, 32: one)
 void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s);
+// the wide prefix as a Kogge-Stone scan over composed elements (wide_prefix_scan.hip): few problems with many chunks
+size_t wide_prefix_scan_workspace(int B, int nchunk, int width_padded);  // doubles; 0 = keep the sequential walk
+int wide_prefix_scan_cap(int width_padded);                                // largest B x nchunk the scan is used for
+void launch_wide_prefix_scan(const BatchParams& P, int width_padded, hipStream_t s);
 int wide_scan_max_width();
 // fp32-state sequential sweep (a measurement for BASELINE config 5, wide_kernels.hip)
 int wide_f32_probe_max_width();

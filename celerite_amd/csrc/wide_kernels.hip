@@ -1181,6 +1181,7 @@ __global__ void __launch_bounds__(256) wide_prefix32_kernel(const BatchParams P_
 
 void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s) {
   if (P.nchunk < 2) return;
+  if (P.scan_ws && P.coop_prefix == 2) { launch_wide_prefix_scan(P, width_padded, s); return; }  // (mode 1: the walk)
   if (width_padded <= 16)
     hipLaunchKernelGGL((prefix_coop_kernel<16, 16>), dim3((P.B + 1) / 2), dim3(64), 0, s, P);
   else if (P.coop_prefix)
