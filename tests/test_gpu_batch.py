@@ -645,6 +645,43 @@ def test_wide_scan_over_chunks(JR, JC):
             assert np.max(np.abs(q[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])) <= 1e-11
 
 
+@pytest.mark.parametrize("JR,JC", [(2, 5), (0, 8), (5, 10), (0, 16)])
+def test_wide_prefix_as_a_parallel_scan(JR, JC):
+    """Few problems with many chunks (csrc/wide_prefix_scan.hip): the prefix of the wide scan is a Kogge-Stone scan over
+    composed chunk elements instead of a walk.  Both forms must give the same results at every chunk count (powers of
+    two and their neighbours, a ragged last chunk, the riderless longer first chunk), equal the oracle, keep the routes
+    (an indefinite problem included) -- and the automatic chunking of a small wide plan must choose many short chunks."""
+    B, N = 3, 9000
+    case = synthetic(B, N, JR, JC, "bench", seed=2 + JR + JC)
+    case["a_real"] = np.array(case["a_real"], copy=True)
+    case["diag"] = np.array(case["diag"], copy=True)
+    if JR:
+        case["a_real"][1, :] = -7.0       # an indefinite problem in the middle
+        case["diag"][1] = 0.0
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    ok = s0 == 0
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        assert plan.chunks[0] >= 32, plan.chunks      # automatic: N / 256 chunks, not 16 long ones
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        for nchunk in (0, 8, 9, 16, 17, 31, 33, 64, 100, 140):
+            plan.set_chunks(nchunk)
+            out = {}
+            for mode in ("walk", "multilevel"):
+                plan.set_prefix_mode(mode)
+                plan.set_coefficients(*coeffs_of(case))
+                out[mode] = plan.log_likelihood()
+                ll, ld, q, st = out[mode]
+                assert np.array_equal(st, s0), (nchunk, mode, st, s0)
+                within("wide plan, prefix as walk / parallel scan: log det vs oracle", np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), REL)
+                within("wide plan, prefix as walk / parallel scan: quadratic form vs oracle", np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])), REL)
+            within("wide plan: parallel scan vs walk, log det", np.max(np.abs(out["walk"][1][ok] - out["multilevel"][1][ok]) / np.abs(d0[ok])), 1e-12)
+            within("wide plan: parallel scan vs walk, quadratic form", np.max(np.abs(out["walk"][2][ok] - out["multilevel"][2][ok]) / np.abs(q0[ok])), 1e-12)
+    finally:
+        plan.close()
+
+
 def test_wide_scan_settles_well_conditioned_problems_without_replay():
     case = synthetic(4, 6000, 0, 16, "bench", seed=9)
     plan = batch.BatchedGP(4, 6000, 0, 16)
