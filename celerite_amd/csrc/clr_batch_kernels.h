@@ -526,10 +526,10 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   for (int i = 0; i < J; ++i) f[i] = st[SZ + i];
   double dld = 0.0, dq = 0.0;
   int sus = 0;
-  double mu = 1.0, eg = 0.0;
+  double mu = 1.0, eg = 0.0, err[2] = {0.0, 0.0};
   chunk_update<J>(P.elems + slot * ELEM, S, f, true, false, P.part[slot * 2 + 0], P.part[slot * 2 + 1],
-                  &dld, &dq, &sus, &mu, !P.logdet_only, P.egerr ? &eg : nullptr);
-  if (P.cond) P.cond[slot * 3 + 1] = mu;
+                  &dld, &dq, &sus, &mu, !P.logdet_only, P.egerr ? &eg : nullptr, P.cond ? err : nullptr);
+  if (P.cond) { P.cond[slot * 3 + 1] = mu; P.cond[slot * 3 + 2] = err[1]; }  // (slot 2: until decide_kernel has read it)
   if (P.egerr) P.egerr[slot] = eg;
   P.part[slot * 2 + 0] += dld;
   P.part[slot * 2 + 1] += dq;
@@ -627,26 +627,43 @@ __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
   // one wave per problem: max / min over the chunks' records are order-independent
   const int b = blockIdx.x, lane = threadIdx.x;
   if (P.only_pending && P.need_scan[b] == 0) return;
-  if (!P.cond || !(P.cert_gamma > 0.0) || P.need_exact[b] != 0) return;
+  if (!P.cond) return;
   // NaN records stick (and then fail the comparison below: ill-conditioned)
   auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
   auto nmin = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x < a ? x : a)); };
   double g = 0.0, m = 1.0, e = 0.0;
+  // the corrections' rounding-error estimates (chunk_update: J eps / mu, times |w.G w| for the quadratic form) summed
+  // over the chunks, against the problem's own log det and quadratic form
+  double err_ld = 0.0, err_q = 0.0, sum_ld = 0.0, sum_q = 0.0;
   for (int c = lane; c < P.nchunk; c += 64) {
-    g = nmax(g, P.cond[((long)b * P.nchunk + c) * 3]);
-    m = nmin(m, P.cond[((long)b * P.nchunk + c) * 3 + 1]);
-    if (P.egerr) e = nmax(e, P.egerr[(long)b * P.nchunk + c]);
+    const long slot = (long)b * P.nchunk + c;
+    g = nmax(g, P.cond[slot * 3]);
+    const double mu = P.cond[slot * 3 + 1];
+    m = nmin(m, mu);
+    if (P.egerr) e = nmax(e, P.egerr[slot]);
+    if (c > 0) err_ld += J * 2.2e-16 / mu;
+    err_q += P.cond[slot * 3 + 2];
+    P.cond[slot * 3 + 2] = 0.0;  // (from here on: the replay's end-state residual)
+    sum_ld += P.part[slot * 2 + 0];
+    sum_q += P.part[slot * 2 + 1];
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     g = nmax(g, __shfl_xor(g, off, 64));
     m = nmin(m, __shfl_xor(m, off, 64));
     e = nmax(e, __shfl_xor(e, off, 64));
+    err_ld += __shfl_xor(err_ld, off, 64);
+    err_q += __shfl_xor(err_q, off, 64);
+    sum_ld += __shfl_xor(sum_ld, off, 64);
+    sum_q += __shfl_xor(sum_q, off, 64);
   }
+  if (lane != 0 || P.need_exact[b] != 0) return;
+  bool replay = !(err_ld <= 3e-12 * fabs(sum_ld)) || (!P.logdet_only && !(err_q <= 3e-12 * fabs(sum_q)));
   // (NaN records count as ill-conditioned)
-  if (lane == 0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
-                    (P.cert_eg > 0.0 && P.egerr && !(g * e < P.cert_eg))))
-    P.need_exact[b] = 1;
+  if (P.cert_gamma > 0.0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
+                             (P.cert_eg > 0.0 && P.egerr && !(g * e < P.cert_eg))))
+    replay = true;
+  if (replay) P.need_exact[b] = 1;
 }
 
 // ---------------------------------------------------------------------------

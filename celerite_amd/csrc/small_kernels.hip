@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(256) small_compute_kernel(const SmallParams P)
 template <int JR, int JC, bool FAST>
 __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, int L) {
   using Wd = Widths<JR, JC>;
-  constexpr int J = Wd::J, SZ = Wd::SZ, ELEM = Wd::ELEM, START = Wd::START;
-  extern __shared__ double lds[];  // [ELEM][T]
+  constexpr int J = Wd::J, SZ = Wd::SZ, ELEM = Wd::ELEM;
+  extern __shared__ double lds[];  // [max(ELEM, 8)][T]
   const int T = blockDim.x, c = threadIdx.x, b = blockIdx.x;
   const int N = P.N;
   const int nreal = (N + L - 1) / L;
@@ -191,9 +191,9 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
   __syncthreads();
   // 3. the chunk's true contributions from its zero-start sums and its start state (chunk_update, clr_core.h:
   //    determinant lemma + Woodbury + the positivity certificate), as correct_kernel does -- no second pass
-  double dld = 0.0, dq = 0.0, mu = 1.0, eg = 0.0;
+  double dld = 0.0, dq = 0.0, mu = 1.0, eg = 0.0, err[2] = {0.0, 0.0};
   int sus = 0;
-  if (c >= 1 && c < nreal) chunk_update<J>(own, S, f, true, false, ld0, q0, &dld, &dq, &sus, &mu, true, &eg);
+  if (c >= 1 && c < nreal) chunk_update<J>(own, S, f, true, false, ld0, q0, &dld, &dq, &sus, &mu, true, &eg, err);
   const double ld = ld0 + dld, qd = q0 + dq;
   int bad = 0;
   if (c < nreal && (flag0 || sus || !isfinite(ld) || !isfinite(qd))) bad = 1;
@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
   lds[3 * T + c] = real ? gamma : 0.0;
   lds[4 * T + c] = real ? mu : 1.0;
   lds[5 * T + c] = real ? eg : 0.0;
+  lds[6 * T + c] = real ? err[0] : 0.0;  // the corrections' rounding-error estimates, summed over the problem (decide_kernel)
+  lds[7 * T + c] = real ? err[1] : 0.0;
   __syncthreads();
   for (int s = T / 2; s >= 1; s >>= 1) {
     if (c < s) {
@@ -216,12 +218,15 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
       lds[3 * T + c] = nmax(lds[3 * T + c], lds[3 * T + c + s]);
       lds[4 * T + c] = nmin(lds[4 * T + c], lds[4 * T + c + s]);
       lds[5 * T + c] = nmax(lds[5 * T + c], lds[5 * T + c + s]);
+      lds[6 * T + c] += lds[6 * T + c + s];
+      lds[7 * T + c] += lds[7 * T + c + s];
     }
     __syncthreads();
   }
   if (c == 0) {
     const double g = lds[3 * T], m = lds[4 * T], er = lds[5 * T];
     bool pending = lds[2 * T] > 0.0;
+    if (!(lds[6 * T] <= 3e-12 * fabs(lds[0])) || !(lds[7 * T] <= 3e-12 * fabs(lds[T]))) pending = true;
     if (P.cert_gamma > 0.0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
                                (P.cert_eg > 0.0 && !(g * er < P.cert_eg))))
       pending = true;  // ill-conditioned: the scan pipeline routes it (checked replay / sequential recurrence)
@@ -243,7 +248,7 @@ template <int JR, int JC>
 bool go_batch(const BatchParams& P, int threads, hipStream_t s) {
   constexpr int ELEM = Widths<JR, JC>::ELEM;
   const int L = (P.N + threads - 1) / threads;
-  const size_t lds = (size_t)(ELEM > 6 ? ELEM : 6) * threads * sizeof(double);
+  const size_t lds = (size_t)(ELEM > 8 ? ELEM : 8) * threads * sizeof(double);
   if (P.fast_trig) hipLaunchKernelGGL((small_batch_kernel<JR, JC, true>), dim3(P.B), dim3(threads), lds, s, P, L);
   else hipLaunchKernelGGL((small_batch_kernel<JR, JC, false>), dim3(P.B), dim3(threads), lds, s, P, L);
   return true;

@@ -779,12 +779,12 @@ __global__ void __launch_bounds__(256) wide_correct_kernel(const BatchParams P) 
     const double q = 2.0 * ef - fJf + wGw;
     const double ld = log(det);
     const double err = J * 2.2e-16 / mu;  // rounding-error estimate of the corrections
-    if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
-    if (!P.logdet_only && !(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;
+    // (err is summed over the problem's chunks and held against the problem's log det / quadratic form by decide_kernel:
+    //  chunk_update's err_out, clr_core.h)
     if ((!P.logdet_only && !isfinite(q)) || !isfinite(ld)) bad = 1;
     P.part[slot * 2 + 0] = ld0 + ld;
     P.part[slot * 2 + 1] = q0 + q;
-    if (P.cond) P.cond[slot * 3 + 1] = mu;
+    if (P.cond) { P.cond[slot * 3 + 1] = mu; P.cond[slot * 3 + 2] = P.logdet_only ? 0.0 : err * fabs(wGw); }
     if (P.egerr) P.egerr[slot] = eg;
     if (bad) {
       P.flags[slot] |= 2;

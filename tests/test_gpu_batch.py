@@ -682,6 +682,42 @@ def test_wide_prefix_as_a_parallel_scan(JR, JC):
         plan.close()
 
 
+@pytest.mark.parametrize("JR,JC", [(4, 11), (2, 7), (2, 3), (0, 2)])
+def test_short_chunks_whose_log_det_sums_to_zero_stay_on_the_fast_route(JR, JC):
+    """The corrections' rounding-error estimate (J eps / mu) is held against the PROBLEM's log det and quadratic form
+    (decide_kernel), not against the chunk's own contribution: on data with pivots around one (unit-variance series,
+    unit amplitudes -- the common case) a chunk's log det sums to nearly zero every few hundred chunks, and rounds 1..3
+    sent such a problem to the sequential recurrence (one series of 1e5 samples at width 26: 84 instead of 1.9 ms,
+    profiles/r04w_chunk_error_budget.txt).  Every chunking of a benign series must be settled from the chunk summaries."""
+    N = 30000
+    rng = np.random.RandomState(JR * 100 + JC)
+    t = np.sort(rng.uniform(0, 0.05 * N, N))
+    yerr = rng.uniform(0.3, 0.5, N)
+    y = rng.randn(N)
+    co = [c[None, :] for c in (np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+                               np.zeros(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)))]
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *co, t[None], (yerr ** 2)[None], y[None])
+    assert s0[0] == 0
+    plan = batch.BatchedGP(1, N, JR, JC)
+    try:
+        plan.set_series(t[None], (yerr ** 2)[None], y[None])
+        seen, routes = set(), []
+        for nchunk in range(40, 118, 2):
+            plan.set_chunks(nchunk)
+            if plan.chunks in seen:
+                continue
+            seen.add(plan.chunks)
+            plan.set_coefficients(*co)
+            ll, ld, q, st = plan.log_likelihood()
+            assert st[0] == 0
+            routes.append(int(plan.exact_levels()[0]))
+            within("short chunks: log det vs oracle", abs(ld[0] - d0[0]) / abs(d0[0]), REL)
+            within("short chunks: quadratic form vs oracle", abs(q[0] - q0[0]) / abs(q0[0]), REL)
+        assert len(routes) >= 15 and max(routes) == 0, routes
+    finally:
+        plan.close()
+
+
 def test_wide_scan_settles_well_conditioned_problems_without_replay():
     case = synthetic(4, 6000, 0, 16, "bench", seed=9)
     plan = batch.BatchedGP(4, 6000, 0, 16)
