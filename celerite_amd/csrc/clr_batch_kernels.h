@@ -526,10 +526,10 @@ __global__ void __launch_bounds__(64) correct_kernel(const BatchParams P) {
   for (int i = 0; i < J; ++i) f[i] = st[SZ + i];
   double dld = 0.0, dq = 0.0;
   int sus = 0;
-  double mu = 1.0, eg = 0.0, err[2] = {0.0, 0.0};
+  double mu = 1.0, eg = 0.0, errq = 0.0;
   chunk_update<J>(P.elems + slot * ELEM, S, f, true, false, P.part[slot * 2 + 0], P.part[slot * 2 + 1],
-                  &dld, &dq, &sus, &mu, !P.logdet_only, P.egerr ? &eg : nullptr, P.cond ? err : nullptr);
-  if (P.cond) { P.cond[slot * 3 + 1] = mu; P.cond[slot * 3 + 2] = err[1]; }  // (slot 2: until decide_kernel has read it)
+                  &dld, &dq, &sus, &mu, !P.logdet_only, P.egerr ? &eg : nullptr, &errq);
+  if (P.cond) { P.cond[slot * 3 + 1] = mu; P.cond[slot * 3 + 2] = errq; }  // (slot 2: until decide_kernel has read it)
   if (P.egerr) P.egerr[slot] = eg;
   P.part[slot * 2 + 0] += dld;
   P.part[slot * 2 + 1] += dq;
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
     double r = 0.0;
     for (int c = 0; c < P.nchunk; ++c) {
       const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
-      if (!(rc <= r)) r = rc;
+      r = (rc != rc) ? INFINITY : fmax(r, rc);  // (a NaN residual counts as inconsistent -- and stays so)
     }
     if (!(r <= P.cert_resid)) level = 2;
   }

@@ -509,8 +509,8 @@ CLR_HD void summarize_chunk(const Problem<JR, JC>& p, Src& src, int L, int n0, i
 // > 1e-5.  The smallest pivot mu also estimates the conditioning of M: the chunk is
 // marked SUSPICIOUS -- and the caller runs the exact replay for that problem -- when
 // the certificate fails, when det M <= 0 or when anything is non-finite.  The rounding-error
-// estimate of the corrections, J eps / mu (times |w.G w| for the quadratic form), is handed to the
-// caller (err_out), which sums it over the problem's chunks and holds it against 3e-12 of the
+// estimate of the corrections, J eps / mu (times |w.G w| for the quadratic form: err_out), goes to
+// the caller, which sums it over the problem's chunks and holds it against 3e-12 of the
 // problem's log det / quadratic form (decide_kernel; round 4 -- rounds 1..3 held it against the
 // CHUNK's own contribution, which with hundreds of short chunks per problem is near zero for one
 // of them more often than not: profiles/r04w_chunk_error_budget.txt); without err_out the old
@@ -735,8 +735,7 @@ CLR_HD void chunk_update(const double* elem, double* P /*[SZ]*/, double* f /*[J]
     if (err_out) {
       // the caller holds the estimates against the PROBLEM's log det and quadratic form (decide_kernel): a chunk's own
       // contribution can be anywhere near zero -- with hundreds of short chunks per problem one of them usually is
-      err_out[0] = err;
-      err_out[1] = check_quad ? err * fabs(wGw) : 0.0;
+      *err_out = check_quad ? err * fabs(wGw) : 0.0;  // (the log det's share is J eps / mu: the caller has mu)
     } else {
       if (!(err <= 3e-12 * fabs(ld0 + ld))) bad = 1;
       if (check_quad && !(err * fabs(wGw) <= 3e-12 * fabs(q0 + q))) bad = 1;

@@ -191,9 +191,9 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
   __syncthreads();
   // 3. the chunk's true contributions from its zero-start sums and its start state (chunk_update, clr_core.h:
   //    determinant lemma + Woodbury + the positivity certificate), as correct_kernel does -- no second pass
-  double dld = 0.0, dq = 0.0, mu = 1.0, eg = 0.0, err[2] = {0.0, 0.0};
+  double dld = 0.0, dq = 0.0, mu = 1.0, eg = 0.0, errq = 0.0;
   int sus = 0;
-  if (c >= 1 && c < nreal) chunk_update<J>(own, S, f, true, false, ld0, q0, &dld, &dq, &sus, &mu, true, &eg, err);
+  if (c >= 1 && c < nreal) chunk_update<J>(own, S, f, true, false, ld0, q0, &dld, &dq, &sus, &mu, true, &eg, &errq);
   const double ld = ld0 + dld, qd = q0 + dq;
   int bad = 0;
   if (c < nreal && (flag0 || sus || !isfinite(ld) || !isfinite(qd))) bad = 1;
@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
   lds[3 * T + c] = real ? gamma : 0.0;
   lds[4 * T + c] = real ? mu : 1.0;
   lds[5 * T + c] = real ? eg : 0.0;
-  lds[6 * T + c] = real ? err[0] : 0.0;  // the corrections' rounding-error estimates, summed over the problem (decide_kernel)
-  lds[7 * T + c] = real ? err[1] : 0.0;
+  lds[6 * T + c] = (real && c >= 1) ? J * 2.2e-16 / mu : 0.0;  // the corrections' rounding-error estimates, summed over the problem (decide_kernel)
+  lds[7 * T + c] = real ? errq : 0.0;
   __syncthreads();
   for (int s = T / 2; s >= 1; s >>= 1) {
     if (c < s) {

@@ -1206,19 +1206,23 @@ void launch_wide_decide(const BatchParams& P, hipStream_t s) {
 // after the chunked replay: a replayed problem whose chunks did not meet the scanned start states
 // goes to the sequential sweep (level 2)
 __global__ void __launch_bounds__(64) wide_check_replay_kernel(const BatchParams P) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.B || !P.cond) return;
+  // one wave per problem, lanes striding over its chunks (round 4: hundreds of chunks per problem -- a lone thread's
+  // dependent loads took 43 us for 390)
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!P.cond) return;
   const int level = P.need_exact[b];
   if (level >= 2 || !(level == 1 || P.force_exact)) return;
   double r = 0.0;
-  for (int c = 0; c < P.nchunk; ++c) {
+  for (int c = lane; c < P.nchunk; c += 64) {
     const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
-    if (!(rc <= r)) r = rc;
+    r = (rc != rc) ? INFINITY : fmax(r, rc);  // (a NaN residual counts as inconsistent)
   }
-  if (!(r <= P.cert_resid)) P.need_exact[b] = 2;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
+  if (lane == 0 && !(r <= P.cert_resid)) P.need_exact[b] = 2;
 }
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(wide_check_replay_kernel, dim3((P.B + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(wide_check_replay_kernel, dim3(P.B), dim3(64), 0, s, P);
 }
 
 // one chunk: the whole recurrence, results written directly; several chunks: the replay phase

@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(256) wide_scan_level_kernel(const ScanLevel K)
   }
   __syncthreads();
 
+  // Gauss-Jordan with partial pivoting: wave w owns rows RW w .. RW w + RW - 1 of the tableau, lane = column (stride 64)
+  constexpr int RW = J / 4;
+  const int wave = tid >> 6;
   for (int col = 0; col < J; ++col) {
     double best = (lane < J && lane >= col) ? fabs(T[lane * LT + col]) : -1.0;
     int piv = lane;
@@ -108,24 +111,28 @@ __global__ void __launch_bounds__(256) wide_scan_level_kernel(const ScanLevel K)
       piv = take ? op : piv;
     }
     __syncthreads();  // (every wave has finished its search of column `col`)
-    if (piv != col) {
-      for (int cc = tid; cc < NC; cc += NT) {
-        const double a = T[col * LT + cc], bb = T[piv * LT + cc];
-        T[col * LT + cc] = bb;
-        T[piv * LT + cc] = a;
-      }
+    // row swap + scaling of the pivot row: thread = column (the pivot itself, column `col`, stays unscaled: it is never
+    // read again)
+    const double inv = 1.0 / T[piv * LT + col];
+    __syncthreads();  // (everybody has read the pivot)
+    if (tid < NC) {
+      const double top = T[piv * LT + tid], old = T[col * LT + tid];
+      if (piv != col) T[piv * LT + tid] = old;
+      T[col * LT + tid] = tid > col ? top * inv : top;
     }
     __syncthreads();
-    const double inv = 1.0 / T[col * LT + col];
-    __syncthreads();
-    for (int cc = tid; cc < NC; cc += NT)
-      if (cc > col) T[col * LT + cc] *= inv;
-    __syncthreads();
-    // rows other than `col`: thread = (row, column stripe); the multiplier is read before the barrier-free update
-    // of the same row's later columns (column `col` itself is never written again)
-    for (int i = tid; i < J * NC; i += NT) {
-      const int r = i / NC, cc = i % NC;
-      if (r != col && cc > col) T[r * LT + cc] = fma(-T[r * LT + col], T[col * LT + cc], T[r * LT + cc]);
+    double m[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) m[r] = T[(RW * wave + r) * LT + col];
+    for (int cc = lane; cc < NC; cc += 64) {
+      if (cc > col) {
+        const double t = T[col * LT + cc];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int row = RW * wave + r;
+          if (row != col) T[row * LT + cc] = fma(-m[r], t, T[row * LT + cc]);
+        }
+      }
     }
     __syncthreads();
   }

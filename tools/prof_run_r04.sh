@@ -57,6 +57,9 @@ for w in $WHAT; do
     widegrad)
       trace widegrad python tools/gpu_wide_grad_profile.py
       ;;
+    singlewide)
+      trace singlewide python tools/gpu_single_wide_profile.py
+      ;;
     general)
       trace general python tools/gpu_general_profile.py
       ;;
