@@ -623,9 +623,10 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
 // the one outlier of the calibration set that both gamma tests let through (a 6-chunk N = 50 problem, 1.9e-9):
 // with all three, 2166 of 3488 settled from the summaries, worst 1.05e-11 (round 2: 2109, worst 1.9e-9).
 template <int J>
-__global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
-  // one wave per problem: max / min over the chunks' records are order-independent
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) decide_kernel(const BatchParams P) {
+  // one workgroup per problem (64 threads, or 256 for the thousands of chunks of one long series): max / min over the
+  // chunks' records are order-independent, the sums only feed a threshold
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
   if (P.only_pending && P.need_scan[b] == 0) return;
   if (!P.cond) return;
   // NaN records stick (and then fail the comparison below: ill-conditioned)
@@ -635,7 +636,7 @@ __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
   // the corrections' rounding-error estimates (chunk_update: J eps / mu, times |w.G w| for the quadratic form) summed
   // over the chunks, against the problem's own log det and quadratic form
   double err_ld = 0.0, err_q = 0.0, sum_ld = 0.0, sum_q = 0.0;
-  for (int c = lane; c < P.nchunk; c += 64) {
+  for (int c = tid; c < P.nchunk; c += NT) {
     const long slot = (long)b * P.nchunk + c;
     g = nmax(g, P.cond[slot * 3]);
     const double mu = P.cond[slot * 3 + 1];
@@ -657,13 +658,48 @@ __global__ void __launch_bounds__(64) decide_kernel(const BatchParams P) {
     sum_ld += __shfl_xor(sum_ld, off, 64);
     sum_q += __shfl_xor(sum_q, off, 64);
   }
-  if (lane != 0 || P.need_exact[b] != 0) return;
+  if (NT > 64) {  // (wave-uniform) the other waves' results through LDS
+    __shared__ double red[4][7];
+    if (lane == 0) {
+      double* o = red[tid >> 6];
+      o[0] = g; o[1] = m; o[2] = e; o[3] = err_ld; o[4] = err_q; o[5] = sum_ld; o[6] = sum_q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NT / 64; ++w) {
+        g = nmax(g, red[w][0]); m = nmin(m, red[w][1]); e = nmax(e, red[w][2]);
+        err_ld += red[w][3]; err_q += red[w][4]; sum_ld += red[w][5]; sum_q += red[w][6];
+      }
+    }
+  }
+  if (tid != 0 || P.need_exact[b] != 0) return;
   bool replay = !(err_ld <= 3e-12 * fabs(sum_ld)) || (!P.logdet_only && !(err_q <= 3e-12 * fabs(sum_q)));
   // (NaN records count as ill-conditioned)
   if (P.cert_gamma > 0.0 && (!(g < P.cert_gamma * m) || (P.cert_gamma_abs > 0.0 && !(g < P.cert_gamma_abs)) ||
                              (P.cert_eg > 0.0 && P.egerr && !(g * e < P.cert_eg))))
     replay = true;
   if (replay) P.need_exact[b] = 1;
+}
+
+// After the chunked replay (level 1 and forced-exact / materialising runs): trust it iff every chunk's end state met the
+// scanned start state of the next chunk (cond[.][2] <= cert_resid), else the problem goes to the sequential recurrence
+// (level 2).  One wave per problem, lanes striding over its chunks (round 4: one long series has thousands of chunks --
+// as a loop of the sequential kernel's lone lane the 4224 dependent loads took 0.47 ms of a 1.1 ms call).
+template <int J>
+__global__ void __launch_bounds__(64) check_replay_kernel(const BatchParams P) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!P.cond) return;
+  if (P.only_pending && P.need_scan[b] == 0) return;
+  const int level = P.need_exact[b];
+  if (level >= 2 || !(level == 1 || P.force_exact)) return;
+  double r = 0.0;
+  for (int c = lane; c < P.nchunk; c += 64) {
+    const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
+    r = (rc != rc) ? INFINITY : fmax(r, rc);  // (a NaN residual counts as inconsistent)
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
+  if (lane == 0 && !(r <= P.cert_resid)) P.need_exact[b] = 2;
 }
 
 // ---------------------------------------------------------------------------
@@ -685,17 +721,8 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
   constexpr int J = Wd::J;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.B) return;
-  int level = P.need_exact[b];
-  if (level < 2 && (level == 1 || P.force_exact) && P.cond) {
-    // the chunked replay ran for this problem: trust it iff every chunk's end state met the scanned
-    // start state of the next chunk
-    double r = 0.0;
-    for (int c = 0; c < P.nchunk; ++c) {
-      const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
-      r = (rc != rc) ? INFINITY : fmax(r, rc);  // (a NaN residual counts as inconsistent -- and stays so)
-    }
-    if (!(r <= P.cert_resid)) level = 2;
-  }
+  // (check_replay_kernel has raised the level of a replayed problem whose chunks did not meet the scanned start states)
+  const int level = P.need_exact[b];
   if (level < 2) return;
   P.need_exact[b] = 2;
   Problem<JR, JC> p;
@@ -911,7 +938,7 @@ struct BatchImpl {
     const long lanes = (long)P.B * P.nchunk;
     hipLaunchKernelGGL((correct_kernel<JR + 2 * JC>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s,
                        P);
-    hipLaunchKernelGGL((decide_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
+    hipLaunchKernelGGL((decide_kernel<JR + 2 * JC>), dim3(P.B), dim3(P.nchunk > 256 ? 256 : 64), 0, s, P);
   }
   static void replay(const BatchParams& P, int materialize, hipStream_t s) {
     dim3 grid((P.nchunk + 63) / 64, P.B);
@@ -926,6 +953,7 @@ struct BatchImpl {
   static void sequential(const BatchParams& P, int materialize, hipStream_t s) {
     if (P.nchunk < 2) return;  // (one chunk: the replay from the zero state IS the recurrence)
     dim3 grid((P.B + 63) / 64);
+    hipLaunchKernelGGL((check_replay_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
 #define CLR_GO(M, F) hipLaunchKernelGGL((sequential_kernel<JR, JC, M, F>), grid, dim3(64), 0, s, P)
 #define CLR_GO2(M) if (P.fast_trig) CLR_GO(M, true); else CLR_GO(M, false);
     if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }

@@ -1200,7 +1200,7 @@ void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) 
 }
 
 void launch_wide_decide(const BatchParams& P, hipStream_t s) {
-  hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), dim3(64), 0, s, P);
+  hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), dim3(P.nchunk > 256 ? 256 : 64), 0, s, P);
 }
 
 // after the chunked replay: a replayed problem whose chunks did not meet the scanned start states

@@ -60,6 +60,9 @@ for w in $WHAT; do
     singlewide)
       trace singlewide python tools/gpu_single_wide_profile.py
       ;;
+    singlenarrow)
+      trace singlenarrow python tools/gpu_single_narrow_profile.py
+      ;;
     general)
       trace general python tools/gpu_general_profile.py
       ;;
