@@ -299,7 +299,10 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind);
  *       start states fan out group by group -- the dependent chain is ~2.2 (g - 1) per level + the top level instead
  *       of nchunk (the reference's loop being parallelised: cholesky.h:126-179);
  *   1 16 lanes per problem walking the chunks one after the other;
- *   0 the single-lane version (the host-checked form; on-device cross-check and A/B). */
+ *   0 the single-lane version (the host-checked form; on-device cross-check and A/B).
+ * Widths 9..32 (and plans with general terms): 2 = a Kogge-Stone scan over composed elements when the plan has few
+ * problems with many chunks (B x nchunk <= 1024 at widths <= 16, 512 above, nchunk >= 8; csrc/wide_prefix_scan.hip) --
+ * such plans then choose N / 256 chunks by themselves --, else and for 1: a workgroup per problem walking the chunks. */
 int clr_batch_set_prefix_mode(clr_batch* h, int mode);
 /* Level structure of mode 2: `levels` (0..3) levels of groups of `group` (>= 2) elements; levels < 0 (default):
  * chosen from the chunk count by a cost model (clr_core.h: plan_prefix).  Re-plans the workspace. */
