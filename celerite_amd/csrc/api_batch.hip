@@ -86,10 +86,10 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
       if (nchunk < 2) nchunk = 1;
       if (nchunk > 16) nchunk = 16;
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
-      // few problems: the prefix is a parallel scan (wide_prefix_scan.hip) as long as B x nchunk <= 512 -- chunks of
-      // >= 256 samples instead of 16 long ones (one series of 1e5 samples: 390 chunks)
-      const int cap = clr::wide_prefix_scan_cap(h->J <= 16 ? 16 : 32);
-      if (h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / 256) > nchunk) nchunk = std::min(cap / h->B, h->N / 256);
+      // few problems: the prefix is a parallel scan (wide_prefix_scan.hip) as long as B x nchunk <= 1024 / 512 -- chunks of
+      // >= 64 / 96 samples instead of 16 long ones (one series of 1e5 samples: 1024 / 512 chunks)
+      const int cap = clr::wide_prefix_scan_cap(h->J <= 16 ? 16 : 32), Lmin = h->J <= 16 ? 64 : 96;  // (r04z_single_wide_short.txt)
+      if (h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk) nchunk = std::min(cap / h->B, h->N / Lmin);
     }
     if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
   } else if (nchunk <= 0) {
@@ -695,9 +695,9 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
     if (nchunk > 16) nchunk = 16;
     while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
-    const int cap = clr::wide_prefix_scan_cap(Wt <= 16 ? 16 : 32);
-    if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / 256) > nchunk)
-      nchunk = std::min(cap / h->B, h->N / 256);  // (few problems: the parallel prefix, clr_batch_set_chunks)
+    const int cap = clr::wide_prefix_scan_cap(Wt <= 16 ? 16 : 32), Lmin = Wt <= 16 ? 64 : 96;
+    if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk)
+      nchunk = std::min(cap / h->B, h->N / Lmin);  // (few problems: the parallel prefix, clr_batch_set_chunks)
     if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)
       nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
     if (nchunk < 1) nchunk = 1;

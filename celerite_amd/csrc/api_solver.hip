@@ -340,15 +340,19 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       // sample, p = 15 us per chunk up to width 16; a = 2.0 us, p = 97 us (three 32^3 products on the matrix
       // cores + a Gauss-Jordan) above.
       nchunk = (int)lround(sqrt((double)N * (J <= 16 ? 0.096 : 0.0208)));
-      // round 4: the prefix is a parallel scan (wide_prefix_scan.hip: ceil(log2 nchunk) launches of 25 / 50 us instead
-      // of nchunk steps of 14 / 50 us), so the chunks only have to stay long enough to amortise their own set-up:
-      // 256 samples, at most 1024 / 512 chunks (profiles/r04v_single_wide_chunks.txt: N = 1e5 width 16 3.0 -> 1.0 ms,
-      // width 32 6.9 -> 1.9 ms)
-      const int cap = clr::wide_prefix_scan_cap(J <= 16 ? 16 : 32);
-      if (std::min(N / 256, cap) >= 8 && !getenv("CLR_WIDE_PREFIX_WALK")) nchunk = std::min(N / 256, cap);
-      if (const char* e = getenv("CLR_SOLVER_WIDE_CHUNKS")) nchunk = atoi(e);  // (tools/gpu_single_wide_chunks.py)
       if (nchunk > N / 256) nchunk = N / 256;
       if (nchunk < 2 || N < 2048) nchunk = 1;  // (short series: the six launches of the chunked flow cost more)
+      // round 4: the prefix is a parallel scan (wide_prefix_scan.hip: ceil(log2 nchunk) launches of 22 / 86 us instead of
+      // nchunk steps of 14 / 50 us), so the chunks only have to amortise their own set-up -- 48 samples up to width 16, 96
+      // above, at most 1024 / 512 chunks, at least 8 (profiles/r04v_single_wide_chunks.txt, r04z_single_wide_short.txt:
+      // N = 1e5 width 16 3.0 -> 0.79 ms, width 32 6.9 -> 1.56 ms; N = 1000 0.74 -> 0.24 / 0.87 -> 0.58 ms)
+      if (!getenv("CLR_WIDE_PREFIX_WALK")) {
+        const int cap = clr::wide_prefix_scan_cap(J <= 16 ? 16 : 32), Lmin = J <= 16 ? 48 : 96;
+        int nk = std::min(N / Lmin, cap);
+        if (nk < 8 && N >= 8 * (J <= 16 ? 32 : 64)) nk = 8;
+        if (nk >= 8) nchunk = nk;
+      }
+      if (const char* e = getenv("CLR_SOLVER_WIDE_CHUNKS")) nchunk = std::max(1, std::min(atoi(e), N / 32));  // (tools/gpu_single_wide_chunks*.py)
     }
     P.L = (N + nchunk - 1) / nchunk;
     P.nchunk = (N + P.L - 1) / P.L;

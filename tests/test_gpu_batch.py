@@ -662,7 +662,7 @@ def test_wide_prefix_as_a_parallel_scan(JR, JC):
     ok = s0 == 0
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
-        assert plan.chunks[0] >= 32, plan.chunks      # automatic: N / 256 chunks, not 16 long ones
+        assert plan.chunks[0] >= 64, plan.chunks      # automatic: chunks of 64 / 96 samples, not 16 long ones
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case))
         for nchunk in (0, 8, 9, 16, 17, 31, 33, 64, 100, 140):
