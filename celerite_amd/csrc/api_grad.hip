@@ -155,8 +155,11 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       const int ng = (h->nchunk + k - 1) / k;
       const double waves = (double)B * ((ng + 63) / 64) * (rev ? 1.0 : groups);
       const double step = rev ? 0.6 + 4.4 * w2 : 0.3 + 2.4 * w2;
-      const double walk = rev ? 0.45 : 0.5 + 4.5 * w2 * J / 8.0;  // per chunk: a wave per problem / a thread per (problem, direction)
-      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * step + ng * walk;
+      const double walk = rev ? 0.2 : 0.5 + 4.5 * w2 * J / 8.0;  // per chunk: a wave per problem / a thread per (problem, direction)
+      // (reverse, >= 256 gradient chunks: the adjoint walk in two levels -- 2 seg + ng / seg dependent steps, seg = sqrt(ng / 2),
+      //  two more launches; profiles/r04z_single_grad_trace.txt)
+      const double walk_total = (rev && ng >= 256) ? 0.3 * 2.0 * std::sqrt(2.0 * ng) + 12.0 : ng * walk;
+      const double tm = std::max(1.0, waves / 1024.0) * k * h->L * step + walk_total;
       if (tm < best) { best = tm; m = k; }
     }
     return m;
@@ -224,7 +227,12 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
     }
     if (flags_fit) HIP_TRY(hipMemsetAsync(h->g_ckflag, 0, nflag, h->stream));
     P.g_ckflag = h->g_ckflag;
-    const size_t small = pc * (RID + 3 * (SZ + J) + NG + 2) + B;
+    // one long series: the adjoint walk over its thousands of gradient chunks in two levels (clr_grad_kernels.h) --
+    // groups of sqrt(chunks / 2): compose + walk the groups + fan out = 2 seg + chunks / seg dependent steps
+    P.g_seg = P.g_nchunk >= 256 ? std::max(16, (int)std::sqrt(0.5 * P.g_nchunk)) : 0;
+    const size_t ngr = P.g_seg ? (size_t)((P.g_nchunk + P.g_seg - 1) / P.g_seg) : 0;
+    const size_t nslab = (size_t)((P.g_nchunk + 255) / 256);
+    const size_t small = pc * (RID + 3 * (SZ + J) + NG + 2) + B + B * ngr * (RID + SZ + J) + B * nslab * 33;
     if (!flags_fit || h->g_rec.reserve(B * (size_t)P.g_rec_stride) != CLR_OK ||
         h->g_ck.reserve(B * (size_t)P.g_ck_stride) != CLR_OK || h->g_riders.reserve(small) != CLR_OK) {
       h->g_rec.release(); h->g_ck.release();
@@ -240,6 +248,9 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       P.g_drift = P.g_part + pc * NG;
       P.g_count = P.g_drift + pc;
       P.g_drift_max = P.g_count + pc;
+      P.g_grp_riders = ngr ? P.g_drift_max + B : nullptr;
+      P.g_grp_adj = ngr ? P.g_grp_riders + B * ngr * RID : nullptr;
+      P.g_slab = P.g_drift_max + B + B * ngr * (RID + SZ + J);
       P.g_from_elems = (P.g_m == 1 && h->grad_riders_mode != 1) ? 1 : 0;
       h->launch->grad_reverse(P, h->stream);
       HIP_TRY(hipGetLastError());

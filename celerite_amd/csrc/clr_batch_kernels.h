@@ -89,6 +89,9 @@ struct BatchParams {
   // reverse mode: per-sample record w, D, x [B][step][J + 2][chunk], stored states every g_K steps
   // [B][checkpoint][SZ + J][chunk], state after / adjoint at the end of every chunk, per-chunk partials and drift
   double *g_rec, *g_ck, *g_ends, *g_adj, *g_adj0, *g_part, *g_drift, *g_drift_max;
+  double* g_slab;                    // [B][slabs of 256 gradient chunks][33]: partial sums of the partials | the slab's certificate
+  double *g_grp_riders, *g_grp_adj;  // two-level adjoint walk: composed riders / end adjoints of groups of g_seg gradient chunks
+  int g_seg;                         // 0: one walk over all gradient chunks
   long g_rec_stride, g_ck_stride;  // doubles per problem
   int g_K;                // stored states: every g_K steps (> 0), or where the accumulated decay asks for one (0: GradStore)
   int g_nalloc;           // slots per chunk in g_ck
@@ -992,9 +995,23 @@ struct BatchImpl {
     } else {
       hipLaunchKernelGGL((grad_riders_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
     }
-    hipLaunchKernelGGL((grad_adjoint_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
+    constexpr int JW = JR + 2 * JC;
+    if (P.g_seg > 0 && P.g_grp_riders) {  // (one long series: thousands of gradient chunks)
+      const int ngr = (P.g_nchunk + P.g_seg - 1) / P.g_seg;
+      hipLaunchKernelGGL((grad_riders_compose_kernel<JW>), dim3(ngr, P.B), dim3(64), 0, s, P.g_riders, P.g_grp_riders,
+                         P.need_exact, P.g_nchunk, P.g_seg);
+      hipLaunchKernelGGL((grad_adjoint_kernel<JW>), dim3(1, P.B), dim3(64), 0, s,
+                         AdjointWalk{P.g_grp_riders, nullptr, P.g_grp_adj, P.need_exact, ngr, ngr});
+      hipLaunchKernelGGL((grad_adjoint_kernel<JW>), dim3(ngr, P.B), dim3(64), 0, s,
+                         AdjointWalk{P.g_riders, P.g_grp_adj, P.g_adj, P.need_exact, P.g_nchunk, P.g_seg});
+    } else {
+      hipLaunchKernelGGL((grad_adjoint_kernel<JW>), dim3(1, P.B), dim3(64), 0, s,
+                         AdjointWalk{P.g_riders, nullptr, P.g_adj, P.need_exact, P.g_nchunk, P.g_nchunk});
+    }
     hipLaunchKernelGGL((grad_backward_kernel<JR, JC, true>), grid, dim3(64), 0, s, P);
-    hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P, Sh::NG);
+    const int nslab = (P.g_nchunk + 255) / 256;
+    hipLaunchKernelGGL((grad_reduce_slab_kernel<JR + 2 * JC>), dim3(nslab, P.B), dim3(256), 0, s, P, Sh::NG);
+    hipLaunchKernelGGL((grad_reduce_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P, Sh::NG, nslab);
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,

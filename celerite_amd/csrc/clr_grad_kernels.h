@@ -142,23 +142,38 @@ __global__ void __launch_bounds__(64) grad_combine_kernel(const BatchParams P, i
   P.g_res[idx] = -0.5 * (dq + dld);
 }
 
-// grad_adjoint_walk (clr_grad_core.h) with one WAVE per problem: lane (i, j) owns entry (i, j) of the J x J products,
-// operands through LDS, the next chunk's riders prefetched into registers while the current chunk is multiplied.
-// One thread per problem walked a chunk in ~6.6 us (0.42 ms at 64 chunks, the longest phase of a single long series);
-// a wave takes ~0.4 us.
+// grad_adjoint_walk (clr_grad_core.h) with one WAVE per segment of a problem's chunks: lane (i, j) owns entry (i, j) of
+// the J x J products, operands through LDS, the next chunk's riders prefetched into registers while the current chunk is
+// multiplied.  One thread per problem walked a chunk in ~6.6 us (0.42 ms at 64 chunks, the longest phase of a single
+// long series); a wave takes ~0.17 us.
+// A segment is `seg` consecutive entries of `riders` ([B][nent][RID]); it starts from seg_start[b][k] (the adjoint at the
+// END of its last entry; null: zeros -- the end of the series) and writes the adjoint at the end of each of its entries
+// into adj ([B][nent][ADJ]).  One segment = the whole walk (rounds 3's kernel).  Round 4, one long series (thousands of
+// gradient chunks, 0.70 ms of a 1.97 ms call as one walk): two levels -- the riders of a group of chunks compose to the
+// riders of the merged chunk (grad_riders_compose_kernel), the groups are walked, and every group walks its own chunks
+// from the adjoint the level above found for its end.
+struct AdjointWalk {
+  const double* riders;
+  const double* seg_start;  // [B][nseg][ADJ] or null
+  double* adj;
+  const int* need_exact;
+  int nent, seg;
+};
 template <int J>
-__global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
+__global__ void __launch_bounds__(64) grad_adjoint_kernel(const AdjointWalk W) {
   constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, ADJ = SZ + J, JJN = J * J;
   __shared__ double AA[JJN], eta[J], JJ[SZ], Sb[JJN], fb[J], g[J], T[JJN];
-  const int b = blockIdx.x, l = threadIdx.x;
-  if (P.need_exact[b] >= 2) return;
+  const int b = blockIdx.y, k = blockIdx.x, l = threadIdx.x;
+  if (W.need_exact[b] >= 2) return;
   const int i = l / J, j = l % J;  // (lanes >= J * J idle)
   const bool mat = l < JJN;
-  const double* riders = P.g_riders + (long)b * P.g_nchunk * RID;
-  double* adj = P.g_adj + (long)b * P.g_nchunk * ADJ;
-  if (mat) Sb[l] = 0.0;
-  if (l < J) fb[l] = 0.0;
-  int c = P.g_nchunk - 1;
+  const int nseg = gridDim.x, lo = k * W.seg, hi = (lo + W.seg < W.nent) ? lo + W.seg : W.nent;
+  const double* riders = W.riders + (long)b * W.nent * RID;
+  double* adj = W.adj + (long)b * W.nent * ADJ;
+  const double* st = W.seg_start ? W.seg_start + ((long)b * nseg + k) * ADJ : nullptr;
+  if (mat) Sb[l] = st ? st[sym(i, j)] : 0.0;
+  if (l < J) fb[l] = st ? st[SZ + l] : 0.0;
+  int c = hi - 1;
   double r_aa = 0.0, r_eta = 0.0, r_jj = 0.0;
   auto fetch = [&](int cc) {
     const double* R = riders + (long)cc * RID;
@@ -166,28 +181,28 @@ __global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
     if (l < J) r_eta = R[JJN + l];
     if (l < SZ) r_jj = R[JJN + J + l];
   };
-  if (c > 0) fetch(c);
+  if (c > lo) fetch(c);
   __syncthreads();
-  for (; c >= 0; --c) {
+  for (; c >= lo; --c) {
     // the adjoint at the end of chunk c
     if (mat && i <= j) adj[(long)c * ADJ + tri(i, j)] = Sb[l];
     if (l < J) adj[(long)c * ADJ + SZ + l] = fb[l];
-    if (c == 0) break;
+    if (c == lo) break;
     if (mat) AA[l] = r_aa;
     if (l < J) eta[l] = r_eta;
     if (l < SZ) JJ[l] = r_jj;
-    if (c > 1) fetch(c - 1);
+    if (c > lo + 1) fetch(c - 1);
     __syncthreads();
     if (l < J) {
       double a = 0.0;
 #pragma unroll
-      for (int k = 0; k < J; ++k) a = fma(AA[k * J + l], fb[k], a);
+      for (int q = 0; q < J; ++q) a = fma(AA[q * J + l], fb[q], a);
       g[l] = a;
     }
     if (mat) {
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < J; ++k) t = fma(Sb[i * J + k], AA[k * J + j], t);
+      for (int q = 0; q < J; ++q) t = fma(Sb[i * J + q], AA[q * J + j], t);
       T[l] = t;
     }
     __syncthreads();
@@ -195,7 +210,7 @@ __global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
     if (mat) {
       s_new = eta[i] * eta[j] - JJ[sym(i, j)] - 0.5 * (g[i] * eta[j] + eta[i] * g[j]);
 #pragma unroll
-      for (int k = 0; k < J; ++k) s_new = fma(AA[k * J + i], T[k * J + j], s_new);
+      for (int q = 0; q < J; ++q) s_new = fma(AA[q * J + i], T[q * J + j], s_new);
     }
     if (l < J) f_new = g[l] - 2.0 * eta[l];
     __syncthreads();
@@ -203,6 +218,64 @@ __global__ void __launch_bounds__(64) grad_adjoint_kernel(const BatchParams P) {
     if (l < J) fb[l] = f_new;
     __syncthreads();
   }
+}
+
+// The riders of a GROUP of consecutive chunks = the riders of the merged chunk (clr_grad_core.h, header: AA is the
+// product of the steps' F, eta and JJ sum r x / D and r r^T / D with r pulled back through the steps before): for chunk a
+// followed by chunk b
+//     AA_ab = AA_b AA_a        eta_ab = eta_a + AA_a^T eta_b        JJ_ab = JJ_a + AA_a^T JJ_b AA_a .
+// One wave per (group, problem), the group's chunks in order; group 0 is skipped (nothing lies before it: the walk over
+// the groups never applies it).  out: [B][ngroup][RID].
+template <int J>
+__global__ void __launch_bounds__(64) grad_riders_compose_kernel(const double* riders_all, double* out, const int* need_exact,
+                                                                 int nent, int seg) {
+  constexpr int SZ = J * (J + 1) / 2, RID = J * J + J + SZ, JJN = J * J;
+  __shared__ double A[JJN], Bm[JJN], eb[J], JB[JJN], T[JJN];
+  const int b = blockIdx.y, k = blockIdx.x, l = threadIdx.x;
+  if (k == 0 || need_exact[b] >= 2) return;
+  const int i = l / J, j = l % J;
+  const bool mat = l < JJN;
+  const int lo = k * seg, hi = (lo + seg < nent) ? lo + seg : nent;
+  const double* riders = riders_all + (long)b * nent * RID;
+  // the running composition: lane (i, j) holds AA[i][j], JJ[i][j] (full, symmetric); lane i < J holds eta[i]
+  double aa = 0.0, jj = 0.0, et = 0.0;
+  {
+    const double* R = riders + (long)lo * RID;
+    if (mat) { aa = R[l]; jj = R[JJN + J + sym(i, j)]; }
+    if (l < J) et = R[JJN + l];
+  }
+  for (int c = lo + 1; c < hi; ++c) {
+    const double* R = riders + (long)c * RID;
+    if (mat) { A[l] = aa; Bm[l] = R[l]; JB[l] = R[JJN + J + sym(i, j)]; }
+    if (l < J) eb[l] = R[JJN + l];
+    __syncthreads();
+    double aa_new = 0.0, t = 0.0;
+    if (mat) {
+#pragma unroll
+      for (int q = 0; q < J; ++q) {
+        aa_new = fma(Bm[i * J + q], A[q * J + j], aa_new);  // AA_b AA_a
+        t = fma(JB[i * J + q], A[q * J + j], t);             // JJ_b AA_a
+      }
+      T[l] = t;
+    }
+    if (l < J) {
+#pragma unroll
+      for (int q = 0; q < J; ++q) et = fma(A[q * J + l], eb[q], et);  // eta_a + AA_a^T eta_b
+    }
+    __syncthreads();
+    if (mat) {
+#pragma unroll
+      for (int q = 0; q < J; ++q) jj = fma(A[q * J + i], T[q * J + j], jj);  // JJ_a + AA_a^T (JJ_b AA_a)
+      aa = aa_new;
+    }
+    __syncthreads();
+  }
+  double* O = out + ((long)b * gridDim.x + k) * RID;
+  if (mat) {
+    O[l] = aa;
+    if (i <= j) O[JJN + J + tri(i, j)] = jj;
+  }
+  if (l < J) O[JJN + l] = et;
 }
 
 template <int JR, int JC, bool FAST>
@@ -226,28 +299,41 @@ __global__ void __launch_bounds__(64) grad_backward_kernel(const BatchParams P) 
   P.g_drift[slot] = drift;
 }
 
-// One wave per problem.  Lane q < NG: -1/2 of the sum over the chunks of partial q (in chunk order).  All lanes,
-// striding over the chunks: the two certificates of the reverse sweep reduced to one number per problem --
+// The partials of a problem = -1/2 of the sum over its gradient chunks, and the two certificates of the reverse sweep
+// reduced to one number per problem --
 //   * the drift of the reconstructed states (g_drift, zero when every state is stored), and
 //   * the adjoint a sweep arrived at for its chunk's first sample (g_adj0) against the one the walk over the riders
 //     predicted for the end of the previous chunk (g_adj): two independent computations of one quantity -- it is what
 //     vouches for riders taken from the scan's elements;
 // a non-finite partial or a NaN anywhere is a failed certificate (reported as +inf).
+// Two kernels (round 4: one workgroup per problem took 0.27-0.32 ms for the 4224 chunks of one long series):
+//   grad_reduce_slab_kernel   workgroup = (slab of 256 chunks, problem).  Thread (stripe s = tid / 32, q = tid % 32 < NG)
+//                             sums partial q over the slab's chunks c = s, s + 8, ... in order, the eight stripes are
+//                             added in a fixed tree; thread = chunk: that chunk's certificate, reduced to the slab's
+//                             maximum.                                              -> g_slab [B][nslab][33]
+//   grad_reduce_kernel        one wave per problem: the slabs in order.
+// The shape of the sums depends on the chunk count only -- not on the batch size or the sharding -- so results stay
+// bit-identical across shard counts.
 template <int J>
-__global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, int NG) {
+__global__ void __launch_bounds__(256) grad_reduce_slab_kernel(const BatchParams P, int NG) {
   constexpr int ADJ = J * (J + 1) / 2 + J;
-  const int b = blockIdx.x, l = threadIdx.x;
-  if (P.need_exact[b] >= 2) return;
-  const int ng = P.g_nchunk;
-  for (int q = l; q < NG; q += 64) {
-    const double* part = P.g_part + (long)b * ng * NG + q;
+  __shared__ double stripe[8][32], wmax[4];
+  const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+  if (P.need_exact[b] >= 2) return;  // (workgroup-uniform)
+  const int ng = P.g_nchunk, c0 = slab * 256, c1 = (c0 + 256 < ng) ? c0 + 256 : ng;
+  {
+    const int q = tid & 31, s = tid >> 5;
     double acc = 0.0;
-    for (int c = 0; c < ng; ++c) acc += part[(long)c * NG];
-    P.g_res[(long)b * NG + q] = -0.5 * acc;
+    if (q < NG) {
+      const double* part = P.g_part + (long)b * ng * NG + q;
+      for (int c = c0 + s; c < c1; c += 8) acc += part[(long)c * NG];
+    }
+    stripe[s][q] = acc;
   }
   double worst = 0.0;
   bool bad = false;
-  for (int c = l; c < ng; c += 64) {
+  const int c = c0 + tid;
+  if (c < c1) {
     const long slot = (long)b * ng + c;
     const double d = P.g_drift[slot];
     if (d != d) bad = true;
@@ -257,6 +343,7 @@ __global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, in
     if (c > 0) {
       const double *want = P.g_adj + (slot - 1) * ADJ, *got = P.g_adj0 + slot * ADJ;
       double big = 0.0, dev = 0.0;
+#pragma unroll
       for (int i = 0; i < ADJ; ++i) {
         const double a = fabs(want[i]), e = fabs(want[i] - got[i]);
         if (a != a || e != e) bad = true;
@@ -267,6 +354,30 @@ __global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, in
     }
   }
   if (bad) worst = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
+  if ((tid & 63) == 0) wmax[tid >> 6] = worst;
+  __syncthreads();
+  double* o = P.g_slab + ((long)b * gridDim.x + slab) * 33;
+  if (tid < 32) {
+    o[tid] = ((stripe[0][tid] + stripe[1][tid]) + (stripe[2][tid] + stripe[3][tid])) +
+             ((stripe[4][tid] + stripe[5][tid]) + (stripe[6][tid] + stripe[7][tid]));
+  }
+  if (tid == 0) o[32] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+}
+
+template <int J>
+__global__ void __launch_bounds__(64) grad_reduce_kernel(const BatchParams P, int NG, int nslab) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  if (P.need_exact[b] >= 2) return;
+  const double* S = P.g_slab + (long)b * nslab * 33;
+  if (l < NG) {
+    double acc = 0.0;
+    for (int k = 0; k < nslab; ++k) acc += S[k * 33 + l];
+    P.g_res[(long)b * NG + l] = -0.5 * acc;
+  }
+  double worst = 0.0;
+  for (int k = l; k < nslab; k += 64) worst = fmax(worst, S[k * 33 + 32]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
   if (l == 0) P.g_drift_max[b] = worst;

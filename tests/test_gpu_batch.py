@@ -1616,6 +1616,41 @@ def test_reverse_gradient_rebuilds_thinned_states_forwards():
             plan.close()
 
 
+@pytest.mark.parametrize("JR,JC", [(2, 3), (1, 0), (0, 2), (3, 1)])
+def test_reverse_gradient_with_the_two_level_adjoint_walk(JR, JC):
+    """Hundreds of gradient chunks per problem (one long series): the adjoint walk runs in two levels -- the riders of a
+    group of chunks compose to the riders of the merged chunk, the groups are walked, every group walks its own chunks
+    (clr_grad_kernels.h).  Same partials as forward mode and as the sequential tangent kernel; the sweep's own
+    certificate (the adjoint it arrives at against the walk's) stays at rounding level."""
+    B, N = 2, 40000
+    case = synthetic(B, N, JR, JC, "bench", seed=40 + JR + JC)
+    jit = np.array([0.0, 0.02])
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        v0, g0, s0 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    scale = np.max(np.abs(g0), axis=1, keepdims=True)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        for nchunk in (300, 1000, 2500):
+            plan.set_chunks(nchunk)
+            plan.set_coefficients(*coeffs_of(case), jitter=jit)
+            plan.set_grad_mode("reverse")
+            v, g, st = plan.grad_log_likelihood()
+            info = plan.grad_info()
+            assert (st == 0).all() and info["reverse"] and info["forward_reruns"] == 0, (nchunk, info)
+            within("two-level adjoint walk: partials vs sequential kernel (of the largest)", np.max(np.abs(g - g0) / scale), 1e-10)
+            within("two-level adjoint walk: value vs sequential kernel", np.max(np.abs(v - v0) / np.abs(v0)), 1e-12)
+            within("two-level adjoint walk: drift / adjoint certificate", info["drift_max"], 1e-9)
+            plan.set_grad_mode("forward")
+            vf, gf, stf = plan.grad_log_likelihood()
+            within("two-level adjoint walk: reverse vs forward", np.max(np.abs(g - gf) / scale), 1e-10)
+    finally:
+        plan.close()
+
+
 def test_plan_gradient_full_size_directional_derivative():
     """The headline shape's series length (N = 1e5, width 8, 17 partials), where no oracle gradient is affordable:
     the gradient must predict the change of the plan's OWN log-likelihood (pinned to the oracle elsewhere) along a

@@ -63,6 +63,9 @@ for w in $WHAT; do
     singlenarrow)
       trace singlenarrow python tools/gpu_single_narrow_profile.py
       ;;
+    singlegrad)
+      trace singlegrad python tools/gpu_single_grad_profile.py
+      ;;
     general)
       trace general python tools/gpu_general_profile.py
       ;;
