@@ -812,7 +812,11 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
   const bool scan = sorted && clr::predict_scan_supported(s->N, s->J_real, s->J_comp);
   int pchunk = 0, pL = 0;
   if (scan) {
-    pchunk = clr::sweep_chunks(s->N);
+    // chunks of 16 samples (at most 8192): the prefix over the chunks is a parallel scan (predict_prefix_kernel), the
+    // prediction points and the chunk summaries walk <= one chunk each (profiles/r04z_predict_chunks.txt: N = 1e5, M = 2e4,
+    // width 8 2.1 -> 0.84 ms, width 32 4.9 -> 1.5 ms; rounds 2-3: 1.8 sqrt(N) chunks, their prefix one thread's walk)
+    pchunk = std::max(1, std::min(s->N / 16, 8192));
+    if (const char* e = getenv("CLR_PREDICT_CHUNKS")) pchunk = std::max(1, std::min(atoi(e), s->N / 8));  // (tools/gpu_predict_chunks.py)
     pL = (s->N + pchunk - 1) / pchunk;
     pchunk = (s->N + pL - 1) / pL;
     if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk, s->J_real + 2 * s->J_comp))) != CLR_OK) return st;

@@ -318,22 +318,57 @@ __global__ void __launch_bounds__(64) predict_summarize_kernel(GenericProblem g,
   for (int j = 0; j < PJ; ++j) { e[j] = A[j]; e[PJ + j] = Q[j]; }
 }
 
-__global__ void __launch_bounds__(64) predict_prefix_kernel(int nchunk, const double* elems, double* starts) {
-  const int dir = threadIdx.x, blk = blockIdx.x;
-  if (dir > 1) return;
-  elems += (long)blk * 2 * nchunk * (2 * PJ);
-  starts += (long)blk * 2 * nchunk * PJ;
-  double Q[PJ];
+// The chunk start states of predict's two diagonal recurrences: Q' = a Q + q per row, an affine map per chunk -- composed
+// per thread over a contiguous run of chunks, scanned over the 256 threads (Kogge-Stone on (a, q) pairs through LDS), then
+// every thread walks its run again from the state the scan found for it.  Workgroup = (row block, direction).
+// (Round 4; rounds 2-3 walked the chunks with ONE thread per direction: 0.30 ms of predict's 2.1 ms at N = 1e5.)
+__global__ void __launch_bounds__(256) predict_prefix_kernel(int nchunk, const double* elems, double* starts) {
+  __shared__ double sa[PJ][256], sq[PJ][256];
+  const int tid = threadIdx.x, dir = blockIdx.y, blk = blockIdx.x;
+  elems += ((long)blk * 2 + dir) * nchunk * (2 * PJ);
+  starts += ((long)blk * 2 + dir) * nchunk * PJ;
+  const int S = (nchunk + 255) / 256, p0 = tid * S, p1 = (p0 + S < nchunk) ? p0 + S : nchunk;
+  auto chunk_at = [&](int p) { return dir == 0 ? p : nchunk - 1 - p; };  // the backward recurrence meets the chunks in reverse
+  double A[PJ], Q[PJ];
 #pragma unroll
-  for (int j = 0; j < PJ; ++j) Q[j] = 0.0;
-  for (int i = 0; i < nchunk; ++i) {
-    const int c = dir == 0 ? i : nchunk - 1 - i;  // the backward recurrence meets the chunks in reverse
-    const double* e = elems + ((long)dir * nchunk + c) * (2 * PJ);
-    double* st = starts + ((long)dir * nchunk + c) * PJ;
+  for (int j = 0; j < PJ; ++j) { A[j] = 1.0; Q[j] = 0.0; }
+  for (int p = p0; p < p1; ++p) {
+    const double* e = elems + (long)chunk_at(p) * (2 * PJ);
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      Q[j] = fma(e[j], Q[j], e[PJ + j]);
+      A[j] *= e[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) { sa[j][tid] = A[j]; sq[j][tid] = Q[j]; }
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {  // inclusive scan: (a1, q1) then (a2, q2) = (a2 a1, a2 q1 + q2)
+    double a1[PJ], q1[PJ];
+    if (tid >= d) {
+#pragma unroll
+      for (int j = 0; j < PJ; ++j) { a1[j] = sa[j][tid - d]; q1[j] = sq[j][tid - d]; }
+    }
+    __syncthreads();
+    if (tid >= d) {
+#pragma unroll
+      for (int j = 0; j < PJ; ++j) {
+        sq[j][tid] = fma(sa[j][tid], q1[j], sq[j][tid]);
+        sa[j][tid] *= a1[j];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) Q[j] = tid > 0 ? sq[j][tid - 1] : 0.0;  // the state before this thread's run
+  for (int p = p0; p < p1; ++p) {
+    const int c = chunk_at(p);
+    const double* e = elems + (long)c * (2 * PJ);
+    double* st = starts + (long)c * PJ;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
       st[j] = Q[j];
-      Q[j] = e[j] * Q[j] + e[PJ + j];
+      Q[j] = fma(e[j], Q[j], e[PJ + j]);
     }
   }
 }
@@ -410,7 +445,7 @@ void launch_predict_scan(const GenericProblem& g, const double* alpha, int M, co
   double* elems = workspace;
   double* starts = workspace + (size_t)nblk * 2 * nchunk * 2 * PJ;
   hipLaunchKernelGGL(predict_summarize_kernel, dim3((nchunk + 63) / 64, 2, nblk), dim3(64), 0, s, g, alpha, nchunk, L, elems);
-  hipLaunchKernelGGL(predict_prefix_kernel, dim3(nblk), dim3(64), 0, s, nchunk, elems, starts);
+  hipLaunchKernelGGL(predict_prefix_kernel, dim3(nblk, 2), dim3(256), 0, s, nchunk, elems, starts);
   hipLaunchKernelGGL(predict_points_kernel, dim3((M + 63) / 64), dim3(64), 0, s, g, alpha, nchunk, L, starts, M, xs, pred);
 }
 

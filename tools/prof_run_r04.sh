@@ -66,6 +66,10 @@ for w in $WHAT; do
     singlegrad)
       trace singlegrad python tools/gpu_single_grad_profile.py
       ;;
+    sweeps8)
+      trace sweeps_w8 python tools/gpu_sweep_profile2.py 2 3
+      trace sweeps_w16 python tools/gpu_sweep_profile2.py 2 7
+      ;;
     general)
       trace general python tools/gpu_general_profile.py
       ;;
