@@ -724,8 +724,17 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
   constexpr int J = Wd::J;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.B) return;
-  // (check_replay_kernel has raised the level of a replayed problem whose chunks did not meet the scanned start states)
-  const int level = P.need_exact[b];
+  int level = P.need_exact[b];
+  if (P.nchunk <= 256 && level < 2 && (level == 1 || P.force_exact) && P.cond) {
+    // the chunked replay ran for this problem: trust it iff every chunk's end state met the scanned start state of the
+    // next chunk (longer chunk lists: check_replay_kernel has done this, a wave per problem)
+    double r = 0.0;
+    for (int c = 0; c < P.nchunk; ++c) {
+      const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
+      r = (rc != rc) ? INFINITY : fmax(r, rc);  // (a NaN residual counts as inconsistent -- and stays so)
+    }
+    if (!(r <= P.cert_resid)) level = 2;
+  }
   if (level < 2) return;
   P.need_exact[b] = 2;
   Problem<JR, JC> p;
@@ -956,7 +965,7 @@ struct BatchImpl {
   static void sequential(const BatchParams& P, int materialize, hipStream_t s) {
     if (P.nchunk < 2) return;  // (one chunk: the replay from the zero state IS the recurrence)
     dim3 grid((P.B + 63) / 64);
-    hipLaunchKernelGGL((check_replay_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);
+    if (P.nchunk > 256) hipLaunchKernelGGL((check_replay_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);  // (else: sequential_kernel's own loop)
 #define CLR_GO(M, F) hipLaunchKernelGGL((sequential_kernel<JR, JC, M, F>), grid, dim3(64), 0, s, P)
 #define CLR_GO2(M) if (P.fast_trig) CLR_GO(M, true); else CLR_GO(M, false);
     if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
