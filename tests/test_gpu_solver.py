@@ -618,6 +618,30 @@ def test_object_api_wide_widths_through_the_wide_scan(JR, JC, N):
         assert np.allclose(a, b, rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("JR,JC", [(2, 5), (0, 8), (4, 11), (0, 16)])
+def test_object_api_wide_widths_around_the_chunking_thresholds(JR, JC):
+    """Widths 9..32 through `CholeskySolver`: from N = 256 (width <= 16) / 512 on the series is cut into >= 8 chunks of
+    >= 48 / 96 samples and the chunks' prefix is a parallel scan (csrc/wide_prefix_scan.hip); below, one sequential sweep.
+    Both sides of each threshold, ragged last chunks, and the stored factor must equal the oracle's."""
+    for N in (255, 256, 257, 383, 385, 511, 512, 513, 767, 1100, 3100):
+        rng = np.random.RandomState(N + JR)
+        t = np.sort(rng.uniform(0, 0.05 * N, N))
+        yerr = rng.uniform(0.3, 0.5, N)
+        y = rng.randn(N)
+        args = (0.0, np.exp(rng.uniform(-1, 0.5, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0.5, JC)),
+                0.1 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(0, 3, JC)),
+                np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t, yerr ** 2)
+        s, r = celerite_amd.CholeskySolver(), ref.RefSolver()
+        s.compute(*args)
+        r.compute(*args)
+        assert abs(s.log_determinant() - r.log_determinant()) <= 1e-10 * abs(r.log_determinant()), N
+        assert abs(s.dot_solve(y) - r.dot_solve(y)) <= 1e-10 * abs(r.dot_solve(y)), N
+        st, st0 = s.__getstate__(), r.state()
+        assert st[:3] == (True, N, JR + 2 * JC)
+        for a, b in zip(st[4:], st0[4:]):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-13), N
+
+
 @pytest.mark.parametrize("JR,JC,N", [(1, 1, 900), (2, 3, 6000), (2, 7, 5000), (0, 16, 4000)])
 def test_hinted_right_hand_side_is_the_same_quadratic_form(JR, JC, N):
     """GP.log_likelihood announces its residual before the factorisation (solver._hint_rhs): compute then
