@@ -570,7 +570,7 @@ static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, do
     clr::SweepParams P;
     memset(&P, 0, sizeof(P));
     P.N = s->N; P.J = s->J; P.nrhs = nr;
-    P.nchunk = wide ? clr::wsweep_chunks(s->N) : clr::sweep_chunks(s->N);
+    P.nchunk = wide ? clr::wsweep_chunks(s->N, s->J) : clr::sweep_chunks(s->N);
     P.L = (s->N - 1 + P.nchunk - 1) / P.nchunk;
     P.nchunk = (s->N - 1 + P.L - 1) / P.L;
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;

@@ -49,6 +49,9 @@ struct SweepParams {
   double* quad;                   // [nrhs] sum x_n^2 / D_n (dot_solve) or null
   int backward;
   double *elems, *starts, *part;  // workspace, set by launch_sweep_scan
+  // two-level prefix of the wave-per-chunk sweeps (wsweep_kernels.hip): runs of run_len chunks, the state at each run's start
+  int run_len;                    // 0: one walk over all chunks
+  const double* run_starts;       // [nrhs][runs][J + 1] or null (the series' first sample)
 };
 bool sweep_scan_supported(int N, int J);
 int sweep_chunks(int N);
@@ -56,7 +59,7 @@ size_t sweep_workspace_doubles(int J, int nchunk, int nrhs);
 void launch_sweep_scan(SweepParams P, double* workspace, hipStream_t s);
 // N >= 2048, width <= 32 (wsweep_kernels.hip): wave per chunk, lane = column of the chunk's affine map
 bool wsweep_scan_supported(int N, int J);
-int wsweep_chunks(int N);
+int wsweep_chunks(int N, int J);
 size_t wsweep_workspace_doubles(int J, int nchunk, int nrhs);
 void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s);
 // dot_L at N >= 2048, any width: wave per chunk, lane = row; workspace nrhs * nchunk * 3 J doubles

@@ -17,6 +17,8 @@
 #include "clr_generic_kernels.h"
 #include "clr_wide.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace clr {
@@ -126,6 +128,70 @@ wsweep_summarize_kernel(const SweepParams P) {
   o[J] = x;
 }
 
+// Two-level prefix (round 4): the maps of a RUN of consecutive chunks compose to one map of the same layout,
+//     [P | a_1 .. a_nrhs]  <-  M_c [P | a] + [0 | a_c] ,   from [I | 0],
+// so the walk over the chunks (0.34-0.6 us each, a third of a sweep) becomes: compose the runs side by side, walk the
+// run maps, walk every run's own chunks from the state found for its start.  One wave per (run, block of CB columns);
+// lane = row, the block's columns of the running product in registers, handed round through LDS.
+constexpr int WS_CB = 8;
+__global__ void __launch_bounds__(64) wsweep_compose_kernel(const SweepParams P, int R, double* run_elems) {
+  __shared__ double X[65][WS_CB];
+  const int J = P.J, K = J + 1, lane = threadIdx.x, run = blockIdx.x, col0 = blockIdx.y * WS_CB;
+  const int ncol = K + P.nrhs;
+  const int c0 = run * R, c1 = min(c0 + R, P.nchunk);
+  // (width 64: K = 65 rows -- lane 0 also owns row 64)
+  const bool have = lane < K, have2 = lane == 0 && K > 64;
+  double acc[WS_CB], acc2[WS_CB];
+#pragma unroll
+  for (int j = 0; j < WS_CB; ++j) {
+    acc[j] = (have && col0 + j == lane) ? 1.0 : 0.0;
+    acc2[j] = (have2 && col0 + j == K - 1) ? 1.0 : 0.0;
+  }
+  const int lrow = min(lane, K - 1);
+  for (int c = c0; c < c1; ++c) {
+    const double* M = P.elems + (long)c * ncol * K;
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < WS_CB; ++j) X[lane][j] = acc[j];
+    }
+    if (have2) {
+#pragma unroll
+      for (int j = 0; j < WS_CB; ++j) X[K - 1][j] = acc2[j];
+    }
+    lds_fence();
+    double nacc[WS_CB], nacc2[WS_CB];
+#pragma unroll
+    for (int j = 0; j < WS_CB; ++j) {
+      const int col = col0 + j;
+      const bool aff = col >= K && col < ncol;
+      nacc[j] = aff ? M[(long)col * K + lrow] : 0.0;
+      nacc2[j] = (aff && have2) ? M[(long)col * K + K - 1] : 0.0;
+    }
+    for (int k = 0; k < K; ++k) {
+      const double m = M[(long)k * K + lrow];
+      const double m2 = have2 ? M[(long)k * K + K - 1] : 0.0;
+#pragma unroll
+      for (int j = 0; j < WS_CB; ++j) {
+        const double x = X[k][j];
+        nacc[j] = fma(m, x, nacc[j]);
+        nacc2[j] = fma(m2, x, nacc2[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WS_CB; ++j) { acc[j] = nacc[j]; acc2[j] = nacc2[j]; }
+    lds_fence();
+  }
+  double* O = run_elems + (long)run * ncol * K;
+#pragma unroll
+  for (int j = 0; j < WS_CB; ++j) {
+    const int col = col0 + j;
+    if (col < ncol) {
+      if (have) O[(long)col * K + lane] = acc[j];
+      if (have2) O[(long)col * K + K - 1] = acc2[j];
+    }
+  }
+}
+
 // One workgroup of NW waves per right-hand side.  Lane i (< K) owns row i of a chunk's map; wave w owns the
 // chunks c = w (mod NW) and fetches its next one right after using the current, so a fetch has NW - 1 chunk
 // times to land; z travels from chunk to chunk through LDS (ping-pong, one barrier per chunk) and is read
@@ -136,6 +202,10 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
   constexpr bool BIG = JP >= 64;   // width 64: K = 65 rows for 64 lanes -- lane 0 also owns row 64 (the x row)
   __shared__ double zbuf[2][2 * H];
   const int J = P.J, K = J + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rhs = blockIdx.x;
+  // (two-level prefix: this workgroup walks the chunks of run blockIdx.y from the state the level above found for it)
+  const int c_lo = P.run_len ? (int)blockIdx.y * P.run_len : 0;
+  const int c_hi = P.run_len ? min(c_lo + P.run_len, P.nchunk) : P.nchunk;
+  const double* z_lo = P.run_starts ? P.run_starts + ((long)rhs * gridDim.y + blockIdx.y) * K : nullptr;
   const bool have = lane < K;
   const bool have2 = BIG && lane == 0 && K > 64;
   const double* in = P.in + (long)rhs * P.N;
@@ -146,7 +216,8 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
     // the sweep's first sample: x_0 = b_0 (cholesky.h:238) / x_{N-1} / D_{N-1} (:249,251)
     for (int i = lane; i < 2 * H; i += 64) {
       double z = 0.0;
-      if (i == J) z = P.backward ? in[P.N - 1] / P.D[P.N - 1] : in[0];
+      if (z_lo) z = i < K ? z_lo[i] : 0.0;
+      else if (i == J) z = P.backward ? in[P.N - 1] / P.D[P.N - 1] : in[0];
       zbuf[0][i] = z;
       zbuf[1][i] = 0.0;
     }
@@ -169,11 +240,11 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
       aff2 = M[(long)(K + rhs) * K + (K - 1)];
     }
   };
-  if (wave < P.nchunk) fetch(wave);
+  if (c_lo + wave < c_hi) fetch(c_lo + wave);
   __syncthreads();
-  for (int c = 0; c < P.nchunk; ++c) {
-    if (c % NW == wave) {
-      const double* zc = zbuf[c & 1];
+  for (int c = c_lo; c < c_hi; ++c) {
+    if ((c - c_lo) % NW == wave) {
+      const double* zc = zbuf[(c - c_lo) & 1];
       double z0[H], z1[H];
 #pragma unroll
       for (int j = 0; j < H; ++j) z0[j] = zc[j];
@@ -194,13 +265,13 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
       }
       double b0 = 0.0;
       if (BIG && K > 64) b0 = wsum(m2 * zmine) + fma(m2last, zlast, aff2);  // (lane j: column j < 64; then column 64)
-      if (have) zbuf[(c + 1) & 1][lane] = (a0 + a1) + (a2 + a3);
-      if (have2) zbuf[(c + 1) & 1][K - 1] = b0;
+      if (have) zbuf[(c - c_lo + 1) & 1][lane] = (a0 + a1) + (a2 + a3);
+      if (have2) zbuf[(c - c_lo + 1) & 1][K - 1] = b0;
       // (the store after the arithmetic: issued before it, the wait for this chunk's map -- vmcnt counts
       // loads and stores in order -- would also wait for the store to be acknowledged)
       if (have) starts[((long)rhs * P.nchunk + c) * K + lane] = zmine;
       if (have2) starts[((long)rhs * P.nchunk + c) * K + K - 1] = zlast;
-      if (c + NW < P.nchunk) fetch(c + NW);
+      if (c + NW < c_hi) fetch(c + NW);
     }
     // LDS traffic only: a plain __syncthreads() would also wait for the fetch just issued (vmcnt(0))
     lds_fence();
@@ -459,9 +530,20 @@ void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s) {
 // sweep_kernels.hip stops at width 8; a sequential sweep costs 0.23 us per step)
 bool wsweep_scan_supported(int N, int J) { return J >= 1 && J <= 64 && (N >= 2048 || (J > 8 && N >= 512)); }
 
+// runs of the two-level prefix: 0 = one walk (widths above 32: a composition costs (J + 1)^3)
+static int wsweep_run_len(int J, int nchunk) {
+  if (const char* e = getenv("CLR_WSWEEP_RUN")) return atoi(e);  // (tools/gpu_wsweep_chunks.py)
+  if (J > 32 || nchunk < 128) return 0;
+  return 8;  // (profiles/r04z_wsweep_two_level.txt: runs of 8 beat 12, 16, 32 at every width <= 32)
+}
+
 // the sequential prefix costs 0.3-0.6 us per chunk, the parallel phases 0.4-0.8 us per step
-int wsweep_chunks(int N) {
+int wsweep_chunks(int N, int J) {
   long nc = (long)(1.0 * sqrt((double)N));
+  // two-level prefix (widths <= 32, long series): one round of 1024 chunk waves -- the walk no longer sets the chunk count
+  // (N = 1e5: dot_solve 0.31 -> 0.18 ms at width 8, 0.44 -> 0.29 at width 32; 1536 chunks are slower again)
+  if (J <= 32 && N >= 16384) nc = 1024;
+  if (const char* e = getenv("CLR_WSWEEP_CHUNKS")) nc = atol(e);
   if (nc < 2) nc = 2;
   const long maxc = std::max<long>(1, (N - 1) / 64);
   if (nc > maxc) nc = maxc;
@@ -470,7 +552,10 @@ int wsweep_chunks(int N) {
 
 size_t wsweep_workspace_doubles(int J, int nchunk, int nrhs) {
   const size_t K = (size_t)J + 1;
-  return (size_t)nchunk * (K + nrhs) * K + (size_t)nrhs * nchunk * K + (size_t)nrhs * nchunk;
+  const int R = wsweep_run_len(J, nchunk);
+  const size_t nrun = R > 0 ? (size_t)((nchunk + R - 1) / R) : 0;
+  return (size_t)nchunk * (K + nrhs) * K + (size_t)nrhs * nchunk * K + (size_t)nrhs * nchunk +
+         nrun * (K + nrhs) * K + (size_t)nrhs * nrun * K;
 }
 
 void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
@@ -487,13 +572,33 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
   else if (P.J <= 48) hipLaunchKernelGGL((wsweep_summarize_kernel<48>), gsum, dim3(64), 0, s, P);
   else if (P.J <= 56) hipLaunchKernelGGL((wsweep_summarize_kernel<56>), gsum, dim3(64), 0, s, P);
   else hipLaunchKernelGGL((wsweep_summarize_kernel<64>), gsum, dim3(64), 0, s, P);
-  if (P.J <= 8) hipLaunchKernelGGL((wsweep_prefix_kernel<8, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
-  else if (P.J <= 16) hipLaunchKernelGGL((wsweep_prefix_kernel<16, 16>), dim3(P.nrhs), dim3(1024), 0, s, P);
-  else if (P.J <= 24) hipLaunchKernelGGL((wsweep_prefix_kernel<24, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
-  else if (P.J <= 32) hipLaunchKernelGGL((wsweep_prefix_kernel<32, 8>), dim3(P.nrhs), dim3(512), 0, s, P);
-  else if (P.J <= 48) hipLaunchKernelGGL((wsweep_prefix_kernel<48, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
-  else if (P.J <= 62) hipLaunchKernelGGL((wsweep_prefix_kernel<62, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((wsweep_prefix_kernel<64, 4>), dim3(P.nrhs), dim3(256), 0, s, P);
+  auto prefix = [&](const SweepParams& Q, int nrun) {
+    const dim3 grid(Q.nrhs, nrun);
+    if (Q.J <= 8) hipLaunchKernelGGL((wsweep_prefix_kernel<8, 16>), grid, dim3(1024), 0, s, Q);
+    else if (Q.J <= 16) hipLaunchKernelGGL((wsweep_prefix_kernel<16, 16>), grid, dim3(1024), 0, s, Q);
+    else if (Q.J <= 24) hipLaunchKernelGGL((wsweep_prefix_kernel<24, 8>), grid, dim3(512), 0, s, Q);
+    else if (Q.J <= 32) hipLaunchKernelGGL((wsweep_prefix_kernel<32, 8>), grid, dim3(512), 0, s, Q);
+    else if (Q.J <= 48) hipLaunchKernelGGL((wsweep_prefix_kernel<48, 4>), grid, dim3(256), 0, s, Q);
+    else if (Q.J <= 62) hipLaunchKernelGGL((wsweep_prefix_kernel<62, 4>), grid, dim3(256), 0, s, Q);
+    else hipLaunchKernelGGL((wsweep_prefix_kernel<64, 4>), grid, dim3(256), 0, s, Q);
+  };
+  const int R = wsweep_run_len(P.J, P.nchunk);
+  if (R > 0 && P.nchunk > R) {
+    // two levels: the runs' maps composed side by side, the run maps walked, every run walked from its start state
+    const int nrun = (P.nchunk + R - 1) / R;
+    double* run_elems = P.part + (size_t)P.nrhs * P.nchunk;
+    double* run_starts = run_elems + (size_t)nrun * (K + P.nrhs) * K;
+    hipLaunchKernelGGL(wsweep_compose_kernel, dim3(nrun, (unsigned)((K + P.nrhs + WS_CB - 1) / WS_CB)), dim3(64), 0, s, P, R, run_elems);
+    SweepParams T = P;
+    T.elems = run_elems; T.nchunk = nrun; T.starts = run_starts; T.run_len = 0; T.run_starts = nullptr;
+    prefix(T, 1);
+    SweepParams F = P;
+    F.run_len = R; F.run_starts = run_starts;
+    prefix(F, nrun);
+  } else {
+    P.run_len = 0; P.run_starts = nullptr;
+    prefix(P, 1);
+  }
   hipLaunchKernelGGL(wsweep_replay_kernel, dim3(P.nchunk, P.nrhs), dim3(64), 0, s, P);
   if (P.quad) hipLaunchKernelGGL(wsweep_finalize_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
 }
