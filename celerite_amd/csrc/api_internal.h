@@ -166,6 +166,8 @@ struct clr_solver {
   DevBuf coeffs;                        // a_real c_real a_comp b_comp c_comp d_comp
   DevBuf t, U, V;                       // inputs kept for predict / dot
   DevBuf scratch, scratch2, scalars;    // right-hand sides, results
+  DevBuf dot_buf[11];                            // clr_solver_dot's own buffers (it must not disturb a computed factor)
+  DevBuf pred_buf[2];                            // clr_solver_predict: the prediction points, the predictions
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
   DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix; level buffers of the wide parallel prefix
   DevBuf gradbuf;                       // grad_log_likelihood staging

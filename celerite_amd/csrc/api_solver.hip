@@ -124,6 +124,8 @@ void clr_solver_destroy(clr_solver* s) {
                       &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
                       &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs, &s->ws_lvl_elems, &s->ws_lvl_starts})
       b->release();
+    for (DevBuf& b : s->dot_buf) b.release();
+    for (DevBuf& b : s->pred_buf) b.release();
     if (s->ws_flags) (void)hipFree(s->ws_flags);
     if (s->d_status) (void)hipFree(s->d_status);
     if (s->pin) (void)hipHostFree(s->pin);
@@ -714,11 +716,12 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
     return CLR_OK;
   }
 
-  // this call must not disturb a previously computed factor: use private buffers
-  DevBuf coeffs, tt, dU, dV, phi, u, v, dg, zin, yout, ws;
-  auto cleanup = [&]() {
-    for (DevBuf* b : {&coeffs, &tt, &dU, &dV, &phi, &u, &v, &dg, &zin, &yout, &ws}) b->release();
-  };
+  // this call must not disturb a previously computed factor: buffers of its own -- kept in the solver object between
+  // calls (round 4: eleven hipMalloc / hipFree pairs per call were ~0.7 of the 1.1-1.2 ms of a call at N = 1e5)
+  DevBuf &coeffs = s->dot_buf[0], &tt = s->dot_buf[1], &dU = s->dot_buf[2], &dV = s->dot_buf[3], &phi = s->dot_buf[4],
+         &u = s->dot_buf[5], &v = s->dot_buf[6], &dg = s->dot_buf[7], &zin = s->dot_buf[8], &yout = s->dot_buf[9],
+         &ws = s->dot_buf[10];
+  auto cleanup = [&]() {};  // (released with the solver)
   std::vector<double> hc;
   double sum_ar = 0.0, sum_ac = 0.0;
   for (int j = 0; j < J_real; ++j) sum_ar += a_real[j];
@@ -821,9 +824,9 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
     pchunk = (s->N + pL - 1) / pL;
     if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk, s->J_real + 2 * s->J_comp))) != CLR_OK) return st;
   }
-  DevBuf dxs, dpred;
+  DevBuf &dxs = s->pred_buf[0], &dpred = s->pred_buf[1];  // (kept between calls)
   if ((st = upload(dxs, xs, (size_t)M, stream)) != CLR_OK) return st;
-  if ((st = dpred.reserve((size_t)M)) != CLR_OK) { dxs.release(); return st; }
+  if ((st = dpred.reserve((size_t)M)) != CLR_OK) return st;
   hipError_t e = hipMemsetAsync(dpred.p, 0, sizeof(double) * (size_t)M, stream);
   const clr::GenericProblem g = generic_view(s);
   if (scan) clr::launch_predict_scan(g, s->scratch2.p, M, dxs.p, dpred.p, s->ws_elems.p, pchunk, pL, stream);
@@ -832,8 +835,6 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
   if (e == hipSuccess)
     e = hipMemcpyAsync(pred, dpred.p, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, stream);
   hipError_t e2 = hipStreamSynchronize(stream);
-  dxs.release();
-  dpred.release();
   if (e != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(CLR_HIP_ERROR, hipGetErrorString(e2));
   return CLR_OK;
