@@ -783,12 +783,13 @@ def test_carma_instability_raises():  # carma.h:185-186, exceptions.h:8-12
     assert abs(got - want) <= 1e-10 * abs(want)
 
 
-@pytest.mark.parametrize("JR,JC,nrhs", [(0, 16, 40), (2, 3, 70), (1, 7, 64)])
-def test_wide_sweeps_many_right_hand_sides(JR, JC, nrhs):
+@pytest.mark.parametrize("JR,JC,nrhs,N", [(0, 16, 40, 3000), (2, 3, 70, 3000), (1, 7, 64, 3000),
+                                          (2, 3, 21, 17000), (0, 16, 9, 20001), (1, 12, 3, 16384)])
+def test_wide_sweeps_many_right_hand_sides(JR, JC, nrhs, N):
     """solve with more right-hand sides than one wave of columns holds (the chunk map's J + 1 columns plus nrhs
     affine columns spill into further column blocks of wsweep_summarize_kernel; the prefix and replay run one
-    workgroup / wave per right-hand side)."""
-    N = 3000
+    workgroup / wave per right-hand side).  From N = 16384 on the prefix runs in two levels: the run maps are composed
+    in blocks of 8 columns of [P | a_1 .. a_nrhs] (wsweep_compose_kernel) -- several blocks here."""
     rng = np.random.RandomState(nrhs)
     t = np.sort(rng.uniform(0, 0.05 * N, N))
     diag = rng.uniform(0.1, 0.3, N)
