@@ -88,8 +88,17 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
       while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
       // few problems: the prefix is a parallel scan (wide_prefix_scan.hip) as long as B x nchunk <= 1024 / 512 -- chunks of
       // >= 64 / 96 samples instead of 16 long ones (one series of 1e5 samples: 1024 / 512 chunks)
-      const int cap = clr::wide_prefix_scan_cap(h->J <= 16 ? 16 : 32), Lmin = h->J <= 16 ? 64 : 96;  // (r04z_single_wide_short.txt)
+      const int cap = clr::wide_prefix_scan_max_chunks(h->J <= 16 ? 16 : 32), Lmin = h->J <= 16 ? 64 : 96;  // (r04z_single_wide_short.txt)
       if (h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk) nchunk = std::min(cap / h->B, h->N / Lmin);
+      // 32..256 problems (profiles/r04zz_wide_midbatch.txt, N = 1e5): 16 long chunks leave the chip half empty -- width <= 16:
+      // 64 chunks at B = 32 (4.1 -> 1.6 ms), 32 at B = 64..256 (3.9 -> 2.8, 5.2 -> 4.9, 9.9 -> 8.5 ms); width 32: 32 chunks at
+      // B = 32 (5.4 -> 3.5 ms), the old counts above (the walk's 50 us per chunk and problem)
+      if (h->coop_prefix == 2 && h->B >= 32 && h->B <= 256) {
+        int want = nchunk;
+        if (h->J <= 16) want = std::max(32, 2048 / h->B);
+        else if (h->B == 32) want = 32;
+        if (want > nchunk && h->N / want >= 512) nchunk = want;
+      }
     }
     if (nchunk > h->N / 64) nchunk = std::max(1, h->N / 64);
   } else if (nchunk <= 0) {
@@ -695,7 +704,7 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
     if (nchunk > 16) nchunk = 16;
     while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
-    const int cap = clr::wide_prefix_scan_cap(Wt <= 16 ? 16 : 32), Lmin = Wt <= 16 ? 64 : 96;
+    const int cap = clr::wide_prefix_scan_max_chunks(Wt <= 16 ? 16 : 32), Lmin = Wt <= 16 ? 64 : 96;
     if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk)
       nchunk = std::min(cap / h->B, h->N / Lmin);  // (few problems: the parallel prefix, clr_batch_set_chunks)
     if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)

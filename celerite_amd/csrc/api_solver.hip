@@ -349,7 +349,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       // above, at most 1024 / 512 chunks, at least 8 (profiles/r04v_single_wide_chunks.txt, r04z_single_wide_short.txt:
       // N = 1e5 width 16 3.0 -> 0.79 ms, width 32 6.9 -> 1.56 ms; N = 1000 0.74 -> 0.24 / 0.87 -> 0.58 ms)
       if (!getenv("CLR_WIDE_PREFIX_WALK")) {
-        const int cap = clr::wide_prefix_scan_cap(J <= 16 ? 16 : 32), Lmin = J <= 16 ? 48 : 96;
+        const int cap = clr::wide_prefix_scan_max_chunks(J <= 16 ? 16 : 32), Lmin = J <= 16 ? 48 : 96;
         int nk = std::min(N / Lmin, cap);
         if (nk < 8 && N >= 8 * (J <= 16 ? 32 : 64)) nk = 8;
         if (nk >= 8) nchunk = nk;

@@ -1056,6 +1056,7 @@ void launch_wide_prefix(const BatchParams& P, int width_padded, hipStream_t s);
 // the wide prefix as a Kogge-Stone scan over composed elements (wide_prefix_scan.hip): few problems with many chunks
 size_t wide_prefix_scan_workspace(int B, int nchunk, int width_padded);  // doubles; 0 = keep the sequential walk
 int wide_prefix_scan_cap(int width_padded);                                // largest B x nchunk the scan is used for
+int wide_prefix_scan_max_chunks(int width_padded);                         // most chunks one series is cut into
 void launch_wide_prefix_scan(const BatchParams& P, int width_padded, hipStream_t s);
 int wide_scan_max_width();
 // fp32-state sequential sweep (a measurement for BASELINE config 5, wide_kernels.hip)

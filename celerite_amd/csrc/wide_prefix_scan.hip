@@ -220,12 +220,14 @@ void run_levels(const BatchParams& P, hipStream_t s) {
 
 }  // namespace
 
-int wide_prefix_scan_cap(int width_padded) { return width_padded <= 16 ? 1024 : 512; }
+// largest B x nchunk the scan is used for (workgroups per level; profiles/r04zz_wide_midbatch.txt: at width 32 the scan loses
+// to the walk from 2048 workgroups per level on, at width 16 it ties at 4096)
+int wide_prefix_scan_cap(int width_padded) { return width_padded <= 16 ? 2048 : 1024; }
+// most chunks ONE series is cut into (profiles/r04v_single_wide_chunks.txt)
+int wide_prefix_scan_max_chunks(int width_padded) { return width_padded <= 16 ? 1024 : 512; }
 
 // doubles of workspace the parallel prefix needs (two level buffers), 0 when this shape keeps the sequential walk
 size_t wide_prefix_scan_workspace(int B, int nchunk, int width_padded) {
-  // workgroups per level: one round at width 32 (two 60-KB workgroups per CU), two at width 16 -- measured on one series of
-  // 4e5 / 1e6 samples (profiles/r04v_single_wide_chunks.txt): width 16 still gains from 1024 chunks, width 32 does not
   long cap = wide_prefix_scan_cap(width_padded);
   if (const char* e = getenv("CLR_WIDE_SCAN_CAP")) cap = atol(e);  // (tools/gpu_single_wide_chunks2.py)
   if (nchunk < 8 || (long)B * nchunk > cap) return 0;  // (... and a walk worth cutting)

@@ -735,6 +735,10 @@ def test_wide_scan_is_chosen_for_small_batches():
     plan = batch.BatchedGP(64, 20000, 0, 16)       # 64 problems: 16 chunks each fill the chip
     assert plan.chunks[0] == 16
     plan.close()
+    for B, JC, want in ((32, 8, 64), (64, 8, 32), (256, 8, 32), (32, 16, 32), (128, 16, 16), (256, 16, 8)):
+        plan = batch.BatchedGP(B, 100000, 0, JC)   # 32..256 long series: enough chunks for one full round of waves
+        assert plan.chunks[0] == want, (B, JC, plan.chunks)
+        plan.close()
     plan = batch.BatchedGP(2048, 20000, 0, 16)     # enough problems: plain sequential sweeps
     assert plan.chunks[0] == 1
     plan.close()
