@@ -93,9 +93,10 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
       // 32..256 problems (profiles/r04zz_wide_midbatch.txt, N = 1e5): 16 long chunks leave the chip half empty -- width <= 16:
       // 64 chunks at B = 32 (4.1 -> 1.6 ms), 32 at B = 64..256 (3.9 -> 2.8, 5.2 -> 4.9, 9.9 -> 8.5 ms); width 32: 32 chunks at
       // B = 32 (5.4 -> 3.5 ms), the old counts above (the walk's 50 us per chunk and problem)
-      if (h->coop_prefix == 2 && h->B >= 32 && h->B <= 256) {
+      // (width <= 16 up to 1024 problems: B = 512 19.6 -> 15.8 ms with 32 chunks, B = 1024 36.2 -> 30.6 ms with 16)
+      if (h->coop_prefix == 2 && h->B >= 32 && h->B <= (h->J <= 16 ? 1024 : 256)) {
         int want = nchunk;
-        if (h->J <= 16) want = std::max(32, 2048 / h->B);
+        if (h->J <= 16) want = h->B <= 512 ? std::max(32, 2048 / h->B) : 16;
         else if (h->B == 32) want = 32;
         if (want > nchunk && h->N / want >= 512) nchunk = want;
       }
