@@ -654,6 +654,20 @@ def main(argv=None):
     plan.set_profiling(False)
     kernel_name = plan.summarize_kernel()
 
+    # several ranks: EVERY rank holds the first problems of its own slice against the CPU oracle (the single-rank run
+    # does the full parity leg below); the worst deviation over the ranks goes into the line
+    rank_parity = None
+    if dist.world > 1:
+        from oracle import ref as _ref
+        nchk = min(2, B)
+        plan.set_coefficients(*coeffs)
+        _, ld_r, q_r, st_r = plan.log_likelihood()
+        _, ld0, q0, st0 = _ref.batch_log_likelihood(0.0, *[c[:nchk] for c in coeffs[:6]], t[:nchk], diag[:nchk], y[:nchk])
+        bad = 0.0 if np.array_equal(st_r[:nchk], st0) else 1.0
+        rank_parity = {"problems_checked_per_rank": nchk,
+                       "logdet_rel_max": dist.max(rel_err(ld_r[:nchk], ld0)), "quad_rel_max": dist.max(rel_err(q_r[:nchk], q0)),
+                       "status_equal": dist.max(bad) == 0.0, "tolerance": 1e-10}
+
     out = None
     if dist.rank == 0:
         per = {k: v / max(nrec, 1) for k, v in kernel_ms.items()}
@@ -818,6 +832,8 @@ def main(argv=None):
             out["shared_series"] = {"error": repr(e)}
         if dist.world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(coeffs, t, diag, y, ld, q, st, B, N))
+        if rank_parity is not None:
+            out["multi_rank_parity"] = rank_parity
     plan.close()
     if dist.rank == 0 and dist.world == 1 and not args.no_accuracy_family:
         try:

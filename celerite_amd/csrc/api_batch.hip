@@ -64,6 +64,7 @@ static int warm_plan_chunks(clr_batch* h);
 static int warm_resolve(clr_batch* h, bool* pin_current);
 static int warm_scan_spans(clr_batch* h);
 static void warm_select(clr_batch* h);
+static int plan_general_chunks(clr_batch* h);
 
 int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   int st = require_device(h->device);
@@ -156,6 +157,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   HIP_TRY(hipMemsetAsync(h->cond.p, 0, pc * 4 * sizeof(double), h->stream));
   h->evaluated = false;
   if ((st = warm_plan_chunks(h)) != CLR_OK) return st;
+  if (h->J_general > 0 && (st = plan_general_chunks(h)) != CLR_OK) return st;  // (its chunking follows the plan's settings)
   return CLR_OK;
 }
 
@@ -277,6 +279,15 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   if ((st = h->diag.reserve(count(diag_stride))) != CLR_OK) return st;
   if ((st = h->y.reserve(count(y_stride))) != CLR_OK) return st;
   HIP_TRY(hipStreamSynchronize(h->stream));  // (kernels of an earlier evaluation may still be reading the old series)
+  // from here on the old series is being overwritten: the plan has NO series until every copy and scan below has
+  // succeeded (a failed upload must not leave have_series set over half-written arrays), and nothing derived from
+  // the old one -- interleaved copies, warm-up spans and their selection -- survives
+  h->have_series = false;
+  h->warm_active = false;
+  h->warm_span.clear();
+  h->relayout_pending = true;
+  h->warm_copy_pending = true;
+  h->grad_span_valid = false;
   const clr::CopyJob jobs[3] = {{h->t.p, t, count(t_stride)}, {h->diag.p, diag, count(diag_stride)}, {h->y.p, y, count(y_stride)}};
   const size_t total = (jobs[0].n + jobs[1].n + jobs[2].n) * sizeof(double);
   bool staged = false;
@@ -300,7 +311,6 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->t_stride = t_stride;
   h->diag_stride = diag_stride;
   h->y_stride = y_stride;
-  h->have_series = true;
   // one pass over t ON THE DEVICE: max |t| over every sample (sortedness is not assumed), the largest and the smallest
   // step, NaN times; then the warm path's spans
   {
@@ -319,9 +329,14 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
     // (a NaN time: NaN bounds select the conservative kernels, sel_max)
     h->tmax = nan ? NAN : tm;
     h->dxmax = nan ? NAN : dm;
-    h->dtmin = nan ? NAN : (N > 1 ? dmin : 0.0);
+    // the smallest step over the finite differences (the device's fmin skips NaN); a negative one means "not sorted"
+    // whatever else the series holds -- the reference's np.any(np.diff(t) < 0), celerite.py:126-129 -- and only a
+    // series without a negative step reports its NaN times as NaN
+    const double finite_min = N > 1 ? dmin : 0.0;
+    h->dtmin = (finite_min < 0.0) ? finite_min : (nan ? NAN : finite_min);
   }
-  if ((st = warm_scan_spans(h)) != CLR_OK) return st;
+  h->have_series = true;
+  if ((st = warm_scan_spans(h)) != CLR_OK) { h->have_series = false; return st; }
   h->set_series_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   h->grad_span_valid = false;
   h->relayout_pending = true;
@@ -585,6 +600,7 @@ int clr_batch_set_prefix_mode(clr_batch* h, int mode) {
   if (mode < 0 || mode > 2) return fail(CLR_INVALID_ARGUMENT, "prefix mode must be 0, 1 or 2");
   h->coop_prefix = mode;
   h->pipeline_pinned = true;
+  if (h->J_general > 0) return plan_general_chunks(h);  // (the parallel prefix asks for other chunk counts)
   return CLR_OK;
 }
 
@@ -675,31 +691,18 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   return CLR_OK;
 }
 
-int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
-                          const double* V, long V_stride) {
+// A plan with general terms on the wide kernels (total width <= 64): its own chunking and workspace, derived from the
+// plan's CURRENT settings -- batch size, explicit chunk count, prefix mode, first-chunk ratio.  Called by
+// clr_batch_set_general and again by every setter that changes one of those (clr_batch_set_chunks and, through it,
+// clr_batch_set_prefix_plan; clr_batch_set_prefix_mode), so that the chunking does not depend on the order of the calls.
+static int plan_general_chunks(clr_batch* h) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  if (J_general < 0) return fail(CLR_INVALID_ARGUMENT, "J_general must be >= 0");
-  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
-  if (J_general == 0) {  // back to the celerite-terms-only plan
-    h->J_general = 0;
-    return CLR_OK;
-  }
-  if (!A || !U || !V) return fail(CLR_INVALID_ARGUMENT, "general terms need A, U and V");
-  if (h->J + J_general > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
-  const long N = h->N, UV = (long)J_general * N;
-  if ((A_stride != 0 && A_stride != N) || (U_stride != 0 && U_stride != UV) || (V_stride != 0 && V_stride != UV))
-    return fail(CLR_INVALID_ARGUMENT, "general-term strides must be 0 (shared) or the size of one problem's block");
-  auto count = [&](long sd, long one) { return (size_t)(sd == 0 ? one : one * (long)h->B); };
-  if ((st = upload(h->gA, A, count(A_stride, N), h->stream)) != CLR_OK) return st;
-  if ((st = upload(h->gU, U, count(U_stride, UV), h->stream)) != CLR_OK) return st;
-  if ((st = upload(h->gV, V, count(V_stride, UV), h->stream)) != CLR_OK) return st;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->J_general = J_general;
-  h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  h->gen_nchunk = 0;
+  const int J_general = h->J_general;
+  if (J_general <= 0) return CLR_OK;
   // Total widths up to 64 run on the wave-per-(problem, chunk) kernels (wide_kernels.hip, GEN flavour): the general rows
   // are one more row class there.  Chunks as for any wide plan: one round of two waves per SIMD, the scan up to width 32.
-  h->gen_nchunk = 0;
   const int Wt = h->J + J_general;
   if (Wt <= clr::wide_max_width()) {
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
@@ -708,7 +711,7 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     const int cap = clr::wide_prefix_scan_max_chunks(Wt <= 16 ? 16 : 32), Lmin = Wt <= 16 ? 64 : 96;
     if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk)
       nchunk = std::min(cap / h->B, h->N / Lmin);  // (few problems: the parallel prefix, clr_batch_set_chunks)
-    if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured here too)
+    if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured, whenever it was made)
       nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
     if (nchunk < 1) nchunk = 1;
     int L = (h->N + nchunk - 1) / nchunk;
@@ -739,6 +742,32 @@ int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_s
     HIP_TRY(hipMemsetAsync(h->gen_cond.p, 0, pc * 4 * sizeof(double), h->stream));
     h->gen_nchunk = nchunk; h->gen_L = L; h->gen_L0 = L0;
   }
+  return CLR_OK;
+}
+
+int clr_batch_set_general(clr_batch* h, int J_general, const double* A, long A_stride, const double* U, long U_stride,
+                          const double* V, long V_stride) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (J_general < 0) return fail(CLR_INVALID_ARGUMENT, "J_general must be >= 0");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (J_general == 0) {  // back to the celerite-terms-only plan
+    h->J_general = 0;
+    return CLR_OK;
+  }
+  if (!A || !U || !V) return fail(CLR_INVALID_ARGUMENT, "general terms need A, U and V");
+  if (h->J + J_general > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  const long N = h->N, UV = (long)J_general * N;
+  if ((A_stride != 0 && A_stride != N) || (U_stride != 0 && U_stride != UV) || (V_stride != 0 && V_stride != UV))
+    return fail(CLR_INVALID_ARGUMENT, "general-term strides must be 0 (shared) or the size of one problem's block");
+  auto count = [&](long sd, long one) { return (size_t)(sd == 0 ? one : one * (long)h->B); };
+  if ((st = upload(h->gA, A, count(A_stride, N), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gU, U, count(U_stride, UV), h->stream)) != CLR_OK) return st;
+  if ((st = upload(h->gV, V, count(V_stride, UV), h->stream)) != CLR_OK) return st;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->J_general = J_general;
+  h->gA_stride = A_stride; h->gU_stride = U_stride; h->gV_stride = V_stride;
+  if ((st = plan_general_chunks(h)) != CLR_OK) { h->J_general = 0; return st; }
   return CLR_OK;
 }
 
@@ -937,6 +966,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (h->J_general > 0) {  // general terms: the any-width sequential recurrence, one workgroup per problem
     if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms: use CholeskySolver");
     h->warm_inflight = false;
+    h->small_inflight = false;
     if (h->gen_nchunk > 0 && h->general_route != 1) {
       // the wide kernels with the general rows as a third row class (chunked scan up to total width 32)
       clr::BatchParams W;
@@ -970,6 +1000,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   }
   mark(0);
   h->warm_inflight = false;
+  h->small_inflight = false;
   if (!warm_runs(h, materialize) && small_runs(h, materialize)) {
     clr::BatchParams Sp;
     h->in_fallback = true;  // (the row-major arrays)
@@ -979,7 +1010,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     mark(1);
     clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
     mark(2); mark(3); mark(4); mark(5); mark(6);
-    h->warm_inflight = true;  // (pending problems are settled like the warm path's: warm_resolve)
+    h->small_inflight = true;  // (pending problems are settled like the warm path's: warm_resolve)
     HIP_TRY(hipGetLastError());
     return CLR_OK;
   }
@@ -1056,8 +1087,12 @@ int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms)
 // results (ll | logdet | quad | status) of this evaluation.
 static int warm_resolve(clr_batch* h, bool* pin_current) {
   if (pin_current) *pin_current = false;
-  if (!h->warm_inflight) return CLR_OK;
+  if (!h->warm_inflight && !h->small_inflight) return CLR_OK;
+  // (the one-launch path of short narrow problems leaves pending problems the same way, but its outcome says nothing
+  //  about the warm-up lengths: the warm path's statistics and its adaptation are not touched on its behalf)
+  const bool was_warm = h->warm_inflight;
   h->warm_inflight = false;
+  h->small_inflight = false;
   const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
   int st;
   if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
@@ -1066,8 +1101,10 @@ static int warm_resolve(clr_batch* h, bool* pin_current) {
   const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
   int pending = 0;
   for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
-  h->warm_fallbacks = pending;
-  h->warm_settled = (int)B - pending;
+  if (was_warm) {
+    h->warm_fallbacks = pending;
+    h->warm_settled = (int)B - pending;
+  }
   if (pending) {
     if ((st = warm_fallback(h)) != CLR_OK) return st;
     HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1076,12 +1113,12 @@ static int warm_resolve(clr_batch* h, bool* pin_current) {
     size_t eligible = 0;
     for (int k : h->warm_K) eligible += k > 0;
     const long failed = (long)pending - (long)(B - eligible);
-    if (h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
-  } else if (h->warm_mode < 0 && h->warm_boost > 0 && ++h->warm_clean >= 8) {
+    if (was_warm && h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
+  } else if (was_warm && h->warm_mode < 0 && h->warm_boost > 0 && ++h->warm_clean >= 8) {
     --h->warm_boost;  // eight clean evaluations in a row: try the shorter warm-ups again
     h->warm_clean = 0;
   }
-  if (pending) h->warm_clean = 0;
+  if (pending && was_warm) h->warm_clean = 0;
   if (pin_current) *pin_current = true;
   return CLR_OK;
 }
@@ -1174,7 +1211,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
       HIP_TRY(hipEventRecord(e[1], h->stream));
       clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
       for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
-      h->warm_inflight = true;
+      h->small_inflight = true;
       continue;
     }
     if (warm_runs(h, materialize)) {  // (the warm path: recurrence + boundary check in the "summarize" slot)

@@ -261,6 +261,7 @@ struct clr_batch {
   bool warm_K_dirty = false;          // warm_K changed on the host after the last upload (set_series re-selected it)
   bool warm_active = false;           // the current (series, coefficients) pair runs the warm path
   bool warm_inflight = false;         // results of a warm evaluation have not been looked at yet
+  bool small_inflight = false;        // ... of a one-launch evaluation (small_batch_kernel): pending problems, no warm statistics
   bool in_fallback = false;           // building the parameters of the scan behind the warm path
   int warm_boost = 0;                 // candidates skipped after an evaluation with many fallbacks
   int warm_clean = 0;                 // consecutive warm evaluations without a fallback (decays warm_boost)

@@ -631,7 +631,12 @@ __global__ void __launch_bounds__(256) decide_kernel(const BatchParams P) {
   // chunks' records are order-independent, the sums only feed a threshold
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
   if (P.only_pending && P.need_scan[b] == 0) return;
-  if (!P.cond) return;
+  if (!P.cond) {
+    // no conditioning record: nothing vouches for the chunk summaries (the correct kernels leave their rounding-error
+    // estimates in it) -- the problem takes the checked replay instead of being settled silently
+    if (tid == 0 && P.need_exact[b] == 0) P.need_exact[b] = 1;
+    return;
+  }
   // NaN records stick (and then fail the comparison below: ill-conditioned)
   auto nmax = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x > a ? x : a)); };
   auto nmin = [](double a, double x) { return (a != a) ? a : ((x != x) ? x : (x < a ? x : a)); };
@@ -1034,7 +1039,7 @@ bool launch_summarize_split(const BatchParams& P, int JR, int JC, hipStream_t s)
 bool have_summarize_split(int JR, int JC);
 
 // decide_kernel at the padded widths of the wide scan
-void launch_wide_decide(const BatchParams& P, hipStream_t s);
+void launch_wide_decide(const BatchParams& P, int width_padded, hipStream_t s);
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s);
 // Per-problem reduction of the chunk partials + the -inf rules (api_kernels.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);

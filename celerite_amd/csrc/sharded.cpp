@@ -238,14 +238,18 @@ int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const
 }
 
 int clr_sharded_get_series_order(const clr_sharded* h, double* dtmin) {
+  // the smallest step over the shards' finite values; a negative one ("not sorted") wins over a NaN time in any
+  // shard, and only a batch without a negative step reports NaN (clr_batch_get_series_order has the same rule)
   double m = 1.0 / 0.0;
+  bool nan = false;
   for (clr_batch* p : h->plan) {
     double d = 0.0;
     const int st = clr_batch_get_series_order(p, &d);
     if (st != CLR_OK) return st;
-    if (!(d >= m)) m = d;  // (NaN sticks)
+    if (d != d) nan = true;
+    else if (d < m) m = d;
   }
-  if (dtmin) *dtmin = m;
+  if (dtmin) *dtmin = (m < 0.0) ? m : (nan ? 0.0 / 0.0 : m);
   return CLR_OK;
 }
 

@@ -1196,11 +1196,14 @@ void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) 
   const dim3 grid((unsigned)((long)P.B * P.nchunk));
   if (width_padded <= 16) hipLaunchKernelGGL((wide_correct_kernel<16>), grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((wide_correct_kernel<32>), grid, dim3(256), 0, s, P);
-  launch_wide_decide(P, s);
+  launch_wide_decide(P, width_padded, s);
 }
 
-void launch_wide_decide(const BatchParams& P, hipStream_t s) {
-  hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), dim3(P.nchunk > 256 ? 256 : 64), 0, s, P);
+// (the corrections' error estimate is J eps / mu per chunk: J = the padded width the correct kernel worked at)
+void launch_wide_decide(const BatchParams& P, int width_padded, hipStream_t s) {
+  const dim3 block(P.nchunk > 256 ? 256 : 64);
+  if (width_padded <= 16) hipLaunchKernelGGL((decide_kernel<16>), dim3(P.B), block, 0, s, P);
+  else hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), block, 0, s, P);
 }
 
 // after the chunked replay: a replayed problem whose chunks did not meet the scanned start states

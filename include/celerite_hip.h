@@ -221,8 +221,13 @@ int clr_batch_set_series(clr_batch* h,
 int clr_batch_set_small_mode(clr_batch* h, int mode);
 int clr_batch_get_small_mode(const clr_batch* h, int* active);
 /* The smallest step t[n + 1] - t[n] over the plan's series, found by the device-side scan of clr_batch_set_series
- * (negative: some series is not sorted -- GP.compute's check, celerite.py:126-129, without a host pass over t; NaN: a
- * NaN time).  clr_batch_clear_series drops the series (a front end that rejects unsorted input calls it). */
+ * (negative: some series is not sorted -- GP.compute's check, celerite.py:126-129, without a host pass over t -- and
+ * that holds whatever else the batch contains: the minimum is taken over the finite steps, as np.diff(t) < 0 would;
+ * NaN: no negative step, but a NaN time somewhere).  clr_batch_clear_series drops the series (a front end that
+ * rejects unsorted input calls it).
+ * clr_batch_set_series replaces the plan's series IN PLACE: from the moment it starts copying, the previous series is
+ * gone -- a call that fails midway, or whose input the front end then rejects, leaves the plan WITHOUT a series
+ * (set one again before the next evaluation), never with a half-overwritten one. */
 int clr_batch_get_series_order(const clr_batch* h, double* dtmin);
 int clr_batch_clear_series(clr_batch* h);
 /* (jitter may be NULL: no jitter) */

@@ -970,6 +970,49 @@ def test_set_series_checks_the_order_on_the_device_and_follows_the_chunking():
         plan4.close()
 
 
+def test_an_unsorted_series_is_rejected_whatever_else_the_batch_holds():
+    """a NaN time in one series must not hide an unsorted series elsewhere (the reference's
+    ``np.any(np.diff(t) < 0)``, celerite.py:126-129, raises on the negative step, NaN or not) -- in a single plan and
+    across shards, whichever shard holds which; a NaN alone is not "unsorted" (the reference accepts it too and the
+    evaluation reports a non-finite result for that problem only).  A rejected ``set_series`` leaves the plan without a
+    series: the previous one is not resurrected."""
+    B, N, JR, JC = 6, 3000, 1, 1
+    case = synthetic(B, N, JR, JC, "bench", seed=77)
+    ndev = batch.device_count()
+    good = (case["t"], case["diag"], case["y"])
+    nan_only = case["t"].copy(); nan_only[4, 100] = np.nan
+    nan_then_unsorted = nan_only.copy(); nan_then_unsorted[1, 2000] = nan_then_unsorted[1, 1999] - 1e-7
+    unsorted_then_nan = case["t"].copy(); unsorted_then_nan[0, 5] = unsorted_then_nan[0, 4] - 1e-7; unsorted_then_nan[5, 7] = np.nan
+    same_series = case["t"].copy(); same_series[2, 10] = np.nan; same_series[2, 500] = same_series[2, 499] - 1e-7
+    for make in (lambda: batch.BatchedGP(B, N, JR, JC),
+                 lambda: batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(3)])):
+        plan = make()
+        try:
+            plan.set_series(*good)
+            plan.set_coefficients(*coeffs_of(case))
+            want = plan.log_likelihood()
+            for bad in (nan_then_unsorted, unsorted_then_nan, same_series):
+                with pytest.raises(ValueError, match="sorted"):
+                    plan.set_series(bad, case["diag"], case["y"])
+                with pytest.raises(RuntimeError):          # no series: the old one is gone, the bad one dropped
+                    plan.log_likelihood()
+            plan.set_series(nan_only, case["diag"], case["y"])   # accepted, as by the reference
+            plan.set_coefficients(*coeffs_of(case))
+            ll, ld, q, st = plan.log_likelihood()
+            ok = np.arange(B) != 4
+            # (NaN bounds select the conservative kernels -- library sincos, no lazy decay: equal to rounding, not bitwise)
+            assert np.max(np.abs(ld[ok] - want[1][ok]) / np.abs(want[1][ok])) <= 1e-12
+            assert np.max(np.abs(q[ok] - want[2][ok]) / np.abs(want[2][ok])) <= 1e-12
+            assert not np.isfinite(ll[4])
+            plan.set_series(*good)
+            plan.set_coefficients(*coeffs_of(case))
+            again = plan.log_likelihood()
+            for a, b in zip(want, again):
+                assert np.array_equal(a, b)
+        finally:
+            plan.close()
+
+
 def test_sharding_a_batch_with_mixed_warm_eligibility():
     """The warm-started recurrence adapts per plan (activation when half of the plan's problems are eligible), so a
     batch in which half of the series forget their past may take it in one sharding and the scan in another: statuses

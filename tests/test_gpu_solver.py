@@ -494,6 +494,49 @@ def test_nyquist_singularity():  # tests/test_celerite.py:501-525
     assert np.allclose(ll, llgp)
 
 
+# ---- BASELINE configs[0] as BASELINE words it ------------------------------------
+def test_config0_gp_log_likelihood_against_the_oracle():
+    """BASELINE configs[0]: one series of N = 1000 samples, 1 real + 1 SHO term (width 3), ``GP.log_likelihood`` on the
+    tests/test_celerite.py path (:311-404: kernel -> GP -> compute -> log_likelihood).  The HIP product is driven
+    through ``terms.RealTerm + terms.SHOTerm -> GP.compute -> GP.log_likelihood``; the comparator is the CPU oracle
+    (``ref.RefSolver``: cholesky.h:41-210, :326-401) on the very arrays the GP hands to its solver, at 1e-10; the
+    batched entry on a table of draws of the same kernel is held against the oracle as well (not against the object
+    API)."""
+    from celerite_amd import batch
+    N = 1000
+    kernel = terms.RealTerm(log_a=0.1, log_c=0.5) + terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.5)
+    assert kernel.coefficients[0].size == 1 and kernel.coefficients[2].size == 1   # width 3: Q >= 1/2 -> one complex pair
+    rng = np.random.RandomState(1000)
+    t = np.sort(rng.uniform(0, 50, N))
+    yerr = rng.uniform(0.1, 0.3, N)
+    y = np.sin(t) + yerr * rng.randn(N)
+    gp = GP(kernel)
+    gp.compute(t, yerr)
+    ll = gp.log_likelihood(y)
+    r = ref.RefSolver()
+    r.compute(kernel.jitter, *kernel.coefficients, *NO_GENERAL, t, yerr ** 2)
+    ld0, q0 = r.log_determinant(), r.dot_solve(y)
+    ll0 = -0.5 * (q0 + ld0 + N * np.log(2.0 * np.pi))
+    assert rel(gp.solver.log_determinant(), ld0) <= REL
+    assert rel(gp.solver.dot_solve(y), q0) <= REL
+    assert rel(ll, ll0) <= REL
+    # a second draw of the hyper-parameters through the same GP (recompute-if-dirty, celerite.py:160-178)
+    p = gp.get_parameter_vector()
+    gp.set_parameter_vector(p + 0.05)
+    r.compute(kernel.jitter, *kernel.coefficients, *NO_GENERAL, t, yerr ** 2)
+    ll1 = -0.5 * (r.dot_solve(y) + r.log_determinant() + N * np.log(2.0 * np.pi))
+    assert rel(gp.log_likelihood(y), ll1) <= REL
+    # the batched entry over a table of draws: every draw against the oracle
+    draws = p[None, :] + 0.05 * rng.randn(8, len(p))
+    tab = batch.kernel_coefficient_table(kernel, draws)
+    llb, ldb, qb, st = batch.batch_log_likelihood(*tab[:6], t, yerr ** 2, y, jitter=tab[6])
+    assert (st == 0).all()
+    for i in range(len(draws)):
+        gp.set_parameter_vector(draws[i])
+        r.compute(kernel.jitter, *kernel.coefficients, *NO_GENERAL, t, yerr ** 2)
+        assert rel(ldb[i], r.log_determinant()) <= REL and rel(qb[i], r.dot_solve(y)) <= REL
+
+
 # ---- golden value and 1e-10 parity -----------------------------------------------
 def test_first_tutorial_known_answer():  # docs/tutorials/first.rst:24-31,74-101
     t, yerr, y = first_tutorial_case()
