@@ -411,6 +411,57 @@ class BatchedGP(object):
         1 the row-major arrays staged through LDS, -1 auto (``clr_batch_set_replay_source``)."""
         _check(_load().clr_batch_set_replay_source(self._h, int(source)))
 
+    def set_rescue(self, mode=-1):
+        """Route-1 problems (ill-conditioned, checked chunked replay) re-planned as a small plan of their own with many
+        short chunks (``clr_batch_set_rescue``): -1 automatic (chunks of >= 1024 samples), 0 the inline replay, 1 always."""
+        lib = _load()
+        lib.clr_batch_set_rescue.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.clr_batch_set_rescue(self._h, int(mode)))
+
+    def rescue(self):
+        """Of the last fetched evaluation: problems re-planned (negative: replayed inline), running total, the side
+        plan's chunking."""
+        lib = _load()
+        last, total, nc, L = C.c_int(), C.c_long(), C.c_int(), C.c_int()
+        lib.clr_batch_get_rescue.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _check(lib.clr_batch_get_rescue(self._h, C.byref(last), C.byref(total), C.byref(nc), C.byref(L)))
+        return {"last": last.value, "total": total.value, "chunks": (nc.value, L.value)}
+
+    FACTOR_LAYOUTS = {"reference": 0, "lean": 1}
+
+    def set_factor_layout(self, layout="reference"):
+        """What a materialising run keeps in HBM (``clr_batch_set_factor_layout``): ``"reference"`` -- phi, u, W, D,
+        ``8 N (3 J + 1)`` bytes per problem -- or ``"lean"`` -- W and D only, ``8 N (J + 1)`` bytes; phi and u are pure
+        functions of the times and the coefficients (cholesky.h:127-147) and :meth:`factor` regenerates them."""
+        lib = _load()
+        lib.clr_batch_set_factor_layout.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.clr_batch_set_factor_layout(self._h, self.FACTOR_LAYOUTS.get(layout, layout)))
+
+    def factor_bytes(self):
+        """Bytes of factor per problem in HBM under the layout and chunking in force."""
+        lib = _load()
+        n = C.c_size_t()
+        lib.clr_batch_get_factor_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        _check(lib.clr_batch_get_factor_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_materialize_pipeline(self, groups=0, summarize_cus=0, summarize_streams=1):
+        """Materialising runs as a pipeline over ``groups`` groups of problems (``clr_batch_set_materialize_pipeline``):
+        the summarize of one group beside the replay of the previous one, on streams owning ``summarize_cus`` /
+        the remaining compute units.  ``groups=0`` switches it off."""
+        lib = _load()
+        lib.clr_batch_set_materialize_pipeline.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _check(lib.clr_batch_set_materialize_pipeline(self._h, int(groups), int(summarize_cus), int(summarize_streams)))
+
+    def cu_census(self, which=0):
+        """Distinct compute units per XCD a grid reaches on the plan's stream (0), the pipeline's summarize stream (1)
+        or its replay stream (2) (``clr_batch_debug_cu_census``)."""
+        lib = _load()
+        out = (C.c_int * 8)()
+        lib.clr_batch_debug_cu_census.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        _check(lib.clr_batch_debug_cu_census(self._h, int(which), out))
+        return list(out)
+
     def set_exact(self, force=True):
         """Replay every problem step by step (the reference's recurrence) instead
         of settling it from the chunk summaries; for A/B runs and cross-checks."""

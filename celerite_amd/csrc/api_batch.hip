@@ -4,6 +4,8 @@
 
 extern "C" {
 
+static void mp_release(clr_batch* h);
+
 /* ---- batched log-likelihood ---------------------------------------------------- */
 clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
   if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) {
@@ -41,6 +43,10 @@ void clr_batch_destroy(clr_batch* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  mp_release(h);
+  if (h->rescue) clr_batch_destroy(h->rescue);
+  h->rescue = nullptr;
+  if (h->rescue_idx) (void)hipFree(h->rescue_idx);
   for (DevBuf* b : {&h->coeffs, &h->t, &h->diag, &h->y, &h->tT, &h->dT, &h->yT,
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
@@ -283,6 +289,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   // succeeded (a failed upload must not leave have_series set over half-written arrays), and nothing derived from
   // the old one -- interleaved copies, warm-up spans and their selection -- survives
   h->have_series = false;
+  h->factor_inputs_changed = true;
   h->warm_active = false;
   h->warm_span.clear();
   h->relayout_pending = true;
@@ -401,6 +408,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   if (st != CLR_OK) return st;
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems of the evaluation in flight: at ITS coefficients)
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
+  h->factor_inputs_changed = true;
   h->dmax = 0.0;
   h->cmax = 0.0;
   for (size_t i = 0; i < nc; ++i) {
@@ -456,6 +464,7 @@ int clr_batch_set_exact(clr_batch* h, int force) {
 int clr_batch_get_exact_count(clr_batch* h, int* count) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems are settled first: their routes too)
   if (!count) return fail(CLR_INVALID_ARGUMENT, "count is null");
   if (h->nchunk < 2 || h->force_exact) {  // every problem went through the reference recurrence
     *count = h->B;
@@ -475,6 +484,7 @@ int clr_batch_get_exact_count(clr_batch* h, int* count) {
 int clr_batch_get_exact_flags(clr_batch* h, int* flags) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems are settled first: their routes too)
   if (!flags) return fail(CLR_INVALID_ARGUMENT, "flags is null");
   if (h->nchunk < 2) {
     for (int b = 0; b < h->B; ++b) flags[b] = 2;  // one chunk: the replay from the zero state is the recurrence
@@ -943,6 +953,199 @@ static int warm_fallback(clr_batch* h) {
   return CLR_OK;
 }
 
+
+// ---- materialising runs as a pipeline over groups of problems ---------------------------------------------------
+// The materialising step is a fp64-VALU-bound pass (summarize: the chunk elements) followed by an HBM-bound one
+// (replay: 8 N (3 J + 1) bytes of factor per problem).  Back to back on one stream they add up -- 2.2 + 3.8 ms at the
+// headline shape, 48 % of the HBM roofline for the whole step.  Here the batch is cut into G contiguous groups of
+// problems; the summarize of group g + 1 runs while group g is replayed, on streams that own DISJOINT sets of compute
+// units (hipExtStreamCreateWithCUMask): the role-split summarize fills a CU completely (2 x 256 registers per SIMD,
+// 160 KB of LDS), so without the masks concurrency only serialises whole kernels.  The prefix and the corrections of
+// a group (small, latency-bound) run on a third, unmasked stream between the two.
+static void mp_release(clr_batch* h) {
+  for (hipStream_t s : h->mp_s) if (s) (void)hipStreamDestroy(s);
+  h->mp_s.clear();
+  if (h->mp_p) (void)hipStreamDestroy(h->mp_p);
+  if (h->mp_r) (void)hipStreamDestroy(h->mp_r);
+  h->mp_p = h->mp_r = nullptr;
+  for (hipEvent_t e : h->mp_ev) (void)hipEventDestroy(e);
+  h->mp_ev.clear();
+}
+
+// CU `i` of the mask belongs to the summarize set iff ((i / 8) + (i % 8)) % 16 < k: whichever way the runtime numbers
+// the mask bits over the 8 XCDs (round-robin or XCD-major) both sets are spread over every XCD -- each XCD's L2 and
+// fabric port then carry their share of the replay's stores.
+static void mp_masks(int total_cus, int summarize_cus, std::vector<uint32_t>& ms, std::vector<uint32_t>& mr) {
+  const int words = (total_cus + 31) / 32, k = summarize_cus / 16;
+  ms.assign(words, 0u);
+  mr.assign(words, 0u);
+  for (int i = 0; i < total_cus; ++i) {
+    const bool sset = ((i / 8) + (i % 8)) % 16 < k;
+    (sset ? ms : mr)[i / 32] |= 1u << (i % 32);
+  }
+}
+
+static int mp_prepare(clr_batch* h) {
+  const int G = h->mp_groups;
+  if (!h->mp_s.empty() && (int)h->mp_ev.size() == 2 * G + 2) return CLR_OK;
+  mp_release(h);
+  int ncu = 0;
+  HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+  std::vector<uint32_t> ms, mr;
+  const bool masked = h->mp_cus >= 16 && h->mp_cus <= ncu - 16;
+  if (masked) mp_masks(ncu, h->mp_cus, ms, mr);
+  h->mp_s.assign((size_t)h->mp_nstreams, nullptr);
+  for (hipStream_t& s : h->mp_s) {
+    if (masked) HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)ms.size(), ms.data()));
+    else HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  }
+  if (masked) HIP_TRY(hipExtStreamCreateWithCUMask(&h->mp_r, (uint32_t)mr.size(), mr.data()));
+  else HIP_TRY(hipStreamCreateWithFlags(&h->mp_r, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->mp_p, hipStreamNonBlocking));
+  h->mp_ev.assign((size_t)2 * G + 2, nullptr);
+  for (hipEvent_t& e : h->mp_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return CLR_OK;
+}
+
+// the kernels' view of problems [b0, b0 + Bg) of the plan: every per-problem pointer advanced, B = Bg (the levels of the
+// multi-level prefix are laid out per view: [Bg][n_l] blocks back to back inside the group's own region)
+static clr::BatchParams group_view(const clr_batch* h, const clr::BatchParams& P, int b0, int Bg) {
+  clr::BatchParams G = P;
+  const size_t o = (size_t)b0, JR = (size_t)h->J_real, JC = (size_t)h->J_comp, J = (size_t)h->J, nc = (size_t)P.nchunk;
+  const size_t E = (size_t)h->launch->elem_doubles, S = (size_t)h->launch->start_doubles, cells = (size_t)P.L * nc;
+  G.B = Bg;
+  G.jitter += o; G.a_real += o * JR; G.c_real += o * JR;
+  G.a_comp += o * JC; G.b_comp += o * JC; G.c_comp += o * JC; G.d_comp += o * JC;
+  G.t += (long)o * P.t_stride; G.diag += (long)o * P.diag_stride; G.y += (long)o * P.y_stride;
+  G.elems += o * nc * E; G.starts += o * nc * S;
+  G.part += o * nc * 2; G.partx += o * nc * 2;
+  if (G.cond) G.cond += o * nc * 3;
+  if (G.egerr) G.egerr += o * nc;
+  G.flags += o * nc; G.flagsx += o * nc; G.need_exact += o;
+  size_t le = 0, ls = 0;
+  clr::multilevel_workspace(P.plan, (int)J, &le, &ls);
+  if (G.lvl_elems) G.lvl_elems += o * le;
+  if (G.lvl_starts) G.lvl_starts += o * ls;
+  if (G.phi) { G.phi += o * J * cells; G.u += o * J * cells; G.W += o * J * cells; G.D += o * cells; }
+  G.out_ll += o; G.out_logdet += o; G.out_quad += o; G.out_status += o;
+  G.only_pending = 0;
+  return G;
+}
+
+// replay mode of a materialising run: 2 the four arrays chunk-interleaved, 3 the lean layout (W, D only)
+static int replay_mode(const clr_batch* h, int materialize) {
+  return materialize ? (h->factor_layout == 1 ? 3 : 2) : 0;
+}
+
+static bool mp_runs(const clr_batch* h, int materialize) {
+  return materialize && h->launch && h->mp_groups >= 2 && h->nchunk > 1 && h->B >= h->mp_groups && h->J_general == 0;
+}
+
+static int materialize_pipeline(clr_batch* h, const clr::BatchParams& P) {
+  int st = mp_prepare(h);
+  if (st != CLR_OK) return st;
+  const int G = h->mp_groups;
+  const clr::BatchParams R = replay_view(h, P, 1);
+  HIP_TRY(hipEventRecord(h->mp_ev[0], h->stream));  // (whatever the plan's stream holds -- uploads, the relayout -- comes first)
+  for (hipStream_t s : h->mp_s) HIP_TRY(hipStreamWaitEvent(s, h->mp_ev[0], 0));
+  HIP_TRY(hipStreamWaitEvent(h->mp_p, h->mp_ev[0], 0));
+  HIP_TRY(hipStreamWaitEvent(h->mp_r, h->mp_ev[0], 0));
+  for (int g = 0; g < G; ++g) {
+    int lo = 0, hi = 0;
+    clr_shard_bounds(h->B, G, g, &lo, &hi);
+    const clr::BatchParams Pg = group_view(h, P, lo, hi - lo), Rg = group_view(h, R, lo, hi - lo);
+    hipStream_t ss = h->mp_s[(size_t)g % h->mp_s.size()];
+    h->launch->summarize(Pg, ss);
+    HIP_TRY(hipEventRecord(h->mp_ev[1 + 2 * g], ss));
+    HIP_TRY(hipStreamWaitEvent(h->mp_p, h->mp_ev[1 + 2 * g], 0));
+    h->launch->prefix(Pg, h->mp_p);
+    h->launch->correct(Pg, h->mp_p);
+    HIP_TRY(hipEventRecord(h->mp_ev[2 + 2 * g], h->mp_p));
+    HIP_TRY(hipStreamWaitEvent(h->mp_r, h->mp_ev[2 + 2 * g], 0));
+    h->launch->replay(Rg, replay_mode(h, 1), h->mp_r);
+    h->launch->sequential(Pg, replay_mode(h, 1), h->mp_r);
+  }
+  HIP_TRY(hipEventRecord(h->mp_ev[2 * G + 1], h->mp_r));  // (the replay stream's last group closes every chain of events)
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->mp_ev[2 * G + 1], 0));
+  h->factor_is_lean = h->factor_layout == 1;
+  h->factor_inputs_changed = false;
+  clr::launch_finalize(P, h->stream);
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
+int clr_batch_set_rescue(clr_batch* h, int mode) {
+  if (mode < -1 || mode > 1) return fail(CLR_INVALID_ARGUMENT, "rescue mode: -1 (auto), 0 (inline chunked replay) or 1 (whenever possible)");
+  int st = warm_resolve(h, nullptr);
+  if (st != CLR_OK) return st;
+  h->rescue_mode = mode;
+  return CLR_OK;
+}
+
+int clr_batch_get_rescue(const clr_batch* h, int* last_count, long* total, int* nchunk, int* chunk_len) {
+  if (last_count) *last_count = h->rescue_last;
+  if (total) *total = h->rescue_total;
+  if (nchunk) *nchunk = h->rescue ? h->rescue->nchunk : 0;
+  if (chunk_len) *chunk_len = h->rescue ? h->rescue->L : 0;
+  return CLR_OK;
+}
+
+int clr_batch_set_factor_layout(clr_batch* h, int layout) {
+  if (layout != 0 && layout != 1) return fail(CLR_INVALID_ARGUMENT, "factor layout: 0 (phi, u, W, D) or 1 (lean: W, D)");
+  if (layout == 1 && !h->launch) return fail(CLR_UNSUPPORTED, "the lean factor layout covers widths 1..8 (wider plans write the reference's storage)");
+  if (layout != h->factor_layout) h->have_factor = false;
+  h->factor_layout = layout;
+  return CLR_OK;
+}
+
+int clr_batch_get_factor_bytes(const clr_batch* h, size_t* bytes_per_problem) {
+  if (!bytes_per_problem) return fail(CLR_INVALID_ARGUMENT, "bytes_per_problem is null");
+  const size_t cells = h->launch ? (size_t)h->L * h->nchunk : (size_t)h->N, J = (size_t)h->J;
+  *bytes_per_problem = 8 * cells * ((h->launch && h->factor_layout == 1) ? (J + 1) : (3 * J + 1));
+  return CLR_OK;
+}
+
+int clr_batch_set_materialize_pipeline(clr_batch* h, int groups, int summarize_cus, int summarize_streams) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (groups < 0 || groups == 1 || groups > 64 || summarize_cus < 0 || summarize_streams < 1 || summarize_streams > 8)
+    return fail(CLR_INVALID_ARGUMENT, "materialize pipeline: groups 0 (off) or 2..64, summarize_cus >= 0, 1..8 summarize streams");
+  if (!h->launch && groups) return fail(CLR_UNSUPPORTED, "the materialising pipeline covers widths 1..8");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (hipStream_t s : h->mp_s) if (s) HIP_TRY(hipStreamSynchronize(s));
+  mp_release(h);
+  h->mp_groups = groups;
+  h->mp_cus = (summarize_cus / 16) * 16;
+  h->mp_nstreams = summarize_streams;
+  return CLR_OK;
+}
+
+int clr_batch_debug_cu_census(clr_batch* h, int which, int* cus_per_xcc /* [8] */) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!cus_per_xcc || which < 0 || which > 2) return fail(CLR_INVALID_ARGUMENT, "cu census: which = 0 (plan), 1 (summarize), 2 (replay)");
+  hipStream_t s = h->stream;
+  if (which > 0) {
+    if (h->mp_groups < 2) return fail(CLR_INVALID_ARGUMENT, "cu census: no materialising pipeline is set");
+    if ((st = mp_prepare(h)) != CLR_OK) return st;
+    s = which == 1 ? h->mp_s[0] : h->mp_r;
+  }
+  int* seen = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&seen), 8 * 256 * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(seen, 0, 8 * 256 * sizeof(int), s));
+  clr::launch_cu_census(seen, 8192, 20000, s);
+  std::vector<int> host(8 * 256);
+  HIP_TRY(hipMemcpyAsync(host.data(), seen, host.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(seen);
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    for (int c = 0; c < 256; ++c) n += host[(size_t)x * 256 + c] > 0;
+    cus_per_xcc[x] = n;
+  }
+  return CLR_OK;
+}
+
 int clr_batch_enqueue(clr_batch* h, int materialize) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
@@ -960,6 +1163,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     ev = &h->prof_events[(size_t)h->prof_steps * (PROF_NK + 1)];
     ++h->prof_steps;
   }
+  if (!P.defer_level1) h->rescue_last = 0;  // (nothing is re-planned behind this evaluation)
   const bool all_marks = h->prof_on != 2;
   auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
   h->evaluated = true;
@@ -995,12 +1199,14 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (!h->launch) {
     mark(0);
     wide_launch(h, P, ev);
+    h->rescue_inflight = P.defer_level1 != 0;
     HIP_TRY(hipGetLastError());
     return CLR_OK;
   }
   mark(0);
   h->warm_inflight = false;
   h->small_inflight = false;
+  h->rescue_inflight = false;
   if (!warm_runs(h, materialize) && small_runs(h, materialize)) {
     clr::BatchParams Sp;
     h->in_fallback = true;  // (the row-major arrays)
@@ -1032,6 +1238,12 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     return CLR_OK;
   }
   if (h->relayout_pending && batch_relayout(h)) h->relayout_pending = false;
+  if (mp_runs(h, materialize)) {  // groups of problems: summarize of one beside the replay of the previous (above)
+    mark(1); mark(2); mark(3); mark(4);
+    if ((st = materialize_pipeline(h, P)) != CLR_OK) return st;
+    mark(5); mark(6);
+    return CLR_OK;
+  }
   mark(1);
   h->launch->summarize(P, h->stream);
   mark(2);
@@ -1039,11 +1251,13 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   mark(3);
   h->launch->correct(P, h->stream);  // (also on forced-exact runs: flags + conditioning record)
   mark(4);
-  h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);  // forced-exact / materialising runs only
-  h->launch->sequential(P, materialize ? 2 : 0, h->stream);  // flagged / ill-conditioned problems only
+  h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);  // forced-exact / materialising runs only
+  h->launch->sequential(P, replay_mode(h, materialize), h->stream);  // flagged / ill-conditioned problems only
+  if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; }
   mark(5);
   clr::launch_finalize(P, h->stream);
   mark(6);
+  h->rescue_inflight = P.defer_level1 != 0;
   // (capturing these five launches in a hipGraph was measured: no gain -- the gaps between
   //  dependent kernels are on the device side; profiles/r01r_small_batches.log)
   HIP_TRY(hipGetLastError());
@@ -1080,6 +1294,114 @@ int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms)
   return CLR_OK;
 }
 
+// ---- level-1 problems re-planned as a small plan of their own ----------------------------------
+// The evaluation left the problems its conditioning record sends to the checked chunked replay PENDING (defer_runs,
+// finalize_kernel).  Their checked replay is three passes -- summarize, prefix, replay + end-state check -- over the
+// chunks of a plan sized for THEM: n problems cut into ~1024 / n chunks each, so that the chip is full and a chunk is a
+// tenth of the parent's.  Same routes, same certificates (a side plan runs forced-exact: every chunk replayed from its
+// scanned start state and checked, mismatches go to its own sequential recurrence), cholesky.h:176 semantics included.
+static int rescue_inline(clr_batch* h) {
+  // too many pending problems for a side plan to pay: the inline chunked replay after all (the flow's own tail)
+  clr::BatchParams P;
+  int st = batch_params(h, 0, P);
+  if (st != CLR_OK) return st;
+  P.defer_level1 = 0;
+  if (!h->launch) {
+    clr::launch_wide_loglike(P, h->J_real, h->J_comp, h->stream);
+    clr::launch_wide_check_replay(P, h->stream);
+    clr::launch_finalize(P, h->stream);
+    clr::BatchParams S = P;
+    S.nchunk = 1; S.L = P.N; S.L0 = 0; S.seq_only = 1; S.force_exact = 1;
+    clr::launch_wide_loglike(S, h->J_real, h->J_comp, h->stream);
+  } else {
+    h->launch->replay(replay_view(h, P, 0), 0, h->stream);
+    h->launch->sequential(P, 0, h->stream);
+    clr::launch_finalize(P, h->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
+static int rescue_run(clr_batch* h, const std::vector<int>& idx) {
+  const int n = (int)idx.size();
+  h->rescue_total += n;
+  if (n > std::max(1, h->B / 4) || n > 256) {
+    h->rescue_last = -n;
+    return rescue_inline(h);
+  }
+  h->rescue_last = n;
+  int st;
+  if (!h->rescue || h->rescue->B != n) {
+    if (h->rescue) clr_batch_destroy(h->rescue);
+    h->rescue = clr_batch_create(n, h->N, h->J_real, h->J_comp, h->device);
+    if (!h->rescue) return CLR_HIP_ERROR;
+    clr_batch* r = h->rescue;
+    r->is_rescue_plan = true;
+    r->force_exact = 1;
+    r->warm_mode = 0;
+    r->small_mode = 0;
+    int nchunk = 0;
+    if (!h->launch) {  // wide: B x nchunk <= the parallel prefix's cap (1024 workgroups per level at width 32, 2048 below)
+      const int JP = h->J <= 16 ? 16 : 32;
+      nchunk = std::min(clr::wide_prefix_scan_cap(JP) / n, clr::wide_prefix_scan_max_chunks(JP));
+      nchunk = std::min(nchunk, h->N / (JP == 16 ? 64 : 96));
+      if (nchunk < 8) nchunk = 0;  // (short series: the plan's own choice)
+    } else {
+      nchunk = auto_chunks(n, h->N, h->J, true);
+    }
+    if ((st = clr_batch_set_chunks(r, nchunk)) != CLR_OK) return st;
+  }
+  clr_batch* r = h->rescue;
+  // the parent's settings that decide routes and kernels
+  r->cert_resid = h->cert_resid; r->cert_gamma = h->cert_gamma; r->cert_gamma_abs = h->cert_gamma_abs; r->cert_eg = h->cert_eg;
+  r->force_library_trig = h->force_library_trig;
+  r->floor_tmax = sel_max(h->tmax, h->floor_tmax); r->floor_dxmax = sel_max(h->dxmax, h->floor_dxmax);
+  r->floor_dmax = sel_max(h->dmax, h->floor_dmax); r->floor_cmax = sel_max(h->cmax, h->floor_cmax);
+  r->tmax = h->tmax; r->dxmax = h->dxmax; r->dmax = h->dmax; r->cmax = h->cmax; r->dtmin = h->dtmin;
+  if ((size_t)n > h->rescue_idx_cap) {
+    if (h->rescue_idx) (void)hipFree(h->rescue_idx);
+    h->rescue_idx = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rescue_idx), (size_t)n * sizeof(int)));
+    h->rescue_idx_cap = (size_t)n;
+  }
+  HIP_TRY(hipStreamSynchronize(r->stream));
+  HIP_TRY(hipMemcpyAsync(h->rescue_idx, idx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, r->stream));
+  HIP_TRY(hipStreamSynchronize(r->stream));  // (pageable source)
+  // series and coefficients of the n problems, device to device (the parent's stream is idle: warm_resolve synchronised it)
+  const size_t N = (size_t)h->N;
+  struct { DevBuf* src; DevBuf* dst; long stride; long* sub_stride; } arrs[3] = {
+      {&h->t, &r->t, h->t_stride, &r->t_stride}, {&h->diag, &r->diag, h->diag_stride, &r->diag_stride}, {&h->y, &r->y, h->y_stride, &r->y_stride}};
+  for (auto& a : arrs) {
+    if (a.stride == 0) {  // one series shared by all problems: shared by the side plan's too
+      if ((st = a.dst->reserve(N)) != CLR_OK) return st;
+      HIP_TRY(hipMemcpyAsync(a.dst->p, a.src->p, N * sizeof(double), hipMemcpyDeviceToDevice, r->stream));
+      *a.sub_stride = 0;
+    } else {
+      if ((st = a.dst->reserve((size_t)n * N)) != CLR_OK) return st;
+      clr::launch_gather_series(a.src->p, a.stride, a.dst->p, h->rescue_idx, n, h->N, r->stream);
+      *a.sub_stride = (long)N;
+    }
+  }
+  r->have_series = true;
+  r->relayout_pending = true;
+  r->warm_copy_pending = true;
+  r->grad_span_valid = false;
+  r->factor_inputs_changed = true;
+  const size_t total = (size_t)n * (2 * h->J_real + 4 * h->J_comp + 1);
+  if ((st = r->coeffs.reserve(total)) != CLR_OK) return st;
+  clr::launch_gather_coeffs(h->coeffs.p, r->coeffs.p, h->rescue_idx, h->B, n, h->J_real, h->J_comp, r->stream);
+  r->host_cmin.assign((size_t)n, 0.0);
+  r->host_cmax.assign((size_t)n, h->cmax);
+  r->host_jitter.assign((size_t)n, 0.0);
+  r->have_coeffs = true;
+  if ((st = clr_batch_enqueue(r, 0)) != CLR_OK) return st;
+  const size_t pc = (size_t)n * r->nchunk, pcp = (size_t)h->B * h->nchunk;
+  clr::launch_scatter_results(r->out.p, r->flags + 2 * pc, n, h->out.p, h->flags + 2 * pcp, h->B, h->rescue_idx, r->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(r->stream));
+  return CLR_OK;
+}
+
 // Problems the warm path could not settle (boundary mismatch, flagged pivot, not eligible) carry a pending status
 // until the scan pipeline has run for them.  That pipeline reads the plan's CURRENT coefficients, series and
 // chunking, so it must run before any of them changes: every state-changing entry point, clr_batch_synchronize and
@@ -1087,12 +1409,13 @@ int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms)
 // results (ll | logdet | quad | status) of this evaluation.
 static int warm_resolve(clr_batch* h, bool* pin_current) {
   if (pin_current) *pin_current = false;
-  if (!h->warm_inflight && !h->small_inflight) return CLR_OK;
+  if (!h->warm_inflight && !h->small_inflight && !h->rescue_inflight) return CLR_OK;
   // (the one-launch path of short narrow problems leaves pending problems the same way, but its outcome says nothing
   //  about the warm-up lengths: the warm path's statistics and its adaptation are not touched on its behalf)
-  const bool was_warm = h->warm_inflight;
+  const bool was_warm = h->warm_inflight, was_rescue = h->rescue_inflight;
   h->warm_inflight = false;
   h->small_inflight = false;
+  h->rescue_inflight = false;
   const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
   int st;
   if ((st = reserve_pinned(h, words)) != CLR_OK) return st;
@@ -1104,6 +1427,19 @@ static int warm_resolve(clr_batch* h, bool* pin_current) {
   if (was_warm) {
     h->warm_fallbacks = pending;
     h->warm_settled = (int)B - pending;
+  }
+  if (was_rescue) {
+    // the scan pipeline itself ran: what is pending are its level-1 problems, re-planned with short chunks
+    h->rescue_last = 0;
+    if (pending) {
+      std::vector<int> idx;
+      for (size_t b = 0; b < B; ++b) if (stw[b] == clr::CLR_PENDING_STATUS) idx.push_back((int)b);
+      if ((st = rescue_run(h, idx)) != CLR_OK) return st;
+      HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (pin_current) *pin_current = true;
+    return CLR_OK;
   }
   if (pending) {
     if ((st = warm_fallback(h)) != CLR_OK) return st;
@@ -1170,6 +1506,16 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   if ((st = h->fu.reserve(J * Nm1)) != CLR_OK) return st;
   if ((st = h->fW.reserve(J * N)) != CLR_OK) return st;
   if ((st = h->fD.reserve(N)) != CLR_OK) return st;
+  if (h->factor_is_lean && h->factor_inputs_changed)
+    return fail(CLR_NOT_COMPUTED, "the lean factor's phi and u are regenerated from the plan's series and coefficients, "
+                                  "which were replaced after the materialising run: materialise again");
+  if (h->factor_is_lean) {
+    // the lean layout holds W and D; phi and u are regenerated from the plan's times and the coefficients in force --
+    // which must still be the ones of the materialising run (any change drops the factor: have_factor)
+    clr::BatchParams P;
+    if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+    h->launch->expand(P, p, h->t.p + (size_t)p * (size_t)h->t_stride, h->fphi.p, h->fu.p, h->fW.p, h->fD.p, h->stream);
+  } else
   clr::launch_deinterleave_factor(h->phi.p + p * J * cells, h->u.p + p * J * cells,
                                   h->W.p + p * J * cells, h->D.p + p * cells, h->fphi.p, h->fu.p,
                                   h->fW.p, h->fD.p, h->N, h->J, h->L, h->nchunk, h->stream);
@@ -1200,6 +1546,10 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[0], h->stream));
     if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
       wide_launch(h, P, e);
+      // (a plan that re-planned level-1 problems at its last evaluation does so inside every timed step: the step's
+      //  time then includes the side plan -- at the price of a host round trip per step)
+      if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; HIP_TRY(hipEventRecord(e[6], h->stream)); }
+      else h->rescue_inflight = P.defer_level1 != 0;
       continue;
     }
     if (!warm_runs(h, materialize) && small_runs(h, materialize)) {  // (one launch, in the "summarize" slot)
@@ -1230,6 +1580,13 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
       continue;
     }
     if (relayout_each_step) batch_relayout(h);
+    if (mp_runs(h, materialize)) {  // (the whole pipeline in the "replay" slot)
+      for (int j = 1; j <= 4; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));
+      if ((st = materialize_pipeline(h, P)) != CLR_OK) return st;
+      HIP_TRY(hipEventRecord(e[5], h->stream));
+      HIP_TRY(hipEventRecord(e[6], h->stream));
+      continue;
+    }
     HIP_TRY(hipEventRecord(e[1], h->stream));
     h->launch->summarize(P, h->stream);
     HIP_TRY(hipEventRecord(e[2], h->stream));
@@ -1237,10 +1594,13 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[3], h->stream));
     h->launch->correct(P, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
-    h->launch->replay(replay_view(h, P, materialize), materialize ? 2 : 0, h->stream);
-    h->launch->sequential(P, materialize ? 2 : 0, h->stream);
+    h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);
+    h->launch->sequential(P, replay_mode(h, materialize), h->stream);
+    if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; }
     HIP_TRY(hipEventRecord(e[5], h->stream));
     clr::launch_finalize(P, h->stream);
+    if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; }
+    else h->rescue_inflight = P.defer_level1 != 0;
     HIP_TRY(hipEventRecord(e[6], h->stream));
   }
   if (relayout_each_step && !warm_runs(h, materialize) && (h->layout == 1 || split_active(h)) && h->nchunk > 1)

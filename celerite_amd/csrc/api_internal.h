@@ -285,8 +285,27 @@ struct clr_batch {
   DevBuf elems, starts, part, partx, cond, out;  // out: ll | logdet | quad | status (B ints)
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int force_exact = 0;
+  int factor_layout = 0;      // clr_batch_set_factor_layout: 0 the reference's four arrays, 1 lean (W, D; phi, u regenerated)
+  bool factor_is_lean = false;  // what the factor in HBM holds (set by the materialising run that wrote it)
+  bool factor_inputs_changed = false;  // series or coefficients replaced since that run (a lean factor can then no longer be expanded)
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
   DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
+  // materialising runs as a pipeline over groups of problems (clr_batch_set_materialize_pipeline): the summarize of
+  // group g + 1 (fp64-VALU-bound) runs beside the replay of group g (HBM-bound) on streams that own disjoint sets of CUs
+  int mp_groups = 0, mp_cus = 0, mp_nstreams = 1;
+  std::vector<hipStream_t> mp_s;        // summarize streams (CU-masked when mp_cus > 0)
+  hipStream_t mp_p = nullptr, mp_r = nullptr;  // prefix + corrections (any CU); replay (the other CUs)
+  std::vector<hipEvent_t> mp_ev;        // [0] start, [1 + 2 g] group g summarized, [2 + 2 g] its start states ready, [last] replay done
+  // problems the conditioning record sends to the checked chunked replay (level 1), re-planned as a small plan of their
+  // own with many short chunks instead of replaying long chunks sequentially beside an idle chip (clr_batch_set_rescue)
+  int rescue_mode = -1;            // -1 auto (chunks of >= 1024 samples), 0 off: the inline chunked replay, 1 whenever possible
+  bool rescue_inflight = false;    // the evaluation in flight deferred its level-1 problems (pending until resolved)
+  bool is_rescue_plan = false;     // this plan IS such a side plan (never defers)
+  struct clr_batch* rescue = nullptr;
+  int* rescue_idx = nullptr;       // device: the re-planned problems' indices
+  size_t rescue_idx_cap = 0;
+  int rescue_last = 0;             // problems of the last resolved evaluation that were re-planned (or replayed inline: negative)
+  long rescue_total = 0;
   // optional per-kernel HIP events around the launches of clr_batch_enqueue (clr_batch_set_profiling)
   int prof_on = 0, prof_steps = 0;
   std::vector<hipEvent_t> prof_events;  // 7 per recorded step
@@ -324,6 +343,18 @@ bool split_active(const clr_batch* h) {
   return h->summarize_mode < 0 && (h->J == 7 || (h->J == 8 && h->J_comp >= 2));
 }
 
+// Level-1 problems (ill-conditioned, not flagged) are left pending and re-planned with short chunks instead of being
+// replayed inline: when the plan's chunks are long enough that ONE such problem would cost the whole batch a sequential
+// chunk-time (config 4: +11 ms on 12.7; profiles/r04zz_wide_midbatch.txt) -- a re-plan is three passes over chunks a
+// tenth as long.  Never on forced-exact / materialising runs (they replay everything), inside the gradient's own
+// evaluation, behind the warm path, or on a side plan.
+bool defer_runs(const clr_batch* h, int materialize) {
+  if (h->rescue_mode == 0 || h->is_rescue_plan || materialize || h->force_exact || h->grad_scan_only || h->in_fallback) return false;
+  if (h->nchunk < 2 || h->J_general > 0 || h->B < 2) return false;
+  if (h->rescue_mode == 1) return true;
+  return h->L >= 1024;
+}
+
 int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   if (!h->have_series || !h->have_coeffs)
     return fail(CLR_INVALID_ARGUMENT, "set_series and set_coefficients must be called first");
@@ -332,8 +363,9 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     // widths 1..8: chunk-interleaved device layout (replay_chunk, MATERIALIZE == 2); widths 9..64: the wide kernels
     // write the reference's own storage per problem (wide_scan_kernel, MODE 0: phi, u [N-1][J], W [N][J], D [N])
     const size_t B = (size_t)h->B, J = (size_t)h->J, cells = h->launch ? (size_t)h->L * h->nchunk : (size_t)h->N;
-    if ((st = h->phi.reserve(B * J * cells)) != CLR_OK) return st;
-    if ((st = h->u.reserve(B * J * cells)) != CLR_OK) return st;
+    const bool lean = h->launch && h->factor_layout == 1;  // (phi and u are not stored: 8 N (J + 1) instead of 8 N (3 J + 1) bytes per problem)
+    if (!lean && (st = h->phi.reserve(B * J * cells)) != CLR_OK) return st;
+    if (!lean && (st = h->u.reserve(B * J * cells)) != CLR_OK) return st;
     if ((st = h->W.reserve(B * J * cells)) != CLR_OK) return st;
     if ((st = h->D.reserve(B * cells)) != CLR_OK) return st;
     h->have_factor = true;
@@ -409,6 +441,7 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     P.wKpad = h->wKpad; P.wrows = h->wrows;
   }
   P.only_pending = h->in_fallback ? 1 : 0;
+  P.defer_level1 = defer_runs(h, materialize) ? 1 : 0;
   P.wide_materialize = (materialize && !h->launch) ? 1 : 0;
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;

@@ -39,6 +39,15 @@ const BatchLaunchers* find_batch_launchers(int JR, int JC) {
 __global__ void __launch_bounds__(64) finalize_kernel(const BatchParams P) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (P.only_pending && P.need_scan[b] == 0) return;  // (settled and written by the warm path)
+  if (P.defer_level1 && !P.force_exact && P.need_exact[b] == 1) {
+    // ill-conditioned but not flagged: the checked replay was deferred -- the host re-plans this problem with many
+    // short chunks before results are handed out (api_batch.hip: rescue_run); until then its status says so
+    if (lane == 0) {
+      P.out_status[b] = CLR_PENDING_STATUS;
+      P.out_ll[b] = NAN; P.out_logdet[b] = NAN; P.out_quad[b] = NAN;
+    }
+    return;
+  }
   // replay-free sums unless the problem was marked for (or the run forces) the exact replay
   const bool exact = P.force_exact || P.need_exact[b] != 0;
   const double* part = exact ? P.partx : P.part;
@@ -166,4 +175,67 @@ void launch_relayout(const double* src, long src_stride, double* dst, long dst_s
   hipLaunchKernelGGL(relayout_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride,
                      N, L, nchunk, pad_kind);
 }
+// ---- re-planning of a few problems as a small plan of their own (api_batch.hip: rescue_run) ---------------------
+// series of the problems idx[0..n) of a plan -> rows 0..n of another plan's arrays (device to device)
+__global__ void __launch_bounds__(256) gather_series_kernel(const double* __restrict__ src, long src_stride,
+                                                            double* __restrict__ dst, const int* __restrict__ idx, int N) {
+  const int k = blockIdx.y;
+  const double* in = src + (long)idx[k] * src_stride;
+  double* out = dst + (long)k * N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) out[i] = in[i];
+}
+void launch_gather_series(const double* src, long src_stride, double* dst, const int* idx, int n, int N, hipStream_t s) {
+  hipLaunchKernelGGL(gather_series_kernel, dim3(std::min((N + 255) / 256, 64), n), dim3(256), 0, s, src, src_stride, dst, idx, N);
+}
+// coefficient tables a_real c_real [B][JR] | a_comp b_comp c_comp d_comp [B][JC] | jitter [B] -> the same layout for n problems
+__global__ void __launch_bounds__(64) gather_coeffs_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                           const int* __restrict__ idx, int B, int n, int JR, int JC) {
+  const int k = blockIdx.x, b = idx[k], per = 2 * JR + 4 * JC + 1;
+  for (int e = threadIdx.x; e < per; e += 64) {
+    long so, dofs;
+    if (e < 2 * JR) { const int blk = e / JR, j = e % JR; so = (long)blk * B * JR + (long)b * JR + j; dofs = (long)blk * n * JR + (long)k * JR + j; }
+    else if (e < 2 * JR + 4 * JC) {
+      const int q = e - 2 * JR, blk = q / JC, j = q % JC;
+      so = 2L * B * JR + (long)blk * B * JC + (long)b * JC + j;
+      dofs = 2L * n * JR + (long)blk * n * JC + (long)k * JC + j;
+    } else { so = 2L * B * JR + 4L * B * JC + b; dofs = 2L * n * JR + 4L * n * JC + k; }
+    dst[dofs] = src[so];
+  }
+}
+void launch_gather_coeffs(const double* src, double* dst, const int* idx, int B, int n, int JR, int JC, hipStream_t s) {
+  hipLaunchKernelGGL(gather_coeffs_kernel, dim3(n), dim3(64), 0, s, src, dst, idx, B, n, JR, JC);
+}
+// results (ll | logdet | quad | status) and route of the n re-planned problems -> their places in the parent plan
+__global__ void __launch_bounds__(64) scatter_results_kernel(const double* __restrict__ sub_out, const int* __restrict__ sub_level,
+                                                             int n, double* __restrict__ out, int* __restrict__ level,
+                                                             int B, const int* __restrict__ idx) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  const int b = idx[k];
+  out[b] = sub_out[k];
+  out[(long)B + b] = sub_out[(long)n + k];
+  out[2L * B + b] = sub_out[2L * n + k];
+  reinterpret_cast<int*>(out + 3L * B)[b] = reinterpret_cast<const int*>(sub_out + 3L * n)[k];
+  const int lv = sub_level[k];
+  level[b] = lv < 1 ? 1 : lv;  // (checked chunked replay at least; 2: the sub-plan's sequential recurrence settled it)
+}
+void launch_scatter_results(const double* sub_out, const int* sub_level, int n, double* out, int* level, int B, const int* idx,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(scatter_results_kernel, dim3((n + 63) / 64), dim3(64), 0, s, sub_out, sub_level, n, out, level, B, idx);
+}
+
+// Which compute units a stream's workgroups land on (diagnostic for CU-masked streams): every workgroup marks the
+// (XCC, HW_ID cu / sh / se) it ran on; `spin` iterations of dependent arithmetic keep it resident long enough for the
+// dispatcher to spread a grid over every unit the stream may use.
+__global__ void __launch_bounds__(64) cu_census_kernel(int* seen, int spin) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7;    // HW_REG_XCC_ID
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+  double x = 1.0 + threadIdx.x * 1e-9;
+  for (int i = 0; i < spin; ++i) x = fma(x, 1.0000001, 1e-9);
+  if (threadIdx.x == 0) atomicAdd(seen + xcc * 256 + ((hw >> 8) & 0xff), x > 0.0 ? 1 : 0);
+}
+void launch_cu_census(int* seen, int blocks, int spin, hipStream_t s) {
+  hipLaunchKernelGGL(cu_census_kernel, dim3(blocks), dim3(64), 0, s, seen, spin);
+}
+
 }  // namespace clr

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "clr_core.h"
 
 namespace clr {
@@ -76,6 +78,10 @@ struct BatchParams {
                          // (cholesky.h:76-78, :703-706; CholeskySolver.compute at widths 9..64)
   int split_lazy;     // role-split summarize with the decay factored out of the state (dense series only)
   int seq_only;       // wide path: this launch only walks the problems with need_exact != 0 (one chunk = all N)
+  int defer_level1;   // problems the conditioning record sends to the checked chunked replay (level 1) are NOT replayed
+                      // inline -- one flagged problem would cost the whole batch a sequential chunk-time -- but left with
+                      // a pending status: the host re-plans them as a small plan of their own with many short chunks
+                      // before results are handed out (api_batch.hip: rescue_run)
   int logdet_only;    // no right-hand side (CholeskySolver.compute): the quadratic form is not checked
   double cert_gamma;  // a problem whose conditioning record gamma_max / mu_min reaches this leaves the
                       // replay-free route (decide_kernel); <= 0: never
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   const int b = blockIdx.y;
   // forced-exact / materialising runs replay everything; otherwise only the problems decide_kernel
   // marked ill-conditioned (level 1; level >= 2 goes straight to sequential_kernel)
-  if (!P.force_exact && P.need_exact[b] != 1) return;
+  if (!P.force_exact && (P.need_exact[b] != 1 || P.defer_level1)) return;
   const int c = blockIdx.x * 64 + threadIdx.x;
   const bool mine = c < P.nchunk;
   if (!STAGED && !mine) return;
@@ -568,12 +574,14 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
     u_o = P.u + (long)b * J * Nm1;
     W_o = P.W + (long)b * J * P.N;
     D_o = P.D + (long)b * P.N;
-  } else if (MATERIALIZE == 2) {  // [problem][i][j][chunk]
+  } else if (MATERIALIZE >= 2) {  // [problem][i][j][chunk] (3: the lean layout, W and D only)
     const long cells = (long)P.L * P.nchunk;
     const int cc = mine ? c : 0;
     fstride = P.nchunk;
-    phi_o = P.phi + (long)b * J * cells + cc;
-    u_o = P.u + (long)b * J * cells + cc;
+    if (MATERIALIZE == 2) {
+      phi_o = P.phi + (long)b * J * cells + cc;
+      u_o = P.u + (long)b * J * cells + cc;
+    }
     W_o = P.W + (long)b * J * cells + cc;
     D_o = P.D + (long)b * cells + cc;
   }
@@ -609,6 +617,42 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   P.partx[((long)b * P.nchunk + c) * 2 + 0] = ld;
   P.partx[((long)b * P.nchunk + c) * 2 + 1] = qd;
   P.flagsx[(long)b * P.nchunk + c] = flag;
+}
+
+// The lean materialised factor of ONE problem in the reference's storage (cholesky.h:76-78, :703-706; __getstate__'s
+// arrays, solver.cpp:36-42).  The replay (MATERIALIZE == 3) stored W and D only; phi[:, n] = exp(-c (t_{n+1} - t_n)) and
+// u[:, n - 1] = U~(t_n) are pure functions of the times and the coefficients (cholesky.h:127-147) and are evaluated here
+// by the same device functions, on the same operands, as in the replay's own step.
+template <int JR, int JC, bool FAST>
+__global__ void __launch_bounds__(256) expand_lean_factor_kernel(const BatchParams P, int b, const double* __restrict__ t,
+                                                                 double* __restrict__ phi, double* __restrict__ u,
+                                                                 double* __restrict__ W, double* __restrict__ D) {
+  using Wd = Widths<JR, JC>;
+  constexpr int J = Wd::J;
+  Problem<JR, JC> p;
+  load_problem<JR, JC>(P, b, p);
+  const long cells = (long)P.L * P.nchunk;
+  const double* Wi = P.W + (long)b * J * cells;
+  const double* Di = P.D + (long)b * cells;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < P.N; n += gridDim.x * 256) {
+    const int c = n / P.L, i = n % P.L;
+    const double tn = t[n];
+    D[n] = Di[(long)i * P.nchunk + c];
+#pragma unroll
+    for (int j = 0; j < J; ++j) W[(long)J * n + j] = Wi[((long)i * J + j) * P.nchunk + c];
+    if (n >= 1) {
+      double uu[J], vv[J];
+      features_uv<JR, JC, FAST>(p, tn, uu, vv);
+#pragma unroll
+      for (int j = 0; j < J; ++j) u[(long)J * (n - 1) + j] = uu[j];
+    }
+    if (n + 1 < P.N) {
+      double phid[nz(JR + JC)];
+      features_phi_distinct<JR, JC>(p, t[n + 1] - tn, phid);
+#pragma unroll
+      for (int j = 0; j < J; ++j) phi[(long)J * n + j] = phid[phi_index<JR>(j)];
+    }
+  }
 }
 
 // decide: after correct_kernel, one wave per problem: a problem the certificate did not flag but
@@ -700,6 +744,7 @@ __global__ void __launch_bounds__(64) check_replay_kernel(const BatchParams P) {
   if (P.only_pending && P.need_scan[b] == 0) return;
   const int level = P.need_exact[b];
   if (level >= 2 || !(level == 1 || P.force_exact)) return;
+  if (P.defer_level1 && !P.force_exact) return;  // (no replay ran for it: pending, see finalize_kernel)
   double r = 0.0;
   for (int c = lane; c < P.nchunk; c += 64) {
     const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];
@@ -730,7 +775,7 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= P.B) return;
   int level = P.need_exact[b];
-  if (P.nchunk <= 256 && level < 2 && (level == 1 || P.force_exact) && P.cond) {
+  if (P.nchunk <= 256 && level < 2 && (level == 1 || P.force_exact) && P.cond && !(P.defer_level1 && !P.force_exact)) {
     // the chunked replay ran for this problem: trust it iff every chunk's end state met the scanned start state of the
     // next chunk (longer chunk lists: check_replay_kernel has done this, a wave per problem)
     double r = 0.0;
@@ -757,11 +802,13 @@ __global__ void __launch_bounds__(64) sequential_kernel(const BatchParams P) {
       u_o = P.u + (long)b * J * Nm1;
       W_o = P.W + (long)b * J * P.N;
       D_o = P.D + (long)b * P.N;
-    } else if (MATERIALIZE == 2) {
+    } else if (MATERIALIZE >= 2) {
       const long cells = (long)P.L * P.nchunk;
       fstride = P.nchunk;
-      phi_o = P.phi + (long)b * J * cells + c;
-      u_o = P.u + (long)b * J * cells + c;
+      if (MATERIALIZE == 2) {
+        phi_o = P.phi + (long)b * J * cells + c;
+        u_o = P.u + (long)b * J * cells + c;
+      }
       W_o = P.W + (long)b * J * cells + c;
       D_o = P.D + (long)b * cells + c;
     }
@@ -919,7 +966,7 @@ struct BatchLaunchers {
   void (*summarize)(const BatchParams&, hipStream_t);  // (role-split kernel when P.split > 0, widths 7, 8)
   void (*prefix)(const BatchParams&, hipStream_t);
   void (*correct)(const BatchParams&, hipStream_t);
-  void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved
+  void (*replay)(const BatchParams&, int materialize, hipStream_t);  // 0 none, 1 reference, 2 interleaved, 3 interleaved lean (W, D)
   void (*sequential)(const BatchParams&, int materialize, hipStream_t);
   // cross-check: compose the chunk elements in groups of g with the cooperative kernel (-> coop) and with the
   // single-lane host-checked form (-> ref); both [B][ceil(nchunk / g)][ELEM]
@@ -927,6 +974,8 @@ struct BatchLaunchers {
   void (*warm)(const BatchParams&, hipStream_t);  // warm_kernel + warm_check_kernel
   void (*grad)(const BatchParams&, hipStream_t);  // riders + tangents + walk over the chunks (needs P.fast_trig)
   void (*grad_reverse)(const BatchParams&, hipStream_t);  // riders + record, adjoint walk, reverse sweep, reduction
+  // lean factor of problem b (replay mode 3) -> the reference's storage, phi and u regenerated (t: the problem's row-major times)
+  void (*expand)(const BatchParams&, int b, const double* t, double* phi, double* u, double* W, double* D, hipStream_t);
   int elem_doubles, start_doubles;
 };
 
@@ -963,7 +1012,7 @@ struct BatchImpl {
 #define CLR_GO2(M)                                                                \
   if (P.fast_trig) { if (P.staged) CLR_GO(M, true, true); else CLR_GO(M, true, false); } \
   else             { if (P.staged) CLR_GO(M, false, true); else CLR_GO(M, false, false); }
-    if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
+    if (materialize == 3) { CLR_GO2(3) } else if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
 #undef CLR_GO2
 #undef CLR_GO
   }
@@ -973,9 +1022,17 @@ struct BatchImpl {
     if (P.nchunk > 256) hipLaunchKernelGGL((check_replay_kernel<JR + 2 * JC>), dim3(P.B), dim3(64), 0, s, P);  // (else: sequential_kernel's own loop)
 #define CLR_GO(M, F) hipLaunchKernelGGL((sequential_kernel<JR, JC, M, F>), grid, dim3(64), 0, s, P)
 #define CLR_GO2(M) if (P.fast_trig) CLR_GO(M, true); else CLR_GO(M, false);
-    if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
+    if (materialize == 3) { CLR_GO2(3) } else if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }
 #undef CLR_GO2
 #undef CLR_GO
+  }
+  // one problem's LEAN factor (W, D chunk-interleaved) -> the reference's four arrays: W and D de-interleaved, phi and u
+  // regenerated from the times and the coefficients with the very device functions the replay evaluates them with
+  static void expand(const BatchParams& P, int b, const double* t_rowmajor, double* phi, double* u, double* W, double* D,
+                     hipStream_t s) {
+    const int blocks = std::min((P.N + 255) / 256, 4096);
+    if (P.fast_trig) hipLaunchKernelGGL((expand_lean_factor_kernel<JR, JC, true>), dim3(blocks), dim3(256), 0, s, P, b, t_rowmajor, phi, u, W, D);
+    else hipLaunchKernelGGL((expand_lean_factor_kernel<JR, JC, false>), dim3(blocks), dim3(256), 0, s, P, b, t_rowmajor, phi, u, W, D);
   }
   static void compose_check(const BatchParams& P, int g, double* coop, double* ref, hipStream_t s) {
     constexpr int J = JR + 2 * JC;
@@ -1029,7 +1086,7 @@ struct BatchImpl {
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,
-                          Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
+                          &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };
 
@@ -1054,6 +1111,13 @@ void launch_relayout(const double* src, long src_stride, double* dst, long dst_s
 void launch_relayout_warm(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L,
                           int nchunk, int Kpad, int rows, int pad_kind, hipStream_t s);
 
+// a few problems of a plan re-planned as a small plan of their own (api_kernels.hip; api_batch.hip: rescue_run)
+void launch_gather_series(const double* src, long src_stride, double* dst, const int* idx, int n, int N, hipStream_t s);
+void launch_gather_coeffs(const double* src, double* dst, const int* idx, int B, int n, int JR, int JC, hipStream_t s);
+void launch_scatter_results(const double* sub_out, const int* sub_level, int n, double* out, int* level, int B, const int* idx,
+                            hipStream_t s);
+// diagnostic: the compute units a stream's workgroups run on, seen[xcc * 256 + HW_ID bits 15:8] (api_kernels.hip)
+void launch_cu_census(int* seen, int blocks, int spin, hipStream_t s);
 // Filled by the per-width translation units (batch_w*.hip).
 const BatchLaunchers* find_batch_launchers(int JR, int JC);
 // prefix phase at the padded widths of the wide scan (16: 2 problems per wave, 32: one)

@@ -1015,7 +1015,9 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
   // pointers are the problem's arrays); 2 = chunk-interleaved device layout: the
   // pointers are already offset to this lane's chunk column and element (local step
   // i, row j) is at [(i * J + j) * fstride] -- the 64 lanes of a wave then store 512
-  // contiguous bytes per instruction (u and phi both at their own sample's slot).
+  // contiguous bytes per instruction (u and phi both at their own sample's slot);
+  // 3 = the LEAN chunk-interleaved layout: W and D as in 2, phi and u not stored at all
+  // (consumers regenerate them from t and the coefficients: expand_lean_factor_kernel).
   constexpr int J = Widths<JR, JC>::J;
   constexpr int SZ = Widths<JR, JC>::SZ;
   double P[SZ], f[J];
@@ -1106,6 +1108,11 @@ CLR_HD void replay_chunk(const Problem<JR, JC>& p, Src& src, int L, int N, int n
         store_stream(W_o + ((long)i * J + j) * fstride, W[j]);
         store_stream(u_o + ((long)i * J + j) * fstride, u[j]);
       }
+    }
+    if (MATERIALIZE == 3 && valid) {  // lean: W and D only -- phi and u are pure functions of (t, coefficients), cholesky.h:127-147
+      store_stream(D_o + (long)i * fstride, D);
+      CLR_UNROLL
+      for (int j = 0; j < J; ++j) store_stream(W_o + ((long)i * J + j) * fstride, W[j]);
     }
     {
       double phid[nz(JR + JC)];

@@ -180,7 +180,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   const double* Vg = gen ? P.gen_V + b * P.gen_V_stride + (long)(row - Wc) * N : nullptr;
   const double* Ap = GEN ? P.gen_A + b * P.gen_A_stride : nullptr;
   // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
-  if (MODE == 0 && P.nchunk > 1 && !P.force_exact && P.need_exact[b] != 1) return;
+  if (MODE == 0 && P.nchunk > 1 && !P.force_exact && (P.need_exact[b] != 1 || (P.defer_level1 && !P.seq_only))) return;
   if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
   const int n_lo = wide_chunk_begin(P, chunk);
   const int n_hi = wide_chunk_begin(P, chunk + 1);
@@ -1215,6 +1215,7 @@ __global__ void __launch_bounds__(64) wide_check_replay_kernel(const BatchParams
   if (!P.cond) return;
   const int level = P.need_exact[b];
   if (level >= 2 || !(level == 1 || P.force_exact)) return;
+  if (P.defer_level1 && !P.force_exact) return;  // (no replay ran for it: pending, see finalize_kernel)
   double r = 0.0;
   for (int c = lane; c < P.nchunk; c += 64) {
     const double rc = P.cond[((long)b * P.nchunk + c) * 3 + 2];

@@ -374,6 +374,47 @@ int clr_batch_set_certificate_gamma(clr_batch* h, double max_gamma, double max_g
 int clr_batch_set_chunks(clr_batch* h, int nchunk);
 int clr_batch_get_chunks(const clr_batch* h, int* nchunk, int* chunk_len);
 
+/* Problems whose conditioning record sends them to the checked chunked replay (route 1, see
+ * clr_batch_get_exact_flags) used to be replayed inline: every chunk of such a problem sequentially, beside an otherwise
+ * idle chip -- ONE borderline problem cost the whole batch a chunk-time (BASELINE configs[4]: +11 ms on 12.7).  Now the
+ * evaluation leaves them pending and, before results are handed out, re-plans them as a small plan of their own with
+ * many short chunks (n problems -> ~1024 / n chunks each at width 32): summarize, parallel prefix, replay of every chunk
+ * from its scanned start state with the end-state check -- the same route with the same certificates (a mismatch goes to
+ * the sequential recurrence, cholesky.h:176 semantics unchanged), a tenth of the chunk length.
+ *   mode -1 (default): plans whose chunks hold >= 1024 samples; 0: never (the inline replay; also restores bit-identical
+ *   results under any sharding for route-1 problems, whose side plan's chunking depends on how many there are per shard);
+ *   1: whenever the plan has more than one chunk.  More pending problems than a quarter of the batch (or 256) are
+ *   replayed inline after all.  Forced-exact and materialising runs replay everything and never defer. */
+int clr_batch_set_rescue(clr_batch* h, int mode);
+/* Of the last evaluation whose results were fetched: how many problems were re-planned (negative: that many were
+ * replayed inline instead), the running total, and the side plan's chunking.  Any pointer may be NULL. */
+int clr_batch_get_rescue(const clr_batch* h, int* last_count, long* total, int* nchunk, int* chunk_len);
+
+/* What a materialising run (clr_batch_enqueue(h, 1), widths 1..8) keeps in HBM:
+ *   0 (default) the reference's four arrays phi, u, W, D (cholesky.h:76-78; 8 N (3 J + 1) bytes per problem);
+ *   1 LEAN: W and D only (8 N (J + 1) bytes per problem, SURVEY.md 8d row A-lean).  phi[:, n] = exp(-c (t_{n+1} - t_n))
+ *     and u[:, n - 1] = U~(t_n) are pure functions of the times and the coefficients (cholesky.h:127-147): the replay does
+ *     not store them, and clr_batch_get_factor regenerates them on the device with the very functions the replay
+ *     evaluates -- W, D and u come back bit-identical to layout 0's, phi to one ulp (the exp tier of a step is chosen per
+ *     wave, and the expanding kernel groups samples into waves differently from the replay).  At B = 1024, N = 1e5, width 8 the factor shrinks
+ *     from 20.5 to 7.4 GB and the materialising replay is no longer bound by its stores.  The lean factor can be
+ *     expanded as long as the plan still holds the series and coefficients of the materialising run (else
+ *     clr_batch_get_factor returns CLR_NOT_COMPUTED). */
+int clr_batch_set_factor_layout(clr_batch* h, int layout);
+/* Bytes of factor one problem occupies in HBM under the layout and chunking in force. */
+int clr_batch_get_factor_bytes(const clr_batch* h, size_t* bytes_per_problem);
+
+/* Materialising runs (widths 1..8) as a PIPELINE over `groups` contiguous groups of problems: the summarize pass of
+ * group g + 1 (fp64-VALU-bound) runs while group g is replayed (HBM-bound: the factor's stores), on streams that own
+ * disjoint sets of compute units -- `summarize_cus` of the device's CUs (a multiple of 16; 0: no CU masks, the
+ * dispatcher decides) for `summarize_streams` summarize streams, the others for the replay stream; the prefix and the
+ * corrections of a group run on a third stream in between.  Results and the factor are those of the plain sequence
+ * of kernels, bit for bit (the same kernels on the same data, group by group).  groups = 0: off (default). */
+int clr_batch_set_materialize_pipeline(clr_batch* h, int groups, int summarize_cus, int summarize_streams);
+/* Diagnostic: on how many distinct compute units of each of the 8 XCDs a grid launched on the plan's stream (which =
+ * 0), on the pipeline's first summarize stream (1) or on its replay stream (2) runs. */
+int clr_batch_debug_cu_census(clr_batch* h, int which, int* cus_per_xcc /* [8] */);
+
 /* Enqueue one evaluation of all B problems on the handle's stream (inputs
  * already resident in HBM).  `materialize` != 0 additionally writes the factor
  * (phi, u, W, D per problem; 8 N (3J+1) bytes each) to HBM, as B separate
