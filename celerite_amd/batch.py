@@ -119,6 +119,16 @@ def device_count():
     return int(_load().clr_device_count())
 
 
+def measure_fp64(waves_per_simd=2, iters=20000):
+    """``(tflops, clock_mhz, cycles_per_fma)``: the fp64 FMA rate the device's vector ALUs sustain under full load, the
+    shader clock during it and the SIMD cycles per issued FMA (``clr_device_measure_fp64``; a roofline measurement)."""
+    lib = _load()
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib.clr_device_measure_fp64.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3
+    _check(lib.clr_device_measure_fp64(int(waves_per_simd), int(iters), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def device_synchronize():
     _check(_load().clr_device_synchronize())
 

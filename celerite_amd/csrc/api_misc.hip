@@ -4,6 +4,29 @@
 thread_local std::string clr_api_last_error;
 thread_local int clr_api_device = 0;
 
+namespace {
+// The fp64 FMA rate the vector ALUs of THIS device sustain when every SIMD issues v_fma_f64 back to back, and the shader
+// clock they do it at: each wave times its own stream of 64 x iters FMAs (8 independent chains) with s_memtime (shader
+// cycles) and s_memrealtime (100 MHz).  The datasheet's 78.6 TFLOP/s is 4 cycles per wave-instruction at 2.4 GHz; under
+// this load the chip clocks ~1.9 GHz and a SIMD issues one FMA per ~4.45 cycles (profiles/r05c_clock_under_fp64_load.txt).
+__global__ void __launch_bounds__(64) fp64_load_kernel(double* out, unsigned long long* rec, int iters, double seed) {
+  double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const double m = 1.0000001, c = 1e-9;
+  unsigned long long c0, r0, c1, r1;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0));
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                   "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+  }
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1));
+  if (threadIdx.x == 0) { rec[2 * blockIdx.x] = c1 - c0; rec[2 * blockIdx.x + 1] = r1 - r0; }
+  out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+}  // namespace
+
 extern "C" {
 
 /* ---- library / device ------------------------------------------------------ */
@@ -63,6 +86,47 @@ int clr_device_memory(size_t* free_bytes, size_t* total_bytes) {
   HIP_TRY(hipMemGetInfo(&f, &t));
   if (free_bytes) *free_bytes = f;
   if (total_bytes) *total_bytes = t;
+  return CLR_OK;
+}
+
+int clr_device_measure_fp64(int waves_per_simd, int iters, double* tflops, double* clock_mhz, double* cycles_per_fma) {
+  int st = require_device(g_device);
+  if (st != CLR_OK) return st;
+  if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 16) return fail(CLR_INVALID_ARGUMENT, "measure_fp64: 1..8 waves per SIMD, iters >= 16");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  const int waves = prop.multiProcessorCount * 4 * waves_per_simd;
+  double* out = nullptr;
+  unsigned long long* rec = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)waves * 64 * sizeof(double)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rec), (size_t)waves * 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(fp64_load_kernel, dim3(waves), dim3(64), 0, 0, out, rec, iters / 4, 1.0);  // (clocks settle)
+  HIP_TRY(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(fp64_load_kernel, dim3(waves), dim3(64), 0, 0, out, rec, iters, 1.0);
+  HIP_TRY(hipEventRecord(e1, 0));
+  HIP_TRY(hipDeviceSynchronize());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)waves * 2);
+  HIP_TRY(hipMemcpy(h.data(), rec, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> mhz((size_t)waves), cpi((size_t)waves);
+  for (int w = 0; w < waves; ++w) {
+    mhz[(size_t)w] = (double)h[2 * (size_t)w] / (double)h[2 * (size_t)w + 1] * 100.0;
+    // cycles the SIMD spends per FMA it issues: the wave's own cycles per instruction over the waves sharing the SIMD
+    cpi[(size_t)w] = (double)h[2 * (size_t)w] / (64.0 * iters) / waves_per_simd;
+  }
+  std::sort(mhz.begin(), mhz.end());
+  std::sort(cpi.begin(), cpi.end());
+  if (tflops) *tflops = 2.0 * 64.0 * 64.0 * iters * waves / (ms * 1e-3) / 1e12;
+  if (clock_mhz) *clock_mhz = mhz[mhz.size() / 2];
+  if (cycles_per_fma) *cycles_per_fma = cpi[cpi.size() / 2];
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  (void)hipFree(rec);
   return CLR_OK;
 }
 

@@ -71,6 +71,13 @@ int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm
  * of series and factor plus 8 B nchunk (J^2 + J (J + 1) + 4 J) of scan workspace. */
 int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
 
+/* A measurement for roofline figures (not a product path): the fp64 FMA rate the vector ALUs of the current device
+ * sustain with `waves_per_simd` waves per SIMD issuing independent v_fma_f64 back to back (64 x iters each), the shader
+ * clock during that load (median over the waves: s_memtime against the 100 MHz s_memrealtime) and the cycles a SIMD
+ * spends per FMA it issues.  MI355X: ~56 TFLOP/s at ~1.9 GHz and ~4.45 cycles with two waves per SIMD -- the datasheet's
+ * 78.6 TFLOP/s assumes 4 cycles at 2.4 GHz.  Any pointer may be NULL. */
+int clr_device_measure_fp64(int waves_per_simd, int iters, double* tflops, double* clock_mhz, double* cycles_per_fma);
+
 /* ---- single-problem solver: celerite::solver::CholeskySolver<double> ----------
  * (cpp/include/celerite/solver/cholesky.h, solver.h), the object behind
  * celerite.solver.CholeskySolver (solver.cpp:241-244).  The factor
