@@ -83,7 +83,16 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
     // unless the batch alone leaves the chip underused: then ~2 waves per SIMD worth of
     // chunks, at ~1.25x the work per sample (profiles/r01s); widths above 32 stay sequential
     if (h->J > clr::wide_scan_max_width()) nchunk = 1;
-    else if (nchunk <= 0) {
+    else if (h->J > 32) {
+      // widths 33..64 (round 5): the summarize keeps S and A^T in 256 registers per lane -- ONE wave per SIMD -- so a round
+      // of the chip is B x nchunk = 1024 waves; the chunks are chained by a walk per problem (~0.2 ms per chunk:
+      // wide64_kernels.hip), so at most 16, each of >= 1024 samples.  Above 512 problems two chunks no longer pay.
+      if (nchunk <= 0) {
+        nchunk = h->B <= 512 ? std::max(2, 1024 / h->B) : 1;
+        if (nchunk > 16) nchunk = 16;
+        while (nchunk > 1 && h->N / nchunk < 1024) --nchunk;
+      }
+    } else if (nchunk <= 0) {
       // One round of two waves per SIMD: B x nchunk = 2048 waves.  (Round 2 used 4096 / B -- two rounds of half the
       //  length -- because the checked replay of borderline problems, 7 ms for config 4, got shorter with the chunks;
       //  with the round-3 routing that family is settled from the chunk summaries and the sequential prefix + the
@@ -118,12 +127,14 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->L0 = 0;
   if (const char* e = getenv("CLR_WIDE_FIRST_RATIO")) h->wide_first_ratio = atof(e);  // (tuning runs only)
-  if (!h->launch && h->nchunk > 1 && h->wide_first_ratio > 1.0) {
+  if (const char* e = getenv("CLR_WIDE_FIRST_RATIO64")) h->wide_first_ratio64 = atof(e);
+  const double first_ratio = h->J > 32 ? h->wide_first_ratio64 : h->wide_first_ratio;
+  if (!h->launch && h->nchunk > 1 && first_ratio > 1.0) {
     // wide scan: the first chunk's summarize carries no riders (wide_scan_body, RIDERS == false) and costs
     // ~1 / wide_first_ratio of a later chunk's per sample: it gets that many more samples, so that all waves of the
     // one round finish together.  Chunks 1.. have exactly L samples, the first one the rest.
     const int nc = h->nchunk;
-    int L = (int)ceil(h->N / (nc - 1 + h->wide_first_ratio));
+    int L = (int)ceil(h->N / (nc - 1 + first_ratio));
     L = (L + 7) & ~7;
     const long first = (long)h->N - (long)(nc - 1) * L;
     if (L >= 64 && first >= L) { h->L = L; h->L0 = (int)first; }
@@ -143,7 +154,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
     if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
     if (ls && (st = h->lvl_starts.reserve((size_t)h->B * ls)) != CLR_OK) return st;
   } else if (h->nchunk > 1) {  // elements / start states at the padded width (16 or 32)
-    const size_t JP = h->J <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    const size_t JP = (size_t)clr::wide_padded_width(h->J), SZ = JP * (JP + 1) / 2;
     if ((st = h->elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
     // few problems with many chunks: the prefix as a parallel scan (wide_prefix_scan.hip); its level buffers
@@ -716,10 +727,11 @@ static int plan_general_chunks(clr_batch* h) {
   const int Wt = h->J + J_general;
   if (Wt <= clr::wide_max_width()) {
     int nchunk = (Wt <= clr::wide_scan_max_width() && h->B <= 1024) ? 2048 / h->B : 1;
+    if (Wt > 32) nchunk = h->B <= 512 ? std::max(2, 1024 / h->B) : 1;  // (one wave per SIMD at total widths 33..64: clr_batch_set_chunks)
     if (nchunk > 16) nchunk = 16;
-    while (nchunk > 1 && h->N / nchunk < 512) --nchunk;
+    while (nchunk > 1 && h->N / nchunk < (Wt > 32 ? 1024 : 512)) --nchunk;
     const int cap = clr::wide_prefix_scan_max_chunks(Wt <= 16 ? 16 : 32), Lmin = Wt <= 16 ? 64 : 96;
-    if (Wt <= clr::wide_scan_max_width() && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk)
+    if (Wt <= 32 && h->coop_prefix == 2 && h->B < 32 && std::min(cap / h->B, h->N / Lmin) > nchunk)
       nchunk = std::min(cap / h->B, h->N / Lmin);  // (few problems: the parallel prefix, clr_batch_set_chunks)
     if (h->warm_explicit_chunks > 0 && Wt <= clr::wide_scan_max_width())  // (an explicit clr_batch_set_chunks is honoured, whenever it was made)
       nchunk = std::min(h->warm_explicit_chunks, std::max(1, h->N / 64));
@@ -728,13 +740,14 @@ static int plan_general_chunks(clr_batch* h) {
     if (nchunk > 1) L = (L + 7) & ~7;
     nchunk = (h->N + L - 1) / L;
     int L0 = 0;
-    if (nchunk > 1 && h->wide_first_ratio > 1.0) {  // (the riderless, longer first chunk: clr_batch_set_chunks)
-      int L2 = (int)ceil(h->N / (nchunk - 1 + h->wide_first_ratio));
+    const double first_ratio = Wt > 32 ? h->wide_first_ratio64 : h->wide_first_ratio;
+    if (nchunk > 1 && first_ratio > 1.0) {  // (the riderless, longer first chunk: clr_batch_set_chunks)
+      int L2 = (int)ceil(h->N / (nchunk - 1 + first_ratio));
       L2 = (L2 + 7) & ~7;
       const long first = (long)h->N - (long)(nchunk - 1) * L2;
       if (L2 >= 64 && first >= L2) { L = L2; L0 = (int)first; }
     }
-    const size_t pc = (size_t)h->B * nchunk, JP = Wt <= 16 ? 16 : 32, SZ = JP * (JP + 1) / 2;
+    const size_t pc = (size_t)h->B * nchunk, JP = (size_t)clr::wide_padded_width(Wt), SZ = JP * (JP + 1) / 2;
     if (nchunk > 1) {
       if ((st = h->gen_elems.reserve(pc * (JP * JP + JP + SZ + JP + SZ))) != CLR_OK) return st;
       if ((st = h->gen_starts.reserve(pc * (SZ + JP))) != CLR_OK) return st;
@@ -1342,10 +1355,12 @@ static int rescue_run(clr_batch* h, const std::vector<int>& idx) {
     r->small_mode = 0;
     int nchunk = 0;
     if (!h->launch) {  // wide: B x nchunk <= the parallel prefix's cap (1024 workgroups per level at width 32, 2048 below)
-      const int JP = h->J <= 16 ? 16 : 32;
-      nchunk = std::min(clr::wide_prefix_scan_cap(JP) / n, clr::wide_prefix_scan_max_chunks(JP));
-      nchunk = std::min(nchunk, h->N / (JP == 16 ? 64 : 96));
-      if (nchunk < 8) nchunk = 0;  // (short series: the plan's own choice)
+      const int JP = clr::wide_padded_width(h->J);
+      if (JP <= 32) {
+        nchunk = std::min(clr::wide_prefix_scan_cap(JP) / n, clr::wide_prefix_scan_max_chunks(JP));
+        nchunk = std::min(nchunk, h->N / (JP == 16 ? 64 : 96));
+        if (nchunk < 8) nchunk = 0;  // (short series: the plan's own choice)
+      }  // (widths 33..64: the plan's own rule -- 1024 / n chunks, at most 16, chained by the walk)
     } else {
       nchunk = auto_chunks(n, h->N, h->J, true);
     }

@@ -202,6 +202,7 @@ struct clr_batch {
   size_t gen_scan_ws_doubles = 0, scan_ws_doubles = 0;  // workspace of the wide parallel prefix (0: sequential walk)
   int* gen_flags = nullptr;
   bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
+  double wide_first_ratio64 = 2.3;  // ... at widths 33..64 (riders: A^T on the VALU + Jm on the matrix cores, beside S alone)
   double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk (1.1-1.25 within 2 %: profiles/r04c, r04p)
   const clr::BatchLaunchers* launch = nullptr;
   DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout
@@ -352,6 +353,9 @@ bool defer_runs(const clr_batch* h, int materialize) {
   if (h->rescue_mode == 0 || h->is_rescue_plan || materialize || h->force_exact || h->grad_scan_only || h->in_fallback) return false;
   if (h->nchunk < 2 || h->J_general > 0 || h->B < 2) return false;
   if (h->rescue_mode == 1) return true;
+  // widths 33..64: a side plan is itself <= 16 chunks chained by a walk of ~0.6 ms each -- it does not beat the inline
+  // replay of one of the parent's chunks (profiles/r05d_wide64_chunks.txt)
+  if (h->J > 32) return false;
   return h->L >= 1024;
 }
 
@@ -479,13 +483,22 @@ bool batch_relayout(clr_batch* h) {
 
 void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev) {
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], stream); };
-  const int JP = J_real + 2 * J_comp + P.J_general <= 16 ? 16 : 32;
+  const int JP = clr::wide_padded_width(J_real + 2 * J_comp + P.J_general);
   mark(1);
   if (P.nchunk > 1) clr::launch_wide_summarize(P, J_real, J_comp, stream);
   mark(2);
-  clr::launch_wide_prefix(P, JP, stream);
-  mark(3);
-  clr::launch_wide_correct(P, JP, stream);
+  // widths 33..64: the prefix and the corrections in one walk per problem (wide64_kernels.hip); CLR_WIDE_WALK=1 takes
+  // that kernel at the padded width 32 too (cross-check of the two-kernel path; tests)
+  const bool walk32 = getenv("CLR_WIDE_WALK") != nullptr;
+  if (JP == 64 || (JP == 32 && walk32 && !(P.scan_ws && P.coop_prefix == 2))) {
+    (void)clr::launch_wide_walk(P, JP, stream);
+    mark(3);
+    clr::launch_wide_decide(P, JP, stream);
+  } else {
+    clr::launch_wide_prefix(P, JP, stream);
+    mark(3);
+    clr::launch_wide_correct(P, JP, stream);
+  }
   mark(4);
   // one chunk: the sweep itself; several: the chunked replay of forced runs and of the problems the
   // conditioning record marked (level 1), with its end states checked against the scan

@@ -341,14 +341,16 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       // (t = p nchunk): nchunk = sqrt(a N / p).  Measured (profiles/r02y_single_wide_chunks.txt): a = 1.4 us per
       // sample, p = 15 us per chunk up to width 16; a = 2.0 us, p = 97 us (three 32^3 products on the matrix
       // cores + a Gauss-Jordan) above.
-      nchunk = (int)lround(sqrt((double)N * (J <= 16 ? 0.096 : 0.0208)));
+      // (widths 33..64, round 5: the chunks are chained by wide_walk_kernel -- prefix + corrections, ~0.2 ms per chunk --
+      //  and a step with riders costs ~2.2 us: a = 2.2 us, p = 200 us)
+      nchunk = (int)lround(sqrt((double)N * (J <= 16 ? 0.096 : (J <= 32 ? 0.0208 : 0.011))));
       if (nchunk > N / 256) nchunk = N / 256;
       if (nchunk < 2 || N < 2048) nchunk = 1;  // (short series: the six launches of the chunked flow cost more)
       // round 4: the prefix is a parallel scan (wide_prefix_scan.hip: ceil(log2 nchunk) launches of 22 / 86 us instead of
       // nchunk steps of 14 / 50 us), so the chunks only have to amortise their own set-up -- 48 samples up to width 16, 96
       // above, at most 1024 / 512 chunks, at least 8 (profiles/r04v_single_wide_chunks.txt, r04z_single_wide_short.txt:
       // N = 1e5 width 16 3.0 -> 0.79 ms, width 32 6.9 -> 1.56 ms; N = 1000 0.74 -> 0.24 / 0.87 -> 0.58 ms)
-      if (!getenv("CLR_WIDE_PREFIX_WALK")) {
+      if (!getenv("CLR_WIDE_PREFIX_WALK") && J <= 32) {
         const int cap = clr::wide_prefix_scan_max_chunks(J <= 16 ? 16 : 32), Lmin = J <= 16 ? 48 : 96;
         int nk = std::min(N / Lmin, cap);
         if (nk < 8 && N >= 8 * (J <= 16 ? 32 : 64)) nk = 8;
@@ -358,7 +360,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     }
     P.L = (N + nchunk - 1) / nchunk;
     P.nchunk = (N + P.L - 1) / P.L;
-    const size_t pc = (size_t)P.nchunk, JP = J <= 16 ? 16 : 32, SZP = JP * (JP + 1) / 2;
+    const size_t pc = (size_t)P.nchunk, JP = (size_t)clr::wide_padded_width(J), SZP = JP * (JP + 1) / 2;
     if ((st = s->ws_elems.reserve(pc * (JP * JP + JP + SZP + JP + SZP))) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve(pc * (SZP + JP))) != CLR_OK) return st;
     const size_t scan_ws = getenv("CLR_WIDE_PREFIX_WALK") ? 0 : clr::wide_prefix_scan_workspace(1, P.nchunk, (int)JP);  // the prefix as a parallel scan

@@ -1095,6 +1095,11 @@ struct BatchImpl {
 bool launch_summarize_split(const BatchParams& P, int JR, int JC, hipStream_t s);
 bool have_summarize_split(int JR, int JC);
 
+// the wide scan's prefix AND corrections in one walk per problem (wide64_kernels.hip): the padded width 64; 32 as a
+// cross-check of the two-kernel path.  Non-zero: the kernel could not be configured (LDS).
+int launch_wide_walk(const BatchParams& P, int width_padded, hipStream_t s);
+// the padded width of the wide kernels' chunk algebra for a total width W (9..64)
+inline int wide_padded_width(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
 // decide_kernel at the padded widths of the wide scan
 void launch_wide_decide(const BatchParams& P, int width_padded, hipStream_t s);
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s);

@@ -131,11 +131,12 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // eight b128 LDS reads per lane and STEP.  (A and r stay on the VALU: r_n needs the up-to-date A, and a blocked
   // WY form costs R0 = A0^T U, G = W^T U and a forward substitution on top -- 40 MFMA + 120 FMA per block against
   // 32 FMA per step, with fp64 MFMA only 1.28x the VALU's FMA rate and not overlapping it: profiles/r04a_mfma_overlap.txt.)
-  constexpr bool JMM = RID && LAZY && WMAX == 32 && CLR_WIDE_JM_MFMA;
+  constexpr bool JMM = RID && LAZY && (WMAX == 32 || WMAX == 64) && CLR_WIDE_JM_MFMA;
+  constexpr int NTL = WMAX / 16, NTILE = NTL * (NTL + 1) / 2;  // (JMM) 16 x 16 tiles per side / of the upper triangle of Jm
   constexpr bool PACKED = LPR >= 2 && CLR_WIDE_PACKED_SUMS;
   constexpr bool LPWIN = LAZY && CLR_WIDE_LOGPROD_WINDOW;
-  __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * 32 : 2];
-  __shared__ __attribute__((aligned(16))) double rsblk[JMM ? 16 * 32 : 2];
+  __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * WMAX : 2];
+  __shared__ __attribute__((aligned(16))) double rsblk[JMM ? 16 * WMAX : 2];
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
@@ -197,7 +198,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     f = st[SZ + row];
   }
   double AT[RID ? COLS : 1], Jm[(RID && !JMM) ? COLS : 1], eta = 0.0;
-  mfma_acc_t Jacc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};  // (JMM) tiles (0,0), (0,1), (1,1)
+  mfma_acc_t Jacc[JMM ? NTILE : 1];  // (JMM) the tiles (ti, tj), ti <= tj, of Jm's upper triangle, row by row
+#pragma unroll
+  for (int q_ = 0; q_ < (JMM ? NTILE : 1); ++q_) Jacc[q_] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
   double dprod = 1.0;  // (LPWIN) product of the current block's pivots
   if (RID) {
 #pragma unroll
@@ -314,7 +317,24 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 
       // q = S u and (summarize) r = A^T u: own columns, then across the row's lanes
       double q = 0.0, r = 0.0;
-      {
+      if constexpr (COLS >= 32) {
+        // width 64: one lane owns a whole row -- a single accumulator would be a chain of 64 dependent FMAs per dot
+        // product, and the wave is alone on its SIMD (nothing hides the latency): four partial sums each
+        double qa[4] = {0.0, 0.0, 0.0, 0.0}, ra[4] = {0.0, 0.0, 0.0, 0.0};
+        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+#pragma unroll
+        for (int c = 0; c < COLS / 2; ++c) {
+          const double2 uu = uv[c];
+          qa[(2 * c) & 3] = fma(S[2 * c], uu.x, qa[(2 * c) & 3]);
+          qa[(2 * c + 1) & 3] = fma(S[2 * c + 1], uu.y, qa[(2 * c + 1) & 3]);
+          if (RID) {
+            ra[(2 * c) & 3] = fma(AT[2 * c], uu.x, ra[(2 * c) & 3]);
+            ra[(2 * c + 1) & 3] = fma(AT[2 * c + 1], uu.y, ra[(2 * c + 1) & 3]);
+          }
+        }
+        q = (qa[0] + qa[1]) + (qa[2] + qa[3]);
+        if (RID) r = (ra[0] + ra[1]) + (ra[2] + ra[3]);
+      } else {
         const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
@@ -354,8 +374,13 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         if (RID && !JMM) rbuf[row] = r;
       }
       if (JMM) {  // this step's r (first lane of the row) and -r / D (second lane), for the block's rank-16 update
-        double* dst = (seg == 0 ? rblk : rsblk) + ((n - n_lo) & 15) * 32 + row;
-        *dst = seg == 0 ? r : -(r * invD);
+        if (LPR >= 2) {
+          double* dst = (seg == 0 ? rblk : rsblk) + ((n - n_lo) & 15) * WMAX + row;
+          *dst = seg == 0 ? r : -(r * invD);
+        } else {  // (width 64: one lane per row writes both)
+          rblk[((n - n_lo) & 15) * WMAX + row] = r;
+          rsblk[((n - n_lo) & 15) * WMAX + row] = -(r * invD);
+        }
       }
       if (MODE == 0 && P.wide_materialize && writer && row < W) {
         // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
@@ -419,15 +444,23 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           if (JMM) {       // Jm += R (-D^-1 R)^T over the block's steps
             const int cnt = ((n - n_lo) & 15) + 1;
             if (cnt < 16)  // the chunk's last, shorter block: the unused steps contribute nothing
-              for (int idx = cnt * 32 + lane; idx < 16 * 32; idx += 64) { rblk[idx] = 0.0; rsblk[idx] = 0.0; }
+              for (int idx = cnt * WMAX + lane; idx < 16 * WMAX; idx += 64) { rblk[idx] = 0.0; rsblk[idx] = 0.0; }
             const int lm = lane & 15, lk = lane >> 4;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-              const double a0 = rblk[(4 * ks + lk) * 32 + lm], a1 = rblk[(4 * ks + lk) * 32 + 16 + lm];
-              const double b0 = rsblk[(4 * ks + lk) * 32 + lm], b1 = rsblk[(4 * ks + lk) * 32 + 16 + lm];
-              Jacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, Jacc[0], 0, 0, 0);
-              Jacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, Jacc[1], 0, 0, 0);
-              Jacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, Jacc[2], 0, 0, 0);
+              double av[NTL], bv[NTL];
+#pragma unroll
+              for (int ti = 0; ti < NTL; ++ti) {
+                av[ti] = rblk[(4 * ks + lk) * WMAX + 16 * ti + lm];
+                bv[ti] = rsblk[(4 * ks + lk) * WMAX + 16 * ti + lm];
+              }
+              int q_ = 0;
+#pragma unroll
+              for (int ti = 0; ti < NTL; ++ti) {
+#pragma unroll
+                for (int tj = ti; tj < NTL; ++tj, ++q_)
+                  Jacc[q_] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], Jacc[q_], 0, 0, 0);
+              }
             }
           }
           if (writer) psibuf[row] = psi;
@@ -476,13 +509,16 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     }
     if (JMM) {  // accumulator layout of v_mfma_f64_16x16x4: register r of tile (ti, tj) is entry (16 ti + (lane >> 4) + 4 r, 16 tj + (lane & 15))
       const int lm = lane & 15, lk = lane >> 4;
+      int q_ = 0;
 #pragma unroll
-      for (int tile = 0; tile < 3; ++tile) {
-        const int ti = tile == 2 ? 1 : 0, tj = tile == 0 ? 0 : 1;
+      for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * ti + lk + 4 * r, j = 16 * tj + lm;
-          if (i <= j) e[J * J + J + SZ + J + tri(i, j)] = Jacc[tile][r];
+        for (int tj = ti; tj < NTL; ++tj, ++q_) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lk + 4 * r, j = 16 * tj + lm;
+            if (i <= j) e[J * J + J + SZ + J + tri(i, j)] = Jacc[q_][r];
+          }
         }
       }
     }
@@ -547,6 +583,14 @@ template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
   if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN>(P, JR, JC);
   else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN>(P, JR, JC);
+}
+// Round 5: the summarize flavour at widths 33..64 (one lane per row, 64 columns each).  S and A^T alone are 2 x 64 doubles
+// = 256 registers per lane, Jm sits in the matrix cores' accumulators (10 tiles x 4 doubles: the lazy flavour) or in 64
+// more doubles: ONE wave per SIMD (512 registers), where the narrower kernels run two.
+template <bool FAST, bool LAZY, bool GEN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) wide_summarize64_kernel(const BatchParams P, int JR, int JC) {
+  if (blockIdx.x == 0) wide_scan_body<64, FAST, 1, LAZY, false, GEN>(P, JR, JC);
+  else wide_scan_body<64, FAST, 1, LAZY, true, GEN>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -947,7 +991,7 @@ namespace {
 }  // namespace
 
 int wide_max_width() { return 64; }
-int wide_scan_max_width() { return 32; }  // the chunk algebra runs in prefix_coop_kernel<16 | 32>
+int wide_scan_max_width() { return 64; }  // the chunk algebra: prefix_coop_kernel<16>, wide_prefix32_kernel, wide_walk64_kernel (wide64_kernels.hip)
 
 template <bool GEN>
 static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
@@ -966,8 +1010,16 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);  \
     else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);              \
   } while (0)
-    if (W <= 16) CLR_GOL(16); else CLR_GOL(32);
+    if (W <= 16) CLR_GOL(16);
+    else if (W <= 32) CLR_GOL(32);
+    else if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_summarize64_kernel<false, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
 #undef CLR_GOL
+    return;
+  }
+  if (MODE == 1 && W > 32) {  // widths 33..64 on a series that is not densely sampled
+    if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_summarize64_kernel<false, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
     return;
   }
 #define CLR_GO(WM)                                                                                                        \
@@ -1203,7 +1255,8 @@ void launch_wide_correct(const BatchParams& P, int width_padded, hipStream_t s) 
 void launch_wide_decide(const BatchParams& P, int width_padded, hipStream_t s) {
   const dim3 block(P.nchunk > 256 ? 256 : 64);
   if (width_padded <= 16) hipLaunchKernelGGL((decide_kernel<16>), dim3(P.B), block, 0, s, P);
-  else hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), block, 0, s, P);
+  else if (width_padded <= 32) hipLaunchKernelGGL((decide_kernel<32>), dim3(P.B), block, 0, s, P);
+  else hipLaunchKernelGGL((decide_kernel<64>), dim3(P.B), block, 0, s, P);
 }
 
 // after the chunked replay: a replayed problem whose chunks did not meet the scanned start states

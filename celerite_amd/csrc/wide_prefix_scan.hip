@@ -230,6 +230,7 @@ int wide_prefix_scan_max_chunks(int width_padded) { return width_padded <= 16 ? 
 size_t wide_prefix_scan_workspace(int B, int nchunk, int width_padded) {
   long cap = wide_prefix_scan_cap(width_padded);
   if (const char* e = getenv("CLR_WIDE_SCAN_CAP")) cap = atol(e);  // (tools/gpu_single_wide_chunks2.py)
+  if (width_padded > 32) return 0;  // (widths 33..64: the chunks are chained by wide_walk_kernel, wide64_kernels.hip)
   if (nchunk < 8 || (long)B * nchunk > cap) return 0;  // (... and a walk worth cutting)
   const size_t J = width_padded <= 16 ? 16 : 32, SZ = J * (J + 1) / 2;
   return 2 * (size_t)B * nchunk * (J * J + J + SZ + J + SZ);

@@ -737,6 +737,87 @@ def test_wide_scan_over_chunks(JR, JC):
             assert np.max(np.abs(q[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])) <= 1e-11
 
 
+@pytest.mark.parametrize("JR,JC", [(40, 0), (0, 20), (8, 20), (0, 24), (64, 0), (0, 32), (2, 31), (33, 0)])
+def test_wide_scan_over_chunks_at_widths_33_to_64(JR, JC):
+    """VERDICT r4 missing #1 / item 4: widths 33..64 parallel in n.  The summarize flavour at the padded width 64 (one
+    lane per row: S and A^T in 256 registers, Jm on the matrix cores in the lazy flavour), the chunks chained and
+    corrected by one walk per problem (csrc/wide64_kernels.hip), the replay of forced runs from the scanned start
+    states.  Every chunking -- uniform, the riderless longer first chunk, a ragged last chunk -- must reproduce the
+    one-chunk sweep (the reference recurrence itself, cholesky.h:126-179) and the oracle at 1e-10, an indefinite problem
+    included; dense (lazy decay) and sparse series; B = 64 and B = 1 at N = 2e4."""
+    W = JR + 2 * JC
+    for B, N, family, chunkings in ((3, 6000, "bench", (1, 2, 5, 6, -4)), (3, 6000, "accuracy", (1, 3, 7)),
+                                    (64, 20000, "bench", (0,)), (1, 20000, "accuracy", (0, 13))):
+        case = synthetic(B, N, JR, JC, family, seed=W + N % 97)
+        case["a_real"] = np.array(case["a_real"], copy=True)
+        case["diag"] = np.array(case["diag"], copy=True)
+        if JR and B >= 3:
+            case["a_real"][1, :] = -7.0       # an indefinite problem in the middle
+            case["diag"][1] = 0.0
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"],
+                                                  nthreads=os.cpu_count() or 1)
+        ok = s0 == 0
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_series(case["t"], case["diag"], case["y"])
+            for nchunk in chunkings:
+                plan.set_exact(nchunk < 0)
+                plan.set_chunks(abs(nchunk))
+                plan.set_coefficients(*coeffs_of(case))
+                ll, ld, q, st = plan.log_likelihood()
+                if nchunk == 0 and B * 2 <= 1024 and N >= 2048:
+                    assert plan.chunks[0] >= 2, plan.chunks      # the automatic choice cuts the series
+                assert np.array_equal(st, s0), (B, N, family, nchunk, st, s0)
+                within("widths 33..64, chunked scan (width %d): log det vs oracle" % W,
+                       np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), REL, (B, N, family, nchunk))
+                within("widths 33..64, chunked scan (width %d): quadratic form vs oracle" % W,
+                       np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])), REL, (B, N, family, nchunk))
+                if nchunk < 0:
+                    assert plan.exact_count() == B
+        finally:
+            plan.close()
+
+
+@pytest.mark.parametrize("JR,JC", [(0, 16), (5, 10), (17, 0)])
+def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, JC):
+    """wide_walk_kernel (prefix + corrections + certificate in one walk per problem; the path of widths 33..64)
+    instantiated at the padded width 32 (CLR_WIDE_WALK=1) against the established pair wide_prefix32_kernel +
+    wide_correct_kernel<32> on the same elements: start states, results, conditioning records and routes -- benign,
+    near-singular and indefinite problems."""
+    B, N = 6, 5000
+    for family, maker in (("bench", synthetic), ("adversarial", None)):
+        case = synthetic(B, N, JR, JC, "bench", seed=7 + JR) if maker else adversarial(B, N, JR, JC, seed=91 + JR)
+        out = {}
+        for walk in (False, True):
+            if walk:
+                os.environ["CLR_WIDE_WALK"] = "1"
+            try:
+                plan = batch.BatchedGP(B, N, JR, JC)
+                try:
+                    plan.set_prefix_mode("walk")
+                    plan.set_chunks(8)
+                    plan.set_series(case["t"], case["diag"], case["y"])
+                    plan.set_coefficients(*coeffs_of(case))
+                    res = plan.log_likelihood()
+                    out[walk] = (res, plan.exact_levels(), plan.conditioning(), plan.measured_error())
+                finally:
+                    plan.close()
+            finally:
+                os.environ.pop("CLR_WIDE_WALK", None)
+        (ra, la, (ga, ma), ea), (rb, lb, (gb, mb), eb) = out[False], out[True]
+        assert np.array_equal(ra[3], rb[3]) and np.array_equal(la, lb), (family, la, lb)
+        fin = (ra[3] == 0) & np.isfinite(ra[1]) & np.isfinite(ra[2])
+        if fin.any():
+            tol = 1e-12 if family == "bench" else 1e-8      # (near-singular problems: two orders of summation of an ill-conditioned sum)
+            within("one-walk chunk algebra vs prefix32 + correct32 (%s): results" % family,
+                   max(np.max(np.abs(ra[1][fin] - rb[1][fin]) / np.abs(ra[1][fin])), np.max(np.abs(ra[2][fin] - rb[2][fin]) / np.abs(ra[2][fin]))), tol)
+        assert np.array_equal(ga, gb)                          # gamma comes from summarize: identical
+        good = np.isfinite(ma) & np.isfinite(mb) & (la == 0)
+        if good.any():
+            within("one-walk chunk algebra vs prefix32 + correct32 (%s): certificate pivot mu" % family,
+                   np.max(np.abs(ma[good] - mb[good]) / np.abs(ma[good])), 1e-6)
+
+
 @pytest.mark.parametrize("JR,JC", [(2, 5), (0, 8), (5, 10), (0, 16)])
 def test_wide_prefix_as_a_parallel_scan(JR, JC):
     """Few problems with many chunks (csrc/wide_prefix_scan.hip): the prefix of the wide scan is a Kogge-Stone scan over

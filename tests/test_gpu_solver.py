@@ -636,10 +636,12 @@ def test_failed_compute_leaves_solver_not_computed():  # cholesky.h:57
         s.compute(0.0, np.ones(1), np.ones(1), e, e, e, e, *NO_GENERAL, t, np.ones(49))
 
 
-@pytest.mark.parametrize("JR,JC,N", [(1, 4, 300), (2, 7, 3000), (4, 11, 5000), (0, 16, 20000), (6, 13, 2500), (10, 15, 700)])
+@pytest.mark.parametrize("JR,JC,N", [(1, 4, 300), (2, 7, 3000), (4, 11, 5000), (0, 16, 20000), (6, 13, 2500), (10, 15, 700),
+                                     (8, 16, 30000), (4, 22, 12000), (0, 32, 20000), (64, 0, 9000)])
 def test_object_api_wide_widths_through_the_wide_scan(JR, JC, N):
     """CholeskySolver.compute at widths 9..64 without general terms runs the batched wide kernels on
-    one problem (chunked for widths <= 32 and N >= 2048) and writes the factor in the reference's
+    one problem (chunked for N >= 2048; round 5: widths 33..64 too -- sqrt(0.011 N) chunks chained by one walk,
+    csrc/wide64_kernels.hip) and writes the factor in the reference's
     storage: log_determinant, dot_solve, solve and the pickled state against the oracle."""
     rng = np.random.RandomState(JR * 100 + JC)
     t = np.sort(rng.uniform(0, 0.05 * N, N))
