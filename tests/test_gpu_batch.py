@@ -915,9 +915,13 @@ def test_wide_scan_is_chosen_for_small_batches():
     plan = batch.BatchedGP(2048, 20000, 0, 16)     # enough problems: plain sequential sweeps
     assert plan.chunks[0] == 1
     plan.close()
-    plan = batch.BatchedGP(8, 20000, 0, 17)        # width 34: no scan above 32
-    assert plan.chunks[0] == 1
-    plan.close()
+    # widths 33..64 (round 5): one wave per SIMD -> 1024 / B chunks, at most 16, of at least 1024 samples each;
+    # above 512 problems the sequential sweep stays
+    for B, N, JC, want in ((8, 20000, 17, 16), (64, 100000, 32, 16), (256, 100000, 32, 4), (512, 100000, 20, 2),
+                           (1024, 100000, 20, 1), (256, 3000, 32, 2), (256, 1500, 32, 1)):
+        plan = batch.BatchedGP(B, N, 0, JC)
+        assert plan.chunks[0] == want, (B, N, JC, plan.chunks)
+        plan.close()
 
 
 # ---- the batch axis over several devices (BASELINE config 4) --------------------
