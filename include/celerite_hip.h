@@ -206,9 +206,11 @@ typedef struct clr_batch clr_batch;
  *   1..8   chunked scan over n, one lane per (problem, chunk)  (the headline path);
  *   9..64  one wave per (problem, chunk), S distributed over the lanes (BASELINE
  *          config 5: 16 complex terms); fused log-likelihood only.  One chunk = the
- *          reference recurrence itself; widths <= 32 are cut into chunks (two-pass
+ *          reference recurrence itself; the series is cut into chunks (two-pass
  *          scan) when B alone leaves SIMDs idle (clr_batch_set_chunks(h, 0) picks
- *          2048 / B, at most 16).  Materialising runs write the reference's storage directly
+ *          2048 / B, at most 16, at widths <= 32; 1024 / B, at most 16, at widths 33..64 -- one
+ *          wave per SIMD there, the chunks chained by one walk per problem: csrc/wide64_kernels.hip).
+ *          Materialising runs write the reference's storage directly
  *          (every chunk replayed from its scanned start state and checked, as CholeskySolver.compute
  *          does); layouts do not apply;
  *   else   CLR_UNSUPPORTED. */
@@ -248,7 +250,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter,
  * problems (N resp. J_general * N) or 0 for one block shared by all problems; J_general = 0 removes them.  A plan
  * with general terms evaluates, up to a total width J_real + 2 J_comp + J_general of 64, on the wave-per-(problem,
  * chunk) kernels of the widths 9..64 with the general rows as a third row class (per-sample features fetched a few
- * steps ahead; chunked scan up to total width 32, as clr_batch_set_chunks(h, 0) would pick for a wide plan), above
+ * steps ahead; chunked scan up to total width 64, as clr_batch_set_chunks(h, 0) would pick for a wide plan), above
  * that -- or after clr_batch_set_general_route(h, 1) -- through the any-width sequential kernel (one workgroup per
  * problem, the reference's step order) up to CLR_MAX_WIDTH; fused log-likelihood only (materialising runs:
  * CholeskySolver). */
