@@ -942,7 +942,12 @@ def main(argv=None):
                             "BASELINE configs[1]: batch=256, N=1e4, width 4 (2 complex terms)", 256, 10000, 0, 2, 20, 64, 7)),
                         ("config4_b256_n1e5_w32", lambda: batch_config(
                             "BASELINE configs[4]: batch=256, N=1e5, width 32 (16 complex terms, log d ~ U(0,3))",
-                            256, 100000, 0, 16, 5, 4, 11, d_spread=True))]:
+                            256, 100000, 0, 16, 5, 4, 11, d_spread=True)),
+                        # not a BASELINE configuration: the reference's dynamic-width arm (cholesky.h:203) at the widest
+                        # shape the chunked scan covers since round 5 (widths 33..64 parallel in n; 174 ms sequential)
+                        ("extra_b256_n1e5_w64", lambda: batch_config(
+                            "extra (not in BASELINE): batch=256, N=1e5, width 64 (32 complex terms, log d ~ U(0,3)): "
+                            "chunked scan at the padded width 64", 256, 100000, 0, 32, 3, 2, 288, d_spread=True))]:
             try:
                 cfg[key] = fn()
             except Exception as e:  # a failing side leg must not lose the headline line
@@ -1001,6 +1006,10 @@ def promote(out):
     c1 = cfgs.get("config1_b256_n1e4_w4")
     if c1:
         r["config1_ms_per_step"] = c1.get("ms_per_step")
+    c64 = cfgs.get("extra_b256_n1e5_w64")
+    if c64 and "ms_per_step" in c64:
+        r["extra_w64"] = {"ms_per_step": c64["ms_per_step"], "scan_chunks": c64.get("scan_chunks"),
+                          "logdet_rel_max": (c64.get("parity") or {}).get("logdet_rel_max")}
     for key, name in (("sharded_product_path", "sharded_2x512"), ("sharded_config3_b8192", "sharded_8x1024")):
         sblk = out.get(key)
         if sblk and "value" in sblk:

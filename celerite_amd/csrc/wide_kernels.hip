@@ -117,12 +117,19 @@ __device__ __forceinline__ int wide_chunk_begin(const BatchParams& P, int c) {
 // row is a "real" row (d = 0: cos = 1, sin = 0, c = 0: phi = 1) whose constants u0, v0 are REPLACED every step by
 // the row's next sample, fetched GEN_PF steps ahead through a register queue -- nothing else in the step changes.
 constexpr int GEN_PF = 6;
-template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN>
+// NW (round 5): waves per (problem, chunk).  NW = 2 at WMAX = 64: a workgroup of 128 lanes, TWO lanes per row with 32
+// columns each -- S and A^T are 2 x 32 doubles per lane (128 registers) instead of 2 x 64 (all 256 architectural
+// registers, 329 v_accvgpr moves per step), two waves per SIMD fit, and both the summarize and the replay flavour run
+// without scratch.  The price is two workgroup barriers per step: the row sums u.q, u.f cross the two waves through LDS
+// (xbuf; both waves add the two partial sums in the same order, so D is bit-identical in both), and the step's w (and r)
+// must be complete before the rank-1 updates read them.  u, phi are published a step ahead as before (their writes and
+// the previous step's reads are separated by those barriers).
+template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN, int NW = 1>
 __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int JC) {
   static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
+  static_assert(NW == 1 || (NW == 2 && WMAX == 64), "two waves per (problem, chunk): the padded width 64");
   constexpr bool RID = MODE == 1 && RIDERS;
-  using G = WideGeom<WMAX>;
-  constexpr int LPR = G::LPR, COLS = G::COLS;
+  constexpr int LPR = 64 * NW / WMAX, COLS = WMAX / LPR;
   constexpr int J = WMAX, SZ = J * (J + 1) / 2;
   constexpr int ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
   // Jm on the matrix cores (width 32, lazy summarize): the r of a 16-step block and -r / D are parked in LDS
@@ -133,6 +140,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // 32 FMA per step, with fp64 MFMA only 1.28x the VALU's FMA rate and not overlapping it: profiles/r04a_mfma_overlap.txt.)
   constexpr bool JMM = RID && LAZY && (WMAX == 32 || WMAX == 64) && CLR_WIDE_JM_MFMA;
   constexpr int NTL = WMAX / 16, NTILE = NTL * (NTL + 1) / 2;  // (JMM) 16 x 16 tiles per side / of the upper triangle of Jm
+  constexpr int NTW = NTILE / NW;                              // ... tiles per wave (NW = 2: every other tile)
   constexpr bool PACKED = LPR >= 2 && CLR_WIDE_PACKED_SUMS;
   constexpr bool LPWIN = LAZY && CLR_WIDE_LOGPROD_WINDOW;
   __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * WMAX : 2];
@@ -145,9 +153,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
   __shared__ __attribute__((aligned(16))) double rbuf[(RID && !JMM) ? WMAX : 2];
   __shared__ __attribute__((aligned(16))) double psibuf[LAZY ? WMAX : 2];
-  const int lane = threadIdx.x;
+  __shared__ double xbuf[NW == 2 ? 8 : 1];  // (NW = 2) the two waves' partial row sums: [wave][u.q | u.f] (and, at the end, their residual maxima)
+  const int tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;  // lane: position in the wave (tiles, DPP, MFMA layout)
+  auto xsync = [&]() { if (NW == 2) lds_barrier(); };             // (LDS-only wait: the tile prefetch stays in flight)
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int row = lane / LPR, seg = lane % LPR;
+  const int row = tid / LPR, seg = tid % LPR;
   const int Wc = JR + 2 * JC;                       // celerite rows
   const int W = Wc + (GEN ? P.J_general : 0);       // + general rows
   const bool writer = seg == 0;
@@ -198,9 +208,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     f = st[SZ + row];
   }
   double AT[RID ? COLS : 1], Jm[(RID && !JMM) ? COLS : 1], eta = 0.0;
-  mfma_acc_t Jacc[JMM ? NTILE : 1];  // (JMM) the tiles (ti, tj), ti <= tj, of Jm's upper triangle, row by row
+  mfma_acc_t Jacc[JMM ? NTW : 1];  // (JMM) the tiles (ti, tj), ti <= tj, of Jm's upper triangle, row by row (NW = 2: tile q of wave q % 2)
 #pragma unroll
-  for (int q_ = 0; q_ < (JMM ? NTILE : 1); ++q_) Jacc[q_] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+  for (int q_ = 0; q_ < (JMM ? NTW : 1); ++q_) Jacc[q_] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
   double dprod = 1.0;  // (LPWIN) product of the current block's pivots
   if (RID) {
 #pragma unroll
@@ -356,6 +366,12 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       if constexpr (PACKED && CLR_WIDE_PERMLANE_SUMS) row_sum2_all<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
       else if constexpr (PACKED) row_sum2<LPR>(ueff * (seg == 0 ? q : f), seg, &s, &ub);
       else { s = row_sum_all<LPR>(ueff * q); ub = row_sum_all<LPR>(ueff * f); }  // (one lane per row: width 64)
+      if (NW == 2) {  // the other wave's rows: partial sums through LDS, added in the same order by both waves
+        if (lane == 0) { xbuf[2 * wvi] = s; xbuf[2 * wvi + 1] = ub; }
+        xsync();
+        s = xbuf[0] + xbuf[2];
+        ub = xbuf[1] + xbuf[3];
+      }
       const double D = diag_n - s;  // (diag_n: the tile already holds K(0) = ((diag + sum a_real) + sum a_comp) + jitter)
       const double invD = (MODE == 1) ? recip_fast(D) : 1.0 / D;  // (the replay writes W = z / D into the factor: IEEE)
       const double x = y_n - ub;
@@ -382,6 +398,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           rsblk[((n - n_lo) & 15) * WMAX + row] = -(r * invD);
         }
       }
+      xsync();  // (NW = 2: the step's w -- and r -- of BOTH waves' rows, before the rank-1 updates read them)
       if (MODE == 0 && P.wide_materialize && writer && row < W) {
         // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
         // u[:, n - 1] = U~(t_n), phi[:, n] = decay n -> n + 1 (cholesky.h:131-151, :177-178)
@@ -443,8 +460,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           }
           if (JMM) {       // Jm += R (-D^-1 R)^T over the block's steps
             const int cnt = ((n - n_lo) & 15) + 1;
-            if (cnt < 16)  // the chunk's last, shorter block: the unused steps contribute nothing
-              for (int idx = cnt * WMAX + lane; idx < 16 * WMAX; idx += 64) { rblk[idx] = 0.0; rsblk[idx] = 0.0; }
+            if (cnt < 16) {  // the chunk's last, shorter block: the unused steps contribute nothing
+              for (int idx = cnt * WMAX + tid; idx < 16 * WMAX; idx += 64 * NW) { rblk[idx] = 0.0; rsblk[idx] = 0.0; }
+              xsync();
+            }
             const int lm = lane & 15, lk = lane >> 4;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -458,12 +477,15 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 #pragma unroll
               for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
-                for (int tj = ti; tj < NTL; ++tj, ++q_)
-                  Jacc[q_] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], Jacc[q_], 0, 0, 0);
+                for (int tj = ti; tj < NTL; ++tj, ++q_) {
+                  if (NW == 1) Jacc[q_] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], Jacc[q_], 0, 0, 0);
+                  else if ((q_ & 1) == wvi) Jacc[q_ >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], Jacc[q_ >> 1], 0, 0, 0);
+                }
               }
             }
           }
           if (writer) psibuf[row] = psi;
+          xsync();
           const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
 #pragma unroll
           for (int c = 0; c < COLS / 2; ++c) {
@@ -514,10 +536,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
         for (int tj = ti; tj < NTL; ++tj, ++q_) {
+          if (NW == 2 && (q_ & 1) != wvi) continue;  // (the other wave's tile)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * ti + lk + 4 * r, j = 16 * tj + lm;
-            if (i <= j) e[J * J + J + SZ + J + tri(i, j)] = Jacc[q_][r];
+            if (i <= j) e[J * J + J + SZ + J + tri(i, j)] = Jacc[NW == 2 ? (q_ >> 1) : q_][r];
           }
         }
       }
@@ -526,7 +549,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       e[J * J + row] = f;                                        // b (the zero-start f)
       e[J * J + J + SZ + row] = eta;
     }
-    if (lane == 0) {  // zero-start sums: correct_kernel<WMAX> turns them into the true contributions
+    if (tid == 0) {  // zero-start sums: correct_kernel<WMAX> turns them into the true contributions
       P.part[slot * 2 + 0] = lp.log_value();
       P.part[slot * 2 + 1] = quad;
       P.flags[slot] = flag;
@@ -553,13 +576,19 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       dp = fmax(dp, __shfl_xor(dp, m, 64)); pm = fmax(pm, __shfl_xor(pm, m, 64));
       df = fmax(df, __shfl_xor(df, m, 64)); fm = fmax(fm, __shfl_xor(fm, m, 64));
     }
-    if (lane == 0) {
+    if (NW == 2) {  // the other wave's rows
+      xsync();
+      if (lane == 0) { xbuf[4 * wvi] = dp; xbuf[4 * wvi + 1] = pm; xbuf[4 * wvi + 2] = df; xbuf[4 * wvi + 3] = fm; }
+      xsync();
+      dp = fmax(xbuf[0], xbuf[4]); pm = fmax(xbuf[1], xbuf[5]); df = fmax(xbuf[2], xbuf[6]); fm = fmax(xbuf[3], xbuf[7]);
+    }
+    if (tid == 0) {
       double res = (pm > 0.0) ? dp / pm : (dp == 0.0 ? 0.0 : INFINITY);
       if (fm > 0.0 && !P.logdet_only) res = fmax(res, df / fm);
       P.cond[slot * 3 + 2] = (chunk + 1 < P.nchunk) ? res : 0.0;
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     const double ld = lp.log_value();
     if (P.nchunk > 1) {  // partial sums of this chunk; finalize_kernel adds them up
       P.partx[slot * 2 + 0] = ld;
@@ -591,6 +620,13 @@ template <bool FAST, bool LAZY, bool GEN>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) wide_summarize64_kernel(const BatchParams P, int JR, int JC) {
   if (blockIdx.x == 0) wide_scan_body<64, FAST, 1, LAZY, false, GEN>(P, JR, JC);
   else wide_scan_body<64, FAST, 1, LAZY, true, GEN>(P, JR, JC);
+}
+// ... and TWO waves per (problem, chunk): two lanes per row, 32 columns per lane (wide_scan_body, NW = 2) -- the state fits
+// the architectural registers, two waves per SIMD, both the summarize (MODE 1) and the replay / sequential sweep (MODE 0).
+template <bool FAST, int MODE, bool LAZY, bool GEN>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) wide_scan64x2_kernel(const BatchParams P, int JR, int JC) {
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<64, FAST, MODE, LAZY, false, GEN, 2>(P, JR, JC);
+  else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -993,11 +1029,18 @@ namespace {
 int wide_max_width() { return 64; }
 int wide_scan_max_width() { return 64; }  // the chunk algebra: prefix_coop_kernel<16>, wide_prefix32_kernel, wide_walk64_kernel (wide64_kernels.hip)
 
+// widths 33..64: two waves per (problem, chunk) (wide_scan64x2_kernel); CLR_WIDE64_ONE_WAVE=1 keeps the one-wave kernels (A/B)
+static bool wide64_one_wave() { return getenv("CLR_WIDE64_ONE_WAVE") != nullptr; }
 template <bool GEN>
 static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const dim3 grid(P.nchunk, P.B);
-  if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
-  else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+  if (wide64_one_wave()) {
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    return;
+  }
+  if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 0, false, GEN>), grid, dim3(128), 0, s, P, JR, JC);
+  else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 0, false, GEN>), grid, dim3(128), 0, s, P, JR, JC);
 }
 
 template <int MODE, bool GEN>
@@ -1012,14 +1055,20 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
   } while (0)
     if (W <= 16) CLR_GOL(16);
     else if (W <= 32) CLR_GOL(32);
-    else if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
-    else hipLaunchKernelGGL((wide_summarize64_kernel<false, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    else if (wide64_one_wave()) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+      else hipLaunchKernelGGL((wide_summarize64_kernel<false, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    } else if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, GEN>), grid, dim3(128), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, GEN>), grid, dim3(128), 0, s, P, JR, JC);
 #undef CLR_GOL
     return;
   }
   if (MODE == 1 && W > 32) {  // widths 33..64 on a series that is not densely sampled
-    if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
-    else hipLaunchKernelGGL((wide_summarize64_kernel<false, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    if (wide64_one_wave()) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+      else hipLaunchKernelGGL((wide_summarize64_kernel<false, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
+    } else if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, false, GEN>), grid, dim3(128), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, false, GEN>), grid, dim3(128), 0, s, P, JR, JC);
     return;
   }
 #define CLR_GO(WM)                                                                                                        \
