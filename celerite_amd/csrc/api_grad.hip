@@ -56,7 +56,7 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
     return fail(CLR_UNSUPPORTED, "the plan gradient with general terms needs the chunked wide scan (total width <= 32, N >= 1024)");
   if (!general && (h->launch || h->nchunk < 2))
     return fail(CLR_UNSUPPORTED, "the plan gradient at widths 9..32 needs a chunked plan: use clr_batch_grad_log_likelihood");
-  if (Wt > clr::wide_scan_max_width())
+  if (Wt > 32)  // (the chunk-wise tangent kernels exist at the padded widths 16 and 32; the scan itself reaches 64)
     return fail(CLR_UNSUPPORTED, "the plan gradient covers total widths up to 32: use clr_batch_grad_log_likelihood");
   int st = clr_batch_enqueue(h, 0);
   if (st != CLR_OK) return st;

@@ -16,4 +16,6 @@ if __name__ == "__main__":
     for db in sys.argv[1:]:
         for r in table(db):
             if "clr" in r[0]:
-                print("%-52s %-26s n=%-3d avg=%-16.6g avg_dur_us=%.1f" % (r[0][:52], r[1], r[2], r[3], r[4] / 1e3))
+                # (name | counter | dispatches | average per dispatch | average duration; the name long enough to tell the
+                #  template instantiations apart)
+                print("%-120s| %-26s n=%-3d avg=%-16.6g avg_dur_us=%.1f" % (r[0][:120], r[1], r[2], r[3], r[4] / 1e3))
