@@ -823,6 +823,48 @@ def test_wide_scan_over_chunks_at_widths_33_to_64(JR, JC):
             plan.close()
 
 
+def test_adversarial_problems_at_widths_33_to_64_keep_the_reference_status():
+    """tests/_cases.adversarial (near-singular and indefinite kernels) through the chunked scan at the padded width 64:
+    the status word is the oracle's (cholesky.h:176) for every problem whatever route settles it -- chunk summaries
+    (route 0: must meet 1e-10), checked chunked replay (route 1) or the sequential sweep (route 2), whose distance from
+    the CPU oracle follows the problem's own cancellation gamma (bound as at the narrow widths)."""
+    shapes = [(33, 0), (8, 16), (0, 20), (40, 2), (2, 31), (64, 0)]
+    n_bad = n_ok = 0
+    n_level = [0, 0, 0]
+    for trial in range(12):
+        JR, JC = shapes[trial % len(shapes)]
+        N = (2100, 4000, 7000)[trial % 3]
+        case = adversarial(4, N, JR, JC, seed=8000 + trial)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"], nthreads=os.cpu_count() or 1)
+        n_bad += int((s0 != 0).sum())
+        plan = batch.BatchedGP(4, N, JR, JC)
+        try:
+            plan.set_series(case["t"], case["diag"], case["y"])
+            for nchunk in (2, 5, 1):
+                plan.set_chunks(nchunk)
+                plan.set_coefficients(*coeffs_of(case))
+                ll, ld, q, st = plan.log_likelihood()
+                assert np.array_equal(st, s0), (trial, nchunk, st, s0)
+                levels = plan.exact_levels()
+                gamma, mu = plan.conditioning()
+                for p in range(4):
+                    if s0[p] != 0 or not (np.isfinite(d0[p]) and np.isfinite(q0[p])):
+                        continue
+                    n_ok += 1
+                    n_level[levels[p]] += 1
+                    dev = max(abs(ld[p] - d0[p]) / abs(d0[p]), abs(q[p] - q0[p]) / abs(q0[p]))
+                    if levels[p] == 0:
+                        within("adversarial family at widths 33..64, route 0: deviation from the oracle", dev, REL, (trial, nchunk, p))
+                    else:
+                        g = gamma[p] if nchunk > 1 else 0.0
+                        bound = min(1e-3, max(1e-10, 1e-17 * g ** 2)) if nchunk > 1 else 1e-6
+                        within("adversarial family at widths 33..64, route %d: deviation / bound" % levels[p], dev / bound, 1.0,
+                               (trial, nchunk, p, dev, g))
+        finally:
+            plan.close()
+    assert n_bad >= 3 and n_ok >= 40, (n_bad, n_ok, n_level)
+
+
 @pytest.mark.parametrize("JR,JC", [(0, 16), (5, 10), (17, 0)])
 def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, JC):
     """wide_walk_kernel (prefix + corrections + certificate in one walk per problem; the path of widths 33..64)
