@@ -763,6 +763,13 @@ def main(argv=None):
         mat_runs = [m / mat_steps for m, _ in mat_all]
         mat_replay_runs = [k["replay"] / mat_steps for _, k in mat_all]
         mat_ms, mat_k = sorted(mat_all, key=lambda mk: mk[0])[len(mat_all) // 2]
+        # the batched solve (CholeskySolver::solve for all B problems, parallel in n) on the factor just written: K^-1 y
+        solve = {}
+        try:
+            plan.solve(); x_ref = plan.solve()
+            solve["reference_layout_device_ms"] = plan.solve_device_ms()
+        except Exception as e:
+            solve["error"] = repr(e)
         # the LEAN layout (SURVEY.md 8d row A-lean): W and D stored, phi and u regenerated by the consumers
         lean = None
         try:
@@ -771,6 +778,20 @@ def main(argv=None):
             lean_all = [plan.run_timed(mat_steps, materialize=True, relayout_each_step=False) for _ in range(5)]
             lean_ms, lean_k = sorted(lean_all, key=lambda mk: mk[0])[len(lean_all) // 2]
             lld, lq = plan.results()[1:3]
+            if "error" not in solve:
+                plan.solve(); x_lean = plan.solve()
+                solve["lean_layout_device_ms"] = plan.solve_device_ms()
+                solve["lean_vs_reference_layout_rel"] = float(np.max(np.abs(x_lean - x_ref)) / np.max(np.abs(x_ref)))
+                from oracle import ref as _ref2
+                _r = _ref2.RefSolver()
+                _e, _e2 = np.empty(0), np.empty((0, 0))
+                t0_ = time.perf_counter()
+                _r.compute(0.0, *[c[0] for c in coeffs], _e, _e2, _e2, t[0], diag[0])
+                t1_ = time.perf_counter()
+                x0 = _r.solve(y[0])[:, 0]
+                solve["cpu_oracle_solve_ms_per_problem"] = (time.perf_counter() - t1_) * 1e3
+                solve["problem0_vs_oracle_rel"] = float(np.max(np.abs(x_lean[0] - x0)) / np.max(np.abs(x0)))
+                del x_lean, x_ref
             lean = {"ms": lean_ms / mat_steps, "k": {k: v / mat_steps for k, v in lean_k.items()},
                     "runs": [m / mat_steps for m, _ in lean_all], "bytes_per_problem": plan.factor_bytes(),
                     "logdet_vs_fused_rel": rel_err(lld[st == 0], ld[st == 0]), "quad_vs_fused_rel": rel_err(lq[st == 0], q[st == 0])}
@@ -890,6 +911,14 @@ def main(argv=None):
                              "bytes_per_step": lean_factor + 2 * bytes_}}
         elif lean:
             out["materialize_lean"] = lean
+        if solve:
+            solve["what"] = ("clr_batch_solve: K^-1 y for all %d problems from the materialised factor (CholeskySolver::solve, cholesky.h:218-318, "
+                             "as two chunked affine scans; device time of its kernels incl. the two relayouts, right-hand side = the "
+                             "plan's resident y); bytes through HBM: four passes over the factor + the relayouts" % B)
+            if "lean_layout_device_ms" in solve:
+                solve["value_lean"] = B / (solve["lean_layout_device_ms"] * 1e-3)
+                solve["unit"] = "solves/s"
+            out["batched_solve"] = solve
         # SURVEY.md 8(d) layout (ii): ONE series shared by all B hyper-parameter draws (the MCMC case; t, diag, y with
         # stride 0: 2.4 MB of series in HBM instead of 2.4 GB).  For information; `value` is layout (i), B distinct series.
         try:
@@ -986,6 +1015,10 @@ def promote(out):
                             "bytes_per_launch": mr["bytes_per_launch"], "traffic": mr.get("traffic")}
         r["materialize_frac"] = mr["frac"]
         r["materialize_whole_step_frac"] = mr["whole_step_frac"]
+    bs = out.get("batched_solve")
+    if bs and "lean_layout_device_ms" in bs:
+        r["batched_solve_ms"] = {"reference_layout": bs.get("reference_layout_device_ms"), "lean_layout": bs["lean_layout_device_ms"],
+                                 "problem0_vs_oracle_rel": bs.get("problem0_vs_oracle_rel")}
     ml = out.get("materialize_lean")
     if ml and "ms_per_step" in ml:
         r["materialize_lean"] = {"step_ms": ml["ms_per_step"], "replay_ms": ml["kernels_ms"]["replay"],

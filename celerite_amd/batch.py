@@ -301,6 +301,32 @@ class BatchedGP(object):
         _check(_load().clr_batch_get_factor(self._h, int(p), _ptr(phi), _ptr(u), _ptr(W), _ptr(D)))
         return phi.T, u.T, W.T, D
 
+    def solve(self, b=None):
+        """``K_p^-1 b_p`` for every problem from the factor of the last materialising run (``clr_batch_solve``;
+        ``CholeskySolver.solve``, cholesky.h:218-318, for B problems at once).  ``b``: ``(B, N)`` or ``(B, nrhs, N)``;
+        ``None``: the plan's own ``y`` (no upload).  Returns an array of the same shape."""
+        lib = _load()
+        lib.clr_batch_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        if b is None:
+            x = np.empty((self.B, self.N))
+            _check(lib.clr_batch_solve(self._h, 1, None, _ptr(x)))
+            return x
+        b = _f64(b)
+        if b.ndim not in (2, 3) or b.shape[0] != self.B or b.shape[-1] != self.N:
+            raise ValueError("dimension mismatch")
+        nrhs = 1 if b.ndim == 2 else b.shape[1]
+        x = np.empty(b.shape)
+        _check(lib.clr_batch_solve(self._h, int(nrhs), _ptr(b), _ptr(x)))
+        return x
+
+    def solve_device_ms(self):
+        """Device time of the last :meth:`solve` (its kernels, without the host <-> HBM copies)."""
+        lib = _load()
+        ms = C.c_double()
+        lib.clr_batch_get_solve_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _check(lib.clr_batch_get_solve_ms(self._h, C.byref(ms)))
+        return ms.value
+
     KERNEL_NAMES = ("relayout", "summarize", "prefix", "correct", "replay", "finalize")
 
     LAYOUTS = {"rowmajor": 0, "interleaved": 1, "staged": 2}

@@ -51,7 +51,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res, &h->g_rec, &h->g_ck})
+                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -142,6 +142,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   h->relayout_pending = true;
   h->grad_span_valid = false;
   h->have_factor = false;  // its layout depends on the chunking
+  h->factor_valid = false;
   const size_t pc = (size_t)h->B * h->nchunk;
   h->plan = clr::plan_prefix(h->nchunk, 0, 0);
   h->scan_ws_doubles = 0;
@@ -1082,6 +1083,7 @@ static int materialize_pipeline(clr_batch* h, const clr::BatchParams& P) {
   HIP_TRY(hipStreamWaitEvent(h->stream, h->mp_ev[2 * G + 1], 0));
   h->factor_is_lean = h->factor_layout == 1;
   h->factor_inputs_changed = false;
+  h->factor_valid = true;
   clr::launch_finalize(P, h->stream);
   HIP_TRY(hipGetLastError());
   return CLR_OK;
@@ -1106,7 +1108,7 @@ int clr_batch_get_rescue(const clr_batch* h, int* last_count, long* total, int* 
 int clr_batch_set_factor_layout(clr_batch* h, int layout) {
   if (layout != 0 && layout != 1) return fail(CLR_INVALID_ARGUMENT, "factor layout: 0 (phi, u, W, D) or 1 (lean: W, D)");
   if (layout == 1 && !h->launch) return fail(CLR_UNSUPPORTED, "the lean factor layout covers widths 1..8 (wider plans write the reference's storage)");
-  if (layout != h->factor_layout) h->have_factor = false;
+  if (layout != h->factor_layout) { h->have_factor = false; h->factor_valid = false; }
   h->factor_layout = layout;
   return CLR_OK;
 }
@@ -1266,7 +1268,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   mark(4);
   h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);  // forced-exact / materialising runs only
   h->launch->sequential(P, replay_mode(h, materialize), h->stream);  // flagged / ill-conditioned problems only
-  if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; }
+  if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; }
   mark(5);
   clr::launch_finalize(P, h->stream);
   mark(6);
@@ -1543,6 +1545,63 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   return CLR_OK;
 }
 
+int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (!h->launch) return fail(CLR_UNSUPPORTED, "clr_batch_solve covers widths 1..8 (wider: CholeskySolver.solve)");
+  if (nrhs < 1 || !x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1 and an output array");
+  if (!b && nrhs != 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: b == NULL means the plan's own y (one right-hand side)");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (!h->have_factor || !h->factor_valid) return fail(CLR_NOT_COMPUTED, "no materialising run has been made (clr_batch_enqueue(h, 1))");
+  if (h->factor_is_lean && h->factor_inputs_changed)
+    return fail(CLR_NOT_COMPUTED, "the lean factor's phi and u are regenerated from the plan's series and coefficients, "
+                                  "which were replaced after the materialising run: materialise again");
+  if (h->nchunk < 2) return fail(CLR_UNSUPPORTED, "clr_batch_solve needs a chunked plan (N >= 128)");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  if (P.staged) {  // the row-major times addressed directly (lean: one time per step and lane)
+    P.t = h->t.p; P.t_stride = h->t_stride; P.lane_is = 1; P.lane_cs = h->L; P.staged = 0;
+  }
+  const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J, R = (size_t)nrhs, cells = (size_t)h->L * h->nchunk;
+  if ((st = h->bs_x.reserve(B * R * cells)) != CLR_OK) return st;
+  if ((st = h->bs_rm.reserve(B * R * N)) != CLR_OK) return st;
+  if ((st = h->bs_M.reserve(B * h->nchunk * J * J)) != CLR_OK) return st;
+  if ((st = h->bs_off.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+  if ((st = h->bs_starts.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+  const double* src = h->y.p;
+  long src_stride = h->y_stride;
+  if (b) {
+    HIP_TRY(hipMemcpyAsync(h->bs_rm.p, b, B * R * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    src = h->bs_rm.p;
+    src_stride = (long)N;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  clr::launch_relayout(src, src_stride, h->bs_x.p, (long)cells, (int)(B * R), h->N, h->L, h->nchunk, 0, h->stream);
+  clr::BSolveParams S;
+  S.nrhs = nrhs; S.r = 0; S.lean = h->factor_is_lean ? 1 : 0;
+  S.xT = h->bs_x.p; S.M = h->bs_M.p; S.off = h->bs_off.p; S.starts = h->bs_starts.p;
+  h->launch->bsolve(P, S, h->stream);
+  clr::launch_relayout_back(h->bs_x.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
+  HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  h->solve_device_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return CLR_OK;
+}
+
+int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms) {
+  if (device_ms) *device_ms = h->solve_device_ms;
+  return CLR_OK;
+}
+
 int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_each_step,
                         double* total_ms, double* kernel_ms) {
   int st = require_device(h->device);
@@ -1611,7 +1670,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[4], h->stream));
     h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);
     h->launch->sequential(P, replay_mode(h, materialize), h->stream);
-    if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; }
+    if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; }
     HIP_TRY(hipEventRecord(e[5], h->stream));
     clr::launch_finalize(P, h->stream);
     if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; }

@@ -286,6 +286,9 @@ struct clr_batch {
   DevBuf elems, starts, part, partx, cond, out;  // out: ll | logdet | quad | status (B ints)
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int force_exact = 0;
+  bool factor_valid = false;  // a materialising run has written the factor under the chunking in force
+  DevBuf bs_rm, bs_x, bs_M, bs_off, bs_starts;  // clr_batch_solve: right-hand sides row-major / chunk-interleaved, chunk maps, offsets, start states
+  double solve_device_ms = 0.0;                 // device time of the last clr_batch_solve (HIP events around its kernels)
   int factor_layout = 0;      // clr_batch_set_factor_layout: 0 the reference's four arrays, 1 lean (W, D; phi, u regenerated)
   bool factor_is_lean = false;  // what the factor in HBM holds (set by the materialising run that wrote it)
   bool factor_inputs_changed = false;  // series or coefficients replaced since that run (a lean factor can then no longer be expanded)

@@ -175,6 +175,30 @@ void launch_relayout(const double* src, long src_stride, double* dst, long dst_s
   hipLaunchKernelGGL(relayout_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride,
                      N, L, nchunk, pad_kind);
 }
+// the inverse of relayout_kernel: [problem][i][chunk] -> [problem][n] for n = chunk * L + i < N (clr_batch_solve's result)
+__global__ void __launch_bounds__(256) relayout_back_kernel(const double* __restrict__ src, long src_stride,
+                                                            double* __restrict__ dst, long dst_stride, int N, int L, int nchunk) {
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z, i0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const double* in = src + (long)b * src_stride;
+  double* out = dst + (long)b * dst_stride;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = i0 + r, c = c0 + threadIdx.x;
+    tile[r][threadIdx.x] = (i < L && c < nchunk) ? in[(long)i * nchunk + c] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int c = c0 + r, i = i0 + threadIdx.x;
+    const long n = (long)c * L + i;
+    if (c < nchunk && i < L && n < N) out[n] = tile[threadIdx.x][r];
+  }
+}
+void launch_relayout_back(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L, int nchunk,
+                          hipStream_t s) {
+  dim3 grid((L + 31) / 32, (nchunk + 31) / 32, nsrc);
+  hipLaunchKernelGGL(relayout_back_kernel, grid, dim3(32, 8), 0, s, src, src_stride, dst, dst_stride, N, L, nchunk);
+}
+
 // ---- re-planning of a few problems as a small plan of their own (api_batch.hip: rescue_run) ---------------------
 // series of the problems idx[0..n) of a plan -> rows 0..n of another plan's arrays (device to device)
 __global__ void __launch_bounds__(256) gather_series_kernel(const double* __restrict__ src, long src_stride,

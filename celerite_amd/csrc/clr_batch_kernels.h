@@ -959,6 +959,7 @@ __global__ void __launch_bounds__(64) warm_check_kernel(const BatchParams P) {
 }  // namespace clr
 #include "clr_prefix_kernels.h"
 #include "clr_grad_kernels.h"
+#include "clr_bsolve_kernels.h"
 namespace clr {
 
 // One table entry per (JR, JC): host-callable launchers.
@@ -974,6 +975,8 @@ struct BatchLaunchers {
   void (*warm)(const BatchParams&, hipStream_t);  // warm_kernel + warm_check_kernel
   void (*grad)(const BatchParams&, hipStream_t);  // riders + tangents + walk over the chunks (needs P.fast_trig)
   void (*grad_reverse)(const BatchParams&, hipStream_t);  // riders + record, adjoint walk, reverse sweep, reduction
+  // K^-1 b for all problems and right-hand sides from the materialised factor (clr_bsolve_kernels.h): S.xT in / out
+  void (*bsolve)(const BatchParams&, BSolveParams S, hipStream_t);
   // lean factor of problem b (replay mode 3) -> the reference's storage, phi and u regenerated (t: the problem's row-major times)
   void (*expand)(const BatchParams&, int b, const double* t, double* phi, double* u, double* W, double* D, hipStream_t);
   int elem_doubles, start_doubles;
@@ -1034,6 +1037,35 @@ struct BatchImpl {
     if (P.fast_trig) hipLaunchKernelGGL((expand_lean_factor_kernel<JR, JC, true>), dim3(blocks), dim3(256), 0, s, P, b, t_rowmajor, phi, u, W, D);
     else hipLaunchKernelGGL((expand_lean_factor_kernel<JR, JC, false>), dim3(blocks), dim3(256), 0, s, P, b, t_rowmajor, phi, u, W, D);
   }
+  // the batched solve: chunk maps once, then per right-hand side the forward and the backward chunked affine scans
+  template <bool LEAN, bool FAST>
+  static void bsolve_go(const BatchParams& P, BSolveParams S, hipStream_t s) {
+    constexpr int J = JR + 2 * JC;
+    const dim3 grid((P.nchunk + 63) / 64, P.B), pgrid((unsigned)(((long)P.B * S.nrhs + 63) / 64));
+    for (int r = 0; r < S.nrhs; ++r) {
+      S.r = r;
+      if (r == 0) hipLaunchKernelGGL((bsolve_summarize_kernel<JR, JC, LEAN, FAST, true>), grid, dim3(64), 0, s, P, S);
+      else hipLaunchKernelGGL((bsolve_summarize_kernel<JR, JC, LEAN, FAST, false>), grid, dim3(64), 0, s, P, S);
+    }
+    hipLaunchKernelGGL((bsolve_prefix_kernel<J, false>), pgrid, dim3(64), 0, s, P, S);
+    for (int r = 0; r < S.nrhs; ++r) {
+      S.r = r;
+      hipLaunchKernelGGL((bsolve_forward_kernel<JR, JC, LEAN, FAST>), grid, dim3(64), 0, s, P, S);
+    }
+    for (int r = 0; r < S.nrhs; ++r) {
+      S.r = r;
+      hipLaunchKernelGGL((bsolve_backward_kernel<JR, JC, LEAN, FAST, true>), grid, dim3(64), 0, s, P, S);
+    }
+    hipLaunchKernelGGL((bsolve_prefix_kernel<J, true>), pgrid, dim3(64), 0, s, P, S);
+    for (int r = 0; r < S.nrhs; ++r) {
+      S.r = r;
+      hipLaunchKernelGGL((bsolve_backward_kernel<JR, JC, LEAN, FAST, false>), grid, dim3(64), 0, s, P, S);
+    }
+  }
+  static void bsolve(const BatchParams& P, BSolveParams S, hipStream_t s) {
+    if (S.lean) { if (P.fast_trig) bsolve_go<true, true>(P, S, s); else bsolve_go<true, false>(P, S, s); }
+    else bsolve_go<false, true>(P, S, s);  // (the stored phi, u: no trigonometry)
+  }
   static void compose_check(const BatchParams& P, int g, double* coop, double* ref, hipStream_t s) {
     constexpr int J = JR + 2 * JC;
     const int np = (P.nchunk + g - 1) / g;
@@ -1086,7 +1118,7 @@ struct BatchImpl {
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,
-                          &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
+                          &bsolve, &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };
 
@@ -1109,6 +1141,9 @@ void launch_finalize(const BatchParams& P, hipStream_t s);
 void launch_deinterleave_factor(const double* phi_i, const double* u_i, const double* W_i,
                                 const double* D_i, double* phi, double* u, double* W, double* D,
                                 int N, int J, int L, int nchunk, hipStream_t s);
+// ... and back: [problem][i][chunk] -> [problem][n] (api_kernels.hip)
+void launch_relayout_back(const double* src, long src_stride, double* dst, long dst_stride, int nsrc, int N, int L, int nchunk,
+                          hipStream_t s);
 // [problem][n] -> [problem][i][chunk] for n = chunk * L + i (api_kernels.hip).
 void launch_relayout(const double* src, long src_stride, double* dst, long dst_stride, int nsrc,
                      int N, int L, int nchunk, int pad_kind, hipStream_t s);

@@ -436,6 +436,19 @@ int clr_batch_synchronize(clr_batch* h);
 /* HBM -> host; any pointer may be NULL. */
 int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
                           double* quad, int* status);
+/* CholeskySolver::solve (cholesky.h:218-318) for every problem of the plan at once: x = K_p^-1 b_p from the factor of
+ * the last materialising run (clr_batch_enqueue(h, 1); either factor layout), parallel in n -- forward substitution,
+ * division by D and backward substitution as two chunked affine scans whose chunk maps are formed once and shared by
+ * all right-hand sides and both sweeps (csrc/clr_bsolve_kernels.h).  b and x: host arrays [B][nrhs][N] (row-major:
+ * right-hand side k of problem p at (p * nrhs + k) * N); b == NULL with nrhs == 1: the plan's own y (already in HBM --
+ * GP.apply_inverse(y) of celerite.py:307-328 for B problems without an upload).  Widths 1..8, chunked plans.  A problem
+ * whose materialising run reported CLR_NOT_POSITIVE_DEFINITE has no factor: its x is undefined (non-finite).  With the
+ * LEAN layout the sweeps regenerate phi and u from (t, coefficients) and move 9 instead of 25 doubles per sample through
+ * HBM four times: the plan must still hold the series and coefficients of the materialising run. */
+int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x);
+/* Device time of the last clr_batch_solve (HIP events around its kernels: relayout, the five phases, relayout back;
+ * the host <-> HBM copies of b and x are outside). */
+int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms);
 /* After a materialising run: copy problem p's factor to host buffers. */
 int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W, double* D);
 

@@ -191,6 +191,59 @@ def test_lean_factor_layout_on_flagged_and_ill_conditioned_problems():
     assert n_checked >= 12
 
 
+@pytest.mark.parametrize("JR,JC", [(1, 0), (0, 1), (2, 1), (1, 2), (3, 2), (2, 3), (8, 0), (0, 4)])
+def test_batched_solve_from_the_materialised_factor(JR, JC):
+    """``clr_batch_solve``: CholeskySolver::solve (cholesky.h:218-318) for every problem of a plan at once, parallel in
+    n (two chunked affine scans over the materialised factor, csrc/clr_bsolve_kernels.h), from BOTH factor layouts --
+    the lean one regenerates phi and u per step.  Against the oracle's ``solve`` problem by problem (1e-10 of the largest
+    entry), one and three right-hand sides, the plan's own y without an upload, a ragged last chunk, dense and sparse
+    series; and the error contract: no factor, a stale lean factor, a re-chunked plan."""
+    B, N = 5, 3000
+    rng = np.random.RandomState(17 + JR + 5 * JC)
+    for family in ("bench", "accuracy"):
+        case = synthetic(B, N, JR, JC, family, seed=300 + JR + 3 * JC)
+        b1 = rng.randn(B, N)
+        b3 = rng.randn(B, 3, N)
+        want1, want3, wanty = np.empty((B, N)), np.empty((B, 3, N)), np.empty((B, N))
+        for p in range(B):
+            r = ref.RefSolver()
+            r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)), case["t"][p], case["diag"][p])
+            want1[p] = r.solve(b1[p])[:, 0]
+            want3[p] = r.solve(b3[p].T).T
+            wanty[p] = r.solve(case["y"][p])[:, 0]
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_chunks(24)
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            with pytest.raises(RuntimeError):
+                plan.solve(b1)                               # no materialising run yet
+            for layout in ("reference", "lean"):
+                plan.set_factor_layout(layout)
+                ll, ld, q, st = plan.log_likelihood(materialize=True)
+                assert (st == 0).all()
+                for got, want, what in ((plan.solve(b1), want1, "one rhs"), (plan.solve(b3), want3, "three rhs"), (plan.solve(), wanty, "y")):
+                    assert got.shape == want.shape
+                    dev = np.max(np.abs(got - want), axis=-1) / np.max(np.abs(want), axis=-1)
+                    within("batched solve (%s layout): vs oracle solve, of the largest entry" % layout, np.max(dev), REL, (family, what))
+                # y^T K^-1 y from the solve equals the fused quadratic form
+                within("batched solve: y . solve(y) vs the fused quadratic form", np.max(np.abs(np.sum(case["y"] * plan.solve(), axis=1) - q) / np.abs(q)), 1e-9)
+            plan.set_coefficients(*coeffs_of(case))          # lean factor: stale now
+            with pytest.raises(RuntimeError):
+                plan.solve(b1)
+            plan.set_factor_layout("reference")
+            plan.log_likelihood(materialize=True)
+            plan.set_coefficients(*coeffs_of(case))          # the reference layout is self-contained: still usable
+            assert np.max(np.abs(plan.solve(b1) - want1)) <= 1e-9 * np.max(np.abs(want1))
+            plan.set_chunks(12)                              # re-chunked: the factor is gone
+            with pytest.raises(RuntimeError):
+                plan.solve(b1)
+            with pytest.raises(ValueError):
+                plan.solve(np.zeros((B, N + 1)))
+        finally:
+            plan.close()
+
+
 def test_materialised_factor_at_the_bench_shape_against_the_oracle_state():
     """VERDICT r4 weak #1c: the factor of the materialising run whose roofline the bench line quotes -- BASELINE
     configs[2]'s shape, 1024 problems x 1e5 samples x width 8, automatic chunking -- against the oracle's state
