@@ -766,7 +766,9 @@ def main(argv=None):
         # the batched solve (CholeskySolver::solve for all B problems, parallel in n) on the factor just written: K^-1 y
         solve = {}
         try:
-            plan.solve(); x_ref = plan.solve()
+            plan.solve()
+            solve["reference_layout_first_solve_device_ms"] = plan.solve_device_ms()   # (forms the chunk maps of this factor)
+            x_ref = plan.solve()
             solve["reference_layout_device_ms"] = plan.solve_device_ms()
         except Exception as e:
             solve["error"] = repr(e)
@@ -779,7 +781,9 @@ def main(argv=None):
             lean_ms, lean_k = sorted(lean_all, key=lambda mk: mk[0])[len(lean_all) // 2]
             lld, lq = plan.results()[1:3]
             if "error" not in solve:
-                plan.solve(); x_lean = plan.solve()
+                plan.solve()
+                solve["lean_layout_first_solve_device_ms"] = plan.solve_device_ms()
+                x_lean = plan.solve()
                 solve["lean_layout_device_ms"] = plan.solve_device_ms()
                 solve["lean_vs_reference_layout_rel"] = float(np.max(np.abs(x_lean - x_ref)) / np.max(np.abs(x_ref)))
                 from oracle import ref as _ref2

@@ -1084,6 +1084,7 @@ static int materialize_pipeline(clr_batch* h, const clr::BatchParams& P) {
   h->factor_is_lean = h->factor_layout == 1;
   h->factor_inputs_changed = false;
   h->factor_valid = true;
+  h->bs_M_valid = false;
   clr::launch_finalize(P, h->stream);
   HIP_TRY(hipGetLastError());
   return CLR_OK;
@@ -1268,7 +1269,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   mark(4);
   h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);  // forced-exact / materialising runs only
   h->launch->sequential(P, replay_mode(h, materialize), h->stream);  // flagged / ill-conditioned problems only
-  if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; }
+  if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
   mark(5);
   clr::launch_finalize(P, h->stream);
   mark(6);
@@ -1582,6 +1583,8 @@ int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
   clr::launch_relayout(src, src_stride, h->bs_x.p, (long)cells, (int)(B * R), h->N, h->L, h->nchunk, 0, h->stream);
   clr::BSolveParams S;
   S.nrhs = nrhs; S.r = 0; S.lean = h->factor_is_lean ? 1 : 0;
+  S.have_M = h->bs_M_valid ? 1 : 0;  // (the chunk maps depend on the factor only: formed by the first solve after a materialising run)
+  h->bs_M_valid = true;
   S.xT = h->bs_x.p; S.M = h->bs_M.p; S.off = h->bs_off.p; S.starts = h->bs_starts.p;
   h->launch->bsolve(P, S, h->stream);
   clr::launch_relayout_back(h->bs_x.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
@@ -1670,7 +1673,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[4], h->stream));
     h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);
     h->launch->sequential(P, replay_mode(h, materialize), h->stream);
-    if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; }
+    if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
     HIP_TRY(hipEventRecord(e[5], h->stream));
     clr::launch_finalize(P, h->stream);
     if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; }

@@ -288,6 +288,7 @@ struct clr_batch {
   int force_exact = 0;
   bool factor_valid = false;  // a materialising run has written the factor under the chunking in force
   DevBuf bs_rm, bs_x, bs_M, bs_off, bs_starts;  // clr_batch_solve: right-hand sides row-major / chunk-interleaved, chunk maps, offsets, start states
+  bool bs_M_valid = false;                      // bs_M holds the chunk maps of the factor in HBM (they depend on the factor only)
   double solve_device_ms = 0.0;                 // device time of the last clr_batch_solve (HIP events around its kernels)
   int factor_layout = 0;      // clr_batch_set_factor_layout: 0 the reference's four arrays, 1 lean (W, D; phi, u regenerated)
   bool factor_is_lean = false;  // what the factor in HBM holds (set by the materialising run that wrote it)

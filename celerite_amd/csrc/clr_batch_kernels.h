@@ -1044,7 +1044,7 @@ struct BatchImpl {
     const dim3 grid((P.nchunk + 63) / 64, P.B), pgrid((unsigned)(((long)P.B * S.nrhs + 63) / 64));
     for (int r = 0; r < S.nrhs; ++r) {
       S.r = r;
-      if (r == 0) hipLaunchKernelGGL((bsolve_summarize_kernel<JR, JC, LEAN, FAST, true>), grid, dim3(64), 0, s, P, S);
+      if (r == 0 && !S.have_M) hipLaunchKernelGGL((bsolve_summarize_kernel<JR, JC, LEAN, FAST, true>), grid, dim3(64), 0, s, P, S);
       else hipLaunchKernelGGL((bsolve_summarize_kernel<JR, JC, LEAN, FAST, false>), grid, dim3(64), 0, s, P, S);
     }
     hipLaunchKernelGGL((bsolve_prefix_kernel<J, false>), pgrid, dim3(64), 0, s, P, S);

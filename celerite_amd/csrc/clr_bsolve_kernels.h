@@ -32,6 +32,7 @@ namespace clr {
 struct BSolveParams {
   int nrhs, r;          // right-hand sides of the call, the one this launch works on
   int lean;             // the factor holds W, D only
+  int have_M;           // the chunk maps of this factor are already in M (an earlier solve formed them)
   double* xT;           // [B][nrhs][L][nchunk] right-hand sides in, solutions out
   double* M;            // [B][nchunk][J*J]
   double* off;          // [B][nrhs][nchunk][J] chunk offsets (forward, then backward)
