@@ -664,6 +664,21 @@ class ShardedBatchedGP(object):
     def set_summarize_mode(self, mode=-1):
         self._ok(_load().clr_sharded_set_summarize_mode(self._h, int(mode)))
 
+    def set_rescue(self, mode=-1):
+        """``clr_batch_set_rescue`` on every shard (route-1 problems re-planned as a side plan per shard; ``mode=0``: the
+        inline replay, bit-identical under any sharding)."""
+        lib = _load()
+        lib.clr_sharded_set_rescue.argtypes = [C.c_void_p, C.c_int]
+        self._ok(lib.clr_sharded_set_rescue(self._h, int(mode)))
+
+    def rescued(self):
+        """Problems of the last fetched evaluation that took the checked route outside the main pass, over all shards."""
+        lib = _load()
+        n = C.c_int()
+        lib.clr_sharded_get_rescue.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._ok(lib.clr_sharded_get_rescue(self._h, C.byref(n)))
+        return n.value
+
     def set_warm_start(self, mode=-1, forced_warmup=0):
         """``clr_batch_set_warm_start`` on every shard.  The warm-started recurrence adapts per plan, so a batch
         may take different (equally certified) routes under different shardings -- results then agree to the scan's

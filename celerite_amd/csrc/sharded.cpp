@@ -208,6 +208,23 @@ int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup) {
   return h->all([=](int s) { return clr_batch_set_warm_start(h->plan[s], mode, forced_warmup); });
 }
 
+int clr_sharded_set_rescue(clr_sharded* h, int mode) {
+  return h->all([=](int s) { return clr_batch_set_rescue(h->plan[s], mode); });
+}
+
+int clr_sharded_get_rescue(const clr_sharded* h, int* last_count) {
+  // problems of the last fetched evaluation that were re-planned, summed over the shards (inline replays count negative)
+  int total = 0;
+  for (clr_batch* p : h->plan) {
+    int n = 0;
+    const int st = clr_batch_get_rescue(p, &n, nullptr, nullptr, nullptr);
+    if (st != CLR_OK) return st;
+    total += n < 0 ? -n : n;
+  }
+  if (last_count) *last_count = total;
+  return CLR_OK;
+}
+
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode) {
   return h->all([=](int s) { return clr_batch_set_summarize_mode(h->plan[s], mode); });
 }

@@ -565,6 +565,12 @@ int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
  * with it a batch may take different -- equally certified -- routes under different shardings: results then agree to
  * the scan's rounding (<= 1e-11), not bit for bit; mode 0 switches it off and restores bit-identity. */
 int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup);
+/* clr_batch_set_rescue on every shard.  A route-1 problem's side plan is sized by how many such problems ITS shard holds,
+ * so their results agree across shardings to the scan's rounding (statuses identical), not bit for bit; mode 0 (the
+ * inline replay) restores bit-identity.  clr_sharded_get_rescue: problems of the last fetched evaluation that took the
+ * checked route outside the main pass, summed over the shards. */
+int clr_sharded_set_rescue(clr_sharded* h, int mode);
+int clr_sharded_get_rescue(const clr_sharded* h, int* last_count);
 /* The summarize kernel all shards will run (clr_batch_get_summarize_kernel; -1 if they disagree). */
 int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind);
 /* clr_batch_get_series_order / clr_batch_clear_series over all shards (the smallest step of the whole batch) */

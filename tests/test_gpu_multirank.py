@@ -91,6 +91,12 @@ def test_sharded_plan_over_every_visible_device():
             assert np.array_equal(a, b, equal_nan=True)
         assert np.array_equal(got[3], s0)
         assert np.max(np.abs(got[1] - d0) / np.abs(d0)) <= REL and np.max(np.abs(got[2] - q0) / np.abs(q0)) <= REL
+        assert sp.rescued() == 0                      # (a benign batch: nothing on the checked route)
+        sp.set_rescue(0)                              # the inline replay on every shard: a setter that reaches all plans
+        got0 = sp.evaluate(*coeffs_of(case))
+        for a, b in zip(want, got0):
+            assert np.array_equal(a, b, equal_nan=True)
+        sp.set_rescue(-1)
         other = synthetic(B, N, JR, JC, "bench", seed=315)
         got2 = sp.evaluate(*coeffs_of(other))
         _, d1, q1, s1 = ref.batch_log_likelihood(0.0, *coeffs_of(other), case["t"], case["diag"], case["y"])
