@@ -14,8 +14,8 @@ clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device) {
   }
   const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
   const int width = J_real + 2 * J_comp;
-  if (!L && (width < 1 || width > clr::wide_max_width())) {
-    fail(CLR_UNSUPPORTED, "batched path supports widths 1..64 (J_real + 2 J_comp)");
+  if (!L && (width < 1 || width > CLR_MAX_WIDTH)) {
+    fail(CLR_UNSUPPORTED, "batched path supports widths 1..128 (J_real + 2 J_comp)");
     return nullptr;
   }
   if (require_device(device) != CLR_OK) return nullptr;
@@ -1183,8 +1183,10 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   const bool all_marks = h->prof_on != 2;
   auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
   h->evaluated = true;
-  if (h->J_general > 0) {  // general terms: the any-width sequential recurrence, one workgroup per problem
-    if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms: use CholeskySolver");
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) {
+    // general terms -- and (round 5) celerite-only kernels of widths 65..128, which have no wave-per-problem kernel --: the
+    // any-width sequential recurrence, one workgroup per problem with S in LDS (generic_loglike_batch_kernel)
+    if (materialize) return fail(CLR_UNSUPPORTED, "materialising runs with general terms or above width 64: use CholeskySolver");
     h->warm_inflight = false;
     h->small_inflight = false;
     if (h->gen_nchunk > 0 && h->general_route != 1) {
@@ -1613,6 +1615,24 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
   h->evaluated = true;
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) {
+    // (plans on the any-width sequential kernel or with general terms: the evaluation itself, `steps` times, as one "replay" slot)
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < steps; ++i)
+      if ((st = clr_batch_enqueue(h, materialize)) != CLR_OK) return st;
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float tot = 0.f;
+    HIP_TRY(hipEventElapsedTime(&tot, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (total_ms) *total_ms = tot;
+    if (kernel_ms) { for (int j = 0; j < 6; ++j) kernel_ms[j] = 0.0; kernel_ms[4] = tot; }
+    return CLR_OK;
+  }
   if (!warm_runs(h, materialize) && h->relayout_pending && !relayout_each_step && batch_relayout(h)) h->relayout_pending = false;
   // one event per kernel boundary per step, all recorded on the handle's stream
   const int NK = 6;
@@ -1713,7 +1733,7 @@ int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double*
     // clr_batch_create recorded why (message in clr_last_error)
     if (B < 1 || N < 1 || J_real < 0 || J_comp < 0) return CLR_INVALID_ARGUMENT;
     const int width = J_real + 2 * J_comp;
-    if (width < 1 || width > clr::wide_max_width()) return CLR_UNSUPPORTED;
+    if (width < 1 || width > CLR_MAX_WIDTH) return CLR_UNSUPPORTED;
     return visible_gfx950() > 0 ? CLR_HIP_ERROR : CLR_NO_DEVICE;
   }
   int st = clr_batch_set_series(h, t, t_stride, diag, diag_stride, y, y_stride);

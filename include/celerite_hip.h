@@ -213,7 +213,9 @@ typedef struct clr_batch clr_batch;
  *          Materialising runs write the reference's storage directly
  *          (every chunk replayed from its scanned start state and checked, as CholeskySolver.compute
  *          does); layouts do not apply;
- *   else   CLR_UNSUPPORTED. */
+ *   65..128 (round 5) the any-width sequential recurrence, one workgroup per problem with S in LDS (the kernel of
+ *          plans with general terms): fused log-likelihood only, sequential in n;
+ *   else   CLR_UNSUPPORTED (the reference's dynamic-width arm, cholesky.h:203, takes any J). */
 clr_batch* clr_batch_create(int B, int N, int J_real, int J_comp, int device);
 void clr_batch_destroy(clr_batch* h);
 

@@ -746,7 +746,36 @@ def test_wide_plan_rejects_what_does_not_apply():
     assert plan.factor(1)[3].shape == (100,)
     plan.close()
     with pytest.raises(RuntimeError):
-        batch.BatchedGP(2, 100, 1, 32)     # width 65
+        batch.BatchedGP(2, 100, 1, 64)     # width 129: above CLR_MAX_WIDTH (65..128: the any-width sequential kernel)
+
+
+def test_widths_65_to_128_in_a_plan():
+    """Round 5: celerite-only kernels of widths 65..128 in the batch API run the any-width sequential recurrence (one
+    workgroup per problem, S in LDS: the kernel of plans with general terms) -- the reference's dynamic-width arm
+    (cholesky.h:203) takes any J.  Parity with the oracle, an indefinite problem, materialising runs refused."""
+    for JR, JC, N in ((65, 0, 300), (3, 40, 500), (0, 64, 400), (128, 0, 200)):
+        case = synthetic(3, N, JR, JC, "accuracy", seed=JR + JC)
+        case["a_real"] = np.array(case["a_real"], copy=True)
+        case["diag"] = np.array(case["diag"], copy=True)
+        if JR:
+            case["a_real"][1, :] = -7.0
+            case["diag"][1] = 0.0
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+        plan = batch.BatchedGP(3, N, JR, JC)
+        try:
+            assert plan.chunks[0] == 1
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            ll, ld, q, st = plan.log_likelihood()
+            assert np.array_equal(st, s0)
+            ok = s0 == 0
+            within("widths 65..128 in a plan: vs oracle", max(np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok]))), REL, (JR, JC))
+            with pytest.raises(RuntimeError):
+                plan.log_likelihood(materialize=True)
+            ms, _ = plan.run_timed(2)
+            assert ms > 0.0
+        finally:
+            plan.close()
 
 
 def test_many_problems_short_series():
