@@ -67,14 +67,16 @@ FP64_LIVE = {}
 
 
 def csrc_fingerprint():
-    """sha1 over the kernel sources (celerite_amd/csrc/*.h, *.hip, *.cpp): profiles/pmc_latest.json carries the
+    """sha1 over the kernel sources (celerite_amd/csrc/*.h, *.hip without the api_* files): profiles/pmc_latest.json carries the
     fingerprint of the build its counters were taken from; a different one means the committed HBM-traffic figures
     describe OTHER kernels and `roofline.traffic` is nulled until someone re-profiles."""
     import glob
     import hashlib
     h = hashlib.sha1()
     for path in sorted(glob.glob(os.path.join(ROOT, "celerite_amd", "csrc", "*"))):
-        if path.endswith((".h", ".hip", ".cpp")):
+        # (the DEVICE code: the api_* translation units, the host-only .cpp files and the pybind module do not change what
+        #  a kernel moves; the chunk count the counters were taken at is compared separately)
+        if path.endswith((".h", ".hip")) and not os.path.basename(path).startswith("api_"):
             h.update(os.path.basename(path).encode())
             h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
