@@ -660,7 +660,7 @@ def main(argv=None):
     K, Wm = max(args.steps, 1), max(args.warmup, 0)
 
     try:  # the fp64 rate / clock of this box (rank 0's device stands for all; a few ms, outside every timed region)
-        tf, mhz, cyc = batch.measure_fp64(2, 20000)
+        tf, mhz, cyc = batch.measure_fp64(2, 20000, device=dist.local_rank % ndev)   # (every rank on its own GPU)
         FP64_LIVE.update({"tflops": tf, "clock_mhz": mhz, "cycles_per_fma": cyc})
     except Exception:
         pass

@@ -119,10 +119,13 @@ def device_count():
     return int(_load().clr_device_count())
 
 
-def measure_fp64(waves_per_simd=2, iters=20000):
+def measure_fp64(waves_per_simd=2, iters=20000, device=None):
     """``(tflops, clock_mhz, cycles_per_fma)``: the fp64 FMA rate the device's vector ALUs sustain under full load, the
-    shader clock during it and the SIMD cycles per issued FMA (``clr_device_measure_fp64``; a roofline measurement)."""
+    shader clock during it and the SIMD cycles per issued FMA (``clr_device_measure_fp64``; a roofline measurement).
+    ``device``: the calling thread's current device is switched to it first (default: left as it is)."""
     lib = _load()
+    if device is not None:
+        _check(lib.clr_set_device(int(device)))
     a, b, c = C.c_double(), C.c_double(), C.c_double()
     lib.clr_device_measure_fp64.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3
     _check(lib.clr_device_measure_fp64(int(waves_per_simd), int(iters), C.byref(a), C.byref(b), C.byref(c)))
