@@ -26,8 +26,14 @@ namespace clr {
 
 namespace {
 
-template <int J>
+// PHASE 0: the walk does everything (few chunks per problem: the corrections ride on the elimination the advance needs anyway).
+// PHASE 1 / 2 (many chunks per problem -- one long series through CholeskySolver, small batches): the walk only ADVANCES
+// (elimination + the two products: the dependent chain), and a second launch, one workgroup per (problem, chunk), repeats
+// the elimination from the start state the walk stored and does the corrections, the probes and the certificate in
+// parallel over the chunks -- the arrangement of the widths <= 32 (wide_prefix32_kernel + wide_correct_kernel).
+template <int J, int PHASE>
 __global__ void __launch_bounds__(256) wide_walk_kernel(const BatchParams P) {
+  constexpr bool ADVANCE = PHASE != 2, CORRECT = PHASE != 1;
   constexpr int SZ = J * (J + 1) / 2, ELEM = J * J + J + SZ + J + SZ, START = SZ + J;
   constexpr int LD = J + 1, NC = 2 * J + 1, LT = NC + 1, NT = 256;
   extern __shared__ double lds[];
@@ -39,23 +45,36 @@ __global__ void __launch_bounds__(256) wide_walk_kernel(const BatchParams P) {
   double* wv = ev + J;              // [J] w = Jm f - eta
   double* pa = wv + J;              // [J] scratch
   double* pb = pa + J;              // [J] scratch
-  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, b = PHASE == 2 ? blockIdx.y : blockIdx.x;
   const long slot0 = (long)b * P.nchunk;
-  if (tid == 0) {
+  if (PHASE != 2 && tid == 0) {
     int raised = 0;
     for (int c = 0; c < P.nchunk; ++c) raised |= P.flags[slot0 + c] ? 2 : 0;  // a zero-start pivot <= 0 (summarize)
     P.need_exact[b] = raised;
     if (P.egerr) P.egerr[slot0] = 0.0;  // the first chunk starts from the zero state: nothing to correct
   }
-  // start state of chunk 1 = (C, b) of chunk 0 (its zero-start trajectory)
-  {
+  if (PHASE == 2) {  // this workgroup's chunk: its start state as the walk stored it
+    const double* st = P.starts + (slot0 + blockIdx.x + 1) * START;
+    for (int idx = tid; idx < J * J; idx += NT) Pm[(idx / J) * LD + idx % J] = st[sym(idx / J, idx % J)];
+    if (tid < J) fv[tid] = st[SZ + tid];
+  } else {  // start state of chunk 1 = (C, b) of chunk 0 (its zero-start trajectory)
     const double* E = P.elems + slot0 * ELEM;
     const double* EC = E + J * J + J;
     for (int idx = tid; idx < J * J; idx += NT) Pm[(idx / J) * LD + idx % J] = EC[sym(idx / J, idx % J)];
     if (tid < J) fv[tid] = E[J * J + tid];
   }
   __syncthreads();
-  for (int c = 1; c < P.nchunk; ++c) {
+  const int c_lo = PHASE == 2 ? (int)blockIdx.x + 1 : 1, c_hi = PHASE == 2 ? c_lo + 1 : P.nchunk;
+  for (int c = c_lo; c < c_hi; ++c) {
+    if (PHASE == 1 && c + 1 == P.nchunk) {  // (advance only: the last chunk's start state, nothing to advance through)
+      double* o = P.starts + (slot0 + c) * START;
+      for (int idx = tid; idx < J * J; idx += NT) {
+        const int i = idx / J, j = idx % J;
+        if (i <= j) o[tri(i, j)] = Pm[i * LD + j];
+      }
+      if (tid < J) o[SZ + tid] = fv[tid];
+      break;
+    }
     const long slot = slot0 + c;
     const double* E = P.elems + slot * ELEM;
     const double* Eb = E + J * J;
@@ -66,10 +85,10 @@ __global__ void __launch_bounds__(256) wide_walk_kernel(const BatchParams P) {
       double* o = P.starts + slot * START;
       for (int idx = tid; idx < J * J; idx += NT) {
         const int i = idx / J, j = idx % J;
-        if (i <= j) o[tri(i, j)] = Pm[i * LD + j];
+        if (PHASE != 2 && i <= j) o[tri(i, j)] = Pm[i * LD + j];
         Jf[i * LD + j] = EJm[sym(i, j)];
       }
-      if (tid < J) { o[SZ + tid] = fv[tid]; ev[tid] = Eeta[tid]; }
+      if (tid < J) { if (PHASE != 2) o[SZ + tid] = fv[tid]; ev[tid] = Eeta[tid]; }
     }
     __syncthreads();
     // T = [ I + P Jm | P | f + P eta ]
@@ -127,6 +146,7 @@ __global__ void __launch_bounds__(256) wide_walk_kernel(const BatchParams P) {
     }
     // T[i][J + j] = G[i][j], T[i][2J] = g[i]
 
+    if (CORRECT) {
     // measured accuracy of G (chunk_update's eg_out, the same two probe vectors)
     double eg = 0.0;
     if (P.egerr) {
@@ -276,6 +296,8 @@ __global__ void __launch_bounds__(256) wide_walk_kernel(const BatchParams P) {
         atomicOr(P.need_exact + b, 2);
       }
     }
+    }  // CORRECT
+    if (!ADVANCE) break;
     if (c + 1 == P.nchunk) break;  // (the last chunk is corrected, not advanced through)
 
     // advance: sym(G) -> Jf ; X = A sym(G) -> T[:, 0:J] ; P' = C + X A^T -> Pm ; f' = A g + b
@@ -325,13 +347,29 @@ size_t walk_lds_bytes() {
 int launch_wide_walk(const BatchParams& P, int width_padded, hipStream_t s) {
   if (P.nchunk < 2) return 0;
   // (more than the default 64 KB of LDS per workgroup at width 64: asked for on every device the library runs on)
+  // few chunks: one fused walk; many (one long series, small batches): the walk advances, the corrections run in parallel
+  // (measured, profiles/r05i_wide64_split_walk.txt: a fused walk step 0.45 ms, an advance-only one 0.27 ms, a round of 256
+  //  correction workgroups -- 132 KB of LDS each: one per CU -- 0.45 ms)
+  const long nc1 = P.nchunk - 1, rounds = ((long)P.B * nc1 + 255) / 256;
+  const bool split = 0.27 * nc1 + 0.45 * rounds < 0.45 * nc1;
+  const dim3 cgrid(P.nchunk - 1, P.B);
   if (width_padded <= 32) {
-    hipLaunchKernelGGL((wide_walk_kernel<32>), dim3(P.B), dim3(256), walk_lds_bytes<32>(), s, P);
+    if (!split) hipLaunchKernelGGL((wide_walk_kernel<32, 0>), dim3(P.B), dim3(256), walk_lds_bytes<32>(), s, P);
+    else {
+      hipLaunchKernelGGL((wide_walk_kernel<32, 1>), dim3(P.B), dim3(256), walk_lds_bytes<32>(), s, P);
+      hipLaunchKernelGGL((wide_walk_kernel<32, 2>), cgrid, dim3(256), walk_lds_bytes<32>(), s, P);
+    }
   } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_walk_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)walk_lds_bytes<64>()) != hipSuccess)
+    const int bytes = (int)walk_lds_bytes<64>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_walk_kernel<64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_walk_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_walk_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
       return 1;
-    hipLaunchKernelGGL((wide_walk_kernel<64>), dim3(P.B), dim3(256), walk_lds_bytes<64>(), s, P);
+    if (!split) hipLaunchKernelGGL((wide_walk_kernel<64, 0>), dim3(P.B), dim3(256), bytes, s, P);
+    else {
+      hipLaunchKernelGGL((wide_walk_kernel<64, 1>), dim3(P.B), dim3(256), bytes, s, P);
+      hipLaunchKernelGGL((wide_walk_kernel<64, 2>), cgrid, dim3(256), bytes, s, P);
+    }
   }
   return 0;
 }

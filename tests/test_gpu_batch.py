@@ -954,7 +954,8 @@ def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, 
     wide_correct_kernel<32> on the same elements: start states, results, conditioning records and routes -- benign,
     near-singular and indefinite problems."""
     B, N = 6, 5000
-    for family, maker in (("bench", synthetic), ("adversarial", None)):
+    # (2 chunks: the fused walk; 8: the walk advances and the corrections run in parallel over the chunks -- the launcher's cost model)
+    for family, maker, nchunk in (("bench", synthetic, 2), ("bench", synthetic, 8), ("adversarial", None, 2), ("adversarial", None, 8)):
         case = synthetic(B, N, JR, JC, "bench", seed=7 + JR) if maker else adversarial(B, N, JR, JC, seed=91 + JR)
         out = {}
         for walk in (False, True):
@@ -964,7 +965,7 @@ def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, 
                 plan = batch.BatchedGP(B, N, JR, JC)
                 try:
                     plan.set_prefix_mode("walk")
-                    plan.set_chunks(8)
+                    plan.set_chunks(nchunk)
                     plan.set_series(case["t"], case["diag"], case["y"])
                     plan.set_coefficients(*coeffs_of(case))
                     res = plan.log_likelihood()
