@@ -47,6 +47,12 @@
 #ifndef CLR_WIDE_LOGPROD_WINDOW
 #define CLR_WIDE_LOGPROD_WINDOW 1  // lazy summarize: plain product of a block's 16 pivots, one frexp per block
 #endif
+// Round 5: the lazy summarize's per-row features (rotation of the (cos, sin) pair, the accumulated decay, u, v) are
+// evaluated once per LPR steps -- the LPR lanes of a row each take ONE of the next LPR samples -- instead of by every
+// lane on every step (wide_scan_body, FB)
+#ifndef CLR_WIDE_FEATURE_BATCH
+#define CLR_WIDE_FEATURE_BATCH 1
+#endif
 
 namespace clr {
 
@@ -102,6 +108,95 @@ __device__ __forceinline__ void decay_pair(double x, double* phi, double* phinv)
   }
 }
 
+// d = a * b + c as ONE v_fma_f64 with all operands in registers.  The compiler turns fma(x, acc, K) with a
+// loop-invariant K into v_mov_b64 tmp, K ; v_fmac_f64 tmp, x, acc -- two issue slots for one; 13 such copies per
+// feature batch in the lazy summarize (profiles/r05k_wide_isa_mix.txt).
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// max(a, |b|) in one instruction (fmax(a, fabs(b)) costs a canonicalising v_max_f64 a, a, a on top)
+__device__ __forceinline__ double max_abs(double a, double b) {
+  double d;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// a value the compiler can no longer see through: a double constant kept as ONE register pair (it otherwise shares
+// equal 32-bit halves between constants and patches them together with v_mov_b32 inside the loop), a loop counter it
+// must keep scalar
+__device__ __forceinline__ double opaque_v(double x) { asm("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm("" : "+s"(x)); return x; }
+// the Taylor coefficients of the FB polynomials, materialised once per kernel
+struct FbConsts {
+  double k6, k24, k120, k720, k5040, k40320, k362880, k3628800;
+  __device__ __forceinline__ void init(bool wide) {
+    k6 = opaque_v(1.0 / 6.0); k24 = opaque_v(1.0 / 24.0); k120 = opaque_v(1.0 / 120.0); k720 = opaque_v(1.0 / 720.0);
+    k5040 = opaque_v(1.0 / 5040.0); k40320 = opaque_v(1.0 / 40320.0);
+    k362880 = wide ? opaque_v(1.0 / 362880.0) : 0.0; k3628800 = wide ? opaque_v(1.0 / 3628800.0) : 0.0;
+  }
+};
+__device__ __forceinline__ double fma3n(double a, double b, double c) {  // a * b - c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double fnma3(double a, double b, double c) {  // c - a * b
+  double d;
+  asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ double min3(double a, double b) {  // min(a, b), no canonicalising copies (both operands are results of arithmetic)
+  double d;
+  asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ double fnma3_one(double a, double b) {  // 1 - a * b (inline constant)
+  double d;
+  asm("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ double fnma3_half(double a, double b) {  // 1/2 - a * b
+  double d;
+  asm("v_fma_f64 %0, -%1, %2, 0.5" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// FB: the decay over a lane's own LPR-step interval, |x| < NB * 2^-7 (host-checked per step: max c dx < 2^-7), so no
+// range test and no exp(): cosh / sinh series, truncation below 5e-17 (NB = 2: next terms x^7 / 5040, x^8 / 40320 at
+// |x| <= 2^-6; NB = 4 carries one more term each for |x| <= 2^-5)
+template <int NB>
+__device__ __forceinline__ void decay_pair_nb(const FbConsts& K, double x, double* phi, double* phinv) {
+  const double x2 = x * x;
+  double ch, sh;
+  if (NB <= 2) {
+    ch = fma(x2, fma(x2, fma3(x2, K.k720, K.k24), 0.5), 1.0);
+    sh = x * fma(x2, fma3(x2, K.k120, K.k6), 1.0);
+  } else {
+    ch = fma(x2, fma(x2, fma3(x2, fma3(x2, K.k40320, K.k720), K.k24), 0.5), 1.0);
+    sh = x * fma(x2, fma3(x2, fma3(x2, K.k5040, K.k120), K.k6), 1.0);
+  }
+  *phi = ch + sh;
+  *phinv = ch - sh;
+}
+// FB: (cos, sin) of a lane's own rotation step, |a| < NB * 2^-5 (host-checked per step: max d dx < 2^-5): absolute
+// truncation below 5e-17 (NB = 2: a^9 / 9!, a^10 / 10! at |a| <= 2^-4; NB = 4 one more term each for |a| <= 2^-3)
+template <int NB>
+__device__ __forceinline__ void small_sincos_nb(const FbConsts& K, double a, double* sn, double* cn) {
+  const double a2 = a * a;
+  // sin a / a = 1 - a2 (1/6 - a2 (1/120 - a2 (1/5040 - a2 / 362880))) ; cos a = 1 - a2 (1/2 - a2 (1/24 - a2 (1/720 - a2 (1/40320 - a2 / 3628800))))
+  // (the same coefficients and Horner order as the signed form; c - a b is the instruction's own negate modifier)
+  if (NB <= 2) {
+    *sn = a * fnma3_one(a2, fnma3(a2, fnma3(a2, K.k5040, K.k120), K.k6));
+    *cn = fnma3_one(a2, fnma3_half(a2, fnma3(a2, fnma3(a2, K.k40320, K.k720), K.k24)));
+  } else {
+    *sn = a * fnma3_one(a2, fnma3(a2, fnma3(a2, fnma3(a2, K.k362880, K.k5040), K.k120), K.k6));
+    *cn = fnma3_one(a2, fnma3_half(a2, fnma3(a2, fnma3(a2, fnma3(a2, K.k3628800, K.k40320), K.k720), K.k24)));
+  }
+}
+
 // first sample of chunk c (c == nchunk: N).  Uniform chunks of L samples, or (L0 > 0) a first chunk of L0 samples
 // followed by chunks of L
 __device__ __forceinline__ int wide_chunk_begin(const BatchParams& P, int c) {
@@ -143,13 +238,28 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   constexpr int NTW = NTILE / NW;                              // ... tiles per wave (NW = 2: every other tile)
   constexpr bool PACKED = LPR >= 2 && CLR_WIDE_PACKED_SUMS;
   constexpr bool LPWIN = LAZY && CLR_WIDE_LOGPROD_WINDOW;
+  // FB (lazy summarize, celerite rows only, two or four lanes per row): a step's features are functions of the times
+  // alone, and every lane of a row used to evaluate all of them on every step -- ~60 of the step's 190 vector
+  // instructions.  Now the row's LPR lanes split the NEXT LPR samples between them: once per LPR steps lane `seg`
+  // advances ITS OWN (cos, sin) pair by d (t_m - t_(m - LPR)) and ITS OWN accumulated decay Psi by
+  // exp(-c (t_m - t_(m - LPR))) for sample m = (first of the batch) + seg, and publishes ubar_m = Psi u_m and
+  // vbar_m = v_m / Psi in LDS slots [m mod 2 LPR][row]; a step reads its own row's pair and the row of ubar back.  No
+  // per-step decay phi is formed at all (Psi at the renormalisation is the lane's Psi carried to t_(n + 1)); the times
+  // come from a 128-entry ring in LDS because every lane needs a different sample's.
+  constexpr bool FB = LAZY && !GEN && LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
+  constexpr int NB = FB ? LPR : 1, NSLOT = 2 * NB;
+  __shared__ __attribute__((aligned(16))) double fuvb[2][FB ? NSLOT : 1][FB ? WMAX : 2];  // [0]: ubar, [1]: vbar (one address register serves both)
+  auto& fub = fuvb[0];
+  auto& fvb = fuvb[1];
+  __shared__ double tring[FB ? 128 : 2];
+  __shared__ double dtile[FB ? 64 : 2], ytile[FB ? 64 : 2];  // (FB) the tile's K(0) + diag and y: a step's pair by two LDS reads (v_readlane: four vector slots)
   __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * WMAX : 2];
   __shared__ __attribute__((aligned(16))) double rsblk[JMM ? 16 * WMAX : 2];
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
-  __shared__ __attribute__((aligned(16))) double ubuf[2][WMAX];
-  __shared__ __attribute__((aligned(16))) double pbuf[2][WMAX];
+  __shared__ __attribute__((aligned(16))) double ubuf[2][FB ? 2 : WMAX];
+  __shared__ __attribute__((aligned(16))) double pbuf[2][FB ? 2 : WMAX];
   __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
   __shared__ __attribute__((aligned(16))) double rbuf[(RID && !JMM) ? WMAX : 2];
   __shared__ __attribute__((aligned(16))) double psibuf[LAZY ? WMAX : 2];
@@ -193,8 +303,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
   if (MODE == 0 && P.nchunk > 1 && !P.force_exact && (P.need_exact[b] != 1 || (P.defer_level1 && !P.seq_only))) return;
   if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
-  const int n_lo = wide_chunk_begin(P, chunk);
-  const int n_hi = wide_chunk_begin(P, chunk + 1);
+  const int n_lo = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk));  // (wave-uniform by construction: keep the loop counters scalar)
+  const int n_hi = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk + 1));
   const long slot = (long)b * P.nchunk + chunk;
 
   double S[COLS];
@@ -247,7 +357,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const double t1v = lane + 1 < 64 ? a1 : b1, t2v = lane + 2 < 64 ? a2 : b2;
     return (n0 + lane + 2 < N) ? t2v - t1v : 0.0;
   };
-  double dxt = LAZY ? tile_steps(n_lo) : 0.0, dxprev = 0.0;
+  double dxt = (LAZY && !FB) ? tile_steps(n_lo) : 0.0, dxprev = 0.0;
   // (GEN) the general rows' features of samples base .. base + GEN_PF - 1; gen_next() hands out the front one as the
   // row's constants and fetches the sample GEN_PF further on
   double gu[GEN ? GEN_PF : 1], gv[GEN ? GEN_PF : 1];
@@ -274,7 +384,44 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // features of the chunk's first sample
   double u, v, phi;
   double psi = 1.0, psinv = 1.0, phinv = 1.0, csr = 1.0, sdr = 0.0, tcur = t_at(0);  // (LAZY)
-  if (LAZY) {
+  // (FB) per lane: tl / tr = the time its Psi / its (cos, sin) pair stand at; tpre = the ring's next 64 times in flight
+  double tl = 0.0, tr = 0.0, tpre = 0.0;
+  FbConsts KF;
+  if (FB) KF.init(NB > 2);
+  auto t_clamped = [&](int m) { return tp[m < N ? m : N - 1]; };  // (past the end: the last time, i.e. steps of 0)
+  auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row
+    const int ms = m + seg;
+    const double tm = tring[ms & 127];
+    if (anchor) {
+      sincos_phase<FAST>(rc.d * tm, &sdr, &csr);
+    } else {
+      double sn, cn;
+      small_sincos_nb<NB>(KF, rc.d * (tm - tr), &sn, &cn);
+      const double c0 = csr, s0 = sdr;
+      csr = fma(c0, cn, -s0 * sn);
+      sdr = fma(s0, cn, c0 * sn);
+    }
+    tr = tm;
+    double e, einv;
+    decay_pair_nb<NB>(KF, -rc.c * (tm - tl), &e, &einv);
+    psi *= e;
+    psinv *= einv;
+    tl = tm;
+    const double uu = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
+    const double vv = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
+    fub[ms & (NSLOT - 1)][row] = psi * uu;
+    fvb[ms & (NSLOT - 1)][row] = psinv * vv;
+  };
+  if (FB) {
+    const int m = n_lo + lane;
+    tring[m & 127] = t_clamped(m);
+    tring[(m + 64) & 127] = t_clamped(m + 64);
+    tpre = t_clamped(m + 128);
+    tl = tr = tring[n_lo & 127];
+    feature_batch(n_lo, true);
+    u = v = phi = 0.0;
+    xsync();  // (NW = 2: the other wave's rows of the first samples)
+  } else if (LAZY) {
     sincos_phase<FAST>(rc.d * tcur, &sdr, &csr);
     u = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
     v = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
@@ -286,17 +433,34 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     if (writer) { ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi; }
   }
 
+  double* const rdst = (seg == 0 ? rblk : rsblk) + (JMM ? row : 0);  // (JMM, two lanes per row) where this lane parks r (first lane) or -r / D (second)
+  double psiR = 1.0;  // (FB) the decay accumulated since the last renormalisation, up to t_(n + 1): set and used on renormalising steps
+  double dmin = INFINITY;  // (LPWIN) smallest zero-start pivot of the samples >= 1
   for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
-    const int nend = (n_hi - n0 < 64) ? n_hi - n0 : 64;
+    const int nend = FB ? opaque_s((n_hi - n0 < 64) ? n_hi - n0 : 64) : ((n_hi - n0 < 64) ? n_hi - n0 : 64);
+    if (FB) { dtile[lane] = dv; ytile[lane] = yv; }
     for (int k = 0; k < nend; ++k) {
       const int n = n0 + k, cur = n & 1;
-      const double diag_n = lane_value(dv, k);
-      const double y_n = lane_value(yv, k);
+      const double diag_n = FB ? dtile[k] : lane_value(dv, k);
+      const double y_n = FB ? ytile[k] : lane_value(yv, k);
 
       // next sample's features (independent of the state): computed and published now
       double u1 = 0.0, v1 = 0.0, phi1 = 1.0, phinv1 = 1.0;
       const bool renorm = LAZY && ((((n - n_lo) & 15) == 15) || n + 1 == n_hi);  // wave-uniform
-      if (n + 1 < N) {
+      if constexpr (FB) {
+        if (((n + 1 - n_lo) & (NB - 1)) == 0 || renorm) {  // (wave-uniform; the other steps touch none of this)
+          if (renorm) {  // carry this lane's Psi to t_(n + 1) (forwards or, at a chunk's ragged end, backwards), new base there
+            const double tb = tring[(n + 1) & 127];
+            double e, einv;
+            decay_pair_nb<NB>(KF, -rc.c * (tb - tl), &e, &einv);
+            psiR = psi * e;
+            psi = 1.0;
+            psinv = 1.0;
+            tl = tb;
+          }
+          if (((n + 1 - n_lo) & (NB - 1)) == 0 && n + 1 < n_hi) feature_batch(n + 1, ((n + 1 - n_lo) & (16 * NB - 1)) == 0);
+        }
+      } else if (n + 1 < N) {
         const double t1 = LAZY ? 0.0 : t_at(k + 1);
         const double dx1 = LAZY ? lane_value(dxt, k) : ((n + 2 < N) ? t_at(k + 2) - t1 : 0.0);
         if (GEN) gen_next();  // the general rows' u0, v0 of sample n + 1
@@ -322,8 +486,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
         }
       }
-      const double ueff = LAZY ? psi * u : u;      // this row's entry of ubar (what ubuf[cur] holds)
-      const double veff = LAZY ? psinv * v : v;    // vbar
+      const double* ucols = FB ? &fub[n & (NSLOT - 1)][seg * COLS] : &ubuf[cur][FB ? 0 : seg * COLS];
+      double ueff, veff;  // this row's entries of ubar (what the row of u in LDS holds) and vbar
+      if constexpr (FB) { ueff = fub[n & (NSLOT - 1)][row]; veff = fvb[n & (NSLOT - 1)][row]; }
+      else { ueff = LAZY ? psi * u : u; veff = LAZY ? psinv * v : v; }
 
       // q = S u and (summarize) r = A^T u: own columns, then across the row's lanes
       double q = 0.0, r = 0.0;
@@ -331,7 +497,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         // width 64: one lane owns a whole row -- a single accumulator would be a chain of 64 dependent FMAs per dot
         // product, and the wave is alone on its SIMD (nothing hides the latency): four partial sums each
         double qa[4] = {0.0, 0.0, 0.0, 0.0}, ra[4] = {0.0, 0.0, 0.0, 0.0};
-        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+        const double2* uv = reinterpret_cast<const double2*>(ucols);
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
           const double2 uu = uv[c];
@@ -345,7 +511,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         q = (qa[0] + qa[1]) + (qa[2] + qa[3]);
         if (RID) r = (ra[0] + ra[1]) + (ra[2] + ra[3]);
       } else {
-        const double2* uv = reinterpret_cast<const double2*>(&ubuf[cur][seg * COLS]);
+        const double2* uv = reinterpret_cast<const double2*>(ucols);
 #pragma unroll
         for (int c = 0; c < COLS / 2; ++c) {
           const double2 uu = uv[c];
@@ -377,11 +543,15 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       const double x = y_n - ub;
       // replay: the reference's test (cholesky.h:176; sample 0 is never checked); summarize: a
       // zero-start pivot <= 0 sends the problem to the replay (as in summarize_chunk)
-      if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
+      if (LPWIN) {  // the smallest pivot, tested once per block (a NaN pivot poisons the block's product, tested there too)
+        // (sample 0 is never checked -- cholesky.h:176 -- and only the first chunk, the body without riders, holds it)
+        if (RIDERS) dmin = min3(dmin, D);
+        else if (n >= 1) dmin = fmin(dmin, D);
+      } else if (n >= 1 && (MODE == 1 ? !(D > 0.0) : D < 0.0)) flag = 1;
       if (LPWIN) dprod *= D; else lp.mul(D);
       const double xs = x * invD;
       quad = fma(x, xs, quad);
-      if (MODE == 1) gam = fmax(gam, fabs(diag_n * invD));
+      if (MODE == 1) gam = max_abs(gam, diag_n * invD);
 
       const double z = veff - q;
       const double w = z * invD;
@@ -391,8 +561,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       }
       if (JMM) {  // this step's r (first lane of the row) and -r / D (second lane), for the block's rank-16 update
         if (LPR >= 2) {
-          double* dst = (seg == 0 ? rblk : rsblk) + ((n - n_lo) & 15) * WMAX + row;
-          *dst = seg == 0 ? r : -(r * invD);
+          rdst[((n - n_lo) & 15) * WMAX] = seg == 0 ? r : -(r * invD);
         } else {  // (width 64: one lane per row writes both)
           rblk[((n - n_lo) & 15) * WMAX + row] = r;
           rsblk[((n - n_lo) & 15) * WMAX + row] = -(r * invD);
@@ -449,11 +618,16 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       if (RID) eta = fma(-r, xs, eta);
       if (LAZY) {
         f = fma(w, x, f);  // fbar
-        psi *= phi;        // Psi now includes this step's decay
-        psinv *= phinv;
-        if (renorm) {      // multiply the accumulated decay out of Sbar, Abar, fbar
+        if (!FB) {
+          psi *= phi;      // Psi now includes this step's decay
+          psinv *= phinv;
+        }
+        // (FB: the test again from an opaque copy of n -- carried across the step the flag costs a v_cndmask and a v_cmp)
+        const int n2 = FB ? opaque_s(n) : n;
+        const bool renorm_now = FB ? ((((n2 - n_lo) & 15) == 15) || n2 + 1 == n_hi) : renorm;
+        if (renorm_now) {  // multiply the accumulated decay out of Sbar, Abar, fbar
           if (LPWIN) {     // the block's pivots: one frexp for (at most) 16 of them
-            if (!(dprod > 1e-250 && dprod < 1e250)) flag = 1;  // (a pivot <= 0 is flagged above; this is over/underflow)
+            if (!(dprod > 1e-250 && dprod < 1e250) || !(dmin > 0.0)) flag = 1;  // (over/underflow or NaN; a pivot <= 0)
             lp.mul_window(dprod);
             lp.renorm();
             dprod = 1.0;
@@ -484,22 +658,30 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
               }
             }
           }
-          if (writer) psibuf[row] = psi;
+          if (writer) psibuf[row] = FB ? psiR : psi;
           xsync();
+          // FB: the row's lanes carried their own Psi, equal up to rounding -- all of them take the writer's.  The
+          // wave barrier is for the COMPILER: without it the other lanes' read of psibuf[row] is folded into the
+          // else-arm of the writer's branch and issued before the store (legal for unsynchronised threads; the
+          // hardware executes a wave's LDS operations in order)
+          if (FB) __builtin_amdgcn_wave_barrier();
+          const double prow = FB ? psibuf[row] : psi;
           const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
 #pragma unroll
           for (int c = 0; c < COLS / 2; ++c) {
             const double2 pc = qv[c];
-            S[2 * c] *= psi * pc.x;
-            S[2 * c + 1] *= psi * pc.y;
+            S[2 * c] *= prow * pc.x;
+            S[2 * c + 1] *= prow * pc.y;
             if (RID) {
               AT[2 * c] *= pc.x;
               AT[2 * c + 1] *= pc.y;
             }
           }
-          f *= psi;
-          psi = 1.0;
-          psinv = 1.0;
+          f *= prow;
+          if (!FB) {
+            psi = 1.0;
+            psinv = 1.0;
+          }
         }
         phinv = phinv1;
       } else {
@@ -508,6 +690,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       u = u1; v = v1; phi = phi1;
     }
     // next tile of the series
+    if (FB) {  // the ring's next 64 times: loaded a tile ago (before this tile's loads are issued: no wait on them),
+               // they replace the samples just processed
+      tring[(n0 + 128 + lane) & 127] = tpre;
+      tpre = t_clamped(n0 + 192 + lane);
+    }
     const int m = n0 + 64 + lane;
     tv = tv2;
     dv = m < N ? dp[m] : 0.0;
@@ -515,7 +702,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     if (GEN && m < N) dv += Ap[m];
     yv = m < N ? yp[m] : 0.0;
     tv2 = m + 64 < N ? tp[m + 64] : 0.0;
-    if (LAZY) dxt = tile_steps(n0 + 64);
+    if (LAZY && !FB) dxt = tile_steps(n0 + 64);
   }
 
   if (MODE == 1) {  // the element, in the narrow kernels' layout at width J = WMAX
