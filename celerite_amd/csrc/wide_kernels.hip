@@ -219,7 +219,30 @@ constexpr int GEN_PF = 6;
 // (xbuf; both waves add the two partial sums in the same order, so D is bit-identical in both), and the step's w (and r)
 // must be complete before the rank-1 updates read them.  u, phi are published a step ahead as before (their writes and
 // the previous step's reads are separated by those barriers).
-template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN, int NW = 1>
+// The body's LDS arrays, ONE set per kernel: a kernel runs the body without riders on its first chunk and the body with
+// riders on the others, a workgroup only ever one of them -- as static arrays of the body they were allocated twice
+// (21.5 KB with the PAIRED slots: seven workgroups per CU instead of the eight that give every SIMD its two waves).
+template <int WMAX, bool LAZY, bool FBF, int NSLOT, bool JMMF, bool RBUF, int NW>
+struct WideLds {
+  alignas(16) double fuvb[2][FBF ? NSLOT : 1][FBF ? WMAX : 2];  // (FB) [0]: ubar, [1]: vbar (one address register serves both)
+  alignas(16) double rblk[JMMF ? 16 * WMAX : 2];
+  alignas(16) double rsblk[JMMF ? 16 * WMAX : 2];
+  alignas(16) double ubuf[2][FBF ? 2 : WMAX];
+  alignas(16) double pbuf[2][FBF ? 2 : WMAX];
+  alignas(16) double wbuf[WMAX];
+  alignas(16) double rbuf[RBUF ? WMAX : 2];
+  alignas(16) double psibuf[LAZY ? WMAX : 2];
+  double tring[FBF ? 128 : 2];
+  double dtile[FBF ? 64 : 2], ytile[FBF ? 64 : 2];  // (FB) the tile's K(0) + diag and y: a step's pair by two LDS reads (v_readlane: four vector slots)
+  double xbuf[NW == 2 ? 8 : 1];  // (NW = 2) the two waves' partial row sums: [wave][u.q | u.f] (and, at the end, their residual maxima)
+};
+template <class L>
+__device__ __forceinline__ L& wide_lds() {
+  __shared__ L lds;
+  return lds;
+}
+
+template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN, int NW = 1, bool PAIRED = false>
 __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int JC) {
   static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
   static_assert(NW == 1 || (NW == 2 && WMAX == 64), "two waves per (problem, chunk): the padded width 64");
@@ -247,23 +270,30 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // per-step decay phi is formed at all (Psi at the renormalisation is the lane's Psi carried to t_(n + 1)); the times
   // come from a 128-entry ring in LDS because every lane needs a different sample's.
   constexpr bool FB = LAZY && !GEN && LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
-  constexpr int NB = FB ? LPR : 1, NSLOT = 2 * NB;
-  __shared__ __attribute__((aligned(16))) double fuvb[2][FB ? NSLOT : 1][FB ? WMAX : 2];  // [0]: ubar, [1]: vbar (one address register serves both)
-  auto& fub = fuvb[0];
-  auto& fvb = fuvb[1];
-  __shared__ double tring[FB ? 128 : 2];
-  __shared__ double dtile[FB ? 64 : 2], ytile[FB ? 64 : 2];  // (FB) the tile's K(0) + diag and y: a step's pair by two LDS reads (v_readlane: four vector slots)
-  __shared__ __attribute__((aligned(16))) double rblk[JMM ? 16 * WMAX : 2];
-  __shared__ __attribute__((aligned(16))) double rsblk[JMM ? 16 * WMAX : 2];
+  // PAIRED (host: no real terms, two lanes per row): the cos and the sin row of a complex term share c and d, hence the
+  // (cos, sin) pair and Psi -- the term's FOUR lanes split the next four samples, and each publishes BOTH rows' entries
+  // of its sample: u = a cos + b sin | a sin - b cos, v = cos | sin (cholesky.h:143-146)
+  constexpr bool PR = FB && PAIRED && LPR == 2;
+  constexpr int NB = FB ? (PR ? 2 * LPR : LPR) : 1, NSLOT = 2 * NB;
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
-  __shared__ __attribute__((aligned(16))) double ubuf[2][FB ? 2 : WMAX];
-  __shared__ __attribute__((aligned(16))) double pbuf[2][FB ? 2 : WMAX];
-  __shared__ __attribute__((aligned(16))) double wbuf[WMAX];
-  __shared__ __attribute__((aligned(16))) double rbuf[(RID && !JMM) ? WMAX : 2];
-  __shared__ __attribute__((aligned(16))) double psibuf[LAZY ? WMAX : 2];
-  __shared__ double xbuf[NW == 2 ? 8 : 1];  // (NW = 2) the two waves' partial row sums: [wave][u.q | u.f] (and, at the end, their residual maxima)
+  // (sizes: those of the body WITH riders, the superset)
+  constexpr bool JMM_ANY = MODE == 1 && LAZY && (WMAX == 32 || WMAX == 64) && CLR_WIDE_JM_MFMA;
+  auto& lds_ = wide_lds<WideLds<WMAX, LAZY, FB, NSLOT, JMM_ANY, MODE == 1 && !JMM_ANY, NW>>();
+  auto& fub = lds_.fuvb[0];
+  auto& fvb = lds_.fuvb[1];
+  auto& tring = lds_.tring;
+  auto& dtile = lds_.dtile;
+  auto& ytile = lds_.ytile;
+  auto& rblk = lds_.rblk;
+  auto& rsblk = lds_.rsblk;
+  auto& ubuf = lds_.ubuf;
+  auto& pbuf = lds_.pbuf;
+  auto& wbuf = lds_.wbuf;
+  auto& rbuf = lds_.rbuf;
+  auto& psibuf = lds_.psibuf;
+  auto& xbuf = lds_.xbuf;
   const int tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;  // lane: position in the wave (tiles, DPP, MFMA layout)
   auto xsync = [&]() { if (NW == 2) lds_barrier(); };             // (LDS-only wait: the tile prefetch stays in flight)
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -389,8 +419,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   FbConsts KF;
   if (FB) KF.init(NB > 2);
   auto t_clamped = [&](int m) { return tp[m < N ? m : N - 1]; };  // (past the end: the last time, i.e. steps of 0)
-  auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row
-    const int ms = m + seg;
+  const int bq = PR ? (row & 1) * LPR + seg : seg;  // this lane's sample within a batch
+  // (PR) the term's own a, b (the row holds (a, b) as (uc, us) or (us, -uc): cholesky.h:143-146)
+  const double ta = (row & 1) ? rc.us : rc.uc, tb = (row & 1) ? -rc.uc : rc.us;
+  auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row (PR: of a term)
+    const int ms = m + bq;
     const double tm = tring[ms & 127];
     if (anchor) {
       sincos_phase<FAST>(rc.d * tm, &sdr, &csr);
@@ -407,10 +440,19 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     psi *= e;
     psinv *= einv;
     tl = tm;
-    const double uu = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
-    const double vv = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
-    fub[ms & (NSLOT - 1)][row] = psi * uu;
-    fvb[ms & (NSLOT - 1)][row] = psinv * vv;
+    if constexpr (PR) {
+      const int r0 = row & ~1;
+      const double uc_ = fma(ta, csr, tb * sdr), us_ = fma(ta, sdr, -(tb * csr));
+      fub[ms & (NSLOT - 1)][r0] = psi * uc_;
+      fub[ms & (NSLOT - 1)][r0 + 1] = psi * us_;
+      fvb[ms & (NSLOT - 1)][r0] = psinv * csr;
+      fvb[ms & (NSLOT - 1)][r0 + 1] = psinv * sdr;
+    } else {
+      const double uu = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
+      const double vv = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
+      fub[ms & (NSLOT - 1)][row] = psi * uu;
+      fvb[ms & (NSLOT - 1)][row] = psinv * vv;
+    }
   };
   if (FB) {
     const int m = n_lo + lane;
@@ -433,6 +475,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     if (writer) { ubuf[n_lo & 1][row] = u; pbuf[n_lo & 1][row] = phi; }
   }
 
+  const double rsel_a = seg == 0 ? 1.0 : 0.0, rsel_b = seg == 0 ? 0.0 : -1.0;
   double* const rdst = (seg == 0 ? rblk : rsblk) + (JMM ? row : 0);  // (JMM, two lanes per row) where this lane parks r (first lane) or -r / D (second)
   double psiR = 1.0;  // (FB) the decay accumulated since the last renormalisation, up to t_(n + 1): set and used on renormalising steps
   double dmin = INFINITY;  // (LPWIN) smallest zero-start pivot of the samples >= 1
@@ -488,7 +531,11 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       }
       const double* ucols = FB ? &fub[n & (NSLOT - 1)][seg * COLS] : &ubuf[cur][FB ? 0 : seg * COLS];
       double ueff, veff;  // this row's entries of ubar (what the row of u in LDS holds) and vbar
-      if constexpr (FB) { ueff = fub[n & (NSLOT - 1)][row]; veff = fvb[n & (NSLOT - 1)][row]; }
+      if constexpr (FB) {  // (one address, the vbar entry at a constant distance)
+        const double* pu = &fub[n & (NSLOT - 1)][row];
+        ueff = pu[0];
+        veff = pu[NSLOT * WMAX];
+      }
       else { ueff = LAZY ? psi * u : u; veff = LAZY ? psinv * v : v; }
 
       // q = S u and (summarize) r = A^T u: own columns, then across the row's lanes
@@ -560,8 +607,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         if (RID && !JMM) rbuf[row] = r;
       }
       if (JMM) {  // this step's r (first lane of the row) and -r / D (second lane), for the block's rank-16 update
-        if (LPR >= 2) {
-          rdst[((n - n_lo) & 15) * WMAX] = seg == 0 ? r : -(r * invD);
+        if (LPR >= 2) {  // r (first lane) | -r / D (second lane) = r * (ra + rb / D) with per-lane constants: no selects
+          rdst[((n - n_lo) & 15) * WMAX] = r * fma(invD, rsel_b, rsel_a);
         } else {  // (width 64: one lane per row writes both)
           rblk[((n - n_lo) & 15) * WMAX + row] = r;
           rsblk[((n - n_lo) & 15) * WMAX + row] = -(r * invD);
@@ -795,10 +842,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   }
 }
 
-template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false>
+template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false, bool PAIRED = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
-  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN>(P, JR, JC);
-  else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN>(P, JR, JC);
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN, 1, PAIRED>(P, JR, JC);
+  else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN, 1, PAIRED>(P, JR, JC);
 }
 // Round 5: the summarize flavour at widths 33..64 (one lane per row, 64 columns each).  S and A^T alone are 2 x 64 doubles
 // = 256 registers per lane, Jm sits in the matrix cores' accumulators (10 tiles x 4 doubles: the lazy flavour) or in 64
@@ -810,10 +857,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 }
 // ... and TWO waves per (problem, chunk): two lanes per row, 32 columns per lane (wide_scan_body, NW = 2) -- the state fits
 // the architectural registers, two waves per SIMD, both the summarize (MODE 1) and the replay / sequential sweep (MODE 0).
-template <bool FAST, int MODE, bool LAZY, bool GEN>
+template <bool FAST, int MODE, bool LAZY, bool GEN, bool PAIRED = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) wide_scan64x2_kernel(const BatchParams P, int JR, int JC) {
-  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<64, FAST, MODE, LAZY, false, GEN, 2>(P, JR, JC);
-  else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2>(P, JR, JC);
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<64, FAST, MODE, LAZY, false, GEN, 2, PAIRED>(P, JR, JC);
+  else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2, PAIRED>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -1240,9 +1287,17 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<WM, true, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);  \
     else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);              \
   } while (0)
+    // complex terms only: the four lanes of a term share the features' work (wide_scan_body, PAIRED)
+    const bool paired = !GEN && JR == 0 && getenv("CLR_WIDE_NO_PAIRED") == nullptr;
     if (W <= 16) CLR_GOL(16);
-    else if (W <= 32) CLR_GOL(32);
-    else if (wide64_one_wave()) {
+    else if (W <= 32 && paired) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+      else hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+    } else if (W <= 32) CLR_GOL(32);
+    else if (!wide64_one_wave() && paired) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+      else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+    } else if (wide64_one_wave()) {
       if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
       else hipLaunchKernelGGL((wide_summarize64_kernel<false, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
     } else if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, GEN>), grid, dim3(128), 0, s, P, JR, JC);

@@ -7,8 +7,10 @@ from celerite_amd import batch
 batch.LIB_PATH = os.environ["CLR_LIB"]
 from bench import make_inputs
 from oracle import ref
-coeffs, t, diag, y = make_inputs(256, 100000, 0, 16, 11, d_spread=True)
-plan = batch.BatchedGP(256, 100000, 0, 16)
+JC = int(os.environ.get("CLR_AB_JC", "16"))   # 16: BASELINE configs[4] (width 32); 32: the extra width-64 workload
+JR = int(os.environ.get("CLR_AB_JR", "0"))
+coeffs, t, diag, y = make_inputs(256, 100000, JR, JC, 11, d_spread=True)
+plan = batch.BatchedGP(256, 100000, JR, JC)
 plan.set_series(t, diag, y); plan.set_coefficients(*coeffs)
 plan.enqueue(); plan.synchronize()
 tot, k = plan.run_timed(3)
