@@ -202,7 +202,7 @@ struct clr_batch {
   size_t gen_scan_ws_doubles = 0, scan_ws_doubles = 0;  // workspace of the wide parallel prefix (0: sequential walk)
   int* gen_flags = nullptr;
   bool pipeline_pinned = false;    // the caller tuned the scan pipeline (chunks, prefix, summarize kernel, layout, certificate): auto small mode stays out
-  double wide_first_ratio64 = 2.3;  // ... at widths 33..64 (riders: A^T on the VALU + Jm on the matrix cores, beside S alone)
+  double wide_first_ratio64 = 1.45;  // ... at widths 33..64 (2.3 before the summarize split the features' work between a row's lanes: profiles/r05k_wide_feature_batch.txt)
   double wide_first_ratio = 1.25;  // wide plans: cost of a chunk with riders / cost of the riderless first chunk (1.1-1.25 within 2 %: profiles/r04c, r04p)
   const clr::BatchLaunchers* launch = nullptr;
   DevBuf coeffs, t, diag, y;          // coefficients (| jitter at the end); series in the API's row-major layout

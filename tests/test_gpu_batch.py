@@ -2237,11 +2237,14 @@ def test_plan_gradient_full_size_directional_derivative():
            np.max(np.abs(g[:2] - g2)) / np.max(np.abs(g2)), 1e-10)
 
 
-@pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13)])
+@pytest.mark.parametrize("JR,JC", [(1, 4), (3, 6), (0, 16), (6, 13), (1, 12), (0, 9)])
 def test_wide_summarize_with_the_lazy_decay(JR, JC):
     """Widths 9..32 on a densely sampled series: the wide summarize with the decay factored out of the
     state and rotated phases (default there) against the plain flavour (mode 0) and the oracle; ragged
-    last chunk, block boundaries of the 16-step renormalisation inside and at the end of a chunk."""
+    last chunk, block boundaries of the 16-step renormalisation inside and at the end of a chunk.
+    Round 5: the lazy flavour evaluates a sample's features ONCE per row (its lanes split the next samples: four
+    lanes per row at widths 9..16, two at 17..32) or once per complex TERM (no real terms: the term's four lanes,
+    (0, 16) and -- with padding rows -- (0, 9)); the latter is also held against the per-row split."""
     for N, nchunk in [(5000, 7), (4097, 4), (1040, 2)]:
         case = synthetic(3, N, JR, JC, "bench", seed=JR + 3 * JC + N)
         case["t"] = case["t"] * 0.03         # dense: max c dx < 2^-7, max d dx < 2^-5
@@ -2259,6 +2262,16 @@ def test_wide_summarize_with_the_lazy_decay(JR, JC):
             assert np.array_equal(st, s0), (N, mode)
             assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, (N, mode)
             assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, (N, mode)
+        if JR == 0:   # the per-term split against the per-row split: the same numbers up to the polynomials' rounding
+            os.environ["CLR_WIDE_NO_PAIRED"] = "1"
+            try:
+                plan.set_summarize_mode(2)
+                row_split = plan.log_likelihood()
+            finally:
+                del os.environ["CLR_WIDE_NO_PAIRED"]
+            assert np.array_equal(row_split[3], s0)
+            assert np.max(np.abs(row_split[1] - outs[2][1]) / np.abs(d0)) <= 1e-12
+            assert np.max(np.abs(row_split[2] - outs[2][2]) / np.abs(q0)) <= 1e-12
         plan.close()
         assert np.max(np.abs(outs[2][1] - outs[0][1]) / np.abs(outs[0][1])) <= 1e-11
         assert np.max(np.abs(outs[2][2] - outs[0][2]) / np.abs(outs[0][2])) <= 1e-11
