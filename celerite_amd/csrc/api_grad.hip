@@ -54,11 +54,15 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   const int Wt = h->J + h->J_general;
   if (general && (h->gen_nchunk < 2 || h->general_route == 1))
     return fail(CLR_UNSUPPORTED, "the plan gradient with general terms needs the chunked wide scan (total width <= 32, N >= 1024)");
-  if (!general && (h->launch || h->nchunk < 2))
+  if (!general && Wt <= 32 && (h->launch || h->nchunk < 2))
     return fail(CLR_UNSUPPORTED, "the plan gradient at widths 9..32 needs a chunked plan: use clr_batch_grad_log_likelihood");
-  if (Wt > 32)  // (the chunk-wise tangent kernels exist at the padded widths 16 and 32; the scan itself reaches 64)
-    return fail(CLR_UNSUPPORTED, "the plan gradient covers total widths up to 32: use clr_batch_grad_log_likelihood");
-  int st = clr_batch_enqueue(h, 0);
+  // widths 33..64: the chunk-wise tangent kernels exist at the padded widths 16 and 32 only (their riders are three
+  // JP x JP matrices per chunk in LDS: 200 KB at 64) -- the plan's gradient there is the SEQUENTIAL tangent kernel on
+  // the plan's resident series and coefficients (one wave per problem and direction, solver.cpp:347-463 as it stands)
+  const bool seq_all = Wt > 32;
+  if (seq_all && general)
+    return fail(CLR_UNSUPPORTED, "the plan gradient with general terms covers total widths up to 32");
+  int st = seq_all ? CLR_OK : clr_batch_enqueue(h, 0);
   if (st != CLR_OK) return st;
   clr::BatchParams P0, P;
   if ((st = batch_params(h, 0, P0)) != CLR_OK) return st;
@@ -66,8 +70,8 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   const size_t B = (size_t)h->B, NG = 1 + 2 * (size_t)h->J_real + 4 * (size_t)h->J_comp;
   const int JP = Wt <= 16 ? 16 : 32;
   const size_t pc = B * (size_t)P.nchunk, RID = 2 * (size_t)JP * JP + JP, OUT = (size_t)JP * JP + JP + 2;
-  if ((st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
-  if ((st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
+  if (!seq_all && (st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
+  if (!seq_all && (st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
   if ((st = h->g_res.reserve(B * (NG + 2))) != CLR_OK) return st;  // value | grad | status (ints in the last B doubles)
   double* d_value = h->g_res.p;
   double* d_grad = h->g_res.p + B;
@@ -93,23 +97,25 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   G.t_stride = h->t_stride; G.diag_stride = h->diag_stride; G.y_stride = h->y_stride;
   G.fast_trig = P.fast_trig;
   G.B = h->B;
-  G.only_level = P.need_exact;
+  G.only_level = seq_all ? nullptr : P.need_exact;
   G.nchunk = P.nchunk; G.L = P.L; G.L0 = P.L0; G.JP = JP;
   G.starts = P.starts; G.rec = h->g_out.p;
   G.out_value = d_value; G.out_grad = d_grad; G.out_status = d_status;
 
-  clr::launch_wide_grad_riders(W, h->stream);
-  clr::launch_grad_chunked(G, h->stream);
-  clr::launch_wide_grad_walk(W, h->stream);
-  clr::launch_grad(G, h->stream);  // (sequential form: only the problems with level >= 2)
+  if (!seq_all) {
+    clr::launch_wide_grad_riders(W, h->stream);
+    clr::launch_grad_chunked(G, h->stream);
+    clr::launch_wide_grad_walk(W, h->stream);
+  }
+  clr::launch_grad(G, h->stream);  // (sequential form: only the problems with level >= 2 -- or, widths 33..64, all)
   HIP_TRY(hipGetLastError());
   std::vector<double> back(B * (NG + 2));
   HIP_TRY(hipMemcpyAsync(back.data(), h->g_res.p, back.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int* hst = reinterpret_cast<const int*>(back.data() + B + B * NG);
   int nfb = 0;
-  std::vector<int> levels(B);
-  HIP_TRY(hipMemcpy(levels.data(), P.need_exact, B * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> levels(B, 2);
+  if (!seq_all) HIP_TRY(hipMemcpy(levels.data(), P.need_exact, B * sizeof(int), hipMemcpyDeviceToHost));
   for (size_t b = 0; b < B; ++b) {
     nfb += levels[b] >= 2;
     const bool ok = hst[b] == CLR_OK;

@@ -513,7 +513,10 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
  * chunk carry the tangent states across the chunk boundaries in a walk over the chunks per direction.  Problems the
  * scan routed to the sequential recurrence take the sequential kernel above (count: clr_batch_get_grad_fallbacks).
  * Synchronous; conventions of value / grad / status as above.  clr_batch_grad_log_likelihood uses this path for
- * widths 1..8 and N >= 512. */
+ * widths 1..8 and N >= 512.  Chunked plans of widths 9..32 (and with general terms up to a total width of 32) run the
+ * same decomposition with a wave per (chunk, direction) (csrc/wide_grad_kernels.hip); plans of widths 33..64 run the
+ * sequential tangent kernel on their resident arrays (every problem counted in clr_batch_get_grad_fallbacks); above
+ * 64: CLR_UNSUPPORTED. */
 int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status);
 int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
 /* How clr_batch_grad differentiates.  mode 0 (default): REVERSE mode -- the riders pass also records w, D, x per

@@ -894,13 +894,20 @@ def test_wide_scan_over_chunks_at_widths_33_to_64(JR, JC):
                 if nchunk < 0:
                     assert plan.exact_count() == B
             if B == 3 and family == "bench":
-                # the plan gradient stops at total width 32 (its chunk-wise tangent kernels exist at the padded widths 16 / 32):
-                # refused, not mis-run, on a chunked plan of widths 33..64; the one-shot entry takes the sequential tangent kernel
+                # the plan gradient at total widths 33..64: the chunk-wise tangent kernels exist at the padded widths 16 / 32
+                # only, so the plan runs the sequential tangent kernel on its resident arrays (every problem counted as a
+                # fallback) -- the same numbers as the one-shot entry, the value the oracle's
                 plan.set_exact(False)
-                plan.set_chunks(4)
-                plan.set_coefficients(*coeffs_of(case))
-                with pytest.raises(RuntimeError):
-                    plan.grad_log_likelihood()
+                for nchunk in (4, 1):
+                    plan.set_chunks(nchunk)
+                    plan.set_coefficients(*coeffs_of(case))
+                    v, g, gst = plan.grad_log_likelihood()
+                    assert plan.grad_fallbacks() == B
+                    v1, g1, st1 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"])
+                    assert np.array_equal(gst, st1) and np.array_equal(gst, s0)
+                    assert np.array_equal(v[ok], v1[ok]) and np.array_equal(g[ok], g1[ok])
+                    within("widths 33..64, plan gradient (sequential tangent kernel): value vs oracle",
+                           np.max(np.abs(v[ok] + 0.5 * (q0[ok] + d0[ok] + np.pi * np.log(N))) / np.abs(v[ok])), REL, (W, nchunk))  # (solver.cpp:415)
         finally:
             plan.close()
 
