@@ -224,7 +224,7 @@ constexpr int GEN_PF = 6;
 // (21.5 KB with the PAIRED slots: seven workgroups per CU instead of the eight that give every SIMD its two waves).
 template <int WMAX, bool LAZY, bool FBF, int NSLOT, bool JMMF, bool RBUF, int NW>
 struct WideLds {
-  alignas(16) double fuvb[2][FBF ? NSLOT : 1][FBF ? WMAX : 2];  // (FB) [0]: ubar, [1]: vbar (one address register serves both)
+  alignas(16) double fuvb[3][FBF ? NSLOT : 1][FBF ? WMAX : 2];  // (FB) [0]: ubar | u, [1]: vbar | v, [2]: (plain flavour) phi (one address register serves all)
   alignas(16) double rblk[JMMF ? 16 * WMAX : 2];
   alignas(16) double rsblk[JMMF ? 16 * WMAX : 2];
   alignas(16) double ubuf[2][FBF ? 2 : WMAX];
@@ -269,20 +269,25 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // vbar_m = v_m / Psi in LDS slots [m mod 2 LPR][row]; a step reads its own row's pair and the row of ubar back.  No
   // per-step decay phi is formed at all (Psi at the renormalisation is the lane's Psi carried to t_(n + 1)); the times
   // come from a 128-entry ring in LDS because every lane needs a different sample's.
-  constexpr bool FB = LAZY && !GEN && LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
+  // The PLAIN flavour (sparse series' summarize, every replay / sequential sweep: FBN) splits the same way -- there a
+  // sample's features are a full sincos of the absolute phase and an exp of the step (cholesky.h:130,137,140), ~100 of
+  // the step's vector instructions, and nothing is carried from sample to sample: u, v, phi go to the slots as they are.
+  constexpr bool FBA = !GEN && LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
+  constexpr bool FB = FBA && LAZY, FBN = FBA && !LAZY;
   // PAIRED (host: no real terms, two lanes per row): the cos and the sin row of a complex term share c and d, hence the
   // (cos, sin) pair and Psi -- the term's FOUR lanes split the next four samples, and each publishes BOTH rows' entries
   // of its sample: u = a cos + b sin | a sin - b cos, v = cos | sin (cholesky.h:143-146)
   constexpr bool PR = FB && PAIRED && LPR == 2;
-  constexpr int NB = FB ? (PR ? 2 * LPR : LPR) : 1, NSLOT = 2 * NB;
+  constexpr int NB = FBA ? (PR ? 2 * LPR : LPR) : 1, NSLOT = 2 * NB;
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
   // operations execute in program order, so no barrier or explicit wait is needed.
   // (sizes: those of the body WITH riders, the superset)
   constexpr bool JMM_ANY = MODE == 1 && LAZY && (WMAX == 32 || WMAX == 64) && CLR_WIDE_JM_MFMA;
-  auto& lds_ = wide_lds<WideLds<WMAX, LAZY, FB, NSLOT, JMM_ANY, MODE == 1 && !JMM_ANY, NW>>();
+  auto& lds_ = wide_lds<WideLds<WMAX, LAZY, FBA, NSLOT, JMM_ANY, MODE == 1 && !JMM_ANY, NW>>();
   auto& fub = lds_.fuvb[0];
   auto& fvb = lds_.fuvb[1];
+  auto& fpb = lds_.fuvb[2];
   auto& tring = lds_.tring;
   auto& dtile = lds_.dtile;
   auto& ytile = lds_.ytile;
@@ -425,6 +430,14 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row (PR: of a term)
     const int ms = m + bq;
     const double tm = tring[ms & 127];
+    if constexpr (!LAZY) {  // (FBN) u~, v~ at t_ms and the decay to t_(ms + 1) (past the end the ring repeats the last time: phi = 1)
+      double uu, vv, ph;
+      row_features<FAST>(rc, tm, tring[(ms + 1) & 127] - tm, &uu, &vv, &ph);
+      fub[ms & (NSLOT - 1)][row] = uu;
+      fvb[ms & (NSLOT - 1)][row] = vv;
+      fpb[ms & (NSLOT - 1)][row] = ph;
+      return;
+    }
     if (anchor) {
       sincos_phase<FAST>(rc.d * tm, &sdr, &csr);
     } else {
@@ -454,7 +467,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       fvb[ms & (NSLOT - 1)][row] = psinv * vv;
     }
   };
-  if (FB) {
+  if (FBA) {
     const int m = n_lo + lane;
     tring[m & 127] = t_clamped(m);
     tring[(m + 64) & 127] = t_clamped(m + 64);
@@ -480,12 +493,12 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   double psiR = 1.0;  // (FB) the decay accumulated since the last renormalisation, up to t_(n + 1): set and used on renormalising steps
   double dmin = INFINITY;  // (LPWIN) smallest zero-start pivot of the samples >= 1
   for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
-    const int nend = FB ? opaque_s((n_hi - n0 < 64) ? n_hi - n0 : 64) : ((n_hi - n0 < 64) ? n_hi - n0 : 64);
-    if (FB) { dtile[lane] = dv; ytile[lane] = yv; }
+    const int nend = FBA ? opaque_s((n_hi - n0 < 64) ? n_hi - n0 : 64) : ((n_hi - n0 < 64) ? n_hi - n0 : 64);
+    if (FBA) { dtile[lane] = dv; ytile[lane] = yv; }
     for (int k = 0; k < nend; ++k) {
       const int n = n0 + k, cur = n & 1;
-      const double diag_n = FB ? dtile[k] : lane_value(dv, k);
-      const double y_n = FB ? ytile[k] : lane_value(yv, k);
+      const double diag_n = FBA ? dtile[k] : lane_value(dv, k);
+      const double y_n = FBA ? ytile[k] : lane_value(yv, k);
 
       // next sample's features (independent of the state): computed and published now
       double u1 = 0.0, v1 = 0.0, phi1 = 1.0, phinv1 = 1.0;
@@ -503,6 +516,12 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           }
           if (((n + 1 - n_lo) & (NB - 1)) == 0 && n + 1 < n_hi) feature_batch(n + 1, ((n + 1 - n_lo) & (16 * NB - 1)) == 0);
         }
+      } else if constexpr (FBN) {
+        if (((n + 1 - n_lo) & (NB - 1)) == 0 && n + 1 < n_hi) feature_batch(n + 1, false);
+        const double* pu = &fub[n & (NSLOT - 1)][row];  // this sample's u, v, phi of the row
+        u = pu[0];
+        v = pu[NSLOT * WMAX];
+        phi = pu[2 * NSLOT * WMAX];
       } else if (n + 1 < N) {
         const double t1 = LAZY ? 0.0 : t_at(k + 1);
         const double dx1 = LAZY ? lane_value(dxt, k) : ((n + 2 < N) ? t_at(k + 2) - t1 : 0.0);
@@ -529,7 +548,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           if (writer) { ubuf[cur ^ 1][row] = u1; pbuf[cur ^ 1][row] = phi1; }
         }
       }
-      const double* ucols = FB ? &fub[n & (NSLOT - 1)][seg * COLS] : &ubuf[cur][FB ? 0 : seg * COLS];
+      const double* ucols = FBA ? &fub[n & (NSLOT - 1)][seg * COLS] : &ubuf[cur][FBA ? 0 : seg * COLS];
       double ueff, veff;  // this row's entries of ubar (what the row of u in LDS holds) and vbar
       if constexpr (FB) {  // (one address, the vbar entry at a constant distance)
         const double* pu = &fub[n & (NSLOT - 1)][row];
@@ -644,7 +663,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           }
         }
       } else {
-        const double2* pv = reinterpret_cast<const double2*>(&pbuf[cur][seg * COLS]);
+        const double2* pv = reinterpret_cast<const double2*>(FBA ? &fpb[n & (NSLOT - 1)][seg * COLS] : &pbuf[cur][FBA ? 0 : seg * COLS]);
         const double2* wv = reinterpret_cast<const double2*>(&wbuf[seg * COLS]);
         const double2* rv = reinterpret_cast<const double2*>(&rbuf[(RID && !JMM) ? seg * COLS : 0]);
         const double zr = phi * z, rs = r * invD;
@@ -733,11 +752,15 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         phinv = phinv1;
       } else {
         f = phi * (f + w * x);
+        // NW = 2 without the feature slots (general terms): the rank-1 update above read pbuf[cur], the buffer the NEXT
+        // step's features go to -- a wave that is one step ahead must not write it yet (found on 64 x 1e5 x width 64:
+        // 1e-7 deviations of the two-wave kernel's plain flavour; the slots of FBN are written a full ring ahead)
+        if (NW == 2 && !FBA) xsync();
       }
-      u = u1; v = v1; phi = phi1;
+      if (!FBN) { u = u1; v = v1; phi = phi1; }
     }
     // next tile of the series
-    if (FB) {  // the ring's next 64 times: loaded a tile ago (before this tile's loads are issued: no wait on them),
+    if (FBA) {  // the ring's next 64 times: loaded a tile ago (before this tile's loads are issued: no wait on them),
                // they replace the samples just processed
       tring[(n0 + 128 + lane) & 127] = tpre;
       tpre = t_clamped(n0 + 192 + lane);

@@ -1191,6 +1191,53 @@ def test_general_terms_in_the_chunked_scan_at_length():
             within("general terms: cost / celerite-only plan of the same width", ms_gen / ms_ref, 3.0, (JR, JC, JG))
 
 
+def test_two_wave_kernels_plain_flavour_at_scale():
+    """Widths 33..64 with TWO waves per (problem, chunk), the flavour without the lazy decay, on a chip-filling grid
+    (64 problems x 16 chunks x 128 lanes).  Round 5 found 1e-7 deviations here: the rank-1 update read the decay buffer
+    of the step the other wave was already publishing into.  Celerite rows now take the feature slots (written a ring
+    ahead); general terms keep the double buffer behind a third barrier.  Every problem against the oracle."""
+    B, N = 64, 40000
+    case = synthetic(B, N, 0, 32, "bench", seed=99)
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"], nthreads=os.cpu_count() or 1)
+    plan = batch.BatchedGP(B, N, 0, 32)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        for mode in (0, -1):       # the plain flavour forced; the automatic choice
+            plan.set_summarize_mode(mode)
+            ll, ld, q, st = plan.log_likelihood()
+            assert plan.chunks[0] >= 8 and np.array_equal(st, s0)
+            within("two-wave kernels at scale (width 64, mode %d): log det vs oracle" % mode, np.max(np.abs(ld - d0) / np.abs(d0)), REL, mode)
+            within("two-wave kernels at scale (width 64, mode %d): quadratic form vs oracle" % mode, np.max(np.abs(q - q0) / np.abs(q0)), REL, mode)
+    finally:
+        plan.close()
+    # general terms at a total width of 62 (two waves, double-buffered features): every fourth problem against RefSolver
+    JR, JC, JG = 0, 28, 6
+    rng = np.random.RandomState(5)
+    case = synthetic(B, N, JR, JC, "accuracy", seed=98)
+    t = case["t"]
+    z = (t - t.mean(axis=1, keepdims=True)) / (t.max(axis=1, keepdims=True) - t.min(axis=1, keepdims=True))
+    U = np.stack([np.vander(zz, JG).T for zz in z])
+    V = U * rng.rand(B, JG)[:, :, None]
+    A = np.sum(U * V, axis=1) + 1e-8
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case), jitter=0.01)
+        plan.set_general(A, U, V)
+        ll, ld, q, st = plan.log_likelihood()
+        assert plan.chunks[0] >= 2
+        for p in range(0, B, 4):
+            r = ref.RefSolver()
+            r.compute(0.01, *coeffs_of(case, p), A[p], U[p], V[p], case["t"][p], case["diag"][p])
+            assert st[p] == 0
+            ld0, q0_ = r.log_determinant(), r.dot_solve(case["y"][p])
+            within("two-wave kernels at scale, general terms (total width 62): vs oracle",
+                   max(abs(ld[p] - ld0) / abs(ld0), abs(q[p] - q0_) / abs(q0_)), REL, p)
+    finally:
+        plan.close()
+
+
 @pytest.mark.parametrize("JR,JC", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (1, 1), (2, 1), (0, 2)])
 def test_short_narrow_problems_in_one_launch(JR, JC):
     """small_batch_kernel (BASELINE configs[1]'s route: one workgroup per problem, Kogge-Stone scan of the composed chunk
