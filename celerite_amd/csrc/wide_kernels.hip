@@ -277,7 +277,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // PAIRED (host: no real terms, two lanes per row): the cos and the sin row of a complex term share c and d, hence the
   // (cos, sin) pair and Psi -- the term's FOUR lanes split the next four samples, and each publishes BOTH rows' entries
   // of its sample: u = a cos + b sin | a sin - b cos, v = cos | sin (cholesky.h:143-146)
-  constexpr bool PR = FB && PAIRED && LPR == 2;
+  constexpr bool PR = FBA && PAIRED && LPR == 2;
   constexpr int NB = FBA ? (PR ? 2 * LPR : LPR) : 1, NSLOT = 2 * NB;
   // u and phi of a step are written one step AHEAD (they do not depend on the state),
   // double-buffered; phi * w is the one true exchange of a step.  A wave's LDS
@@ -431,11 +431,25 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     const int ms = m + bq;
     const double tm = tring[ms & 127];
     if constexpr (!LAZY) {  // (FBN) u~, v~ at t_ms and the decay to t_(ms + 1) (past the end the ring repeats the last time: phi = 1)
-      double uu, vv, ph;
-      row_features<FAST>(rc, tm, tring[(ms + 1) & 127] - tm, &uu, &vv, &ph);
-      fub[ms & (NSLOT - 1)][row] = uu;
-      fvb[ms & (NSLOT - 1)][row] = vv;
-      fpb[ms & (NSLOT - 1)][row] = ph;
+      if constexpr (PR) {  // one sincos and one exp for the term's two rows (row_features spelled out for the pair)
+        double sd, cs;
+        sincos_phase<FAST>(rc.d * tm, &sd, &cs);
+        const double x = -rc.c * (tring[(ms + 1) & 127] - tm);
+        const double ph = CLR_WAVE_ALL(fabs(x) < 0.0078125) ? exp_small(x) : exp(x);
+        const int r0 = row & ~1, sl = ms & (NSLOT - 1);
+        fub[sl][r0] = fma(ta, cs, tb * sd);
+        fub[sl][r0 + 1] = fma(ta, sd, -(tb * cs));
+        fvb[sl][r0] = cs;
+        fvb[sl][r0 + 1] = sd;
+        fpb[sl][r0] = ph;
+        fpb[sl][r0 + 1] = ph;
+      } else {
+        double uu, vv, ph;
+        row_features<FAST>(rc, tm, tring[(ms + 1) & 127] - tm, &uu, &vv, &ph);
+        fub[ms & (NSLOT - 1)][row] = uu;
+        fvb[ms & (NSLOT - 1)][row] = vv;
+        fpb[ms & (NSLOT - 1)][row] = ph;
+      }
       return;
     }
     if (anchor) {
@@ -1288,9 +1302,15 @@ int wide_scan_max_width() { return 64; }  // the chunk algebra: prefix_coop_kern
 
 // widths 33..64: two waves per (problem, chunk) (wide_scan64x2_kernel); CLR_WIDE64_ONE_WAVE=1 keeps the one-wave kernels (A/B)
 static bool wide64_one_wave() { return getenv("CLR_WIDE64_ONE_WAVE") != nullptr; }
+static bool wide_paired(int JR) { return JR == 0 && getenv("CLR_WIDE_NO_PAIRED") == nullptr; }  // complex terms only: a term's four lanes share its features
 template <bool GEN>
 static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const dim3 grid(P.nchunk, P.B);
+  if (!GEN && !wide64_one_wave() && wide_paired(JR)) {
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 0, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 0, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+    return;
+  }
   if (wide64_one_wave()) {
     if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<64, true, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
     else hipLaunchKernelGGL((wide_scan_kernel<64, false, 0, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
@@ -1311,7 +1331,7 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     else hipLaunchKernelGGL((wide_scan_kernel<WM, false, 1, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);              \
   } while (0)
     // complex terms only: the four lanes of a term share the features' work (wide_scan_body, PAIRED)
-    const bool paired = !GEN && JR == 0 && getenv("CLR_WIDE_NO_PAIRED") == nullptr;
+    const bool paired = !GEN && wide_paired(JR);
     if (W <= 16) CLR_GOL(16);
     else if (W <= 32 && paired) {
       if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true>), grid, dim3(64), 0, s, P, JR, JC);
@@ -1329,6 +1349,11 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     return;
   }
   if (MODE == 1 && W > 32) {  // widths 33..64 on a series that is not densely sampled
+    if (!GEN && !wide64_one_wave() && wide_paired(JR)) {
+      if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+      else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+      return;
+    }
     if (wide64_one_wave()) {
       if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
       else hipLaunchKernelGGL((wide_summarize64_kernel<false, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);
@@ -1342,7 +1367,10 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     else hipLaunchKernelGGL((wide_scan_kernel<WM, false, MODE, false, GEN>), grid, dim3(64), 0, s, P, JR, JC);            \
   } while (0)
   if (W <= 16) CLR_GO(16);
-  else if (W <= 32 || MODE == 1) CLR_GO(32);
+  else if (W <= 32 && !GEN && wide_paired(JR)) {
+    if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<32, true, MODE, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan_kernel<32, false, MODE, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+  } else if (W <= 32 || MODE == 1) CLR_GO(32);
   else launch_wide64<GEN>(P, JR, JC, s);
 #undef CLR_GO
 }
