@@ -224,7 +224,7 @@ constexpr int GEN_PF = 6;
 // (21.5 KB with the PAIRED slots: seven workgroups per CU instead of the eight that give every SIMD its two waves).
 template <int WMAX, bool LAZY, bool FBF, int NSLOT, bool JMMF, bool RBUF, int NW>
 struct WideLds {
-  alignas(16) double fuvb[3][FBF ? NSLOT : 1][FBF ? WMAX : 2];  // (FB) [0]: ubar | u, [1]: vbar | v, [2]: (plain flavour) phi (one address register serves all)
+  alignas(16) double fuvb[LAZY ? 2 : 3][FBF ? NSLOT : 1][FBF ? WMAX : 2];  // (FB) [0]: ubar | u, [1]: vbar | v, [2]: (plain flavour) phi (one address register serves all)
   alignas(16) double rblk[JMMF ? 16 * WMAX : 2];
   alignas(16) double rsblk[JMMF ? 16 * WMAX : 2];
   alignas(16) double ubuf[2][FBF ? 2 : WMAX];
@@ -287,7 +287,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   auto& lds_ = wide_lds<WideLds<WMAX, LAZY, FBA, NSLOT, JMM_ANY, MODE == 1 && !JMM_ANY, NW>>();
   auto& fub = lds_.fuvb[0];
   auto& fvb = lds_.fuvb[1];
-  auto& fpb = lds_.fuvb[2];
+  auto& fpb = lds_.fuvb[LAZY ? 1 : 2];  // (the plain flavour's plane; never touched by the lazy one)
   auto& tring = lds_.tring;
   auto& dtile = lds_.dtile;
   auto& ytile = lds_.ytile;
