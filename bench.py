@@ -300,6 +300,13 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         kms, nrec = plan.profile()
         plan.set_profiling(False)
         per = {k: v / max(nrec, 1) for k, v in kms.items()}
+        # routes of every draw of the timed loop (a draw with one problem on the checked route pays a chunk-time of replay:
+        # the kernels_ms above average over the draws)
+        levels_by_draw = []
+        for dr in draws[1:]:
+            plan.set_coefficients(*dr)
+            plan.log_likelihood()
+            levels_by_draw.append([int(v) for v in np.bincount(plan.exact_levels(), minlength=3)[:3]])
         plan.set_coefficients(*coeffs)
         ll, ld, q, st = plan.log_likelihood()
         levels = np.bincount(plan.exact_levels(), minlength=3)[:3]
@@ -321,7 +328,8 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         "scan_chunks": chunks[0], "chunk_len": chunks[1], "steps": steps,
         "prefix_plan": {"levels": prefix_plan[0], "groups": prefix_plan[1], "elements_per_level": prefix_plan[2]},
         "levels": {"what": "problems by route: 0 settled from the chunk summaries, 1 checked chunked replay, "
-                           "2 sequential recurrence", "histogram": [int(v) for v in levels]},
+                           "2 sequential recurrence", "histogram": [int(v) for v in levels],
+                   "histograms_of_the_other_draws_of_the_timed_loop": levels_by_draw},
         # (the one-launch path of short narrow problems settles them without leaving a per-chunk record: zeros)
         "conditioning": {"gamma_max": float(np.max(gam)), "mu_min": float(np.min(mu)),
                          "gamma_over_mu_max": float(np.max(gam / np.where(mu > 0, mu, np.inf))),
