@@ -272,7 +272,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // The PLAIN flavour (sparse series' summarize, every replay / sequential sweep: FBN) splits the same way -- there a
   // sample's features are a full sincos of the absolute phase and an exp of the step (cholesky.h:130,137,140), ~100 of
   // the step's vector instructions, and nothing is carried from sample to sample: u, v, phi go to the slots as they are.
-  constexpr bool FBA = !GEN && LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
+  // General rows ride along: their "features" are the row's U, V samples (no arithmetic), fetched a batch ahead.
+  constexpr bool FBA = LPR >= 2 && CLR_WIDE_FEATURE_BATCH;
   constexpr bool FB = FBA && LAZY, FBN = FBA && !LAZY;
   // PAIRED (host: no real terms, two lanes per row): the cos and the sin row of a complex term share c and d, hence the
   // (cos, sin) pair and Psi -- the term's FOUR lanes split the next four samples, and each publishes BOTH rows' entries
@@ -414,7 +415,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     gv[GQ - 1] = (gen && m < N) ? Vg[m] : 0.0;
     ++gbase;
   };
-  if (GEN) gen_next();  // the chunk's first sample
+  if (GEN && !FBA) gen_next();  // the chunk's first sample
 
   // features of the chunk's first sample
   double u, v, phi;
@@ -425,11 +426,20 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   if (FB) KF.init(NB > 2);
   auto t_clamped = [&](int m) { return tp[m < N ? m : N - 1]; };  // (past the end: the last time, i.e. steps of 0)
   const int bq = PR ? (row & 1) * LPR + seg : seg;  // this lane's sample within a batch
+  // (GEN with the feature batch) this general row's U, V of the lane's sample in the NEXT batch
+  double gq_u = (GEN && FBA && gen && n_lo + bq < N) ? Ug[n_lo + bq] : 0.0;
+  double gq_v = (GEN && FBA && gen && n_lo + bq < N) ? Vg[n_lo + bq] : 0.0;
   // (PR) the term's own a, b (the row holds (a, b) as (uc, us) or (us, -uc): cholesky.h:143-146)
   const double ta = (row & 1) ? rc.us : rc.uc, tb = (row & 1) ? -rc.uc : rc.us;
   auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row (PR: of a term)
     const int ms = m + bq;
     const double tm = tring[ms & 127];
+    if constexpr (GEN) {  // a general row's constants of this sample (loaded a batch ago), the next batch's on their way
+      if (gen) { rc.u0 = gq_u; rc.v0 = gq_v; }
+      const int mn = ms + NB;
+      gq_u = (gen && mn < N) ? Ug[mn] : 0.0;
+      gq_v = (gen && mn < N) ? Vg[mn] : 0.0;
+    }
     if constexpr (!LAZY) {  // (FBN) u~, v~ at t_ms and the decay to t_(ms + 1) (past the end the ring repeats the last time: phi = 1)
       if constexpr (PR) {  // one sincos and one exp for the term's two rows (row_features spelled out for the pair)
         double sd, cs;
@@ -539,7 +549,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       } else if (n + 1 < N) {
         const double t1 = LAZY ? 0.0 : t_at(k + 1);
         const double dx1 = LAZY ? lane_value(dxt, k) : ((n + 2 < N) ? t_at(k + 2) - t1 : 0.0);
-        if (GEN) gen_next();  // the general rows' u0, v0 of sample n + 1
+        if (GEN && !FBA) gen_next();  // the general rows' u0, v0 of sample n + 1
         if (LAZY) {
           if (((n + 1 - n_lo) & 15) == 0) {
             sincos_phase<FAST>(rc.d * t_at(k + 1), &sdr, &csr);  // anchor
