@@ -261,6 +261,12 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   constexpr int NTW = NTILE / NW;                              // ... tiles per wave (NW = 2: every other tile)
   constexpr bool PACKED = LPR >= 2 && CLR_WIDE_PACKED_SUMS;
   constexpr bool LPWIN = LAZY && CLR_WIDE_LOGPROD_WINDOW;
+#ifndef CLR_WIDE_RENORM_STEPS
+#define CLR_WIDE_RENORM_STEPS 64
+#endif
+  // (LAZY) steps between renormalisations: a multiple of 16.  The padded width 64 keeps 16 and the one block it had:
+  // its kernels sit at 256 registers, and the second block costs them 500 more spilled registers (98 ms instead of 41)
+  constexpr int RN = WMAX == 64 ? 16 : CLR_WIDE_RENORM_STEPS;
   // FB (lazy summarize, celerite rows only, two or four lanes per row): a step's features are functions of the times
   // alone, and every lane of a row used to evaluate all of them on every step -- ~60 of the step's 190 vector
   // instructions.  Now the row's LPR lanes split the NEXT LPR samples between them: once per LPR steps lane `seg`
@@ -516,6 +522,33 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   double* const rdst = (seg == 0 ? rblk : rsblk) + (JMM ? row : 0);  // (JMM, two lanes per row) where this lane parks r (first lane) or -r / D (second)
   double psiR = 1.0;  // (FB) the decay accumulated since the last renormalisation, up to t_(n + 1): set and used on renormalising steps
   double dmin = INFINITY;  // (LPWIN) smallest zero-start pivot of the samples >= 1
+  // (LAZY) multiply the accumulated decay out of Sbar, Abar, fbar -- on renormalising steps
+  auto renormalise = [&]() {
+    if (writer) psibuf[row] = FB ? psiR : psi;
+    xsync();
+    // FB: the row's lanes carried their own Psi, equal up to rounding -- all of them take the writer's.  The
+    // wave barrier is for the COMPILER: without it the other lanes' read of psibuf[row] is folded into the
+    // else-arm of the writer's branch and issued before the store (legal for unsynchronised threads; the
+    // hardware executes a wave's LDS operations in order)
+    if (FB) __builtin_amdgcn_wave_barrier();
+    const double prow = FB ? psibuf[row] : psi;
+    const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
+#pragma unroll
+    for (int c = 0; c < COLS / 2; ++c) {
+      const double2 pc = qv[c];
+      S[2 * c] *= prow * pc.x;
+      S[2 * c + 1] *= prow * pc.y;
+      if (RID) {
+        AT[2 * c] *= pc.x;
+        AT[2 * c + 1] *= pc.y;
+      }
+    }
+    f *= prow;
+    if (!FB) {
+      psi = 1.0;
+      psinv = 1.0;
+    }
+  };
   for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
     const int nend = FBA ? opaque_s((n_hi - n0 < 64) ? n_hi - n0 : 64) : ((n_hi - n0 < 64) ? n_hi - n0 : 64);
     if (FBA) { dtile[lane] = dv; ytile[lane] = yv; }
@@ -526,7 +559,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 
       // next sample's features (independent of the state): computed and published now
       double u1 = 0.0, v1 = 0.0, phi1 = 1.0, phinv1 = 1.0;
-      const bool renorm = LAZY && ((((n - n_lo) & 15) == 15) || n + 1 == n_hi);  // wave-uniform
+      // (round 5: every RN = 64 steps -- Psi >= exp(-1/2) there; the 16-step blocks of the pivots' product and of Jm's
+      //  rank-16 updates do not depend on the base: r = Abar^T ubar is the true A^T u whatever Psi is)
+      const bool renorm = LAZY && ((((n - n_lo) & (RN - 1)) == RN - 1) || n + 1 == n_hi);  // wave-uniform
       if constexpr (FB) {
         if (((n + 1 - n_lo) & (NB - 1)) == 0 || renorm) {  // (wave-uniform; the other steps touch none of this)
           if (renorm) {  // carry this lane's Psi to t_(n + 1) (forwards or, at a chunk's ragged end, backwards), new base there
@@ -714,8 +749,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         }
         // (FB: the test again from an opaque copy of n -- carried across the step the flag costs a v_cndmask and a v_cmp)
         const int n2 = FB ? opaque_s(n) : n;
-        const bool renorm_now = FB ? ((((n2 - n_lo) & 15) == 15) || n2 + 1 == n_hi) : renorm;
-        if (renorm_now) {  // multiply the accumulated decay out of Sbar, Abar, fbar
+        const bool renorm_now = FB ? ((((n2 - n_lo) & (RN - 1)) == RN - 1) || n2 + 1 == n_hi) : renorm;
+        const bool block_end = RN == 16 ? renorm_now : ((((n2 - n_lo) & 15) == 15) || n2 + 1 == n_hi);
+        if (block_end) {
           if (LPWIN) {     // the block's pivots: one frexp for (at most) 16 of them
             if (!(dprod > 1e-250 && dprod < 1e250) || !(dmin > 0.0)) flag = 1;  // (over/underflow or NaN; a pivot <= 0)
             lp.mul_window(dprod);
@@ -748,31 +784,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
               }
             }
           }
-          if (writer) psibuf[row] = FB ? psiR : psi;
-          xsync();
-          // FB: the row's lanes carried their own Psi, equal up to rounding -- all of them take the writer's.  The
-          // wave barrier is for the COMPILER: without it the other lanes' read of psibuf[row] is folded into the
-          // else-arm of the writer's branch and issued before the store (legal for unsynchronised threads; the
-          // hardware executes a wave's LDS operations in order)
-          if (FB) __builtin_amdgcn_wave_barrier();
-          const double prow = FB ? psibuf[row] : psi;
-          const double2* qv = reinterpret_cast<const double2*>(&psibuf[seg * COLS]);
-#pragma unroll
-          for (int c = 0; c < COLS / 2; ++c) {
-            const double2 pc = qv[c];
-            S[2 * c] *= prow * pc.x;
-            S[2 * c + 1] *= prow * pc.y;
-            if (RID) {
-              AT[2 * c] *= pc.x;
-              AT[2 * c + 1] *= pc.y;
-            }
-          }
-          f *= prow;
-          if (!FB) {
-            psi = 1.0;
-            psinv = 1.0;
-          }
+          if (RN == 16) renormalise();
         }
+        if (RN != 16 && renorm_now) renormalise();
         phinv = phinv1;
       } else {
         f = phi * (f + w * x);
