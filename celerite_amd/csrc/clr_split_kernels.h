@@ -273,16 +273,20 @@ __device__ __forceinline__ void split_riders(const Problem<JR, JC>& p, int L, in
 //     x = y - ubar.bbar ;  r = Abar^T ubar ;  Abar -= Wbar r^T ;  Cbar += zbar Wbar^T ;  bbar += Wbar x
 // and Psi <- Phi Psi: one FMA per state entry instead of FMA + MUL, the rider wave no longer needs phi
 // or Phi W (18 published doubles instead of 21), ~110 fp64 instructions fewer per step of ~590.  Every
-// 16 steps (and at the end of the chunk) the state is multiplied out and Psi reset to 1, so Psi stays
-// within [0.88, 1] and Psi^-1 (accumulated beside it from exp(+c dx)) within [1, 1.14]: the scaling is
-// rounding-neutral, and the drift of Psi * Psi^-1 from 1 is bounded by 16 roundings.
+// RENORM steps (and at the end of the chunk) the state is multiplied out and Psi reset to 1: 64 since round 5 (16
+// before: headline summarize 2.169 -> 2.14 ms, the log determinants' checksum unchanged to 13 digits), so Psi stays
+// within [0.6, 1] and Psi^-1 (accumulated beside it from exp(+c dx)) within [1, 1.65]: the scaling is
+// rounding-neutral, and the drift of Psi * Psi^-1 from 1 is bounded by 64 roundings.
 // ---------------------------------------------------------------------------------------------------
 template <int JR, int JC>
 struct SplitLinkLazy {
   static constexpr int J = JR + 2 * JC;
   static constexpr int F_U = 0, F_W = J, F_INVD = 2 * J, F_Y = 2 * J + 1, NPAY = 2 * J + 2;
   static constexpr int M = JR + JC;  // distinct decays: one slot area of M doubles per lane for Psi
-  static constexpr int RENORM = 16;
+#ifndef CLR_SPLIT_RENORM
+#define CLR_SPLIT_RENORM 64
+#endif
+  static constexpr int RENORM = CLR_SPLIT_RENORM;
 };
 
 // phi = exp(-c dx) and 1/phi = exp(+c dx) of the distinct decays, sharing the even / odd parts
@@ -458,7 +462,7 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       }
       tn = t_cur_next;
     }
-    lp0.renorm();  // (16 factors in [0.5, 1) since the last one)
+    lp0.renorm();  // (RENORM factors in [0.5, 1) since the last one)
     {  // multiply the accumulated decay out (the rider does the same to Abar, bbar)
       double pp[nz(M * (M + 1) / 2)];
 #pragma unroll
