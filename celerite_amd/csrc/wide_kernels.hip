@@ -15,19 +15,24 @@
 // their updates at step n; features u~, v~ at t_n, decay phi for t_n -> t_{n+1}):
 //     q = S u ; D = a - u.q ; z = v - q ; w = z / D ; x = y_n - u.f
 //     S <- Phi (S + z w^T) Phi ; f <- Phi (f + w x)
-// * every lane evaluates its own row's features (sin/cos of the absolute phase,
-//   cholesky.h:137; exp of the step, :130,140);
+// * a sample's features (sin/cos of the absolute phase, cholesky.h:137; exp of the step,
+//   :130,140) are evaluated ONCE per row -- the row's lanes split the next samples between
+//   them, once per LPR steps -- or once per complex term when there are no real terms
+//   (round 5: wide_scan_body, FB / FBN / PAIRED; every lane did all of it on every step before);
 // * the three vectors a lane needs for its COLUMNS (u, phi, phi*w) cross the wave
 //   through small LDS buffers (one write + broadcast b128 reads; a wave's LDS
-//   operations execute in program order, so no barrier is needed); u and phi do not
-//   depend on the state and are published one step ahead, so phi*w is the only
-//   exchange on a step's critical path;
+//   operations execute in program order, so no barrier is needed -- but the COMPILER may
+//   reorder a load against another lane's store across divergent arms: see the wave
+//   barrier in the renormalisation); u and phi do not depend on the state and are
+//   published a batch ahead, so phi*w is the only exchange on a step's critical path;
 // * row dot products finish with log2(LPR) DPP butterfly stages, u.q and u.f with
 //   the remaining DPP stages inside 16 lanes and four v_readlane pairs across them
 //   (a lone wave would wait ~100 cycles on every ds_bpermute of a __shfl_xor);
 // * t, diag, y are fetched 64 samples at a time (one coalesced 512-B load per array)
-//   and handed out with v_readlane.
-// Flops per step ~ 3.5 W^2; instruction slots per step and lane at W = 32: ~240.
+//   and handed out through LDS (a time ring for the per-lane samples of the feature
+//   batch, K(0) + diag and y by two uniform reads per step; v_readlane before round 5).
+// Flops per step ~ 3.5 W^2; vector instructions per step at W = 32: ~130 (lazy summarize
+// with riders, profiles/r05k_wide_isa_mix.txt; round 4: 190, round 1: ~240).
 // B problems alone use B of the chip's 1024 SIMDs; for smaller batches (widths <= 32) the
 // time axis is cut into chunks as in the narrow scan: MODE 1 of the kernel also builds the
 // chunk's transfer element and zero-start sums, prefix_coop_kernel<16 | 32> chains the chunks,
