@@ -698,6 +698,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         }
       }
       xsync();  // (NW = 2: the step's w -- and r -- of BOTH waves' rows, before the rank-1 updates read them)
+      // (one wave: program order is enough for the hardware; this pins it for the compiler too -- the rank-1 updates
+      //  below read wbuf / rbuf entries other lanes wrote inside the `writer` arm above)
+      if (NW == 1) __builtin_amdgcn_wave_barrier();
       if (MODE == 0 && P.wide_materialize && writer && row < W) {
         // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
         // u[:, n - 1] = U~(t_n), phi[:, n] = decay n -> n + 1 (cholesky.h:131-151, :177-178)
