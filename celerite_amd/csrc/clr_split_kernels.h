@@ -370,7 +370,10 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
   for (int i0 = 0; i0 < L; i0 += Lk::RENORM) {
     const int i1 = (i0 + Lk::RENORM < L) ? i0 + Lk::RENORM : L;
     // anchor: the full sincos of the absolute phase at the block's first sample (cholesky.h:137); at
-    // most 15 rotations (a few 1e-15 absolute) accumulate before the next anchor
+    // most RENORM - 1 = 63 rotations (~1e-14 absolute; 15 until round 5) accumulate before the next anchor.
+    // (The series queue's shift costs 9 v_mov_b64 per step.  Three steps per trip -- the rotation closes after PF
+    //  steps and the copies vanish -- was tried in round 5: the compiler then hoists the next step's
+    //  state-independent work over the barrier, 58 registers spill, 2.20 -> 3.85 ms.)
 #pragma unroll
     for (int j = 0; j < JC; ++j) sincos_phase<FAST>(p.dc[j] * tn, &sdv[j], &cdv[j]);
     for (int i = i0; i < i1; ++i) {
