@@ -334,6 +334,22 @@ bool lazy_eligible(const clr_batch* h) {
   return h->have_series && h->have_coeffs && cmax * dxmax < 0.0078125 && dmax * dxmax < 0.03125;
 }
 
+// Wide plans (wave per (problem, chunk), widths 9..64): the lazy flavour of the summarize takes any series since round 5 --
+// a lane whose own interval is too long for the Taylor steps sends its wave through the full sincos / exp for that batch
+// (wide_scan_body, feature_batch) -- as long as the decay accumulated between two renormalisations (64 steps) stays far
+// from the exponent range: Psi^-2 < e^(2 x 64 x 2) = e^256.  (The one-wave kernels of CLR_WIDE64_ONE_WAVE keep the strict rule.)
+bool lazy_eligible_wide(const clr_batch* h) {
+  static const char* one_wave = getenv("CLR_WIDE64_ONE_WAVE");
+  if (one_wave && h->J > 32) return lazy_eligible(h);
+  static const char* env = getenv("CLR_WIDE_LAZY_BOUND");  // (tuning runs: 0 = the strict rule of the narrow kernels)
+  const double bound = env ? atof(env) : 2.0;
+  // widths 9..16 (four lanes per row): the two flavours cost the same there -- 6.5 against 6.7 ms on a dense series, 7.4
+  // against 7.0 on one where EVERY batch takes the slow path (profiles/r05m_wide_lazy_gaps.txt) -- so they keep the strict rule
+  if (!(bound > 0.0) || h->J + h->J_general <= 16) return lazy_eligible(h);
+  const double cmax = sel_max(h->cmax, h->floor_cmax), dxmax = sel_max(h->dxmax, h->floor_dxmax);
+  return h->have_series && h->have_coeffs && cmax * dxmax < bound;
+}
+
 bool split_active(const clr_batch* h) {
   // explicit modes 1 / 2, or auto (-1):
   //  * widths 7 and 8 on a densely sampled series: the split kernel with the decay factored out of the state
@@ -401,7 +417,7 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.split = split ? 1 : 0;
   P.split_lazy = (split && h->summarize_mode != 1 && lazy_eligible(h)) ? 1 : 0;
   // wide plans: the lazy-decay flavour of the wide summarize on dense series (mode 0 / 1 switch it off)
-  if (!h->launch && h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible(h))
+  if (!h->launch && h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible_wide(h))
     P.split_lazy = 1;
   // (the wide kernels, the warm-started recurrence and the scan behind it read the row-major arrays)
   if (h->launch && (h->layout == 1 || split) && h->nchunk > 1 && !h->in_fallback) {
@@ -532,7 +548,7 @@ void general_wide_params(const clr_batch* h, const clr::BatchParams& P, clr::Bat
   W.t = h->t.p; W.diag = h->diag.p; W.y = h->y.p;
   W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
   W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
-  W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;
+  W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible_wide(h)) ? 1 : 0;
   W.coop_prefix = h->coop_prefix == 2 ? 2 : 1;  // (2: the parallel prefix where its workspace exists, else the walk)
   W.J_general = h->J_general;
   W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;

@@ -473,18 +473,25 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       }
       return;
     }
-    if (anchor) {
+    // The series and Taylor steps above hold for |d dt| < NB 2^-5, |c dt| < NB 2^-7 -- every step of a densely sampled
+    // series.  A lane whose interval is larger (an observing gap) sends the WAVE through the full sincos / exp for this
+    // batch: the lazy flavour is then exact for any series whose accumulated decay between two renormalisations stays
+    // representable (the host admits max c x max dx < 2: Psi^-2 < e^256), and a gap costs one slow batch.
+    const double ang = rc.d * (tm - tr), xdec = -rc.c * (tm - tl);
+    const bool small = CLR_WAVE_ALL(fabs(ang) < NB * 0.03125 && fabs(xdec) < NB * 0.0078125);
+    if (anchor || !small) {
       sincos_phase<FAST>(rc.d * tm, &sdr, &csr);
     } else {
       double sn, cn;
-      small_sincos_nb<NB>(KF, rc.d * (tm - tr), &sn, &cn);
+      small_sincos_nb<NB>(KF, ang, &sn, &cn);
       const double c0 = csr, s0 = sdr;
       csr = fma(c0, cn, -s0 * sn);
       sdr = fma(s0, cn, c0 * sn);
     }
     tr = tm;
     double e, einv;
-    decay_pair_nb<NB>(KF, -rc.c * (tm - tl), &e, &einv);
+    if (small) decay_pair_nb<NB>(KF, xdec, &e, &einv);
+    else { e = exp(xdec); einv = exp(-xdec); }
     psi *= e;
     psinv *= einv;
     tl = tm;
@@ -572,7 +579,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
           if (renorm) {  // carry this lane's Psi to t_(n + 1) (forwards or, at a chunk's ragged end, backwards), new base there
             const double tb = tring[(n + 1) & 127];
             double e, einv;
-            decay_pair_nb<NB>(KF, -rc.c * (tb - tl), &e, &einv);
+            const double xr = -rc.c * (tb - tl);
+            if (CLR_WAVE_ALL(fabs(xr) < NB * 0.0078125)) decay_pair_nb<NB>(KF, xr, &e, &einv);
+            else e = exp(xr);  // (a gap inside the lane's interval)
             psiR = psi * e;
             psi = 1.0;
             psinv = 1.0;

@@ -2331,6 +2331,45 @@ def test_wide_summarize_with_the_lazy_decay(JR, JC):
         assert np.max(np.abs(outs[2][2] - outs[0][2]) / np.abs(outs[0][2])) <= 1e-11
 
 
+@pytest.mark.parametrize("JR,JC", [(0, 16), (3, 9), (0, 32), (2, 20)])
+def test_wide_lazy_flavour_on_gappy_and_sparse_series(JR, JC):
+    """Round 5: at widths 17..64 the lazy flavour of the summarize no longer needs a densely sampled series -- a lane whose own
+    interval is too long for the Taylor steps sends its wave through the full sincos / exp for that batch -- and is chosen
+    whenever max c x max dx < 2.  Dense series with 2 % of the steps stretched 300-fold (observing gaps), a uniformly
+    sparse series just inside the bound, and one beyond it (the plain flavour again): the oracle at 1e-10 on every problem,
+    the flavour the plan reports, and the lazy and the plain flavour against each other."""
+    B, N = 3, 9000
+    case = synthetic(B, N, JR, JC, "bench", seed=31 + JR + JC)
+    cmax = max(np.max(case["c_real"]) if JR else 0.0, np.max(case["c_comp"]))
+    rng = np.random.default_rng(JC)
+    base = case["t"] * 0.03                                   # dense: max c dx < 2^-7
+    dt = np.diff(base, axis=1, prepend=0.0)
+    gappy = np.cumsum(np.where(rng.random(dt.shape) < 0.02, 300.0 * dt, dt), axis=1)
+    def stretched(target):                                    # the whole axis scaled so that max c x max dx = target
+        return base * (target / (cmax * np.max(np.diff(base, axis=1))))
+    for label, t, lazy in (("gaps", gappy, True), ("sparse, c dx <= 1.8", stretched(1.8), True), ("sparse, c dx <= 2.5", stretched(2.5), False)):
+        y = np.sin(2.0 * t / np.max(t) * 50.0)
+        l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), t, case["diag"], y, nthreads=os.cpu_count() or 1)
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_chunks(6)
+            plan.set_series(t, case["diag"], y)
+            plan.set_coefficients(*coeffs_of(case))
+            assert ("lazy" in plan.summarize_kernel()) == lazy, (label, plan.summarize_kernel(), plan.selection_bounds())
+            outs = {}
+            for mode in (-1, 0):
+                plan.set_summarize_mode(mode)
+                ll, ld, q, st = plan.log_likelihood()
+                outs[mode] = (ld, q)
+                assert np.array_equal(st, s0), (label, mode)
+                within("wide lazy flavour on gappy / sparse series (%s): log det vs oracle" % label, np.max(np.abs(ld - d0) / np.abs(d0)), REL, (JR, JC, mode))
+                within("wide lazy flavour on gappy / sparse series (%s): quadratic form vs oracle" % label, np.max(np.abs(q - q0) / np.abs(q0)), REL, (JR, JC, mode))
+            assert np.max(np.abs(outs[-1][0] - outs[0][0]) / np.abs(d0)) <= 1e-11
+            assert np.max(np.abs(outs[-1][1] - outs[0][1]) / np.abs(q0)) <= 1e-11
+        finally:
+            plan.close()
+
+
 def test_device_memory_and_plan_lifecycle():
     """clr_device_memory (hipMemGetInfo) and no leak over create / evaluate / destroy cycles of batch plans,
     solver objects and CARMA models (tools/gpu_soak.py is the longer version)."""
