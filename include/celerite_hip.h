@@ -280,11 +280,14 @@ int clr_batch_set_library_trig(clr_batch* h, int force);
  *      registers, Jm in LDS) linked through LDS; reads a chunk-interleaved copy of the series made
  *      once per clr_batch_set_series (layout 1 below is implied);
  *   2  the same with the decay factored out of the state ("lazy": one FMA per state entry and step
- *      instead of FMA + MUL, renormalised every 16 steps) when the series is densely sampled
+ *      instead of FMA + MUL, renormalised every 64 steps) when the series is densely sampled
  *      (max c * max dx < 2^-7 and max d * max dx < 2^-5: the phases then advance by small-angle
- *      rotations, re-anchored with the full sincos every 16 steps), else as 1;
+ *      rotations, re-anchored with the full sincos every 64 steps), else as 1;
  *  -1  (default) 2 at widths 7 and 8 on a dense series; otherwise 1 at width 7 and at width 8 with at least two
- *      complex terms, else 0. */
+ *      complex terms, else 0.
+ * Wide plans (widths 9..64: csrc/wide_kernels.hip) know two flavours: 0 plain, 2 (and -1 where eligible) lazy.  At widths
+ * 17..64 the lazy flavour is eligible whenever max c * max dx < 2 -- a lane whose interval is too long for the small-step
+ * series sends its wave through the full sincos / exp for that batch -- at widths 9..16 under the dense-series rule above. */
 int clr_batch_set_summarize_mode(clr_batch* h, int mode);
 /* Series that FORGET their past (the decay between samples is not small: e.g. the paper's accuracy family,
  * paper/figures/error/error.py:24-25, or most real light curves) do not need the scan: every chunk runs the
