@@ -709,7 +709,8 @@ int clr_batch_get_summarize_kernel(const clr_batch* h, int* kind) {
   if (!kind) return fail(CLR_INVALID_ARGUMENT, "kind is null");
   *kind = split_active(h) ? ((h->summarize_mode != 1 && lazy_eligible(h)) ? 2 : 1) : 0;
   if (!h->launch)  // wide plans: plain or lazy flavour of the one-wave-per-chunk summarize
-    *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible_wide(h)) ? 2 : 0;
+    *kind = (h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) &&
+             (h->J_general > 0 ? lazy_eligible(h) : lazy_eligible_wide(h))) ? 2 : 0;
   return CLR_OK;
 }
 

@@ -417,8 +417,9 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.split = split ? 1 : 0;
   P.split_lazy = (split && h->summarize_mode != 1 && lazy_eligible(h)) ? 1 : 0;
   // wide plans: the lazy-decay flavour of the wide summarize on dense series (mode 0 / 1 switch it off)
+  // (1: dense everywhere -- the strict rule; 2: only the relaxed one: the flavour with the per-batch range test)
   if (!h->launch && h->nchunk > 1 && (h->summarize_mode < 0 || h->summarize_mode == 2) && lazy_eligible_wide(h))
-    P.split_lazy = 1;
+    P.split_lazy = lazy_eligible(h) ? 1 : 2;
   // (the wide kernels, the warm-started recurrence and the scan behind it read the row-major arrays)
   if (h->launch && (h->layout == 1 || split) && h->nchunk > 1 && !h->in_fallback) {
     const long cells = (long)h->nchunk * h->L;
@@ -548,7 +549,7 @@ void general_wide_params(const clr_batch* h, const clr::BatchParams& P, clr::Bat
   W.t = h->t.p; W.diag = h->diag.p; W.y = h->y.p;
   W.t_stride = h->t_stride; W.diag_stride = h->diag_stride; W.y_stride = h->y_stride;
   W.lane_is = 1; W.lane_cs = W.L; W.staged = 0; W.split = 0; W.only_pending = 0;
-  W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible_wide(h)) ? 1 : 0;
+  W.split_lazy = ((h->summarize_mode < 0 || h->summarize_mode == 2) && W.nchunk > 1 && lazy_eligible(h)) ? 1 : 0;  // (general terms: the strict rule)
   W.coop_prefix = h->coop_prefix == 2 ? 2 : 1;  // (2: the parallel prefix where its workspace exists, else the walk)
   W.J_general = h->J_general;
   W.gen_A = h->gA.p; W.gen_U = h->gU.p; W.gen_V = h->gV.p;

@@ -247,7 +247,7 @@ __device__ __forceinline__ L& wide_lds() {
   return lds;
 }
 
-template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN, int NW = 1, bool PAIRED = false>
+template <int WMAX, bool FAST, int MODE, bool LAZY, bool RIDERS, bool GEN, int NW = 1, bool PAIRED = false, bool GAPS = false>
 __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int JC) {
   static_assert(!LAZY || MODE == 1, "the lazy decay is a summarize flavour");
   static_assert(NW == 1 || (NW == 2 && WMAX == 64), "two waves per (problem, chunk): the padded width 64");
@@ -474,11 +474,13 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       return;
     }
     // The series and Taylor steps above hold for |d dt| < NB 2^-5, |c dt| < NB 2^-7 -- every step of a densely sampled
-    // series.  A lane whose interval is larger (an observing gap) sends the WAVE through the full sincos / exp for this
-    // batch: the lazy flavour is then exact for any series whose accumulated decay between two renormalisations stays
-    // representable (the host admits max c x max dx < 2: Psi^-2 < e^256), and a gap costs one slow batch.
+    // series (the host's strict rule: GAPS == false, no test here).  GAPS: a lane whose interval is larger (an observing
+    // gap) sends the WAVE through the full sincos / exp for this batch: the lazy flavour is then exact for any series
+    // whose accumulated decay between two renormalisations stays representable (the host admits max c x max dx < 2:
+    // Psi^-2 < e^256), and a gap costs one slow batch.  A flavour of its own: the slow path's constants and the two
+    // compares cost the dense flavour 5 % when they share a kernel (profiles/r05m_wide_lazy_gaps.txt).
     const double ang = rc.d * (tm - tr), xdec = -rc.c * (tm - tl);
-    const bool small = CLR_WAVE_ALL(fabs(ang) < NB * 0.03125 && fabs(xdec) < NB * 0.0078125);
+    const bool small = !GAPS || CLR_WAVE_ALL(fabs(ang) < NB * 0.03125 && fabs(xdec) < NB * 0.0078125);
     if (anchor || !small) {
       sincos_phase<FAST>(rc.d * tm, &sdr, &csr);
     } else {
@@ -580,7 +582,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
             const double tb = tring[(n + 1) & 127];
             double e, einv;
             const double xr = -rc.c * (tb - tl);
-            if (CLR_WAVE_ALL(fabs(xr) < NB * 0.0078125)) decay_pair_nb<NB>(KF, xr, &e, &einv);
+            if (!GAPS || CLR_WAVE_ALL(fabs(xr) < NB * 0.0078125)) decay_pair_nb<NB>(KF, xr, &e, &einv);
             else e = exp(xr);  // (a gap inside the lane's interval)
             psiR = psi * e;
             psi = 1.0;
@@ -920,10 +922,10 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   }
 }
 
-template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false, bool PAIRED = false>
+template <int WMAX, bool FAST, int MODE, bool LAZY = false, bool GEN = false, bool PAIRED = false, bool GAPS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) wide_scan_kernel(const BatchParams P, int JR, int JC) {
-  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN, 1, PAIRED>(P, JR, JC);
-  else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN, 1, PAIRED>(P, JR, JC);
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<WMAX, FAST, MODE, LAZY, false, GEN, 1, PAIRED, GAPS>(P, JR, JC);
+  else wide_scan_body<WMAX, FAST, MODE, LAZY, true, GEN, 1, PAIRED, GAPS>(P, JR, JC);
 }
 // Round 5: the summarize flavour at widths 33..64 (one lane per row, 64 columns each).  S and A^T alone are 2 x 64 doubles
 // = 256 registers per lane, Jm sits in the matrix cores' accumulators (10 tiles x 4 doubles: the lazy flavour) or in 64
@@ -935,10 +937,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 }
 // ... and TWO waves per (problem, chunk): two lanes per row, 32 columns per lane (wide_scan_body, NW = 2) -- the state fits
 // the architectural registers, two waves per SIMD, both the summarize (MODE 1) and the replay / sequential sweep (MODE 0).
-template <bool FAST, int MODE, bool LAZY, bool GEN, bool PAIRED = false>
+template <bool FAST, int MODE, bool LAZY, bool GEN, bool PAIRED = false, bool GAPS = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) wide_scan64x2_kernel(const BatchParams P, int JR, int JC) {
-  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<64, FAST, MODE, LAZY, false, GEN, 2, PAIRED>(P, JR, JC);
-  else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2, PAIRED>(P, JR, JC);
+  if (MODE == 1 && blockIdx.x == 0) wide_scan_body<64, FAST, MODE, LAZY, false, GEN, 2, PAIRED, GAPS>(P, JR, JC);
+  else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2, PAIRED, GAPS>(P, JR, JC);
 }
 
 // ---------------------------------------------------------------------------
@@ -1373,14 +1375,29 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
   } while (0)
     // complex terms only: the four lanes of a term share the features' work (wide_scan_body, PAIRED)
     const bool paired = !GEN && wide_paired(JR);
+    const bool gaps = !GEN && P.split_lazy == 2 && W > 16;  // (host: not dense everywhere, max c x max dx < 2)
     if (W <= 16) CLR_GOL(16);
-    else if (W <= 32 && paired) {
-      if (P.fast_trig) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true>), grid, dim3(64), 0, s, P, JR, JC);
-      else hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+    else if (W <= 32 && !GEN && (paired || gaps)) {
+      if (P.fast_trig) {
+        if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
+        else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
+        else hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+      } else {
+        if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
+        else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
+        else hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+      }
     } else if (W <= 32) CLR_GOL(32);
-    else if (!wide64_one_wave() && paired) {
-      if (P.fast_trig) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, true>), grid, dim3(128), 0, s, P, JR, JC);
-      else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+    else if (!wide64_one_wave() && !GEN && (paired || gaps)) {
+      if (P.fast_trig) {
+        if (paired && gaps) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, true, true>), grid, dim3(128), 0, s, P, JR, JC);
+        else if (paired) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, true, false>), grid, dim3(128), 0, s, P, JR, JC);
+        else hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+      } else {
+        if (paired && gaps) hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, false, true, true>), grid, dim3(128), 0, s, P, JR, JC);
+        else if (paired) hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, false, true, false>), grid, dim3(128), 0, s, P, JR, JC);
+        else hipLaunchKernelGGL((wide_scan64x2_kernel<false, 1, true, false, false, true>), grid, dim3(128), 0, s, P, JR, JC);
+      }
     } else if (wide64_one_wave()) {
       if (P.fast_trig) hipLaunchKernelGGL((wide_summarize64_kernel<true, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
       else hipLaunchKernelGGL((wide_summarize64_kernel<false, true, GEN>), grid, dim3(64), 0, s, P, JR, JC);
