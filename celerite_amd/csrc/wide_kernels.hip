@@ -442,6 +442,9 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   double gq_v = (GEN && FBA && gen && n_lo + bq < N) ? Vg[n_lo + bq] : 0.0;
   // (PR) the term's own a, b (the row holds (a, b) as (uc, us) or (us, -uc): cholesky.h:143-146)
   const double ta = (row & 1) ? rc.us : rc.uc, tb = (row & 1) ? -rc.uc : rc.us;
+  // (PR) 1 on the term's rows, 0 on padding rows: their v must stay 0 like their u (the pair form writes cos | sin for
+  // every row pair; nonzero v on padding rows is contained in the padding entries of the element, but keep those clean)
+  const double vone = (PR && row >= W) ? 0.0 : 1.0;
   auto feature_batch = [&](int m, bool anchor) {  // samples m .. m + NB - 1, one per lane of a row (PR: of a term)
     const int ms = m + bq;
     const double tm = tring[ms & 127];
@@ -460,8 +463,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         const int r0 = row & ~1, sl = ms & (NSLOT - 1);
         fub[sl][r0] = fma(ta, cs, tb * sd);
         fub[sl][r0 + 1] = fma(ta, sd, -(tb * cs));
-        fvb[sl][r0] = cs;
-        fvb[sl][r0 + 1] = sd;
+        fvb[sl][r0] = vone * cs;
+        fvb[sl][r0 + 1] = vone * sd;
         fpb[sl][r0] = ph;
         fpb[sl][r0 + 1] = ph;
       } else {
@@ -502,8 +505,8 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       const double uc_ = fma(ta, csr, tb * sdr), us_ = fma(ta, sdr, -(tb * csr));
       fub[ms & (NSLOT - 1)][r0] = psi * uc_;
       fub[ms & (NSLOT - 1)][r0 + 1] = psi * us_;
-      fvb[ms & (NSLOT - 1)][r0] = psinv * csr;
-      fvb[ms & (NSLOT - 1)][r0 + 1] = psinv * sdr;
+      fvb[ms & (NSLOT - 1)][r0] = (vone * psinv) * csr;
+      fvb[ms & (NSLOT - 1)][r0 + 1] = (vone * psinv) * sdr;
     } else {
       const double uu = fma(rc.uc, csr, fma(rc.us, sdr, rc.u0));
       const double vv = fma(rc.vc, csr, fma(rc.vs, sdr, rc.v0));
