@@ -339,9 +339,9 @@ bool lazy_eligible(const clr_batch* h) {
 // (wide_scan_body, feature_batch) -- as long as the decay accumulated between two renormalisations (64 steps) stays far
 // from the exponent range: Psi^-2 < e^(2 x 64 x 2) = e^256.  (The one-wave kernels of CLR_WIDE64_ONE_WAVE keep the strict rule.)
 bool lazy_eligible_wide(const clr_batch* h) {
-  static const char* one_wave = getenv("CLR_WIDE64_ONE_WAVE");
-  if (one_wave && h->J > 32) return lazy_eligible(h);
-  static const char* env = getenv("CLR_WIDE_LAZY_BOUND");  // (tuning runs: 0 = the strict rule of the narrow kernels)
+  // (read per call, like the launcher's own getenv: a process may toggle them between plans)
+  if (getenv("CLR_WIDE64_ONE_WAVE") && h->J > 32) return lazy_eligible(h);
+  const char* env = getenv("CLR_WIDE_LAZY_BOUND");  // (tuning runs: 0 = the strict rule of the narrow kernels)
   const double bound = env ? atof(env) : 2.0;
   // widths 9..16 (four lanes per row): the two flavours cost the same there -- 6.5 against 6.7 ms on a dense series, 7.4
   // against 7.0 on one where EVERY batch takes the slow path (profiles/r05m_wide_lazy_gaps.txt) -- so they keep the strict rule
