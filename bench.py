@@ -31,22 +31,24 @@ WORLD_SIZE and with --gpus N > 1, this script starts its own N ranks
 single-process alternative is the product's `ShardedBatchedGP` /
 `clr_sharded_*`: one host thread per GPU.)
 
-Rank 0 prints ONE JSON line; `configs` under it carries BASELINE configs
-0, 1 and 4 (object API at N = 1e3; B = 256 x N = 1e4 width 4; B = 256 x N = 1e5
-width 32), each with its own time, rate, roofline and parity on a sample (and, for
-the batch configs, the histogram of problems by route and the conditioning record).
-`accuracy_family` is SURVEY.md 8(d)'s second input family at the headline shape
-(sparse sampling: the plan runs the warm-started plain recurrence instead of the
-scan); `sharded_product_path` times the product's own sharding (one process, one
-host thread + plan per shard: batch.ShardedBatchedGP) next to the process-per-GPU
-number `--gpus N` reports; `value_steady` is the 2.5 s steady-state leg of the
-real loop.
+Rank 0 prints ONE JSON line on stdout, the LAST thing written there and below 6 KB (the driver keeps the
+last 8 KB of stdout): the contract's keys, `config`, `roofline` (the dominant kernel + the promoted numbers of
+the side legs) and `cpu_baseline` -- `headline_line()`, held to that size by tests/test_host_api.py.  The
+COMPLETE record goes to `gpurun_out/bench_full.json` (or $CLR_BENCH_FULL) and to stderr: `configs` in it
+carries BASELINE configs 0, 1 and 4 (object API at N = 1e3; B = 256 x N = 1e4 width 4; B = 256 x N = 1e5
+width 32), each with its own time, rate, roofline and parity on a sample (and, for the batch configs, the
+histogram of problems by route and the conditioning record).  `accuracy_family` is SURVEY.md 8(d)'s second
+input family at the headline shape (sparse sampling: the plan runs the warm-started plain recurrence instead
+of the scan); `sharded_product_path` times the product's own sharding (one process, one host thread + plan
+per shard: batch.ShardedBatchedGP) next to the process-per-GPU number `--gpus N` reports; `value_steady` is
+the 2.5 s steady-state leg of the real loop.
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 import timeit
 
@@ -1001,12 +1003,107 @@ def main(argv=None):
     dist.barrier()
     dist.close()
     if out is not None:
+        full_path = write_full_record(out)
+        line = headline_line(out, full_path)
+        sys.stderr.flush()
         if json_fd is None:
-            print(json.dumps(out))
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
         else:
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os.write(json_fd, (line + "\n").encode())
     return out
+
+
+HEADLINE_MAX_BYTES = 6000     # the driver keeps the last 8 KB of stdout: the line it parses must fit with room to spare
+
+# the keys of the driver's contract, in the order they are printed
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "timed_region_s")
+# what may be dropped from `roofline` (last first) when the line would not fit: the promoted side numbers, never the
+# dominant kernel's own figures
+ROOFLINE_CORE = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_flops_per_launch",
+                 "algorithmic_bytes_per_launch", "hbm_achieved_GBps", "hbm_frac")
+CONFIG_CORE = ("workload", "batch_per_gpu", "N", "width", "J_real", "J_comp", "scan_chunks", "chunk_len", "parallelism",
+               "summarize_kernel", "problems_replayed", "value_steady")
+
+
+def _short(obj, limit=160):
+    """Strings cut to `limit` characters, floats to 6 significant digits, recursively (the headline carries numbers;
+    the prose lives in the full record)."""
+    if isinstance(obj, str):
+        return obj if len(obj) <= limit else obj[:limit - 1] + "~"
+    if isinstance(obj, bool) or obj is None or isinstance(obj, int):
+        return obj
+    if isinstance(obj, float):
+        if obj != obj or obj in (float("inf"), float("-inf")):
+            return None               # strict JSON has no NaN / Infinity
+        return float("%.6g" % obj)
+    if isinstance(obj, dict):
+        return {str(k): _short(v, limit) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_short(v, limit) for v in obj]
+    try:
+        return _short(float(obj), limit)
+    except Exception:
+        return _short(str(obj), limit)
+
+
+def headline_record(out, full_path=None):
+    """The record of the ONE stdout line: the contract's keys + `config`, `roofline` (with the promoted numbers) and
+    `cpu_baseline`.  Everything else of `out` is named in `extra_keys` and kept in the full record."""
+    rec = {k: out.get(k) for k in HEADLINE_KEYS}
+    rec["config"] = {k: v for k, v in (out.get("config") or {}).items() if k in CONFIG_CORE}
+    rec["roofline"] = dict(out.get("roofline") or {})
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        rec["cpu_baseline"] = cb
+    if out.get("multi_rank_parity") is not None:
+        rec["multi_rank_parity"] = out["multi_rank_parity"]
+    rec["status_not_ok"] = out.get("status_not_ok")
+    rec["full_record"] = full_path
+    rec["extra_keys"] = sorted(k for k in out if k not in rec)
+    return _short(rec)
+
+
+def headline_line(out, full_path=None, max_bytes=HEADLINE_MAX_BYTES):
+    """One strict-JSON line of at most `max_bytes` bytes (tests/test_host_api.py holds it to that)."""
+    rec = headline_record(out, full_path)
+    line = json.dumps(rec, allow_nan=False, separators=(",", ":"))
+    droppable = [k for k in rec["roofline"] if k not in ROOFLINE_CORE]
+    while len(line.encode()) > max_bytes and droppable:
+        rec["roofline"].pop(droppable.pop())
+        line = json.dumps(rec, allow_nan=False, separators=(",", ":"))
+    for key in ("extra_keys", "multi_rank_parity"):
+        if len(line.encode()) > max_bytes and key in rec:
+            rec.pop(key)
+            line = json.dumps(rec, allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) > max_bytes:
+        rec = _short(rec, 60)
+        line = json.dumps(rec, allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) > max_bytes:
+        raise RuntimeError("bench.py: the headline line is %d bytes (> %d)" % (len(line.encode()), max_bytes))
+    return line
+
+
+def write_full_record(out):
+    """The complete record (every leg, every note) goes to a side file and to stderr; stdout carries the headline only."""
+    text = json.dumps(out)
+    path = os.environ.get("CLR_BENCH_FULL")
+    if not path:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_full.json")
+        except OSError:
+            path = os.path.join(tempfile.gettempdir(), "bench_full.json")
+    try:
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        path = None
+    sys.stderr.write("bench.py full record:\n" + text + "\n")
+    return path
 
 
 def promote(out):

@@ -61,6 +61,47 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     par = out["multi_rank_parity"]
     assert par["status_equal"] and par["logdet_rel_max"] <= REL and par["quad_rel_max"] <= REL, par
     assert "roofline" in out and out["roofline"]["frac"] > 0.0
+    assert len(lines[0].encode()) < 6000
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_gpu_line_as_the_driver_parses_it():
+    """``python bench.py --gpus 1 --steps 20 --warmup 5`` -- the driver's round-end command.  The driver keeps the last
+    8 KB of stdout and parses the LAST line: that line must be strict JSON, well under 8 KB, and carry the headline,
+    ``config.workload``, ``roofline`` and ``cpu_baseline`` (round 5's 26.5 KB line came back ``parsed: null``).  The
+    complete record goes to a side file."""
+    env = dict(os.environ)
+    full = os.path.join(ROOT, "gpurun_out", "bench_full_test.json")
+    env["CLR_BENCH_FULL"] = full
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=840)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    stdout = r.stdout.decode()
+    assert len(stdout.encode()) < 8000, len(stdout)
+    last = stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 6000
+
+    def no_constants(name):
+        raise ValueError("not strict JSON: %s" % name)
+
+    out = json.loads(last, parse_constant=no_constants)
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["metric"].startswith("GP log-likelihoods/sec") and out["unit"] == "log-likelihoods/s"
+    assert out["higher_is_better"] is True and out["dtype"] == "f64" and out["vs_baseline"] is None
+    assert abs(out["value"] - 1024 * 20 / out["timed_region_s"]) <= 1e-4 * out["value"]
+    assert "configs[2]" in out["config"]["workload"] and out["config"]["batch_per_gpu"] == 1024
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms"):
+        assert key in roof, key
+    assert 0.0 < roof["frac"] < 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert roof["launch_ms"] < out["ms_per_step"]
+    assert roof["parity"]["status_equal"] and roof["parity"]["logdet_rel_max"] <= REL and roof["parity"]["quad_rel_max"] <= REL
+    cpu = out["cpu_baseline"]
+    assert cpu["value"] > 0 and cpu["cores"] == 1 and cpu["kind"] == "port" and cpu["sample"]
+    assert out["status_not_ok"] == 0
+    whole = json.load(open(full))
+    assert whole["value"] == pytest.approx(out["value"], rel=1e-5) and "configs" in whole and "materialize" in whole
 
 
 def test_sharded_plan_over_every_visible_device():

@@ -269,3 +269,55 @@ def test_device_memory_needs_a_gpu():
     else:
         free, total = batch.device_memory()
         assert 0 < free <= total
+
+
+def test_bench_headline_line_is_small_strict_json():
+    """The driver keeps the last 8 KB of bench.py's stdout and parses the last line (round 5's 26.5 KB line came back
+    ``parsed: null``).  The headline built from a real full record (round 5's, ``profiles/r05end_bench.json``), from the
+    same record with every string blown up and non-finite numbers in it, and from a minimal one must be ONE strict-JSON
+    line below 6000 bytes that carries the contract's keys, ``config.workload``, ``roofline`` and ``cpu_baseline``."""
+    import json
+
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05end_bench.json")))
+    assert len(json.dumps(full)) > 20000          # (the canned record IS the one the driver could not parse)
+
+    def no_constants(name):
+        raise ValueError("not strict JSON: %s" % name)
+
+    def check(record):
+        line = bench.headline_line(record, "gpurun_out/bench_full.json")
+        assert "\n" not in line and len(line.encode()) < bench.HEADLINE_MAX_BYTES <= 6000
+        out = json.loads(line, parse_constant=no_constants)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in out, key
+        assert out["value"] == pytest.approx(record["value"], rel=1e-5)
+        assert out["config"]["workload"].startswith("BASELINE configs[2]")
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in out["roofline"], key
+        assert out["roofline"]["frac"] == pytest.approx(record["roofline"]["frac"], rel=1e-5)
+        return out
+
+    out = check(full)
+    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["roofline"]["config1_ms_per_step"] > 0 and "materialize" in out["roofline"]
+    assert "configs" in out["extra_keys"] and "configs" not in out
+
+    import copy
+    fat = copy.deepcopy(full)
+    fat["config"]["workload"] = "BASELINE configs[2]: " + "x" * 20000
+    fat["roofline"]["measured_valu_fma_rate_note"] = "y" * 50000
+    fat["roofline"]["nan"] = float("nan")
+    fat["roofline"]["inf"] = float("inf")
+    fat["roofline"]["np"] = np.float64(1.5)
+    for i in range(300):                          # a roofline that somebody keeps adding promoted numbers to
+        fat["roofline"]["promoted_%d" % i] = {"ms": 1.0 * i, "note": "z" * 100}
+    fat["cpu_baseline"]["sample"] = "s" * 9000
+    check(fat)
+
+    lean = {k: full[k] for k in bench.HEADLINE_KEYS if k in full}
+    lean["config"] = {"workload": full["config"]["workload"]}
+    lean["roofline"] = {k: full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    check(lean)
