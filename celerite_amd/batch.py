@@ -668,8 +668,8 @@ class ShardedBatchedGP(object):
         self._ok(_load().clr_sharded_set_summarize_mode(self._h, int(mode)))
 
     def set_rescue(self, mode=-1):
-        """``clr_batch_set_rescue`` on every shard (route-1 problems re-planned as a side plan per shard; ``mode=0``: the
-        inline replay, bit-identical under any sharding)."""
+        """``clr_batch_set_rescue`` on every shard.  Side plan or inline replay of route-1 problems, and the side plan's
+        chunk count, follow their number in the WHOLE batch: bit-identical under any sharding."""
         lib = _load()
         lib.clr_sharded_set_rescue.argtypes = [C.c_void_p, C.c_int]
         self._ok(lib.clr_sharded_set_rescue(self._h, int(mode)))
@@ -682,10 +682,19 @@ class ShardedBatchedGP(object):
         self._ok(lib.clr_sharded_get_rescue(self._h, C.byref(n)))
         return n.value
 
+    def set_certificate(self, max_gamma_over_mu=1e7, max_residual=1e-11, max_gamma=None, max_gamma_error=None):
+        """``BatchedGP.set_certificate`` on every shard (the routing bounds of ill-conditioned problems)."""
+        lib = _load()
+        lib.clr_sharded_set_certificate.argtypes = [C.c_void_p] + [C.c_double] * 4
+        touch = max_gamma is not None or max_gamma_error is not None
+        self._ok(lib.clr_sharded_set_certificate(self._h, float(max_gamma_over_mu), float(max_residual),
+                                                 float(1e4 if max_gamma is None else max_gamma) if touch else -1.0,
+                                                 float(3e-9 if max_gamma_error is None else max_gamma_error) if touch else -1.0))
+
     def set_warm_start(self, mode=-1, forced_warmup=0):
-        """``clr_batch_set_warm_start`` on every shard.  The warm-started recurrence adapts per plan, so a batch
-        may take different (equally certified) routes under different shardings -- results then agree to the scan's
-        rounding, not bit for bit; ``mode=0`` switches it off."""
+        """``clr_batch_set_warm_start`` on every shard.  Activation (half of the problems of the WHOLE batch eligible) and
+        the adaptation of the warm-up lengths are decided once for the batch: the same route -- the same bits -- under
+        any sharding; ``mode=0`` switches the warm start off."""
         lib = _load()
         lib.clr_sharded_set_warm_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
         self._ok(lib.clr_sharded_set_warm_start(self._h, int(mode), int(forced_warmup)))

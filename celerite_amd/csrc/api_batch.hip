@@ -1,6 +1,7 @@
 // celerite_amd/csrc/api_batch.hip -- C ABI of the batched plans (clr_batch_*): HBM residency, path selection
 // (scan pipeline, warm-started recurrence, one-launch path, wide kernels, general terms), evaluation and results.
 #include "api_internal.h"
+#include "clr_group_hooks.h"
 
 extern "C" {
 
@@ -57,6 +58,7 @@ void clr_batch_destroy(clr_batch* h) {
   if (h->wints) (void)hipFree(h->wints);
   if (h->g_ckflag) (void)hipFree(h->g_ckflag);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  for (hipEvent_t& e : h->bs_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (h->pin) (void)hipHostFree(h->pin);
   clr::staging_destroy(h->staging);
   h->scan.release();
@@ -149,7 +151,7 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
-    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, h->B, h->J);
+    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, sel_B(h), h->J);
     size_t le = 0, ls = 0;
     clr::multilevel_workspace(h->plan, h->J, &le, &ls);
     if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
@@ -256,6 +258,8 @@ static void warm_select(clr_batch* h) {
   const size_t B = (size_t)h->B;
   h->warm_active = false;
   h->warm_K_dirty = false;
+  h->warm_eligible = 0;
+  h->warm_eligible_total = -1;
   if (h->warm_mode == 0 || h->wnchunk < 2 || !h->have_series || h->warm_span.empty() || h->host_cmin.size() != B) return;
   h->warm_K.assign(B, 0);
   size_t eligible = 0;
@@ -277,8 +281,11 @@ static void warm_select(clr_batch* h) {
     h->warm_K[b] = K;
     eligible += K > 0;
   }
-  // (a batch with only a few eligible problems is not worth a second set of launches)
-  h->warm_active = eligible * 2 >= B;
+  // (a batch with only a few eligible problems is not worth a second set of launches; a slice of a larger batch waits
+  //  for the count over the whole batch: clr_group::set_warm_eligible_total)
+  h->warm_eligible = (long)eligible;
+  h->warm_eligible_total = -1;
+  h->warm_active = h->group_B > 0 ? false : eligible * 2 >= B;
   h->warm_K_dirty = h->warm_active;  // (uploaded behind the next coefficients, or by the next enqueue)
 }
 
@@ -402,6 +409,7 @@ int clr_batch_set_selection_bounds(clr_batch* h, double tmax, double dxmax, doub
 
 static int reserve_pinned(clr_batch* h, size_t doubles) {
   if (doubles <= h->pin_cap && h->pin) return CLR_OK;
+  h->pin_results = false;
   if (h->pin) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     (void)hipHostFree(h->pin);
@@ -421,6 +429,7 @@ int clr_batch_set_coefficients(clr_batch* h, const double* jitter, const double*
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;  // (pending problems of the evaluation in flight: at ITS coefficients)
   const size_t B = (size_t)h->B, nr = B * h->J_real, nc = B * h->J_comp;
   h->factor_inputs_changed = true;
+  h->pin_results = false;  // (the staging buffer is about to carry the coefficients)
   h->dmax = 0.0;
   h->cmax = 0.0;
   for (size_t i = 0; i < nc; ++i) {
@@ -915,7 +924,7 @@ static bool small_runs(const clr_batch* h, int materialize) {
   // automatic: not when the caller tuned the scan pipeline explicitly, and only while a workgroup per problem fits
   // one round of the chip (widths 3, 4: one workgroup per CU by registers and LDS; narrower: four) -- above that the
   // pipeline's throughput wins (profiles/r04i_small_batch.txt: 1024 x 1e4 x width 4 0.29 ms against 0.34)
-  return !h->pipeline_pinned && h->B <= (h->J >= 3 ? 256 : 1024);
+  return !h->pipeline_pinned && sel_B(h) <= (h->J >= 3 ? 256 : 1024);
 }
 
 static bool warm_runs(const clr_batch* h, int materialize) {
@@ -1041,7 +1050,11 @@ static clr::BatchParams group_view(const clr_batch* h, const clr::BatchParams& P
   clr::multilevel_workspace(P.plan, (int)J, &le, &ls);
   if (G.lvl_elems) G.lvl_elems += o * le;
   if (G.lvl_starts) G.lvl_starts += o * ls;
-  if (G.phi) { G.phi += o * J * cells; G.u += o * J * cells; G.W += o * J * cells; G.D += o * cells; }
+  // (the lean factor layout stores W and D only: phi / u are never reserved there)
+  if (G.phi) G.phi += o * J * cells;
+  if (G.u) G.u += o * J * cells;
+  if (G.W) G.W += o * J * cells;
+  if (G.D) G.D += o * cells;
   G.out_ll += o; G.out_logdet += o; G.out_quad += o; G.out_status += o;
   G.only_pending = 0;
   return G;
@@ -1181,6 +1194,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     ++h->prof_steps;
   }
   if (!P.defer_level1) h->rescue_last = 0;  // (nothing is re-planned behind this evaluation)
+  h->pin_results = false;
   const bool all_marks = h->prof_on != 2;
   auto mark = [&](int i) { if (ev && (all_marks || i == 1 || i == 2)) (void)hipEventRecord(ev[i], h->stream); };
   h->evaluated = true;
@@ -1195,7 +1209,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
       clr::BatchParams W;
       general_wide_params(h, P, W);
       mark(0);
-      wide_flow(W, h->J_real, h->J_comp, h->stream, ev);
+      if ((st = wide_flow(W, h->J_real, h->J_comp, h->stream, ev)) != CLR_OK) return st;
       HIP_TRY(hipGetLastError());
       return CLR_OK;
     }
@@ -1217,7 +1231,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   }
   if (!h->launch) {
     mark(0);
-    wide_launch(h, P, ev);
+    if ((st = wide_launch(h, P, ev)) != CLR_OK) return st;
     h->rescue_inflight = P.defer_level1 != 0;
     HIP_TRY(hipGetLastError());
     return CLR_OK;
@@ -1341,17 +1355,21 @@ static int rescue_inline(clr_batch* h) {
   return CLR_OK;
 }
 
-static int rescue_run(clr_batch* h, const std::vector<int>& idx) {
+// `n_total`: the pending problems of the WHOLE batch (the plan's own count unless it is a slice of a larger batch):
+// side plan or inline replay, and the side plan's chunk count, follow that number -- never the slice's own -- so that
+// a problem is re-planned the same way under any sharding.
+static int rescue_run(clr_batch* h, const std::vector<int>& idx, long n_total) {
   const int n = (int)idx.size();
   h->rescue_total += n;
-  if (n > std::max(1, h->B / 4) || n > 256) {
+  if (n_total > std::max(1, sel_B(h) / 4) || n_total > 256) {
     h->rescue_last = -n;
     return rescue_inline(h);
   }
   h->rescue_last = n;
   int st;
-  if (!h->rescue || h->rescue->B != n) {
+  if (!h->rescue || h->rescue->B != n || h->rescue_plan_key != n_total) {
     if (h->rescue) clr_batch_destroy(h->rescue);
+    h->rescue_plan_key = -1;
     h->rescue = clr_batch_create(n, h->N, h->J_real, h->J_comp, h->device);
     if (!h->rescue) return CLR_HIP_ERROR;
     clr_batch* r = h->rescue;
@@ -1359,18 +1377,30 @@ static int rescue_run(clr_batch* h, const std::vector<int>& idx) {
     r->force_exact = 1;
     r->warm_mode = 0;
     r->small_mode = 0;
+    r->group_B = (int)n_total;  // (its prefix plan's time model: the side plan of the whole batch)
     int nchunk = 0;
+    const int nt = (int)n_total;
     if (!h->launch) {  // wide: B x nchunk <= the parallel prefix's cap (1024 workgroups per level at width 32, 2048 below)
       const int JP = clr::wide_padded_width(h->J);
       if (JP <= 32) {
-        nchunk = std::min(clr::wide_prefix_scan_cap(JP) / n, clr::wide_prefix_scan_max_chunks(JP));
+        nchunk = std::min(clr::wide_prefix_scan_cap(JP) / nt, clr::wide_prefix_scan_max_chunks(JP));
         nchunk = std::min(nchunk, h->N / (JP == 16 ? 64 : 96));
         if (nchunk < 8) nchunk = 0;  // (short series: the plan's own choice)
       }  // (widths 33..64: the plan's own rule -- 1024 / n chunks, at most 16, chained by the walk)
+      if (nchunk == 0) {  // the automatic rule, asked as the side plan of the whole batch would ask it
+        clr_batch* probe = (nt == n) ? nullptr : clr_batch_create(nt, h->N, h->J_real, h->J_comp, h->device);
+        if (probe) { nchunk = probe->nchunk; clr_batch_destroy(probe); }
+      }
     } else {
-      nchunk = auto_chunks(n, h->N, h->J, true);
+      nchunk = auto_chunks(nt, h->N, h->J, true);
     }
-    if ((st = clr_batch_set_chunks(r, nchunk)) != CLR_OK) return st;
+    // (a failed set-up must not leave a half-initialised side plan behind: the next resolve would take it for ready)
+    if ((st = clr_batch_set_chunks(r, nchunk)) != CLR_OK) {
+      clr_batch_destroy(h->rescue);
+      h->rescue = nullptr;
+      return st;
+    }
+    h->rescue_plan_key = n_total;
   }
   clr_batch* r = h->rescue;
   // the parent's settings that decide routes and kernels
@@ -1428,12 +1458,23 @@ static int rescue_run(clr_batch* h, const std::vector<int>& idx) {
 // chunking, so it must run before any of them changes: every state-changing entry point, clr_batch_synchronize and
 // clr_batch_get_results call this first.  *pin_current (may be null): the pinned staging buffer holds the final
 // results (ll | logdet | quad | status) of this evaluation.
-static int warm_resolve(clr_batch* h, bool* pin_current) {
-  if (pin_current) *pin_current = false;
+//
+// Two halves (a plan that is a slice of a larger batch has the sharded layer add up the counts between them,
+// clr_group_hooks.h): resolve_begin waits for the evaluation and counts, resolve_finish acts on the counts of the
+// whole batch.
+static int resolve_begin(clr_batch* h, long* pending_out, long* eligible_out) {
+  if (pending_out) *pending_out = 0;
+  if (eligible_out) *eligible_out = 0;
+  if (h->res_open) {  // (begin twice without a finish: the same counts again)
+    if (pending_out) *pending_out = h->res_pending;
+    if (eligible_out) *eligible_out = h->res_was_warm ? h->warm_eligible : 0;
+    return CLR_OK;
+  }
   if (!h->warm_inflight && !h->small_inflight && !h->rescue_inflight) return CLR_OK;
   // (the one-launch path of short narrow problems leaves pending problems the same way, but its outcome says nothing
   //  about the warm-up lengths: the warm path's statistics and its adaptation are not touched on its behalf)
-  const bool was_warm = h->warm_inflight, was_rescue = h->rescue_inflight;
+  h->res_was_warm = h->warm_inflight;
+  h->res_was_rescue = h->rescue_inflight;
   h->warm_inflight = false;
   h->small_inflight = false;
   h->rescue_inflight = false;
@@ -1443,40 +1484,76 @@ static int warm_resolve(clr_batch* h, bool* pin_current) {
   HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
-  int pending = 0;
+  long pending = 0;
   for (size_t b = 0; b < B; ++b) pending += stw[b] == clr::CLR_PENDING_STATUS;
-  if (was_warm) {
-    h->warm_fallbacks = pending;
-    h->warm_settled = (int)B - pending;
+  if (h->res_was_warm) {
+    h->warm_fallbacks = (int)pending;
+    h->warm_settled = (int)B - (int)pending;
   }
+  h->res_pending = pending;
+  h->res_open = true;
+  h->pin_results = true;  // (final unless something is pending: resolve_finish re-reads then)
+  if (pending_out) *pending_out = pending;
+  if (eligible_out) *eligible_out = h->res_was_warm ? h->warm_eligible : 0;
+  return CLR_OK;
+}
+
+// `pending_total`, `eligible_total`: the counts over the whole batch (the plan's own when it is the whole batch)
+static int resolve_finish(clr_batch* h, long pending_total, long eligible_total) {
+  if (!h->res_open) return CLR_OK;
+  h->res_open = false;
+  const size_t B = (size_t)h->B, words = 3 * B + (B + 1) / 2;
+  const bool was_warm = h->res_was_warm, was_rescue = h->res_was_rescue;
+  const long pending = h->res_pending;
+  const int* stw = reinterpret_cast<const int*>(h->pin + 3 * B);
+  int st;
   if (was_rescue) {
     // the scan pipeline itself ran: what is pending are its level-1 problems, re-planned with short chunks
     h->rescue_last = 0;
     if (pending) {
       std::vector<int> idx;
       for (size_t b = 0; b < B; ++b) if (stw[b] == clr::CLR_PENDING_STATUS) idx.push_back((int)b);
-      if ((st = rescue_run(h, idx)) != CLR_OK) return st;
+      h->pin_results = false;
+      if ((st = rescue_run(h, idx, pending_total)) != CLR_OK) return st;
       HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
+      h->pin_results = true;
     }
-    if (pin_current) *pin_current = true;
     return CLR_OK;
   }
   if (pending) {
+    h->pin_results = false;
     if ((st = warm_fallback(h)) != CLR_OK) return st;
     HIP_TRY(hipMemcpyAsync(h->pin, h->out.p, words * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->pin_results = true;
+  }
+  if (pending_total) {
     // many mismatches among the problems that did warm up: longer warm-ups from the next coefficients on
-    size_t eligible = 0;
-    for (int k : h->warm_K) eligible += k > 0;
-    const long failed = (long)pending - (long)(B - eligible);
-    if (was_warm && h->warm_mode < 0 && failed * 10 > (long)eligible && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
+    const long failed = pending_total - ((long)sel_B(h) - eligible_total);
+    if (was_warm && h->warm_mode < 0 && failed * 10 > eligible_total && h->warm_boost < clr_batch::WARM_NK - 1) ++h->warm_boost;
   } else if (was_warm && h->warm_mode < 0 && h->warm_boost > 0 && ++h->warm_clean >= 8) {
     --h->warm_boost;  // eight clean evaluations in a row: try the shorter warm-ups again
     h->warm_clean = 0;
   }
-  if (pending && was_warm) h->warm_clean = 0;
-  if (pin_current) *pin_current = true;
+  if (pending_total && was_warm) h->warm_clean = 0;
+  return CLR_OK;
+}
+
+static int warm_resolve(clr_batch* h, bool* pin_current) {
+  if (pin_current) *pin_current = false;
+  if (!h->res_open && !h->warm_inflight && !h->small_inflight && !h->rescue_inflight) {
+    // (nothing in flight; an evaluation the sharded layer has already resolved left its results in the staging buffer)
+    if (pin_current) *pin_current = h->pin_results;
+    return CLR_OK;
+  }
+  long pending = 0, eligible = 0;
+  int st = resolve_begin(h, &pending, &eligible);
+  if (st != CLR_OK) return st;
+  // (a slice of a larger batch resolved on its own -- clr_batch_run_timed's steps, a direct call -- acts on its own
+  //  counts scaled to nothing: the slice's numbers stand for the batch's)
+  if ((st = resolve_finish(h, pending, eligible)) != CLR_OK) return st;
+  if (pin_current) *pin_current = h->pin_results;
   return CLR_OK;
 }
 
@@ -1579,15 +1656,18 @@ int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
     src = h->bs_rm.p;
     src_stride = (long)N;
   }
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  for (hipEvent_t& e : h->bs_ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  hipEvent_t e0 = h->bs_ev[0], e1 = h->bs_ev[1];
   HIP_TRY(hipEventRecord(e0, h->stream));
   clr::launch_relayout(src, src_stride, h->bs_x.p, (long)cells, (int)(B * R), h->N, h->L, h->nchunk, 0, h->stream);
   clr::BSolveParams S;
   S.nrhs = nrhs; S.r = 0; S.lean = h->factor_is_lean ? 1 : 0;
-  S.have_M = h->bs_M_valid ? 1 : 0;  // (the chunk maps depend on the factor only: formed by the first solve after a materialising run)
-  h->bs_M_valid = true;
+  // (the chunk maps depend on the factor only: formed by the first solve after a materialising run; they count as
+  //  formed only once that solve's kernels have run to completion -- a failed launch or copy must not leave the next
+  //  solve reading uninitialised maps)
+  S.have_M = h->bs_M_valid ? 1 : 0;
+  h->bs_M_valid = false;
   S.xT = h->bs_x.p; S.M = h->bs_M.p; S.off = h->bs_off.p; S.starts = h->bs_starts.p;
   h->launch->bsolve(P, S, h->stream);
   clr::launch_relayout_back(h->bs_x.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
@@ -1595,11 +1675,10 @@ int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->bs_M_valid = true;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   h->solve_device_ms = ms;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return CLR_OK;
 }
 
@@ -1616,6 +1695,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   if ((st = batch_params(h, materialize, P)) != CLR_OK) return st;
   if (steps < 1) steps = 1;
   h->evaluated = true;
+  h->pin_results = false;
   if (h->J_general > 0 || h->J > clr::wide_max_width()) {
     // (plans on the any-width sequential kernel or with general terms: the evaluation itself, `steps` times, as one "replay" slot)
     hipEvent_t e0, e1;
@@ -1643,7 +1723,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     hipEvent_t* e = &ev[(size_t)i * (NK + 1)];
     HIP_TRY(hipEventRecord(e[0], h->stream));
     if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
-      wide_launch(h, P, e);
+      if ((st = wide_launch(h, P, e)) != CLR_OK) return st;
       // (a plan that re-planned level-1 problems at its last evaluation does so inside every timed step: the step's
       //  time then includes the side plan -- at the price of a host round trip per step)
       if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; HIP_TRY(hipEventRecord(e[6], h->stream)); }
@@ -1747,3 +1827,37 @@ int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double*
 }
 
 }  // extern "C"
+
+// ---- hooks of the sharded layer (clr_group_hooks.h; not part of the C ABI) ----------------------------------------
+namespace clr_group {
+
+void set_batch_context(clr_batch* h, int B_total) {
+  h->group_B = B_total > h->B ? B_total : 0;  // (a single shard IS the whole batch)
+}
+
+long warm_eligible(const clr_batch* h) { return h->warm_eligible; }
+
+void set_warm_eligible_total(clr_batch* h, long eligible_total) {
+  if (h->group_B <= 0) return;
+  const bool selectable = h->warm_mode != 0 && h->wnchunk >= 2 && h->have_series && !h->warm_span.empty() &&
+                          h->host_cmin.size() == (size_t)h->B && h->warm_K.size() == (size_t)h->B;
+  h->warm_eligible_total = eligible_total;
+  h->warm_active = selectable && eligible_total * 2 >= (long)h->group_B;
+  h->warm_K_dirty = h->warm_active;  // (K per problem goes up with the next enqueue)
+}
+
+bool in_flight(const clr_batch* h) { return h->res_open || h->warm_inflight || h->small_inflight || h->rescue_inflight; }
+
+int resolve_begin(clr_batch* h, long* pending, long* eligible) {
+  const int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  return ::resolve_begin(h, pending, eligible);
+}
+
+int resolve_finish(clr_batch* h, long pending_total, long eligible_total) {
+  const int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  return ::resolve_finish(h, pending_total, eligible_total);
+}
+
+}  // namespace clr_group

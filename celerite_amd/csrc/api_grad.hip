@@ -62,7 +62,18 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   const bool seq_all = Wt > 32;
   if (seq_all && general)
     return fail(CLR_UNSUPPORTED, "the plan gradient with general terms covers total widths up to 32");
-  int st = seq_all ? CLR_OK : clr_batch_enqueue(h, 0);
+  // (the tangent kernels are built up to the padded width 64: rows beyond it would be dropped while the diagonal sums
+  //  still covered every term -- a wrong gradient with CLR_OK)
+  if (Wt > clr::wide_max_width())
+    return fail(CLR_UNSUPPORTED, "the plan gradient covers widths up to 64");
+  // The evaluation behind the gradient must hand out FINAL values: no level-1 problem may be left pending for a side
+  // plan (defer_runs) -- the walk reads ll / status straight from the device, before any resolve could run
+  int st = CLR_OK;
+  if (!seq_all) {
+    h->grad_scan_only = true;
+    st = clr_batch_enqueue(h, 0);
+    h->grad_scan_only = false;
+  }
   if (st != CLR_OK) return st;
   clr::BatchParams P0, P;
   if ((st = batch_params(h, 0, P0)) != CLR_OK) return st;

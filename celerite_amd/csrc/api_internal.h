@@ -290,6 +290,7 @@ struct clr_batch {
   DevBuf bs_rm, bs_x, bs_M, bs_off, bs_starts;  // clr_batch_solve: right-hand sides row-major / chunk-interleaved, chunk maps, offsets, start states
   bool bs_M_valid = false;                      // bs_M holds the chunk maps of the factor in HBM (they depend on the factor only)
   double solve_device_ms = 0.0;                 // device time of the last clr_batch_solve (HIP events around its kernels)
+  hipEvent_t bs_ev[2] = {nullptr, nullptr};     // ... its two timing events, created by the first solve, kept for the plan's life
   int factor_layout = 0;      // clr_batch_set_factor_layout: 0 the reference's four arrays, 1 lean (W, D; phi, u regenerated)
   bool factor_is_lean = false;  // what the factor in HBM holds (set by the materialising run that wrote it)
   bool factor_inputs_changed = false;  // series or coefficients replaced since that run (a lean factor can then no longer be expanded)
@@ -311,6 +312,18 @@ struct clr_batch {
   size_t rescue_idx_cap = 0;
   int rescue_last = 0;             // problems of the last resolved evaluation that were re-planned (or replayed inline: negative)
   long rescue_total = 0;
+  long rescue_plan_key = -1;       // the batch-wide count of pending problems the side plan in `rescue` was chunked for
+  // A plan that is ONE SLICE of a larger batch (csrc/sharded.cpp, clr_group_hooks.h): every decision that looks at a
+  // count over "the plan's problems" -- the prefix plan's time model, the one-launch path, the warm path's activation
+  // and adaptation, deferring level-1 problems, side plan or inline replay and the side plan's chunk count -- is
+  // taken from the counts over the WHOLE batch, so that a problem's result does not depend on the sharding.
+  int group_B = 0;                 // problems of the whole batch (0: this plan is the whole batch)
+  long warm_eligible = 0;          // problems of this plan the warm path could start at the coefficients in force
+  long warm_eligible_total = -1;   // ... of the whole batch, as handed down (group_B > 0 only)
+  // warm_resolve in two halves (resolve_begin / resolve_finish): the state between them
+  bool res_open = false, res_was_warm = false, res_was_rescue = false;
+  long res_pending = 0;
+  bool pin_results = false;        // the pinned staging buffer holds the final results of the evaluation in force
   // optional per-kernel HIP events around the launches of clr_batch_enqueue (clr_batch_set_profiling)
   int prof_on = 0, prof_steps = 0;
   std::vector<hipEvent_t> prof_events;  // 7 per recorded step
@@ -326,6 +339,8 @@ double sel_max(double own, double floor) {  // (NaN on either side wins: the con
   if (floor != floor) return floor;
   return own >= floor ? own : floor;
 }
+// the batch size the selection rules look at: the whole batch's when the plan is a slice of one (clr_batch::group_B)
+int sel_B(const clr_batch* h) { return h->group_B > 0 ? h->group_B : h->B; }
 bool lazy_eligible(const clr_batch* h) {
   // |c dx| < 2^-7 at every step: Psi stays within [0.88, 1] over the 16 steps between renormalisations;
   // |d dx| < 2^-5: the per-step rotation of the (cos, sin) pairs uses a short Taylor series
@@ -371,7 +386,7 @@ bool split_active(const clr_batch* h) {
 // evaluation, behind the warm path, or on a side plan.
 bool defer_runs(const clr_batch* h, int materialize) {
   if (h->rescue_mode == 0 || h->is_rescue_plan || materialize || h->force_exact || h->grad_scan_only || h->in_fallback) return false;
-  if (h->nchunk < 2 || h->J_general > 0 || h->B < 2) return false;
+  if (h->nchunk < 2 || h->J_general > 0 || sel_B(h) < 2) return false;
   if (h->rescue_mode == 1) return true;
   // widths 33..64: a side plan is itself <= 16 chunks chained by a walk of ~0.6 ms each -- it does not beat the inline
   // replay of one of the parent's chunks (profiles/r05d_wide64_chunks.txt)
@@ -502,7 +517,9 @@ bool batch_relayout(clr_batch* h) {
 }
 
 
-void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev) {
+// CLR_OK, or CLR_HIP_ERROR when a kernel of the flow could not be configured (nothing after it is launched: the later
+// kernels would run on stale start states)
+int wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, hipEvent_t* ev) {
   auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], stream); };
   const int JP = clr::wide_padded_width(J_real + 2 * J_comp + P.J_general);
   mark(1);
@@ -512,7 +529,8 @@ void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, 
   // that kernel at the padded width 32 too (cross-check of the two-kernel path; tests)
   const bool walk32 = getenv("CLR_WIDE_WALK") != nullptr;
   if (JP == 64 || (JP == 32 && walk32 && !(P.scan_ws && P.coop_prefix == 2))) {
-    (void)clr::launch_wide_walk(P, JP, stream);
+    if (clr::launch_wide_walk(P, JP, stream) != 0)
+      return fail(CLR_HIP_ERROR, "the width-64 walk kernel needs 132 KB of dynamic LDS per workgroup: the device refused the attribute");
     mark(3);
     clr::launch_wide_decide(P, JP, stream);
   } else {
@@ -533,9 +551,10 @@ void wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, 
   }
   mark(5);
   mark(6);
+  return CLR_OK;
 }
-void wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
-  wide_flow(P, h->J_real, h->J_comp, h->stream, ev);
+int wide_launch(clr_batch* h, clr::BatchParams& P, hipEvent_t* ev) {
+  return wide_flow(P, h->J_real, h->J_comp, h->stream, ev);
 }
 
 const int PROF_NK = 6, PROF_MAX_STEPS = 4096;

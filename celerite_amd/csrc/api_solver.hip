@@ -387,7 +387,10 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
     HIP_TRY(hipMemsetAsync(P.need_exact, 0, sizeof(int), stream));  // (one chunk: no prefix kernel clears it)
-    wide_flow(P, J_real, J_comp, stream, nullptr);
+    {
+      const int wst = wide_flow(P, J_real, J_comp, stream, nullptr);
+      if (wst != CLR_OK) return wst;
+    }
     HIP_TRY(hipGetLastError());
     double back_local[4];
     double* pinned_back = arena_take(s, 4);

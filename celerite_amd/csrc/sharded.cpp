@@ -3,17 +3,22 @@
 // cholesky.h:703-706), so a sharded plan is nothing but S single-device plans (clr_batch_*)
 // over contiguous slices of the batch axis: no collective, no device-to-device traffic.
 //
-// Kernel selection is resolved ONCE for the whole batch: the maxima the single-device plans look at
-// (max |t|, largest time step, largest decay rate and frequency) are taken over all problems and handed
-// to every shard (clr_batch_set_selection_bounds), and all shards use the first shard's chunk count, so
-// a batch gives bit-identical results under any sharding with the default settings -- as long as the
-// warm-started recurrence (series that forget their past) does not come into play.  That path is
-// ADAPTIVE per plan: it is switched on when at least half of the plan's problems are eligible, its chunking looks at
-// the plan's batch size and its warm-up lengths grow with the plan's own history of fallbacks.  A batch in which
-// about half of the problems forget can therefore take the warm recurrence in one sharding and the scan in another:
-// two certified evaluations of the same numbers, equal to the rounding of the scan (<= 1e-11 relative, statuses
-// identical; tests/test_gpu_batch.py::test_sharding_a_batch_with_mixed_warm_eligibility), not bit for bit.
-// clr_batch_set_warm_start(plan, 0, 0) on every shard (ShardedBatchedGP.set_warm_start(0)) restores bit-identity.
+// EVERY decision a plan takes from a quantity over "its" problems is taken ONCE for the whole batch, so that a batch
+// gives bit-identical results under any sharding with the default settings (given one chunk count, see below):
+//  * kernel selection: the maxima the single-device plans look at (max |t|, largest time step, largest decay rate and
+//    frequency) are taken over all problems and handed to every shard (clr_batch_set_selection_bounds);
+//  * the prefix plan's time model, the one-launch path of short narrow problems and the deferral of level-1 problems
+//    look at the size of the WHOLE batch (clr_group::set_batch_context);
+//  * the warm-started recurrence (series that forget their past) is switched on when at least half
+//    of the problems OF THE BATCH are eligible, and its warm-up lengths adapt to the fallbacks OF THE BATCH: the shards'
+//    counts are added up here and handed back (reselect_all, resolve_all);
+//  * level-1 problems left pending by an evaluation are re-planned as a side plan whose chunk count follows their number
+//    IN THE BATCH (or replayed inline when the batch holds too many of them): resolve_all adds the pending counts up
+//    between the two halves of every shard's resolve (clr_group_hooks.h).
+// Round 5 left the last two per plan (bit-identity only with the warm start and the side plans switched off).
+// The chunk count: all shards use the first shard's, i.e. the automatic choice looks at a SHARD's batch size -- what
+// fills one GPU -- and may differ from the unsharded plan's; clr_sharded_set_chunks pins it (a pinned count also pins the
+// warm path's chunking), and with equal chunk counts the bits are equal.
 //
 // Each shard has its own host worker thread (which owns the shard's HIP device binding,
 // stream and pinned staging through its clr_batch handle); an API call posts one job to every
@@ -29,6 +34,7 @@
 #include <vector>
 
 #include "../../include/celerite_hip.h"
+#include "clr_group_hooks.h"
 
 namespace {
 
@@ -114,6 +120,44 @@ struct clr_sharded {
   }
 };
 
+namespace {
+
+// the warm path's activation: eligible problems of the whole batch -> every shard (host fields only; the workers idle)
+void reselect_all(clr_sharded* h) {
+  if (h->plan.size() < 2) return;
+  long total = 0;
+  for (clr_batch* p : h->plan) total += clr_group::warm_eligible(p);
+  for (clr_batch* p : h->plan) clr_group::set_warm_eligible_total(p, total);
+}
+
+// the two halves of the shards' resolve around the batch-wide sums (pending problems, warm-eligible problems)
+int resolve_finish_all(clr_sharded* h, const std::vector<long>& pend, const std::vector<long>& elig,
+                       const std::function<int(int)>& then) {
+  long P = 0, E = 0;
+  for (long v : pend) P += v;
+  for (long v : elig) E += v;
+  return h->all([=](int s) {
+    const int st = clr_group::resolve_finish(h->plan[s], P, E);
+    return (st == CLR_OK && then) ? then(s) : st;
+  });
+}
+
+int resolve_all(clr_sharded* h) {
+  if (h->plan.size() < 2) return CLR_OK;  // (a single shard is the whole batch: its plan resolves by itself)
+  bool any = false;
+  for (clr_batch* p : h->plan) any = any || clr_group::in_flight(p);
+  if (!any) return CLR_OK;
+  const size_t S = h->plan.size();
+  std::vector<long> pend(S, 0), elig(S, 0);
+  long* pp = pend.data();
+  long* ee = elig.data();
+  const int st = h->all([=](int s) { return clr_group::resolve_begin(h->plan[s], pp + s, ee + s); });
+  if (st != CLR_OK) return st;
+  return resolve_finish_all(h, pend, elig, nullptr);
+}
+
+}  // namespace
+
 extern "C" {
 
 int clr_shard_bounds(int total, int nshards, int shard, int* lo, int* hi) {
@@ -182,6 +226,7 @@ clr_sharded* clr_sharded_create(int B, int N, int J_real, int J_comp, const int*
     g_sharded_error = keep;
     return nullptr;
   }
+  for (clr_batch* p : h->plan) clr_group::set_batch_context(p, nshards > 1 ? B : 0);
   // one chunk count for all shards (the automatic choice looks at the shard's own batch size, which differs by
   // one between shards when B is not a multiple of the shard count)
   int nchunk = 0;
@@ -201,15 +246,43 @@ int clr_sharded_get_shard(const clr_sharded* h, int shard, int* device, int* lo,
 }
 
 int clr_sharded_set_chunks(clr_sharded* h, int nchunk) {
-  return h->all([=](int s) { return clr_batch_set_chunks(h->plan[s], nchunk); });
+  int st = resolve_all(h);
+  if (st != CLR_OK) return st;
+  if (nchunk <= 0 && h->plan.size() > 1) {  // automatic: the first shard's choice for all
+    clr_batch* p0 = h->plan[0];
+    h->worker[0]->post([p0] { return clr_batch_set_chunks(p0, 0); });  // (on the shard's own thread: its device binding)
+    if ((st = h->worker[0]->wait()) != CLR_OK) return st;
+    clr_batch_get_chunks(p0, &nchunk, nullptr);
+  }
+  st = h->all([=](int s) { return clr_batch_set_chunks(h->plan[s], nchunk); });
+  reselect_all(h);
+  return st;
 }
 
 int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup) {
-  return h->all([=](int s) { return clr_batch_set_warm_start(h->plan[s], mode, forced_warmup); });
+  int st = resolve_all(h);
+  if (st != CLR_OK) return st;
+  st = h->all([=](int s) { return clr_batch_set_warm_start(h->plan[s], mode, forced_warmup); });
+  reselect_all(h);
+  return st;
 }
 
 int clr_sharded_set_rescue(clr_sharded* h, int mode) {
+  const int st = resolve_all(h);
+  if (st != CLR_OK) return st;
   return h->all([=](int s) { return clr_batch_set_rescue(h->plan[s], mode); });
+}
+
+int clr_sharded_set_certificate(clr_sharded* h, double max_gamma_over_mu, double max_residual, double max_gamma,
+                                double max_gamma_times_error) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  return h->all([=](int s) {
+    int st = clr_batch_set_certificate(h->plan[s], max_gamma_over_mu, max_residual);
+    if (st == CLR_OK && !(max_gamma < 0.0) && !(max_gamma_times_error < 0.0))
+      st = clr_batch_set_certificate_gamma(h->plan[s], max_gamma, max_gamma_times_error);
+    return st;
+  });
 }
 
 int clr_sharded_get_rescue(const clr_sharded* h, int* last_count) {
@@ -226,6 +299,8 @@ int clr_sharded_get_rescue(const clr_sharded* h, int* last_count) {
 }
 
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) { return clr_batch_set_summarize_mode(h->plan[s], mode); });
 }
 
@@ -236,7 +311,9 @@ int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* ch
 
 int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const double* diag,
                            long diag_stride, const double* y, long y_stride) {
-  int st = h->all([=](int s) {
+  int st = resolve_all(h);  // (an evaluation in flight is settled on ITS series, by the counts of the whole batch)
+  if (st != CLR_OK) return st;
+  st = h->all([=](int s) {
     const long lo = h->lo[s];
     return clr_batch_set_series(h->plan[s], t + lo * t_stride, t_stride, diag + lo * diag_stride,
                                 diag_stride, y + lo * y_stride, y_stride);
@@ -251,6 +328,7 @@ int clr_sharded_set_series(clr_sharded* h, const double* t, long t_stride, const
     if (!(b <= dxmax)) dxmax = b;
   }
   for (clr_batch* p : h->plan) clr_batch_set_selection_bounds(p, tmax, dxmax, -1.0, -1.0);
+  reselect_all(h);
   return CLR_OK;
 }
 
@@ -271,6 +349,8 @@ int clr_sharded_get_series_order(const clr_sharded* h, double* dtmin) {
 }
 
 int clr_sharded_clear_series(clr_sharded* h) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) { return clr_batch_clear_series(h->plan[s]); });
 }
 
@@ -307,13 +387,17 @@ int clr_sharded_set_coefficients(clr_sharded* h, const double* jitter, const dou
                                  const double* c_real, const double* a_comp, const double* b_comp,
                                  const double* c_comp, const double* d_comp) {
   const long JR = h->J_real, JC = h->J_comp;
+  int st = resolve_all(h);  // (pending problems of an evaluation in flight: at ITS coefficients and selection bounds)
+  if (st != CLR_OK) return st;
   global_coefficient_bounds(h, c_real, c_comp, d_comp);
-  return h->all([=](int s) {
+  st = h->all([=](int s) {
     const long lo = h->lo[s];
     return clr_batch_set_coefficients(h->plan[s], jitter ? jitter + lo : nullptr, a_real + lo * JR, c_real + lo * JR,
                                       a_comp + lo * JC, b_comp + lo * JC, c_comp + lo * JC,
                                       d_comp + lo * JC);
   });
+  reselect_all(h);
+  return st;
 }
 
 int clr_sharded_enqueue(clr_sharded* h) {
@@ -321,10 +405,14 @@ int clr_sharded_enqueue(clr_sharded* h) {
 }
 
 int clr_sharded_synchronize(clr_sharded* h) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) { return clr_batch_synchronize(h->plan[s]); });
 }
 
 int clr_sharded_get_results(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) {
     const long lo = h->lo[s];
     return clr_batch_get_results(h->plan[s], loglike ? loglike + lo : nullptr, logdet ? logdet + lo : nullptr,
@@ -335,6 +423,8 @@ int clr_sharded_get_results(clr_sharded* h, double* loglike, double* logdet, dou
 // value + gradient of every problem at the coefficients in force: clr_batch_grad on every shard concurrently
 int clr_sharded_grad(clr_sharded* h, double* value, double* grad, int* status) {
   const long NG = 1 + 2 * (long)h->J_real + 4 * (long)h->J_comp;
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) {
     const long lo = h->lo[s];
     return clr_batch_grad(h->plan[s], value ? value + lo : nullptr, grad ? grad + lo * NG : nullptr,
@@ -345,22 +435,41 @@ int clr_sharded_grad(clr_sharded* h, double* value, double* grad, int* status) {
 int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_real, const double* c_real,
                          const double* a_comp, const double* b_comp, const double* c_comp,
                          const double* d_comp, double* loglike, double* logdet, double* quad, int* status) {
-  const long JR = h->J_real, JC = h->J_comp;
-  global_coefficient_bounds(h, c_real, c_comp, d_comp);
-  return h->all([=](int s) {
+  if (h->plan.size() < 2) {  // one shard: the plan is the whole batch, one job
+    global_coefficient_bounds(h, c_real, c_comp, d_comp);
+    return h->all([=](int s) {
+      clr_batch* p = h->plan[s];
+      int st = clr_batch_set_coefficients(p, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+      if (st == CLR_OK) st = clr_batch_enqueue(p, 0);
+      if (st == CLR_OK) st = clr_batch_get_results(p, loglike, logdet, quad, status);
+      return st;
+    });
+  }
+  // several shards, three rounds of jobs with the batch-wide sums between them: coefficients in (then the warm path's
+  // activation over the whole batch); launches + the first half of the resolve (then the pending / eligible counts of
+  // the whole batch); the second half + the results
+  int st = clr_sharded_set_coefficients(h, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+  if (st != CLR_OK) return st;
+  const size_t S = h->plan.size();
+  std::vector<long> pend(S, 0), elig(S, 0);
+  long* pp = pend.data();
+  long* ee = elig.data();
+  st = h->all([=](int s) {
+    const int e = clr_batch_enqueue(h->plan[s], 0);
+    return e != CLR_OK ? e : clr_group::resolve_begin(h->plan[s], pp + s, ee + s);
+  });
+  if (st != CLR_OK) return st;
+  return resolve_finish_all(h, pend, elig, [=](int s) {
     const long lo = h->lo[s];
-    clr_batch* p = h->plan[s];
-    int st = clr_batch_set_coefficients(p, jitter ? jitter + lo : nullptr, a_real + lo * JR, c_real + lo * JR, a_comp + lo * JC,
-                                        b_comp + lo * JC, c_comp + lo * JC, d_comp + lo * JC);
-    if (st == CLR_OK) st = clr_batch_enqueue(p, 0);
-    if (st == CLR_OK)
-      st = clr_batch_get_results(p, loglike ? loglike + lo : nullptr, logdet ? logdet + lo : nullptr,
+    return clr_batch_get_results(h->plan[s], loglike ? loglike + lo : nullptr, logdet ? logdet + lo : nullptr,
                                  quad ? quad + lo : nullptr, status ? status + lo : nullptr);
-    return st;
   });
 }
 
 int clr_sharded_run_timed(clr_sharded* h, int steps, double* shard_ms /* [nshards] or NULL */) {
+  // (a timing tool: every shard times its own steps and settles them by its own counts)
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
   return h->all([=](int s) {
     double total = 0.0, k[6];
     const int st = clr_batch_run_timed(h->plan[s], 0, steps, 0, &total, k);

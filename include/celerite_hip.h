@@ -546,9 +546,13 @@ int clr_batch_get_grad_info(const clr_batch* h, int* reverse_used, int* forward_
  * contiguous slice clr_shard_bounds(B, S, s) and is an ordinary clr_batch plan on
  * devices[s], driven by its own host thread (stream + pinned staging per shard).  No
  * collective, no device-to-device traffic; results are concatenated on the host.
- * A device may be listed more than once (the shards then share it): results do not depend
- * on the sharding, bit for bit, as long as every shard uses the same chunk count
- * (clr_sharded_set_chunks; the automatic choice depends on the shard's batch size). */
+ * A device may be listed more than once (the shards then share it).
+ * Results do not depend on the sharding, BIT FOR BIT, with the default settings, as long as every
+ * sharding uses the same chunk count (clr_sharded_set_chunks; the automatic choice looks at a shard's
+ * batch size -- what fills one GPU): every decision a plan takes from a count over its problems --
+ * kernel selection, the prefix plan, the warm-started recurrence's activation and adaptation, side
+ * plan or inline replay of level-1 problems and the side plan's chunk count -- is taken once, from
+ * the counts over the WHOLE batch (csrc/sharded.cpp, csrc/clr_group_hooks.h). */
 typedef struct clr_sharded clr_sharded;
 
 /* [lo, hi) of `shard` when `total` problems are cut into `nshards` contiguous slices
@@ -568,17 +572,21 @@ int clr_sharded_get_chunks(const clr_sharded* h, int shard, int* nchunk, int* ch
 /* (the automatic choice of the summarize kernel is resolved once for the whole batch: the shards are handed the
  * batch-wide maxima of the series and coefficients, so the choice does not depend on the sharding) */
 int clr_sharded_set_summarize_mode(clr_sharded* h, int mode);
-/* clr_batch_set_warm_start on every shard.  The warm-started recurrence adapts PER PLAN (activation when half of the
- * plan's problems are eligible, chunking by the plan's batch size, warm-up lengths by its history of fallbacks), so
- * with it a batch may take different -- equally certified -- routes under different shardings: results then agree to
- * the scan's rounding (<= 1e-11), not bit for bit; mode 0 switches it off and restores bit-identity. */
+/* clr_batch_set_warm_start on every shard.  The warm-started recurrence is switched on when at least half of the
+ * problems OF THE BATCH are eligible and lengthens its warm-ups by the fallbacks OF THE BATCH (the shards' counts are
+ * added up between the two halves of every evaluation's resolve): the same route under any sharding.  Its chunking
+ * follows the chunk count when that is pinned, else the shard's batch size. */
 int clr_sharded_set_warm_start(clr_sharded* h, int mode, int forced_warmup);
-/* clr_batch_set_rescue on every shard.  A route-1 problem's side plan is sized by how many such problems ITS shard holds,
- * so their results agree across shardings to the scan's rounding (statuses identical), not bit for bit; mode 0 (the
- * inline replay) restores bit-identity.  clr_sharded_get_rescue: problems of the last fetched evaluation that took the
- * checked route outside the main pass, summed over the shards. */
+/* clr_batch_set_rescue on every shard.  Side plan or inline replay, and the side plan's chunk count, follow the number
+ * of route-1 problems of the WHOLE batch: bit-identical under any sharding (round 5: per shard).
+ * clr_sharded_get_rescue: problems of the last fetched evaluation that took the checked route outside the main pass,
+ * summed over the shards. */
 int clr_sharded_set_rescue(clr_sharded* h, int mode);
 int clr_sharded_get_rescue(const clr_sharded* h, int* last_count);
+/* clr_batch_set_certificate + clr_batch_set_certificate_gamma on every shard (the routing bounds of ill-conditioned
+ * problems; a negative max_gamma / max_gamma_times_error leaves the gamma bounds as they are). */
+int clr_sharded_set_certificate(clr_sharded* h, double max_gamma_over_mu, double max_residual, double max_gamma,
+                                double max_gamma_times_error);
 /* The summarize kernel all shards will run (clr_batch_get_summarize_kernel; -1 if they disagree). */
 int clr_sharded_get_summarize_kernel(const clr_sharded* h, int* kind);
 /* clr_batch_get_series_order / clr_batch_clear_series over all shards (the smallest step of the whole batch) */

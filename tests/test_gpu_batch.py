@@ -154,6 +154,42 @@ def test_lean_factor_layout_expands_to_the_reference_arrays(JR, JC):
             plan.close()
 
 
+@pytest.mark.parametrize("layout", ["reference", "lean"])
+def test_materialise_pipeline_over_groups_writes_every_groups_factor(layout):
+    """``clr_batch_set_materialize_pipeline`` (groups of problems, summarize and replay overlapped on their own streams)
+    under BOTH factor layouts: results, every problem's factor arrays and the batched solve must equal the plain
+    sequence's bit for bit.  (with the lean layout phi / u are never reserved and the group views did not
+    advance W / D -- every group wrote into group 0's region.)"""
+    B, N, JR, JC = 13, 4000, 2, 3                 # (ragged groups: 13 problems over 4 groups)
+    case = synthetic(B, N, JR, JC, "bench", seed=77)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_chunks(32)
+        plan.set_factor_layout(layout)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        want = plan.log_likelihood(materialize=True)
+        want_f = [plan.factor(p) for p in range(B)]
+        want_x = plan.solve()
+        plan.set_materialize_pipeline(4, 0, 1)
+        got = plan.log_likelihood(materialize=True)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        for p in range(B):
+            for name, a, b in zip(("phi", "u", "W", "D"), plan.factor(p), want_f[p]):
+                assert np.array_equal(a, b), (layout, p, name)
+        assert np.array_equal(plan.solve(), want_x)
+        plan.set_materialize_pipeline(0, 0, 1)
+        # ... and against the oracle's state on a problem of the LAST group
+        p = B - 1
+        r = ref.RefSolver()
+        r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)), case["t"][p], case["diag"][p])
+        _, _, _, logdet, rphi, ru, rW, rD = r.state()
+        assert np.allclose(want_f[p][2], rW, rtol=1e-9, atol=1e-12) and np.allclose(want_f[p][3], rD, rtol=1e-11, atol=0)
+    finally:
+        plan.close()
+
+
 def test_lean_factor_layout_on_flagged_and_ill_conditioned_problems():
     """The lean layout through every route of a materialising run: problems the chunked replay cannot certify have
     their factor columns rewritten by the sequential recurrence (``sequential_kernel<..., 3>``), indefinite problems
@@ -653,6 +689,51 @@ def test_wide_plan_gradient_parallel_in_n(JR, JC, JG):
         plan.close()
 
 
+def test_wide_plan_gradient_with_a_level1_problem_in_a_chunked_plan():
+    """a chunked width-32 plan with chunks of >= 1024 samples defers its level-1 problems to a side plan
+    (clr_batch_set_rescue) -- but the evaluation INSIDE clr_batch_grad must hand out final values: the walk over the
+    chunks reads ll / status straight from the device.  With one problem of the batch on route 1 the gradient used to come
+    back as value -inf, gradient 0, status -1 (pending) for it.  Now: its value and partials equal the sequential tangent
+    kernel's, statuses are OK, and nothing is left in flight (a plain evaluation afterwards still defers and resolves)."""
+    import celerite_amd
+    B, N, JR, JC = 4, 20000, 0, 16
+    case = synthetic(B, N, JR, JC, "bench", seed=99)
+    jit = np.array([0.0, 0.02, 0.1, 0.05])
+    empty, empty2 = np.empty(0), np.empty((0, 0))
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    try:
+        want = [celerite_amd.CholeskySolver().grad_log_likelihood(jit[b], *[c[b] for c in coeffs_of(case)], empty, empty2, empty2,
+                                                                  case["t"][b], case["y"][b], case["diag"][b]) for b in range(B)]
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_chunks(8)                                  # chunks of 2500 samples: the automatic rescue mode defers
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_certificate(max_gamma=1e9)
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        plan.log_likelihood()
+        gamma, _ = plan.conditioning()
+        order = np.argsort(gamma)[::-1]
+        plan.set_certificate(max_gamma=0.5 * (gamma[order[0]] + gamma[order[1]]))
+        plan.set_coefficients(*coeffs_of(case), jitter=jit)
+        ll, ld, q, st0 = plan.log_likelihood()
+        levels = plan.exact_levels()
+        assert levels[order[0]] == 1 and (np.delete(levels, order[0]) == 0).all() and plan.rescue()["last"] == 1
+        v, g, st = plan.grad_log_likelihood()
+        assert (st == 0).all(), st
+        for b in range(B):
+            v0, g0 = want[b]
+            within("wide plan gradient with a level-1 problem: value vs sequential kernel", abs(v[b] - v0) / abs(v0), 1e-11, b)
+            within("wide plan gradient with a level-1 problem: partials vs sequential kernel (of the largest)",
+                   np.max(np.abs(g[b] - g0)) / np.max(np.abs(g0)), 1e-9, b)
+            assert abs(v[b] - ll[b]) <= 1e-11 * abs(ll[b])
+        ll2, ld2, q2, st2 = plan.log_likelihood()            # (the plain evaluation afterwards: deferred and resolved as before)
+        assert np.array_equal(ll2, ll) and np.array_equal(st2, st0) and plan.rescue()["last"] == 1
+    finally:
+        plan.close()
+
+
 def test_batched_gradient_reaches_the_kernel_parameters():
     """The optimiser loop without autograd (celerite.py:221-305 for B draws at once): coefficient tables and
     their Jacobians from a `terms` kernel (batch.kernel_coefficient_table / kernel_coefficient_jacobian_table), the
@@ -774,6 +855,9 @@ def test_widths_65_to_128_in_a_plan():
                 plan.log_likelihood(materialize=True)
             ms, _ = plan.run_timed(2)
             assert ms > 0.0
+            # the plan gradient stops at the padded width 64 (the tangent kernels' rows): refused, not silently truncated
+            with pytest.raises(RuntimeError):
+                plan.grad_log_likelihood()
         finally:
             plan.close()
 
@@ -1551,42 +1635,111 @@ def test_an_unsorted_series_is_rejected_whatever_else_the_batch_holds():
 
 
 def test_sharding_a_batch_with_mixed_warm_eligibility():
-    """The warm-started recurrence adapts per plan (activation when half of the plan's problems are eligible), so a
-    batch in which half of the series forget their past may take it in one sharding and the scan in another: statuses
-    must be identical and values equal to the scan's rounding; with the warm start switched off on every shard the
-    results are bit-identical again (csrc/sharded.cpp header)."""
+    """A batch in which about half of the series forget their past: whether the warm-started recurrence runs (half of
+    the problems eligible) and how long its warm-ups are (the history of fallbacks) used to be decided PER PLAN, so such
+    a batch could take the warm recurrence in one sharding and the scan in another (round 5: equal to 1e-11 only).  The
+    sharded layer now adds the shards' counts up and decides once for the whole batch (csrc/sharded.cpp,
+    clr_group_hooks.h): with the DEFAULT settings the results are bit-identical for 1 / 2 / 3 / 4 / 8 shards -- over
+    several evaluations, so that the adaptation of the warm-up lengths is covered too -- and equal to the unsharded
+    plan's; with the warm start switched off as well."""
     B, N, JR, JC = 12, 6000, 2, 3
     a, b = synthetic(B, N, JR, JC, "accuracy", seed=21), synthetic(B, N, JR, JC, "bench", seed=22)
-    case = dict(a)
-    for k in ("t", "diag", "y"):
-        case[k] = np.where((np.arange(B) % 3 == 0)[:, None], b[k], a[k])      # every third series is dense
-    case["a_real"][5] *= -30.0
-    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    l0 = {}
     ndev = batch.device_count()
-    outs = {}
-    for warm in (-1, 0):
-        for S in (1, 2, 3, 4):
-            sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+    for dense_every in (3, 2):                      # a third / half of the series are dense (never warm-eligible)
+        case = dict(a)
+        for k in ("t", "diag", "y"):
+            case[k] = np.where((np.arange(B) % dense_every == 0)[:, None], b[k], a[k])
+        case["a_real"][5] *= -30.0
+        draws = [coeffs_of(case)] + [tuple(c * f for c in coeffs_of(case)) for f in (1.05, 0.95)]
+        want = [ref.batch_log_likelihood(0.0, *d, case["t"], case["diag"], case["y"]) for d in draws]
+        outs = {}
+        for warm in (-1, 0):
+            plan = batch.BatchedGP(B, N, JR, JC)
             try:
-                sp.set_chunks(16)
-                sp.set_warm_start(warm)
-                sp.set_series(case["t"], case["diag"], case["y"])
-                outs[warm, S] = sp.evaluate(*coeffs_of(case))
+                plan.set_chunks(16)
+                plan.set_warm_start(warm)
+                plan.set_series(case["t"], case["diag"], case["y"])
+                outs[warm, 0] = []
+                for d in draws:
+                    plan.set_coefficients(*d)
+                    outs[warm, 0].append(plan.log_likelihood())
+                if warm == -1 and dense_every == 3:
+                    assert plan.warm_start()["active"]          # (the case does exercise the warm path)
             finally:
-                sp.close()
-            ll, ld, q, st = outs[warm, S]
-            ok = s0 == 0
-            assert np.array_equal(st, s0), (warm, S)
-            within("mixed warm eligibility, %s: vs oracle" % ("warm auto" if warm else "warm off"),
-                   max(np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok]))), REL)
-            ref_out = outs[warm, 1]
-            if warm == 0:
-                for x, y_ in zip(outs[warm, S], ref_out):
-                    assert np.array_equal(x, y_, equal_nan=True), S
-            else:
-                within("mixed warm eligibility, warm auto: sharded vs unsharded",
-                       max(np.max(np.abs(ld[ok] - ref_out[1][ok]) / np.abs(ref_out[1][ok])),
-                           np.max(np.abs(q[ok] - ref_out[2][ok]) / np.abs(ref_out[2][ok]))), 1e-11)
+                plan.close()
+            for S in (1, 2, 3, 4, 8):
+                sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+                try:
+                    sp.set_chunks(16)
+                    sp.set_warm_start(warm)
+                    sp.set_series(case["t"], case["diag"], case["y"])
+                    outs[warm, S] = [sp.evaluate(*d) for d in draws]
+                    # the other call sequence: coefficients, enqueue, results
+                    sp.set_coefficients(*draws[0]); sp.enqueue()
+                    again = sp.results()
+                finally:
+                    sp.close()
+                for i, (got, w) in enumerate(zip(outs[warm, S], want)):
+                    ll, ld, q, st = got
+                    ok = w[3] == 0
+                    assert np.array_equal(st, w[3]), (warm, S, i)
+                    within("mixed warm eligibility, %s: vs oracle" % ("warm auto" if warm else "warm off"),
+                           max(np.max(np.abs(ld[ok] - w[1][ok]) / np.abs(w[1][ok])), np.max(np.abs(q[ok] - w[2][ok]) / np.abs(w[2][ok]))), REL)
+                    for x, y_ in zip(got, outs[warm, 0][i]):
+                        assert np.array_equal(x, y_, equal_nan=True), (dense_every, warm, S, i)
+                # (the re-evaluation of draw 0 comes after two other draws: the warm-up lengths may have adapted, in every
+                #  sharding alike -- compare the shardings with one another)
+                outs[warm, S].append(again)
+                for x, y_ in zip(again, outs[warm, 1][3]):
+                    assert np.array_equal(x, y_, equal_nan=True), (dense_every, warm, S, "again")
+
+
+def test_sharding_a_batch_with_route1_problems_is_bit_identical():
+    """Level-1 problems (ill-conditioned, not flagged) are left pending and re-planned as a side plan whose chunk count
+    follows their NUMBER -- round 5 counted them per shard, so their results depended on the sharding to ~1e-11.  The
+    pending counts are now added up over the shards (side plan or inline replay, and the side plan's chunk count, from
+    the batch's total): the default settings give the same bits for 1 / 2 / 3 / 8 shards and the unsharded plan, with
+    2 and 5 such problems (side plans) and with 7 of 24 (more than a quarter of the batch: the inline replay
+    everywhere, although no single shard holds more than a quarter of ITS problems... or all of them do)."""
+    B, N, JR, JC = 24, 40000, 2, 3
+    case = synthetic(B, N, JR, JC, "bench", seed=515)
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"], nthreads=os.cpu_count() or 1)
+    ndev = batch.device_count()
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_chunks(32)                              # chunks of 1250 samples: the automatic mode defers
+        plan.set_series(case["t"], case["diag"], case["y"])
+        for k, expect in ((2, 2), (5, 5), (7, -7)):
+            plan.set_certificate()
+            plan.set_certificate(max_gamma=1e4)
+            plan.set_coefficients(*coeffs_of(case)); plan.log_likelihood()
+            gamma, _ = plan.conditioning()
+            order = np.argsort(gamma)[::-1]
+            bound = 0.5 * (gamma[order[k - 1]] + gamma[order[k]])
+            picked = np.sort(order[:k])
+            plan.set_certificate(max_gamma=bound)
+            plan.set_coefficients(*coeffs_of(case))
+            want = plan.log_likelihood()
+            assert plan.rescue()["last"] == expect and np.array_equal(np.flatnonzero(plan.exact_levels()), picked)
+            assert np.array_equal(want[3], s0)
+            for S in (1, 2, 3, 8):
+                sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+                try:
+                    sp.set_chunks(32)
+                    sp.set_certificate(max_gamma=bound)
+                    sp.set_series(case["t"], case["diag"], case["y"])
+                    got = sp.evaluate(*coeffs_of(case))
+                    assert sp.rescued() == k, (k, S, sp.rescued())
+                    sp.set_coefficients(*coeffs_of(case)); sp.enqueue()
+                    got2 = sp.results()
+                finally:
+                    sp.close()
+                for x, y_, z in zip(want, got, got2):
+                    assert np.array_equal(x, y_, equal_nan=True) and np.array_equal(x, z, equal_nan=True), (k, S)
+            within("sharded route-1 problems: vs oracle", max(np.max(np.abs(want[1] - d0) / np.abs(d0)), np.max(np.abs(want[2] - q0) / np.abs(q0))), REL, k)
+    finally:
+        plan.close()
 
 
 def test_state_changes_settle_a_warm_evaluation_in_flight_first():
