@@ -151,7 +151,11 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (h->launch) {
     if ((st = h->elems.reserve(pc * h->launch->elem_doubles)) != CLR_OK) return st;
     if ((st = h->starts.reserve(pc * h->launch->start_doubles)) != CLR_OK) return st;
-    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, sel_B(h), h->J);
+    // The prefix plan fixes the ORDER in which chunk elements are composed, i.e. the bits of every result: it must not
+    // depend on how many problems happen to share the plan (a slice of a sharded batch, a side plan of pending problems
+    // and the unsharded plan must agree bit for bit).  Its time model is asked for the batch size the automatic chunking
+    // pairs with this chunk count -- about 65536 (problem, chunk) lanes, one round of the chip -- instead of the plan's own.
+    h->plan = clr::plan_prefix(h->nchunk, h->plan_levels, h->plan_g, std::max(1, 65536 / std::max(1, h->nchunk)), h->J);
     size_t le = 0, ls = 0;
     clr::multilevel_workspace(h->plan, h->J, &le, &ls);
     if (le && (st = h->lvl_elems.reserve((size_t)h->B * le)) != CLR_OK) return st;
@@ -1377,7 +1381,6 @@ static int rescue_run(clr_batch* h, const std::vector<int>& idx, long n_total) {
     r->force_exact = 1;
     r->warm_mode = 0;
     r->small_mode = 0;
-    r->group_B = (int)n_total;  // (its prefix plan's time model: the side plan of the whole batch)
     int nchunk = 0;
     const int nt = (int)n_total;
     if (!h->launch) {  // wide: B x nchunk <= the parallel prefix's cap (1024 workgroups per level at width 32, 2048 below)

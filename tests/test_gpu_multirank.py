@@ -55,8 +55,9 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert out["unit"] == "log-likelihoods/s" and out["dtype"] == "f64"
     assert out["config"]["batch_per_gpu"] == 64 and "x2" in out["config"]["parallelism"]
     # whole-job aggregate: the problems of BOTH ranks over the max-over-ranks time of the K steps
-    assert abs(out["value"] - 2 * 64 * 3 / out["timed_region_s"]) <= 1e-9 * out["value"]
-    assert abs(out["ms_per_step"] - out["timed_region_s"] / 3 * 1e3) <= 1e-9 * out["ms_per_step"]
+    # (the headline line carries six significant digits)
+    assert abs(out["value"] - 2 * 64 * 3 / out["timed_region_s"]) <= 1e-4 * out["value"]
+    assert abs(out["ms_per_step"] - out["timed_region_s"] / 3 * 1e3) <= 1e-4 * out["ms_per_step"]
     assert out["status_not_ok"] == 0
     par = out["multi_rank_parity"]
     assert par["status_equal"] and par["logdet_rel_max"] <= REL and par["quad_rel_max"] <= REL, par
