@@ -45,7 +45,7 @@ $(LIB): $(HIP_OBJS) $(BUILD)/host_helpers.o $(BUILD)/sharded.o
 $(PYMOD): $(CSRC)/solver_pybind.cpp include/celerite_hip.h $(LIB)
 	$(CXX) $(CXXFLAGS) $(PY_INC) -shared $< -o $@ -Lcelerite_amd -lcelerite_hip -Wl,-rpath,'$$ORIGIN'
 
-$(ORACLE): oracle/celerite_ref.c oracle/celerite_ref_loops.inc oracle/celerite_ref.h
+$(ORACLE): oracle/celerite_ref.c oracle/celerite_ref_quad.c oracle/celerite_ref_loops.inc oracle/celerite_ref.h
 	$(MAKE) -C oracle
 
 clean:

@@ -476,6 +476,13 @@ class BatchedGP(object):
         lib.clr_batch_set_factor_layout.argtypes = [C.c_void_p, C.c_int]
         _check(lib.clr_batch_set_factor_layout(self._h, self.FACTOR_LAYOUTS.get(layout, layout)))
 
+    def set_factor_refine(self, samples=64):
+        """Samples at the head of every chunk a materialising run recomputes from the previous chunk's replayed end
+        state (``clr_batch_set_factor_refine``; 0 switches the refinement off)."""
+        lib = _load()
+        lib.clr_batch_set_factor_refine.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.clr_batch_set_factor_refine(self._h, int(samples)))
+
     def factor_bytes(self):
         """Bytes of factor per problem in HBM under the layout and chunking in force."""
         lib = _load()

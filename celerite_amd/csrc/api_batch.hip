@@ -52,7 +52,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts})
+                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->ends})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1059,6 +1059,7 @@ static clr::BatchParams group_view(const clr_batch* h, const clr::BatchParams& P
   if (G.u) G.u += o * J * cells;
   if (G.W) G.W += o * J * cells;
   if (G.D) G.D += o * cells;
+  if (G.ends) G.ends += o * nc * S;
   G.out_ll += o; G.out_logdet += o; G.out_quad += o; G.out_status += o;
   G.only_pending = 0;
   return G;
@@ -1067,6 +1068,13 @@ static clr::BatchParams group_view(const clr_batch* h, const clr::BatchParams& P
 // replay mode of a materialising run: 2 the four arrays chunk-interleaved, 3 the lean layout (W, D only)
 static int replay_mode(const clr_batch* h, int materialize) {
   return materialize ? (h->factor_layout == 1 ? 3 : 2) : 0;
+}
+
+// the fix-up pass of a materialising run: the first `factor_refine` samples of every chunk from the previous chunk's
+// replayed end state (BatchParams::ends / fixup_steps, replay_kernel)
+static void refine_chunk_heads(const clr_batch* h, clr::BatchParams R, int materialize, hipStream_t s) {
+  R.fixup_steps = h->factor_refine;
+  h->launch->replay(R, replay_mode(h, materialize), s);
 }
 
 static bool mp_runs(const clr_batch* h, int materialize) {
@@ -1095,6 +1103,7 @@ static int materialize_pipeline(clr_batch* h, const clr::BatchParams& P) {
     HIP_TRY(hipEventRecord(h->mp_ev[2 + 2 * g], h->mp_p));
     HIP_TRY(hipStreamWaitEvent(h->mp_r, h->mp_ev[2 + 2 * g], 0));
     h->launch->replay(Rg, replay_mode(h, 1), h->mp_r);
+    if (Rg.ends) refine_chunk_heads(h, Rg, 1, h->mp_r);
     h->launch->sequential(Pg, replay_mode(h, 1), h->mp_r);
   }
   HIP_TRY(hipEventRecord(h->mp_ev[2 * G + 1], h->mp_r));  // (the replay stream's last group closes every chain of events)
@@ -1129,6 +1138,12 @@ int clr_batch_set_factor_layout(clr_batch* h, int layout) {
   if (layout == 1 && !h->launch) return fail(CLR_UNSUPPORTED, "the lean factor layout covers widths 1..8 (wider plans write the reference's storage)");
   if (layout != h->factor_layout) { h->have_factor = false; h->factor_valid = false; }
   h->factor_layout = layout;
+  return CLR_OK;
+}
+
+int clr_batch_set_factor_refine(clr_batch* h, int samples) {
+  if (samples < 0) return fail(CLR_INVALID_ARGUMENT, "factor refine: samples per chunk head >= 0");
+  h->factor_refine = samples;
   return CLR_OK;
 }
 
@@ -1289,6 +1304,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   h->launch->correct(P, h->stream);  // (also on forced-exact runs: flags + conditioning record)
   mark(4);
   h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);  // forced-exact / materialising runs only
+  if (P.ends) refine_chunk_heads(h, replay_view(h, P, materialize), materialize, h->stream);
   h->launch->sequential(P, replay_mode(h, materialize), h->stream);  // flagged / ill-conditioned problems only
   if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
   mark(5);
@@ -1776,6 +1792,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     h->launch->correct(P, h->stream);
     HIP_TRY(hipEventRecord(e[4], h->stream));
     h->launch->replay(replay_view(h, P, materialize), replay_mode(h, materialize), h->stream);
+    if (P.ends) refine_chunk_heads(h, replay_view(h, P, materialize), materialize, h->stream);
     h->launch->sequential(P, replay_mode(h, materialize), h->stream);
     if (materialize) { h->factor_is_lean = h->factor_layout == 1; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
     HIP_TRY(hipEventRecord(e[5], h->stream));

@@ -295,6 +295,9 @@ struct clr_batch {
   bool factor_is_lean = false;  // what the factor in HBM holds (set by the materialising run that wrote it)
   bool factor_inputs_changed = false;  // series or coefficients replaced since that run (a lean factor can then no longer be expanded)
   DevBuf phi, u, W, D;        // materialised factor, chunk-interleaved device layout
+  // heads of the chunks recomputed from the previous chunk's replayed end state (clr_batch_set_factor_refine; BatchParams::ends)
+  int factor_refine = 64;     // samples per chunk head (0: off -- round 5's factor)
+  DevBuf ends;                // [B][nchunk][START] states at the chunks' ends, written by the materialising replay
   DevBuf fphi, fu, fW, fD;    // one problem in the reference's storage (get_factor)
   // materialising runs as a pipeline over groups of problems (clr_batch_set_materialize_pipeline): the summarize of
   // group g + 1 (fp64-VALU-bound) runs beside the replay of group g (HBM-bound) on streams that own disjoint sets of CUs
@@ -483,6 +486,12 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.only_pending = h->in_fallback ? 1 : 0;
   P.defer_level1 = defer_runs(h, materialize) ? 1 : 0;
   P.wide_materialize = (materialize && !h->launch) ? 1 : 0;
+  P.ends = nullptr;
+  P.fixup_steps = 0;
+  if (materialize && h->launch && h->nchunk > 1 && h->factor_refine > 0) {
+    if ((st = h->ends.reserve((size_t)h->B * h->nchunk * h->launch->start_doubles)) != CLR_OK) return st;
+    P.ends = h->ends.p;
+  }
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
 }

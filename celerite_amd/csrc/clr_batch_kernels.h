@@ -78,6 +78,15 @@ struct BatchParams {
                          // (cholesky.h:76-78, :703-706; CholeskySolver.compute at widths 9..64)
   int split_lazy;     // role-split summarize with the decay factored out of the state (dense series only)
   int seq_only;       // wide path: this launch only walks the problems with need_exact != 0 (one chunk = all N)
+  // Materialising runs, refinement of the chunk heads (clr_batch_set_factor_refine): the materialising replay writes the
+  // state it reaches at every chunk's END to `ends`; a second, short launch of the same kernel (`fixup_steps` > 0)
+  // recomputes the first fixup_steps samples of every chunk c >= 1 from ends[c - 1] -- the reference recurrence carried
+  // across the boundary -- instead of from the scanned start state, whose rounding (the scan algebra's, amplified by the
+  // cancellation in D = a - u^T S u) otherwise shows in W and D for the ~32 samples the recurrence needs to forget it
+  // (profiles/r06d_factor_error.txt: 4e-11 at a chunk's first sample, 4e-13 from sample 32 on -- the sequential
+  // oracle's own distance from the binary128 truth).
+  double* ends;       // [B][nchunk][START] or null
+  int fixup_steps;    // > 0: this launch is the fix-up pass
   int defer_level1;   // problems the conditioning record sends to the checked chunked replay (level 1) are NOT replayed
                       // inline -- one flagged problem would cost the whole batch a sequential chunk-time -- but left with
                       // a pending status: the host re-plans them as a small plan of their own with many short chunks
@@ -566,7 +575,14 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   double ld, qd;
   int flag;
   const long Nm1 = P.N - 1;
-  const double* start = (mine && c > 0) ? P.starts + ((long)b * P.nchunk + c) * Wd::START : nullptr;
+  const bool fixup = P.fixup_steps > 0;
+  if (fixup && !STAGED && c == 0) return;  // (chunk 0 starts from the exact zero state: nothing to refine)
+  const double* start = (mine && c > 0) ? (fixup ? P.ends + ((long)b * P.nchunk + c - 1) * Wd::START
+                                                 : P.starts + ((long)b * P.nchunk + c) * Wd::START) : nullptr;
+  // (fix-up pass: lanes that only keep a staged wave's tile loads company -- chunk 0, lanes past the last chunk -- see an
+  //  empty series: no sample of theirs is "valid", nothing is stored)
+  const int steps = fixup ? (P.fixup_steps < P.L ? P.fixup_steps : P.L) : P.L;
+  const int N_eff = (fixup && (c == 0 || !mine)) ? 0 : P.N;
   double *phi_o = nullptr, *u_o = nullptr, *W_o = nullptr, *D_o = nullptr;
   long fstride = 0;
   if (MATERIALIZE == 1) {  // reference storage, one problem after the other
@@ -588,14 +604,19 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   double endst[Wd::START];
   if (STAGED) {
     StagedSeries src = make_staged(P, b, c, tiles);
-    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
+    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, steps, N_eff, n0, start, &ld, &qd, &flag, phi_o, u_o,
                                             W_o, D_o, fstride, endst);
   } else {
     DirectSeries src = make_direct(P, b, c);
-    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, P.L, P.N, n0, start, &ld, &qd, &flag, phi_o, u_o,
+    replay_chunk<JR, JC, MATERIALIZE, FAST>(p, src, steps, N_eff, n0, start, &ld, &qd, &flag, phi_o, u_o,
                                             W_o, D_o, fstride, endst);
   }
-  if (!mine) return;
+  if (!mine || fixup) return;  // (the fix-up pass rewrites factor entries only: sums, flags and the record stand)
+  if (P.ends) {
+    double* e = P.ends + ((long)b * P.nchunk + c) * Wd::START;
+#pragma unroll
+    for (int i = 0; i < Wd::START; ++i) e[i] = endst[i];
+  }
   if (P.cond) {
     // the recurrence carried this chunk from the scanned start state of chunk c to sample (c+1) L:
     // how far is that from the scanned start state of chunk c+1?  (Both are the same quantity; the

@@ -415,6 +415,15 @@ int clr_batch_get_rescue(const clr_batch* h, int* last_count, long* total, int* 
  *     expanded as long as the plan still holds the series and coefficients of the materialising run (else
  *     clr_batch_get_factor returns CLR_NOT_COMPUTED). */
 int clr_batch_set_factor_layout(clr_batch* h, int layout);
+/* Accuracy of the materialised factor at the chunk heads (widths 1..8).  The chunked replay starts every chunk from its
+ * SCANNED start state; the scan algebra's rounding in that state -- amplified by the cancellation in
+ * D_n = a - u^T S u (cholesky.h:162-175) -- shows in W and D for the ~32 samples the recurrence needs to forget it:
+ * 4e-11 (of the largest entry) at a chunk's first sample against 4e-13 from sample 32 on, which is the distance of the
+ * reference's own sequential recurrence from a binary128 evaluation (profiles/r06d_factor_error.txt; N = 1e5, width 8).
+ * With `samples` > 0 (default 64) a materialising run recomputes the first `samples` entries of every chunk from the
+ * state the PREVIOUS chunk's replay reached at the boundary -- the reference recurrence carried across it -- in a
+ * second, short launch (samples / chunk_len of a replay: 4 % at the bench shape).  0: round 5's factor. */
+int clr_batch_set_factor_refine(clr_batch* h, int samples);
 /* Bytes of factor one problem occupies in HBM under the layout and chunking in force. */
 int clr_batch_get_factor_bytes(const clr_batch* h, size_t* bytes_per_problem);
 

@@ -33,10 +33,13 @@ def build(force=False):
 def _load():
     build()
     try:
-        return C.CDLL(_LIB_PATH)
+        lib = C.CDLL(_LIB_PATH)
+        if hasattr(lib, "refq_factor_solve"):
+            return lib
     except OSError:
-        build(force=True)
-        return C.CDLL(_LIB_PATH)
+        pass
+    build(force=True)      # (a library from before celerite_ref_quad.c, or built for another machine)
+    return C.CDLL(_LIB_PATH)
 
 
 _lib = _load()
@@ -229,3 +232,35 @@ def batch_log_likelihood(jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,
                                   p(t), ts, p(diag), ds, p(y), ys,
                                   p(ll), p(ld), p(q), st.ctypes.data_as(_ip), int(nthreads))
     return ll, ld, q, st
+
+
+def quad_factor_solve(jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp, t, diag, y, want_factor=True):
+    """ONE problem through the reference's recurrences carried in IEEE binary128 (oracle/celerite_ref_quad.c:
+    cholesky.h:126-179, :236-260, :343-357 in the same operation order, __float128 from the double inputs).  Returns
+    ``(W[J, N], D[N], x[N], logdet, quad)`` rounded to double -- "the truth" deviations are attributed with; ``W`` and
+    ``D`` are ``None`` unless ``want_factor``.  Raises ``RefLinAlgError`` where the reference would (cholesky.h:176)."""
+    ar, pa, JR = _vec(a_real)
+    cr, pc, _ = _vec(c_real)
+    ac, pac, JC = _vec(a_comp)
+    bc, pbc, _ = _vec(b_comp)
+    cc, pcc, _ = _vec(c_comp)
+    dc, pdc, _ = _vec(d_comp)
+    tt, pt, N = _vec(t)
+    dd, pd, _ = _vec(diag)
+    yy, py, _ = _vec(y)
+    J = JR + 2 * JC
+    W = np.empty(J * N) if want_factor else None
+    D = np.empty(N) if want_factor else None
+    x = np.empty(N)
+    ld, q = C.c_double(), C.c_double()
+    _lib.refq_factor_solve.restype = C.c_int
+    _lib.refq_factor_solve.argtypes = [C.c_double, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp,
+                                       _dp, _dp, _dp, _dp, _dp]
+    st = _lib.refq_factor_solve(float(jitter), JR, pa, pc, JC, pac, pbc, pcc, pdc, N, pt, pd, py,
+                                W.ctypes.data_as(_dp) if want_factor else None, D.ctypes.data_as(_dp) if want_factor else None,
+                                x.ctypes.data_as(_dp), C.byref(ld), C.byref(q))
+    if st == REF_LINALG:
+        raise RefLinAlgError("failed to factorize or solve matrix")
+    if st != REF_OK:
+        raise ValueError("dimension mismatch")
+    return (W.reshape(N, J).T.copy() if want_factor else None), D, x, ld.value, q.value

@@ -149,6 +149,47 @@ def test_against_extended_precision():
     assert abs(s.dot_solve(y) - q_mp) < 1e-12 * abs(q_mp)
 
 
+def test_binary128_recurrence_is_pinned():
+    """oracle/celerite_ref_quad.c -- the reference's recurrences carried in binary128, "the truth" the -m gpu tests
+    attribute deviations with -- against (i) the mpmath 40-digit dense LDL^T (log det, quadratic form: it must be at
+    least as close as the double-precision restatement, and within 1e-14), (ii) the double restatement on a long series
+    (W, D, solve: agreement to the latter's rounding, a few 1e-13) and (iii) its failure contract (cholesky.h:176)."""
+    case = synthetic(1, 160, 2, 3, "accuracy", seed=3)
+    co = coeffs_of(case, 0)
+    t, diag, y = case["t"][0], case["diag"][0], case["y"][0]
+    K = dense.dense_matrix(0.0, *co, *NO_GENERAL, t, diag)
+    ld_mp, q_mp = dense.mp_logdet_quad(K, y)
+    W, D, x, ld, q = ref.quad_factor_solve(0.0, *co, t, diag, y)
+    s = ref.RefSolver()
+    s.compute(0.0, *co, *NO_GENERAL, t, diag)
+    assert abs(ld - ld_mp) <= 1e-14 * abs(ld_mp) and abs(q - q_mp) <= 1e-14 * abs(q_mp)
+    assert abs(ld - ld_mp) <= abs(s.log_determinant() - ld_mp) + 1e-15 * abs(ld_mp)
+    assert np.allclose(x, np.linalg.solve(K, y), rtol=0, atol=1e-11 * np.max(np.abs(x)))
+    # (the accuracy family's times reach 1.6e4: the double-precision product d t in the argument of cos / sin is itself
+    #  rounded at 1e-12 absolute, which binary128 does not share -- the looser bar there)
+    for JR, JC, family, tol in ((2, 3, "bench", 2e-12), (0, 2, "accuracy", 1e-10), (3, 0, "bench", 2e-12)):
+        case = synthetic(1, 20000, JR, JC, family, seed=11 + JR)
+        co = coeffs_of(case, 0)
+        t, diag, y = case["t"][0], case["diag"][0], case["y"][0]
+        W, D, x, ld, q = ref.quad_factor_solve(0.05, *co, t, diag, y)
+        s = ref.RefSolver()
+        s.compute(0.05, *co, *NO_GENERAL, t, diag)
+        _, N, J, logdet, _, _, rW, rD = s.state()
+        assert W.shape == rW.shape == (J, N)
+        assert np.max(np.abs(W - rW)) <= tol * np.max(np.abs(rW)) and np.max(np.abs(D - rD) / np.abs(rD)) <= tol
+        assert abs(ld - logdet) <= 1e-12 * abs(logdet) and abs(q - s.dot_solve(y)) <= 1e-12 * abs(q)
+        xs = s.solve(y)[:, 0]
+        assert np.max(np.abs(x - xs)) <= 10 * tol * np.max(np.abs(xs))
+    bad = synthetic(1, 300, 1, 1, "bench", seed=5)
+    co = list(coeffs_of(bad, 0))
+    co[0] = -5.0 * np.abs(co[0])
+    with pytest.raises(ref.RefLinAlgError):
+        ref.quad_factor_solve(0.0, *co, bad["t"][0], np.zeros(300), bad["y"][0])
+    with pytest.raises(ref.RefLinAlgError):
+        s = ref.RefSolver()
+        s.compute(0.0, *co, *NO_GENERAL, bad["t"][0], np.zeros(300))
+
+
 def test_error_codes_and_edge_shapes():
     s = ref.RefSolver()
     e = np.empty(0)
