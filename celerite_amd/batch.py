@@ -115,6 +115,38 @@ def _check(status):
     raise RuntimeError(msg + (": " + detail if detail else ""))
 
 
+def set_option(key, value=None):
+    """A tuning / cross-check switch of the library (``clr_set_option``, include/celerite_hip.h lists the keys);
+    ``value=None`` removes it.  Environment variables of the same names count only under ``CLR_ALLOW_ENV=1``."""
+    lib = _load()
+    lib.clr_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    _check(lib.clr_set_option(key.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(key):
+    lib = _load()
+    lib.clr_get_option.argtypes = [C.c_char_p]
+    lib.clr_get_option.restype = C.c_char_p
+    v = lib.clr_get_option(key.encode())
+    return None if v is None else v.decode()
+
+
+class option(object):
+    """``with batch.option("CLR_GRAD_SEQUENTIAL", 1): ...`` -- the switch is removed (or restored) on exit."""
+
+    def __init__(self, key, value="1"):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = get_option(self.key)
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old)
+        return False
+
+
 def device_count():
     return int(_load().clr_device_count())
 

@@ -1,6 +1,7 @@
 // celerite_amd/csrc/api_batch.hip -- C ABI of the batched plans (clr_batch_*): HBM residency, path selection
 // (scan pipeline, warm-started recurrence, one-launch path, wide kernels, general terms), evaluation and results.
 #include "api_internal.h"
+#include "clr_options.h"
 #include "clr_group_hooks.h"
 
 extern "C" {
@@ -128,8 +129,8 @@ int clr_batch_set_chunks(clr_batch* h, int nchunk) {
   if (nchunk > 1 && h->L > 8) h->L = (h->L + 7) & ~7;  // 64-B aligned chunk rows for the tile loads
   h->nchunk = (h->N + h->L - 1) / h->L;
   h->L0 = 0;
-  if (const char* e = getenv("CLR_WIDE_FIRST_RATIO")) h->wide_first_ratio = atof(e);  // (tuning runs only)
-  if (const char* e = getenv("CLR_WIDE_FIRST_RATIO64")) h->wide_first_ratio64 = atof(e);
+  if (const char* e = clr::option("CLR_WIDE_FIRST_RATIO")) h->wide_first_ratio = atof(e);  // (tuning runs only)
+  if (const char* e = clr::option("CLR_WIDE_FIRST_RATIO64")) h->wide_first_ratio64 = atof(e);
   const double first_ratio = h->J > 32 ? h->wide_first_ratio64 : h->wide_first_ratio;
   if (!h->launch && h->nchunk > 1 && first_ratio > 1.0) {
     // wide scan: the first chunk's summarize carries no riders (wide_scan_body, RIDERS == false) and costs

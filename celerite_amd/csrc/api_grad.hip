@@ -2,6 +2,7 @@
 // their settings): reverse / forward mode on the narrow plans (clr_grad_kernels.h), the chunk-parallel forward mode
 // at widths 9..32 and with general terms (wide_grad_kernels.hip), the sequential tangent kernel as the fallback.
 #include "api_internal.h"
+#include "clr_options.h"
 
 extern "C" {
 
@@ -215,7 +216,7 @@ int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status) {
       // states the rule asks for fewer than g_span steps after a stored one are rebuilt forwards by the sweep
       // (GradStore::span; profiles/r04t_grad_rebuild_span.txt); CLR_GRAD_REBUILD_SPAN: the tools' A/B knob
       P.g_span = h->grad_rebuild_span;
-      if (const char* e = getenv("CLR_GRAD_REBUILD_SPAN")) P.g_span = std::max(1, std::min(atoi(e), 200));
+      if (const char* e = clr::option("CLR_GRAD_REBUILD_SPAN")) P.g_span = std::max(1, std::min(atoi(e), 200));
       if ((st = grad_chunk_spans(h)) != CLR_OK) return st;
       double need = 0.0;
       for (size_t b = 0; b < B; ++b) {
@@ -399,7 +400,7 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
     if (sd != 0 && sd != N) return fail(CLR_INVALID_ARGUMENT, "series stride must be 0 (shared) or N");
   int st = require_device(device);
   if (st != CLR_OK) return st;
-  if (J_real + 2 * J_comp <= 8 && N >= 512 && !getenv("CLR_GRAD_SEQUENTIAL")) {
+  if (J_real + 2 * J_comp <= 8 && N >= 512 && !clr::option("CLR_GRAD_SEQUENTIAL")) {
     // widths 1..8: parallel in n through a plan (clr_batch_grad); short series and the other widths below
     clr_batch* h = clr_batch_create(B, N, J_real, J_comp, device);
     if (h) {

@@ -19,12 +19,14 @@
 #include <vector>
 
 #include "../../include/celerite_hip.h"
+#include "../../include/celerite_hip_debug.h"
 #include "clr_batch_kernels.h"
 #include "clr_carma.h"
 #include "clr_generic_kernels.h"
 #include "clr_series_io.h"
 #include "clr_small.h"
 #include "clr_wide.h"
+#include "clr_options.h"
 
 // the last error message of the calling thread (clr_last_error) and its current device: ONE object per thread for the
 // whole library (defined in api_misc.hip)
@@ -358,8 +360,8 @@ bool lazy_eligible(const clr_batch* h) {
 // from the exponent range: Psi^-2 < e^(2 x 64 x 2) = e^256.  (The one-wave kernels of CLR_WIDE64_ONE_WAVE keep the strict rule.)
 bool lazy_eligible_wide(const clr_batch* h) {
   // (read per call, like the launcher's own getenv: a process may toggle them between plans)
-  if (getenv("CLR_WIDE64_ONE_WAVE") && h->J > 32) return lazy_eligible(h);
-  const char* env = getenv("CLR_WIDE_LAZY_BOUND");  // (tuning runs: 0 = the strict rule of the narrow kernels)
+  if (clr::option("CLR_WIDE64_ONE_WAVE") && h->J > 32) return lazy_eligible(h);
+  const char* env = clr::option("CLR_WIDE_LAZY_BOUND");  // (tuning runs: 0 = the strict rule of the narrow kernels)
   const double bound = env ? atof(env) : 2.0;
   // widths 9..16 (four lanes per row): the two flavours cost the same there -- 6.5 against 6.7 ms on a dense series, 7.4
   // against 7.0 on one where EVERY batch takes the slow path (profiles/r05m_wide_lazy_gaps.txt) -- so they keep the strict rule
@@ -536,7 +538,7 @@ int wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, h
   mark(2);
   // widths 33..64: the prefix and the corrections in one walk per problem (wide64_kernels.hip); CLR_WIDE_WALK=1 takes
   // that kernel at the padded width 32 too (cross-check of the two-kernel path; tests)
-  const bool walk32 = getenv("CLR_WIDE_WALK") != nullptr;
+  const bool walk32 = clr::option("CLR_WIDE_WALK") != nullptr;
   if (JP == 64 || (JP == 32 && walk32 && !(P.scan_ws && P.coop_prefix == 2))) {
     if (clr::launch_wide_walk(P, JP, stream) != 0)
       return fail(CLR_HIP_ERROR, "the width-64 walk kernel needs 132 KB of dynamic LDS per workgroup: the device refused the attribute");

@@ -1,8 +1,39 @@
 // celerite_amd/csrc/api_misc.hip -- C ABI: library / device entries and the CARMA handle (clr_carma_*).
 #include "api_internal.h"
 
+#include <map>
+#include <mutex>
+
 thread_local std::string clr_api_last_error;
 thread_local int clr_api_device = 0;
+
+// ---- the option table (clr_options.h) ---------------------------------------------------------------------------
+namespace {
+std::mutex g_option_mutex;
+std::map<std::string, std::string>& option_table() {
+  static std::map<std::string, std::string> table;
+  return table;
+}
+bool env_allowed() {
+  static const bool allowed = [] { const char* e = getenv("CLR_ALLOW_ENV"); return e && e[0] == '1'; }();
+  return allowed;
+}
+}  // namespace
+
+namespace clr {
+const char* option(const char* key) {
+  thread_local std::string value;
+  {
+    std::lock_guard<std::mutex> lock(g_option_mutex);
+    auto it = option_table().find(key);
+    if (it != option_table().end()) {
+      value = it->second;
+      return value.c_str();
+    }
+  }
+  return env_allowed() ? getenv(key) : nullptr;
+}
+}  // namespace clr
 
 namespace {
 // The fp64 FMA rate the vector ALUs of THIS device sustain when every SIMD issues v_fma_f64 back to back, and the shader
@@ -47,6 +78,16 @@ const char* clr_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+int clr_set_option(const char* key, const char* value) {
+  if (!key || strncmp(key, "CLR_", 4) != 0) return fail(CLR_INVALID_ARGUMENT, "clr_set_option: keys start with CLR_");
+  std::lock_guard<std::mutex> lock(g_option_mutex);
+  if (value) option_table()[key] = value;
+  else option_table().erase(key);
+  return CLR_OK;
+}
+
+const char* clr_get_option(const char* key) { return key ? clr::option(key) : nullptr; }
 
 int clr_device_count(void) { return visible_gfx950(); }
 

@@ -1,6 +1,7 @@
 // celerite_amd/csrc/api_solver.hip -- C ABI of the object API (clr_solver_*): what the pybind11 module
 // celerite_amd.solver binds in place of the reference's CholeskySolver<double> (celerite/solver.cpp:64-664).
 #include "api_internal.h"
+#include "clr_options.h"
 
 namespace {
 
@@ -192,7 +193,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   // One short series of a narrow kernel: the whole factorisation in ONE launch and one upload (small_kernels.hip);
   // it settles the problem itself when every chunk boundary is consistent and no pivot is flagged, and hands it to
   // the general route below otherwise.
-  if (!has_general && clr::small_compute_supported(J_real, J_comp, N) && !getenv("CLR_NO_SMALL_SOLVER")) {
+  if (!has_general && clr::small_compute_supported(J_real, J_comp, N) && !clr::option("CLR_NO_SMALL_SOLVER")) {
     const size_t ELEM = (size_t)J * J + 2 * J + (size_t)J * (J + 1);
     int threads = 64;
     while (threads < 256 && threads * 8 < N && (size_t)threads * 2 * ELEM * sizeof(double) <= 60000) threads *= 2;
@@ -350,20 +351,20 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       // nchunk steps of 14 / 50 us), so the chunks only have to amortise their own set-up -- 48 samples up to width 16, 96
       // above, at most 1024 / 512 chunks, at least 8 (profiles/r04v_single_wide_chunks.txt, r04z_single_wide_short.txt:
       // N = 1e5 width 16 3.0 -> 0.79 ms, width 32 6.9 -> 1.56 ms; N = 1000 0.74 -> 0.24 / 0.87 -> 0.58 ms)
-      if (!getenv("CLR_WIDE_PREFIX_WALK") && J <= 32) {
+      if (!clr::option("CLR_WIDE_PREFIX_WALK") && J <= 32) {
         const int cap = clr::wide_prefix_scan_max_chunks(J <= 16 ? 16 : 32), Lmin = J <= 16 ? 48 : 96;
         int nk = std::min(N / Lmin, cap);
         if (nk < 8 && N >= 8 * (J <= 16 ? 32 : 64)) nk = 8;
         if (nk >= 8) nchunk = nk;
       }
-      if (const char* e = getenv("CLR_SOLVER_WIDE_CHUNKS")) nchunk = std::max(1, std::min(atoi(e), N / 32));  // (tools/gpu_single_wide_chunks*.py)
+      if (const char* e = clr::option("CLR_SOLVER_WIDE_CHUNKS")) nchunk = std::max(1, std::min(atoi(e), N / 32));  // (tools/gpu_single_wide_chunks*.py)
     }
     P.L = (N + nchunk - 1) / nchunk;
     P.nchunk = (N + P.L - 1) / P.L;
     const size_t pc = (size_t)P.nchunk, JP = (size_t)clr::wide_padded_width(J), SZP = JP * (JP + 1) / 2;
     if ((st = s->ws_elems.reserve(pc * (JP * JP + JP + SZP + JP + SZP))) != CLR_OK) return st;
     if ((st = s->ws_starts.reserve(pc * (SZP + JP))) != CLR_OK) return st;
-    const size_t scan_ws = getenv("CLR_WIDE_PREFIX_WALK") ? 0 : clr::wide_prefix_scan_workspace(1, P.nchunk, (int)JP);  // the prefix as a parallel scan
+    const size_t scan_ws = clr::option("CLR_WIDE_PREFIX_WALK") ? 0 : clr::wide_prefix_scan_workspace(1, P.nchunk, (int)JP);  // the prefix as a parallel scan
     if (scan_ws && (st = s->ws_lvl_elems.reserve(scan_ws)) != CLR_OK) return st;
     P.scan_ws = scan_ws ? s->ws_lvl_elems.p : nullptr;
     if ((st = s->ws_part.reserve(pc * 4)) != CLR_OK) return st;
@@ -463,7 +464,7 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   // widths 9..32, and general terms up to a total width of 32: the wide scan + chunk-wise forward-mode tangents
   // (wide_batch_grad); chunk count for ONE problem from profiles/r04k_wide_grad_chunks.txt
   const bool wide_plan = !narrow_plan && Wc >= 1 && Wt <= 32 && (Wc >= 9 || JG > 0) && N >= 4096;
-  if ((narrow_plan || wide_plan) && !getenv("CLR_GRAD_SEQUENTIAL")) {
+  if ((narrow_plan || wide_plan) && !clr::option("CLR_GRAD_SEQUENTIAL")) {
     // parallel in n: the scan + the chunk-wise tangents (clr_batch_grad) on a one-problem plan
     if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC || s->grad_wide != wide_plan) {
       if (s->grad_plan) clr_batch_destroy(s->grad_plan);
@@ -824,7 +825,7 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
     // prediction points and the chunk summaries walk <= one chunk each (profiles/r04z_predict_chunks.txt: N = 1e5, M = 2e4,
     // width 8 2.1 -> 0.84 ms, width 32 4.9 -> 1.5 ms; rounds 2-3: 1.8 sqrt(N) chunks, their prefix one thread's walk)
     pchunk = std::max(1, std::min(s->N / 16, 8192));
-    if (const char* e = getenv("CLR_PREDICT_CHUNKS")) pchunk = std::max(1, std::min(atoi(e), s->N / 8));  // (tools/gpu_predict_chunks.py)
+    if (const char* e = clr::option("CLR_PREDICT_CHUNKS")) pchunk = std::max(1, std::min(atoi(e), s->N / 8));  // (tools/gpu_predict_chunks.py)
     pL = (s->N + pchunk - 1) / pchunk;
     pchunk = (s->N + pL - 1) / pL;
     if ((st = s->ws_elems.reserve(clr::predict_workspace_doubles(pchunk, s->J_real + 2 * s->J_comp))) != CLR_OK) return st;

@@ -39,6 +39,7 @@
 // wide_correct_kernel turns the sums into the true contributions, and MODE 0 replays only the
 // problems it could not certify (profiles/r01s_wide_scan.log: config 5, 80.6 -> 21.5 ms).
 #include "../../include/celerite_hip.h"
+#include "clr_options.h"
 #include "clr_batch_kernels.h"
 #include "clr_wide.h"
 
@@ -1347,8 +1348,8 @@ int wide_max_width() { return 64; }
 int wide_scan_max_width() { return 64; }  // the chunk algebra: prefix_coop_kernel<16>, wide_prefix32_kernel, wide_walk64_kernel (wide64_kernels.hip)
 
 // widths 33..64: two waves per (problem, chunk) (wide_scan64x2_kernel); CLR_WIDE64_ONE_WAVE=1 keeps the one-wave kernels (A/B)
-static bool wide64_one_wave() { return getenv("CLR_WIDE64_ONE_WAVE") != nullptr; }
-static bool wide_paired(int JR) { return JR == 0 && getenv("CLR_WIDE_NO_PAIRED") == nullptr; }  // complex terms only: a term's four lanes share its features
+static bool wide64_one_wave() { return clr::option("CLR_WIDE64_ONE_WAVE") != nullptr; }
+static bool wide_paired(int JR) { return JR == 0 && clr::option("CLR_WIDE_NO_PAIRED") == nullptr; }  // complex terms only: a term's four lanes share its features
 template <bool GEN>
 static void launch_wide64(const BatchParams& P, int JR, int JC, hipStream_t s) {
   const dim3 grid(P.nchunk, P.B);

@@ -17,6 +17,7 @@
 // (BatchParams::L0): only its (C, b) is read.  Elimination: Gauss-Jordan with partial pivoting on
 // [ I + C1 Jm2 | C1 | A1 | b1 + C1 eta2 ] in LDS, 256 threads -- wide_correct_kernel's, with J more right-hand sides.
 #include "clr_batch_kernels.h"
+#include "clr_options.h"
 
 #include <stdlib.h>
 
@@ -229,7 +230,7 @@ int wide_prefix_scan_max_chunks(int width_padded) { return width_padded <= 16 ? 
 // doubles of workspace the parallel prefix needs (two level buffers), 0 when this shape keeps the sequential walk
 size_t wide_prefix_scan_workspace(int B, int nchunk, int width_padded) {
   long cap = wide_prefix_scan_cap(width_padded);
-  if (const char* e = getenv("CLR_WIDE_SCAN_CAP")) cap = atol(e);  // (tools/gpu_single_wide_chunks2.py)
+  if (const char* e = clr::option("CLR_WIDE_SCAN_CAP")) cap = atol(e);  // (tools/gpu_single_wide_chunks2.py)
   if (width_padded > 32) return 0;  // (widths 33..64: the chunks are chained by wide_walk_kernel, wide64_kernels.hip)
   if (nchunk < 8 || (long)B * nchunk > cap) return 0;  // (... and a walk worth cutting)
   const size_t J = width_padded <= 16 ? 16 : 32, SZ = J * (J + 1) / 2;

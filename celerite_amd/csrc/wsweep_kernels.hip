@@ -15,6 +15,7 @@
 // A sequential sweep costs 0.23 us per step (25-50 ms at N = 1e5, where the CPU needs 0.6-4 ms); measured here
 // at N = 1e5 (profiles/r02y_sweeps_*): dot_solve 0.29 ms at width 8, 0.49 ms at width 32; solve twice that.
 #include "clr_generic_kernels.h"
+#include "clr_options.h"
 #include "clr_wide.h"
 
 #include <stdlib.h>
@@ -532,7 +533,7 @@ bool wsweep_scan_supported(int N, int J) { return J >= 1 && J <= 64 && (N >= 204
 
 // runs of the two-level prefix: 0 = one walk (widths above 32: a composition costs (J + 1)^3)
 static int wsweep_run_len(int J, int nchunk) {
-  if (const char* e = getenv("CLR_WSWEEP_RUN")) return atoi(e);  // (tools/gpu_wsweep_chunks.py)
+  if (const char* e = clr::option("CLR_WSWEEP_RUN")) return atoi(e);  // (tools/gpu_wsweep_chunks.py)
   if (J > 32 || nchunk < 128) return 0;
   return 8;  // (profiles/r04z_wsweep_two_level.txt: runs of 8 beat 12, 16, 32 at every width <= 32)
 }
@@ -543,7 +544,7 @@ int wsweep_chunks(int N, int J) {
   // two-level prefix (widths <= 32, long series): one round of 1024 chunk waves -- the walk no longer sets the chunk count
   // (N = 1e5: dot_solve 0.31 -> 0.18 ms at width 8, 0.44 -> 0.29 at width 32; 1536 chunks are slower again)
   if (J <= 32 && N >= 16384) nc = 1024;
-  if (const char* e = getenv("CLR_WSWEEP_CHUNKS")) nc = atol(e);
+  if (const char* e = clr::option("CLR_WSWEEP_CHUNKS")) nc = atol(e);
   if (nc < 2) nc = 2;
   const long maxc = std::max<long>(1, (N - 1) / 64);
   if (nc > maxc) nc = maxc;

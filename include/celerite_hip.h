@@ -71,12 +71,19 @@ int clr_device_info(char* name, size_t name_len, int* compute_units, size_t* hbm
  * of series and factor plus 8 B nchunk (J^2 + J (J + 1) + 4 J) of scan workspace. */
 int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
 
-/* A measurement for roofline figures (not a product path): the fp64 FMA rate the vector ALUs of the current device
- * sustain with `waves_per_simd` waves per SIMD issuing independent v_fma_f64 back to back (64 x iters each), the shader
- * clock during that load (median over the waves: s_memtime against the 100 MHz s_memrealtime) and the cycles a SIMD
- * spends per FMA it issues.  MI355X: ~56 TFLOP/s at ~1.9 GHz and ~4.45 cycles with two waves per SIMD -- the datasheet's
- * 78.6 TFLOP/s assumes 4 cycles at 2.4 GHz.  Any pointer may be NULL. */
-int clr_device_measure_fp64(int waves_per_simd, int iters, double* tflops, double* clock_mhz, double* cycles_per_fma);
+/* Tuning and cross-check switches of the library, ONE table per process (round 5 read 19 environment variables
+ * directly: a stray variable silently changed kernel selection).  `value` NULL removes the option.  Environment variables
+ * of the same names are honoured only when the process was started with CLR_ALLOW_ENV=1.  The keys (all "CLR_..."):
+ *   CLR_GRAD_SEQUENTIAL      the sequential tangent kernel for every gradient (cross-checks)
+ *   CLR_GRAD_REBUILD_SPAN    reverse-mode gradient: distance of the stored states
+ *   CLR_NO_SMALL_SOLVER      CholeskySolver: never the one-workgroup kernel of short narrow problems
+ *   CLR_WIDE_WALK            widths 17..32: prefix + corrections as one walk per problem (cross-check of the two-kernel path)
+ *   CLR_WIDE_PREFIX_WALK     CholeskySolver at widths 9..32: the sequential walk instead of the parallel prefix
+ *   CLR_WIDE_NO_PAIRED, CLR_WIDE64_ONE_WAVE, CLR_WIDE_LAZY_BOUND, CLR_WIDE_FIRST_RATIO, CLR_WIDE_FIRST_RATIO64,
+ *   CLR_WIDE_SCAN_CAP, CLR_SOLVER_WIDE_CHUNKS, CLR_PREDICT_CHUNKS, CLR_WSWEEP_RUN, CLR_WSWEEP_CHUNKS   (tuning runs, tools/)
+ * clr_get_option: the value in force (NULL: not set); the pointer is valid until the calling thread's next call. */
+int clr_set_option(const char* key, const char* value);
+const char* clr_get_option(const char* key);
 
 /* ---- single-problem solver: celerite::solver::CholeskySolver<double> ----------
  * (cpp/include/celerite/solver/cholesky.h, solver.h), the object behind
@@ -329,13 +336,8 @@ int clr_batch_set_prefix_plan(clr_batch* h, int levels, int group);
 /* The plan in force: number of composition levels (0 = plain walk), group size per level [3], element count per
  * level [4] (counts[0] = chunks). */
 int clr_batch_get_prefix_plan(const clr_batch* h, int* levels, int* groups, int* counts);
-/* Diagnostics (tests): the chunk start states of the last evaluation, [B][nchunk][J(J+1)/2 + J] (packed upper
- * triangle of P, then f) ... */
-int clr_batch_debug_get_starts(clr_batch* h, double* starts);
-/* ... and the cooperative composition kernel against the single-lane host-checked form on the last evaluation's
- * chunk elements in groups of `group`: the largest difference relative to the largest entry of the same block
- * (A, b, C, eta, Jm) of the same composed element, and the largest magnitude seen. */
-int clr_batch_debug_compose_check(clr_batch* h, int group, double* max_rel_diff, double* max_abs_value);
+
+
 /* The maxima the kernel selection looks at -- max |t|, largest time step, largest |d_comp|, largest decay rate of the
  * plan's own series / coefficients -- and the host time of the last clr_batch_set_series (scan + uploads, ms).  Any
  * pointer may be NULL. */
@@ -434,9 +436,7 @@ int clr_batch_get_factor_bytes(const clr_batch* h, size_t* bytes_per_problem);
  * corrections of a group run on a third stream in between.  Results and the factor are those of the plain sequence
  * of kernels, bit for bit (the same kernels on the same data, group by group).  groups = 0: off (default). */
 int clr_batch_set_materialize_pipeline(clr_batch* h, int groups, int summarize_cus, int summarize_streams);
-/* Diagnostic: on how many distinct compute units of each of the 8 XCDs a grid launched on the plan's stream (which =
- * 0), on the pipeline's first summarize stream (1) or on its replay stream (2) runs. */
-int clr_batch_debug_cu_census(clr_batch* h, int which, int* cus_per_xcc /* [8] */);
+
 
 /* Enqueue one evaluation of all B problems on the handle's stream (inputs
  * already resident in HBM).  `materialize` != 0 additionally writes the factor
@@ -486,11 +486,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
 int clr_batch_set_profiling(clr_batch* h, int on);
 int clr_batch_get_profile(clr_batch* h, double* kernel_ms /* [6] */, int* steps);
 
-/* A measurement, not a product path (BASELINE config 5 asks for the fp32-vs-fp64 tolerance of the wide
- * recurrence): the sequential sweep of a width 9..32 plan with the state and every per-step operation in
- * float (features in fp64, rounded; log det and the quadratic form accumulated in fp64 from the float
- * pivots).  Returns per-problem log det / quadratic form and the kernel's time for the whole batch. */
-int clr_batch_fp32_probe(clr_batch* h, double* logdet, double* quad, double* ms);
+
 
 /* Convenience: create + set + enqueue + get + destroy, host pointers in/out. */
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp,

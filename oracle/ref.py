@@ -194,8 +194,31 @@ class RefSolver(object):
                 grab(s.W, J, N), np.ctypeslib.as_array(s.D, shape=(N,)).copy())
 
 
+def load_native():
+    """The same oracle source compiled ON THIS MACHINE with ``-O3 -march=native`` (oracle/Makefile, target ``native``;
+    BASELINE.md section 3.1) -- for bench.py's cpu_baseline leg on the GPU box, whose host CPU is not the build
+    container's.  Returns ``(library, flags)`` or ``(None, reason)`` when there is no compiler / the build fails."""
+    path = os.path.join(_HERE, "libcelerite_ref_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], timeout=120,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(path)
+        lib.ref_batch_log_likelihood.argtypes = _lib.ref_batch_log_likelihood.argtypes
+    except Exception as e:  # no gcc / make on the box, a build error, a timeout
+        return None, repr(e)
+    flags = "-O3 -march=native -fno-fast-math -ffp-contract=off"
+    try:
+        out = subprocess.check_output(["gcc", "-march=native", "-Q", "--help=target"], timeout=30, stderr=subprocess.DEVNULL).decode()
+        arch = [ln.split()[-1] for ln in out.splitlines() if ln.strip().startswith("-march=")]
+        if arch:
+            flags += " (native = %s)" % arch[0]
+    except Exception:
+        pass
+    return lib, flags
+
+
 def batch_log_likelihood(jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,
-                         t, diag, y, nthreads=1):
+                         t, diag, y, nthreads=1, lib=None):
     """Oracle version of the batched entry point.
 
     Coefficients: (B, J_real) / (B, J_comp); ``t``, ``diag``, ``y``: (B, N) or
@@ -227,10 +250,10 @@ def batch_log_likelihood(jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp,
     q = np.empty(B)
     st = np.zeros(B, dtype=np.int32)
     p = lambda a: a.ctypes.data_as(_dp)
-    _lib.ref_batch_log_likelihood(B, N, J_real, J_comp, p(jitter), p(a_real), p(c_real),
-                                  p(a_comp), p(b_comp), p(c_comp), p(d_comp),
-                                  p(t), ts, p(diag), ds, p(y), ys,
-                                  p(ll), p(ld), p(q), st.ctypes.data_as(_ip), int(nthreads))
+    (lib or _lib).ref_batch_log_likelihood(B, N, J_real, J_comp, p(jitter), p(a_real), p(c_real),
+                                           p(a_comp), p(b_comp), p(c_comp), p(d_comp),
+                                           p(t), ts, p(diag), ds, p(y), ys,
+                                           p(ll), p(ld), p(q), st.ctypes.data_as(_ip), int(nthreads))
     return ll, ld, q, st
 
 

@@ -674,7 +674,7 @@ def test_wide_plan_gradient_parallel_in_n(JR, JC, JG):
         A = np.sum(U * V, axis=1) + 1e-8
     empty, empty2 = np.empty(0), np.empty((0, 0))
     want = []
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         for b in range(B):
             gen = (A[b], U[b], V[b]) if JG else (empty, empty2, empty2)
@@ -684,7 +684,7 @@ def test_wide_plan_gradient_parallel_in_n(JR, JC, JG):
             except celerite_amd.solver.LinAlgError:
                 want.append(None)
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     assert want[2] is None and all(w is not None for i, w in enumerate(want) if i != 2)
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
@@ -730,12 +730,12 @@ def test_wide_plan_gradient_with_a_level1_problem_in_a_chunked_plan():
     case = synthetic(B, N, JR, JC, "bench", seed=99)
     jit = np.array([0.0, 0.02, 0.1, 0.05])
     empty, empty2 = np.empty(0), np.empty((0, 0))
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         want = [celerite_amd.CholeskySolver().grad_log_likelihood(jit[b], *[c[b] for c in coeffs_of(case)], empty, empty2, empty2,
                                                                   case["t"][b], case["y"][b], case["diag"][b]) for b in range(B)]
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
         plan.set_chunks(8)                                  # chunks of 2500 samples: the automatic rescue mode defers
@@ -1082,7 +1082,7 @@ def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, 
         out = {}
         for walk in (False, True):
             if walk:
-                os.environ["CLR_WIDE_WALK"] = "1"
+                batch.set_option("CLR_WIDE_WALK", "1")
             try:
                 plan = batch.BatchedGP(B, N, JR, JC)
                 try:
@@ -1095,7 +1095,7 @@ def test_the_one_walk_chunk_algebra_against_the_two_kernel_path_at_width_32(JR, 
                 finally:
                     plan.close()
             finally:
-                os.environ.pop("CLR_WIDE_WALK", None)
+                batch.set_option("CLR_WIDE_WALK", None)
         (ra, la, (ga, ma), ea), (rb, lb, (gb, mb), eb) = out[False], out[True]
         assert np.array_equal(ra[3], rb[3]) and np.array_equal(la, lb), (family, la, lb)
         fin = (ra[3] == 0) & np.isfinite(ra[1]) & np.isfinite(ra[2])
@@ -2130,11 +2130,11 @@ def test_plan_gradient_parallel_in_n(JR, JC, family, mode):
     case = synthetic(B, N, JR, JC, family, seed=77 + JR + 10 * JC)
     jit = np.array([0.0, 0.01, 0.1, 0.3, 0.0])
     (case["a_real"] if JR else case["a_comp"])[3:4] *= -50.0
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         v_seq, g_seq, st_seq = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
         plan.set_series(case["t"], case["diag"], case["y"])
@@ -2210,11 +2210,11 @@ def test_plan_gradient_full_size_against_the_oracle_fixture(mode):
         # oracle fixture, per partial: the plan is held to 1e-10 above; the sequential kernel is measured here and bounded at
         # 1e-8 (its tangent recurrences accumulate rounding over the whole series in one chain; the plan's chains are one
         # chunk long and its reverse sweep is certified by the drift of its reconstructed states).
-        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
         try:
             v2, g2, st2 = batch.batch_grad_log_likelihood(*[c[:1] for c in coeffs], t[:1], diag[:1], y[:1], jitter=gold["jitter"])
         finally:
-            del os.environ["CLR_GRAD_SEQUENTIAL"]
+            batch.set_option("CLR_GRAD_SEQUENTIAL", None)
         assert st2[0] == 0 and abs(v2[0] - gold["value"]) <= 1e-10 * abs(gold["value"])
         within("N = 1e5 gradient, SEQUENTIAL tangent kernel: worst partial vs oracle fixture (bound 1e-8)",
                np.max(np.abs(g2[0] - g0) / np.abs(g0)), 1e-8)
@@ -2231,11 +2231,11 @@ def test_plan_gradient_on_the_adversarial_family(JR, JC):
     for trial in range(10):
         B, N = 6, 3000
         case = adversarial(B, N, JR, JC, seed=4000 + trial)
-        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
         try:
             v0, g0, st0 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"])
         finally:
-            del os.environ["CLR_GRAD_SEQUENTIAL"]
+            batch.set_option("CLR_GRAD_SEQUENTIAL", None)
         plan = batch.BatchedGP(B, N, JR, JC)
         try:
             plan.set_series(case["t"], case["diag"], case["y"])
@@ -2272,11 +2272,11 @@ def test_plan_gradient_every_width_shape(JR, JC):
     case = synthetic(B, N, JR, JC, "accuracy" if (JR + JC) % 2 else "bench", seed=200 + 10 * JR + JC)
     t, diag, y = case["t"][0], case["diag"][0], case["y"][0]
     jit = np.array([0.0, 1e-3, 0.05, 0.4])
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         v0, g0, st0 = batch.batch_grad_log_likelihood(*coeffs_of(case), t, diag, y, jitter=jit)
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
         plan.set_series(t, diag, y)
@@ -2381,13 +2381,13 @@ def test_reverse_gradient_rebuilds_thinned_states_forwards():
             plan.set_grad_mode("reverse")
             for span in (None, 1, 2, 3, 7):
                 if span is None:
-                    os.environ.pop("CLR_GRAD_REBUILD_SPAN", None)
+                    batch.set_option("CLR_GRAD_REBUILD_SPAN", None)
                 else:
-                    os.environ["CLR_GRAD_REBUILD_SPAN"] = str(span)
+                    batch.set_option("CLR_GRAD_REBUILD_SPAN", str(span))
                 try:
                     v, g, st = plan.grad_log_likelihood()
                 finally:
-                    os.environ.pop("CLR_GRAD_REBUILD_SPAN", None)
+                    batch.set_option("CLR_GRAD_REBUILD_SPAN", None)
                 info = plan.grad_info()
                 assert (st == 0).all() and info["reverse"] and info["forward_reruns"] == 0, (JR, JC, span, info)
                 within("reverse gradient with thinned stored states vs forward mode", np.max(np.abs(g - g0) / scale), 1e-10)
@@ -2406,11 +2406,11 @@ def test_reverse_gradient_with_the_two_level_adjoint_walk(JR, JC):
     B, N = 2, 40000
     case = synthetic(B, N, JR, JC, "bench", seed=40 + JR + JC)
     jit = np.array([0.0, 0.02])
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         v0, g0, s0 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"], jitter=jit)
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     scale = np.max(np.abs(g0), axis=1, keepdims=True)
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
@@ -2465,11 +2465,11 @@ def test_plan_gradient_full_size_directional_derivative():
         assert np.max(np.abs(fd - pred) / np.abs(pred)) <= 2e-5, np.max(np.abs(fd - pred) / np.abs(pred))
     finally:
         plan.close()
-    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+    batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
     try:
         v2, g2, st2 = batch.batch_grad_log_likelihood(*[c[:2] for c in coeffs], t[:2], diag[:2], y[:2], jitter=jit[:2])
     finally:
-        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
     within("full-size gradient vs sequential kernel: value", np.max(np.abs(v[:2] - v2) / np.abs(v2)), 1e-11)
     within("full-size gradient vs sequential kernel: partials (of the largest)",
            np.max(np.abs(g[:2] - g2)) / np.max(np.abs(g2)), 1e-10)
@@ -2501,12 +2501,12 @@ def test_wide_summarize_with_the_lazy_decay(JR, JC):
             assert np.max(np.abs(ld - d0) / np.abs(d0)) <= REL, (N, mode)
             assert np.max(np.abs(q - q0) / np.abs(q0)) <= REL, (N, mode)
         if JR == 0:   # the per-term split against the per-row split: the same numbers up to the polynomials' rounding
-            os.environ["CLR_WIDE_NO_PAIRED"] = "1"
+            batch.set_option("CLR_WIDE_NO_PAIRED", "1")
             try:
                 plan.set_summarize_mode(2)
                 row_split = plan.log_likelihood()
             finally:
-                del os.environ["CLR_WIDE_NO_PAIRED"]
+                batch.set_option("CLR_WIDE_NO_PAIRED", None)
             assert np.array_equal(row_split[3], s0)
             assert np.max(np.abs(row_split[1] - outs[2][1]) / np.abs(d0)) <= 1e-12
             assert np.max(np.abs(row_split[2] - outs[2][2]) / np.abs(q0)) <= 1e-12

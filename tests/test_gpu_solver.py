@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import celerite_amd
-from celerite_amd import GP, terms
+from celerite_amd import GP, batch, terms
 from celerite_amd.solver import get_kernel_value, LinAlgError
 from oracle import dense, ref
 from _cases import (COEFFS_W4, COEFFS_W10, COEFFS_DOT, COEFFS_PICKLE, COEFFS_CC_REAL, COEFFS_CC_COMP,
@@ -351,11 +351,11 @@ def test_grad_log_likelihood_at_widths_9_to_32_and_with_general_terms_is_paralle
               0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
         args = (0.1 * trial,) + co + gen + (x, y, diag)
         value, g = s.grad_log_likelihood(*args)
-        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
         try:
             v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(*args)
         finally:
-            del os.environ["CLR_GRAD_SEQUENTIAL"]
+            batch.set_option("CLR_GRAD_SEQUENTIAL", None)
         within("wide / general gradient, object API: value vs sequential kernel", abs(value - v1) / abs(v1), 1e-12, (JR, JC, JG))
         within("wide / general gradient, object API: partials vs sequential kernel (of the largest)",
                np.max(np.abs(g - g1)) / np.max(np.abs(g1)), 1e-10, (JR, JC, JG))
@@ -389,11 +389,11 @@ def test_grad_log_likelihood_of_a_long_series_is_parallel_in_n(JR, JC, N):
               0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
         args = (0.1 * trial,) + co + NO_GENERAL + (x, y, diag)
         value, g = s.grad_log_likelihood(*args)
-        os.environ["CLR_GRAD_SEQUENTIAL"] = "1"
+        batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
         try:
             v1, g1 = celerite_amd.CholeskySolver().grad_log_likelihood(*args)
         finally:
-            del os.environ["CLR_GRAD_SEQUENTIAL"]
+            batch.set_option("CLR_GRAD_SEQUENTIAL", None)
         assert abs(value - v1) <= 1e-11 * abs(v1)
         assert np.max(np.abs(g - g1)) <= 1e-8 * np.max(np.abs(g1)), np.max(np.abs(g - g1)) / np.max(np.abs(g1))
         assert (g[0] == 0.0) == (trial == 0)

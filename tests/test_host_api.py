@@ -321,3 +321,58 @@ def test_bench_headline_line_is_small_strict_json():
     lean["config"] = {"workload": full["config"]["workload"]}
     lean["roofline"] = {k: full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     check(lean)
+
+
+def test_import_celerite_resolves_to_this_build():
+    """The north star's "keeping the existing ... API as a drop-in": ``import celerite`` (the reference's package name,
+    celerite/__init__.py:20-33) is this build -- package, public names and submodules."""
+    import importlib
+
+    import celerite
+    import celerite.modeling
+    import celerite.solver
+    import celerite.terms
+    from celerite import GP as GP2, terms as terms2
+    from celerite.modeling import Model
+    from celerite.solver import CholeskySolver
+
+    assert celerite.GP is GP is GP2 and celerite.terms is terms is terms2 is celerite_amd.terms
+    assert celerite.solver is solver and celerite.modeling is modeling and Model is modeling.Model
+    assert CholeskySolver is solver.CholeskySolver is celerite.CholeskySolver
+    assert importlib.import_module("celerite.terms") is terms
+    for name in ("terms", "solver", "modeling", "GP", "CholeskySolver", "__library_version__", "__version__"):
+        assert hasattr(celerite, name), name
+    assert celerite.__library_version__ == "0.3.0"
+    k = celerite.terms.RealTerm(log_a=0.1, log_c=0.2) + celerite.terms.SHOTerm(log_S0=0.1, log_Q=1.0, log_omega0=0.3)
+    assert celerite.GP(k).kernel is k
+
+
+def test_options_table_and_the_split_of_the_headers():
+    """``clr_set_option`` replaces round 5's 19 direct ``getenv`` reads: one table per process, environment variables
+    honoured only under CLR_ALLOW_ENV=1; the diagnostics live in include/celerite_hip_debug.h, not in the boundary."""
+    assert os.environ.get("CLR_ALLOW_ENV") != "1"
+    os.environ["CLR_GRAD_SEQUENTIAL"] = "1"            # a stray variable must NOT reach the library
+    try:
+        assert batch.get_option("CLR_GRAD_SEQUENTIAL") is None
+        batch.set_option("CLR_GRAD_SEQUENTIAL", "1")
+        assert batch.get_option("CLR_GRAD_SEQUENTIAL") == "1"
+        with batch.option("CLR_GRAD_SEQUENTIAL", 0):
+            assert batch.get_option("CLR_GRAD_SEQUENTIAL") == "0"
+        assert batch.get_option("CLR_GRAD_SEQUENTIAL") == "1"
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
+        assert batch.get_option("CLR_GRAD_SEQUENTIAL") is None
+        with pytest.raises(RuntimeError):
+            batch.set_option("PATH", "x")
+    finally:
+        del os.environ["CLR_GRAD_SEQUENTIAL"]
+        batch.set_option("CLR_GRAD_SEQUENTIAL", None)
+    boundary = open(os.path.join(ROOT, "include", "celerite_hip.h")).read()
+    debug = open(os.path.join(ROOT, "include", "celerite_hip_debug.h")).read()
+    for name in ("clr_batch_debug_get_starts", "clr_batch_debug_compose_check", "clr_batch_debug_cu_census",
+                 "clr_batch_fp32_probe", "clr_device_measure_fp64"):
+        assert name + "(" in debug and name + "(" not in boundary, name
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "celerite_amd", "csrc")):
+        for f in files:
+            text = open(os.path.join(dirpath, f)).read()
+            if f != "api_misc.hip":
+                assert "getenv(" not in text.replace("own getenv", ""), f
