@@ -1646,10 +1646,69 @@ int clr_batch_get_factor(clr_batch* h, int p, double* phi, double* u, double* W,
   return CLR_OK;
 }
 
+// clr_batch_solve on a wide plan (widths 9..64): the factor lies in the reference's storage, problem after problem
+// (wide_scan_kernel, MODE 0), and the two sweeps of CholeskySolver::solve are the object API's chunked affine scans
+// (wsweep_kernels.hip: one wave per chunk, one lane per column of the chunk's map) launched ONCE for the whole batch --
+// grid.z = problem (SweepParams::batch).  Chunks per problem: about two rounds of the chip's SIMDs over the batch
+// (2048 / B, at most the single solver's 1024, at least 2).
+static int wide_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
+  int st;
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (!h->have_factor || !h->factor_valid) return fail(CLR_NOT_COMPUTED, "no materialising run has been made (clr_batch_enqueue(h, 1))");
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) return fail(CLR_UNSUPPORTED, "clr_batch_solve covers celerite-only plans of widths 1..64");
+  if (!clr::wsweep_scan_supported(h->N, h->J)) return fail(CLR_UNSUPPORTED, "clr_batch_solve on a wide plan needs N >= 512 (shorter series: CholeskySolver.solve)");
+  const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J, R = (size_t)nrhs;
+  clr::SweepParams P;
+  memset(&P, 0, sizeof(P));
+  P.N = h->N; P.J = h->J; P.nrhs = nrhs;
+  int nchunk = std::min(clr::wsweep_chunks(h->N, h->J), std::max(2, (int)(2048 / B)));
+  if (nchunk > (h->N - 1) / 64) nchunk = std::max(1, (h->N - 1) / 64);
+  P.L = (h->N - 1 + nchunk - 1) / nchunk;
+  P.nchunk = (h->N - 1 + P.L - 1) / P.L;
+  const size_t ws = clr::wsweep_workspace_doubles(h->J, P.nchunk, nrhs);
+  if ((st = h->bs_M.reserve(B * ws)) != CLR_OK) return st;
+  if ((st = h->bs_x.reserve(B * R * N)) != CLR_OK) return st;   // the forward sweep's output (undivided)
+  if ((st = h->bs_rm.reserve(B * R * N)) != CLR_OK) return st;  // right-hand sides in, results out
+  const double* src = h->y.p;
+  long src_stride = h->y_stride;
+  if (b) {
+    HIP_TRY(hipMemcpyAsync(h->bs_rm.p, b, B * R * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    src = h->bs_rm.p;
+    src_stride = (long)(R * N);
+  }
+  for (hipEvent_t& e : h->bs_ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipEventRecord(h->bs_ev[0], h->stream));
+  P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
+  P.batch = h->B;
+  P.stride_phi = (long)(J * (N - 1)); P.stride_W = (long)(J * N); P.stride_D = (long)N;
+  P.stride_ws = (long)ws;
+  P.in = src; P.stride_in = src_stride;
+  P.out = h->bs_x.p; P.stride_out = (long)(R * N);
+  P.backward = 0;
+  clr::launch_wsweep_scan(P, h->bs_M.p, h->stream);
+  P.in = h->bs_x.p; P.stride_in = (long)(R * N);
+  P.out = h->bs_rm.p; P.stride_out = (long)(R * N);
+  P.backward = 1;
+  clr::launch_wsweep_scan(P, h->bs_M.p, h->stream);
+  HIP_TRY(hipEventRecord(h->bs_ev[1], h->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->bs_ev[0], h->bs_ev[1]));
+  h->solve_device_ms = ms;
+  return CLR_OK;
+}
+
 int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  if (!h->launch) return fail(CLR_UNSUPPORTED, "clr_batch_solve covers widths 1..8 (wider: CholeskySolver.solve)");
+  if (!h->launch) {
+    if (nrhs < 1 || !x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1 and an output array");
+    if (!b && nrhs != 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: b == NULL means the plan's own y (one right-hand side)");
+    return wide_batch_solve(h, nrhs, b, x);
+  }
   if (nrhs < 1 || !x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1 and an output array");
   if (!b && nrhs != 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: b == NULL means the plan's own y (one right-hand side)");
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;

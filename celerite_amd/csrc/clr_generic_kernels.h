@@ -52,6 +52,12 @@ struct SweepParams {
   // two-level prefix of the wave-per-chunk sweeps (wsweep_kernels.hip): runs of run_len chunks, the state at each run's start
   int run_len;                    // 0: one walk over all chunks
   const double* run_starts;       // [nrhs][runs][J + 1] or null (the series' first sample)
+  // a BATCH of problems in one launch (clr_batch_solve on the wide plans' factors: wsweep_kernels.hip, grid.z = problem):
+  // problem b's arrays start b strides further on; 0 / 1 problems: the single solver
+  int batch;
+  long stride_phi, stride_W, stride_D;  // doubles between two problems' phi / u, W, D
+  long stride_in, stride_out;           // ... right-hand sides and results (nrhs * N each)
+  long stride_ws;                       // ... workspaces (wsweep_workspace_doubles)
 };
 bool sweep_scan_supported(int N, int J);
 int sweep_chunks(int N);

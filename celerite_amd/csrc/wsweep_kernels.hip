@@ -30,6 +30,20 @@ __device__ __forceinline__ double wsum(double v) { return row_sum<1>(v); }
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// problem blockIdx.z of a batched launch (SweepParams::batch): every per-problem pointer advanced
+__device__ __forceinline__ SweepParams batch_view(SweepParams P) {
+  const long b = blockIdx.z;
+  if (b == 0) return P;
+  P.phi += b * P.stride_phi; P.u += b * P.stride_phi; P.W += b * P.stride_W; P.D += b * P.stride_D;
+  P.in += b * P.stride_in;
+  if (P.out) P.out += b * P.stride_out;
+  if (P.quad) P.quad += b * P.nrhs;
+  P.elems += b * P.stride_ws; P.starts += b * P.stride_ws;
+  if (P.part) P.part += b * P.stride_ws;
+  if (P.run_starts) P.run_starts += b * P.stride_ws;
+  return P;
+}
+
 // One wave per (chunk, 64 columns).  The step data (p, g, h: 3 J doubles per step) is the same for every
 // lane: the wave copies KB steps at a time into LDS with coalesced vector loads (fetched one tile ahead,
 // in registers) and every lane reads it back with uniform-address (broadcast) LDS reads.  (Through the
@@ -40,7 +54,8 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 // chunk's end are (1, 0, 0) -- the identity on f -- and keep x through a select.
 template <int JP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-wsweep_summarize_kernel(const SweepParams P) {
+wsweep_summarize_kernel(const SweepParams P0) {
+  const SweepParams P = batch_view(P0);
   constexpr int KB = 8, ROUNDS = KB * JP / 64;
   constexpr int GS = (JP % 16 == 0) ? 16 : 8, NG = JP / GS;
   __shared__ double tile[KB][3][JP];
@@ -135,7 +150,9 @@ wsweep_summarize_kernel(const SweepParams P) {
 // run maps, walk every run's own chunks from the state found for its start.  One wave per (run, block of CB columns);
 // lane = row, the block's columns of the running product in registers, handed round through LDS.
 constexpr int WS_CB = 8;
-__global__ void __launch_bounds__(64) wsweep_compose_kernel(const SweepParams P, int R, double* run_elems) {
+__global__ void __launch_bounds__(64) wsweep_compose_kernel(const SweepParams P0, int R, double* run_elems0) {
+  const SweepParams P = batch_view(P0);
+  double* run_elems = run_elems0 + (long)blockIdx.z * P0.stride_ws;
   __shared__ double X[65][WS_CB];
   const int J = P.J, K = J + 1, lane = threadIdx.x, run = blockIdx.x, col0 = blockIdx.y * WS_CB;
   const int ncol = K + P.nrhs;
@@ -198,7 +215,8 @@ __global__ void __launch_bounds__(64) wsweep_compose_kernel(const SweepParams P,
 // times to land; z travels from chunk to chunk through LDS (ping-pong, one barrier per chunk) and is read
 // back with broadcast reads.
 template <int JP, int NW>
-__global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParams P) {
+__global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParams P0) {
+  const SweepParams P = batch_view(P0);
   constexpr int H = (JP + 2) / 2;  // z is read back in two halves of H (columns 0 .. JP+1, the last one padding)
   constexpr bool BIG = JP >= 64;   // width 64: K = 65 rows for 64 lanes -- lane 0 also owns row 64 (the x row)
   __shared__ double zbuf[2][2 * H];
@@ -282,7 +300,8 @@ __global__ void __launch_bounds__(64 * NW) wsweep_prefix_kernel(const SweepParam
 }
 
 // one wave per (chunk, right-hand side); lane = row of the state
-__global__ void __launch_bounds__(64) wsweep_replay_kernel(const SweepParams P) {
+__global__ void __launch_bounds__(64) wsweep_replay_kernel(const SweepParams P0) {
+  const SweepParams P = batch_view(P0);
   constexpr int KB = 8;
   const int J = P.J, K = J + 1, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
   const bool have = lane < J;
@@ -340,7 +359,8 @@ __global__ void __launch_bounds__(64) wsweep_replay_kernel(const SweepParams P) 
 }
 
 // dot_solve: chunk partials, one wave per right-hand side (lane-strided sums, then a fixed reduction tree)
-__global__ void __launch_bounds__(64) wsweep_finalize_kernel(const SweepParams P) {
+__global__ void __launch_bounds__(64) wsweep_finalize_kernel(const SweepParams P0) {
+  const SweepParams P = batch_view(P0);
   const int rhs = blockIdx.x, lane = threadIdx.x;
   double q = 0.0;
   for (int c = lane; c < P.nchunk; c += 64) q += P.part[(long)rhs * P.nchunk + c];
@@ -564,7 +584,8 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
   P.elems = workspace;
   P.starts = P.elems + (size_t)P.nchunk * (K + P.nrhs) * K;
   P.part = P.starts + (size_t)P.nrhs * P.nchunk * K;
-  const dim3 gsum(P.nchunk, (unsigned)((K + P.nrhs + 63) / 64));
+  const unsigned nb = P.batch > 1 ? (unsigned)P.batch : 1u;
+  const dim3 gsum(P.nchunk, (unsigned)((K + P.nrhs + 63) / 64), nb);
   if (P.J <= 8) hipLaunchKernelGGL((wsweep_summarize_kernel<8>), gsum, dim3(64), 0, s, P);
   else if (P.J <= 16) hipLaunchKernelGGL((wsweep_summarize_kernel<16>), gsum, dim3(64), 0, s, P);
   else if (P.J <= 24) hipLaunchKernelGGL((wsweep_summarize_kernel<24>), gsum, dim3(64), 0, s, P);
@@ -574,7 +595,7 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
   else if (P.J <= 56) hipLaunchKernelGGL((wsweep_summarize_kernel<56>), gsum, dim3(64), 0, s, P);
   else hipLaunchKernelGGL((wsweep_summarize_kernel<64>), gsum, dim3(64), 0, s, P);
   auto prefix = [&](const SweepParams& Q, int nrun) {
-    const dim3 grid(Q.nrhs, nrun);
+    const dim3 grid(Q.nrhs, nrun, nb);
     if (Q.J <= 8) hipLaunchKernelGGL((wsweep_prefix_kernel<8, 16>), grid, dim3(1024), 0, s, Q);
     else if (Q.J <= 16) hipLaunchKernelGGL((wsweep_prefix_kernel<16, 16>), grid, dim3(1024), 0, s, Q);
     else if (Q.J <= 24) hipLaunchKernelGGL((wsweep_prefix_kernel<24, 8>), grid, dim3(512), 0, s, Q);
@@ -589,7 +610,7 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
     const int nrun = (P.nchunk + R - 1) / R;
     double* run_elems = P.part + (size_t)P.nrhs * P.nchunk;
     double* run_starts = run_elems + (size_t)nrun * (K + P.nrhs) * K;
-    hipLaunchKernelGGL(wsweep_compose_kernel, dim3(nrun, (unsigned)((K + P.nrhs + WS_CB - 1) / WS_CB)), dim3(64), 0, s, P, R, run_elems);
+    hipLaunchKernelGGL(wsweep_compose_kernel, dim3(nrun, (unsigned)((K + P.nrhs + WS_CB - 1) / WS_CB), nb), dim3(64), 0, s, P, R, run_elems);
     SweepParams T = P;
     T.elems = run_elems; T.nchunk = nrun; T.starts = run_starts; T.run_len = 0; T.run_starts = nullptr;
     prefix(T, 1);
@@ -600,8 +621,8 @@ void launch_wsweep_scan(SweepParams P, double* workspace, hipStream_t s) {
     P.run_len = 0; P.run_starts = nullptr;
     prefix(P, 1);
   }
-  hipLaunchKernelGGL(wsweep_replay_kernel, dim3(P.nchunk, P.nrhs), dim3(64), 0, s, P);
-  if (P.quad) hipLaunchKernelGGL(wsweep_finalize_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(wsweep_replay_kernel, dim3(P.nchunk, P.nrhs, nb), dim3(64), 0, s, P);
+  if (P.quad) hipLaunchKernelGGL(wsweep_finalize_kernel, dim3(P.nrhs, 1, nb), dim3(64), 0, s, P);
 }
 
 }  // namespace clr

@@ -455,7 +455,9 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
  * division by D and backward substitution as two chunked affine scans whose chunk maps are formed once and shared by
  * all right-hand sides and both sweeps (csrc/clr_bsolve_kernels.h).  b and x: host arrays [B][nrhs][N] (row-major:
  * right-hand side k of problem p at (p * nrhs + k) * N); b == NULL with nrhs == 1: the plan's own y (already in HBM --
- * GP.apply_inverse(y) of celerite.py:307-328 for B problems without an upload).  Widths 1..8, chunked plans.  A problem
+ * GP.apply_inverse(y) of celerite.py:307-328 for B problems without an upload).  Widths 1..8: chunked plans (N >= 128).
+ * Widths 9..64 (round 6): the factor lies in the reference's storage and the sweeps are the object API's wave-per-chunk
+ * affine scans (csrc/wsweep_kernels.hip) launched once for the whole batch, grid.z = problem; N >= 512.  A problem
  * whose materialising run reported CLR_NOT_POSITIVE_DEFINITE has no factor: its x is undefined (non-finite).  With the
  * LEAN layout the sweeps regenerate phi and u from (t, coefficients) and move 9 instead of 25 doubles per sample through
  * HBM four times: the plan must still hold the series and coefficients of the materialising run. */
