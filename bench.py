@@ -317,6 +317,24 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         dev_ms, _ = plan.run_timed(steps, relayout_each_step=False)
         chunks = plan.chunks
         prefix_plan = plan.prefix_plan if W <= 8 else (0, [], [chunks[0]])
+        # the batched solve on this plan's materialised factor (round 6: widths 9..64 too), problem 0 against the oracle's solve
+        solve = None
+        if W == 32:
+            try:
+                mat_ms, _ = plan.run_timed(2, materialize=True, relayout_each_step=False)
+                plan.solve()
+                x = plan.solve()
+                r = ref.RefSolver()
+                e_, e2_ = np.empty(0), np.empty((0, 0))
+                r.compute(0.0, *[c[0] for c in coeffs], e_, e2_, e2_, t[0], diag[0])
+                x0 = r.solve(y[0])[:, 0]
+                solve = {"what": "clr_batch_solve: K^-1 y for all %d problems from the wide plan's materialised factor "
+                                 "(wsweep affine scans, grid.z = problem)" % B,
+                         "materialising_step_ms": mat_ms / 2, "solve_device_ms": plan.solve_device_ms(),
+                         "problem0_vs_oracle_rel": float(np.max(np.abs(x[0] - x0)) / np.max(np.abs(x0)))}
+                del x
+            except Exception as e:  # a failing side leg must not lose the line
+                solve = {"error": repr(e)}
     finally:
         plan.close()
     S = min(sample, B)
@@ -344,6 +362,7 @@ def batch_config(name, B, N, JR, JC, steps, sample, seed, d_spread=False):
         "parity": {"problems_checked": int(S), "status_equal": bool(np.array_equal(st[:S], s0)),
                    "logdet_rel_max": rel_err(ld[:S][ok], d0[ok]), "quad_rel_max": rel_err(q[:S][ok], q0[ok]),
                    "tolerance": 1e-10},
+        "batched_solve": solve,
     }
 
 
@@ -1147,6 +1166,11 @@ def promote(out):
                         "whole_step_frac": c4["roofline"]["whole_step"]["frac_fp64"],
                         "routes": (c4.get("levels") or {}).get("histogram"),
                         "logdet_rel_max": (c4.get("parity") or {}).get("logdet_rel_max")}
+        bs4 = c4.get("batched_solve") or {}
+        if "solve_device_ms" in bs4:
+            r["config4"]["batched_solve_ms"] = bs4["solve_device_ms"]
+            r["config4"]["batched_solve_problem0_vs_oracle_rel"] = bs4["problem0_vs_oracle_rel"]
+            r["config4"]["materialising_step_ms"] = bs4["materialising_step_ms"]
     c1 = cfgs.get("config1_b256_n1e4_w4")
     if c1:
         r["config1_ms_per_step"] = c1.get("ms_per_step")

@@ -1074,7 +1074,7 @@ static int replay_mode(const clr_batch* h, int materialize) {
 // the fix-up pass of a materialising run: the first `factor_refine` samples of every chunk from the previous chunk's
 // replayed end state (BatchParams::ends / fixup_steps, replay_kernel)
 static void refine_chunk_heads(const clr_batch* h, clr::BatchParams R, int materialize, hipStream_t s) {
-  R.fixup_steps = h->factor_refine;
+  R.fixup_steps = R.refine_samples;
   h->launch->replay(R, replay_mode(h, materialize), s);
 }
 
@@ -1252,6 +1252,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   if (!h->launch) {
     mark(0);
     if ((st = wide_launch(h, P, ev)) != CLR_OK) return st;
+    if (materialize) { h->factor_is_lean = false; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
     h->rescue_inflight = P.defer_level1 != 0;
     HIP_TRY(hipGetLastError());
     return CLR_OK;
@@ -1803,6 +1804,7 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     HIP_TRY(hipEventRecord(e[0], h->stream));
     if (!h->launch) {  // wide path (one chunk: the whole sweep is reported in the "replay" slot)
       if ((st = wide_launch(h, P, e)) != CLR_OK) return st;
+      if (materialize) { h->factor_is_lean = false; h->factor_inputs_changed = false; h->factor_valid = true; h->bs_M_valid = false; }
       // (a plan that re-planned level-1 problems at its last evaluation does so inside every timed step: the step's
       //  time then includes the side plan -- at the price of a host round trip per step)
       if (P.defer_level1 && h->rescue_last != 0) { h->rescue_inflight = true; if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st; HIP_TRY(hipEventRecord(e[6], h->stream)); }

@@ -490,9 +490,15 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.wide_materialize = (materialize && !h->launch) ? 1 : 0;
   P.ends = nullptr;
   P.fixup_steps = 0;
-  if (materialize && h->launch && h->nchunk > 1 && h->factor_refine > 0) {
-    if ((st = h->ends.reserve((size_t)h->B * h->nchunk * h->launch->start_doubles)) != CLR_OK) return st;
+  P.refine_samples = 0;
+  if (materialize && h->nchunk > 1 && h->factor_refine > 0 && h->J_general == 0 && h->J <= clr::wide_max_width()) {
+    size_t START = 0;
+    if (h->launch) START = (size_t)h->launch->start_doubles;
+    else { const size_t JP = (size_t)clr::wide_padded_width(h->J); START = JP * (JP + 1) / 2 + JP; }
+    if ((st = h->ends.reserve((size_t)h->B * h->nchunk * START)) != CLR_OK) return st;
     P.ends = h->ends.p;
+    // (the recurrence needs a few J samples to forget a start state: wide plans take the setting per 16 rows of state)
+    P.refine_samples = h->launch ? h->factor_refine : h->factor_refine * (clr::wide_padded_width(h->J) / 16);
   }
   P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
   return CLR_OK;
@@ -553,11 +559,16 @@ int wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, h
   // one chunk: the sweep itself; several: the chunked replay of forced runs and of the problems the
   // conditioning record marked (level 1), with its end states checked against the scan
   clr::launch_wide_loglike(P, J_real, J_comp, stream);
+  if (P.nchunk > 1 && P.ends && P.wide_materialize && P.refine_samples > 0) {
+    clr::BatchParams F = P;  // the heads of the chunks again, from the previous chunk's replayed end state
+    F.fixup_steps = P.refine_samples;
+    clr::launch_wide_loglike(F, J_real, J_comp, stream);
+  }
   if (P.nchunk > 1) {
     clr::launch_wide_check_replay(P, stream);
     clr::launch_finalize(P, stream);
     clr::BatchParams S = P;  // the flagged problems, sequentially
-    S.nchunk = 1; S.L = P.N; S.L0 = 0; S.seq_only = 1; S.force_exact = 1;
+    S.nchunk = 1; S.L = P.N; S.L0 = 0; S.seq_only = 1; S.force_exact = 1; S.ends = nullptr; S.fixup_steps = 0;
     clr::launch_wide_loglike(S, J_real, J_comp, stream);
   }
   mark(5);

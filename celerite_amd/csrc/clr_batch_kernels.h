@@ -87,6 +87,7 @@ struct BatchParams {
   // oracle's own distance from the binary128 truth).
   double* ends;       // [B][nchunk][START] or null
   int fixup_steps;    // > 0: this launch is the fix-up pass
+  int refine_samples; // the setting (samples per chunk head) the flow launches the fix-up pass with
   int defer_level1;   // problems the conditioning record sends to the checked chunked replay (level 1) are NOT replayed
                       // inline -- one flagged problem would cost the whole batch a sequential chunk-time -- but left with
                       // a pending status: the host re-plans them as a small plan of their own with many short chunks

@@ -351,8 +351,13 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // chunked replay: forced-exact runs, or the problems the conditioning record sent here (level 1)
   if (MODE == 0 && P.nchunk > 1 && !P.force_exact && (P.need_exact[b] != 1 || (P.defer_level1 && !P.seq_only))) return;
   if (MODE == 0 && P.seq_only && P.need_exact[b] < 2) return;  // sequential pass: level >= 2 only
+  // (materialising runs, BatchParams::ends / fixup_steps: the fix-up pass recomputes the heads of the chunks c >= 1 from
+  //  the state the previous chunk's replay reached at the boundary -- clr_batch_kernels.h, replay_kernel has the story)
+  const bool fixup = MODE == 0 && P.fixup_steps > 0;
+  if (fixup && chunk == 0) return;
   const int n_lo = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk));  // (wave-uniform by construction: keep the loop counters scalar)
-  const int n_hi = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk + 1));
+  const int n_end = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk + 1));
+  const int n_hi = fixup ? (n_lo + P.fixup_steps < n_end ? n_lo + P.fixup_steps : n_end) : n_end;
   const long slot = (long)b * P.nchunk + chunk;
 
   double S[COLS];
@@ -360,7 +365,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 #pragma unroll
   for (int c = 0; c < COLS; ++c) S[c] = 0.0;
   if (MODE == 0 && chunk > 0) {  // start state of this chunk (packed upper triangle | f), from the prefix phase
-    const double* st = P.starts + slot * START;
+    const double* st = fixup ? P.ends + (slot - 1) * START : P.starts + slot * START;
 #pragma unroll
     for (int c = 0; c < COLS; ++c) S[c] = st[sym(row, seg * COLS + c)];
     f = st[SZ + row];
@@ -874,6 +879,16 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
       if (P.cond) { P.cond[slot * 3 + 0] = gam; P.cond[slot * 3 + 1] = 1.0; P.cond[slot * 3 + 2] = 0.0; }
     }
     return;
+  }
+  if (fixup) return;  // (factor entries only: sums, flags and the record stand)
+  if (MODE == 0 && P.nchunk > 1 && P.ends) {  // the state at the chunk's end, for the fix-up pass
+    double* e = P.ends + slot * START;
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+      const int col = seg * COLS + c;
+      if (row <= col && col < WMAX) e[sym(row, col)] = S[c];
+    }
+    if (writer) e[SZ + row] = f;
   }
   if (MODE == 0 && P.nchunk > 1 && P.cond) {
     // end state of this chunk against the scanned start state of the next one (as replay_kernel)

@@ -319,7 +319,7 @@ def test_batched_solve_on_wide_plans(JR, JC, N, B):
             scale = np.max(np.abs(want), axis=0)
             got = np.column_stack([x_y[p], x_3[p].T])
             within("batched solve on wide plans (width %d, N = %d): vs oracle solve, of the largest entry" % (JR + 2 * JC, N),
-                   np.max(np.abs(got - want) / scale), 1e-10, p)
+                   np.max(np.abs(got - want) / scale), 2e-11, p)
             within("batched solve on wide plans: y . solve(y) vs the fused quadratic form", abs(np.dot(case["y"][p], x_y[p]) - q[p]) / abs(q[p]), 1e-9, p)
     finally:
         plan.close()
