@@ -354,6 +354,24 @@ class BatchedGP(object):
         _check(lib.clr_batch_solve(self._h, int(nrhs), _ptr(b), _ptr(x)))
         return x
 
+    def predict(self, xs):
+        """The conditional mean ``K_p(x*, t_p) K_p^-1 y_p`` of every problem at the prediction points ``xs`` --
+        ``(M,)`` shared by all problems or ``(B, M)`` -- from the factor of the last materialising run
+        (``clr_batch_predict``; ``CholeskySolver.predict``, cholesky.h:599-698, for B problems).  Returns ``(B, M)``."""
+        lib = _load()
+        lib.clr_batch_predict.argtypes = [C.c_void_p, C.c_int, _dp, C.c_long, _dp]
+        xs = _f64(xs)
+        if xs.ndim == 1:
+            stride = 0
+        elif xs.ndim == 2 and xs.shape[0] == self.B:
+            stride = xs.shape[1]
+        else:
+            raise ValueError("dimension mismatch")
+        M = xs.shape[-1]
+        pred = np.empty((self.B, M))
+        _check(lib.clr_batch_predict(self._h, int(M), _ptr(xs), stride, _ptr(pred)))
+        return pred
+
     def solve_device_ms(self):
         """Device time of the last :meth:`solve` (its kernels, without the host <-> HBM copies)."""
         lib = _load()

@@ -1694,7 +1694,7 @@ static int wide_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) 
   clr::launch_wsweep_scan(P, h->bs_M.p, h->stream);
   HIP_TRY(hipEventRecord(h->bs_ev[1], h->stream));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (x) HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));  // (null: the result stays in bs_rm)
   HIP_TRY(hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->bs_ev[0], h->bs_ev[1]));
@@ -1702,16 +1702,13 @@ static int wide_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) 
   return CLR_OK;
 }
 
-int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
+// x == null: the result stays on the device, row-major [B][nrhs][N] in bs_rm (clr_batch_predict)
+static int batch_solve_impl(clr_batch* h, int nrhs, const double* b, double* x) {
   int st = require_device(h->device);
   if (st != CLR_OK) return st;
-  if (!h->launch) {
-    if (nrhs < 1 || !x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1 and an output array");
-    if (!b && nrhs != 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: b == NULL means the plan's own y (one right-hand side)");
-    return wide_batch_solve(h, nrhs, b, x);
-  }
-  if (nrhs < 1 || !x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1 and an output array");
+  if (nrhs < 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: nrhs >= 1");
   if (!b && nrhs != 1) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: b == NULL means the plan's own y (one right-hand side)");
+  if (!h->launch) return wide_batch_solve(h, nrhs, b, x);
   if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
   if (!h->have_factor || !h->factor_valid) return fail(CLR_NOT_COMPUTED, "no materialising run has been made (clr_batch_enqueue(h, 1))");
   if (h->factor_is_lean && h->factor_inputs_changed)
@@ -1753,13 +1750,73 @@ int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
   clr::launch_relayout_back(h->bs_x.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
   HIP_TRY(hipEventRecord(e1, h->stream));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (x) HIP_TRY(hipMemcpyAsync(x, h->bs_rm.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->bs_M_valid = true;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   h->solve_device_ms = ms;
   return CLR_OK;
+}
+
+int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
+  if (!x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: an output array");
+  return batch_solve_impl(h, nrhs, b, x);
+}
+
+// CholeskySolver::predict (cholesky.h:599-698; GP.predict's conditional mean, celerite.py:330-420) for every problem of
+// the plan: mu*_p(x*) = K_p(x*, t_p) K_p^-1 y_p at M points per problem.  alpha = K^-1 y is the batched solve on the
+// materialised factor (either layout, any width <= 64), left on the device; the reference's two passes over the sorted
+// prediction points are the object API's chunked diagonal scans (generic_kernels.hip: launch_predict_scan, a parallel
+// prefix over chunks of 16 samples + one thread per point) run problem by problem on the plan's resident times and
+// coefficients -- they need nothing of the factor.  Unsorted points: the sequential walk (launch_predict).
+int clr_batch_predict(clr_batch* h, int M, const double* xs, long xs_stride, double* pred) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (M < 0 || (M > 0 && (!xs || !pred))) return fail(CLR_INVALID_ARGUMENT, "clr_batch_predict: M >= 0, the points and an output array");
+  if (xs_stride != 0 && xs_stride != M) return fail(CLR_INVALID_ARGUMENT, "clr_batch_predict: the points' stride is 0 (shared by all problems) or M");
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) return fail(CLR_UNSUPPORTED, "clr_batch_predict covers celerite-only plans of widths 1..64");
+  if (M == 0) return CLR_OK;
+  if ((st = batch_solve_impl(h, 1, nullptr, nullptr)) != CLR_OK) return st;  // alpha = K^-1 y -> bs_rm [B][N]
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t B = (size_t)h->B, Mm = (size_t)M, nsrc = xs_stride == 0 ? 1 : B;
+  DevBuf dxs, dpred, ws;
+  auto cleanup = [&](int code) { dxs.release(); dpred.release(); ws.release(); return code; };
+  if ((st = dxs.reserve(nsrc * Mm)) != CLR_OK) return cleanup(st);
+  if ((st = dpred.reserve(B * Mm)) != CLR_OK) return cleanup(st);
+  const bool scan_ok = clr::predict_scan_supported(h->N, h->J_real, h->J_comp);
+  int pchunk = 0, pL = 0;
+  if (scan_ok) {
+    pchunk = std::max(1, std::min(h->N / 16, 8192));
+    pL = (h->N + pchunk - 1) / pchunk;
+    pchunk = (h->N + pL - 1) / pL;
+    if ((st = ws.reserve(clr::predict_workspace_doubles(pchunk, h->J))) != CLR_OK) return cleanup(st);
+  }
+  if (hipMemcpyAsync(dxs.p, xs, nsrc * Mm * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemsetAsync(dpred.p, 0, B * Mm * sizeof(double), h->stream) != hipSuccess)
+    return cleanup(fail(CLR_HIP_ERROR, "clr_batch_predict: upload failed"));
+  std::vector<char> sorted(nsrc, 1);
+  for (size_t p = 0; p < nsrc; ++p)
+    for (size_t m = 1; m < Mm && sorted[p]; ++m) sorted[p] = xs[p * Mm + m - 1] <= xs[p * Mm + m];
+  for (size_t p = 0; p < B; ++p) {
+    clr::GenericProblem g;
+    g.N = h->N; g.J = h->J; g.J_real = h->J_real; g.J_comp = h->J_comp; g.J_general = 0;
+    g.a_real = P.a_real + p * h->J_real; g.c_real = P.c_real + p * h->J_real;
+    g.a_comp = P.a_comp + p * h->J_comp; g.b_comp = P.b_comp + p * h->J_comp;
+    g.c_comp = P.c_comp + p * h->J_comp; g.d_comp = P.d_comp + p * h->J_comp;
+    g.U = nullptr; g.V = nullptr;
+    g.t = h->t.p + p * (size_t)h->t_stride;
+    const double* alpha = h->bs_rm.p + p * (size_t)h->N;
+    const double* xp = dxs.p + (xs_stride == 0 ? 0 : p * Mm);
+    if (scan_ok && sorted[xs_stride == 0 ? 0 : p]) clr::launch_predict_scan(g, alpha, M, xp, dpred.p + p * Mm, ws.p, pchunk, pL, h->stream);
+    else clr::launch_predict(g, alpha, M, xp, dpred.p + p * Mm, h->stream);
+  }
+  if (hipGetLastError() != hipSuccess ||
+      hipMemcpyAsync(pred, dpred.p, B * Mm * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return cleanup(fail(CLR_HIP_ERROR, "clr_batch_predict: kernels or the download failed"));
+  return cleanup(CLR_OK);
 }
 
 int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms) {

@@ -462,6 +462,13 @@ int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
  * LEAN layout the sweeps regenerate phi and u from (t, coefficients) and move 9 instead of 25 doubles per sample through
  * HBM four times: the plan must still hold the series and coefficients of the materialising run. */
 int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x);
+/* CholeskySolver::predict (cholesky.h:599-698: the conditional mean K_p(x*, t_p) K_p^-1 y_p behind GP.predict,
+ * celerite.py:330-420) for every problem of the plan, M prediction points each: xs host [B][M] (xs_stride = M) or one
+ * set of M points shared by all problems (xs_stride = 0); pred host [B][M].  alpha = K^-1 y comes from the batched solve
+ * on the factor of the last materialising run (any layout, widths 1..64) and stays on the device; the two passes over
+ * the prediction points are the object API's chunked diagonal scans on the plan's resident times and coefficients
+ * (sorted points: parallel in n; unsorted: the sequential walk of the reference). */
+int clr_batch_predict(clr_batch* h, int M, const double* xs, long xs_stride, double* pred);
 /* Device time of the last clr_batch_solve (HIP events around its kernels: relayout, the five phases, relayout back;
  * the host <-> HBM copies of b and x are outside). */
 int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms);

@@ -325,6 +325,40 @@ def test_batched_solve_on_wide_plans(JR, JC, N, B):
         plan.close()
 
 
+@pytest.mark.parametrize("JR,JC,N,layout", [(2, 3, 6000, "reference"), (2, 3, 6000, "lean"), (1, 1, 3000, "lean"), (0, 8, 5000, "reference"), (4, 14, 4000, "reference")])
+def test_batched_predict_on_plans(JR, JC, N, layout):
+    """VERDICT r5 item 6: ``clr_batch_predict`` -- ``CholeskySolver::predict`` (cholesky.h:599-698; GP.predict's mean) for
+    every problem of a plan from its materialised factor, narrow (both layouts) and wide: points shared by all problems,
+    points per problem, points outside the series on both sides, unsorted points (the sequential walk), against the
+    oracle's ``predict`` problem by problem."""
+    B = 5
+    case = synthetic(B, N, JR, JC, "bench", seed=70 + JR + JC)
+    rng = np.random.RandomState(9)
+    lo, hi = case["t"].min(), case["t"].max()
+    shared = np.sort(np.concatenate([rng.uniform(lo - 0.05, hi + 0.05, 700), case["t"][0, ::97]]))
+    own = np.sort(rng.uniform(lo, hi, (B, 300)), axis=1)
+    shuffled = rng.permutation(shared)[:200]
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        if JR + 2 * JC <= 8:
+            plan.set_chunks(24)
+            plan.set_factor_layout(layout)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        plan.log_likelihood(materialize=True)
+        got = {"shared": plan.predict(shared), "own": plan.predict(own), "shuffled": plan.predict(shuffled)}
+        assert got["shared"].shape == (B, len(shared)) and got["own"].shape == (B, 300)
+        for p in range(B):
+            r = ref.RefSolver()
+            r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)), case["t"][p], case["diag"][p])
+            for key, pts in (("shared", shared), ("own", own[p]), ("shuffled", shuffled)):
+                want = r.predict(case["y"][p], pts)
+                within("batched predict on plans (%s points): vs oracle predict, of the largest" % key,
+                       np.max(np.abs(got[key][p] - want)) / np.max(np.abs(want)), 1e-10, (JR, JC, layout, p))
+    finally:
+        plan.close()
+
+
 def test_materialised_factor_at_the_bench_shape_against_the_oracle_state():
     """The factor of the materialising run whose roofline the bench line quotes -- BASELINE configs[2]'s shape, 1024
     problems x 1e5 samples x width 8, automatic chunking -- and the batched solve on it, in both layouts (the
