@@ -376,16 +376,8 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
     //  state-independent work over the barrier, 58 registers spill, 2.20 -> 3.85 ms.)
 #pragma unroll
     for (int j = 0; j < JC; ++j) sincos_phase<FAST>(p.dc[j] * tn, &sdv[j], &cdv[j]);
-    for (int i = i0; i < i1; ++i) {
-      const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
-#pragma unroll
-      for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
-      tq[PF - 1] = src.tp[ot];
-      dq[PF - 1] = src.dp[od];
-      yq[PF - 1] = src.yp[od];
-      ++id;
-      od = (id == L) ? src.cs : od + src.is;
-      ot = (id + 1 == L) ? src.cs : ot + src.is;
+    // one trajectory step on the sample (t_cur_next, diag_cur, y_cur) handed in (the caller owns the series queue)
+    auto one_step = [&](int i, const double t_cur_next, const double diag_cur, const double y_cur) __attribute__((always_inline)) {
       double* slot = slot0 + (i & 1) * SLOT_STRIDE;
       slot[Lk::F_Y * 64] = y_cur;
       double u[J], v[J];
@@ -458,12 +450,46 @@ __device__ __forceinline__ void split_trajectory_lazy(const Problem<JR, JC>& p, 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       split_barrier();  // B(i)
+#ifdef CLR_SPLIT_UNROLL3
+      // (three steps per loop trip: nothing of the NEXT step may be computed on this side of the barrier -- round 5's
+      //  attempt died of exactly that hoisting, 58 registers spilled -- so the queue's registers pass through an opaque
+      //  asm here and the scheduler is fenced)
+      asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(yq[0]), "+v"(yq[1]), "+v"(yq[2]));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int j = 0; j < J; ++j) {
 #pragma unroll
         for (int k = 0; k <= j; ++k) C[tri(k, j)] = fma(z[k], W[j], C[tri(k, j)]);
       }
       tn = t_cur_next;
+    };
+    auto refill = [&](int k) __attribute__((always_inline)) {  // entry k of the queue <- the sample PF steps ahead
+      tq[k] = src.tp[ot];
+      dq[k] = src.dp[od];
+      yq[k] = src.yp[od];
+      ++id;
+      od = (id == L) ? src.cs : od + src.is;
+      ot = (id + 1 == L) ? src.cs : ot + src.is;
+    };
+    int i = i0;
+#ifdef CLR_SPLIT_UNROLL3
+    static_assert(PF == 3, "the unrolled trip rotates a queue of three samples");
+    // The queue by INDEX instead of by shifting (9 v_mov_b64 per step): step i uses entry i mod 3 and refills it with
+    // sample i + 3; after three steps the rotation has closed.  (RENORM is not a multiple of 3: the block's last one
+    // or two steps take the shifting form below, on a queue that is in canonical order again.)
+    for (; i + 3 <= i1; i += 3) {
+      { const double a = tq[0], b_ = dq[0], c_ = yq[0]; refill(0); one_step(i, a, b_, c_); }
+      { const double a = tq[1], b_ = dq[1], c_ = yq[1]; refill(1); one_step(i + 1, a, b_, c_); }
+      { const double a = tq[2], b_ = dq[2], c_ = yq[2]; refill(2); one_step(i + 2, a, b_, c_); }
+    }
+#endif
+    for (; i < i1; ++i) {
+      const double t_cur_next = tq[0], diag_cur = dq[0], y_cur = yq[0];
+#pragma unroll
+      for (int k = 0; k + 1 < PF; ++k) { tq[k] = tq[k + 1]; dq[k] = dq[k + 1]; yq[k] = yq[k + 1]; }
+      refill(PF - 1);
+      one_step(i, t_cur_next, diag_cur, y_cur);
     }
     lp0.renorm();  // (RENORM factors in [0.5, 1) since the last one)
     {  // multiply the accumulated decay out (the rider does the same to Abar, bbar)
