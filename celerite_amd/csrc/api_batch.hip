@@ -53,7 +53,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->ends})
+                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->ends, &h->sT, &h->sD, &h->sY})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -206,6 +206,7 @@ static int warm_plan_chunks(clr_batch* h) {
   h->wKpad = std::min(128, h->wL / 2);  // rows of warm-up every chunk's column carries (the largest candidate)
   h->wrows = h->wKpad + h->wL + 8;
   h->warm_copy_pending = true;
+  h->small_copy_pending = true;
   const size_t pc = (size_t)h->B * nc, START = (size_t)h->launch->start_doubles;
   int st;
   if ((st = h->wstarts.reserve(pc * START)) != CLR_OK) return st;
@@ -318,6 +319,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->warm_span.clear();
   h->relayout_pending = true;
   h->warm_copy_pending = true;
+  h->small_copy_pending = true;
   h->grad_span_valid = false;
   const clr::CopyJob jobs[3] = {{h->t.p, t, count(t_stride)}, {h->diag.p, diag, count(diag_stride)}, {h->y.p, y, count(y_stride)}};
   const size_t total = (jobs[0].n + jobs[1].n + jobs[2].n) * sizeof(double);
@@ -372,6 +374,7 @@ int clr_batch_set_series(clr_batch* h, const double* t, long t_stride, const dou
   h->grad_span_valid = false;
   h->relayout_pending = true;
   h->warm_copy_pending = true;
+  h->small_copy_pending = true;
   // a new series: the warm-ups chosen for the previous one's spans do not apply, nor does its history of fallbacks
   if (h->warm_mode < 0) h->warm_boost = 0;
   warm_select(h);
@@ -932,6 +935,39 @@ static bool small_runs(const clr_batch* h, int materialize) {
   return !h->pipeline_pinned && sel_B(h) <= (h->J >= 3 ? 256 : 1024);
 }
 
+// The one-launch path's view of the series: lane = chunk of ceil(N / 256) samples, so the row-major arrays would be read
+// with a stride of one chunk between the lanes -- every load instruction touches 64 cache lines of which it uses 8 bytes
+// each, and the 768 lines a workgroup walks (256 lanes x 3 arrays) do not fit the CU's vector L1: each line is fetched
+// from L2 sixteen times (BASELINE configs[1]: 3.8 MB per problem through a 64-B/clk port -- the summarize phase was
+// bound by exactly that, profiles/r06l_config1_ab.txt).  The kernel therefore reads a chunk-interleaved copy
+// [problem][i][chunk] made once per set_series (launch_relayout with the path's own chunking, padded as the plan's copy):
+// one coalesced 512-B load per array, wave and step.
+static int small_params(clr_batch* h, clr::BatchParams& Sp) {
+  h->in_fallback = true;  // (the plan's row-major arrays, no role split)
+  int st = batch_params(h, 0, Sp);
+  h->in_fallback = false;
+  if (st != CLR_OK) return st;
+  const int T = 256, L = (h->N + T - 1) / T;
+  const long cells = (long)L * T;
+  auto nsrc = [&](long sd) { return (size_t)(sd == 0 ? 1 : h->B); };
+  if ((st = h->sT.reserve(nsrc(h->t_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->sD.reserve(nsrc(h->diag_stride) * cells)) != CLR_OK) return st;
+  if ((st = h->sY.reserve(nsrc(h->y_stride) * cells)) != CLR_OK) return st;
+  if (h->small_copy_pending) {
+    struct { DevBuf* src; DevBuf* dst; long stride; int pad; } jobs[3] = {
+        {&h->t, &h->sT, h->t_stride, 1}, {&h->diag, &h->sD, h->diag_stride, 2}, {&h->y, &h->sY, h->y_stride, 0}};
+    for (auto& j : jobs)
+      clr::launch_relayout(j.src->p, j.stride, j.dst->p, j.stride ? cells : 0, j.stride ? h->B : 1, h->N, L, T, j.pad, h->stream);
+    h->small_copy_pending = false;
+  }
+  Sp.t = h->sT.p; Sp.diag = h->sD.p; Sp.y = h->sY.p;
+  Sp.t_stride = h->t_stride ? cells : 0;
+  Sp.diag_stride = h->diag_stride ? cells : 0;
+  Sp.y_stride = h->y_stride ? cells : 0;
+  Sp.lane_is = T; Sp.lane_cs = 1;
+  return CLR_OK;
+}
+
 static bool warm_runs(const clr_batch* h, int materialize) {
   if (h->grad_scan_only) return false;
   return h->launch && h->warm_active && !materialize && !h->force_exact && h->nchunk > 1 && h->wnchunk > 1;
@@ -1263,10 +1299,7 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
   h->rescue_inflight = false;
   if (!warm_runs(h, materialize) && small_runs(h, materialize)) {
     clr::BatchParams Sp;
-    h->in_fallback = true;  // (the row-major arrays)
-    st = batch_params(h, 0, Sp);
-    h->in_fallback = false;
-    if (st != CLR_OK) return st;
+    if ((st = small_params(h, Sp)) != CLR_OK) return st;
     mark(1);
     clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
     mark(2); mark(3); mark(4); mark(5); mark(6);
@@ -1457,6 +1490,7 @@ static int rescue_run(clr_batch* h, const std::vector<int>& idx, long n_total) {
   r->have_series = true;
   r->relayout_pending = true;
   r->warm_copy_pending = true;
+  r->small_copy_pending = true;
   r->grad_span_valid = false;
   r->factor_inputs_changed = true;
   const size_t total = (size_t)n * (2 * h->J_real + 4 * h->J_comp + 1);
@@ -1870,10 +1904,8 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
     }
     if (!warm_runs(h, materialize) && small_runs(h, materialize)) {  // (one launch, in the "summarize" slot)
       clr::BatchParams Sp;
-      h->in_fallback = true;
-      st = batch_params(h, 0, Sp);
-      h->in_fallback = false;
-      if (st != CLR_OK) return st;
+      if (relayout_each_step) h->small_copy_pending = true;  // (new series every step: the copy is rebuilt inside it)
+      if ((st = small_params(h, Sp)) != CLR_OK) return st;
       HIP_TRY(hipEventRecord(e[1], h->stream));
       clr::launch_small_batch(h->J_real, h->J_comp, Sp, 256, h->stream);
       for (int j = 2; j <= 6; ++j) HIP_TRY(hipEventRecord(e[j], h->stream));

@@ -273,6 +273,8 @@ struct clr_batch {
   DevBuf wT, wD, wY;                  // the warm kernel's padded chunk-interleaved copy of the series
   int wKpad = 0, wrows = 0;
   bool warm_copy_pending = true;
+  DevBuf sT, sD, sY;                  // the one-launch path's chunk-interleaved copy of the series (small_params, api_batch.hip)
+  bool small_copy_pending = true;
   int* wints = nullptr;               // wflags [B * wnchunk] | need_scan [B] | K [B]
   size_t wints_cap = 0;
   // general terms for the whole batch (clr_batch_set_general): the plan then evaluates through the any-width sequential
@@ -491,6 +493,10 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.ends = nullptr;
   P.fixup_steps = 0;
   P.refine_samples = 0;
+  {  // (the rotation of the phases needs |d dx| < 2^-5 at every step; the decay is not involved)
+    const double dmax = sel_max(h->dmax, h->floor_dmax), dxmax = sel_max(h->dxmax, h->floor_dxmax);
+    P.dense = (h->have_series && h->have_coeffs && dmax * dxmax < 0.03125) ? 1 : 0;
+  }
   if (materialize && h->nchunk > 1 && h->factor_refine > 0 && h->J_general == 0 && h->J <= clr::wide_max_width()) {
     size_t START = 0;
     if (h->launch) START = (size_t)h->launch->start_doubles;

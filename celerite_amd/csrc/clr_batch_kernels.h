@@ -87,6 +87,7 @@ struct BatchParams {
   // oracle's own distance from the binary128 truth).
   double* ends;       // [B][nchunk][START] or null
   int fixup_steps;    // > 0: this launch is the fix-up pass
+  int dense;          // the plan's series are densely sampled: max |d| x max dx < 2^-5 (the phases may advance by rotations)
   int refine_samples; // the setting (samples per chunk head) the flow launches the fix-up pass with
   int defer_level1;   // problems the conditioning record sends to the checked chunked replay (level 1) are NOT replayed
                       // inline -- one flagged problem would cost the whole batch a sequential chunk-time -- but left with

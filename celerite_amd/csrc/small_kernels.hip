@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(256) small_compute_kernel(const SmallParams P)
 // runs the scan pipeline (with all its routes) for those problems before it hands results out, as behind the
 // warm-started recurrence (clr_batch_kernels.h).
 // ---------------------------------------------------------------------------------------------------------------
-template <int JR, int JC, bool FAST>
+// DENSE: the plan's series are densely sampled (BatchParams::dense, lazy_eligible on the host): the complex terms'
+// phases advance by small-angle rotations (summarize_chunk, DENSE) -- the summarize phase is issue-bound (one wave per
+// SIMD at one instruction per ~2.4 ns), so its instruction count is its time.
+template <int JR, int JC, bool FAST, bool DENSE>
 __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, int L) {
   using Wd = Widths<JR, JC>;
   constexpr int J = Wd::J, SZ = Wd::SZ, ELEM = Wd::ELEM;
@@ -158,9 +161,10 @@ __global__ void __launch_bounds__(256) small_batch_kernel(const BatchParams P, i
   double ld0 = 0.0, q0 = 0.0, gamma = 0.0;
   int flag0 = 0;
   {
-    DirectSeries src{P.t + (long)b * P.t_stride + (long)c * L, P.diag + (long)b * P.diag_stride + (long)c * L,
-                     P.y + (long)b * P.y_stride + (long)c * L, 1, L, L, (long)N - (long)c * L};
-    summarize_chunk<JR, JC, FAST>(p, src, L, c * L, N, true, e, &ld0, &q0, &flag0, &gamma);
+    // (the chunk-interleaved copy: lane_is = 256, lane_cs = 1 -- api_batch.hip: small_params)
+    DirectSeries src{P.t + (long)b * P.t_stride + (long)c * P.lane_cs, P.diag + (long)b * P.diag_stride + (long)c * P.lane_cs,
+                     P.y + (long)b * P.y_stride + (long)c * P.lane_cs, P.lane_is, P.lane_cs, L, (long)N - (long)c * L};
+    summarize_chunk<JR, JC, FAST, DirectSeries, DENSE>(p, src, L, c * L, N, true, e, &ld0, &q0, &flag0, &gamma);
   }
 #pragma unroll
   for (int k = 0; k < ELEM; ++k) own[k] = (k >= J * J + J + SZ) ? e[k] : 0.0;  // (eta | Jm; the rest is never read)
@@ -249,8 +253,10 @@ bool go_batch(const BatchParams& P, int threads, hipStream_t s) {
   constexpr int ELEM = Widths<JR, JC>::ELEM;
   const int L = (P.N + threads - 1) / threads;
   const size_t lds = (size_t)(ELEM > 8 ? ELEM : 8) * threads * sizeof(double);
-  if (P.fast_trig) hipLaunchKernelGGL((small_batch_kernel<JR, JC, true>), dim3(P.B), dim3(threads), lds, s, P, L);
-  else hipLaunchKernelGGL((small_batch_kernel<JR, JC, false>), dim3(P.B), dim3(threads), lds, s, P, L);
+  if (P.fast_trig) {
+    if (P.dense && JC > 0) hipLaunchKernelGGL((small_batch_kernel<JR, JC, true, true>), dim3(P.B), dim3(threads), lds, s, P, L);
+    else hipLaunchKernelGGL((small_batch_kernel<JR, JC, true, false>), dim3(P.B), dim3(threads), lds, s, P, L);
+  } else hipLaunchKernelGGL((small_batch_kernel<JR, JC, false, false>), dim3(P.B), dim3(threads), lds, s, P, L);
   return true;
 }
 
