@@ -241,10 +241,15 @@ def spawn_ranks(n, argv):
 def real_loop(plan, draws, steps, offset=0):
     """`steps` optimiser-style evaluations: upload a fresh draw, launch, fetch the results."""
     out = None
+    evaluate = getattr(plan, "evaluate", None)
     for k in range(steps):
-        plan.set_coefficients(*draws[(offset + k) % len(draws)])
-        plan.enqueue()
-        out = plan.results()
+        d = draws[(offset + k) % len(draws)]
+        if evaluate is not None:            # one library call: set_coefficients + enqueue + results (clr_batch_evaluate)
+            out = evaluate(*d)
+        else:
+            plan.set_coefficients(*d)
+            plan.enqueue()
+            out = plan.results()
     return out
 
 

@@ -214,6 +214,7 @@ class BatchedGP(object):
         if not self._h:
             raise RuntimeError("clr_batch_create failed: " + lib.clr_last_error().decode())
         self._h = C.c_void_p(self._h)
+        self._evaluate_fn = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -318,6 +319,30 @@ class BatchedGP(object):
         st = np.empty(self.B, dtype=np.int32)
         _check(_load().clr_batch_get_results(self._h, _ptr(ll), _ptr(ld), _ptr(q),
                                              st.ctypes.data_as(_ip)))
+        return ll, ld, q, st
+
+    def evaluate(self, a_real, c_real, a_comp, b_comp, c_comp, d_comp, jitter=0.0):
+        """One optimiser / MCMC evaluation in ONE library call (``clr_batch_evaluate``): new coefficient tables in,
+        ``(loglike, logdet, quad, status)`` of all B problems out -- ``set_coefficients`` + ``enqueue`` + ``results``
+        without two of the three trips through ctypes.  Arrays that already are C-contiguous float64 of the right shape
+        are passed as they are."""
+        B, JR, JC = self.B, self.J_real, self.J_comp
+        tabs = []
+        for a, w in ((a_real, JR), (c_real, JR), (a_comp, JC), (b_comp, JC), (c_comp, JC), (d_comp, JC)):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (B, w)):
+                try:
+                    a = _f64(a, (B, w))
+                except ValueError:
+                    raise ValueError("dimension mismatch")
+            tabs.append(a)
+        jit = np.ascontiguousarray(np.broadcast_to(np.asarray(jitter, dtype=np.float64), (B,)))
+        ll, ld, q, st = np.empty(B), np.empty(B), np.empty(B), np.empty(B, dtype=np.int32)
+        fn = self._evaluate_fn
+        if fn is None:
+            fn = _load().clr_batch_evaluate
+            fn.argtypes = [C.c_void_p] * 12      # (plain addresses: ndarray.ctypes.data is cheaper than data_as)
+            self._evaluate_fn = fn
+        _check(fn(self._h, jit.ctypes.data, *([a.ctypes.data for a in tabs] + [ll.ctypes.data, ld.ctypes.data, q.ctypes.data, st.ctypes.data])))
         return ll, ld, q, st
 
     def log_likelihood(self, materialize=False):

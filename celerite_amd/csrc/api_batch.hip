@@ -1974,6 +1974,17 @@ int clr_batch_run_timed(clr_batch* h, int materialize, int steps, int relayout_e
   return CLR_OK;
 }
 
+// one optimiser / MCMC evaluation in one call: new coefficients in, the B results out (celerite.py:160-219 per problem:
+// set_parameter_vector -> compute -> log_likelihood)
+int clr_batch_evaluate(clr_batch* h, const double* jitter, const double* a_real, const double* c_real,
+                       const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
+                       double* loglike, double* logdet, double* quad, int* status) {
+  int st = clr_batch_set_coefficients(h, jitter, a_real, c_real, a_comp, b_comp, c_comp, d_comp);
+  if (st == CLR_OK) st = clr_batch_enqueue(h, 0);
+  if (st == CLR_OK) st = clr_batch_get_results(h, loglike, logdet, quad, status);
+  return st;
+}
+
 int clr_batch_log_likelihood(int B, int N, int J_real, int J_comp, const double* jitter,
                              const double* a_real, const double* c_real, const double* a_comp,
                              const double* b_comp, const double* c_comp, const double* d_comp,

@@ -450,6 +450,12 @@ int clr_batch_synchronize(clr_batch* h);
 /* HBM -> host; any pointer may be NULL. */
 int clr_batch_get_results(clr_batch* h, double* loglike, double* logdet,
                           double* quad, int* status);
+/* One optimiser / MCMC evaluation (celerite.py:160-219 per problem: new parameters -> compute -> log_likelihood) in
+ * one call: clr_batch_set_coefficients + clr_batch_enqueue(h, 0) + clr_batch_get_results.  For launch-latency-sized
+ * batches (BASELINE configs[1]: a 65-us kernel) the three separate calls of a Python caller cost as much as the kernel. */
+int clr_batch_evaluate(clr_batch* h, const double* jitter, const double* a_real, const double* c_real,
+                       const double* a_comp, const double* b_comp, const double* c_comp, const double* d_comp,
+                       double* loglike, double* logdet, double* quad, int* status);
 /* CholeskySolver::solve (cholesky.h:218-318) for every problem of the plan at once: x = K_p^-1 b_p from the factor of
  * the last materialising run (clr_batch_enqueue(h, 1); either factor layout), parallel in n -- forward substitution,
  * division by D and backward substitution as two chunked affine scans whose chunk maps are formed once and shared by

@@ -61,6 +61,28 @@ def test_config2_shape():
     check(synthetic(256, 10000, 0, 2, "bench", seed=2))
 
 
+def test_evaluate_is_the_three_calls_in_one():
+    """``clr_batch_evaluate`` (new coefficients in, results out, one library call) equals ``set_coefficients`` +
+    ``enqueue`` + ``results`` bit for bit -- on the scan pipeline, the one-launch path of short narrow problems and a wide
+    plan -- with non-contiguous / non-float64 inputs converted, a scalar and a per-problem jitter."""
+    for B, N, JR, JC in ((6, 5000, 2, 3), (40, 3000, 0, 2), (3, 4000, 0, 8)):
+        case = synthetic(B, N, JR, JC, "bench", seed=B)
+        plan = batch.BatchedGP(B, N, JR, JC)
+        try:
+            plan.set_series(case["t"], case["diag"], case["y"])
+            for jit in (0.0, np.linspace(0.0, 0.1, B)):
+                plan.set_coefficients(*coeffs_of(case), jitter=jit)
+                want = plan.log_likelihood()
+                got = plan.evaluate(*coeffs_of(case), jitter=jit)
+                odd = plan.evaluate(*[np.asfortranarray(c) if c.ndim == 2 else c for c in coeffs_of(case)], jitter=jit)
+                for a, b_, c_ in zip(want, got, odd):
+                    assert np.array_equal(a, b_, equal_nan=True) and np.array_equal(a, c_, equal_nan=True)
+            with pytest.raises(ValueError):
+                plan.evaluate(*[c[:-1] for c in coeffs_of(case)])
+        finally:
+            plan.close()
+
+
 def test_shared_series_many_draws():
     """One light curve, B hyper-parameter draws (stride-0 series)."""
     case = synthetic(64, 5000, 2, 3, "bench", seed=11)

@@ -4,7 +4,7 @@
 # Usage: bash tools/prof_run_r05.sh [headline] [wide] [accuracy] [sweeps] [grad]
 set -u
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof_r05
+OUT=$PWD/gpurun_out/prof_${PROF_TAG:-r05}
 mkdir -p "$OUT"
 WHAT="${*:-headline wide accuracy}"
 BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --no-accuracy-family --no-gradient --sharded 0 --no-config3 --steady-seconds 0 --settle-seconds 0"
