@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 src = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
 
 
 def table(name):
@@ -47,8 +47,9 @@ rec = {
         "summarize (single wave)": traffic(hf, hw, "summarize_kernel<2, 3, true, true"),
         "prefix": None,
         "correct": traffic(hf, hw, "correct_kernel<8>"),
-        "replay (materialising)": traffic(hf, hw, "replay_kernel<2, 3, 2, true, false"),
-        "replay (materialising, lean)": traffic(hf, hw, "replay_kernel<2, 3, 3, true, false"),
+        "replay (materialising)": traffic(hf, hw, "replay_kernel<2, 3, 2, true, false, false>"),
+        "replay (materialising, lean)": traffic(hf, hw, "replay_kernel<2, 3, 3, true, false, false>"),
+        "chunk-head fix-up of a materialising run (round 6)": traffic(hf, hw, "replay_kernel<2, 3, 2, true, false, true>"),
     },
     "other_shapes": dict(old.get("other_shapes", {})),
 }
