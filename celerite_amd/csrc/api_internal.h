@@ -173,6 +173,15 @@ struct clr_solver {
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
   DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix; level buffers of the wide parallel prefix
   DevBuf gradbuf;                       // grad_log_likelihood staging
+  // The factor's chunk heads (clr_batch_kernels.h, BatchParams::ends): compute() writes the factor from the SCANNED
+  // start states, whose rounding shows in W and D for the ~32 samples the recurrence needs to forget it -- with the ~50
+  // to 100-sample chunks of one long series that is most of the factor (N = 1e5, width 8: W 1.1e-10, solve 1.8e-10 of
+  // the oracle, profiles/r06n_solver_factor_error.txt).  log_determinant and the hinted dot_solve do not depend on it,
+  // so GP.log_likelihood pays nothing: the FIRST call that reads the factor (solve, dot_solve of another vector, dot_L,
+  // predict, __getstate__) replays every chunk once more from the state the previous chunk's replay reached.
+  DevBuf keep_diag, keep_jitter, ws_ends;  // compute's diag / jitter (kept for that pass), the chunks' end states
+  clr::BatchParams refine_P;
+  int refine_pending = 0;               // 0 nothing to do, 1 narrow plan kernels, 2 wide kernels
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   // clr_solver_hint_rhs: the right-hand side the caller is about to pass to dot_solve; the next compute
   // folds b^T K^-1 b into its own pass over the series and dot_solve returns it for that very vector

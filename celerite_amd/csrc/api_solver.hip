@@ -122,7 +122,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
-                      &s->scratch, &s->scratch2, &s->scalars, &s->ws_elems, &s->ws_starts,
+                      &s->scratch, &s->scratch2, &s->scalars, &s->keep_diag, &s->keep_jitter, &s->ws_ends, &s->ws_elems, &s->ws_starts,
                       &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs, &s->ws_lvl_elems, &s->ws_lvl_starts})
       b->release();
     for (DevBuf& b : s->dot_buf) b.release();
@@ -144,6 +144,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
                        int n_x, const double* x, int n_diag, const double* diag) {
   const int N = n_x;
   s->computed = 0;  // cholesky.h:57
+  s->refine_pending = 0;
   s->have_quad = false;
   const bool use_rhs = s->rhs_hint && (int)s->host_rhs.size() == N;
   s->rhs_hint = false;  // (one shot)
@@ -254,8 +255,8 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   } else if (!has_general && J <= 8 && clr::find_batch_launchers(J_real, J_comp)) {
     // fixed-width chunked scan, materialising the reference-layout factor
     const clr::BatchLaunchers* L = clr::find_batch_launchers(J_real, J_comp);
-    if ((st = stage_upload(s, s->scratch, diag, (size_t)N)) != CLR_OK) return st;
-    if ((st = stage_upload(s, s->scratch2, &jitter, 1)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->keep_diag, diag, (size_t)N)) != CLR_OK) return st;   // (kept: the chunk-head pass reads them again)
+    if ((st = stage_upload(s, s->keep_jitter, &jitter, 1)) != CLR_OK) return st;
     clr::BatchParams P;
     memset(&P, 0, sizeof(P));
     P.B = 1;
@@ -287,12 +288,16 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if ((st = s->ws_cond.reserve((size_t)P.nchunk * 4)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, (size_t)P.nchunk + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
-    P.jitter = s->scratch2.p;
+    P.jitter = s->keep_jitter.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
     // row-major arrays; with more than one chunk the kernels stage them through LDS
     if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
-    P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
+    P.t = s->t.p; P.diag = s->keep_diag.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
+    if (P.nchunk > 1) {
+      if ((st = s->ws_ends.reserve((size_t)P.nchunk * L->start_doubles)) != CLR_OK) return st;
+      P.ends = s->ws_ends.p;
+    }
     P.lane_is = 1; P.lane_cs = P.L;
     P.staged = P.nchunk > 1 ? 1 : 0;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p; P.part = s->ws_part.p;
@@ -320,13 +325,19 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     memcpy(&h_status, &back[3], sizeof(int));
     h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
     if (use_rhs && !h_status) { s->cached_quad = back[2]; s->have_quad = true; }
+    if (!h_status && P.ends) {  // the chunk heads once more, when the factor is first read (ensure_refined)
+      s->refine_P = P;
+      s->refine_P.y = s->t.p;       // (the pass writes factor entries only; the hinted rhs may be gone by then)
+      s->refine_P.logdet_only = 1;
+      s->refine_pending = 1;
+    }
   } else if (!has_general && J >= 9 && J <= clr::wide_max_width()) {
     // widths 9..64 without general terms: the batched wide kernels on one problem -- one wave per
     // chunk with S distributed over the lanes, up to 16 chunks chained by the scan (widths <= 32),
     // the replay writing the factor in the reference's storage (instead of factor_generic_kernel:
     // one workgroup, five barriers per step)
-    if ((st = stage_upload(s, s->scratch, diag, (size_t)N)) != CLR_OK) return st;
-    if ((st = stage_upload(s, s->scratch2, &jitter, 1)) != CLR_OK) return st;
+    if ((st = stage_upload(s, s->keep_diag, diag, (size_t)N)) != CLR_OK) return st;   // (kept: the chunk-head pass reads them again)
+    if ((st = stage_upload(s, s->keep_jitter, &jitter, 1)) != CLR_OK) return st;
     clr::BatchParams P;
     memset(&P, 0, sizeof(P));
     P.B = 1;
@@ -371,11 +382,15 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if ((st = s->ws_cond.reserve(pc * 4)) != CLR_OK) return st;
     if ((st = reserve_flags(s->ws_flags, s->ws_flags_cap, 2 * pc + 1)) != CLR_OK) return st;
     const clr::GenericProblem g = generic_view(s);
-    P.jitter = s->scratch2.p;
+    P.jitter = s->keep_jitter.p;
     P.a_real = g.a_real; P.c_real = g.c_real;
     P.a_comp = g.a_comp; P.b_comp = g.b_comp; P.c_comp = g.c_comp; P.d_comp = g.d_comp;
     if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
-    P.t = s->t.p; P.diag = s->scratch.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
+    P.t = s->t.p; P.diag = s->keep_diag.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
+    if (P.nchunk > 1) {  // (refine_samples stays 0: wide_flow does not run the pass itself, ensure_refined does later)
+      if ((st = s->ws_ends.reserve(pc * (SZP + JP))) != CLR_OK) return st;
+      P.ends = s->ws_ends.p;
+    }
     P.lane_is = 1; P.lane_cs = P.L;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p;
     P.part = s->ws_part.p; P.partx = s->ws_part.p + pc * 2;
@@ -391,6 +406,12 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     {
       const int wst = wide_flow(P, J_real, J_comp, stream, nullptr);
       if (wst != CLR_OK) return wst;
+    }
+    if (P.ends) {
+      s->refine_P = P;
+      s->refine_P.y = s->t.p;
+      s->refine_P.logdet_only = 1;
+      s->refine_pending = 2;  // (dropped below when the factorisation failed)
     }
     HIP_TRY(hipGetLastError());
     double back_local[4];
@@ -595,6 +616,8 @@ static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, do
   return CLR_OK;
 }
 
+static int ensure_refined(clr_solver* s);
+
 int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double* out) {
   clr_solver* s = const_cast<clr_solver*>(cs);
   if (n_b != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");  // :327
@@ -607,6 +630,7 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   }
   int st = ensure_stream(s);
   if (st != CLR_OK) return st;
+  if ((st = ensure_refined(s)) != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
   if (sweep_scan_ok(s)) {
@@ -621,11 +645,29 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   return CLR_OK;
 }
 
+// the factor is about to be read: the pending pass over the chunk heads (clr_solver::refine_pending) runs first -- every
+// chunk once more from the state the previous chunk's replay reached (fixup_steps = the chunk length)
+static int ensure_refined(clr_solver* s) {
+  if (!s->refine_pending || !s->computed) return CLR_OK;
+  clr::BatchParams F = s->refine_P;
+  F.fixup_steps = F.L + (F.L0 > F.L ? F.L0 - F.L : 0);
+  if (s->refine_pending == 1) {
+    const clr::BatchLaunchers* L = clr::find_batch_launchers(s->J_real, s->J_comp);
+    if (L) L->replay(F, 1, s->stream);
+  } else {
+    clr::launch_wide_loglike(F, s->J_real, s->J_comp, s->stream);
+  }
+  s->refine_pending = 0;
+  HIP_TRY(hipGetLastError());
+  return CLR_OK;
+}
+
 static int sweep_common(clr_solver* s, int rows, int nrhs, const double* in) {
   if (rows != s->N) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
   if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
   int st = ensure_stream(s);
   if (st != CLR_OK) return st;
+  if ((st = ensure_refined(s)) != CLR_OK) return st;
   const size_t n = (size_t)s->N * (size_t)std::max(nrhs, 0);
   if ((st = upload(s->scratch, in, n, s->stream)) != CLR_OK) return st;
   return s->scratch2.reserve(n);
@@ -859,6 +901,7 @@ int clr_solver_get_state(const clr_solver* cs, double* phi, double* u, double* W
   if (!s->computed) return fail(CLR_NOT_COMPUTED, "you must call 'compute' first");
   int st = ensure_stream(s);
   if (st != CLR_OK) return st;
+  if ((st = ensure_refined(s)) != CLR_OK) return st;
   const size_t N = (size_t)s->N, J = (size_t)s->J, Nm1 = N - 1;
   if (J * Nm1) {
     HIP_TRY(hipMemcpyAsync(phi, s->phi.p, sizeof(double) * J * Nm1, hipMemcpyDeviceToHost, s->stream));
@@ -876,6 +919,7 @@ int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_d
   // solver.cpp:44-58: plain member assignment; coefficients and t are NOT part
   // of the state (so predict is unavailable afterwards, as in the reference).
   s->computed = 0;
+  s->refine_pending = 0;
   s->N = N;
   s->J = J;
   s->log_det = log_det;

@@ -580,6 +580,8 @@ __global__ void __launch_bounds__(64) replay_kernel(const BatchParams P) {
   int flag;
   const long Nm1 = P.N - 1;
   constexpr bool fixup = FIXUP;
+  // (a problem the sequential recurrence settled -- level >= 2 -- keeps ITS factor: wave-uniform)
+  if (fixup && P.need_exact && P.need_exact[b] >= 2) return;
   if (fixup && !STAGED && c == 0) return;  // (chunk 0 starts from the exact zero state: nothing to refine)
   const double* start = (mine && c > 0) ? (fixup ? P.ends + ((long)b * P.nchunk + c - 1) * Wd::START
                                                  : P.starts + ((long)b * P.nchunk + c) * Wd::START) : nullptr;
@@ -1044,8 +1046,8 @@ struct BatchImpl {
 #define CLR_GOF2(M)                                                                \
   if (P.fast_trig) { if (P.staged) CLR_GOF(M, true, true); else CLR_GOF(M, true, false); } \
   else             { if (P.staged) CLR_GOF(M, false, true); else CLR_GOF(M, false, false); }
-    if (P.fixup_steps > 0) {  // (the chunk heads of a materialising run, chunk-interleaved layouts only)
-      if (materialize == 3) { CLR_GOF2(3) } else if (materialize == 2) { CLR_GOF2(2) }
+    if (P.fixup_steps > 0) {  // (the chunk heads of a materialising run; mode 1: the object API's lazy pass, api_solver.hip)
+      if (materialize == 3) { CLR_GOF2(3) } else if (materialize == 2) { CLR_GOF2(2) } else if (materialize == 1) { CLR_GOF2(1) }
       return;
     }
     if (materialize == 3) { CLR_GO2(3) } else if (materialize == 2) { CLR_GO2(2) } else if (materialize == 1) { CLR_GO2(1) } else { CLR_GO2(0) }

@@ -354,7 +354,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // (materialising runs, BatchParams::ends / fixup_steps: the fix-up pass recomputes the heads of the chunks c >= 1 from
   //  the state the previous chunk's replay reached at the boundary -- clr_batch_kernels.h, replay_kernel has the story)
   const bool fixup = MODE == 0 && P.fixup_steps > 0;
-  if (fixup && chunk == 0) return;
+  if (fixup && (chunk == 0 || P.need_exact[b] >= 2)) return;  // (level >= 2: the sequential pass wrote that problem's factor)
   const int n_lo = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk));  // (wave-uniform by construction: keep the loop counters scalar)
   const int n_end = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk + 1));
   const int n_hi = fixup ? (n_lo + P.fixup_steps < n_end ? n_lo + P.fixup_steps : n_end) : n_end;

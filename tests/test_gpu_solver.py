@@ -22,7 +22,7 @@ from celerite_amd.solver import get_kernel_value, LinAlgError
 from oracle import dense, ref
 from _cases import (COEFFS_W4, COEFFS_W10, COEFFS_DOT, COEFFS_PICKLE, COEFFS_CC_REAL, COEFFS_CC_COMP,
                     NO_GENERAL, FIRST_TUTORIAL_LOGLIKE, first_tutorial_case, general_terms,
-                    logdet_case, solve_case, synthetic, coeffs_of)
+                    logdet_case, solve_case, synthetic, coeffs_of, within)
 
 pytestmark = pytest.mark.gpu
 REL = 1e-10  # north-star tolerance on log_determinant and dot_solve
@@ -876,3 +876,48 @@ def test_dot_long_series_is_a_chunked_scan(JR, JC, N, general):
         K[np.diag_indices_from(K)] += gen[0]
         K += np.tril(np.dot(gen[1].T, gen[2]), -1) + np.triu(np.dot(gen[2].T, gen[1]), 1)
     assert np.allclose(np.dot(K, z), y, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("JR,JC,spread", [(2, 3, False), (0, 8, True), (0, 16, True)])
+def test_long_series_factor_and_solve_are_as_accurate_as_the_sequential_recurrence(JR, JC, spread):
+    """Round 6: one series of 1e5 samples through ``CholeskySolver`` (the reference's own API, cholesky.h:41-318).  The
+    factor is written chunk by chunk from SCANNED start states whose rounding showed in W and D at the chunk heads -- with
+    ~50-sample chunks that was most of the factor: W 1.1e-10, ``solve`` 1.8e-10 of the oracle at width 8
+    (profiles/r06n_solver_factor_error.txt).  The first call that reads the factor now replays the chunks once more from
+    the previous chunk's replayed end state: the state (W, D), ``solve``, ``dot_solve`` of a fresh vector, ``dot_L`` and
+    ``predict`` within 2e-11 of the oracle, in whatever order they are first called; ``log_determinant`` and the hinted
+    ``dot_solve`` (GP.log_likelihood) are what they were; a pickled solver carries the refined factor."""
+    from bench import make_inputs
+    N = 100000
+    coeffs, t, diag, y = make_inputs(1, N, JR, JC, 42, d_spread=spread)
+    cs = [c[0] for c in coeffs]
+    e_, e2_ = np.empty(0), np.empty((0, 0))
+    r = ref.RefSolver()
+    r.compute(0.0, *cs, e_, e2_, e2_, t[0], diag[0])
+    _, _, J, logdet, rphi, ru, rW, rD = r.state()
+    rng = np.random.RandomState(5)
+    z = rng.randn(N)
+    xs = np.sort(rng.uniform(t[0].min(), t[0].max(), 500))
+    want = {"solve": r.solve(y[0])[:, 0], "dot_solve": r.dot_solve(z), "dot_L": r.dot_L(z)[:, 0], "predict": r.predict(y[0], xs)}
+    calls = {"solve": lambda s: s.solve(y[0])[:, 0], "dot_solve": lambda s: s.dot_solve(z), "dot_L": lambda s: s.dot_L(z)[:, 0],
+             "predict": lambda s: s.predict(y[0], xs)}
+    for first in ("solve", "dot_L", "predict", "dot_solve", "state"):
+        s = celerite_amd.CholeskySolver()
+        s._hint_rhs(y[0])
+        s.compute(0.0, *cs, e_, e2_, e2_, t[0], diag[0])
+        assert abs(s.log_determinant() - logdet) <= 1e-12 * abs(logdet)
+        assert abs(s.dot_solve(y[0]) - r.dot_solve(y[0])) <= 1e-11 * abs(r.dot_solve(y[0]))    # (the hinted vector: no factor read)
+        order = [first] + [k for k in calls if k != first] if first != "state" else list(calls)
+        if first == "state":
+            s = pickle.loads(pickle.dumps(s, -1))
+        for k in order:
+            got = np.atleast_1d(calls[k](s)) if (first != "state" or k != "predict") else None
+            if got is None:
+                continue                                   # (a restored solver cannot predict: solver.cpp:36-42)
+            w = np.atleast_1d(want[k])
+            within("one long series (N = 1e5) through CholeskySolver, %s vs oracle (of the largest)" % k,
+                   np.max(np.abs(got - w)) / np.max(np.abs(w)), 2e-11, (JR, JC, first))
+        st = s.__getstate__()
+        W, D = np.asarray(st[6]).reshape(rW.shape), np.asarray(st[7])
+        within("one long series (N = 1e5) through CholeskySolver, state: W vs oracle (of the largest entry)", np.max(np.abs(W - rW)) / np.max(np.abs(rW)), 1e-11, (JR, JC, first))
+        within("one long series (N = 1e5) through CholeskySolver, state: D vs oracle (relative)", np.max(np.abs(D - rD) / np.abs(rD)), 1e-11, (JR, JC, first))
