@@ -156,7 +156,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   const bool has_general = (n_A != 0);
   const int J_general = U_rows, J_real = n_a_real, J_comp = n_a_comp;
   const int J = J_real + 2 * J_comp + J_general;
-  if (J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  if (J > CLR_MAX_WIDTH_ANY) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH_ANY");
   // rows of U/V are only read when general terms are active (cholesky.h:148-152
   // would read them regardless; a non-empty U with empty A is a caller error)
   if (J_general > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
@@ -440,6 +440,10 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       if ((st = upload(s->V, V, (size_t)J_general * N, stream)) != CLR_OK) return st;
     }
     const clr::GenericProblem g = generic_view(s);
+    if (J > CLR_MAX_WIDTH) {  // S (J^2 doubles) in HBM / L2 instead of LDS (huge_kernels.hip)
+      if ((st = s->ws_elems.reserve(clr::factor_huge_workspace_doubles(J))) != CLR_OK) return st;
+      clr::launch_factor_huge(g, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
+    } else
     clr::launch_factor_generic(g, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p,
                                stream);
     HIP_TRY(hipGetLastError());
@@ -633,7 +637,9 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   if ((st = ensure_refined(s)) != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
-  if (sweep_scan_ok(s)) {
+  if (s->J > CLR_MAX_WIDTH) {
+    clr::launch_dot_solve_huge(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scalars.p, s->stream);
+  } else if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, nullptr, s->scalars.p, 0)) != CLR_OK) return st;
   } else {
     clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
@@ -678,7 +684,9 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
   int st = sweep_common(s, b_rows, nrhs, b);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  if (sweep_scan_ok(s)) {
+  if (s->J > CLR_MAX_WIDTH) {
+    clr::launch_solve_huge(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scratch2.p, s->stream);
+  } else if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, nrhs, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;   // :240-248
     if ((st = sweep_scan(s, nrhs, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;  // :249-259
   } else {
@@ -694,6 +702,7 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
 
 int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z, double* y) {
   clr_solver* s = const_cast<clr_solver*>(cs);
+  if (s->computed && s->J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "dot_L covers widths up to CLR_MAX_WIDTH (128)");
   int st = sweep_common(s, z_rows, nrhs, z);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
@@ -836,6 +845,7 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
 int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, const double* xs,
                        double* pred) {
   clr_solver* s = const_cast<clr_solver*>(cs);
+  if (s->computed && s->J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "predict covers widths up to CLR_MAX_WIDTH (128)");
   int st = sweep_common(s, n_y, 1, y);  // also checks N / computed (:600-601)
   if (st != CLR_OK) return st;
   if (M <= 0) return CLR_OK;
@@ -925,7 +935,7 @@ int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_d
   s->log_det = log_det;
   s->J_real = s->J_comp = s->J_general = 0;
   if (!computed) return CLR_OK;
-  if (J < 0 || J > CLR_MAX_WIDTH || N < 1) return fail(CLR_INVALID_ARGUMENT, "Invalid state!");
+  if (J < 0 || J > CLR_MAX_WIDTH_ANY || N < 1) return fail(CLR_INVALID_ARGUMENT, "Invalid state!");
   int st = ensure_stream(s);
   if (st != CLR_OK) return st;
   const size_t Nn = (size_t)N, Jn = (size_t)J, Nm1 = Nn - 1;

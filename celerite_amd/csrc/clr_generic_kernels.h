@@ -157,6 +157,14 @@ void launch_dot(int N, int J, int nrhs, const double* phi, const double* u, cons
 // cholesky.h:599-698 given alpha = K^-1 y.
 void launch_predict(const GenericProblem& g, const double* alpha, int M, const double* xs,
                     double* pred, hipStream_t s);
+// widths above CLR_MAX_WIDTH up to CLR_MAX_WIDTH_ANY (huge_kernels.hip): S in HBM, one workgroup per problem / right-hand side
+size_t factor_huge_workspace_doubles(int J);
+void launch_factor_huge(const GenericProblem& g, double* S, double* phi, double* u, double* W, double* D, int* status,
+                        double* log_det, hipStream_t s);
+void launch_dot_solve_huge(int N, int J, const double* phi, const double* u, const double* W, const double* D,
+                           const double* b, double* out, hipStream_t s);
+void launch_solve_huge(int N, int J, int nrhs, const double* phi, const double* u, const double* W, const double* D,
+                       const double* b, double* x, hipStream_t s);
 // J == 0 and small element-wise helpers.
 void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,
                       hipStream_t s);

@@ -46,6 +46,10 @@ typedef enum clr_status {
 
 /* Widest semiseparable rank J = J_real + 2 J_comp + J_general accepted. */
 #define CLR_MAX_WIDTH 128
+/* CholeskySolver.compute / log_determinant / dot_solve / solve take ANY width up to this one (round 6; the reference's
+ * dynamic-width arm, cholesky.h:203, has no limit and its benchmark goes to 512): above CLR_MAX_WIDTH the state S lives
+ * in HBM / L2 instead of LDS (csrc/huge_kernels.hip).  Everything else stops at CLR_MAX_WIDTH. */
+#define CLR_MAX_WIDTH_ANY 1024
 #define CLR_CARMA_MAX_ORDER 32 /* autoregressive order p of clr_carma (state p, covariance p x p in LDS) */
 
 /* ---- library / device ------------------------------------------------------ */
