@@ -182,6 +182,10 @@ struct clr_solver {
   DevBuf keep_diag, keep_jitter, ws_ends;  // compute's diag / jitter (kept for that pass), the chunks' end states
   clr::BatchParams refine_P;
   int refine_pending = 0;               // 0 nothing to do, 1 narrow plan kernels, 2 wide kernels
+  // the route the last compute took through the chunked flow (clr_solver_debug_route): device pointers into the workspace
+  const int* route_level = nullptr;
+  const double* route_cond = nullptr;
+  int route_nchunk = 0;
   std::vector<double> host_coeffs;      // staging of the last upload (kept alive: async copy)
   // clr_solver_hint_rhs: the right-hand side the caller is about to pass to dot_solve; the next compute
   // folds b^T K^-1 b into its own pass over the series and dot_solve returns it for that very vector
@@ -477,6 +481,7 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.cert_eg = h->cert_eg;
   P.egerr = h->cond.p + (size_t)h->B * h->nchunk * 3;
   P.cert_resid = h->cert_resid;
+  P.head_cap = clr::output_check_cap(); P.head_tol = clr::output_check_tol();  // (materialising wide plans: BatchParams::head_check)
   {
     const size_t pc = B * (size_t)h->nchunk;
     P.partx = h->partx.p; P.flagsx = h->flags + pc; P.need_exact = h->flags + 2 * pc;
@@ -499,7 +504,7 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
   P.only_pending = h->in_fallback ? 1 : 0;
   P.defer_level1 = defer_runs(h, materialize) ? 1 : 0;
   P.wide_materialize = (materialize && !h->launch) ? 1 : 0;
-  P.ends = nullptr;
+  P.ends = nullptr; P.ends_alt = nullptr; P.ends_in = nullptr;
   P.fixup_steps = 0;
   P.refine_samples = 0;
   {  // (the rotation of the phases needs |d dx| < 2^-5 at every step; the decay is not involved)
@@ -510,8 +515,9 @@ int batch_params(clr_batch* h, int materialize, clr::BatchParams& P) {
     size_t START = 0;
     if (h->launch) START = (size_t)h->launch->start_doubles;
     else { const size_t JP = (size_t)clr::wide_padded_width(h->J); START = JP * (JP + 1) / 2 + JP; }
-    if ((st = h->ends.reserve((size_t)h->B * h->nchunk * START)) != CLR_OK) return st;
+    if ((st = h->ends.reserve((size_t)h->B * h->nchunk * START * (h->launch ? 1 : 2))) != CLR_OK) return st;
     P.ends = h->ends.p;
+    if (!h->launch) P.ends_alt = h->ends.p + (size_t)h->B * h->nchunk * START;  // (wide plans: the output check's second buffer)
     // (the recurrence needs a few J samples to forget a start state: wide plans take the setting per 16 rows of state)
     P.refine_samples = h->launch ? h->factor_refine : h->factor_refine * (clr::wide_padded_width(h->J) / 16);
   }
@@ -574,13 +580,31 @@ int wide_flow(clr::BatchParams& P, int J_real, int J_comp, hipStream_t stream, h
   // one chunk: the sweep itself; several: the chunked replay of forced runs and of the problems the
   // conditioning record marked (level 1), with its end states checked against the scan
   clr::launch_wide_loglike(P, J_real, J_comp, stream);
+  if (P.nchunk > 1) {
+    clr::launch_wide_check_replay(P, stream);
+    if (P.head_cap > 0.0 && P.ends && P.ends_alt && P.wide_materialize && P.cond) {
+      // end states off the scanned start states, but not by much (level 3): the chunks again, each from the previous
+      // chunk's replayed end state, until what two consecutive replays wrote agrees (BatchParams::head_check); an even
+      // number of attempts, so that P.ends holds the last (or last but one: equal to head_tol) end states for the fix-up
+      int attempts = 4;
+      if (const char* e = clr::option("CLR_OUTPUT_CHECK_ATTEMPTS")) attempts = std::max(1, std::min(atoi(e), 16));  // (tools/gpu_reference_family_factor.py)
+      for (int k = 0; k < attempts; ++k) {
+        clr::BatchParams F = P;
+        F.fixup_steps = P.L + (P.L0 > P.L ? P.L0 - P.L : 0);
+        F.head_check = (k + 1 == attempts) ? 2 : 1;
+        F.ends_in = (k & 1) ? P.ends_alt : P.ends;
+        F.ends = (k & 1) ? P.ends : P.ends_alt;
+        clr::launch_wide_loglike(F, J_real, J_comp, stream);
+        clr::launch_wide_head_decide(F, stream);
+      }
+    }
+  }
   if (P.nchunk > 1 && P.ends && P.wide_materialize && P.refine_samples > 0) {
     clr::BatchParams F = P;  // the heads of the chunks again, from the previous chunk's replayed end state
     F.fixup_steps = P.refine_samples;
     clr::launch_wide_loglike(F, J_real, J_comp, stream);
   }
   if (P.nchunk > 1) {
-    clr::launch_wide_check_replay(P, stream);
     clr::launch_finalize(P, stream);
     clr::BatchParams S = P;  // the flagged problems, sequentially
     S.nchunk = 1; S.L = P.N; S.L0 = 0; S.seq_only = 1; S.force_exact = 1; S.ends = nullptr; S.fixup_steps = 0;

@@ -33,6 +33,14 @@ const char* option(const char* key) {
   }
   return env_allowed() ? getenv(key) : nullptr;
 }
+double output_check_cap() {
+  if (const char* e = option("CLR_OUTPUT_CHECK_CAP")) return atof(e);
+  return 1e-6;
+}
+double output_check_tol() {
+  if (const char* e = option("CLR_OUTPUT_CHECK_TOL")) return atof(e);
+  return 2e-11;
+}
 }  // namespace clr
 
 namespace {

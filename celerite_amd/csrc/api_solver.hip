@@ -106,6 +106,12 @@ int stage_upload(clr_solver* s, DevBuf& buf, const double* host, size_t n) {
 
 }  // namespace
 
+// the end-state mismatch of the chunked replay that still counts as consistent (tuning: CLR_SOLVER_CERT_RESID)
+static double solver_cert_resid() {
+  if (const char* e = clr::option("CLR_SOLVER_CERT_RESID")) return atof(e);
+  return 1e-11;
+}
+
 extern "C" {
 
 /* ---- single-problem solver --------------------------------------------------- */
@@ -145,6 +151,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   const int N = n_x;
   s->computed = 0;  // cholesky.h:57
   s->refine_pending = 0;
+  s->route_level = nullptr; s->route_nchunk = 0;
   s->have_quad = false;
   const bool use_rhs = s->rhs_hint && (int)s->host_rhs.size() == N;
   s->rhs_hint = false;  // (one shot)
@@ -307,7 +314,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
     P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
-    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = solver_cert_resid(); P.logdet_only = use_rhs ? 0 : 1;
     if (P.nchunk < 2) HIP_TRY(hipMemsetAsync(P.need_exact, 0, sizeof(int), stream));  // (no prefix kernel clears it)
     L->summarize(P, stream);
     L->prefix(P, stream);
@@ -325,6 +332,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     memcpy(&h_status, &back[3], sizeof(int));
     h_status = (h_status == CLR_NOT_POSITIVE_DEFINITE) ? 1 : 0;
     if (use_rhs && !h_status) { s->cached_quad = back[2]; s->have_quad = true; }
+    s->route_level = P.need_exact; s->route_cond = P.cond; s->route_nchunk = P.nchunk;
     if (!h_status && P.ends) {  // the chunk heads once more, when the factor is first read (ensure_refined)
       s->refine_P = P;
       s->refine_P.y = s->t.p;       // (the pass writes factor entries only; the hinted rhs may be gone by then)
@@ -388,16 +396,18 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
     P.t = s->t.p; P.diag = s->keep_diag.p; P.y = use_rhs ? s->rhs.p : s->t.p;  // (without a hinted rhs y is irrelevant)
     if (P.nchunk > 1) {  // (refine_samples stays 0: wide_flow does not run the pass itself, ensure_refined does later)
-      if ((st = s->ws_ends.reserve(pc * (SZP + JP))) != CLR_OK) return st;
+      if ((st = s->ws_ends.reserve(2 * pc * (SZP + JP))) != CLR_OK) return st;
       P.ends = s->ws_ends.p;
+      P.ends_alt = s->ws_ends.p + pc * (SZP + JP);  // (the output check's second buffer: BatchParams::head_check)
     }
     P.lane_is = 1; P.lane_cs = P.L;
     P.elems = s->ws_elems.p; P.starts = s->ws_starts.p;
     P.part = s->ws_part.p; P.partx = s->ws_part.p + pc * 2;
     P.flags = s->ws_flags; P.flagsx = s->ws_flags + pc; P.need_exact = s->ws_flags + 2 * pc;
-    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = 1e-11; P.logdet_only = use_rhs ? 0 : 1;
+    P.cond = s->ws_cond.p; P.cert_gamma = 1e7; P.cert_gamma_abs = 1e4; P.cert_eg = 3e-9; P.egerr = s->ws_cond.p + (size_t)P.nchunk * 3; P.cert_resid = solver_cert_resid(); P.logdet_only = use_rhs ? 0 : 1;
     P.force_exact = 1;       // the factor is wanted: every chunk is replayed (and checked against the scan)
     P.wide_materialize = 1;
+    P.head_cap = clr::output_check_cap(); P.head_tol = clr::output_check_tol();  // (a state mismatch no output sees: BatchParams::head_check)
     P.coop_prefix = P.scan_ws ? 2 : 1;  // (2: the parallel prefix, wide_prefix_scan.hip)
     P.out_ll = s->scalars.p; P.out_logdet = s->scalars.p + 1; P.out_quad = s->scalars.p + 2;
     P.out_status = reinterpret_cast<int*>(s->scalars.p + 3);
@@ -413,6 +423,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       s->refine_P.logdet_only = 1;
       s->refine_pending = 2;  // (dropped below when the factorisation failed)
     }
+    s->route_level = P.need_exact; s->route_cond = P.cond; s->route_nchunk = P.nchunk;
     HIP_TRY(hipGetLastError());
     double back_local[4];
     double* pinned_back = arena_take(s, 4);
@@ -621,6 +632,27 @@ static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, do
 }
 
 static int ensure_refined(clr_solver* s);
+
+int clr_solver_debug_route(const clr_solver* cs, int* level, int* nchunk, double* residual) {
+  clr_solver* s = const_cast<clr_solver*>(cs);
+  if (level) *level = -1;
+  if (nchunk) *nchunk = 0;
+  if (residual) *residual = 0.0;
+  if (!s->computed || !s->route_level || s->route_nchunk < 2) return CLR_OK;
+  int st = ensure_stream(s);
+  if (st != CLR_OK) return st;
+  int lv = -1;
+  std::vector<double> rec((size_t)s->route_nchunk * 3);
+  HIP_TRY(hipMemcpyAsync(&lv, s->route_level, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (s->route_cond) HIP_TRY(hipMemcpyAsync(rec.data(), s->route_cond, rec.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double r = 0.0;
+  for (int c = 0; c < s->route_nchunk; ++c) { const double v = rec[(size_t)c * 3 + 2]; r = (v != v) ? INFINITY : std::max(r, v); }
+  if (level) *level = lv;
+  if (nchunk) *nchunk = s->route_nchunk;
+  if (residual) *residual = r;
+  return CLR_OK;
+}
 
 int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double* out) {
   clr_solver* s = const_cast<clr_solver*>(cs);

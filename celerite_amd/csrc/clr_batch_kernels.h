@@ -100,6 +100,22 @@ struct BatchParams {
   double cert_eg;         // ... or whose gamma_max x (largest measured G error of its chunks) reaches this (<= 0: no test)
   double cert_resid;  // largest relative mismatch between a replayed chunk's end state and the scanned
                       // start state of the next chunk that still counts as consistent
+  // Output check (round 6).  A state mismatch above cert_resid need not show in any output: with IDENTICAL (or nearly
+  // identical) terms -- the reference's own benchmark kernels, examples/benchmark/run.py:80-84 -- the state has directions
+  // no u_n ever probes, rounding of the scan algebra and of the recurrence collect there without being forgotten, and the
+  // END-STATE test sends a problem whose factor agrees with the oracle to 1e-12 to the sequential recurrence (width 16,
+  // N = 65536: 29.6 ms instead of 0.6; profiles/r06q_family_factor.txt).  Such a problem (level 3: state mismatch in
+  // (cert_resid, head_cap]) is replayed again, every chunk c >= 1 from the END state of chunk c - 1's previous replay --
+  // the recurrence carried across the boundary -- and what the two replays WROTE is compared: D relatively, W against
+  // the chunk's largest entry.  Within head_tol: settled (level 1) -- consecutive replays that agree are the sequential
+  // recurrence's own factor to that tolerance (what the outputs see of a start state is forgotten along a chunk; replay
+  // k is exact up to chunk k) -- and the last replay's entries, sums and flags stand; else once more from the new end
+  // states (`ends_in` / `ends` swap), after the last attempt the sequential recurrence.
+  int head_check;     // this fix-up launch is that check (2: the last attempt): level-3 problems only, cond[.][2] = the output mismatch
+  const double* ends_in;  // ... the end states it starts from (`ends`: the ones it writes)
+  double* ends_alt;       // the flow's second buffer of end states ([B][nchunk][START]; null: no output check)
+  double head_cap;    // > 0: the route is on (check_replay kernels raise level 3 instead of 2 up to this state mismatch)
+  double head_tol;    // largest output mismatch that counts as agreement
   // chunk-parallel gradient (clr_grad_kernels.h): riders [B][nchunk][RID], records [B][nchunk][NG][OUT], result [B][NG]
   double *g_riders, *g_out, *g_res;
   int g_m, g_nchunk;      // a gradient chunk = g_m chunks of the scan; g_nchunk = ceil(nchunk / g_m)
@@ -1172,6 +1188,7 @@ inline int wide_padded_width(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64);
 // decide_kernel at the padded widths of the wide scan
 void launch_wide_decide(const BatchParams& P, int width_padded, hipStream_t s);
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s);
+void launch_wide_head_decide(const BatchParams& P, hipStream_t s);
 // Per-problem reduction of the chunk partials + the -inf rules (api_kernels.hip).
 void launch_finalize(const BatchParams& P, hipStream_t s);
 // One problem's interleaved factor -> the reference's storage (api_kernels.hip).

@@ -7,4 +7,9 @@
 namespace clr {
 // null when the option is not set; the pointer is valid until the calling thread's next call
 const char* option(const char* key);
+// the output check of a chunked replay whose end states missed the scanned start states (BatchParams::head_check):
+// largest state mismatch it is attempted for (CLR_OUTPUT_CHECK_CAP, default 1e-6; 0: route off) and largest output
+// mismatch that settles the problem (CLR_OUTPUT_CHECK_TOL, default 2e-11)
+double output_check_cap();
+double output_check_tol();
 }  // namespace clr

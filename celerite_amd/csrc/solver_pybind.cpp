@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/celerite_hip.h"
+#include "../../include/celerite_hip_debug.h"
 
 namespace py = pybind11;
 
@@ -287,6 +288,16 @@ PYBIND11_MODULE(solver, m) {
           },
           "not in the reference: announce the vector of the coming dot_solve so that the next compute folds "
           "its quadratic form into the factorisation pass (clr_solver_hint_rhs)");
+
+  cls.def("_route",
+          [](Solver& s) {
+            int level = -1, nchunk = 0;
+            double residual = 0.0;
+            check(clr_solver_debug_route(s.h(), &level, &nchunk, &residual));
+            return std::make_tuple(level, nchunk, residual);
+          },
+          "not in the reference: (level, chunks, residual) of the last compute's chunked flow (clr_solver_debug_route, "
+          "include/celerite_hip_debug.h); level -1: the flow was not taken");
 
   cls.def("dot_L",
           [](Solver& s, const darray& z) {

@@ -354,7 +354,16 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
   // (materialising runs, BatchParams::ends / fixup_steps: the fix-up pass recomputes the heads of the chunks c >= 1 from
   //  the state the previous chunk's replay reached at the boundary -- clr_batch_kernels.h, replay_kernel has the story)
   const bool fixup = MODE == 0 && P.fixup_steps > 0;
-  if (fixup && (chunk == 0 || P.need_exact[b] >= 2)) return;  // (level >= 2: the sequential pass wrote that problem's factor)
+  // (the output check -- BatchParams::head_check -- is the same pass for the problems at level 3 only; the plain fix-up
+  //  leaves level >= 2 alone: the sequential pass writes that problem's factor)
+  const bool hcheck = fixup && P.head_check != 0;
+  if (hcheck && P.need_exact[b] != 3) return;
+  if (hcheck && chunk == 0) {  // (chunk 0 starts from the exact zero state: its replay stands, its end state moves on)
+    for (int i = tid; i < START; i += 64 * NW) P.ends[(long)b * P.nchunk * START + i] = P.ends_in[(long)b * P.nchunk * START + i];
+    return;
+  }
+  if (fixup && !hcheck && (chunk == 0 || P.need_exact[b] >= 2)) return;
+  float hc_dd = 0.f, hc_dw = 0.f, hc_wm = 0.f;  // (output check) largest |D / D' - 1|, |w - w'|, |w'| against the entries in place
   const int n_lo = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk));  // (wave-uniform by construction: keep the loop counters scalar)
   const int n_end = __builtin_amdgcn_readfirstlane(wide_chunk_begin(P, chunk + 1));
   const int n_hi = fixup ? (n_lo + P.fixup_steps < n_end ? n_lo + P.fixup_steps : n_end) : n_end;
@@ -365,7 +374,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
 #pragma unroll
   for (int c = 0; c < COLS; ++c) S[c] = 0.0;
   if (MODE == 0 && chunk > 0) {  // start state of this chunk (packed upper triangle | f), from the prefix phase
-    const double* st = fixup ? P.ends + (slot - 1) * START : P.starts + slot * START;
+    const double* st = fixup ? (hcheck ? P.ends_in : P.ends) + (slot - 1) * START : P.starts + slot * START;
 #pragma unroll
     for (int c = 0; c < COLS; ++c) S[c] = st[sym(row, seg * COLS + c)];
     f = st[SZ + row];
@@ -725,6 +734,17 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
         // the factor in the reference's storage, element (j, n) at [j + W n]: W[:, n], D[n],
         // u[:, n - 1] = U~(t_n), phi[:, n] = decay n -> n + 1 (cholesky.h:131-151, :177-178)
         const long Wl = W;
+        if (hcheck) {  // what the first replay wrote (a NaN difference counts as infinite)
+          const double wo = P.W[(long)b * Wl * N + Wl * n + row];
+          const float dw = (float)fabs(w - wo), wm = (float)fabs(wo);
+          if (!(dw <= hc_dw)) hc_dw = (dw != dw) ? INFINITY : dw;
+          if (!(wm <= hc_wm)) hc_wm = (wm != wm) ? INFINITY : wm;
+          if (row == 0) {
+            const double Do = P.D[(long)b * N + n];
+            const float dd = (float)fabs((D - Do) / Do);
+            if (!(dd <= hc_dd)) hc_dd = (dd != dd) ? INFINITY : dd;
+          }
+        }
         P.W[(long)b * Wl * N + Wl * n + row] = w;
         if (row == 0) P.D[(long)b * N + n] = D;
         if (n >= 1) P.u[(long)b * Wl * (N - 1) + Wl * (n - 1) + row] = u;
@@ -880,7 +900,27 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     }
     return;
   }
-  if (fixup) return;  // (factor entries only: sums, flags and the record stand)
+  if (fixup) {  // (factor entries only: sums, flags and the record stand)
+    if (hcheck && P.cond) {  // the output mismatch of this chunk, where the replay had left its end-state residual
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) {
+        hc_dd = fmaxf(hc_dd, __shfl_xor(hc_dd, m, 64));
+        hc_dw = fmaxf(hc_dw, __shfl_xor(hc_dw, m, 64));
+        hc_wm = fmaxf(hc_wm, __shfl_xor(hc_wm, m, 64));
+      }
+      if (NW == 2) {  // the other wave's rows
+        xsync();
+        if (lane == 0) { xbuf[4 * wvi] = hc_dd; xbuf[4 * wvi + 1] = hc_dw; xbuf[4 * wvi + 2] = hc_wm; }
+        xsync();
+        hc_dd = fmaxf((float)xbuf[0], (float)xbuf[4]); hc_dw = fmaxf((float)xbuf[1], (float)xbuf[5]); hc_wm = fmaxf((float)xbuf[2], (float)xbuf[6]);
+      }
+      if (tid == 0) {
+        const double rw = (hc_wm > 0.f) ? (double)hc_dw / (double)hc_wm : (hc_dw == 0.f ? 0.0 : (double)INFINITY);
+        P.cond[slot * 3 + 2] = fmax((double)hc_dd, rw);
+      }
+    }
+    if (!hcheck) return;  // (the output check is a whole replay: its end state, sums and flags replace the first one's)
+  }
   if (MODE == 0 && P.nchunk > 1 && P.ends) {  // the state at the chunk's end, for the fix-up pass
     double* e = P.ends + slot * START;
 #pragma unroll
@@ -890,7 +930,7 @@ __device__ __forceinline__ void wide_scan_body(const BatchParams& P, int JR, int
     }
     if (writer) e[SZ + row] = f;
   }
-  if (MODE == 0 && P.nchunk > 1 && P.cond) {
+  if (MODE == 0 && P.nchunk > 1 && P.cond && !hcheck) {
     // end state of this chunk against the scanned start state of the next one (as replay_kernel)
     double dp = 0.0, pm = 0.0, df = 0.0, fm = 0.0;
     if (chunk + 1 < P.nchunk) {
@@ -1695,7 +1735,24 @@ __global__ void __launch_bounds__(64) wide_check_replay_kernel(const BatchParams
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
-  if (lane == 0 && !(r <= P.cert_resid)) P.need_exact[b] = 2;
+  // (level 3: the outputs of a second replay decide -- BatchParams::head_check)
+  if (lane == 0 && !(r <= P.cert_resid)) P.need_exact[b] = (P.head_cap > 0.0 && P.ends && P.ends_alt && P.wide_materialize && r <= P.head_cap) ? 3 : 2;
+}
+// after the output check's pass: level 3 -> 1 (the two replays wrote the same factor to head_tol) or 2 (sequential)
+__global__ void __launch_bounds__(64) wide_head_decide_kernel(const BatchParams P) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (P.need_exact[b] != 3) return;
+  double r = 0.0;
+  for (int c = lane; c < P.nchunk; c += 64) {
+    const double rc = c == 0 ? 0.0 : P.cond[((long)b * P.nchunk + c) * 3 + 2];   // (chunk 0 starts from the exact zero state: its record is the end-state residual still)
+    r = (rc != rc) ? INFINITY : fmax(r, rc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
+  if (lane == 0 && (r <= P.head_tol || P.head_check == 2)) P.need_exact[b] = (r <= P.head_tol) ? 1 : 2;   // (head_check == 2: the last attempt)
+}
+void launch_wide_head_decide(const BatchParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(wide_head_decide_kernel, dim3(P.B), dim3(64), 0, s, P);
 }
 void launch_wide_check_replay(const BatchParams& P, hipStream_t s) {
   hipLaunchKernelGGL(wide_check_replay_kernel, dim3(P.B), dim3(64), 0, s, P);

@@ -83,6 +83,10 @@ int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
  *   CLR_NO_SMALL_SOLVER      CholeskySolver: never the one-workgroup kernel of short narrow problems
  *   CLR_WIDE_WALK            widths 17..32: prefix + corrections as one walk per problem (cross-check of the two-kernel path)
  *   CLR_WIDE_PREFIX_WALK     CholeskySolver at widths 9..32: the sequential walk instead of the parallel prefix
+ *   CLR_OUTPUT_CHECK_CAP, CLR_OUTPUT_CHECK_TOL   materialising replays at widths 9..64 whose end states miss the scanned start
+ *                            states by more than the certificate's bound but less than CAP (default 1e-6; 0: off) are
+ *                            settled by comparing what a second replay writes (within TOL, default 2e-11) instead of
+ *                            going to the sequential recurrence; CLR_SOLVER_CERT_RESID: that bound for CholeskySolver (1e-11)
  *   CLR_WIDE_NO_PAIRED, CLR_WIDE64_ONE_WAVE, CLR_WIDE_LAZY_BOUND, CLR_WIDE_FIRST_RATIO, CLR_WIDE_FIRST_RATIO64,
  *   CLR_WIDE_SCAN_CAP, CLR_SOLVER_WIDE_CHUNKS, CLR_PREDICT_CHUNKS, CLR_WSWEEP_RUN, CLR_WSWEEP_CHUNKS   (tuning runs, tools/)
  * clr_get_option: the value in force (NULL: not set); the pointer is valid until the calling thread's next call. */

@@ -21,6 +21,13 @@ extern "C" {
  * 78.6 TFLOP/s assumes 4 cycles at 2.4 GHz.  Any pointer may be NULL. */
 int clr_device_measure_fp64(int waves_per_simd, int iters, double* tflops, double* clock_mhz, double* cycles_per_fma);
 
+/* Which route the last clr_solver_compute took through the chunked flow (widths 1..64 without general terms, more than
+ * one chunk; otherwise level = -1): level 0 / 1 the chunked replay from the scanned start states stands, 2 the sequential
+ * recurrence; residual = the largest entry of the chunks' record -- after a replay that met the scanned start states its
+ * relative end-state mismatch, after the output check (BatchParams::head_check; a state mismatch above the certificate's
+ * bound) the largest mismatch of what the two replays wrote. */
+int clr_solver_debug_route(const clr_solver* s, int* level, int* nchunk, double* residual);
+
 /* Diagnostics (tests): the chunk start states of the last evaluation, [B][nchunk][J(J+1)/2 + J] (packed upper
  * triangle of P, then f) ... */
 int clr_batch_debug_get_starts(clr_batch* h, double* starts);

@@ -968,3 +968,87 @@ def test_any_width_above_128_through_the_object_api(JR, JC, N):
     assert not s3.computed()
     with pytest.raises(RuntimeError):        # ... and above CLR_MAX_WIDTH_ANY: refused
         celerite_amd.CholeskySolver().compute(0.0, np.ones(1100), np.ones(1100), E0, E0, E0, E0, *NO_GENERAL, t, diag)
+
+
+def _reference_benchmark_kernel(width):
+    """The kernels of the reference's own benchmark (examples/benchmark/run.py:80-84): real terms (1.0, 0.1) and IDENTICAL
+    complex terms (0.1, 2.0, 1.6) up to the width asked for."""
+    j = width // 2
+    kernel = terms.RealTerm(1.0, 0.1)
+    for _ in range((2 * j - 1) % 2):
+        kernel += terms.RealTerm(1.0, 0.1)
+    for _ in range((2 * j - 1) // 2):
+        kernel += terms.ComplexTerm(0.1, 2.0, 1.6)
+    return kernel
+
+
+@pytest.mark.parametrize("width,N", [(16, 8192), (16, 65536), (32, 8192), (32, 65536)])
+def test_reference_benchmark_kernels_are_settled_by_the_output_check(width, N):
+    """Round 6: identical terms leave directions of the state no sample ever probes; the rounding of the scan and of the
+    recurrence collects there, the chunked replay's END STATES miss the scanned start states by 1.2e-11 .. 2.8e-11 (bound
+    1e-11) and ``CholeskySolver.compute`` used to hand the reference's own benchmark problems to the sequential recurrence
+    (width 16, N = 65536: 29.6 ms against the CPU's 11.2; profiles/r06q_family_factor.txt).  Now the chunks are replayed
+    again from the previous replay's end states until what two consecutive replays WROTE agrees to 2e-11
+    (BatchParams::head_check): level 1, the factor within the sequential recurrence's own distance of the oracle -- and
+    with the check switched off the same problem still takes the sequential route and gives the same answers."""
+    rng = np.random.RandomState(42)
+    t = np.sort(rng.rand(2 ** 19))[:N]
+    yerr = rng.uniform(0.1, 0.2, 2 ** 19)[:N]
+    y = np.sin(t)
+    cs = [np.asarray(c, dtype=float) for c in _reference_benchmark_kernel(width).coefficients]
+    e_, e2_ = np.empty(0), np.empty((0, 0))
+    r = ref.RefSolver()
+    r.compute(0.0, *cs, e_, e2_, e2_, t, yerr ** 2)
+    _, _, J, logdet, rphi, ru, rW, rD = r.state()
+    assert J == width
+    want_solve, want_quad = r.solve(y)[:, 0], r.dot_solve(y)
+    got = {}
+    for check in (True, False):
+        batch.set_option("CLR_OUTPUT_CHECK_CAP", None if check else "0")
+        try:
+            s = celerite_amd.CholeskySolver()
+            s._hint_rhs(y)
+            s.compute(0.0, *cs, e_, e2_, e2_, t, yerr ** 2)
+            level, nchunk, residual = s._route()
+        finally:
+            batch.set_option("CLR_OUTPUT_CHECK_CAP", None)
+        assert nchunk > 1
+        if check:
+            assert level == 1 and residual <= 2e-11, (level, residual)    # (settled by consecutive replays that agree)
+        else:
+            assert level == 2 and residual > 1e-11, (level, residual)     # (the end-state test alone: sequential)
+        tag = (width, N, "output check" if check else "end-state test only")
+        within("reference benchmark kernels through CholeskySolver: log det vs oracle", abs(s.log_determinant() - logdet) / abs(logdet), 1e-12, tag)
+        within("reference benchmark kernels through CholeskySolver: hinted dot_solve vs oracle", abs(s.dot_solve(y) - want_quad) / abs(want_quad), 1e-11, tag)
+        sv = s.solve(y)[:, 0]
+        within("reference benchmark kernels through CholeskySolver: solve vs oracle (of the largest)", np.max(np.abs(sv - want_solve)) / np.max(np.abs(want_solve)), 2e-11, tag)
+        st = s.__getstate__()
+        W, D = np.asarray(st[6]).reshape(rW.shape), np.asarray(st[7])
+        within("reference benchmark kernels through CholeskySolver: W vs oracle (of the largest entry)", np.max(np.abs(W - rW)) / np.max(np.abs(rW)), 2e-11, tag)
+        within("reference benchmark kernels through CholeskySolver: D vs oracle (relative)", np.max(np.abs(D - rD) / np.abs(rD)), 3e-11, tag)
+        got[check] = (s.log_determinant(), sv)
+    assert abs(got[True][0] - got[False][0]) <= 1e-12 * abs(logdet)
+
+
+def test_output_check_that_never_agrees_ends_in_the_sequential_recurrence():
+    """The other exit of the output check: with an unreachable tolerance every attempt fails and the problem is settled by
+    the sequential recurrence -- same answers, level 2."""
+    N, width = 8192, 16
+    rng = np.random.RandomState(42)
+    t = np.sort(rng.rand(2 ** 19))[:N]
+    yerr = rng.uniform(0.1, 0.2, 2 ** 19)[:N]
+    cs = [np.asarray(c, dtype=float) for c in _reference_benchmark_kernel(width).coefficients]
+    e_, e2_ = np.empty(0), np.empty((0, 0))
+    r = ref.RefSolver()
+    r.compute(0.0, *cs, e_, e2_, e2_, t, yerr ** 2)
+    batch.set_option("CLR_OUTPUT_CHECK_TOL", "1e-300")
+    try:
+        s = celerite_amd.CholeskySolver()
+        s.compute(0.0, *cs, e_, e2_, e2_, t, yerr ** 2)
+        level, nchunk, residual = s._route()
+    finally:
+        batch.set_option("CLR_OUTPUT_CHECK_TOL", None)
+    assert level == 2 and residual > 0.0
+    assert abs(s.log_determinant() - r.log_determinant()) <= 1e-12 * abs(r.log_determinant())
+    z = rng.randn(N)
+    assert abs(s.dot_solve(z) - r.dot_solve(z)) <= 1e-11 * abs(r.dot_solve(z))
