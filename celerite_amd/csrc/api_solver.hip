@@ -451,7 +451,14 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       if ((st = upload(s->V, V, (size_t)J_general * N, stream)) != CLR_OK) return st;
     }
     const clr::GenericProblem g = generic_view(s);
-    if (J > CLR_MAX_WIDTH) {  // S (J^2 doubles) in HBM / L2 instead of LDS (huge_kernels.hip)
+    if (J >= 33 && clr::factor_rows_supported(J) && !clr::option("CLR_NO_ROWS_KERNEL")) {
+      // S in the registers of 1 .. 64 workgroups (rows_kernels.hip; round 6: width 128 20.5 -> ~1 us per step)
+      if ((st = s->ws_elems.reserve(clr::factor_rows_workspace_doubles(J))) != CLR_OK) return st;
+      double dmax = 0.0;
+      for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
+      const int fast = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
+      clr::launch_factor_rows(g, fast, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
+    } else if (J > CLR_MAX_WIDTH) {  // S (J^2 doubles) in HBM / L2 instead of LDS (huge_kernels.hip)
       if ((st = s->ws_elems.reserve(clr::factor_huge_workspace_doubles(J))) != CLR_OK) return st;
       clr::launch_factor_huge(g, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
     } else
@@ -464,6 +471,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     HIP_TRY(hipStreamSynchronize(stream));
   }
 
+  if (h_status == 3) return fail(CLR_HIP_ERROR, "the workgroups of the row-distributed factorisation lost each other (rows_kernels.hip)");
   if (h_status != 0)
     return fail(CLR_NOT_POSITIVE_DEFINITE, "failed to factorize or solve matrix");
   s->log_det = h_logdet;

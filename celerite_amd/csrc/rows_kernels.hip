@@ -1,0 +1,294 @@
+// celerite_amd/csrc/rows_kernels.hip -- CholeskySolver.compute at widths 33 .. 1024 that the chunked scans do not take
+// (general terms above width 32, every width above 64): the reference's dynamic-width arm (cholesky.h:203), whose published
+// benchmark goes to width 512 (examples/benchmark/run.py:37-39).  Sequential in n like the reference, parallel over the
+// J^2 entries of the state, with S in REGISTERS:
+//
+//   layout     512 threads per workgroup; TPR adjacent lanes share a row of S, 32 columns each (64 registers); the padded
+//              width is JP = 32 TPR, a workgroup holds 512 / TPR rows, G = TPR^2 / 16 workgroups hold the matrix:
+//              width <= 128: TPR 4, one workgroup;  <= 256: TPR 8, 4 workgroups;  <= 512: TPR 16, 16;  <= 1024: TPR 32, 64.
+//              S is kept whole (both triangles): twice the arithmetic of the triangle, but q = S u~ is then a row sum
+//              with no mirrored contributions to exchange.
+//   a step     (Y) S <- phi phi^T o (S + D_{n-1} W W^T) (cholesky.h:154-160) and q = S u~ (:163-175) in ONE pass over the
+//              lane's 32 entries -- four vector instructions and 1.5 LDS reads (phi_k, W_k, u~_k: broadcast within a
+//              column block, the blocks 34 doubles apart = conflict-free) per entry; the row sum over the TPR lanes by
+//              shuffles; (X) D_n = d_n - u~ . q, W_n = (v~ - q) / D_n (:170-178), thread per row, and the NEXT sample's
+//              phi, u~, v~: its exp and sincos calls one per thread, whole waves of one kind, issued before the barrier
+//              (hidden behind the wait for the other workgroups), composed into the rows' features after it.
+//              Two workgroup barriers per step; generic_kernels.hip's LDS-resident kernel needs five and leaves 3 of 4
+//              threads idle in the matrix-vector product (width 128: 20.5 us per step there, the CPU 6.2).
+//   G > 1      the workgroups exchange their rows of q and their share of u~ . q through a double-buffered array in HBM
+//              (agent-scope atomic stores / loads: the 8 XCDs' L2s are not coherent for plain accesses) and meet at ONE
+//              counter barrier per step; every workgroup then forms D_n and all of W_n itself, in the same order -- bit-
+//              identical across workgroups, so a failed pivot (cholesky.h:176) is seen by all of them at the same step.
+//              At most 64 workgroups on 256 compute units: co-resident by construction; the spin is bounded all the same
+//              (status 3 instead of a hung queue).
+//
+// The sums run in another order than the reference's loops: results agree to rounding, not bit for bit (tests: 1e-10).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+
+#include "../../include/celerite_hip.h"
+#include "clr_generic_kernels.h"
+#include "clr_wide.h"
+
+namespace clr {
+
+namespace {
+
+constexpr int ROWS_THREADS = 512;
+constexpr int ROWS_COLS = 32;  // columns of S per lane
+
+__device__ __forceinline__ void agent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double agent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// column k of the per-column arrays in LDS: the 32-column blocks start 34 doubles apart, so that the TPR different blocks
+// a wave reads in one ds_read_b128 fall into different banks
+__device__ __forceinline__ int col_slot(int k) { return k + ((k >> 5) << 1); }
+
+struct RowsExchange {
+  double* q;           // [2][JP]  rows of q = S u~ of the step (parity of n)
+  double* part;        // [2][G]   the workgroups' shares of u~ . q
+  unsigned int* bar;   // arrivals, counted up over the whole run (zeroed before the launch)
+};
+
+// the row sum over the TPR adjacent lanes of a row, delivered to all of them (DPP butterflies, clr_wide.h)
+template <int TPR>
+__device__ __forceinline__ double rows_row_sum(double v) {
+  v = dpp_add<DPP_QUAD_XOR1>(v);
+  v = dpp_add<DPP_QUAD_XOR2>(v);
+  if (TPR >= 8) v = dpp_add<DPP_HALF_MIRROR>(v);
+  if (TPR >= 16) v = dpp_add<DPP_MIRROR>(v);
+  if (TPR >= 32) v = swap_add16(v);
+  return v;
+}
+
+template <int TPR, bool FAST>
+__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, double* phi, double* u, double* W, double* D,
+                                                                   int* status, double* log_det) {
+  constexpr int JP = ROWS_COLS * TPR, RB = ROWS_THREADS / TPR, G = JP / RB, SLOTS = 34 * TPR;
+  constexpr int RPT = (JP + ROWS_THREADS - 1) / ROWS_THREADS;  // rows per thread in the per-row phases
+  __shared__ __attribute__((aligned(16))) double sphi[SLOTS], su[SLOTS], sw[SLOTS];
+  __shared__ double sv[JP], sq[G == 1 ? JP : 1], spart[ROWS_THREADS / 64], sshare[G];
+  // the transcendental functions of a sample, one TASK per thread (whole waves of one kind: a wave whose lanes split
+  // between exp and sincos runs both): decay of real row i | decay of complex term i - J_real | sin, cos of term jj
+  __shared__ double sdecay[JP], ssin[JP / 2], scos[JP / 2];
+  __shared__ int sabort;
+  const int J = g.J, N = g.N, tid = threadIdx.x, wg = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int part = tid % TPR, row = wg * RB + tid / TPR;  // this lane's row of S and block of columns
+  const bool first = wg == 0;
+  const int JR = g.J_real, JC = g.J_comp, Wc = JR + 2 * JC, ndecay = JR + JC;
+
+  double S[ROWS_COLS];
+#pragma unroll
+  for (int c = 0; c < ROWS_COLS; ++c) S[c] = 0.0;
+  if (tid == 0) sabort = 0;
+
+  // this thread's tasks (rate of a decay / frequency of a phase) and the constants of the rows it composes
+  double trate[RPT];
+  int tkind[RPT];  // 0 none, 1 decay, 2 phase
+  double ra[RPT], rb[RPT];
+  int rkind[RPT], rsrc[RPT];  // 0 padding, 1 real, 2 complex even, 3 complex odd, 4 general; index of the decay / term / general row
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int k = tid + i * ROWS_THREADS;
+    tkind[i] = 0; trate[i] = 0.0;
+    if (k < ndecay) { tkind[i] = 1; trate[i] = k < JR ? g.c_real[k] : g.c_comp[k - JR]; }
+    else if (k < ndecay + JC) { tkind[i] = 2; trate[i] = g.d_comp[k - ndecay]; }
+    rkind[i] = 0; rsrc[i] = 0; ra[i] = 0.0; rb[i] = 0.0;
+    if (k < JR) { rkind[i] = 1; rsrc[i] = k; ra[i] = g.a_real[k]; }
+    else if (k < Wc) { const int jj = (k - JR) >> 1; rkind[i] = 2 + ((k - JR) & 1); rsrc[i] = jj; ra[i] = g.a_comp[jj]; rb[i] = g.b_comp[jj]; }
+    else if (k < J) { rkind[i] = 4; rsrc[i] = k - Wc; }
+  }
+  auto run_tasks = [&](double t, double dx) {  // this thread's share of sample's exp / sincos, into the staging arrays
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int k = tid + i * ROWS_THREADS;
+      if (tkind[i] == 1) sdecay[k] = exp(-trate[i] * dx);
+      else if (tkind[i] == 2) {
+        double sd, cd;
+        sincos_phase<FAST>(trate[i] * t, &sd, &cd);
+        ssin[k - ndecay] = sd;
+        scos[k - ndecay] = cd;
+      }
+    }
+  };
+  auto compose = [&](int i, int n, double& ph, double& uu, double& vv) {  // phi, u~, v~ of this thread's i-th row at sample n (cholesky.h:129-152)
+    ph = 1.0; uu = 0.0; vv = 0.0;
+    if (rkind[i] == 1) { ph = sdecay[rsrc[i]]; uu = ra[i]; vv = 1.0; }
+    else if (rkind[i] == 2 || rkind[i] == 3) {
+      const double sd = ssin[rsrc[i]], cd = scos[rsrc[i]];
+      ph = sdecay[JR + rsrc[i]];
+      uu = rkind[i] == 3 ? (ra[i] * sd - rb[i] * cd) : (ra[i] * cd + rb[i] * sd);
+      vv = rkind[i] == 3 ? sd : cd;
+    } else if (rkind[i] == 4) {
+      uu = g.U[(long)rsrc[i] * N + n];
+      vv = g.V[(long)rsrc[i] * N + n];
+    }
+  };
+
+  // sample 0: cholesky.h:100-117; features of sample 1
+  double Dprev = D[0];
+  LogProduct lp;
+  lp.init();
+  lp.mul(Dprev);
+  {
+    const double value = 1.0 / Dprev;
+    const double t0 = g.t[0], t1 = N > 1 ? g.t[1] : g.t[0];
+    run_tasks(t0, 0.0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int k = tid + i * ROWS_THREADS;
+      if (k < JP) {
+        double ph, uu, vv;
+        compose(i, 0, ph, uu, vv);
+        const double w = vv * value;
+        sw[col_slot(k)] = w;
+        if (first && k < J) W[k] = w;
+      }
+    }
+    __syncthreads();
+    run_tasks(t1, t1 - t0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int k = tid + i * ROWS_THREADS;
+      if (k < JP) {
+        double ph, uu, vv;
+        compose(i, N > 1 ? 1 : 0, ph, uu, vv);
+        sphi[col_slot(k)] = ph;
+        su[col_slot(k)] = uu;
+        sv[k] = vv;
+        if (first && k < J && N > 1) { phi[k] = ph; u[k] = uu; }
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int n = 1; n < N; ++n) {
+    const double dn = D[n];  // (the full diagonal as handed over: cholesky.h:98-99)
+    const bool more = n + 1 < N;
+    const double tn1 = more ? g.t[n + 1] : 0.0, dx1 = more ? tn1 - g.t[n] : 0.0;
+    // ---- (Y) the state's step and q = S u~, one pass ----------------------------------------------------------------
+    const double pr = sphi[col_slot(row)];
+    const double dw = Dprev * sw[col_slot(row)];
+    double acc0 = 0.0, acc1 = 0.0;
+    {
+      const double2* pk2 = reinterpret_cast<const double2*>(&sphi[34 * part]);
+      const double2* wk2 = reinterpret_cast<const double2*>(&sw[34 * part]);
+      const double2* uk2 = reinterpret_cast<const double2*>(&su[34 * part]);
+#pragma unroll
+      for (int c = 0; c < ROWS_COLS / 2; ++c) {
+        const double2 pk = pk2[c], wk = wk2[c], uk = uk2[c];
+        const double s0 = pr * (pk.x * fma(dw, wk.x, S[2 * c]));
+        const double s1 = pr * (pk.y * fma(dw, wk.y, S[2 * c + 1]));
+        S[2 * c] = s0;
+        S[2 * c + 1] = s1;
+        acc0 = fma(s0, uk.x, acc0);
+        acc1 = fma(s1, uk.y, acc1);
+      }
+    }
+    const double q = rows_row_sum<TPR>(acc0 + acc1);
+    const double mine = (part == 0) ? su[col_slot(row)] * q : 0.0;  // (padding rows: u~ = 0)
+    const double wsum = row_sum_all<1>(mine);
+    if (lane == 0) spart[wave] = wsum;
+    if (part == 0) {
+      if (G == 1) sq[row] = q;
+      else agent_store(X.q + (size_t)(n & 1) * JP + row, q);
+    }
+    // the next sample's exp / sincos (nobody reads the staging arrays during (Y))
+    if (more) run_tasks(tn1, dx1);
+    __syncthreads();
+    double total = 0.0;
+    if (G == 1) {
+#pragma unroll
+      for (int w = 0; w < ROWS_THREADS / 64; ++w) total += spart[w];
+    } else {
+      if (tid == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < ROWS_THREADS / 64; ++w) s += spart[w];
+        agent_store(X.part + (size_t)(n & 1) * G + wg, s);
+        __atomic_thread_fence(__ATOMIC_RELEASE);  // (agent scope by default on this target: the rows of q the other waves stored, too)
+        __hip_atomic_fetch_add(X.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int want = (unsigned int)G * (unsigned int)n;
+        long spins = 0;
+        while (__hip_atomic_load(X.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (++spins > (1L << 26)) { status[0] = 3; sabort = 1; break; }  // (a workgroup that never arrives: give up rather than hang the queue)
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      }
+      if (wave == 0 && lane < G) sshare[lane] = agent_load(X.part + (size_t)(n & 1) * G + lane);
+      __syncthreads();
+#pragma unroll 8
+      for (int w = 0; w < G; ++w) total += sshare[w];  // (every thread, every workgroup: the same order)
+    }
+    // ---- (X) the pivot, W_n, and the features move on ---------------------------------------------------------------
+    const double Dn = dn - total;
+    if (Dn < 0.0 || (G > 1 && sabort)) {  // cholesky.h:176
+      if (first && tid == 0) { if (!sabort) status[0] = 1; log_det[0] = NAN; }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int k = tid + i * ROWS_THREADS;
+      if (k < JP) {
+        const double qk = (G == 1) ? sq[k] : agent_load(X.q + (size_t)(n & 1) * JP + k);
+        double ph, uu, vv;
+        compose(i, more ? n + 1 : n, ph, uu, vv);
+        const double w = (sv[k] - qk) / Dn;  // cholesky.h:170-178
+        sw[col_slot(k)] = w;
+        sphi[col_slot(k)] = ph;
+        su[col_slot(k)] = uu;
+        sv[k] = vv;
+        if (first && k < J) {
+          W[(long)J * n + k] = w;
+          if (more) { phi[(long)J * n + k] = ph; u[(long)J * n + k] = uu; }
+        }
+      }
+    }
+    if (first && tid == 0) { D[n] = Dn; lp.mul(Dn); }
+    Dprev = Dn;
+    __syncthreads();
+  }
+  if (first && tid == 0) { status[0] = 0; log_det[0] = lp.log_value(); }
+}
+
+int rows_tpr(int J) { return J <= 128 ? 4 : (J <= 256 ? 8 : (J <= 512 ? 16 : 32)); }
+
+}  // namespace
+
+bool factor_rows_supported(int J) { return J >= 1 && J <= 1024; }
+
+// doubles of workspace (q | shares | the counter in the last slot)
+size_t factor_rows_workspace_doubles(int J) {
+  const int tpr = rows_tpr(J), JP = ROWS_COLS * tpr, G = tpr * tpr / 16;
+  return (size_t)2 * JP + 2 * G + 2;
+}
+
+// D arrives initialised to the full diagonal (cholesky.h:98-99); status[0] = 1: a pivot D_n < 0 (n >= 1), 3: the
+// workgroups lost each other (never seen; reported as a HIP error by the caller)
+void launch_factor_rows(const GenericProblem& g, int fast_trig, double* workspace, double* phi, double* u, double* W, double* D, int* status,
+                        double* log_det, hipStream_t s) {
+  const int tpr = rows_tpr(g.J), JP = ROWS_COLS * tpr, G = tpr * tpr / 16;
+  RowsExchange X;
+  X.q = workspace;
+  X.part = workspace + (size_t)2 * JP;
+  X.bar = reinterpret_cast<unsigned int*>(workspace + (size_t)2 * JP + 2 * G);
+  (void)hipMemsetAsync(X.bar, 0, 2 * sizeof(double), s);
+  (void)hipMemsetAsync(status, 0, sizeof(int), s);
+#define CLR_ROWS_LAUNCH(T)                                                                                                                  \
+  do {                                                                                                                                      \
+    if (fast_trig) hipLaunchKernelGGL((factor_rows_kernel<T, true>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, phi, u, W, D, status, log_det); \
+    else hipLaunchKernelGGL((factor_rows_kernel<T, false>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, phi, u, W, D, status, log_det);          \
+  } while (0)
+  if (tpr == 4) CLR_ROWS_LAUNCH(4);
+  else if (tpr == 8) CLR_ROWS_LAUNCH(8);
+  else if (tpr == 16) CLR_ROWS_LAUNCH(16);
+  else CLR_ROWS_LAUNCH(32);
+#undef CLR_ROWS_LAUNCH
+}
+
+}  // namespace clr

@@ -1052,3 +1052,66 @@ def test_output_check_that_never_agrees_ends_in_the_sequential_recurrence():
     assert abs(s.log_determinant() - r.log_determinant()) <= 1e-12 * abs(r.log_determinant())
     z = rng.randn(N)
     assert abs(s.dot_solve(z) - r.dot_solve(z)) <= 1e-11 * abs(r.dot_solve(z))
+
+
+@pytest.mark.parametrize("JR,JC,N,with_general", [(2, 16, 700, True), (1, 40, 900, False), (3, 60, 500, True), (2, 100, 400, True),
+                                                  (0, 200, 300, False), (0, 512, 160, False)])
+def test_row_distributed_factorisation_against_the_oracle_and_the_older_kernels(JR, JC, N, with_general):
+    """Round 6: ``CholeskySolver.compute`` outside the chunked scans (general terms above width 32, every width above 64)
+    keeps S in the REGISTERS of 1 / 4 / 16 / 64 workgroups that meet at one counter barrier per step (csrc/rows_kernels.hip;
+    the reference's dynamic-width arm, cholesky.h:203).  The stored factor (phi, u, W, D), log det, ``dot_solve`` and
+    ``solve`` against the oracle at widths 38 (general terms), 81, 127, 206 (general terms, four workgroups), 400 (sixteen)
+    and 1024 (sixty-four) -- and against the one-workgroup kernels it replaces (S in LDS / in L2: ``CLR_NO_ROWS_KERNEL``)."""
+    J = JR + 2 * JC
+    case = synthetic(1, N, JR, JC, "accuracy", seed=J)
+    cs = list(coeffs_of(case, 0))
+    t, diag, y = case["t"][0], case["diag"][0] + 0.05, case["y"][0]
+    np.random.seed(J)
+    gen = NO_GENERAL
+    if with_general:
+        # four general rows that ARE a positive definite kernel: two undamped cosines a cos(w (t_i - t_j)) = U^T V with
+        # U = a (cos w t, sin w t), V = (cos w t, sin w t), A = a.  (tests/test_celerite.py:102-105's polynomial rows with
+        # random scalings are not: at N = 700 the recurrence amplifies rounding to 1e-5 of log det -- the oracle's own
+        # double loops and a long-double run of them differ by that much, 4e-13 at N = 50.)
+        a1, w1, a2, w2 = 0.3, 1.7, 0.2, 0.45
+        U = np.vstack([a1 * np.cos(w1 * t), a1 * np.sin(w1 * t), a2 * np.cos(w2 * t), a2 * np.sin(w2 * t)])
+        V = np.vstack([np.cos(w1 * t), np.sin(w1 * t), np.cos(w2 * t), np.sin(w2 * t)])
+        gen = (np.full(N, a1 + a2), U, V)
+    Jt = J + (4 if with_general else 0)
+    r = ref.RefSolver()
+    r.compute(0.1, *cs, *gen, t, diag)
+    _, _, Jo, logdet, rphi, ru, rW, rD = r.state()
+    assert Jo == Jt
+    b = np.random.RandomState(J).randn(N, 2)
+    want_solve, want_quad = r.solve(b), r.dot_solve(y)
+    got = {}
+    for rows in (True, False):
+        batch.set_option("CLR_NO_ROWS_KERNEL", None if rows else "1")
+        try:
+            s = celerite_amd.CholeskySolver()
+            s.compute(0.1, *cs, *gen, t, diag)
+        finally:
+            batch.set_option("CLR_NO_ROWS_KERNEL", None)
+        tag = (Jt, "rows" if rows else "one workgroup")
+        within("row-distributed factorisation: log det vs oracle", abs(s.log_determinant() - logdet) / abs(logdet), 1e-12, tag)
+        within("row-distributed factorisation: dot_solve vs oracle", abs(s.dot_solve(y) - want_quad) / abs(want_quad), 1e-10, tag)
+        within("row-distributed factorisation: solve vs oracle (of the largest entry)", np.max(np.abs(s.solve(b) - want_solve)) / np.max(np.abs(want_solve)), 1e-10, tag)
+        st = s.__getstate__()
+        phi, u = np.asarray(st[4]).reshape(rphi.shape), np.asarray(st[5]).reshape(ru.shape)
+        W, D = np.asarray(st[6]).reshape(rW.shape), np.asarray(st[7])
+        within("row-distributed factorisation: phi vs oracle", np.max(np.abs(phi - rphi)), 1e-15, tag)
+        within("row-distributed factorisation: u vs oracle (of the largest entry)", np.max(np.abs(u - ru)) / np.max(np.abs(ru)), 1e-15, tag)
+        within("row-distributed factorisation: W vs oracle (of the largest entry)", np.max(np.abs(W - rW)) / np.max(np.abs(rW)), 1e-10, tag)
+        within("row-distributed factorisation: D vs oracle (relative)", np.max(np.abs(D - rD) / np.abs(rD)), 1e-10, tag)
+        got[rows] = (s.log_determinant(), W, D)
+    assert abs(got[True][0] - got[False][0]) <= 1e-12 * abs(logdet)
+    # a pivot below zero is seen by every workgroup at the same step (cholesky.h:176)
+    bad = list(cs)
+    if JR:
+        bad[0] = -20.0 * np.abs(bad[0])
+    else:
+        bad[2] = -20.0 * np.abs(bad[2])
+    s3 = celerite_amd.CholeskySolver()
+    with pytest.raises(LinAlgError):
+        s3.compute(0.0, *bad, *gen, t, np.zeros(N))
+    assert not s3.computed()
