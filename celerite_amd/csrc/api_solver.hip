@@ -451,13 +451,17 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
       if ((st = upload(s->V, V, (size_t)J_general * N, stream)) != CLR_OK) return st;
     }
     const clr::GenericProblem g = generic_view(s);
+    bool rows_quad = false;
     if (J >= 33 && clr::factor_rows_supported(J) && !clr::option("CLR_NO_ROWS_KERNEL")) {
       // S in the registers of 1 .. 64 workgroups (rows_kernels.hip; round 6: width 128 20.5 -> ~1 us per step)
       if ((st = s->ws_elems.reserve(clr::factor_rows_workspace_doubles(J))) != CLR_OK) return st;
       double dmax = 0.0;
       for (int j = 0; j < J_comp; ++j) { const double m = fabs(d_comp[j]); if (!(m <= dmax)) dmax = m; }
       const int fast = (dmax * max_abs(x, N) < CLR_FAST_TRIG_LIMIT) ? 1 : 0;
-      clr::launch_factor_rows(g, fast, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
+      // (a hinted right-hand side: its quadratic form comes out of the same pass, as on the chunked routes)
+      if (use_rhs && (st = stage_upload(s, s->rhs, s->host_rhs.data(), (size_t)N)) != CLR_OK) return st;
+      clr::launch_factor_rows(g, fast, use_rhs ? s->rhs.p : nullptr, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
+      rows_quad = use_rhs;
     } else if (J > CLR_MAX_WIDTH) {  // S (J^2 doubles) in HBM / L2 instead of LDS (huge_kernels.hip)
       if ((st = s->ws_elems.reserve(clr::factor_huge_workspace_doubles(J))) != CLR_OK) return st;
       clr::launch_factor_huge(g, s->ws_elems.p, s->phi.p, s->u.p, s->W.p, s->D.p, s->d_status, s->scalars.p, stream);
@@ -466,9 +470,11 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
                                stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&h_status, s->d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&h_logdet, s->scalars.p, sizeof(double), hipMemcpyDeviceToHost,
-                           stream));
+    double two[2] = {0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(two, s->scalars.p, (rows_quad ? 2 : 1) * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    h_logdet = two[0];
+    if (rows_quad && h_status == 0) { s->cached_quad = two[1]; s->have_quad = true; }
   }
 
   if (h_status == 3) return fail(CLR_HIP_ERROR, "the workgroups of the row-distributed factorisation lost each other (rows_kernels.hip)");

@@ -168,8 +168,9 @@ void launch_solve_huge(int N, int J, int nrhs, const double* phi, const double* 
 // widths 33 .. 1024 (rows_kernels.hip): S in the registers of 1 / 4 / 16 / 64 workgroups, one counter barrier per step
 bool factor_rows_supported(int J);
 size_t factor_rows_workspace_doubles(int J);
-void launch_factor_rows(const GenericProblem& g, int fast_trig /* host-verified: max|d_comp| max|t| < CLR_FAST_TRIG_LIMIT */, double* workspace,
-                        double* phi, double* u, double* W, double* D, int* status, double* log_det, hipStream_t s);
+void launch_factor_rows(const GenericProblem& g, int fast_trig /* host-verified: max|d_comp| max|t| < CLR_FAST_TRIG_LIMIT */,
+                        const double* y /* device [N] or null: log_det[1] = y^T K^-1 y */, double* workspace, double* phi, double* u, double* W,
+                        double* D, int* status, double* log_det /* [2] */, hipStream_t s);
 // J == 0 and small element-wise helpers.
 void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,
                       hipStream_t s);

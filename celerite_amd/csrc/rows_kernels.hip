@@ -30,6 +30,7 @@
 
 #include "../../include/celerite_hip.h"
 #include "clr_generic_kernels.h"
+#include "clr_options.h"
 #include "clr_wide.h"
 
 namespace clr {
@@ -38,6 +39,10 @@ namespace {
 
 constexpr int ROWS_THREADS = 512;
 constexpr int ROWS_COLS = 32;  // columns of S per lane
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the wave's global STORES
+// (s_waitcnt vmcnt(0)) -- W, phi, u~ of the step, a microsecond of write latency per barrier that nobody needs to see
+__device__ __forceinline__ void rows_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void agent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double agent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -63,17 +68,21 @@ __device__ __forceinline__ double rows_row_sum(double v) {
   return v;
 }
 
-template <int TPR, bool FAST>
-__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, double* phi, double* u, double* W, double* D,
-                                                                   int* status, double* log_det) {
+template <int TPR, bool FAST, bool BLOCKED = false>
+__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, const double* __restrict__ y, double* phi, double* u,
+                                                                   double* W, double* D, int* status, double* log_det) {
   constexpr int JP = ROWS_COLS * TPR, RB = ROWS_THREADS / TPR, G = JP / RB, SLOTS = 34 * TPR;
   constexpr int RPT = (JP + ROWS_THREADS - 1) / ROWS_THREADS;  // rows per thread in the per-row phases
   __shared__ __attribute__((aligned(16))) double sphi[SLOTS], su[SLOTS], sw[SLOTS];
   __shared__ double sv[JP], sq[G == 1 ? JP : 1], spart[ROWS_THREADS / 64], sshare[G];
+  __shared__ double sdot[ROWS_THREADS / 64];  // (y given) the waves' shares of u~_n . f_n, the forward sweep of dot_solve carried along
   // the transcendental functions of a sample, one TASK per thread (whole waves of one kind: a wave whose lanes split
   // between exp and sincos runs both): decay of real row i | decay of complex term i - J_real | sin, cos of term jj
   __shared__ double sdecay[JP], ssin[JP / 2], scos[JP / 2];
   __shared__ int sabort;
+  // t, the diagonal and y of 2 x 64 samples: a step's values come from here -- a global load at the top of a step is on
+  // its critical path (sample n + 1's time feeds the exp / sincos tasks at once); the next tile is fetched 64 steps ahead
+  __shared__ double tile_t[2][64], tile_d[2][64], tile_y[2][64];
   const int J = g.J, N = g.N, tid = threadIdx.x, wg = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int part = tid % TPR, row = wg * RB + tid / TPR;  // this lane's row of S and block of columns
@@ -128,11 +137,24 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
     }
   };
 
+  if (tid < 128) {
+    tile_t[tid >> 6][tid & 63] = tid < N ? g.t[tid] : 0.0;
+    tile_d[tid >> 6][tid & 63] = tid < N ? D[tid] : 0.0;
+    tile_y[tid >> 6][tid & 63] = (y && tid < N) ? y[tid] : 0.0;
+  }
+  __syncthreads();
+  auto tile_at = [](const double (*tile)[64], int i) { return tile[(i >> 6) & 1][i & 63]; };
+
   // sample 0: cholesky.h:100-117; features of sample 1
   double Dprev = D[0];
   LogProduct lp;
   lp.init();
   lp.mul(Dprev);
+  // the forward sweep of dot_solve (cholesky.h:343-357) for the vector announced by clr_solver_hint_rhs: f row by row in
+  // the threads that compose the rows (every workgroup: all rows), x_n = y_n - u~_n . f_n from the waves' shares
+  double fr[RPT], xm1 = y ? y[0] : 0.0, quad = xm1 * (xm1 / Dprev), gsum = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) fr[i] = 0.0;
   {
     const double value = 1.0 / Dprev;
     const double t0 = g.t[0], t1 = N > 1 ? g.t[1] : g.t[0];
@@ -162,45 +184,115 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
         su[col_slot(k)] = uu;
         sv[k] = vv;
         if (first && k < J && N > 1) { phi[k] = ph; u[k] = uu; }
+        if (y) {  // cholesky.h:343-352: f_1 = phi (0 + W_0 x_0), and this row's term of u~_1 . f_1
+          fr[i] = ph * (sw[col_slot(k)] * xm1);
+          gsum += uu * fr[i];
+        }
       }
+    }
+    if (y) {
+      const double ws = row_sum_all<1>(gsum);
+      if (lane == 0) sdot[wave] = ws;
     }
   }
   __syncthreads();
 
   for (int n = 1; n < N; ++n) {
-    const double dn = D[n];  // (the full diagonal as handed over: cholesky.h:98-99)
-    const bool more = n + 1 < N;
-    const double tn1 = more ? g.t[n + 1] : 0.0, dx1 = more ? tn1 - g.t[n] : 0.0;
-    // ---- (Y) the state's step and q = S u~, one pass ----------------------------------------------------------------
-    const double pr = sphi[col_slot(row)];
-    const double dw = Dprev * sw[col_slot(row)];
-    double acc0 = 0.0, acc1 = 0.0;
-    {
-      const double2* pk2 = reinterpret_cast<const double2*>(&sphi[34 * part]);
-      const double2* wk2 = reinterpret_cast<const double2*>(&sw[34 * part]);
-      const double2* uk2 = reinterpret_cast<const double2*>(&su[34 * part]);
-#pragma unroll
-      for (int c = 0; c < ROWS_COLS / 2; ++c) {
-        const double2 pk = pk2[c], wk = wk2[c], uk = uk2[c];
-        const double s0 = pr * (pk.x * fma(dw, wk.x, S[2 * c]));
-        const double s1 = pr * (pk.y * fma(dw, wk.y, S[2 * c + 1]));
-        S[2 * c] = s0;
-        S[2 * c + 1] = s1;
-        acc0 = fma(s0, uk.x, acc0);
-        acc1 = fma(s1, uk.y, acc1);
-      }
+    const double dn = tile_at(tile_d, n);  // (the full diagonal as handed over: cholesky.h:98-99)
+    const bool fetch = (n & 63) == 0 && n >= 64 && tid < 64;  // the tile after this one (its buffer held the previous tile)
+    double ft = 0.0, fd = 0.0, fy = 0.0;
+    if (fetch) {
+      const int i = n + 64 + tid;
+      if (i < N) { ft = g.t[i]; fd = D[i]; fy = y ? y[i] : 0.0; }
     }
-    const double q = rows_row_sum<TPR>(acc0 + acc1);
-    const double mine = (part == 0) ? su[col_slot(row)] * q : 0.0;  // (padding rows: u~ = 0)
-    const double wsum = row_sum_all<1>(mine);
-    if (lane == 0) spart[wave] = wsum;
-    if (part == 0) {
-      if (G == 1) sq[row] = q;
-      else agent_store(X.q + (size_t)(n & 1) * JP + row, q);
+    double xn = 0.0;
+    if (y) {
+      xn = tile_at(tile_y, n);
+      double dot = 0.0;
+#pragma unroll
+      for (int w = 0; w < ROWS_THREADS / 64; ++w) dot += sdot[w];
+      xn -= dot;  // cholesky.h:353
+    }
+    const bool more = n + 1 < N;
+    const double tn1 = more ? tile_at(tile_t, n + 1) : 0.0, dx1 = more ? tn1 - tile_at(tile_t, n) : 0.0;
+    // ---- (Y) the state's step and q = S u~, one pass ----------------------------------------------------------------
+    if constexpr (BLOCKED) {
+      // width <= 128, one workgroup: a lane holds 4 rows x 8 columns.  The row-per-lane-group layout below reads 48 + 2
+      // LDS quadwords per lane and step -- 8 waves x 50 x 8 cycles of LDS return path = 3200 cycles, the step's bound
+      // (1.8 us measured); the block needs 12 (columns) + 4 (rows), at the price of four row sums over 16 lanes.
+      const int cb = tid & 15, r0 = (tid >> 4) * 4;
+      const double2* pk2 = reinterpret_cast<const double2*>(&sphi[col_slot(8 * cb)]);
+      const double2* wk2 = reinterpret_cast<const double2*>(&sw[col_slot(8 * cb)]);
+      const double2* uk2 = reinterpret_cast<const double2*>(&su[col_slot(8 * cb)]);
+      const double2* pr2 = reinterpret_cast<const double2*>(&sphi[col_slot(r0)]);
+      const double2* wr2 = reinterpret_cast<const double2*>(&sw[col_slot(r0)]);
+      double pk[8], wk[8], uk[8], prr[4], dwr[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 a = pk2[c], bb = wk2[c], cc = uk2[c];
+        pk[2 * c] = a.x; pk[2 * c + 1] = a.y; wk[2 * c] = bb.x; wk[2 * c + 1] = bb.y; uk[2 * c] = cc.x; uk[2 * c + 1] = cc.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double2 a = pr2[c], bb = wr2[c];
+        prr[2 * c] = a.x; prr[2 * c + 1] = a.y; dwr[2 * c] = Dprev * bb.x; dwr[2 * c + 1] = Dprev * bb.y;
+      }
+      double qr[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          const double s0 = prr[rr] * (pk[c] * fma(dwr[rr], wk[c], S[8 * rr + c]));
+          const double s1 = prr[rr] * (pk[c + 1] * fma(dwr[rr], wk[c + 1], S[8 * rr + c + 1]));
+          S[8 * rr + c] = s0;
+          S[8 * rr + c + 1] = s1;
+          a0 = fma(s0, uk[c], a0);
+          a1 = fma(s1, uk[c + 1], a1);
+        }
+        qr[rr] = rows_row_sum<16>(a0 + a1);
+      }
+      double mine = 0.0;
+      if (cb == 0) {
+        const double2* ur2 = reinterpret_cast<const double2*>(&su[col_slot(r0)]);
+        const double2 u01 = ur2[0], u23 = ur2[1];
+        mine = (u01.x * qr[0] + u01.y * qr[1]) + (u23.x * qr[2] + u23.y * qr[3]);  // (padding rows: u~ = 0)
+        sq[r0] = qr[0]; sq[r0 + 1] = qr[1]; sq[r0 + 2] = qr[2]; sq[r0 + 3] = qr[3];
+      }
+      const double wsum = row_sum_all<1>(mine);
+      if (lane == 0) spart[wave] = wsum;
+    } else {
+      const double pr = sphi[col_slot(row)];
+      const double dw = Dprev * sw[col_slot(row)];
+      double acc0 = 0.0, acc1 = 0.0;
+      {
+        const double2* pk2 = reinterpret_cast<const double2*>(&sphi[34 * part]);
+        const double2* wk2 = reinterpret_cast<const double2*>(&sw[34 * part]);
+        const double2* uk2 = reinterpret_cast<const double2*>(&su[34 * part]);
+#pragma unroll
+        for (int c = 0; c < ROWS_COLS / 2; ++c) {
+          const double2 pk = pk2[c], wk = wk2[c], uk = uk2[c];
+          const double s0 = pr * (pk.x * fma(dw, wk.x, S[2 * c]));
+          const double s1 = pr * (pk.y * fma(dw, wk.y, S[2 * c + 1]));
+          S[2 * c] = s0;
+          S[2 * c + 1] = s1;
+          acc0 = fma(s0, uk.x, acc0);
+          acc1 = fma(s1, uk.y, acc1);
+        }
+      }
+      const double q = rows_row_sum<TPR>(acc0 + acc1);
+      const double mine = (part == 0) ? su[col_slot(row)] * q : 0.0;  // (padding rows: u~ = 0)
+      const double wsum = row_sum_all<1>(mine);
+      if (lane == 0) spart[wave] = wsum;
+      if (part == 0) {
+        if (G == 1) sq[row] = q;
+        else agent_store(X.q + (size_t)(n & 1) * JP + row, q);
+      }
     }
     // the next sample's exp / sincos (nobody reads the staging arrays during (Y))
     if (more) run_tasks(tn1, dx1);
-    __syncthreads();
+    if (G == 1) rows_lds_barrier();
+    else __syncthreads();  // (the rows of q this wave stored must have left before thread 0 announces the workgroup's arrival)
     double total = 0.0;
     if (G == 1) {
 #pragma unroll
@@ -221,7 +313,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
       }
       if (wave == 0 && lane < G) sshare[lane] = agent_load(X.part + (size_t)(n & 1) * G + lane);
-      __syncthreads();
+      rows_lds_barrier();
 #pragma unroll 8
       for (int w = 0; w < G; ++w) total += sshare[w];  // (every thread, every workgroup: the same order)
     }
@@ -231,6 +323,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       if (first && tid == 0) { if (!sabort) status[0] = 1; log_det[0] = NAN; }
       return;
     }
+    gsum = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int k = tid + i * ROWS_THREADS;
@@ -247,13 +340,26 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
           W[(long)J * n + k] = w;
           if (more) { phi[(long)J * n + k] = ph; u[(long)J * n + k] = uu; }
         }
+        if (y && more) {
+          fr[i] = ph * (fr[i] + w * xn);  // cholesky.h:350-352
+          gsum += uu * fr[i];
+        }
       }
     }
+    if (y) {
+      quad += xn * xn / Dn;  // cholesky.h:355
+      const double ws = row_sum_all<1>(gsum);
+      if (lane == 0) sdot[wave] = ws;  // (read at the top of the next step, behind the barrier below)
+    }
     if (first && tid == 0) { D[n] = Dn; lp.mul(Dn); }
+    if (fetch) {
+      const int bsel = ((n >> 6) + 1) & 1;
+      tile_t[bsel][tid] = ft; tile_d[bsel][tid] = fd; tile_y[bsel][tid] = fy;
+    }
     Dprev = Dn;
-    __syncthreads();
+    rows_lds_barrier();
   }
-  if (first && tid == 0) { status[0] = 0; log_det[0] = lp.log_value(); }
+  if (first && tid == 0) { status[0] = 0; log_det[0] = lp.log_value(); log_det[1] = quad; }
 }
 
 int rows_tpr(int J) { return J <= 128 ? 4 : (J <= 256 ? 8 : (J <= 512 ? 16 : 32)); }
@@ -269,9 +375,10 @@ size_t factor_rows_workspace_doubles(int J) {
 }
 
 // D arrives initialised to the full diagonal (cholesky.h:98-99); status[0] = 1: a pivot D_n < 0 (n >= 1), 3: the
-// workgroups lost each other (never seen; reported as a HIP error by the caller)
-void launch_factor_rows(const GenericProblem& g, int fast_trig, double* workspace, double* phi, double* u, double* W, double* D, int* status,
-                        double* log_det, hipStream_t s) {
+// workgroups lost each other (never seen; reported as a HIP error by the caller).  log_det[0] = sum log D_n; with y given
+// (device, [N]) log_det[1] = y^T K^-1 y: the forward sweep of dot_solve (cholesky.h:343-357) carried along.
+void launch_factor_rows(const GenericProblem& g, int fast_trig, const double* y, double* workspace, double* phi, double* u, double* W, double* D,
+                        int* status, double* log_det, hipStream_t s) {
   const int tpr = rows_tpr(g.J), JP = ROWS_COLS * tpr, G = tpr * tpr / 16;
   RowsExchange X;
   X.q = workspace;
@@ -281,10 +388,14 @@ void launch_factor_rows(const GenericProblem& g, int fast_trig, double* workspac
   (void)hipMemsetAsync(status, 0, sizeof(int), s);
 #define CLR_ROWS_LAUNCH(T)                                                                                                                  \
   do {                                                                                                                                      \
-    if (fast_trig) hipLaunchKernelGGL((factor_rows_kernel<T, true>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, phi, u, W, D, status, log_det); \
-    else hipLaunchKernelGGL((factor_rows_kernel<T, false>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, phi, u, W, D, status, log_det);          \
+    if (fast_trig) hipLaunchKernelGGL((factor_rows_kernel<T, true>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, y, phi, u, W, D, status, log_det); \
+    else hipLaunchKernelGGL((factor_rows_kernel<T, false>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, y, phi, u, W, D, status, log_det);          \
   } while (0)
-  if (tpr == 4) CLR_ROWS_LAUNCH(4);
+  if (tpr == 4) {  // (one workgroup: the 4 x 8 register blocks; CLR_ROWS_NO_BLOCKS=1 keeps the row-per-lane-group layout for A/B)
+    if (clr::option("CLR_ROWS_NO_BLOCKS")) CLR_ROWS_LAUNCH(4);
+    else if (fast_trig) hipLaunchKernelGGL((factor_rows_kernel<4, true, true>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, y, phi, u, W, D, status, log_det);
+    else hipLaunchKernelGGL((factor_rows_kernel<4, false, true>), dim3(G), dim3(ROWS_THREADS), 0, s, g, X, y, phi, u, W, D, status, log_det);
+  }
   else if (tpr == 8) CLR_ROWS_LAUNCH(8);
   else if (tpr == 16) CLR_ROWS_LAUNCH(16);
   else CLR_ROWS_LAUNCH(32);

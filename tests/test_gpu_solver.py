@@ -1089,10 +1089,14 @@ def test_row_distributed_factorisation_against_the_oracle_and_the_older_kernels(
         batch.set_option("CLR_NO_ROWS_KERNEL", None if rows else "1")
         try:
             s = celerite_amd.CholeskySolver()
+            s._hint_rhs(y)      # (GP.log_likelihood's way: the quadratic form of y out of the factorisation pass itself)
             s.compute(0.1, *cs, *gen, t, diag)
         finally:
             batch.set_option("CLR_NO_ROWS_KERNEL", None)
         tag = (Jt, "rows" if rows else "one workgroup")
+        within("row-distributed factorisation: hinted dot_solve vs oracle", abs(s.dot_solve(y) - want_quad) / abs(want_quad), 1e-10, tag)
+        want_b0 = r.dot_solve(b[:, 0])
+        within("row-distributed factorisation: dot_solve vs oracle", abs(s.dot_solve(b[:, 0]) - want_b0) / abs(want_b0), 1e-10, tag)
         within("row-distributed factorisation: log det vs oracle", abs(s.log_determinant() - logdet) / abs(logdet), 1e-12, tag)
         within("row-distributed factorisation: dot_solve vs oracle", abs(s.dot_solve(y) - want_quad) / abs(want_quad), 1e-10, tag)
         within("row-distributed factorisation: solve vs oracle (of the largest entry)", np.max(np.abs(s.solve(b) - want_solve)) / np.max(np.abs(want_solve)), 1e-10, tag)
