@@ -86,7 +86,10 @@ int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
  *   CLR_OUTPUT_CHECK_CAP, CLR_OUTPUT_CHECK_TOL   materialising replays at widths 9..64 whose end states miss the scanned start
  *                            states by more than the certificate's bound but less than CAP (default 1e-6; 0: off) are
  *                            settled by comparing what a second replay writes (within TOL, default 2e-11) instead of
- *                            going to the sequential recurrence; CLR_SOLVER_CERT_RESID: that bound for CholeskySolver (1e-11)
+ *                            going to the sequential recurrence; CLR_SOLVER_CERT_RESID: that bound for CholeskySolver (1e-11);
+ *                            CLR_OUTPUT_CHECK_ATTEMPTS: replays before giving up (4)
+ *   CLR_NO_ROWS_KERNEL       CholeskySolver above width 64 / general terms above 32: the one-workgroup kernels (S in LDS / L2)
+ *                            instead of the row-distributed one (cross-checks); CLR_ROWS_NO_BLOCKS: its row-per-lane-group layout
  *   CLR_WIDE_NO_PAIRED, CLR_WIDE64_ONE_WAVE, CLR_WIDE_LAZY_BOUND, CLR_WIDE_FIRST_RATIO, CLR_WIDE_FIRST_RATIO64,
  *   CLR_WIDE_SCAN_CAP, CLR_SOLVER_WIDE_CHUNKS, CLR_PREDICT_CHUNKS, CLR_WSWEEP_RUN, CLR_WSWEEP_CHUNKS   (tuning runs, tools/)
  * clr_get_option: the value in force (NULL: not set); the pointer is valid until the calling thread's next call. */
