@@ -72,20 +72,25 @@ template <int TPR, bool FAST, bool BLOCKED = false>
 __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, const double* __restrict__ y, double* phi, double* u,
                                                                    double* W, double* D, int* status, double* log_det) {
   constexpr int JP = ROWS_COLS * TPR, RB = ROWS_THREADS / TPR, G = JP / RB, SLOTS = 34 * TPR;
-  constexpr int RPT = (JP + ROWS_THREADS - 1) / ROWS_THREADS;  // rows per thread in the per-row phases
-  __shared__ __attribute__((aligned(16))) double sphi[SLOTS], su[SLOTS], sw[SLOTS];
-  __shared__ double sv[JP], sq[G == 1 ? JP : 1], spart[ROWS_THREADS / 64], sshare[G];
+  constexpr int RPT = (JP + ROWS_THREADS - 1) / ROWS_THREADS;  // rows (tasks) per thread in the per-row phases
+  // Who does what besides the state's step (Y), in whole waves: the rows' pivots-and-W phase (X) belongs to threads
+  // [0, JP); the exp / sincos TASKS of the sample two steps ahead to threads [TOFF, ...); COMPOSING the next sample's
+  // phi, u~, v~ from the staged tasks to threads [COFF, ...).  At width <= 128 these are three different pairs of waves:
+  // tasks and composition run while the (X) waves are still in (Y) or wait at the barrier, so that (X) itself -- on the
+  // step's critical path, two waves of eight -- is just D, W and the hand-over (profiles/r06u_rows_kernel_phases.txt).
+  constexpr int TOFF = JP <= 128 ? 128 : (JP <= 256 ? 256 : 0), COFF = JP <= 128 ? 256 : 0;
+  __shared__ __attribute__((aligned(16))) double sphi[2][SLOTS], su[2][SLOTS], sw[SLOTS];  // features by the sample's parity
+  __shared__ double sv[2][JP], sq[G == 1 ? JP : 1], spart[ROWS_THREADS / 64], sshare[G];
   __shared__ double sdot[ROWS_THREADS / 64];  // (y given) the waves' shares of u~_n . f_n, the forward sweep of dot_solve carried along
-  // the transcendental functions of a sample, one TASK per thread (whole waves of one kind: a wave whose lanes split
-  // between exp and sincos runs both): decay of real row i | decay of complex term i - J_real | sin, cos of term jj
-  __shared__ double sdecay[JP], ssin[JP / 2], scos[JP / 2];
+  // staged tasks by the sample's parity: decay of real row i | of complex term i - J_real; sin, cos of term jj
+  __shared__ double sdecay[2][JP], ssin[2][JP / 2], scos[2][JP / 2];
   __shared__ int sabort;
-  // t, the diagonal and y of 2 x 64 samples: a step's values come from here -- a global load at the top of a step is on
-  // its critical path (sample n + 1's time feeds the exp / sincos tasks at once); the next tile is fetched 64 steps ahead
+  // t, the diagonal and y of 2 x 64 samples: a step's values come from here (a global load at the top of a step would be
+  // on its critical path); the next tile is fetched 64 steps ahead
   __shared__ double tile_t[2][64], tile_d[2][64], tile_y[2][64];
   const int J = g.J, N = g.N, tid = threadIdx.x, wg = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int part = tid % TPR, row = wg * RB + tid / TPR;  // this lane's row of S and block of columns
+  const int part = tid % TPR, row = wg * RB + tid / TPR;  // (row-per-lane-group layout) this lane's row of S and block of columns
   const bool first = wg == 0;
   const int JR = g.J_real, JC = g.J_comp, Wc = JR + 2 * JC, ndecay = JR + JC;
 
@@ -96,44 +101,59 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
 
   // this thread's tasks (rate of a decay / frequency of a phase) and the constants of the rows it composes
   double trate[RPT];
-  int tkind[RPT];  // 0 none, 1 decay, 2 phase
+  int tkind[RPT], tidx[RPT];  // 0 none, 1 decay, 2 phase; the task's index
   double ra[RPT], rb[RPT];
-  int rkind[RPT], rsrc[RPT];  // 0 padding, 1 real, 2 complex even, 3 complex odd, 4 general; index of the decay / term / general row
+  int rkind[RPT], rsrc[RPT], crow[RPT];  // 0 none / padding, 1 real, 2 complex even, 3 complex odd, 4 general; index of the decay / term / general row; the row
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int k = tid + i * ROWS_THREADS;
-    tkind[i] = 0; trate[i] = 0.0;
-    if (k < ndecay) { tkind[i] = 1; trate[i] = k < JR ? g.c_real[k] : g.c_comp[k - JR]; }
-    else if (k < ndecay + JC) { tkind[i] = 2; trate[i] = g.d_comp[k - ndecay]; }
-    rkind[i] = 0; rsrc[i] = 0; ra[i] = 0.0; rb[i] = 0.0;
-    if (k < JR) { rkind[i] = 1; rsrc[i] = k; ra[i] = g.a_real[k]; }
-    else if (k < Wc) { const int jj = (k - JR) >> 1; rkind[i] = 2 + ((k - JR) & 1); rsrc[i] = jj; ra[i] = g.a_comp[jj]; rb[i] = g.b_comp[jj]; }
-    else if (k < J) { rkind[i] = 4; rsrc[i] = k - Wc; }
+    const int tk = tid - TOFF + i * ROWS_THREADS;
+    tkind[i] = 0; trate[i] = 0.0; tidx[i] = tk;
+    if (tk >= 0 && tk < ndecay) { tkind[i] = 1; trate[i] = tk < JR ? g.c_real[tk] : g.c_comp[tk - JR]; }
+    else if (tk >= ndecay && tk < ndecay + JC) { tkind[i] = 2; trate[i] = g.d_comp[tk - ndecay]; }
+    const int k = tid - COFF + i * ROWS_THREADS;
+    rkind[i] = -1; rsrc[i] = 0; ra[i] = 0.0; rb[i] = 0.0; crow[i] = k;
+    if (k >= 0 && k < JP) {
+      rkind[i] = 0;
+      if (k < JR) { rkind[i] = 1; rsrc[i] = k; ra[i] = g.a_real[k]; }
+      else if (k < Wc) { const int jj = (k - JR) >> 1; rkind[i] = 2 + ((k - JR) & 1); rsrc[i] = jj; ra[i] = g.a_comp[jj]; rb[i] = g.b_comp[jj]; }
+      else if (k < J) { rkind[i] = 4; rsrc[i] = k - Wc; }
+    }
   }
-  auto run_tasks = [&](double t, double dx) {  // this thread's share of sample's exp / sincos, into the staging arrays
+  auto run_tasks = [&](double t, double dx, int sb) {  // this thread's share of a sample's exp / sincos, into staging buffer sb
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int k = tid + i * ROWS_THREADS;
-      if (tkind[i] == 1) sdecay[k] = exp(-trate[i] * dx);
+      if (tkind[i] == 1) sdecay[sb][tidx[i]] = exp(-trate[i] * dx);
       else if (tkind[i] == 2) {
         double sd, cd;
         sincos_phase<FAST>(trate[i] * t, &sd, &cd);
-        ssin[k - ndecay] = sd;
-        scos[k - ndecay] = cd;
+        ssin[sb][tidx[i] - ndecay] = sd;
+        scos[sb][tidx[i] - ndecay] = cd;
       }
     }
   };
-  auto compose = [&](int i, int n, double& ph, double& uu, double& vv) {  // phi, u~, v~ of this thread's i-th row at sample n (cholesky.h:129-152)
-    ph = 1.0; uu = 0.0; vv = 0.0;
-    if (rkind[i] == 1) { ph = sdecay[rsrc[i]]; uu = ra[i]; vv = 1.0; }
-    else if (rkind[i] == 2 || rkind[i] == 3) {
-      const double sd = ssin[rsrc[i]], cd = scos[rsrc[i]];
-      ph = sdecay[JR + rsrc[i]];
-      uu = rkind[i] == 3 ? (ra[i] * sd - rb[i] * cd) : (ra[i] * cd + rb[i] * sd);
-      vv = rkind[i] == 3 ? sd : cd;
-    } else if (rkind[i] == 4) {
-      uu = g.U[(long)rsrc[i] * N + n];
-      vv = g.V[(long)rsrc[i] * N + n];
+  // phi, u~, v~ of this thread's rows at sample n (cholesky.h:129-152) from staging buffer sb into feature buffer n & 1;
+  // the factor's phi, u~ of the move n - 1 -> n
+  auto compose = [&](int n, int sb) {
+    const int fb = n & 1;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      if (rkind[i] < 0) continue;
+      double ph = 1.0, uu = 0.0, vv = 0.0;
+      if (rkind[i] == 1) { ph = sdecay[sb][rsrc[i]]; uu = ra[i]; vv = 1.0; }
+      else if (rkind[i] == 2 || rkind[i] == 3) {
+        const double sd = ssin[sb][rsrc[i]], cd = scos[sb][rsrc[i]];
+        ph = sdecay[sb][JR + rsrc[i]];
+        uu = rkind[i] == 3 ? (ra[i] * sd - rb[i] * cd) : (ra[i] * cd + rb[i] * sd);
+        vv = rkind[i] == 3 ? sd : cd;
+      } else if (rkind[i] == 4) {
+        uu = g.U[(long)rsrc[i] * N + n];
+        vv = g.V[(long)rsrc[i] * N + n];
+      }
+      const int k = crow[i];
+      sphi[fb][col_slot(k)] = ph;
+      su[fb][col_slot(k)] = uu;
+      sv[fb][k] = vv;
+      if (first && k < J && n >= 1) { phi[(long)J * (n - 1) + k] = ph; u[(long)J * (n - 1) + k] = uu; }
     }
   };
 
@@ -145,48 +165,44 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
   __syncthreads();
   auto tile_at = [](const double (*tile)[64], int i) { return tile[(i >> 6) & 1][i & 63]; };
 
-  // sample 0: cholesky.h:100-117; features of sample 1
-  double Dprev = D[0];
+  // sample 0: cholesky.h:100-117; the features of sample 1, the tasks of sample 2
+  double Dprev = tile_at(tile_d, 0);
   LogProduct lp;
   lp.init();
   lp.mul(Dprev);
   // the forward sweep of dot_solve (cholesky.h:343-357) for the vector announced by clr_solver_hint_rhs: f row by row in
-  // the threads that compose the rows (every workgroup: all rows), x_n = y_n - u~_n . f_n from the waves' shares
-  double fr[RPT], xm1 = y ? y[0] : 0.0, quad = xm1 * (xm1 / Dprev), gsum = 0.0;
+  // the threads of (X) (every workgroup: all rows), x_n = y_n - u~_n . f_n from the waves' shares
+  double fr[RPT], xm1 = y ? tile_at(tile_y, 0) : 0.0, quad = xm1 * (xm1 / Dprev), gsum = 0.0;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) fr[i] = 0.0;
   {
-    const double value = 1.0 / Dprev;
-    const double t0 = g.t[0], t1 = N > 1 ? g.t[1] : g.t[0];
-    run_tasks(t0, 0.0);
+    const double t0 = tile_at(tile_t, 0), t1 = N > 1 ? tile_at(tile_t, 1) : t0, t2 = N > 2 ? tile_at(tile_t, 2) : t1;
+    run_tasks(t0, 0.0, 0);
     __syncthreads();
+    compose(0, 0);
+    __syncthreads();
+    const double value = 1.0 / Dprev;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int k = tid + i * ROWS_THREADS;
       if (k < JP) {
-        double ph, uu, vv;
-        compose(i, 0, ph, uu, vv);
-        const double w = vv * value;
+        const double w = sv[0][k] * value;
         sw[col_slot(k)] = w;
         if (first && k < J) W[k] = w;
       }
     }
+    run_tasks(t1, t1 - t0, 1);
     __syncthreads();
-    run_tasks(t1, t1 - t0);
+    if (N > 1) compose(1, 1);
+    run_tasks(t2, t2 - t1, 0);
     __syncthreads();
+    if (y && N > 1) {  // cholesky.h:343-352: f_1 = phi (0 + W_0 x_0), and the rows' terms of u~_1 . f_1
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int k = tid + i * ROWS_THREADS;
-      if (k < JP) {
-        double ph, uu, vv;
-        compose(i, N > 1 ? 1 : 0, ph, uu, vv);
-        sphi[col_slot(k)] = ph;
-        su[col_slot(k)] = uu;
-        sv[k] = vv;
-        if (first && k < J && N > 1) { phi[k] = ph; u[k] = uu; }
-        if (y) {  // cholesky.h:343-352: f_1 = phi (0 + W_0 x_0), and this row's term of u~_1 . f_1
-          fr[i] = ph * (sw[col_slot(k)] * xm1);
-          gsum += uu * fr[i];
+      for (int i = 0; i < RPT; ++i) {
+        const int k = tid + i * ROWS_THREADS;
+        if (k < JP) {
+          fr[i] = sphi[1][col_slot(k)] * (sw[col_slot(k)] * xm1);
+          gsum += su[1][col_slot(k)] * fr[i];
         }
       }
     }
@@ -198,6 +214,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
   __syncthreads();
 
   for (int n = 1; n < N; ++n) {
+    const int cur = n & 1, nxt = cur ^ 1;
     const double dn = tile_at(tile_d, n);  // (the full diagonal as handed over: cholesky.h:98-99)
     const bool fetch = (n & 63) == 0 && n >= 64 && tid < 64;  // the tile after this one (its buffer held the previous tile)
     double ft = 0.0, fd = 0.0, fy = 0.0;
@@ -214,17 +231,23 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       xn -= dot;  // cholesky.h:353
     }
     const bool more = n + 1 < N;
-    const double tn1 = more ? tile_at(tile_t, n + 1) : 0.0, dx1 = more ? tn1 - tile_at(tile_t, n) : 0.0;
+    // the next sample's features from the tasks staged one step ago; the tasks of the sample after it (nobody reads
+    // either target during this step's (Y)).  FIRST: the dependent chains of exp / sincos then fill the issue slots the
+    // SIMD's other wave leaves in its (Y); after (Y) they would run alone, every other wave waiting at the barrier.
+    if (more) compose(n + 1, nxt);
+    if (n + 2 < N) {
+      const double ta = tile_at(tile_t, n + 1), tb = tile_at(tile_t, n + 2);
+      run_tasks(tb, tb - ta, cur);
+    }
     // ---- (Y) the state's step and q = S u~, one pass ----------------------------------------------------------------
     if constexpr (BLOCKED) {
-      // width <= 128, one workgroup: a lane holds 4 rows x 8 columns.  The row-per-lane-group layout below reads 48 + 2
-      // LDS quadwords per lane and step -- 8 waves x 50 x 8 cycles of LDS return path = 3200 cycles, the step's bound
-      // (1.8 us measured); the block needs 12 (columns) + 4 (rows), at the price of four row sums over 16 lanes.
+      // width <= 128, one workgroup: a lane holds 4 rows x 8 columns -- 12 (columns) + 4 (rows) LDS quadwords per lane
+      // and step where the row-per-lane-group layout below reads 48 + 2, at the price of four row sums over 16 lanes
       const int cb = tid & 15, r0 = (tid >> 4) * 4;
-      const double2* pk2 = reinterpret_cast<const double2*>(&sphi[col_slot(8 * cb)]);
+      const double2* pk2 = reinterpret_cast<const double2*>(&sphi[cur][col_slot(8 * cb)]);
       const double2* wk2 = reinterpret_cast<const double2*>(&sw[col_slot(8 * cb)]);
-      const double2* uk2 = reinterpret_cast<const double2*>(&su[col_slot(8 * cb)]);
-      const double2* pr2 = reinterpret_cast<const double2*>(&sphi[col_slot(r0)]);
+      const double2* uk2 = reinterpret_cast<const double2*>(&su[cur][col_slot(8 * cb)]);
+      const double2* pr2 = reinterpret_cast<const double2*>(&sphi[cur][col_slot(r0)]);
       const double2* wr2 = reinterpret_cast<const double2*>(&sw[col_slot(r0)]);
       double pk[8], wk[8], uk[8], prr[4], dwr[4];
 #pragma unroll
@@ -254,7 +277,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       }
       double mine = 0.0;
       if (cb == 0) {
-        const double2* ur2 = reinterpret_cast<const double2*>(&su[col_slot(r0)]);
+        const double2* ur2 = reinterpret_cast<const double2*>(&su[cur][col_slot(r0)]);
         const double2 u01 = ur2[0], u23 = ur2[1];
         mine = (u01.x * qr[0] + u01.y * qr[1]) + (u23.x * qr[2] + u23.y * qr[3]);  // (padding rows: u~ = 0)
         sq[r0] = qr[0]; sq[r0 + 1] = qr[1]; sq[r0 + 2] = qr[2]; sq[r0 + 3] = qr[3];
@@ -262,13 +285,13 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       const double wsum = row_sum_all<1>(mine);
       if (lane == 0) spart[wave] = wsum;
     } else {
-      const double pr = sphi[col_slot(row)];
+      const double pr = sphi[cur][col_slot(row)];
       const double dw = Dprev * sw[col_slot(row)];
       double acc0 = 0.0, acc1 = 0.0;
       {
-        const double2* pk2 = reinterpret_cast<const double2*>(&sphi[34 * part]);
+        const double2* pk2 = reinterpret_cast<const double2*>(&sphi[cur][34 * part]);
         const double2* wk2 = reinterpret_cast<const double2*>(&sw[34 * part]);
-        const double2* uk2 = reinterpret_cast<const double2*>(&su[34 * part]);
+        const double2* uk2 = reinterpret_cast<const double2*>(&su[cur][34 * part]);
 #pragma unroll
         for (int c = 0; c < ROWS_COLS / 2; ++c) {
           const double2 pk = pk2[c], wk = wk2[c], uk = uk2[c];
@@ -281,7 +304,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
         }
       }
       const double q = rows_row_sum<TPR>(acc0 + acc1);
-      const double mine = (part == 0) ? su[col_slot(row)] * q : 0.0;  // (padding rows: u~ = 0)
+      const double mine = (part == 0) ? su[cur][col_slot(row)] * q : 0.0;  // (padding rows: u~ = 0)
       const double wsum = row_sum_all<1>(mine);
       if (lane == 0) spart[wave] = wsum;
       if (part == 0) {
@@ -289,8 +312,6 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
         else agent_store(X.q + (size_t)(n & 1) * JP + row, q);
       }
     }
-    // the next sample's exp / sincos (nobody reads the staging arrays during (Y))
-    if (more) run_tasks(tn1, dx1);
     if (G == 1) rows_lds_barrier();
     else __syncthreads();  // (the rows of q this wave stored must have left before thread 0 announces the workgroup's arrival)
     double total = 0.0;
@@ -317,7 +338,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
 #pragma unroll 8
       for (int w = 0; w < G; ++w) total += sshare[w];  // (every thread, every workgroup: the same order)
     }
-    // ---- (X) the pivot, W_n, and the features move on ---------------------------------------------------------------
+    // ---- (X) the pivot and W_n ------------------------------------------------------------------------------------------
     const double Dn = dn - total;
     if (Dn < 0.0 || (G > 1 && sabort)) {  // cholesky.h:176
       if (first && tid == 0) { if (!sabort) status[0] = 1; log_det[0] = NAN; }
@@ -329,20 +350,12 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       const int k = tid + i * ROWS_THREADS;
       if (k < JP) {
         const double qk = (G == 1) ? sq[k] : agent_load(X.q + (size_t)(n & 1) * JP + k);
-        double ph, uu, vv;
-        compose(i, more ? n + 1 : n, ph, uu, vv);
-        const double w = (sv[k] - qk) / Dn;  // cholesky.h:170-178
+        const double w = (sv[cur][k] - qk) / Dn;  // cholesky.h:170-178
         sw[col_slot(k)] = w;
-        sphi[col_slot(k)] = ph;
-        su[col_slot(k)] = uu;
-        sv[k] = vv;
-        if (first && k < J) {
-          W[(long)J * n + k] = w;
-          if (more) { phi[(long)J * n + k] = ph; u[(long)J * n + k] = uu; }
-        }
+        if (first && k < J) W[(long)J * n + k] = w;
         if (y && more) {
-          fr[i] = ph * (fr[i] + w * xn);  // cholesky.h:350-352
-          gsum += uu * fr[i];
+          fr[i] = sphi[nxt][col_slot(k)] * (fr[i] + w * xn);  // cholesky.h:350-352
+          gsum += su[nxt][col_slot(k)] * fr[i];
         }
       }
     }
