@@ -748,7 +748,6 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
 
 int clr_solver_dot_L(const clr_solver* cs, int z_rows, int nrhs, const double* z, double* y) {
   clr_solver* s = const_cast<clr_solver*>(cs);
-  if (s->computed && s->J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "dot_L covers widths up to CLR_MAX_WIDTH (128)");
   int st = sweep_common(s, z_rows, nrhs, z);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
@@ -794,7 +793,7 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
   const bool has_general = (n_A != 0);
   const int J_general = U_rows, J_real = n_a_real, J_comp = n_a_comp;
   const int J = J_real + 2 * J_comp + J_general;
-  if (J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH");
+  if (J > CLR_MAX_WIDTH_ANY) return fail(CLR_UNSUPPORTED, "width above CLR_MAX_WIDTH_ANY");
   if (J_general > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
   if (N < 1 || nrhs < 1) return CLR_OK;
 
@@ -891,7 +890,6 @@ int clr_solver_dot(clr_solver* s, double jitter, int n_a_real, const double* a_r
 int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, const double* xs,
                        double* pred) {
   clr_solver* s = const_cast<clr_solver*>(cs);
-  if (s->computed && s->J > CLR_MAX_WIDTH) return fail(CLR_UNSUPPORTED, "predict covers widths up to CLR_MAX_WIDTH (128)");
   int st = sweep_common(s, n_y, 1, y);  // also checks N / computed (:600-601)
   if (st != CLR_OK) return st;
   if (M <= 0) return CLR_OK;
@@ -908,6 +906,8 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
   if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;
     if ((st = sweep_scan(s, 1, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;
+  } else if (s->J > CLR_MAX_WIDTH) {
+    clr::launch_solve_huge(s->N, s->J, 1, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scratch2.p, stream);
   } else {
     clr::launch_solve(s->N, s->J, 1, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
                       s->scratch2.p, stream);

@@ -530,14 +530,17 @@ __global__ void __launch_bounds__(64) dot_kernel(int N, int J, const double* phi
 
 // cholesky.h:599-698.  Row types: real rows carry one Q, a complex pair carries
 // the cos-like and sin-like Q; general rows do not take part (as in the reference).
+template <int R>  // rows per lane: 2 up to width 128, 16 up to 1024 (round 6)
 __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const double* alpha,
                                                      int M, const double* xs, double* pred) {
   const int N = g.N, Jrc = g.J_real + 2 * g.J_comp;
   const double* t_ = g.t;
-  // each lane serves rows lane and lane + 64
-  double a[2] = {0, 0}, b[2] = {0, 0}, c[2] = {0, 0}, d[2] = {0, 0};
-  int kind[2] = {-1, -1};  // 0 real, 1 complex-cos row, 2 complex-sin row
-  for (int r = 0; r < 2; ++r) {
+  // each lane serves rows lane, lane + 64, ...
+  double a[R], b[R], c[R], d[R];
+  int kind[R];  // 0 real, 1 complex-cos row, 2 complex-sin row
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    a[r] = 0.0; b[r] = 0.0; c[r] = 0.0; d[r] = 0.0; kind[r] = -1;
     const int j = threadIdx.x + 64 * r;
     if (j < g.J_real) {
       kind[r] = 0; a[r] = g.a_real[j]; c[r] = g.c_real[j];
@@ -547,7 +550,9 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
       a[r] = g.a_comp[jj]; b[r] = g.b_comp[jj]; c[r] = g.c_comp[jj]; d[r] = g.d_comp[jj];
     }
   }
-  double Q[2] = {0.0, 0.0};
+  double Q[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) Q[r] = 0.0;
 
   // forward pass :615-653
   int m = 0;
@@ -557,7 +562,8 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
     const double tref = (n < N - 1) ? t_[n + 1] : t_[N - 1];
     const double tn = t_[n];
     double dt = tref - tn;
-    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       if (kind[r] == 0) {
         Q[r] = (Q[r] + alphan) * exp(-c[r] * dt);
       } else if (kind[r] > 0) {
@@ -570,7 +576,8 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
       const double xm = xs[m];
       dt = xm - tref;
       double pm = 0.0;
-      for (int r = 0; r < 2; ++r) {
+  #pragma unroll
+    for (int r = 0; r < R; ++r) {
         if (kind[r] == 0) {
           pm += a[r] * exp(-c[r] * dt) * Q[r];
         } else if (kind[r] > 0) {
@@ -592,13 +599,15 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
   // backward pass :656-695
   m = M - 1;
   while (m >= 0 && xs[m] > t_[N - 1]) --m;
-  Q[0] = Q[1] = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) Q[r] = 0.0;
   for (int n = N - 1; n >= 0; --n) {
     const double alphan = alpha[n];
     const double tref = (n > 0) ? t_[n - 1] : t_[0];
     const double tn = t_[n];
     double dt = tn - tref;
-    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       if (kind[r] == 0) {
         Q[r] = (Q[r] + alphan * a[r]) * exp(-c[r] * dt);
       } else if (kind[r] > 0) {
@@ -612,7 +621,8 @@ __global__ void __launch_bounds__(64) predict_kernel(GenericProblem g, const dou
       const double xm = xs[m];
       dt = tref - xm;
       double pm = 0.0;
-      for (int r = 0; r < 2; ++r) {
+  #pragma unroll
+    for (int r = 0; r < R; ++r) {
         if (kind[r] == 0) {
           pm += exp(-c[r] * dt) * Q[r];
         } else if (kind[r] > 0) {
@@ -685,7 +695,8 @@ void launch_dot(int N, int J, int nrhs, const double* phi, const double* u, cons
 
 void launch_predict(const GenericProblem& g, const double* alpha, int M, const double* xs,
                     double* pred, hipStream_t s) {
-  hipLaunchKernelGGL(predict_kernel, dim3(1), dim3(64), 0, s, g, alpha, M, xs, pred);
+  if (g.J_real + 2 * g.J_comp <= 128) hipLaunchKernelGGL((predict_kernel<2>), dim3(1), dim3(64), 0, s, g, alpha, M, xs, pred);
+  else hipLaunchKernelGGL((predict_kernel<16>), dim3(1), dim3(64), 0, s, g, alpha, M, xs, pred);
 }
 
 }  // namespace clr

@@ -14,6 +14,7 @@
 //              lane = row, DPP reductions, factor rows prefetched KB steps ahead (as generic_kernels.hip).
 // A sequential sweep costs 0.23 us per step (25-50 ms at N = 1e5, where the CPU needs 0.6-4 ms); measured here
 // at N = 1e5 (profiles/r02y_sweeps_*): dot_solve 0.29 ms at width 8, 0.49 ms at width 32; solve twice that.
+#include "../../include/celerite_hip.h"
 #include "clr_generic_kernels.h"
 #include "clr_options.h"
 #include "clr_wide.h"
@@ -369,19 +370,21 @@ __global__ void __launch_bounds__(64) wsweep_finalize_kernel(const SweepParams P
 }
 
 // dot_L (cholesky.h:409-431) at any width: f_j <- phi_j (f_j + W_j sqrt(D_{n-1}) z_{n-1}) is DIAGONAL in j,
-// so a chunk is (a_j, f_j) per row; one wave per (chunk, right-hand side), lane = row.
-template <bool REPLAY>
-__global__ void __launch_bounds__(64) wdotl_kernel(const SweepParams P) {
+// so a chunk is (a_j, f_j) per row; NW waves per (chunk, right-hand side), thread = row (round 6: widths above 64 --
+// the replay's sum over the rows then goes through LDS, one workgroup barrier per tile of KB steps).
+template <bool REPLAY, int NW>
+__global__ void __launch_bounds__(64 * NW) wdotl_kernel(const SweepParams P) {
   constexpr int KB = 8;
-  const int J = P.J, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
-  const bool have = lane < J;
+  __shared__ double xw[2][NW][KB];
+  const int J = P.J, row = threadIdx.x, lane = row & 63, wave = row >> 6, c = blockIdx.x, rhs = blockIdx.y;
+  const bool have = row < J;
   const double* z = P.in + (long)rhs * P.N;
   double* y = P.out + (long)rhs * P.N;
   const long slot = (long)rhs * P.nchunk + c;
-  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + lane] : 0.0;
+  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + row] : 0.0;
   const int s0 = c * P.L + 1;
   const int s1 = min(s0 + P.L, P.N);
-  if (REPLAY && c == 0 && lane == 0) y[0] = sqrt(P.D[0]) * z[0];  // :421-422
+  if (REPLAY && c == 0 && row == 0) y[0] = sqrt(P.D[0]) * z[0];  // :421-422
   double np[KB], nw[KB], nu[KB], ntz = 0.0;
   auto fetch = [&](int sb) {
 #pragma unroll
@@ -389,19 +392,21 @@ __global__ void __launch_bounds__(64) wdotl_kernel(const SweepParams P) {
       const int n = sb + k;
       const long col = (long)J * (n - 1);
       const bool ok = n < s1 && have;
-      np[k] = ok ? P.phi[col + lane] : 0.0;
-      nw[k] = ok ? P.W[col + lane] : 0.0;
-      nu[k] = (REPLAY && ok) ? P.u[col + lane] : 0.0;
+      np[k] = ok ? P.phi[col + row] : 0.0;
+      nw[k] = ok ? P.W[col + row] : 0.0;
+      nu[k] = (REPLAY && ok) ? P.u[col + row] : 0.0;
     }
-    const int n = sb - 1 + lane;  // lanes 0..KB: sqrt(D_n) z_n for n = sb-1 .. sb+KB-1
+    const int n = sb - 1 + lane;  // lanes 0..KB (of every wave): sqrt(D_n) z_n for n = sb-1 .. sb+KB-1
     ntz = (lane <= KB && n < s1) ? sqrt(P.D[n]) * z[n] : 0.0;
   };
   fetch(s0);
-  for (int sb = s0; sb < s1; sb += KB) {
+  int par = 0;
+  for (int sb = s0; sb < s1; sb += KB, par ^= 1) {
     double cp[KB], cw[KB], cu[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) { cp[k] = np[k]; cw[k] = nw[k]; cu[k] = nu[k]; }
     const double ctz = ntz;
+    const double ctz_up = (REPLAY && NW > 1) ? __shfl(ctz, (lane + 1) & 63, 64) : 0.0;  // lane k: sqrt(D_n) z_n of step sb + k
     if (sb + KB < s1) fetch(sb + KB);
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
@@ -410,19 +415,30 @@ __global__ void __launch_bounds__(64) wdotl_kernel(const SweepParams P) {
         f = cp[k] * (f + cw[k] * lane_value(ctz, k));  // :424-425
         if (!REPLAY) a *= cp[k];
         if (REPLAY) {
-          const double v = lane_value(ctz, k + 1) + wsum(cu[k] * f);  // :426
-          if (lane == 0) y[n] = v;
+          const double rows = wsum(cu[k] * f);
+          if (NW == 1) {
+            const double v = lane_value(ctz, k + 1) + rows;  // :426
+            if (lane == 0) y[n] = v;
+          } else if (lane == 0) xw[par][wave][k] = rows;
         }
+      }
+    }
+    if (REPLAY && NW > 1) {  // the tile's sums over the waves (the buffer of the tile before last is free again: one barrier)
+      __syncthreads();
+      if (wave == 0 && lane < KB && sb + lane < s1) {
+        double v = ctz_up;
+        for (int w = 0; w < NW; ++w) v += xw[par][w][lane];
+        y[sb + lane] = v;
       }
     }
   }
   if (!REPLAY && have) {
-    P.elems[slot * 2 * J + lane] = a;
-    P.elems[slot * 2 * J + J + lane] = f;
+    P.elems[slot * 2 * J + row] = a;
+    P.elems[slot * 2 * J + J + row] = f;
   }
 }
 
-__global__ void __launch_bounds__(64) wdotl_prefix_kernel(const SweepParams P) {
+__global__ void __launch_bounds__(1024) wdotl_prefix_kernel(const SweepParams P) {  // (thread = row: 64 ... 1024 threads)
   constexpr int KB = 16;  // chunks fetched ahead
   const int J = P.J, lane = threadIdx.x, rhs = blockIdx.x;
   if (lane >= J) return;
@@ -455,19 +471,20 @@ __global__ void __launch_bounds__(64) wdotl_prefix_kernel(const SweepParams P) {
 // dot (cholesky.h:533-560): y = K z from phi, u, v (all J x N) and the diagonal dg -- two more diagonal
 // recurrences, PASS 0 the upper triangle walking n down (:536-547), PASS 1 the lower one walking n up (:549-559),
 // each as summarize / prefix (wdotl_prefix_kernel) / replay over chunks of the step index s = 1 .. N-1.
-template <bool REPLAY, int PASS>
-__global__ void __launch_bounds__(64) wdot_kernel(const SweepParams P, const double* __restrict__ v,
-                                                  const double* __restrict__ dg) {
+template <bool REPLAY, int PASS, int NW>
+__global__ void __launch_bounds__(64 * NW) wdot_kernel(const SweepParams P, const double* __restrict__ v,
+                                                       const double* __restrict__ dg) {
   constexpr int KB = 8;
-  const int J = P.J, N = P.N, lane = threadIdx.x, c = blockIdx.x, rhs = blockIdx.y;
-  const bool have = lane < J;
+  __shared__ double xw[2][NW][KB];
+  const int J = P.J, N = P.N, row = threadIdx.x, lane = row & 63, wave = row >> 6, c = blockIdx.x, rhs = blockIdx.y;
+  const bool have = row < J;
   const double* z = P.in + (long)rhs * N;
   double* y = P.out + (long)rhs * N;
   const long slot = (long)rhs * P.nchunk + c;
-  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + lane] : 0.0;
+  double a = 1.0, f = (REPLAY && have) ? P.starts[slot * J + row] : 0.0;
   const int s0 = c * P.L + 1;
   const int s1 = min(s0 + P.L, N);
-  if (REPLAY && PASS == 0 && c == 0 && lane == 0) y[N - 1] = dg[N - 1] * z[N - 1];  // :535
+  if (REPLAY && PASS == 0 && c == 0 && row == 0) y[N - 1] = dg[N - 1] * z[N - 1];  // :535
   const double* wp = PASS == 0 ? P.u : v;   // weight of the incoming z
   const double* op = PASS == 0 ? v : P.u;   // weight of f in the output
   double np[KB], nw[KB], no[KB], nzin = 0.0, nbase = 0.0;
@@ -478,18 +495,19 @@ __global__ void __launch_bounds__(64) wdot_kernel(const SweepParams P, const dou
       const int n = PASS == 0 ? N - 1 - s : s;
       const long base = (long)J * (PASS == 0 ? n : n - 1);
       const bool ok = s < s1 && have;
-      np[k] = ok ? P.phi[base + lane] : 0.0;
-      nw[k] = ok ? wp[base + lane] : 0.0;
-      no[k] = (REPLAY && ok) ? op[base + lane] : 0.0;
+      np[k] = ok ? P.phi[base + row] : 0.0;
+      nw[k] = ok ? wp[base + row] : 0.0;
+      no[k] = (REPLAY && ok) ? op[base + row] : 0.0;
     }
-    const int s = sb + lane;  // lanes 0 .. KB-1: the step's scalars
+    const int s = sb + lane;  // lanes 0 .. KB-1 (of every wave): the step's scalars
     const int n = PASS == 0 ? N - 1 - s : s;
     const bool ok = lane < KB && s < s1;
     nzin = ok ? z[PASS == 0 ? n + 1 : n - 1] : 0.0;
     nbase = (REPLAY && ok) ? (PASS == 0 ? dg[n] * z[n] : y[n]) : 0.0;  // (PASS 1 adds to PASS 0's result)
   };
   fetch(s0);
-  for (int sb = s0; sb < s1; sb += KB) {
+  int par = 0;
+  for (int sb = s0; sb < s1; sb += KB, par ^= 1) {
     double cp[KB], cw[KB], co[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) { cp[k] = np[k]; cw[k] = nw[k]; co[k] = no[k]; }
@@ -502,35 +520,63 @@ __global__ void __launch_bounds__(64) wdot_kernel(const SweepParams P, const dou
         f = cp[k] * (f + cw[k] * lane_value(czin, k));  // :540-542 / :552-554
         if (!REPLAY) a *= cp[k];
         if (REPLAY) {
-          const double val = lane_value(cbase, k) + wsum(co[k] * f);  // :543-545 / :555-557
-          if (lane == 0) y[PASS == 0 ? N - 1 - s : s] = val;
+          const double rows = wsum(co[k] * f);
+          if (NW == 1) {
+            const double val = lane_value(cbase, k) + rows;  // :543-545 / :555-557
+            if (lane == 0) y[PASS == 0 ? N - 1 - s : s] = val;
+          } else if (lane == 0) xw[par][wave][k] = rows;
         }
+      }
+    }
+    if (REPLAY && NW > 1) {  // the tile's sums over the waves
+      __syncthreads();
+      if (wave == 0 && lane < KB && sb + lane < s1) {
+        double val = cbase;  // (lane k holds step sb + k's base value)
+        for (int w = 0; w < NW; ++w) val += xw[par][w][lane];
+        const int s = sb + lane;
+        y[PASS == 0 ? N - 1 - s : s] = val;
       }
     }
   }
   if (!REPLAY && have) {
-    P.elems[slot * 2 * J + lane] = a;
-    P.elems[slot * 2 * J + J + lane] = f;
+    P.elems[slot * 2 * J + row] = a;
+    P.elems[slot * 2 * J + J + row] = f;
   }
 }
 
 }  // namespace
 
 // workspace: nrhs * nchunk * 3 J doubles; P.phi, P.u = phi, u of `dot`'s own setup (J x N), P.in = z, P.out = y
+// waves per workgroup of the diagonal scans: thread = row
+static int wdot_waves(int J) { return J <= 64 ? 1 : (J <= 128 ? 2 : (J <= 256 ? 4 : (J <= 512 ? 8 : 16))); }
+#define CLR_WDOT_DISPATCH(NWV, CALL) \
+  do {                               \
+    switch (NWV) {                   \
+      case 1: { constexpr int NW = 1; CALL; break; }   \
+      case 2: { constexpr int NW = 2; CALL; break; }   \
+      case 4: { constexpr int NW = 4; CALL; break; }   \
+      case 8: { constexpr int NW = 8; CALL; break; }   \
+      default: { constexpr int NW = 16; CALL; break; } \
+    }                                \
+  } while (0)
+
 void launch_wdot_scan(SweepParams P, const double* v, const double* dg, double* workspace, hipStream_t s) {
   const size_t pc = (size_t)P.nrhs * P.nchunk;
   P.elems = workspace;
   P.starts = P.elems + pc * 2 * P.J;
   const dim3 grid(P.nchunk, P.nrhs);
-  hipLaunchKernelGGL((wdot_kernel<false, 0>), grid, dim3(64), 0, s, P, v, dg);
-  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
-  hipLaunchKernelGGL((wdot_kernel<true, 0>), grid, dim3(64), 0, s, P, v, dg);
-  hipLaunchKernelGGL((wdot_kernel<false, 1>), grid, dim3(64), 0, s, P, v, dg);
-  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
-  hipLaunchKernelGGL((wdot_kernel<true, 1>), grid, dim3(64), 0, s, P, v, dg);
+  const int nwv = wdot_waves(P.J);
+  const dim3 block(64 * nwv);
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdot_kernel<false, 0, NW>), grid, block, 0, s, P, v, dg));
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), block, 0, s, P);
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdot_kernel<true, 0, NW>), grid, block, 0, s, P, v, dg));
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdot_kernel<false, 1, NW>), grid, block, 0, s, P, v, dg));
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), block, 0, s, P);
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdot_kernel<true, 1, NW>), grid, block, 0, s, P, v, dg));
 }
 
-bool wdotl_scan_supported(int N, int J) { return J >= 1 && J <= 64 && N >= 2048; }
+// long series at any width; above width 128 (no sequential kernel there) every series of two samples or more
+bool wdotl_scan_supported(int N, int J) { return J >= 1 && J <= CLR_MAX_WIDTH_ANY && (N >= 2048 || (J > CLR_MAX_WIDTH && N >= 2)); }
 int wdotl_chunks(int N) { return std::max(2, std::min(512, (N - 1) / 128)); }
 
 // workspace: nrhs * nchunk * 3 J doubles
@@ -539,9 +585,11 @@ void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s) {
   P.elems = workspace;
   P.starts = P.elems + pc * 2 * P.J;
   const dim3 grid(P.nchunk, P.nrhs);
-  hipLaunchKernelGGL((wdotl_kernel<false>), grid, dim3(64), 0, s, P);
-  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), dim3(64), 0, s, P);
-  hipLaunchKernelGGL((wdotl_kernel<true>), grid, dim3(64), 0, s, P);
+  const int nwv = wdot_waves(P.J);
+  const dim3 block(64 * nwv);
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdotl_kernel<false, NW>), grid, block, 0, s, P));
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), block, 0, s, P);
+  CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdotl_kernel<true, NW>), grid, block, 0, s, P));
 }
 
 // (measured at N = 1e5, width 8: 0.29 ms against 1.35 ms for the lane-per-chunk scan of sweep_kernels.hip, which

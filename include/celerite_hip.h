@@ -44,11 +44,14 @@ typedef enum clr_status {
   CLR_CARMA_INSTABILITY = 8      /* celerite::carma_exception     exceptions.h:8-12  */
 } clr_status;
 
-/* Widest semiseparable rank J = J_real + 2 J_comp + J_general accepted. */
+/* Widest semiseparable rank J = J_real + 2 J_comp + J_general of the batched plans (fused log-likelihood; the scans stop
+ * at 64) and of the one-workgroup kernels of the object API. */
 #define CLR_MAX_WIDTH 128
-/* CholeskySolver.compute / log_determinant / dot_solve / solve take ANY width up to this one (round 6; the reference's
- * dynamic-width arm, cholesky.h:203, has no limit and its benchmark goes to 512): above CLR_MAX_WIDTH the state S lives
- * in HBM / L2 instead of LDS (csrc/huge_kernels.hip).  Everything else stops at CLR_MAX_WIDTH. */
+/* The object API -- CholeskySolver.compute / log_determinant / dot_solve / solve / dot_L / dot / predict and the pickled
+ * state -- takes ANY width up to this one (round 6; the reference's dynamic-width arm, cholesky.h:203, has no limit and
+ * its benchmark goes to 512): compute above 64 keeps S in the registers of 1 .. 64 workgroups (csrc/rows_kernels.hip),
+ * dot_L / dot are diagonal scans with one thread per row, the sweeps of solve / dot_solve above 128 one workgroup per
+ * right-hand side (csrc/huge_kernels.hip).  grad_log_likelihood stops at width 64. */
 #define CLR_MAX_WIDTH_ANY 1024
 #define CLR_CARMA_MAX_ORDER 32 /* autoregressive order p of clr_carma (state p, covariance p x p in LDS) */
 
