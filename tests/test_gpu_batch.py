@@ -2907,3 +2907,49 @@ def test_general_terms_in_the_batch(JR, JC, JG, N, shared):
     ok = s0 == 0
     assert np.max(np.abs(ld2[ok] - d0[ok]) / np.abs(d0[ok])) <= REL
     plan.close()
+
+
+@pytest.mark.parametrize("width,B,N", [(16, 6, 30000), (32, 4, 30000)])
+def test_materialising_plan_of_reference_benchmark_kernels_is_settled_by_the_output_check(width, B, N):
+    """Round 6: the output check (BatchParams::head_check, csrc/api_internal.h wide_flow) in a PLAN.  The reference
+    benchmark's kernels (identical complex terms, examples/benchmark/run.py:80-84) at widths 16 / 32: a materialising run
+    whose chunked replay misses the scanned start states by more than the bound is settled by consecutive replays that
+    agree (route 1) -- with the check off, by the sequential recurrence (route 2) -- and either way the factor and the
+    batched solve agree with the oracle."""
+    j = width // 2
+    JR, JC = 1 + (2 * j - 1) % 2, (2 * j - 1) // 2
+    rng = np.random.RandomState(width)
+    t = np.sort(rng.rand(B, 2 ** 19), axis=1)[:, :N].copy()     # (the benchmark's own sampling: the first N of 2^19 draws)
+    diag = rng.uniform(0.1, 0.2, (B, N)) ** 2
+    y = np.sin(t)
+    a_real = np.full((B, JR), 1.0); c_real = np.full((B, JR), 0.1)
+    a_comp = np.full((B, JC), 0.1); b_comp = np.zeros((B, JC)); c_comp = np.full((B, JC), 2.0); d_comp = np.full((B, JC), 1.6)
+    e_, e2_ = np.empty(0), np.empty((0, 0))
+    levels = {}
+    for check in (True, False):
+        batch.set_option("CLR_OUTPUT_CHECK_CAP", None if check else "0")
+        try:
+            plan = batch.BatchedGP(B, N, JR, JC)
+            plan.set_series(t, diag, y)
+            plan.set_coefficients(a_real, c_real, a_comp, b_comp, c_comp, d_comp)
+            ll, ld, q, st = plan.log_likelihood(materialize=True)
+            levels[check] = plan.exact_levels().copy()
+            x = plan.solve()
+            for p in (0, B - 1):
+                r = ref.RefSolver()
+                r.compute(0.0, a_real[p], c_real[p], a_comp[p], b_comp[p], c_comp[p], d_comp[p], e_, e2_, e2_, t[p], diag[p])
+                _, _, J, logdet, rphi, ru, rW, rD = r.state()
+                phi, u, W, D = plan.factor(p)
+                tag = (width, "output check" if check else "end-state test only", p)
+                within("materialising plan, reference benchmark kernels: log det vs oracle", abs(ld[p] - logdet) / abs(logdet), 1e-12, tag)
+                within("materialising plan, reference benchmark kernels: W vs oracle (of the largest entry)", np.max(np.abs(W - rW)) / np.max(np.abs(rW)), 3e-11, tag)
+                within("materialising plan, reference benchmark kernels: D vs oracle (relative)", np.max(np.abs(D - rD) / np.abs(rD)), 3e-11, tag)
+                want = r.solve(y[p])[:, 0]
+                within("materialising plan, reference benchmark kernels: batched solve vs oracle (of the largest)", np.max(np.abs(x[p] - want)) / np.max(np.abs(want)), 3e-11, tag)
+            plan.close()
+        finally:
+            batch.set_option("CLR_OUTPUT_CHECK_CAP", None)
+    # (whether the end states miss the bound depends on the draw; where they do, the check must have kept the problem chunked)
+    print("routes without / with the output check:", levels[False], levels[True])
+    assert np.any(levels[False] == 2), levels[False]
+    assert np.all(levels[True][levels[False] == 2] == 1), (levels[True], levels[False])
