@@ -182,6 +182,10 @@ struct clr_solver {
   DevBuf keep_diag, keep_jitter, ws_ends;  // compute's diag / jitter (kept for that pass), the chunks' end states
   clr::BatchParams refine_P;
   int refine_pending = 0;               // 0 nothing to do, 1 narrow plan kernels, 2 wide kernels
+  // chunk maps of the affine scans over the stored factor at widths above 64 (bigsweep_kernels.hip): per direction, built by
+  // the first sweep that needs them, dropped with the factor
+  DevBuf big_maps[2];
+  bool big_maps_valid[2] = {false, false};
   // the route the last compute took through the chunked flow (clr_solver_debug_route): device pointers into the workspace
   const int* route_level = nullptr;
   const double* route_cond = nullptr;

@@ -152,6 +152,7 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
   s->computed = 0;  // cholesky.h:57
   s->refine_pending = 0;
   s->route_level = nullptr; s->route_nchunk = 0;
+  s->big_maps_valid[0] = s->big_maps_valid[1] = false;
   s->have_quad = false;
   const bool use_rhs = s->rhs_hint && (int)s->host_rhs.size() == N;
   s->rhs_hint = false;  // (one shot)
@@ -617,10 +618,38 @@ int clr_solver_log_determinant(const clr_solver* s, double* out) {
 // dot_solve / solve as chunked scans for long series: N >= 2048 and width <= 32 one wave per chunk, one lane
 // per column of the chunk's map (wsweep_kernels.hip); 256 <= N < 2048 and width <= 8 one lane per chunk
 // (sweep_kernels.hip); otherwise the sequential sweeps (generic_kernels.hip)
+static bool big_sweep(const clr_solver* s) { return clr::bigsweep_supported(s->N, s->J) && !clr::option("CLR_NO_BIG_SWEEP"); }
 static bool sweep_scan_ok(const clr_solver* s) {
-  return clr::sweep_scan_supported(s->N, s->J) || clr::wsweep_scan_supported(s->N, s->J);
+  return clr::sweep_scan_supported(s->N, s->J) || clr::wsweep_scan_supported(s->N, s->J) || big_sweep(s);
+}
+// widths above 64: the affine scans of bigsweep_kernels.hip (`in` and `out` must be different arrays)
+static int big_sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, double* quad, int backward) {
+  const int nc0 = clr::bigsweep_chunks(s->N, s->J);
+  const int L = (s->N - 1 + nc0 - 1) / nc0, nchunk = (s->N - 1 + L - 1) / L;
+  int st;
+  if (!s->big_maps_valid[backward]) {
+    if ((st = s->big_maps[backward].reserve(clr::bigsweep_maps_doubles(s->J, nchunk))) != CLR_OK) return st;
+    clr::launch_bigsweep_maps(s->N, s->J, nchunk, L, backward, s->phi.p, s->u.p, s->W.p, s->big_maps[backward].p, s->stream);
+    s->big_maps_valid[backward] = true;
+  }
+  const int SLICE = 4096;
+  for (int r0 = 0; r0 < nrhs; r0 += SLICE) {
+    const int nr = std::min(SLICE, nrhs - r0);
+    clr::SweepParams P;
+    memset(&P, 0, sizeof(P));
+    P.N = s->N; P.J = s->J; P.nrhs = nr; P.nchunk = nchunk; P.L = L;
+    P.phi = s->phi.p; P.u = s->u.p; P.W = s->W.p; P.D = s->D.p;
+    P.in = in + (size_t)r0 * s->N;
+    P.out = out ? out + (size_t)r0 * s->N : nullptr;
+    P.quad = quad ? quad + r0 : nullptr;
+    P.backward = backward;
+    if ((st = s->ws_elems.reserve(clr::bigsweep_workspace_doubles(s->J, nchunk, nr))) != CLR_OK) return st;
+    clr::launch_bigsweep_scan(P, s->big_maps[backward].p, s->ws_elems.p, s->stream);
+  }
+  return CLR_OK;
 }
 static int sweep_scan(clr_solver* s, int nrhs, const double* in, double* out, double* quad, int backward) {
+  if (big_sweep(s)) return big_sweep_scan(s, nrhs, in, out, quad, backward);
   const bool wide = clr::wsweep_scan_supported(s->N, s->J);
   const int SLICE = 16384;  // right-hand sides per launch (grid.y / workspace bound); stream order keeps the slices apart
   for (int r0 = 0; r0 < nrhs; r0 += SLICE) {
@@ -683,10 +712,10 @@ int clr_solver_dot_solve(const clr_solver* cs, int n_b, const double* b, double*
   if ((st = ensure_refined(s)) != CLR_OK) return st;
   if ((st = upload(s->scratch, b, (size_t)s->N, s->stream)) != CLR_OK) return st;
   if ((st = s->scalars.reserve(8)) != CLR_OK) return st;
-  if (s->J > CLR_MAX_WIDTH) {
-    clr::launch_dot_solve_huge(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scalars.p, s->stream);
-  } else if (sweep_scan_ok(s)) {
+  if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, nullptr, s->scalars.p, 0)) != CLR_OK) return st;
+  } else if (s->J > CLR_MAX_WIDTH) {
+    clr::launch_dot_solve_huge(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scalars.p, s->stream);
   } else {
     clr::launch_dot_solve(s->N, s->J, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
                           s->scalars.p, s->stream);
@@ -730,17 +759,22 @@ int clr_solver_solve(const clr_solver* cs, int b_rows, int nrhs, const double* b
   int st = sweep_common(s, b_rows, nrhs, b);
   if (st != CLR_OK) return st;
   if (nrhs <= 0) return CLR_OK;
-  if (s->J > CLR_MAX_WIDTH) {
-    clr::launch_solve_huge(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scratch2.p, s->stream);
+  double* result = s->scratch2.p;
+  if (big_sweep(s)) {  // (its passes do not work in place: b -> scratch2 -> scratch)
+    if ((st = sweep_scan(s, nrhs, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;   // :240-248
+    if ((st = sweep_scan(s, nrhs, s->scratch2.p, s->scratch.p, nullptr, 1)) != CLR_OK) return st;   // :249-259
+    result = s->scratch.p;
   } else if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, nrhs, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;   // :240-248
     if ((st = sweep_scan(s, nrhs, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;  // :249-259
+  } else if (s->J > CLR_MAX_WIDTH) {
+    clr::launch_solve_huge(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p, s->scratch2.p, s->stream);
   } else {
     clr::launch_solve(s->N, s->J, nrhs, s->phi.p, s->u.p, s->W.p, s->D.p, s->scratch.p,
                       s->scratch2.p, s->stream);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(x, s->scratch2.p, sizeof(double) * (size_t)s->N * nrhs,
+  HIP_TRY(hipMemcpyAsync(x, result, sizeof(double) * (size_t)s->N * nrhs,
                          hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return CLR_OK;
@@ -903,7 +937,11 @@ int clr_solver_predict(const clr_solver* cs, int n_y, const double* y, int M, co
                 "state does not carry them (same as the reference, solver.cpp:36-42)");
   hipStream_t stream = s->stream;
   // alpha = K^-1 y  (:608)
-  if (sweep_scan_ok(s)) {
+  if (big_sweep(s)) {  // (not in place: y -> scratch2 -> scratch, then back to scratch2 where predict reads alpha)
+    if ((st = sweep_scan(s, 1, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;
+    if ((st = sweep_scan(s, 1, s->scratch2.p, s->scratch.p, nullptr, 1)) != CLR_OK) return st;
+    HIP_TRY(hipMemcpyAsync(s->scratch2.p, s->scratch.p, sizeof(double) * (size_t)s->N, hipMemcpyDeviceToDevice, stream));
+  } else if (sweep_scan_ok(s)) {
     if ((st = sweep_scan(s, 1, s->scratch.p, s->scratch2.p, nullptr, 0)) != CLR_OK) return st;
     if ((st = sweep_scan(s, 1, s->scratch2.p, s->scratch2.p, nullptr, 1)) != CLR_OK) return st;
   } else if (s->J > CLR_MAX_WIDTH) {
@@ -975,6 +1013,7 @@ int clr_solver_set_state(clr_solver* s, int computed, int N, int J, double log_d
   // solver.cpp:44-58: plain member assignment; coefficients and t are NOT part
   // of the state (so predict is unavailable afterwards, as in the reference).
   s->computed = 0;
+  s->big_maps_valid[0] = s->big_maps_valid[1] = false;
   s->refine_pending = 0;
   s->N = N;
   s->J = J;

@@ -165,6 +165,14 @@ void launch_dot_solve_huge(int N, int J, const double* phi, const double* u, con
                            const double* b, double* out, hipStream_t s);
 void launch_solve_huge(int N, int J, int nrhs, const double* phi, const double* u, const double* W, const double* D,
                        const double* b, double* x, hipStream_t s);
+// dot_solve / solve at widths 65 .. 1024 on long series (bigsweep_kernels.hip): chunked affine scans whose J x J chunk maps
+// are built once per factor and direction (maps: bigsweep_maps_doubles per direction) and shared by all right-hand sides
+bool bigsweep_supported(int N, int J);
+int bigsweep_chunks(int N, int J);
+size_t bigsweep_maps_doubles(int J, int nchunk);
+size_t bigsweep_workspace_doubles(int J, int nchunk, int nrhs);
+void launch_bigsweep_maps(int N, int J, int nchunk, int L, int backward, const double* phi, const double* u, const double* W, double* maps, hipStream_t s);
+void launch_bigsweep_scan(const SweepParams& P, const double* maps, double* workspace, hipStream_t s);  // P.in != P.out
 // widths 33 .. 1024 (rows_kernels.hip): S in the registers of 1 / 4 / 16 / 64 workgroups, one counter barrier per step
 bool factor_rows_supported(int J);
 size_t factor_rows_workspace_doubles(int J);

@@ -50,8 +50,8 @@ typedef enum clr_status {
 /* The object API -- CholeskySolver.compute / log_determinant / dot_solve / solve / dot_L / dot / predict and the pickled
  * state -- takes ANY width up to this one (round 6; the reference's dynamic-width arm, cholesky.h:203, has no limit and
  * its benchmark goes to 512): compute above 64 keeps S in the registers of 1 .. 64 workgroups (csrc/rows_kernels.hip),
- * dot_L / dot are diagonal scans with one thread per row, the sweeps of solve / dot_solve above 128 one workgroup per
- * right-hand side (csrc/huge_kernels.hip).  grad_log_likelihood stops at width 64. */
+ * dot_L / dot are diagonal scans with one thread per row, solve / dot_solve above 64 chunked affine scans with
+ * J x J chunk maps built once per factor (csrc/bigsweep_kernels.hip; short series: one workgroup per right-hand side).  grad_log_likelihood stops at width 64. */
 #define CLR_MAX_WIDTH_ANY 1024
 #define CLR_CARMA_MAX_ORDER 32 /* autoregressive order p of clr_carma (state p, covariance p x p in LDS) */
 
@@ -93,6 +93,7 @@ int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
  *                            CLR_OUTPUT_CHECK_ATTEMPTS: replays before giving up (4)
  *   CLR_NO_ROWS_KERNEL       CholeskySolver above width 64 / general terms above 32: the one-workgroup kernels (S in LDS / L2)
  *                            instead of the row-distributed one (cross-checks); CLR_ROWS_NO_BLOCKS: its row-per-lane-group layout
+ *   CLR_NO_BIG_SWEEP         dot_solve / solve above width 64: the sequential sweeps instead of the chunked affine scans
  *   CLR_WIDE_NO_PAIRED, CLR_WIDE64_ONE_WAVE, CLR_WIDE_LAZY_BOUND, CLR_WIDE_FIRST_RATIO, CLR_WIDE_FIRST_RATIO64,
  *   CLR_WIDE_SCAN_CAP, CLR_SOLVER_WIDE_CHUNKS, CLR_PREDICT_CHUNKS, CLR_WSWEEP_RUN, CLR_WSWEEP_CHUNKS   (tuning runs, tools/)
  * clr_get_option: the value in force (NULL: not set); the pointer is valid until the calling thread's next call. */

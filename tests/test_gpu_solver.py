@@ -1148,3 +1148,44 @@ def test_diagonal_scans_with_several_waves_per_chunk(JR, JC, N):
     want = r.dot(0.1, *cs, *NO_GENERAL, t, z)
     got = celerite_amd.CholeskySolver().dot(0.1, *cs, *NO_GENERAL, t, z)
     within("diagonal scans, several waves: dot vs oracle (of the largest entry)", np.max(np.abs(got - want)) / np.max(np.abs(want)), 1e-11, J)
+
+
+@pytest.mark.parametrize("JR,JC,N", [(0, 40, 5000), (1, 63, 9000), (2, 100, 6000), (0, 200, 4500)])
+def test_sweeps_above_width_64_as_affine_scans(JR, JC, N):
+    """Round 6: ``dot_solve`` / ``solve`` (and ``predict``'s alpha) on long series above width 64 as chunked affine scans
+    whose J x J chunk maps are built once per factor and direction (csrc/bigsweep_kernels.hip) -- against the oracle and
+    against the sequential sweeps they replace (``CLR_NO_BIG_SWEEP``), several right-hand sides, a second call that
+    reuses the maps, a new factor in the same solver.  cholesky.h:236-260, :343-357."""
+    J = JR + 2 * JC
+    case = synthetic(1, N, JR, JC, "accuracy", seed=J)
+    cs = list(coeffs_of(case, 0))
+    t, diag, y = case["t"][0], case["diag"][0] + 0.05, case["y"][0]
+    rng = np.random.RandomState(J)
+    b = rng.randn(N, 3)
+    r = ref.RefSolver()
+    r.compute(0.1, *cs, *NO_GENERAL, t, diag)
+    want_solve, want_q = r.solve(b), [r.dot_solve(b[:, k]) for k in range(3)]
+    s = celerite_amd.CholeskySolver()
+    s.compute(0.1, *cs, *NO_GENERAL, t, diag)
+    for attempt in range(2):      # (the second round reuses the chunk maps)
+        for k in range(3):
+            within("affine scans above width 64: dot_solve vs oracle", abs(s.dot_solve(b[:, k]) - want_q[k]) / abs(want_q[k]), 1e-11, (J, attempt))
+        got = s.solve(b)
+        within("affine scans above width 64: solve vs oracle (of the largest entry)", np.max(np.abs(got - want_solve)) / np.max(np.abs(want_solve)), 1e-11, (J, attempt))
+    batch.set_option("CLR_NO_BIG_SWEEP", "1")
+    try:
+        seq = s.solve(b)
+        seq_q = s.dot_solve(b[:, 0])
+    finally:
+        batch.set_option("CLR_NO_BIG_SWEEP", None)
+    within("affine scans above width 64: solve vs the sequential sweep (of the largest entry)", np.max(np.abs(got - seq)) / np.max(np.abs(seq)), 1e-11, J)
+    within("affine scans above width 64: dot_solve vs the sequential sweep", abs(s.dot_solve(b[:, 0]) - seq_q) / abs(seq_q), 1e-11, J)
+    xs = np.sort(rng.uniform(t.min(), t.max(), 50))
+    want_p = r.predict(y, xs)
+    within("affine scans above width 64: predict vs oracle (of the largest entry)", np.max(np.abs(s.predict(y, xs) - want_p)) / np.max(np.abs(want_p)), 1e-11, J)
+    # another factor in the same solver: the maps are rebuilt
+    diag2 = diag * 1.3 + 0.01
+    r.compute(0.05, *cs, *NO_GENERAL, t, diag2)
+    s.compute(0.05, *cs, *NO_GENERAL, t, diag2)
+    want2 = r.solve(b)
+    within("affine scans above width 64: solve vs oracle (of the largest entry)", np.max(np.abs(s.solve(b) - want2)) / np.max(np.abs(want2)), 1e-11, (J, "new factor"))
