@@ -5,7 +5,7 @@ Usage: python tools/collect_prof_r05.py gpurun_out/prof_r05 r05f ; then tools/ma
 import os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-for name, out in (("headline", tag), ("wide", tag + "_wide"), ("wide64", tag + "_wide64")):
+for name, out in (("headline", tag), ("wide", tag + "_wide"), ("wide64", tag + "_wide64"), ("small", tag + "_small"), ("rows", tag + "_rows")):
     tr = os.path.join(src, name + "_kernel_trace_stats.txt")
     if os.path.exists(tr):
         shutil.copy(tr, os.path.join(root, out + "_kernel_trace_stats.txt"))

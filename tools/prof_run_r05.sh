@@ -54,6 +54,9 @@ for w in $WHAT; do
       pmc grad_fetch "FETCH_SIZE" python tools/gpu_grad_profile.py
       pmc grad_write "WRITE_SIZE" python tools/gpu_grad_profile.py
       ;;
+    rows)
+      trace rows python tools/gpu_rows_profile.py
+      ;;
     small)
       trace small python tools/gpu_small_profile.py
       pmc small_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES" python tools/gpu_small_profile.py
