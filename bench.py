@@ -656,6 +656,7 @@ def main(argv=None):
     ap.add_argument("--no-shared-series", action="store_true", help="skip the layout-(ii) leg (profiling runs: keeps the per-kernel counter averages to the distinct-series launches)")
     ap.add_argument("--no-accuracy-family", action="store_true", help="skip the accuracy-family leg")
     ap.add_argument("--no-gradient", action="store_true", help="skip the grad_log_likelihood leg")
+    ap.add_argument("--no-object-api", action="store_true", help="skip the single-series CholeskySolver leg (the reference's own benchmark kernels)")
     ap.add_argument("--sharded", type=int, default=2, help="shards of the product's own sharded plan (0: skip the leg)")
     ap.add_argument("--no-config3", action="store_true", help="skip the 8-shard B = 8192 leg (20 GB of host arrays)")
     ap.add_argument("--steady-seconds", type=float, default=2.5)
@@ -987,6 +988,11 @@ def main(argv=None):
             out["accuracy_family"] = accuracy_family_block(B, N, JR, JC, max(K // 2, 5), 8, 4242)
         except Exception as e:  # a failing side leg must not lose the headline line
             out["accuracy_family"] = {"error": repr(e)}
+    if dist.rank == 0 and dist.world == 1 and not args.no_object_api:
+        try:
+            out["object_api"] = object_api_block()
+        except Exception as e:  # (a side leg must not cost the headline line)
+            out["object_api"] = {"error": repr(e)}
     if dist.rank == 0 and dist.world == 1 and not args.no_gradient:
         try:
             out["gradient"] = gradient_block(B, N, JR, JC, 42)
@@ -1130,6 +1136,53 @@ def write_full_record(out):
     return path
 
 
+def object_api_block():
+    """One series through ``CholeskySolver`` -- the reference's OWN benchmark (examples/benchmark/run.py:37-38, 66-84,
+    131-138: real terms (1, 0.1) + identical complex terms (0.1, 2, 1.6), t = sort(rand), yerr ~ U(0.1, 0.2); `compute`
+    and `dot_solve` timed apart, best of 3) at N = 65 536 and widths 16 / 128, with the CPU oracle's compute of the
+    narrower one beside it (one core; tools/gpu_reference_benchmark_grid.py has the whole grid)."""
+    import celerite_amd
+    from celerite_amd import terms
+    from oracle import ref
+    rng = np.random.RandomState(42)
+    N = 65536
+    t = np.sort(rng.rand(2 ** 19))[:N]
+    d = rng.uniform(0.1, 0.2, 2 ** 19)[:N] ** 2
+    z = rng.randn(N)
+    e_, e2_ = np.empty(0), np.empty((0, 0))
+
+    def best(fn, reps=3):
+        b = np.inf
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); b = min(b, time.perf_counter() - t0)
+        return b * 1e3
+
+    res = {"N": N, "what": "reference benchmark kernels (examples/benchmark/run.py), one series, ms per call, best of 3"}
+    for width in (16, 128):
+        j = width // 2
+        kernel = terms.RealTerm(1.0, 0.1)
+        for _ in range((2 * j - 1) % 2):
+            kernel += terms.RealTerm(1.0, 0.1)
+        for _ in range((2 * j - 1) // 2):
+            kernel += terms.ComplexTerm(0.1, 2.0, 1.6)
+        cs = [np.asarray(c, dtype=float) for c in kernel.coefficients]
+        s = celerite_amd.CholeskySolver()
+        s.compute(0.0, *cs, e_, e2_, e2_, t, d)
+        s.dot_solve(z)
+        rec = {"compute_ms": best(lambda: s.compute(0.0, *cs, e_, e2_, e2_, t, d))}
+        s.dot_solve(z)      # (builds whatever the sweeps keep per factor)
+        rec["dot_solve_ms"] = best(lambda: s.dot_solve(z))
+        rec["route"] = list(s._route()[:2])
+        if width == 16:
+            r = ref.RefSolver()
+            rec["cpu_compute_ms"] = best(lambda: r.compute(0.0, *cs, e_, e2_, e2_, t, d), 1)
+            rec["cpu_dot_solve_ms"] = best(lambda: r.dot_solve(z), 1)
+            rec["logdet_rel"] = abs(s.log_determinant() - r.log_determinant()) / abs(r.log_determinant())
+            rec["dot_solve_rel"] = abs(s.dot_solve(z) - r.dot_solve(z)) / abs(r.dot_solve(z))
+        res["width%d" % width] = rec
+    return res
+
+
 def promote(out):
     """The driver's record keeps `config`, `roofline` and `cpu_baseline` of the line in full and only the NAMES of the
     other keys: the numbers the north star's bars are judged on are copied into `roofline` / `config` (compact, no
@@ -1196,6 +1249,10 @@ def promote(out):
     a = out.get("accuracy_family")
     if a and "ms_per_step" in a:
         r["accuracy_family_ms_per_step"] = a["ms_per_step"]
+    oa = out.get("object_api")
+    if oa and "width16" in oa:
+        r["object_api_ms"] = {k: {kk: oa[k][kk] for kk in ("compute_ms", "dot_solve_ms", "cpu_compute_ms", "cpu_dot_solve_ms") if kk in oa[k]}
+                              for k in ("width16", "width128") if k in oa}
 
 
 def cpu_baseline_and_parity(coeffs, t, diag, y, ld_gpu, q_gpu, st_gpu, B, N):

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_${PROF_TAG:-r05}
 mkdir -p "$OUT"
 WHAT="${*:-headline wide accuracy}"
-BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --no-accuracy-family --no-gradient --sharded 0 --no-config3 --steady-seconds 0 --settle-seconds 0"
+BENCH="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-shared-series --no-accuracy-family --no-gradient --no-object-api --sharded 0 --no-config3 --steady-seconds 0 --settle-seconds 0"
 
 trace() {  # name, command...
   local name=$1; shift
