@@ -1,6 +1,8 @@
 // celerite_amd/csrc/api_solver.hip -- C ABI of the object API (clr_solver_*): what the pybind11 module
 // celerite_amd.solver binds in place of the reference's CholeskySolver<double> (celerite/solver.cpp:64-664).
 #include "api_internal.h"
+
+#include <mutex>
 #include "clr_options.h"
 
 namespace {
@@ -453,7 +455,14 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     }
     const clr::GenericProblem g = generic_view(s);
     bool rows_quad = false;
+    // Above width 128 the row-distributed kernel's workgroups (4 .. 64 of them) spin on each other: they must all be
+    // resident at once.  One such kernel always is (<= 64 workgroups on 256 compute units); several at a time -- solvers
+    // of other host threads -- could each hold a part of the chip and wait for the rest.  They are serialised here, up to
+    // the synchronisation below (the bounded spin turns what another PROCESS could still cause into CLR_HIP_ERROR).
+    static std::mutex rows_many_mutex;
+    std::unique_lock<std::mutex> rows_lock(rows_many_mutex, std::defer_lock);
     if (J >= 33 && clr::factor_rows_supported(J) && !clr::option("CLR_NO_ROWS_KERNEL")) {
+      if (J > 128) rows_lock.lock();
       // S in the registers of 1 .. 64 workgroups (rows_kernels.hip; round 6: width 128 20.5 -> ~1 us per step)
       if ((st = s->ws_elems.reserve(clr::factor_rows_workspace_doubles(J))) != CLR_OK) return st;
       double dmax = 0.0;

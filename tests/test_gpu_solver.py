@@ -1189,3 +1189,38 @@ def test_sweeps_above_width_64_as_affine_scans(JR, JC, N):
     s.compute(0.05, *cs, *NO_GENERAL, t, diag2)
     want2 = r.solve(b)
     within("affine scans above width 64: solve vs oracle (of the largest entry)", np.max(np.abs(s.solve(b) - want2)) / np.max(np.abs(want2)), 1e-11, (J, "new factor"))
+
+
+def test_row_distributed_factorisations_from_several_host_threads():
+    """The workgroups of one row-distributed factorisation above width 128 spin on each other and must all be resident;
+    solvers of several host threads are serialised for that kernel (csrc/api_solver.hip): six threads, widths 300 / 520,
+    every result against the oracle, no time-out status."""
+    import threading
+    cases = []
+    for k, (JR, JC, N) in enumerate([(0, 150, 300), (2, 259, 200)] * 3):
+        case = synthetic(1, N, JR, JC, "accuracy", seed=100 + k)
+        cs = list(coeffs_of(case, 0))
+        t, diag = case["t"][0], case["diag"][0] + 0.05
+        r = ref.RefSolver()
+        r.compute(0.1, *cs, *NO_GENERAL, t, diag)
+        cases.append((cs, t, diag, r.log_determinant()))
+    got, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            cs, t, diag, _ = cases[i]
+            for _ in range(3):
+                s = celerite_amd.CholeskySolver()
+                s.compute(0.1, *cs, *NO_GENERAL, t, diag)
+            got[i] = s.log_determinant()
+        except Exception as e:  # (a lost workgroup would surface here as RuntimeError)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i, (_, _, _, want) in enumerate(cases):
+        within("row-distributed factorisation from several host threads: log det vs oracle", abs(got[i] - want) / abs(want), 1e-12, i)
