@@ -1280,6 +1280,11 @@ int clr_batch_enqueue(clr_batch* h, int materialize) {
     G.A_stride = h->gA_stride; G.U_stride = h->gU_stride; G.V_stride = h->gV_stride;
     G.out_ll = P.out_ll; G.out_logdet = P.out_logdet; G.out_quad = P.out_quad; G.out_status = P.out_status;
     mark(0); mark(1);
+    // (round 6) total widths 33 .. 128: S in the registers of the problem's workgroup (rows_kernels.hip: 1.6 us per sample at
+    // width 128 where the LDS-resident kernel takes 20)
+    if (clr::factor_rows_batch_supported(h->J + h->J_general) && !clr::option("CLR_NO_ROWS_KERNEL"))
+      clr::launch_factor_rows_batch(G, P.fast_trig, h->stream);
+    else
     clr::launch_generic_loglike_batch(G, h->stream);
     mark(2); mark(3); mark(4); mark(5); mark(6);
     HIP_TRY(hipGetLastError());

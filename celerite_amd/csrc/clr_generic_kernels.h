@@ -179,6 +179,8 @@ size_t factor_rows_workspace_doubles(int J);
 void launch_factor_rows(const GenericProblem& g, int fast_trig /* host-verified: max|d_comp| max|t| < CLR_FAST_TRIG_LIMIT */,
                         const double* y /* device [N] or null: log_det[1] = y^T K^-1 y */, double* workspace, double* phi, double* u, double* W,
                         double* D, int* status, double* log_det /* [2] */, hipStream_t s);
+bool factor_rows_batch_supported(int J_total);
+void launch_factor_rows_batch(const GenericBatch& G, int fast_trig, hipStream_t s);
 // J == 0 and small element-wise helpers.
 void launch_diag_only(int N, const double* diag, double jitter, double* D, double* log_det,
                       hipStream_t s);

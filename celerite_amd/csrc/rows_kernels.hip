@@ -68,9 +68,20 @@ __device__ __forceinline__ double rows_row_sum(double v) {
   return v;
 }
 
-template <int TPR, bool FAST, bool BLOCKED = false>
-__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, const double* __restrict__ y, double* phi, double* u,
-                                                                   double* W, double* D, int* status, double* log_det) {
+// BATCH (one workgroup per problem of a plan, widths 33 .. 128: factor_rows_batch_kernel): nothing of the factor is stored,
+// the diagonal is formed from the plan's series (`diag_in`, `dsum` = ((. + sum a_real) + sum a_comp) + jitter in the
+// reference's order, cholesky.h:98-99, `A_in` added last), and the results go to the plan's output arrays.
+struct RowsBatchOut {
+  const double* diag_in;
+  const double* A_in;
+  double sum_ar, sum_ac, jitter;
+  double *out_ll, *out_logdet, *out_quad;
+  int* out_status;
+};
+
+template <int TPR, bool FAST, bool BLOCKED, bool BATCH>
+__device__ __forceinline__ void factor_rows_body(const GenericProblem& g, RowsExchange X, const double* __restrict__ y, double* phi, double* u,
+                                                 double* W, double* D, int* status, double* log_det, const RowsBatchOut& BO) {
   constexpr int JP = ROWS_COLS * TPR, RB = ROWS_THREADS / TPR, G = JP / RB, SLOTS = 34 * TPR;
   constexpr int RPT = (JP + ROWS_THREADS - 1) / ROWS_THREADS;  // rows (tasks) per thread in the per-row phases
   // Who does what besides the state's step (Y), in whole waves: the rows' pivots-and-W phase (X) belongs to threads
@@ -88,10 +99,16 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
   // t, the diagonal and y of 2 x 64 samples: a step's values come from here (a global load at the top of a step would be
   // on its critical path); the next tile is fetched 64 steps ahead
   __shared__ double tile_t[2][64], tile_d[2][64], tile_y[2][64];
-  const int J = g.J, N = g.N, tid = threadIdx.x, wg = blockIdx.x;
+  const int J = g.J, N = g.N, tid = threadIdx.x, wg = BATCH ? 0 : blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int part = tid % TPR, row = wg * RB + tid / TPR;  // (row-per-lane-group layout) this lane's row of S and block of columns
-  const bool first = wg == 0;
+  const bool first = !BATCH && wg == 0;  // (who stores the factor)
+  auto diag_at = [&](int i) {  // the full diagonal of sample i as handed over / formed from the plan's series
+    if (!BATCH) return D[i];
+    double d = ((BO.diag_in[i] + BO.sum_ar) + BO.sum_ac) + BO.jitter;
+    if (BO.A_in) d += BO.A_in[i];
+    return d;
+  };
   const int JR = g.J_real, JC = g.J_comp, Wc = JR + 2 * JC, ndecay = JR + JC;
 
   double S[ROWS_COLS];
@@ -159,7 +176,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
 
   if (tid < 128) {
     tile_t[tid >> 6][tid & 63] = tid < N ? g.t[tid] : 0.0;
-    tile_d[tid >> 6][tid & 63] = tid < N ? D[tid] : 0.0;
+    tile_d[tid >> 6][tid & 63] = tid < N ? diag_at(tid) : 0.0;
     tile_y[tid >> 6][tid & 63] = (y && tid < N) ? y[tid] : 0.0;
   }
   __syncthreads();
@@ -220,7 +237,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
     double ft = 0.0, fd = 0.0, fy = 0.0;
     if (fetch) {
       const int i = n + 64 + tid;
-      if (i < N) { ft = g.t[i]; fd = D[i]; fy = y ? y[i] : 0.0; }
+      if (i < N) { ft = g.t[i]; fd = diag_at(i); fy = y ? y[i] : 0.0; }
     }
     double xn = 0.0;
     if (y) {
@@ -342,6 +359,7 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
     const double Dn = dn - total;
     if (Dn < 0.0 || (G > 1 && sabort)) {  // cholesky.h:176
       if (first && tid == 0) { if (!sabort) status[0] = 1; log_det[0] = NAN; }
+      if (BATCH && tid == 0) { BO.out_status[0] = 2; BO.out_ll[0] = -INFINITY; BO.out_logdet[0] = NAN; BO.out_quad[0] = NAN; }
       return;
     }
     gsum = 0.0;
@@ -364,7 +382,8 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
       const double ws = row_sum_all<1>(gsum);
       if (lane == 0) sdot[wave] = ws;  // (read at the top of the next step, behind the barrier below)
     }
-    if (first && tid == 0) { D[n] = Dn; lp.mul(Dn); }
+    if (first && tid == 0) D[n] = Dn;
+    if (tid == 0) lp.mul(Dn);
     if (fetch) {
       const int bsel = ((n >> 6) + 1) & 1;
       tile_t[bsel][tid] = ft; tile_d[bsel][tid] = fd; tile_y[bsel][tid] = fy;
@@ -373,6 +392,44 @@ __global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProble
     rows_lds_barrier();
   }
   if (first && tid == 0) { status[0] = 0; log_det[0] = lp.log_value(); log_det[1] = quad; }
+  if (BATCH && tid == 0) {
+    const double ld = lp.log_value();
+    double ll = -0.5 * (quad + ld + N * 1.8378770664093453);
+    if (!isfinite(ld) || !isfinite(ll)) ll = -INFINITY;  // celerite.py:211-218
+    BO.out_status[0] = 0; BO.out_logdet[0] = ld; BO.out_quad[0] = quad; BO.out_ll[0] = ll;
+  }
+}
+
+template <int TPR, bool FAST, bool BLOCKED = false>
+__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_kernel(GenericProblem g, RowsExchange X, const double* __restrict__ y, double* phi, double* u,
+                                                                   double* W, double* D, int* status, double* log_det) {
+  factor_rows_body<TPR, FAST, BLOCKED, false>(g, X, y, phi, u, W, D, status, log_det, RowsBatchOut{});
+}
+
+// one workgroup per problem of a plan (total width 33 .. 128, general terms included): the fused log-likelihood
+template <bool FAST>
+__global__ void __launch_bounds__(ROWS_THREADS) factor_rows_batch_kernel(const GenericBatch G) {
+  const int b = blockIdx.x;
+  GenericProblem g;
+  g.N = G.N;
+  g.J_real = G.J_real; g.J_comp = G.J_comp; g.J_general = G.J_general;
+  g.J = G.J_real + 2 * G.J_comp + G.J_general;
+  g.a_real = G.a_real + (long)b * G.J_real; g.c_real = G.c_real + (long)b * G.J_real;
+  g.a_comp = G.a_comp + (long)b * G.J_comp; g.b_comp = G.b_comp + (long)b * G.J_comp;
+  g.c_comp = G.c_comp + (long)b * G.J_comp; g.d_comp = G.d_comp + (long)b * G.J_comp;
+  g.U = G.U ? G.U + (long)b * G.U_stride : nullptr;
+  g.V = G.V ? G.V + (long)b * G.V_stride : nullptr;
+  g.t = G.t + (long)b * G.t_stride;
+  RowsBatchOut BO;
+  BO.diag_in = G.diag + (long)b * G.diag_stride;
+  BO.A_in = G.A ? G.A + (long)b * G.A_stride : nullptr;
+  double sum_ar = 0.0, sum_ac = 0.0;  // cholesky.h:98: the reference's summation order
+  for (int j = 0; j < G.J_real; ++j) sum_ar += g.a_real[j];
+  for (int j = 0; j < G.J_comp; ++j) sum_ac += g.a_comp[j];
+  BO.sum_ar = sum_ar; BO.sum_ac = sum_ac; BO.jitter = G.jitter[b];
+  BO.out_ll = G.out_ll + b; BO.out_logdet = G.out_logdet + b; BO.out_quad = G.out_quad + b; BO.out_status = G.out_status + b;
+  factor_rows_body<4, FAST, true, true>(g, RowsExchange{nullptr, nullptr, nullptr}, G.y + (long)b * G.y_stride, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, BO);
 }
 
 int rows_tpr(int J) { return J <= 128 ? 4 : (J <= 256 ? 8 : (J <= 512 ? 16 : 32)); }
@@ -413,6 +470,13 @@ void launch_factor_rows(const GenericProblem& g, int fast_trig, const double* y,
   else if (tpr == 16) CLR_ROWS_LAUNCH(16);
   else CLR_ROWS_LAUNCH(32);
 #undef CLR_ROWS_LAUNCH
+}
+
+// the plans' fused log-likelihood at total widths 33 .. 128 (general terms included): one workgroup per problem
+bool factor_rows_batch_supported(int J_total) { return J_total >= 33 && J_total <= 128; }
+void launch_factor_rows_batch(const GenericBatch& G, int fast_trig, hipStream_t s) {
+  if (fast_trig) hipLaunchKernelGGL((factor_rows_batch_kernel<true>), dim3(G.B), dim3(ROWS_THREADS), 0, s, G);
+  else hipLaunchKernelGGL((factor_rows_batch_kernel<false>), dim3(G.B), dim3(ROWS_THREADS), 0, s, G);
 }
 
 }  // namespace clr

@@ -2953,3 +2953,43 @@ def test_materialising_plan_of_reference_benchmark_kernels_is_settled_by_the_out
     print("routes without / with the output check:", levels[False], levels[True])
     assert np.any(levels[False] == 2), levels[False]
     assert np.all(levels[True][levels[False] == 2] == 1), (levels[True], levels[False])
+
+
+@pytest.mark.parametrize("JR,JC,N", [(33, 0, 400), (3, 40, 700), (0, 64, 1500), (128, 0, 300)])
+def test_plans_at_widths_33_to_128_keep_the_state_in_registers(JR, JC, N):
+    """Round 6: the plans' any-width route (widths 65 .. 128; general terms up to a total width of 128) runs the
+    row-distributed kernel with one workgroup per problem (csrc/rows_kernels.hip, ``factor_rows_batch_kernel``: S in
+    registers, two barriers per step) where round 5 had the LDS-resident one (``CLR_NO_ROWS_KERNEL``: still there, as the
+    cross-check): both against the oracle, an indefinite problem in the batch, and the time per sample of both."""
+    B = 5
+    case = synthetic(B, N, JR, JC, "accuracy", seed=JR + JC)
+    case["a_real"] = np.array(case["a_real"], copy=True)
+    case["diag"] = np.array(case["diag"], copy=True)
+    if JR:
+        case["a_real"][1, :] = -7.0
+        case["diag"][1] = 0.0
+    l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
+    times = {}
+    for rows in (True, False):
+        batch.set_option("CLR_NO_ROWS_KERNEL", None if rows else "1")
+        try:
+            plan = batch.BatchedGP(B, N, JR, JC)
+            plan.set_series(case["t"], case["diag"], case["y"])
+            plan.set_coefficients(*coeffs_of(case))
+            ll, ld, q, st = plan.log_likelihood()
+            times[rows] = plan.run_timed(2)[0]
+            plan.close()
+        finally:
+            batch.set_option("CLR_NO_ROWS_KERNEL", None)
+        assert np.array_equal(st, s0)
+        ok = s0 == 0
+        tag = (JR, JC, "rows" if rows else "LDS")
+        if JR + 2 * JC <= 64:
+            continue      # (width <= 64 without general terms is the wide kernels' plan: nothing of this test's to compare)
+        within("plans at widths 65..128, state in registers: log det vs oracle", np.max(np.abs(ld[ok] - d0[ok]) / np.abs(d0[ok])), 1e-11, tag)
+        within("plans at widths 65..128, state in registers: quadratic form vs oracle", np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok])), 1e-10, tag)
+        within("plans at widths 65..128, state in registers: log-likelihood vs oracle", np.max(np.abs(ll[ok] - l0[ok]) / np.abs(l0[ok])), 1e-11, tag)
+        assert np.all(ll[~ok] == -np.inf)
+    if JR + 2 * JC > 64:
+        print("width %d: %.2f us per sample in registers, %.2f in LDS" % (JR + 2 * JC, times[True] * 1e3 / N, times[False] * 1e3 / N))
+        assert times[True] < times[False]
