@@ -461,7 +461,11 @@ int clr_solver_compute(clr_solver* s, double jitter, int n_a_real, const double*
     // the synchronisation below (the bounded spin turns what another PROCESS could still cause into CLR_HIP_ERROR).
     static std::mutex rows_many_mutex;
     std::unique_lock<std::mutex> rows_lock(rows_many_mutex, std::defer_lock);
-    if (J >= 33 && clr::factor_rows_supported(J) && !clr::option("CLR_NO_ROWS_KERNEL")) {
+    // (general terms at ANY total width: even at width 5 the padded width-128 step of the rows kernel, 1.6 us, is shorter
+    //  than the LDS-resident kernel's five barriers, 1.9 .. 5.6 us at widths 5 .. 40 -- tools/gpu_rows_min_width.py)
+    int rows_min = 1;
+    if (const char* e = clr::option("CLR_ROWS_MIN_WIDTH")) rows_min = std::max(1, atoi(e));
+    if (J >= rows_min && clr::factor_rows_supported(J) && !clr::option("CLR_NO_ROWS_KERNEL")) {
       if (J > 128) rows_lock.lock();
       // S in the registers of 1 .. 64 workgroups (rows_kernels.hip; round 6: width 128 20.5 -> ~1 us per step)
       if ((st = s->ws_elems.reserve(clr::factor_rows_workspace_doubles(J))) != CLR_OK) return st;

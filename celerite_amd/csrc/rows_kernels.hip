@@ -1,5 +1,5 @@
-// celerite_amd/csrc/rows_kernels.hip -- CholeskySolver.compute at widths 33 .. 1024 that the chunked scans do not take
-// (general terms above width 32, every width above 64): the reference's dynamic-width arm (cholesky.h:203), whose published
+// celerite_amd/csrc/rows_kernels.hip -- CholeskySolver.compute at the widths the chunked scans do not take (general terms
+// at any width, every width above 64; the plans' any-width route from a total width of 33): the reference's dynamic-width arm (cholesky.h:203), whose published
 // benchmark goes to width 512 (examples/benchmark/run.py:37-39).  Sequential in n like the reference, parallel over the
 // J^2 entries of the state, with S in REGISTERS:
 //
