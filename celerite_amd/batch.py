@@ -397,6 +397,34 @@ class BatchedGP(object):
         _check(lib.clr_batch_predict(self._h, int(M), _ptr(xs), stride, _ptr(pred)))
         return pred
 
+    def dot_L(self, z):
+        """``L_p z_p`` with ``K_p = L_p L_p^T`` for every problem from the factor of the last materialising run
+        (``clr_batch_dot_L``; ``CholeskySolver.dot_L``, cholesky.h:409-431, for B problems at once).  ``z``: ``(B, N)``
+        or ``(B, nrhs, N)``; returns an array of the same shape."""
+        lib = _load()
+        lib.clr_batch_dot_L.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        z = _f64(z)
+        if z.ndim not in (2, 3) or z.shape[0] != self.B or z.shape[-1] != self.N:
+            raise ValueError("dimension mismatch")
+        nrhs = 1 if z.ndim == 2 else z.shape[1]
+        y = np.empty(z.shape)
+        _check(lib.clr_batch_dot_L(self._h, int(nrhs), _ptr(z), _ptr(y)))
+        return y
+
+    def sample(self, size=None, mean=None, random=None):
+        """Draws from every problem's prior ``N(mean_p, K_p)`` (``GP.sample``, celerite.py:422-451: ``mean + L n`` with
+        standard normal ``n``) from the factor of the last materialising run.  ``size=None``: ``(B, N)``; else
+        ``(B, size, N)``.  ``mean``: ``None``, a scalar, ``(N,)`` or ``(B, N)``."""
+        rng = np.random if random is None else random
+        shape = (self.B, self.N) if size is None else (self.B, int(size), self.N)
+        y = self.dot_L(rng.standard_normal(shape))
+        if mean is not None:
+            m = np.asarray(mean, dtype=float)
+            if m.ndim == 2 and size is not None:
+                m = m[:, None, :]
+            y += m
+        return y
+
     def solve_device_ms(self):
         """Device time of the last :meth:`solve` (its kernels, without the host <-> HBM copies)."""
         lib = _load()

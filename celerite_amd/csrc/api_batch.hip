@@ -53,7 +53,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->ends, &h->sT, &h->sD, &h->sY})
+                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->bs_decay, &h->ends, &h->sT, &h->sD, &h->sY})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1801,6 +1801,85 @@ static int batch_solve_impl(clr_batch* h, int nrhs, const double* b, double* x) 
 int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x) {
   if (!x) return fail(CLR_INVALID_ARGUMENT, "clr_batch_solve: an output array");
   return batch_solve_impl(h, nrhs, b, x);
+}
+
+// CholeskySolver::dot_L (cholesky.h:409-431; GP.sample draws L z, celerite.py:422-451) for every problem of the plan from
+// the factor of its last materialising run.  Narrow plans: the chunked diagonal scan of clr_bdotl_kernels.h on the
+// chunk-interleaved factor (either layout), lane = (problem, chunk).  Wide plans (widths 9..64): the factor lies in the
+// reference's storage and the object API's wave-per-chunk scan (wsweep_kernels.hip: wdotl_kernel) runs once for the whole
+// batch, grid.z = problem; series too short for it: the sequential kernel, problem by problem.
+int clr_batch_dot_L(clr_batch* h, int nrhs, const double* z, double* y) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (nrhs < 1 || nrhs > 65535 || !z || !y) return fail(CLR_INVALID_ARGUMENT, "clr_batch_dot_L: 1 <= nrhs <= 65535 (grid.z), z and an output array");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (!h->have_factor || !h->factor_valid) return fail(CLR_NOT_COMPUTED, "no materialising run has been made (clr_batch_enqueue(h, 1))");
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) return fail(CLR_UNSUPPORTED, "clr_batch_dot_L covers celerite-only plans of widths 1..64");
+  const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J, R = (size_t)nrhs;
+  if ((st = h->bs_rm.reserve(B * R * N)) != CLR_OK) return st;
+  for (hipEvent_t& e : h->bs_ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipMemcpyAsync(h->bs_rm.p, z, B * R * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const double* result = nullptr;
+  if (!h->launch) {  // wide plans
+    if ((st = h->bs_x.reserve(B * R * N)) != CLR_OK) return st;
+    HIP_TRY(hipEventRecord(h->bs_ev[0], h->stream));
+    if (clr::wdotl_scan_supported(h->N, h->J)) {
+      clr::SweepParams P;
+      memset(&P, 0, sizeof(P));
+      P.N = h->N; P.J = h->J; P.nrhs = nrhs;
+      // chunks per problem: about two rounds of the chip's SIMDs over the batch (not a function of nrhs: a right-hand
+      // side's result does not depend on how many others ride along)
+      int nchunk = std::min(clr::wdotl_chunks(h->N), std::max(2, (int)(2048 / B)));
+      P.L = (h->N - 1 + nchunk - 1) / nchunk;
+      P.nchunk = (h->N - 1 + P.L - 1) / P.L;
+      const size_t ws = R * (size_t)P.nchunk * 3 * J;
+      if ((st = h->bs_off.reserve(B * ws)) != CLR_OK) return st;
+      P.phi = h->phi.p; P.u = h->u.p; P.W = h->W.p; P.D = h->D.p;
+      P.batch = h->B;
+      P.stride_phi = (long)(J * (N - 1)); P.stride_W = (long)(J * N); P.stride_D = (long)N;
+      P.stride_ws = (long)ws;
+      P.in = h->bs_rm.p; P.stride_in = (long)(R * N);
+      P.out = h->bs_x.p; P.stride_out = (long)(R * N);
+      clr::launch_wdotl_scan(P, h->bs_off.p, h->stream);
+    } else {
+      for (size_t p = 0; p < B; ++p)
+        clr::launch_dot_L(h->N, h->J, nrhs, h->phi.p + p * J * (N - 1), h->u.p + p * J * (N - 1), h->W.p + p * J * N,
+                          h->D.p + p * N, h->bs_rm.p + p * R * N, h->bs_x.p + p * R * N, h->stream);
+    }
+    HIP_TRY(hipEventRecord(h->bs_ev[1], h->stream));
+    result = h->bs_x.p;
+  } else {
+    if (h->factor_is_lean && h->factor_inputs_changed)
+      return fail(CLR_NOT_COMPUTED, "the lean factor's phi and u are regenerated from the plan's series and coefficients, "
+                                    "which were replaced after the materialising run: materialise again");
+    clr::BatchParams P;
+    if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+    if (P.staged) {  // the row-major times addressed directly (lean: one time per step and lane)
+      P.t = h->t.p; P.t_stride = h->t_stride; P.lane_is = 1; P.lane_cs = h->L; P.staged = 0;
+    }
+    const size_t cells = (size_t)h->L * h->nchunk;
+    if ((st = h->bs_x.reserve(B * R * cells)) != CLR_OK) return st;
+    if ((st = h->bs_decay.reserve(B * h->nchunk * J)) != CLR_OK) return st;
+    if ((st = h->bs_off.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+    if ((st = h->bs_starts.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+    HIP_TRY(hipEventRecord(h->bs_ev[0], h->stream));
+    clr::launch_relayout(h->bs_rm.p, (long)N, h->bs_x.p, (long)cells, (int)(B * R), h->N, h->L, h->nchunk, 0, h->stream);
+    clr::BDotLParams S;
+    S.nrhs = nrhs; S.lean = h->factor_is_lean ? 1 : 0;
+    S.xT = h->bs_x.p; S.decay = h->bs_decay.p; S.off = h->bs_off.p; S.starts = h->bs_starts.p;
+    h->launch->bdotl(P, S, h->stream);
+    clr::launch_relayout_back(h->bs_x.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
+    HIP_TRY(hipEventRecord(h->bs_ev[1], h->stream));
+    result = h->bs_rm.p;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(y, result, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->bs_ev[0], h->bs_ev[1]));
+  h->solve_device_ms = ms;
+  return CLR_OK;
 }
 
 // CholeskySolver::predict (cholesky.h:599-698; GP.predict's conditional mean, celerite.py:330-420) for every problem of

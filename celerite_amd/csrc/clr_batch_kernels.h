@@ -1003,6 +1003,7 @@ __global__ void __launch_bounds__(64) warm_check_kernel(const BatchParams P) {
 #include "clr_prefix_kernels.h"
 #include "clr_grad_kernels.h"
 #include "clr_bsolve_kernels.h"
+#include "clr_bdotl_kernels.h"
 namespace clr {
 
 // One table entry per (JR, JC): host-callable launchers.
@@ -1020,6 +1021,8 @@ struct BatchLaunchers {
   void (*grad_reverse)(const BatchParams&, hipStream_t);  // riders + record, adjoint walk, reverse sweep, reduction
   // K^-1 b for all problems and right-hand sides from the materialised factor (clr_bsolve_kernels.h): S.xT in / out
   void (*bsolve)(const BatchParams&, BSolveParams S, hipStream_t);
+  // L z for all problems and right-hand sides from the materialised factor (clr_bdotl_kernels.h): S.xT in / out
+  void (*bdotl)(const BatchParams&, BDotLParams S, hipStream_t);
   // lean factor of problem b (replay mode 3) -> the reference's storage, phi and u regenerated (t: the problem's row-major times)
   void (*expand)(const BatchParams&, int b, const double* t, double* phi, double* u, double* W, double* D, hipStream_t);
   int elem_doubles, start_doubles;
@@ -1119,6 +1122,18 @@ struct BatchImpl {
     if (S.lean) { if (P.fast_trig) bsolve_go<true, true>(P, S, s); else bsolve_go<true, false>(P, S, s); }
     else bsolve_go<false, true>(P, S, s);  // (the stored phi, u: no trigonometry)
   }
+  // the batched dot_L: chunk offsets and decay products, the walk over the chunks, the recurrence from the start states
+  template <bool LEAN, bool FAST>
+  static void bdotl_go(const BatchParams& P, const BDotLParams& S, hipStream_t s) {
+    const dim3 grid((P.nchunk + 63) / 64, P.B, S.nrhs), pgrid((unsigned)(((long)P.B * S.nrhs + 63) / 64));
+    hipLaunchKernelGGL((bdotl_kernel<JR, JC, LEAN, FAST, false>), grid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdotl_prefix_kernel<JR + 2 * JC>), pgrid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdotl_kernel<JR, JC, LEAN, FAST, true>), grid, dim3(64), 0, s, P, S);
+  }
+  static void bdotl(const BatchParams& P, BDotLParams S, hipStream_t s) {
+    if (S.lean) { if (P.fast_trig) bdotl_go<true, true>(P, S, s); else bdotl_go<true, false>(P, S, s); }
+    else bdotl_go<false, true>(P, S, s);  // (the stored phi, u: no trigonometry)
+  }
   static void compose_check(const BatchParams& P, int g, double* coop, double* ref, hipStream_t s) {
     constexpr int J = JR + 2 * JC;
     const int np = (P.nchunk + g - 1) / g;
@@ -1171,7 +1186,7 @@ struct BatchImpl {
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,
-                          &bsolve, &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
+                          &bsolve, &bdotl, &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };
 

@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(64) wsweep_finalize_kernel(const SweepParams P
 // so a chunk is (a_j, f_j) per row; NW waves per (chunk, right-hand side), thread = row (round 6: widths above 64 --
 // the replay's sum over the rows then goes through LDS, one workgroup barrier per tile of KB steps).
 template <bool REPLAY, int NW>
-__global__ void __launch_bounds__(64 * NW) wdotl_kernel(const SweepParams P) {
+__global__ void __launch_bounds__(64 * NW) wdotl_kernel(const SweepParams P0) {
+  const SweepParams P = batch_view(P0);  // (clr_batch_dot_L on the wide plans: grid.z = problem)
   constexpr int KB = 8;
   __shared__ double xw[2][NW][KB];
   const int J = P.J, row = threadIdx.x, lane = row & 63, wave = row >> 6, c = blockIdx.x, rhs = blockIdx.y;
@@ -438,7 +439,8 @@ __global__ void __launch_bounds__(64 * NW) wdotl_kernel(const SweepParams P) {
   }
 }
 
-__global__ void __launch_bounds__(1024) wdotl_prefix_kernel(const SweepParams P) {  // (thread = row: 64 ... 1024 threads)
+__global__ void __launch_bounds__(1024) wdotl_prefix_kernel(const SweepParams P0) {  // (thread = row: 64 ... 1024 threads)
+  const SweepParams P = batch_view(P0);
   constexpr int KB = 16;  // chunks fetched ahead
   const int J = P.J, lane = threadIdx.x, rhs = blockIdx.x;
   if (lane >= J) return;
@@ -579,16 +581,17 @@ void launch_wdot_scan(SweepParams P, const double* v, const double* dg, double* 
 bool wdotl_scan_supported(int N, int J) { return J >= 1 && J <= CLR_MAX_WIDTH_ANY && (N >= 2048 || (J > CLR_MAX_WIDTH && N >= 2)); }
 int wdotl_chunks(int N) { return std::max(2, std::min(512, (N - 1) / 128)); }
 
-// workspace: nrhs * nchunk * 3 J doubles
+// workspace: nrhs * nchunk * 3 J doubles (per problem of a batched launch: P.stride_ws apart)
 void launch_wdotl_scan(SweepParams P, double* workspace, hipStream_t s) {
   const size_t pc = (size_t)P.nrhs * P.nchunk;
   P.elems = workspace;
   P.starts = P.elems + pc * 2 * P.J;
-  const dim3 grid(P.nchunk, P.nrhs);
+  const unsigned nb = P.batch > 1 ? (unsigned)P.batch : 1u;
+  const dim3 grid(P.nchunk, P.nrhs, nb);
   const int nwv = wdot_waves(P.J);
   const dim3 block(64 * nwv);
   CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdotl_kernel<false, NW>), grid, block, 0, s, P));
-  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs), block, 0, s, P);
+  hipLaunchKernelGGL(wdotl_prefix_kernel, dim3(P.nrhs, 1, nb), block, 0, s, P);
   CLR_WDOT_DISPATCH(nwv, hipLaunchKernelGGL((wdotl_kernel<true, NW>), grid, block, 0, s, P));
 }
 

@@ -490,6 +490,13 @@ int clr_batch_solve(clr_batch* h, int nrhs, const double* b, double* x);
  * the prediction points are the object API's chunked diagonal scans on the plan's resident times and coefficients
  * (sorted points: parallel in n; unsorted: the sequential walk of the reference). */
 int clr_batch_predict(clr_batch* h, int M, const double* xs, long xs_stride, double* pred);
+/* CholeskySolver::dot_L (cholesky.h:409-431: y = L z with K = L L^T, what GP.sample draws, celerite.py:422-451) for
+ * every problem of the plan from the factor of its last materialising run (either layout): z, y host [B][nrhs][N].
+ * Widths 1..8: a chunked diagonal scan on the chunk-interleaved factor, lane = (problem, chunk)
+ * (csrc/clr_bdotl_kernels.h); widths 9..64: the object API's wave-per-chunk scan launched once for the whole batch
+ * (grid.z = problem; series shorter than 2048 samples: the sequential kernel per problem).  clr_batch_get_solve_ms
+ * then reports this call's device time. */
+int clr_batch_dot_L(clr_batch* h, int nrhs, const double* z, double* y);
 /* Device time of the last clr_batch_solve (HIP events around its kernels: relayout, the five phases, relayout back;
  * the host <-> HBM copies of b and x are outside). */
 int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms);

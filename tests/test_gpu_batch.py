@@ -381,6 +381,77 @@ def test_batched_predict_on_plans(JR, JC, N, layout):
         plan.close()
 
 
+@pytest.mark.parametrize("JR,JC,N,layout,chunks", [
+    (2, 3, 6000, "reference", 24), (2, 3, 6000, "lean", 24), (1, 1, 3001, "lean", 7), (3, 0, 100, "reference", 0),
+    (0, 4, 20000, "reference", 0), (1, 0, 257, "lean", 2),
+    (4, 14, 4000, "reference", 0), (0, 8, 1500, "reference", 0), (2, 7, 30000, "reference", 0), (0, 32, 2500, "reference", 0)])
+def test_batched_dot_L_on_plans(JR, JC, N, layout, chunks):
+    """``clr_batch_dot_L`` -- ``CholeskySolver::dot_L`` (cholesky.h:409-431; what ``GP.sample`` draws, celerite.py:422-451)
+    for every problem of a plan from its materialised factor: narrow plans in both factor layouts (the chunked diagonal
+    scan of csrc/clr_bdotl_kernels.h; a series shorter than one chunk, a ragged last chunk), wide plans (the object
+    API's wave-per-chunk scan with a batch dimension; short series: the sequential kernel), one and several right-hand
+    sides, against the oracle's ``dot_L`` problem by problem; ``L (L^T ... )`` closes on K through the oracle's ``dot``;
+    ``sample`` is ``mean + L n`` of the same generator."""
+    B = 5
+    case = synthetic(B, N, JR, JC, "bench", seed=90 + JR + JC)
+    rng = np.random.RandomState(17)
+    z = rng.randn(B, 3, N)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        if JR + 2 * JC <= 8:
+            if chunks:
+                plan.set_chunks(chunks)
+            plan.set_factor_layout(layout)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        ll, ld, q, st = plan.log_likelihood(materialize=True)
+        assert np.all(st == 0)
+        y1 = plan.dot_L(z[:, 0])
+        ms = plan.solve_device_ms()
+        y3 = plan.dot_L(z)
+        assert y1.shape == (B, N) and y3.shape == (B, 3, N) and ms > 0.0
+        assert np.array_equal(y3[:, 0], y1)
+        draw = plan.sample(size=2, mean=case["y"], random=np.random.RandomState(5))
+        again = plan.dot_L(np.random.RandomState(5).standard_normal((B, 2, N))) + case["y"][:, None, :]
+        assert draw.shape == (B, 2, N) and np.array_equal(draw, again)
+        # the solve's chunk maps are untouched by dot_L (their buffers are shared)
+        if (JR + 2 * JC > 8 and N >= 512) or (JR + 2 * JC <= 8 and plan.chunks[0] >= 2):
+            x_before = plan.solve()
+            plan.dot_L(z)
+            assert np.array_equal(plan.solve(), x_before)
+        for p in range(B):
+            r = ref.RefSolver()
+            r.compute(0.0, *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)), case["t"][p], case["diag"][p])
+            want = r.dot_L(z[p].T)
+            within("batched dot_L on plans (width %d, N = %d, %s): vs oracle dot_L, of the largest entry" % (JR + 2 * JC, N, layout),
+                   np.max(np.abs(y3[p].T - want)) / np.max(np.abs(want)), 1e-12, p)
+    finally:
+        plan.close()
+
+
+def test_batched_dot_L_argument_and_state_errors():
+    """``clr_batch_dot_L`` before a materialising run is CLR_NOT_COMPUTED (the reference's ``compute_exception``,
+    cholesky.h:411), a wrong shape a dimension mismatch (:410), and a lean factor whose inputs were replaced is refused."""
+    B, N, JR, JC = 3, 2000, 2, 3
+    case = synthetic(B, N, JR, JC, "bench", seed=5)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        plan.set_factor_layout("lean")
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        with pytest.raises(RuntimeError):
+            plan.dot_L(np.zeros((B, N)))
+        plan.log_likelihood(materialize=True)
+        with pytest.raises(ValueError):
+            plan.dot_L(np.zeros((B, N + 1)))
+        plan.dot_L(np.zeros((B, N)))
+        plan.set_coefficients(*coeffs_of(case))
+        with pytest.raises(RuntimeError):
+            plan.dot_L(np.zeros((B, N)))
+    finally:
+        plan.close()
+
+
 def test_materialised_factor_at_the_bench_shape_against_the_oracle_state():
     """The factor of the materialising run whose roofline the bench line quotes -- BASELINE configs[2]'s shape, 1024
     problems x 1e5 samples x width 8, automatic chunking -- and the batched solve on it, in both layouts (the
