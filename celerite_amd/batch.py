@@ -890,6 +890,62 @@ class ShardedBatchedGP(object):
                                               [_ptr(ll), _ptr(ld), _ptr(q), st.ctypes.data_as(_ip)])))
         return ll, ld, q, st
 
+    def materialize(self):
+        """A materialising evaluation on every shard (``clr_sharded_materialize``): ``(loglike, logdet, quad, status)``
+        as :meth:`log_likelihood`, and every shard's factor left in its HBM for :meth:`solve`, :meth:`dot_L`,
+        :meth:`sample` and :meth:`predict`."""
+        ll, ld, q, st = self._out()
+        lib = _load()
+        lib.clr_sharded_materialize.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
+        self._ok(lib.clr_sharded_materialize(self._h, _ptr(ll), _ptr(ld), _ptr(q), st.ctypes.data_as(_ip)))
+        return ll, ld, q, st
+
+    def _rhs(self, b):
+        b = _f64(b)
+        if b.ndim not in (2, 3) or b.shape[0] != self.B or b.shape[-1] != self.N:
+            raise ValueError("dimension mismatch")
+        return b, (1 if b.ndim == 2 else b.shape[1])
+
+    def solve(self, b=None):
+        """``K_p^-1 b_p`` for every problem (as :meth:`BatchedGP.solve`), every shard on its slice."""
+        lib = _load()
+        lib.clr_sharded_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        if b is None:
+            x = np.empty((self.B, self.N))
+            self._ok(lib.clr_sharded_solve(self._h, 1, None, _ptr(x)))
+            return x
+        b, nrhs = self._rhs(b)
+        x = np.empty(b.shape)
+        self._ok(lib.clr_sharded_solve(self._h, int(nrhs), _ptr(b), _ptr(x)))
+        return x
+
+    def dot_L(self, z):
+        """``L_p z_p`` for every problem (as :meth:`BatchedGP.dot_L`), every shard on its slice."""
+        lib = _load()
+        lib.clr_sharded_dot_L.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        z, nrhs = self._rhs(z)
+        y = np.empty(z.shape)
+        self._ok(lib.clr_sharded_dot_L(self._h, int(nrhs), _ptr(z), _ptr(y)))
+        return y
+
+    sample = BatchedGP.sample
+
+    def predict(self, xs):
+        """The conditional mean of every problem at ``xs`` (``(M,)`` shared or ``(B, M)``), as :meth:`BatchedGP.predict`."""
+        lib = _load()
+        lib.clr_sharded_predict.argtypes = [C.c_void_p, C.c_int, _dp, C.c_long, _dp]
+        xs = _f64(xs)
+        if xs.ndim == 1:
+            stride = 0
+        elif xs.ndim == 2 and xs.shape[0] == self.B:
+            stride = xs.shape[1]
+        else:
+            raise ValueError("dimension mismatch")
+        M = xs.shape[-1]
+        pred = np.empty((self.B, M))
+        self._ok(lib.clr_sharded_predict(self._h, int(M), _ptr(xs), stride, _ptr(pred)))
+        return pred
+
     def run_timed(self, steps):
         """``steps`` evaluations on every shard concurrently; per-shard HIP-event ms."""
         n = _load().clr_sharded_num_shards(self._h)

@@ -466,6 +466,66 @@ int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_r
   });
 }
 
+// a materialising evaluation of every shard (clr_batch_enqueue(plan, 1)) settled with the batch-wide counts: what
+// clr_sharded_solve / _dot_L / _predict read
+int clr_sharded_materialize(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status) {
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  auto results = [=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_get_results(h->plan[s], loglike ? loglike + lo : nullptr, logdet ? logdet + lo : nullptr,
+                                 quad ? quad + lo : nullptr, status ? status + lo : nullptr);
+  };
+  if (h->plan.size() < 2)
+    return h->all([=](int s) {
+      const int e = clr_batch_enqueue(h->plan[s], 1);
+      return e != CLR_OK ? e : results(s);
+    });
+  const size_t S = h->plan.size();
+  std::vector<long> pend(S, 0), elig(S, 0);
+  long* pp = pend.data();
+  long* ee = elig.data();
+  const int st = h->all([=](int s) {
+    const int e = clr_batch_enqueue(h->plan[s], 1);
+    return e != CLR_OK ? e : clr_group::resolve_begin(h->plan[s], pp + s, ee + s);
+  });
+  if (st != CLR_OK) return st;
+  return resolve_finish_all(h, pend, elig, results);
+}
+
+// clr_batch_solve / clr_batch_dot_L / clr_batch_predict on every shard concurrently, each on its slice of the host arrays
+int clr_sharded_solve(clr_sharded* h, int nrhs, const double* b, double* x) {
+  if (nrhs < 1 || !x) return CLR_INVALID_ARGUMENT;
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  const long per = (long)nrhs * h->N;
+  return h->all([=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_solve(h->plan[s], nrhs, b ? b + lo * per : nullptr, x + lo * per);
+  });
+}
+
+int clr_sharded_dot_L(clr_sharded* h, int nrhs, const double* z, double* y) {
+  if (nrhs < 1 || !z || !y) return CLR_INVALID_ARGUMENT;
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  const long per = (long)nrhs * h->N;
+  return h->all([=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_dot_L(h->plan[s], nrhs, z + lo * per, y + lo * per);
+  });
+}
+
+int clr_sharded_predict(clr_sharded* h, int M, const double* xs, long xs_stride, double* pred) {
+  if (M < 0 || (M > 0 && (!xs || !pred)) || (xs_stride != 0 && xs_stride != M)) return CLR_INVALID_ARGUMENT;
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  return h->all([=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_predict(h->plan[s], M, xs + lo * xs_stride, xs_stride, pred + lo * (long)M);
+  });
+}
+
 int clr_sharded_run_timed(clr_sharded* h, int steps, double* shard_ms /* [nshards] or NULL */) {
   // (a timing tool: every shard times its own steps and settles them by its own counts)
   const int st0 = resolve_all(h);

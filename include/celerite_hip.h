@@ -650,6 +650,16 @@ int clr_sharded_grad(clr_sharded* h, double* value, double* grad, int* status);
 int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_real, const double* c_real,
                          const double* a_comp, const double* b_comp, const double* c_comp,
                          const double* d_comp, double* loglike, double* logdet, double* quad, int* status);
+/* The consumers of the factor on a sharded batch (GP.apply_inverse / .sample / .predict for B problems over several
+ * GPUs): clr_sharded_materialize runs clr_batch_enqueue(plan, 1) on every shard, settles the evaluation with the
+ * batch-wide counts (results as clr_sharded_get_results; any pointer may be NULL) and leaves every shard's factor in
+ * its HBM; clr_sharded_solve / _dot_L / _predict are clr_batch_solve / _dot_L / _predict on every shard concurrently,
+ * each on its contiguous slice of the host arrays ([B][nrhs][N]; xs [B][M] or shared with xs_stride = 0).  No
+ * collective: every problem's state is its own (cholesky.h:703-706). */
+int clr_sharded_materialize(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status);
+int clr_sharded_solve(clr_sharded* h, int nrhs, const double* b, double* x);
+int clr_sharded_dot_L(clr_sharded* h, int nrhs, const double* z, double* y);
+int clr_sharded_predict(clr_sharded* h, int M, const double* xs, long xs_stride, double* pred);
 /* `steps` back-to-back evaluations on every shard concurrently (HIP events per shard);
  * shard_ms[s] = that shard's first-to-last event time. */
 int clr_sharded_run_timed(clr_sharded* h, int steps, double* shard_ms);

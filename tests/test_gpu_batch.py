@@ -1837,6 +1837,55 @@ def test_an_unsorted_series_is_rejected_whatever_else_the_batch_holds():
             plan.close()
 
 
+@pytest.mark.parametrize("JR,JC,N", [(2, 3, 6000), (4, 6, 5000)])
+def test_sharded_factor_consumers(JR, JC, N):
+    """``clr_sharded_materialize`` + ``clr_sharded_solve`` / ``_dot_L`` / ``_predict``: the consumers of the factor
+    (``GP.apply_inverse`` / ``.sample`` / ``.predict``, celerite.py:307-451) on a batch sharded over 1 / 2 / 3 / 7 plans --
+    every shard works on its slice, no collective (state is per problem: cholesky.h:703-706).  Narrow plans: bit-identical
+    to the unsharded plan (same chunk count); wide plans (the sweeps' chunk count follows the shard's batch size): to
+    1e-11 of the largest entry."""
+    B = 7
+    case = synthetic(B, N, JR, JC, "bench", seed=33)
+    rng = np.random.RandomState(2)
+    rhs, z = rng.randn(B, 2, N), rng.randn(B, N)
+    xs = np.sort(rng.uniform(case["t"].min(), case["t"].max(), (B, 200)), axis=1)
+    narrow = JR + 2 * JC <= 8
+    ndev = batch.device_count()
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        if narrow:
+            plan.set_chunks(16)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*coeffs_of(case))
+        want = {"ll": plan.log_likelihood(materialize=True), "solve_y": plan.solve(), "solve": plan.solve(rhs),
+                "dot_L": plan.dot_L(z), "predict": plan.predict(xs), "predict_shared": plan.predict(xs[0])}
+    finally:
+        plan.close()
+    for S in (1, 2, 3, 7):
+        sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(S)])
+        try:
+            if narrow:
+                sp.set_chunks(16)
+            sp.set_series(case["t"], case["diag"], case["y"])
+            with pytest.raises(RuntimeError):
+                sp.set_coefficients(*coeffs_of(case)); sp.solve()          # nothing materialised yet
+            got = {"ll": sp.materialize(), "solve_y": sp.solve(), "solve": sp.solve(rhs), "dot_L": sp.dot_L(z),
+                   "predict": sp.predict(xs), "predict_shared": sp.predict(xs[0])}
+            draw = sp.sample(size=2, random=np.random.RandomState(8))
+            assert draw.shape == (B, 2, N) and np.array_equal(draw, sp.dot_L(np.random.RandomState(8).standard_normal((B, 2, N))))
+        finally:
+            sp.close()
+        for k in want:
+            if k == "ll":
+                for a, b in zip(got[k], want[k]):
+                    assert np.array_equal(a, b), (S, k)
+            elif narrow:
+                assert np.array_equal(got[k], want[k]), (S, k)
+            else:
+                within("sharded factor consumers (wide plan), %s: vs the unsharded plan, of the largest entry" % k,
+                       np.max(np.abs(got[k] - want[k])) / np.max(np.abs(want[k])), 1e-11, S)
+
+
 def test_sharding_a_batch_with_mixed_warm_eligibility():
     """A batch in which about half of the series forget their past: whether the warm-started recurrence runs (half of
     the problems eligible) and how long its warm-ups are (the history of fallbacks) used to be decided PER PLAN, so such
