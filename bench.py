@@ -807,6 +807,9 @@ def main(argv=None):
             solve["reference_layout_first_solve_device_ms"] = plan.solve_device_ms()   # (forms the chunk maps of this factor)
             x_ref = plan.solve()
             solve["reference_layout_device_ms"] = plan.solve_device_ms()
+            # ... and the batched dot_L (CholeskySolver::dot_L, cholesky.h:409-431: what GP.sample draws) of the same factor
+            plan.dot_L(y)
+            solve["dot_L_reference_layout_device_ms"] = plan.solve_device_ms()
         except Exception as e:
             solve["error"] = repr(e)
         # the LEAN layout (SURVEY.md 8d row A-lean): W and D stored, phi and u regenerated by the consumers
@@ -833,6 +836,11 @@ def main(argv=None):
                 solve["cpu_oracle_solve_ms_per_problem"] = (time.perf_counter() - t1_) * 1e3
                 solve["problem0_vs_oracle_rel"] = float(np.max(np.abs(x_lean[0] - x0)) / np.max(np.abs(x0)))
                 del x_lean, x_ref
+                Lz = plan.dot_L(y)
+                solve["dot_L_lean_layout_device_ms"] = plan.solve_device_ms()
+                Lz0 = _r.dot_L(y[0])[:, 0]
+                solve["dot_L_problem0_vs_oracle_rel"] = float(np.max(np.abs(Lz[0] - Lz0)) / np.max(np.abs(Lz0)))
+                del Lz
             lean = {"ms": lean_ms / mat_steps, "k": {k: v / mat_steps for k, v in lean_k.items()},
                     "runs": [m / mat_steps for m, _ in lean_all], "bytes_per_problem": plan.factor_bytes(),
                     "logdet_vs_fused_rel": rel_err(lld[st == 0], ld[st == 0]), "quad_vs_fused_rel": rel_err(lq[st == 0], q[st == 0])}
@@ -1207,6 +1215,9 @@ def promote(out):
     if bs and "lean_layout_device_ms" in bs:
         r["batched_solve_ms"] = {"reference_layout": bs.get("reference_layout_device_ms"), "lean_layout": bs["lean_layout_device_ms"],
                                  "problem0_vs_oracle_rel": bs.get("problem0_vs_oracle_rel")}
+        if "dot_L_lean_layout_device_ms" in bs:
+            r["batched_dot_L_ms"] = {"reference_layout": bs.get("dot_L_reference_layout_device_ms"), "lean_layout": bs["dot_L_lean_layout_device_ms"],
+                                     "problem0_vs_oracle_rel": bs.get("dot_L_problem0_vs_oracle_rel")}
     ml = out.get("materialize_lean")
     if ml and "ms_per_step" in ml:
         r["materialize_lean"] = {"step_ms": ml["ms_per_step"], "replay_ms": ml["kernels_ms"]["replay"],
