@@ -173,6 +173,7 @@ struct clr_solver {
   DevBuf ws_elems, ws_starts, ws_part, ws_cond;  // scan workspace
   DevBuf ws_lvl_elems, ws_lvl_starts;            // upper levels of the multi-level prefix; level buffers of the wide parallel prefix
   DevBuf gradbuf;                       // grad_log_likelihood staging
+  DevBuf gradws;                        // ... above width 64: S and dS of a round of directions (grad_any_kernels.hip)
   // The factor's chunk heads (clr_batch_kernels.h, BatchParams::ends): compute() writes the factor from the SCANNED
   // start states, whose rounding shows in W and D for the ~32 samples the recurrence needs to forget it -- with the ~50
   // to 100-sample chunks of one long series that is most of the factor (N = 1e5, width 8: W 1.1e-10, solve 1.8e-10 of

@@ -131,7 +131,7 @@ void clr_solver_destroy(clr_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     for (DevBuf* b : {&s->phi, &s->u, &s->W, &s->D, &s->coeffs, &s->t, &s->U, &s->V,
                       &s->scratch, &s->scratch2, &s->scalars, &s->keep_diag, &s->keep_jitter, &s->ws_ends, &s->ws_elems, &s->ws_starts,
-                      &s->ws_part, &s->ws_cond, &s->gradbuf, &s->rhs, &s->ws_lvl_elems, &s->ws_lvl_starts})
+                      &s->ws_part, &s->ws_cond, &s->gradbuf, &s->gradws, &s->rhs, &s->ws_lvl_elems, &s->ws_lvl_starts})
       b->release();
     for (DevBuf& b : s->dot_buf) b.release();
     for (DevBuf& b : s->pred_buf) b.release();
@@ -517,7 +517,7 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   const bool has_general = (n_A != 0);
   const int JG = U_rows, JR = n_a_real, JC = n_a_comp;
   if (JG > 0 && !has_general) return fail(CLR_DIMENSION_MISMATCH, "dimension mismatch");
-  if (JR + 2 * JC + JG > 64) return fail(CLR_UNSUPPORTED, "grad_log_likelihood supports widths up to 64");
+  if (JR + 2 * JC + JG > CLR_MAX_WIDTH_ANY) return fail(CLR_UNSUPPORTED, "grad_log_likelihood supports widths up to 1024");
   const int G = 1 + 2 * JR + 4 * JC;
   if (n_grad != G || !value || !grad) return fail(CLR_INVALID_ARGUMENT, "grad must hold 1 + 2 J_real + 4 J_comp values");
   if ((st = ensure_stream(s)) != CLR_OK) return st;
@@ -599,6 +599,11 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   P.out_value = s->gradbuf.p + o_out;
   P.out_grad = s->gradbuf.p + o_out + 1;
   P.out_status = s->d_status;
+  if (Wt > 64 || clr::option("CLR_GRAD_ANY_WIDTH")) {
+    // above width 64 (round 6): one workgroup per direction, S and dS in an HBM / L2 workspace (grad_any_kernels.hip)
+    if ((st = s->gradws.reserve(clr::grad_any_workspace_doubles(Wt, G))) != CLR_OK) return st;
+    if (clr::launch_grad_any(P, s->gradws.p, stream) != 0) return fail(CLR_HIP_ERROR, "grad_log_likelihood: the any-width kernel could not be configured");
+  } else
   clr::launch_grad(P, stream);
   HIP_TRY(hipGetLastError());
   std::vector<double> out((size_t)G + 1);

@@ -113,6 +113,10 @@ struct GradParams {
 };
 void launch_grad(const GradParams& P, hipStream_t s);
 void launch_grad_chunked(const GradParams& P, hipStream_t s);  // (the batched form, P.nchunk >= 2)
+// one problem (P.B == 0) at any total width up to CLR_MAX_WIDTH_ANY (grad_any_kernels.hip): one workgroup per direction,
+// S and dS in `workspace` (grad_any_workspace_doubles); non-zero: the kernel could not be configured
+size_t grad_any_workspace_doubles(int J, int NG);
+int launch_grad_any(const GradParams& P, double* workspace, hipStream_t s);
 
 // The other two kernels of the chunk-parallel gradient at the padded widths JP = 16 / 32 (wide_grad_kernels.hip):
 struct WideGradWalk {

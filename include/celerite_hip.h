@@ -51,7 +51,9 @@ typedef enum clr_status {
  * state -- takes ANY width up to this one (round 6; the reference's dynamic-width arm, cholesky.h:203, has no limit and
  * its benchmark goes to 512): compute above 64 keeps S in the registers of 1 .. 64 workgroups (csrc/rows_kernels.hip),
  * dot_L / dot are diagonal scans with one thread per row, solve / dot_solve above 64 chunked affine scans with
- * J x J chunk maps built once per factor (csrc/bigsweep_kernels.hip; short series: one workgroup per right-hand side).  grad_log_likelihood stops at width 64. */
+ * J x J chunk maps built once per factor (csrc/bigsweep_kernels.hip; short series: one workgroup per right-hand side);
+ * grad_log_likelihood above width 64: one workgroup per partial, S and its tangent in an HBM / L2 workspace
+ * (csrc/grad_any_kernels.hip; sequential in n). */
 #define CLR_MAX_WIDTH_ANY 1024
 #define CLR_CARMA_MAX_ORDER 32 /* autoregressive order p of clr_carma (state p, covariance p x p in LDS) */
 
@@ -81,7 +83,8 @@ int clr_device_memory(size_t* free_bytes, size_t* total_bytes);
 /* Tuning and cross-check switches of the library, ONE table per process (round 5 read 19 environment variables
  * directly: a stray variable silently changed kernel selection).  `value` NULL removes the option.  Environment variables
  * of the same names are honoured only when the process was started with CLR_ALLOW_ENV=1.  The keys (all "CLR_..."):
- *   CLR_GRAD_SEQUENTIAL      the sequential tangent kernel for every gradient (cross-checks)
+ *   CLR_GRAD_SEQUENTIAL      the sequential tangent kernel for every gradient (cross-checks); with CLR_GRAD_ANY_WIDTH the
+ *                            workgroup-per-partial kernel of the widths above 64 at every width
  *   CLR_GRAD_REBUILD_SPAN    reverse-mode gradient: distance of the stored states
  *   CLR_NO_SMALL_SOLVER      CholeskySolver: never the one-workgroup kernel of short narrow problems
  *   CLR_WIDE_WALK            widths 17..32: prefix + corrections as one walk per problem (cross-check of the two-kernel path)

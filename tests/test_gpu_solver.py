@@ -324,6 +324,89 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
+def _grad_case(rng, JR, JC, JG, N):
+    x = np.sort(rng.uniform(0, 30, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    y = rng.randn(N)
+    co = (np.exp(rng.uniform(-1, 1, JR)), np.exp(rng.uniform(-2, 0, JR)), np.exp(rng.uniform(-1, 0, JC)),
+          0.2 * rng.rand(JC), np.exp(rng.uniform(-2, 0, JC)), np.exp(rng.uniform(-1, 1.5, JC)))
+    if JG:
+        U = np.vander(x - np.mean(x), JG).T * 1e-3
+        V = U * rng.rand(JG)[:, None]
+        gen = (np.sum(U * V, axis=0) + 1e-8, U, V)
+    else:
+        gen = NO_GENERAL
+    return co, gen, x, y, diag
+
+
+def test_grad_log_likelihood_above_width_64():
+    """``grad_log_likelihood`` at any width (the reference's dual-number solver takes any J: solver.cpp:347-463,
+    cholesky.h:203): above 64 one workgroup per partial with S and its tangent in an HBM / L2 workspace
+    (csrc/grad_any_kernels.hip).  Against the dual-number oracle at widths 70 (2 real + 34 complex: 141 partials) and 67
+    (general terms as constant rows); forced at width 40 against the oracle AND the wave-per-partial kernel it extends;
+    at width 130 and 260 (rounds of 256 partials) against central differences of the device's own log-likelihood;
+    the zero-jitter rule, the indefinite matrix and the dimension checks as below width 64."""
+    from oracle import grad as ograd
+
+    rng = np.random.RandomState(11)
+    s = celerite_amd.CholeskySolver()
+    for JR, JC, JG, N in ((2, 34, 0, 120), (1, 30, 6, 100)):
+        co, gen, x, y, diag = _grad_case(rng, JR, JC, JG, N)
+        for jitter in (0.0, 0.3):
+            args = (jitter,) + co + gen + (x, y, diag)
+            value, g = s.grad_log_likelihood(*args)
+            v0, g0 = ograd.grad_log_likelihood(*args)
+            within("gradient above width 64 (width %d): value vs the dual-number oracle" % (JR + 2 * JC + JG), abs(value - v0) / abs(v0), 1e-11)
+            within("gradient above width 64 (width %d): partials vs the dual-number oracle, of 1 + |g|" % (JR + 2 * JC + JG),
+                   np.max(np.abs(g - g0) / (1.0 + np.abs(g0))), 1e-9)
+            assert (g[0] == 0.0) == (jitter == 0.0)   # solver.cpp:379-389,419-426
+    # the same kernel forced at width 40, where the wave-per-partial kernel exists
+    co, gen, x, y, diag = _grad_case(rng, 4, 18, 0, 700)
+    args = (0.2,) + co + gen + (x, y, diag)
+    with batch.option("CLR_GRAD_SEQUENTIAL"):
+        v_wave, g_wave = s.grad_log_likelihood(*args)
+        with batch.option("CLR_GRAD_ANY_WIDTH"):
+            v_any, g_any = s.grad_log_likelihood(*args)
+    v0, g0 = ograd.grad_log_likelihood(*args)
+    within("any-width gradient kernel forced at width 40: value vs oracle", abs(v_any - v0) / abs(v0), 1e-11)
+    within("any-width gradient kernel forced at width 40: partials vs oracle, of 1 + |g|", np.max(np.abs(g_any - g0) / (1.0 + np.abs(g0))), 1e-9)
+    within("any-width gradient kernel forced at width 40: partials vs the wave-per-partial kernel, of 1 + |g|",
+           np.max(np.abs(g_any - g_wave) / (1.0 + np.abs(g_wave))), 1e-10)
+    # widths 130 / 260: central differences of the device's own log-likelihood in a few directions
+    for JR, JC, N in ((2, 64, 300), (4, 128, 150)):
+        co, gen, x, y, diag = _grad_case(rng, JR, JC, 0, N)
+        jitter = 0.1
+        value, g = s.grad_log_likelihood(jitter, *co, *gen, x, y, diag)
+        assert g.shape == (1 + 2 * JR + 4 * JC,) and np.all(np.isfinite(g))
+
+        def ll(jit, cc):
+            s.compute(jit, *cc, *gen, x, diag)
+            return -0.5 * (s.dot_solve(y) + s.log_determinant() + np.pi * np.log(N))   # solver.cpp:415
+
+        within("gradient at width %d: value vs compute + dot_solve" % (JR + 2 * JC), abs(value - ll(jitter, co)) / abs(value), 1e-11)
+        offs = np.cumsum([1, JR, JR, JC, JC, JC])          # a_real, c_real, a_comp, b_comp, c_comp, d_comp
+        picks = [(-1, 0)] + [(k, j) for k in range(6) for j in ((0, len(co[k]) - 1) if len(co[k]) > 1 else (0,))]
+        for k, j in picks:
+            base = jitter if k < 0 else co[k][j]
+            h = 1e-6 * max(abs(base), 1e-2)
+            def shifted(d):
+                if k < 0:
+                    return ll(jitter + d, co)
+                cc = [c.copy() for c in co]
+                cc[k][j] += d
+                return ll(jitter, cc)
+            fd = (shifted(h) - shifted(-h)) / (2.0 * h)
+            got = g[0] if k < 0 else g[offs[k] + j]
+            within("gradient at width %d: partials vs central differences of the device log-likelihood, of 1 + |g|" % (JR + 2 * JC),
+                   abs(got - fd) / (1.0 + abs(fd)), 2e-5, (k, j))
+    co = (np.array([-300.0]), np.array([0.5]), np.exp(rng.uniform(-1, 0, 33)), np.zeros(33), np.exp(rng.uniform(-2, 0, 33)), np.exp(rng.uniform(-1, 1, 33)))
+    x = np.sort(rng.uniform(0, 30, 200))
+    with pytest.raises(celerite_amd.solver.LinAlgError):
+        s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, rng.randn(200), np.zeros(200))
+    with pytest.raises(RuntimeError):
+        s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, rng.randn(199), np.full(200, 0.1))
+
+
 @pytest.mark.parametrize("JR,JC,JG,N", [(4, 4, 0, 4200), (0, 8, 0, 20000), (2, 5, 0, 9000), (0, 16, 0, 8000), (6, 13, 0, 5000),
                                         (2, 3, 4, 6000), (0, 8, 3, 5000), (1, 0, 2, 4096)])
 def test_grad_log_likelihood_at_widths_9_to_32_and_with_general_terms_is_parallel_in_n(JR, JC, JG, N):
