@@ -23,7 +23,7 @@ ORACLE := oracle/libcelerite_ref.so
 
 HIP_SRCS := api_misc api_solver api_batch api_grad api_kernels series_io small_kernels generic_kernels wide_kernels wide64_kernels wide_prefix_scan grad_kernels grad_any_kernels wide_grad_kernels sweep_kernels wsweep_kernels huge_kernels rows_kernels bigsweep_kernels carma batch_w1 batch_w2 batch_w3 batch_w4 batch_w5 batch_w6 batch_w7 batch_w8 batch_split7 batch_split8
 HIP_OBJS := $(addprefix $(BUILD)/,$(addsuffix .o,$(HIP_SRCS)))
-HDRS     := $(CSRC)/api_internal.h $(CSRC)/clr_series_io.h $(CSRC)/clr_carma.h $(CSRC)/clr_small.h $(CSRC)/clr_prefix_kernels.h $(CSRC)/clr_grad_core.h $(CSRC)/clr_grad_kernels.h $(CSRC)/clr_core.h $(CSRC)/clr_wide.h $(CSRC)/clr_batch_kernels.h $(CSRC)/clr_split_kernels.h $(CSRC)/clr_generic_kernels.h $(CSRC)/clr_group_hooks.h $(CSRC)/clr_bsolve_kernels.h $(CSRC)/clr_bdotl_kernels.h $(CSRC)/clr_options.h include/celerite_hip.h include/celerite_hip_debug.h
+HDRS     := $(CSRC)/api_internal.h $(CSRC)/clr_series_io.h $(CSRC)/clr_carma.h $(CSRC)/clr_small.h $(CSRC)/clr_prefix_kernels.h $(CSRC)/clr_grad_core.h $(CSRC)/clr_grad_kernels.h $(CSRC)/clr_core.h $(CSRC)/clr_wide.h $(CSRC)/clr_batch_kernels.h $(CSRC)/clr_split_kernels.h $(CSRC)/clr_generic_kernels.h $(CSRC)/clr_group_hooks.h $(CSRC)/clr_bsolve_kernels.h $(CSRC)/clr_bdotl_kernels.h $(CSRC)/clr_bdot_kernels.h $(CSRC)/clr_options.h include/celerite_hip.h include/celerite_hip_debug.h
 
 all: $(LIB) $(PYMOD) $(ORACLE)
 

@@ -411,6 +411,20 @@ class BatchedGP(object):
         _check(lib.clr_batch_dot_L(self._h, int(nrhs), _ptr(z), _ptr(y)))
         return y
 
+    def dot(self, z):
+        """``K_p z_p`` for every problem at the coefficients in force (``clr_batch_dot``; ``CholeskySolver.dot``,
+        cholesky.h:441-596, for B problems at once -- the kernel matrix WITHOUT the observational variance, as
+        ``GP.dot``).  ``z``: ``(B, N)`` or ``(B, nrhs, N)``; returns an array of the same shape."""
+        lib = _load()
+        lib.clr_batch_dot.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        z = _f64(z)
+        if z.ndim not in (2, 3) or z.shape[0] != self.B or z.shape[-1] != self.N:
+            raise ValueError("dimension mismatch")
+        nrhs = 1 if z.ndim == 2 else z.shape[1]
+        y = np.empty(z.shape)
+        _check(lib.clr_batch_dot(self._h, int(nrhs), _ptr(z), _ptr(y)))
+        return y
+
     def sample(self, size=None, mean=None, random=None):
         """Draws from every problem's prior ``N(mean_p, K_p)`` (``GP.sample``, celerite.py:422-451: ``mean + L n`` with
         standard normal ``n``) from the factor of the last materialising run.  ``size=None``: ``(B, N)``; else
@@ -929,6 +943,15 @@ class ShardedBatchedGP(object):
         return y
 
     sample = BatchedGP.sample
+
+    def dot(self, z):
+        """``K_p z_p`` for every problem (as :meth:`BatchedGP.dot`), every shard on its slice."""
+        lib = _load()
+        lib.clr_sharded_dot.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        z, nrhs = self._rhs(z)
+        y = np.empty(z.shape)
+        self._ok(lib.clr_sharded_dot(self._h, int(nrhs), _ptr(z), _ptr(y)))
+        return y
 
     def predict(self, xs):
         """The conditional mean of every problem at ``xs`` (``(M,)`` shared or ``(B, M)``), as :meth:`BatchedGP.predict`."""

@@ -53,7 +53,7 @@ void clr_batch_destroy(clr_batch* h) {
                     &h->elems, &h->starts, &h->part, &h->partx, &h->cond, &h->out, &h->phi, &h->u, &h->W, &h->D,
                     &h->fphi, &h->fu, &h->fW, &h->fD, &h->lvl_elems, &h->lvl_starts, &h->wstarts, &h->wends,
                     &h->wpart, &h->wresid, &h->wT, &h->wD, &h->wY, &h->gA, &h->gU, &h->gV, &h->g_riders, &h->g_out,
-                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->bs_decay, &h->ends, &h->sT, &h->sD, &h->sY})
+                    &h->g_res, &h->g_rec, &h->g_ck, &h->bs_rm, &h->bs_x, &h->bs_M, &h->bs_off, &h->bs_starts, &h->bs_decay, &h->bs_y, &h->ends, &h->sT, &h->sD, &h->sY})
     b->release();
   if (h->flags) (void)hipFree(h->flags);
   if (h->wints) (void)hipFree(h->wints);
@@ -1876,6 +1876,108 @@ int clr_batch_dot_L(clr_batch* h, int nrhs, const double* z, double* y) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(y, result, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->bs_ev[0], h->bs_ev[1]));
+  h->solve_device_ms = ms;
+  return CLR_OK;
+}
+
+// CholeskySolver::dot (cholesky.h:441-596; GP.dot, celerite.py:453-489) for every problem of the plan: y_p = K_p z_p with
+// K_p given by the plan's resident times and the coefficients in force (diagonal sum a_real + sum a_comp + jitter: no
+// observational variance, :483-485) -- no factor, no materialising run.  Narrow plans: the two triangles as chunked
+// diagonal scans with the features evaluated on the fly (clr_bdot_kernels.h), lane = (problem, chunk).  Wide plans
+// (widths 9..64): the object API's kernels problem by problem (launch_dot_setup + the wave-per-chunk scans of
+// wsweep_kernels.hip, or the sequential kernel on short series) on the plan's resident arrays.
+int clr_batch_dot(clr_batch* h, int nrhs, const double* z, double* y) {
+  int st = require_device(h->device);
+  if (st != CLR_OK) return st;
+  if (nrhs < 1 || nrhs > 65535 || !z || !y) return fail(CLR_INVALID_ARGUMENT, "clr_batch_dot: 1 <= nrhs <= 65535 (grid.z), z and an output array");
+  if ((st = warm_resolve(h, nullptr)) != CLR_OK) return st;
+  if (h->J_general > 0 || h->J > clr::wide_max_width()) return fail(CLR_UNSUPPORTED, "clr_batch_dot covers celerite-only plans of widths 1..64");
+  clr::BatchParams P;
+  if ((st = batch_params(h, 0, P)) != CLR_OK) return st;
+  const size_t B = (size_t)h->B, N = (size_t)h->N, J = (size_t)h->J, R = (size_t)nrhs;
+  if ((st = h->bs_rm.reserve(B * R * N)) != CLR_OK) return st;
+  for (hipEvent_t& e : h->bs_ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipMemcpyAsync(h->bs_rm.p, z, B * R * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const double* result = nullptr;
+  if (!h->launch) {  // wide plans: problem by problem
+    const size_t nr = B * h->J_real, nc = B * h->J_comp;
+    std::vector<double> hc(2 * nr + 4 * nc + B);
+    HIP_TRY(hipMemcpyAsync(hc.data(), h->coeffs.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<double> hdg(B * N);
+    for (size_t p = 0; p < B; ++p) {
+      double sr = 0.0, sc = 0.0;
+      for (int j = 0; j < h->J_real; ++j) sr += hc[p * h->J_real + j];
+      for (int j = 0; j < h->J_comp; ++j) sc += hc[2 * nr + p * h->J_comp + j];
+      const double d = (sr + sc) + hc[2 * nr + 4 * nc + p];  // cholesky.h:483-485
+      for (size_t n = 0; n < N; ++n) hdg[p * N + n] = d;
+    }
+    DevBuf feat, dgb, ws;
+    auto cleanup = [&](int code) { (void)hipStreamSynchronize(h->stream); feat.release(); dgb.release(); ws.release(); return code; };
+    if ((st = feat.reserve(3 * J * N)) != CLR_OK) return cleanup(st);
+    if ((st = dgb.reserve(B * N)) != CLR_OK) return cleanup(st);
+    if ((st = h->bs_x.reserve(B * R * N)) != CLR_OK) return cleanup(st);
+    if (hipMemcpyAsync(dgb.p, hdg.data(), B * N * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+      return cleanup(fail(CLR_HIP_ERROR, "clr_batch_dot: upload failed"));
+    const bool scan = clr::wdotl_scan_supported(h->N, h->J);
+    clr::SweepParams SP;
+    memset(&SP, 0, sizeof(SP));
+    if (scan) {
+      SP.N = h->N; SP.J = h->J; SP.nrhs = nrhs;
+      SP.nchunk = clr::wdotl_chunks(h->N);
+      SP.L = (h->N - 1 + SP.nchunk - 1) / SP.nchunk;
+      SP.nchunk = (h->N - 1 + SP.L - 1) / SP.L;
+      if ((st = ws.reserve(R * (size_t)SP.nchunk * 3 * J)) != CLR_OK) return cleanup(st);
+    }
+    (void)hipEventRecord(h->bs_ev[0], h->stream);
+    for (size_t p = 0; p < B; ++p) {
+      clr::GenericProblem g;
+      g.N = h->N; g.J = h->J; g.J_real = h->J_real; g.J_comp = h->J_comp; g.J_general = 0;
+      g.a_real = P.a_real + p * h->J_real; g.c_real = P.c_real + p * h->J_real;
+      g.a_comp = P.a_comp + p * h->J_comp; g.b_comp = P.b_comp + p * h->J_comp;
+      g.c_comp = P.c_comp + p * h->J_comp; g.d_comp = P.d_comp + p * h->J_comp;
+      g.U = nullptr; g.V = nullptr;
+      g.t = h->t.p + p * (size_t)h->t_stride;
+      double *phi = feat.p, *u = feat.p + J * N, *v = feat.p + 2 * J * N;
+      clr::launch_dot_setup(g, phi, u, v, h->stream);
+      if (scan) {
+        SP.phi = phi; SP.u = u;
+        SP.in = h->bs_rm.p + p * R * N; SP.out = h->bs_x.p + p * R * N;
+        clr::launch_wdot_scan(SP, v, dgb.p + p * N, ws.p, h->stream);
+      } else {
+        clr::launch_dot(h->N, h->J, nrhs, phi, u, v, dgb.p + p * N, h->bs_rm.p + p * R * N, h->bs_x.p + p * R * N, h->stream);
+      }
+    }
+    (void)hipEventRecord(h->bs_ev[1], h->stream);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(y, h->bs_x.p, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+      return cleanup(fail(CLR_HIP_ERROR, "clr_batch_dot: kernels or the download failed"));
+    if ((st = cleanup(CLR_OK)) != CLR_OK) return st;
+  } else {
+    // the row-major times addressed directly (the chunk-interleaved copy of the role-split summarize is only made by an
+    // evaluation: clr_batch_dot must not depend on one having run)
+    P.t = h->t.p; P.t_stride = h->t_stride; P.lane_is = 1; P.lane_cs = h->L; P.staged = 0;
+    const size_t cells = (size_t)h->L * h->nchunk;
+    if ((st = h->bs_x.reserve(B * R * cells)) != CLR_OK) return st;
+    if ((st = h->bs_y.reserve(B * R * cells)) != CLR_OK) return st;
+    if ((st = h->bs_decay.reserve(B * h->nchunk * J)) != CLR_OK) return st;
+    if ((st = h->bs_off.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+    if ((st = h->bs_starts.reserve(B * R * h->nchunk * J)) != CLR_OK) return st;
+    HIP_TRY(hipEventRecord(h->bs_ev[0], h->stream));
+    clr::launch_relayout(h->bs_rm.p, (long)N, h->bs_x.p, (long)cells, (int)(B * R), h->N, h->L, h->nchunk, 0, h->stream);
+    clr::BDotParams S;
+    S.nrhs = nrhs; S.zT = h->bs_x.p; S.yT = h->bs_y.p; S.decay = h->bs_decay.p; S.off = h->bs_off.p; S.starts = h->bs_starts.p;
+    h->launch->bdot(P, S, h->stream);
+    clr::launch_relayout_back(h->bs_y.p, (long)cells, h->bs_rm.p, (long)N, (int)(B * R), h->N, h->L, h->nchunk, h->stream);
+    HIP_TRY(hipEventRecord(h->bs_ev[1], h->stream));
+    result = h->bs_rm.p;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(y, result, B * R * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->bs_ev[0], h->bs_ev[1]));
   h->solve_device_ms = ms;

@@ -309,7 +309,7 @@ struct clr_batch {
   int* flags = nullptr;                    // flags [B*nchunk] | flagsx [B*nchunk] | need_exact [B]
   int force_exact = 0;
   bool factor_valid = false;  // a materialising run has written the factor under the chunking in force
-  DevBuf bs_decay;                              // clr_batch_dot_L: the chunks' decay products
+  DevBuf bs_decay, bs_y;                        // clr_batch_dot_L / clr_batch_dot: the chunks' decay products; dot's output, chunk-interleaved
   DevBuf bs_rm, bs_x, bs_M, bs_off, bs_starts;  // clr_batch_solve: right-hand sides row-major / chunk-interleaved, chunk maps, offsets, start states
   bool bs_M_valid = false;                      // bs_M holds the chunk maps of the factor in HBM (they depend on the factor only)
   double solve_device_ms = 0.0;                 // device time of the last clr_batch_solve (HIP events around its kernels)

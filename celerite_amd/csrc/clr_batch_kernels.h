@@ -1004,6 +1004,7 @@ __global__ void __launch_bounds__(64) warm_check_kernel(const BatchParams P) {
 #include "clr_grad_kernels.h"
 #include "clr_bsolve_kernels.h"
 #include "clr_bdotl_kernels.h"
+#include "clr_bdot_kernels.h"
 namespace clr {
 
 // One table entry per (JR, JC): host-callable launchers.
@@ -1023,6 +1024,8 @@ struct BatchLaunchers {
   void (*bsolve)(const BatchParams&, BSolveParams S, hipStream_t);
   // L z for all problems and right-hand sides from the materialised factor (clr_bdotl_kernels.h): S.xT in / out
   void (*bdotl)(const BatchParams&, BDotLParams S, hipStream_t);
+  // K z for all problems and right-hand sides from the plan's times and coefficients (clr_bdot_kernels.h): S.zT -> S.yT
+  void (*bdot)(const BatchParams&, BDotParams S, hipStream_t);
   // lean factor of problem b (replay mode 3) -> the reference's storage, phi and u regenerated (t: the problem's row-major times)
   void (*expand)(const BatchParams&, int b, const double* t, double* phi, double* u, double* W, double* D, hipStream_t);
   int elem_doubles, start_doubles;
@@ -1134,6 +1137,21 @@ struct BatchImpl {
     if (S.lean) { if (P.fast_trig) bdotl_go<true, true>(P, S, s); else bdotl_go<true, false>(P, S, s); }
     else bdotl_go<false, true>(P, S, s);  // (the stored phi, u: no trigonometry)
   }
+  // the batched dot: per triangle the chunk offsets (and, once, the decay products), the walk, the recurrence
+  template <bool FAST>
+  static void bdot_go(const BatchParams& P, const BDotParams& S, hipStream_t s) {
+    constexpr int J = JR + 2 * JC;
+    const dim3 grid((P.nchunk + 63) / 64, P.B, S.nrhs), pgrid((unsigned)(((long)P.B * S.nrhs + 63) / 64));
+    hipLaunchKernelGGL((bdot_kernel<JR, JC, FAST, 0, false>), grid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdot_prefix_kernel<J, 0>), pgrid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdot_kernel<JR, JC, FAST, 0, true>), grid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdot_kernel<JR, JC, FAST, 1, false>), grid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdot_prefix_kernel<J, 1>), pgrid, dim3(64), 0, s, P, S);
+    hipLaunchKernelGGL((bdot_kernel<JR, JC, FAST, 1, true>), grid, dim3(64), 0, s, P, S);
+  }
+  static void bdot(const BatchParams& P, BDotParams S, hipStream_t s) {
+    if (P.fast_trig) bdot_go<true>(P, S, s); else bdot_go<false>(P, S, s);
+  }
   static void compose_check(const BatchParams& P, int g, double* coop, double* ref, hipStream_t s) {
     constexpr int J = JR + 2 * JC;
     const int np = (P.nchunk + g - 1) / g;
@@ -1186,7 +1204,7 @@ struct BatchImpl {
   }
   static BatchLaunchers table() {
     return BatchLaunchers{&summarize, &prefix, &correct, &replay, &sequential, &compose_check, &warm, &grad, &grad_reverse,
-                          &bsolve, &bdotl, &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
+                          &bsolve, &bdotl, &bdot, &expand, Widths<JR, JC>::ELEM, Widths<JR, JC>::START};
   }
 };
 

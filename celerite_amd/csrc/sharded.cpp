@@ -516,6 +516,17 @@ int clr_sharded_dot_L(clr_sharded* h, int nrhs, const double* z, double* y) {
   });
 }
 
+int clr_sharded_dot(clr_sharded* h, int nrhs, const double* z, double* y) {
+  if (nrhs < 1 || !z || !y) return CLR_INVALID_ARGUMENT;
+  const int st0 = resolve_all(h);
+  if (st0 != CLR_OK) return st0;
+  const long per = (long)nrhs * h->N;
+  return h->all([=](int s) {
+    const long lo = h->lo[s];
+    return clr_batch_dot(h->plan[s], nrhs, z + lo * per, y + lo * per);
+  });
+}
+
 int clr_sharded_predict(clr_sharded* h, int M, const double* xs, long xs_stride, double* pred) {
   if (M < 0 || (M > 0 && (!xs || !pred)) || (xs_stride != 0 && xs_stride != M)) return CLR_INVALID_ARGUMENT;
   const int st0 = resolve_all(h);

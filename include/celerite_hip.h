@@ -500,6 +500,12 @@ int clr_batch_predict(clr_batch* h, int M, const double* xs, long xs_stride, dou
  * (grid.z = problem; series shorter than 2048 samples: the sequential kernel per problem).  clr_batch_get_solve_ms
  * then reports this call's device time. */
 int clr_batch_dot_L(clr_batch* h, int nrhs, const double* z, double* y);
+/* CholeskySolver::dot (cholesky.h:441-596: y = K z, GP.dot of celerite.py:453-489) for every problem of the plan, K_p given
+ * by the plan's resident times and the coefficients in force -- its diagonal is sum a_real + sum a_comp + jitter, the
+ * observational variance is not part of it (:483-485); no factor and no materialising run are needed.  z, y host
+ * [B][nrhs][N].  Widths 1..8: both triangles as chunked diagonal scans with the features evaluated on the fly, lane =
+ * (problem, chunk) (csrc/clr_bdot_kernels.h); widths 9..64: the object API's kernels problem by problem. */
+int clr_batch_dot(clr_batch* h, int nrhs, const double* z, double* y);
 /* Device time of the last clr_batch_solve (HIP events around its kernels: relayout, the five phases, relayout back;
  * the host <-> HBM copies of b and x are outside). */
 int clr_batch_get_solve_ms(const clr_batch* h, double* device_ms);
@@ -656,12 +662,13 @@ int clr_sharded_evaluate(clr_sharded* h, const double* jitter, const double* a_r
 /* The consumers of the factor on a sharded batch (GP.apply_inverse / .sample / .predict for B problems over several
  * GPUs): clr_sharded_materialize runs clr_batch_enqueue(plan, 1) on every shard, settles the evaluation with the
  * batch-wide counts (results as clr_sharded_get_results; any pointer may be NULL) and leaves every shard's factor in
- * its HBM; clr_sharded_solve / _dot_L / _predict are clr_batch_solve / _dot_L / _predict on every shard concurrently,
+ * its HBM; clr_sharded_solve / _dot_L / _dot / _predict are clr_batch_solve / _dot_L / _dot / _predict on every shard concurrently,
  * each on its contiguous slice of the host arrays ([B][nrhs][N]; xs [B][M] or shared with xs_stride = 0).  No
  * collective: every problem's state is its own (cholesky.h:703-706). */
 int clr_sharded_materialize(clr_sharded* h, double* loglike, double* logdet, double* quad, int* status);
 int clr_sharded_solve(clr_sharded* h, int nrhs, const double* b, double* x);
 int clr_sharded_dot_L(clr_sharded* h, int nrhs, const double* z, double* y);
+int clr_sharded_dot(clr_sharded* h, int nrhs, const double* z, double* y);
 int clr_sharded_predict(clr_sharded* h, int M, const double* xs, long xs_stride, double* pred);
 /* `steps` back-to-back evaluations on every shard concurrently (HIP events per shard);
  * shard_ms[s] = that shard's first-to-last event time. */

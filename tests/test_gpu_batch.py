@@ -429,6 +429,63 @@ def test_batched_dot_L_on_plans(JR, JC, N, layout, chunks):
         plan.close()
 
 
+@pytest.mark.parametrize("JR,JC,N,chunks,family", [
+    (2, 3, 6000, 24, "bench"), (1, 1, 3001, 7, "accuracy"), (3, 0, 100, 0, "bench"), (0, 4, 20000, 0, "accuracy"), (1, 0, 257, 2, "bench"),
+    (4, 14, 4000, 0, "bench"), (0, 8, 1500, 0, "accuracy"), (0, 32, 2500, 0, "bench")])
+def test_batched_dot_on_plans(JR, JC, N, chunks, family):
+    """``clr_batch_dot`` -- ``CholeskySolver::dot`` (cholesky.h:441-596; ``GP.dot``, celerite.py:453-489) for every problem
+    of a plan: y = K z with K from the plan's times and the coefficients in force (no factor; the diagonal is
+    sum a + jitter, :483-485).  Narrow plans: the two triangles as chunked diagonal scans with features on the fly
+    (csrc/clr_bdot_kernels.h; one chunk, a ragged last chunk, a jitter per problem); wide plans: the object API's
+    kernels problem by problem.  Against the oracle's ``dot`` problem by problem and, on a short series, the dense K
+    from ``get_kernel_value``; sharded over 3 plans bit-identical."""
+    B = 5
+    case = synthetic(B, N, JR, JC, family, seed=60 + JR + JC)
+    rng = np.random.RandomState(23)
+    z = rng.randn(B, 2, N)
+    jitter = rng.uniform(0.0, 0.5, B)
+    co = coeffs_of(case)
+    plan = batch.BatchedGP(B, N, JR, JC)
+    try:
+        if JR + 2 * JC <= 8 and chunks:
+            plan.set_chunks(chunks)
+        plan.set_series(case["t"], case["diag"], case["y"])
+        plan.set_coefficients(*co, jitter=jitter)
+        y1 = plan.dot(z[:, 0])
+        y2 = plan.dot(z)
+        assert y1.shape == (B, N) and y2.shape == (B, 2, N) and plan.solve_device_ms() > 0.0
+        assert np.array_equal(y2[:, 0], y1)
+        ll = plan.log_likelihood()                         # an evaluation afterwards is undisturbed
+        assert np.all(np.isfinite(ll[0]))
+        for p in range(B):
+            r = ref.RefSolver()
+            want = r.dot(jitter[p], *coeffs_of(case, p), np.empty(0), np.empty((0, 0)), np.empty((0, 0)), case["t"][p], z[p].T)
+            within("batched dot on plans (width %d, N = %d, %s): vs oracle dot, of the largest entry" % (JR + 2 * JC, N, family),
+                   np.max(np.abs(y2[p].T - want)) / np.max(np.abs(want)), 1e-12, p)
+        if N <= 300:
+            from celerite_amd.solver import get_kernel_value
+            for p in range(B):
+                K = get_kernel_value(*coeffs_of(case, p), case["t"][p][:, None] - case["t"][p][None, :])
+                K[np.diag_indices_from(K)] += jitter[p]
+                within("batched dot on plans: vs the dense kernel matrix, of the largest entry",
+                       np.max(np.abs(y2[p].T - K @ z[p].T)) / np.max(np.abs(K @ z[p].T)), 1e-12, p)
+    finally:
+        plan.close()
+    ndev = batch.device_count()
+    sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[s % ndev for s in range(3)])
+    try:
+        if JR + 2 * JC <= 8 and chunks:
+            sp.set_chunks(chunks)
+        sp.set_series(case["t"], case["diag"], case["y"])
+        sp.set_coefficients(*co, jitter=jitter)
+        if JR + 2 * JC <= 8 and not chunks:
+            pass          # (the automatic chunk count follows the shard's batch size: equal results, not equal bits)
+        else:
+            assert np.array_equal(sp.dot(z), y2)
+    finally:
+        sp.close()
+
+
 def test_batched_dot_L_argument_and_state_errors():
     """``clr_batch_dot_L`` before a materialising run is CLR_NOT_COMPUTED (the reference's ``compute_exception``,
     cholesky.h:411), a wrong shape a dimension mismatch (:410), and a lean factor whose inputs were replaced is refused."""
