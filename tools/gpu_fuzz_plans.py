@@ -1,7 +1,9 @@
 # -*- coding: utf-8 -*-
 """Randomised cross-check of the batched plans against the CPU oracle: random (B, N, J_real, J_comp) over widths 1 .. 128,
 both synthetic families, shared or per-problem series, a few indefinite problems mixed in; log-likelihood / log det /
-quadratic form / status of every problem, and on every third case a materialising run with the batched solve.
+quadratic form / status of every problem, on every third case a materialising run with the batched solve and the batched
+dot_L (either factor layout on narrow plans), and on every case of width <= 64 the batched dot (before OR after the
+evaluation: it must not depend on one having run) -- the last two also through a sharded plan on every sixth case.
 Usage: gpu_fuzz_plans.py [cases] [seed]"""
 import os
 import sys
@@ -46,10 +48,28 @@ for k in range(cases):
     l0, d0, q0, s0 = ref.batch_log_likelihood(0.0, *coeffs_of(case), case["t"], case["diag"], case["y"])
     plan = batch.BatchedGP(B, N, JR, JC)
     try:
+        lean = width <= 8 and rng.randint(2) == 1
+        if lean:
+            plan.set_factor_layout("lean")
         plan.set_series(case["t"], case["diag"], case["y"])
         plan.set_coefficients(*coeffs_of(case))
+        zz = rng.randn(B, N)
+        pd = int(rng.randint(B))
+        dot_first = width <= 64 and rng.randint(2) == 0
+        if dot_first:
+            kz = plan.dot(zz)
         ll, ld, q, st = plan.log_likelihood()
         tag = (B, N, JR, JC, family, plan.chunks)
+        if width <= 64:
+            if not dot_first:
+                kz = plan.dot(zz)
+            want = ref.RefSolver().dot(0.0, *coeffs_of(case, pd), E, E2, E2, case["t"][pd], zz[pd])[:, 0]
+            dv = np.max(np.abs(kz[pd] - want)) / max(np.max(np.abs(want)), 1e-300)
+            if not (dv <= worst.get("batched dot", (0.0,))[0]):
+                worst["batched dot"] = (float(dv), tag)
+            if not (dv <= 1e-9):
+                bad += 1
+                print("ABOVE 1e-9: batched dot %.2e %s first=%s" % (dv, tag, dot_first), flush=True)
         if not np.array_equal(st != 0, s0 != 0):
             bad += 1
             print("STATUS differs:", tag, st, s0, flush=True)
@@ -72,6 +92,25 @@ for k in range(cases):
             r.compute(0.0, *coeffs_of(case, p), E, E2, E2, case["t"][p], case["diag"][p])
             want = r.solve(case["y"][p])[:, 0]
             devs["batched solve"] = np.max(np.abs(x[p] - want)) / np.max(np.abs(want))
+        if k % 3 == 0 and width <= 64 and ok.all() and N >= 2:
+            plan.log_likelihood(materialize=True)
+            lz = plan.dot_L(zz)
+            p = int(rng.randint(B))
+            r = ref.RefSolver()
+            r.compute(0.0, *coeffs_of(case, p), E, E2, E2, case["t"][p], case["diag"][p])
+            want = r.dot_L(zz[p])[:, 0]
+            devs["batched dot_L"] = np.max(np.abs(lz[p] - want)) / np.max(np.abs(want))
+            if k % 6 == 0 and B >= 2:
+                sp = batch.ShardedBatchedGP(B, N, JR, JC, devices=[0] * min(B, 3))
+                try:
+                    sp.set_chunks(plan.chunks[0])
+                    sp.set_series(case["t"], case["diag"], case["y"])
+                    sp.set_coefficients(*coeffs_of(case))
+                    sp.materialize()
+                    devs["sharded dot_L vs plan"] = np.max(np.abs(sp.dot_L(zz) - lz)) / np.max(np.abs(lz))
+                    devs["sharded dot vs plan"] = np.max(np.abs(sp.dot(zz) - kz)) / np.max(np.abs(kz))
+                finally:
+                    sp.close()
         for name, v in devs.items():
             v = float(v)
             if not (v <= worst.get(name, (0.0,))[0]):
