@@ -546,8 +546,8 @@ def gradient_block(B, N, JR, JC, seed):
     # widths 16 and 32 through the object API (one series of N samples): the wide scan + chunk-wise forward-mode
     # tangents (csrc/wide_grad_kernels.hip) against the sequential tangent kernel
     wide = {}
-    for name, jc in (("width16", 8), ("width32", 16)):
-        wc, wt, wd, wy = make_inputs(1, N, 0, jc, seed + 5, d_spread=(jc == 16))
+    for name, jc in (("width16", 8), ("width32", 16), ("width64", 32)):   # (width 64: round 6, wide_grad_riders64_kernel)
+        wc, wt, wd, wy = make_inputs(1, N, 0, jc, seed + 5, d_spread=(jc >= 16))
         wargs = (0.01,) + tuple(c[0] for c in wc) + (e, e2, e2, wt[0], wy[0], wd[0])
         ws = celerite_amd.CholeskySolver()
         ws.grad_log_likelihood(*wargs)

@@ -57,10 +57,11 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
     return fail(CLR_UNSUPPORTED, "the plan gradient with general terms needs the chunked wide scan (total width <= 32, N >= 1024)");
   if (!general && Wt <= 32 && (h->launch || h->nchunk < 2))
     return fail(CLR_UNSUPPORTED, "the plan gradient at widths 9..32 needs a chunked plan: use clr_batch_grad_log_likelihood");
-  // widths 33..64: the chunk-wise tangent kernels exist at the padded widths 16 and 32 only (their riders are three
-  // JP x JP matrices per chunk in LDS: 200 KB at 64) -- the plan's gradient there is the SEQUENTIAL tangent kernel on
-  // the plan's resident series and coefficients (one wave per problem and direction, solver.cpp:347-463 as it stands)
-  const bool seq_all = Wt > 32;
+  // widths 33..64: chunked plans take the chunk-wise tangents at the padded width 64 (round 6: the riders' elimination
+  // in 133 KB of LDS under a workgroup of 256 threads, wide_grad_riders64_kernel); a plan of one chunk runs the SEQUENTIAL
+  // tangent kernel on the plan's resident series and coefficients (one wave per problem and direction,
+  // solver.cpp:347-463 as it stands).  CLR_GRAD_SEQUENTIAL: the sequential kernel for every problem (cross-checks).
+  const bool seq_all = Wt > 32 && (h->nchunk < 2 || clr::option("CLR_GRAD_SEQUENTIAL") != nullptr);
   if (seq_all && general)
     return fail(CLR_UNSUPPORTED, "the plan gradient with general terms covers total widths up to 32");
   // (the tangent kernels are built up to the padded width 64: rows beyond it would be dropped while the diagonal sums
@@ -80,7 +81,7 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   if ((st = batch_params(h, 0, P0)) != CLR_OK) return st;
   if (general) general_wide_params(h, P0, P); else P = P0;
   const size_t B = (size_t)h->B, NG = 1 + 2 * (size_t)h->J_real + 4 * (size_t)h->J_comp;
-  const int JP = Wt <= 16 ? 16 : 32;
+  const int JP = Wt <= 16 ? 16 : (Wt <= 32 ? 32 : 64);
   const size_t pc = B * (size_t)P.nchunk, RID = 2 * (size_t)JP * JP + JP, OUT = (size_t)JP * JP + JP + 2;
   if (!seq_all && (st = h->g_riders.reserve(pc * RID)) != CLR_OK) return st;
   if (!seq_all && (st = h->g_out.reserve(pc * NG * OUT)) != CLR_OK) return st;
@@ -115,9 +116,9 @@ static int wide_batch_grad(clr_batch* h, double* value, double* grad, int* statu
   G.out_value = d_value; G.out_grad = d_grad; G.out_status = d_status;
 
   if (!seq_all) {
-    clr::launch_wide_grad_riders(W, h->stream);
+    if (clr::launch_wide_grad_riders(W, h->stream) != 0) return fail(CLR_HIP_ERROR, "the riders kernel could not be configured (LDS)");
     clr::launch_grad_chunked(G, h->stream);
-    clr::launch_wide_grad_walk(W, h->stream);
+    if (clr::launch_wide_grad_walk(W, h->stream) != 0) return fail(CLR_HIP_ERROR, "the walk kernel could not be configured (LDS)");
   }
   clr::launch_grad(G, h->stream);  // (sequential form: only the problems with level >= 2 -- or, widths 33..64, all)
   HIP_TRY(hipGetLastError());

@@ -527,7 +527,8 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
   const bool narrow_plan = !has_general && JG == 0 && Wc >= 1 && Wc <= 8 && N >= 1024;
   // widths 9..32, and general terms up to a total width of 32: the wide scan + chunk-wise forward-mode tangents
   // (wide_batch_grad); chunk count for ONE problem from profiles/r04k_wide_grad_chunks.txt
-  const bool wide_plan = !narrow_plan && Wc >= 1 && Wt <= 32 && (Wc >= 9 || JG > 0) && N >= 4096;
+  // (round 6) widths 33..64 without general terms: the same at the padded width 64, one direction per tangent wave
+  const bool wide_plan = !narrow_plan && Wc >= 1 && (Wt <= 32 || (Wt <= 64 && JG == 0)) && (Wc >= 9 || JG > 0) && N >= 4096;
   if ((narrow_plan || wide_plan) && !clr::option("CLR_GRAD_SEQUENTIAL")) {
     // parallel in n: the scan + the chunk-wise tangents (clr_batch_grad) on a one-problem plan
     if (!s->grad_plan || s->grad_N != N || s->grad_JR != JR || s->grad_JC != JC || s->grad_wide != wide_plan) {
@@ -536,11 +537,18 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
       s->grad_series.clear();
       s->grad_N = N; s->grad_JR = JR; s->grad_JC = JC; s->grad_wide = wide_plan;
       if (s->grad_plan && wide_plan) {
+        // (the gradient's time is the tangent waves', one per (direction, chunk), and a tangent step costs the same in the
+        //  first chunk as in any other: chunks of EQUAL length, not the evaluation's longer riderless first chunk)
+        s->grad_plan->wide_first_ratio = 1.0;
+        s->grad_plan->wide_first_ratio64 = 1.0;
         // chunks: the tangent pass dominates (one wave per (pair of partials, chunk), ~1.2 us per step whatever else the
         // SIMD holds): exactly one wave per SIMD -- ceil(G / 2) x nc <= 1024 -- as long as a chunk keeps >= 768 samples
         // (profiles/r04s_wide_grad_two_directions.txt: 17 x 60 = 1020 waves 4.04 ms, 17 x 64 = 1088 waves 4.72 ms -- the 64
         // SIMDs with a second wave finish last)
         int nc = std::min(1024 / ((G + 1) / 2), N / 768);
+        // (widths 33..64: a wave per direction, S and dS of its row in 512 registers -- one wave per SIMD; the
+        //  width-64 scan walks its chunks with one workgroup: a few dozen at most)
+        if (Wt > 32) nc = std::min(std::min(1024 / G, N / 768), 32);
         nc = std::max(4, std::min(nc, 128));
         if ((st = clr_batch_set_chunks(s->grad_plan, nc)) != CLR_OK) return st;
       }

@@ -133,8 +133,8 @@ struct WideGradWalk {
   double* out_grad;       // [B][NG]
   int* out_status;        // [B]
 };
-void launch_wide_grad_riders(const WideGradWalk& W, hipStream_t s);  // riders of every (problem, chunk) from element + start
-void launch_wide_grad_walk(const WideGradWalk& W, hipStream_t s);    // one wave per (problem, direction): walk the chunks
+int launch_wide_grad_riders(const WideGradWalk& W, hipStream_t s);  // riders of every (problem, chunk) from element + start; non-zero: LDS not configurable
+int launch_wide_grad_walk(const WideGradWalk& W, hipStream_t s);    // one wave per (problem, direction): walk the chunks
 
 // cholesky.h:41-210.  D must arrive initialised to the full diagonal
 // (diag + sum a_real + sum a_comp + jitter [+ A], cholesky.h:98-99).

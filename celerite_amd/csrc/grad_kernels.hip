@@ -558,6 +558,12 @@ void launch_grad_chunked(const GradParams& P, hipStream_t s) {
 #define CLR_GRAD_TWO_DIRECTIONS 1
 #endif
   const int NG = 1 + 2 * P.J_real + 4 * P.J_comp;
+  if (P.JP == 64) {  // widths 33..64 (round 6): one direction per wave (a row of S and of dS per lane: 256 registers)
+    const dim3 grid(NG, P.B, P.nchunk);
+    if (P.fast_trig) hipLaunchKernelGGL((wide_grad_kernel<64, true, true>), grid, dim3(64), 0, s, P);
+    else hipLaunchKernelGGL((wide_grad_kernel<64, false, true>), grid, dim3(64), 0, s, P);
+    return;
+  }
   if (CLR_GRAD_TWO_DIRECTIONS) {  // two directions per wave on one base recurrence
     const dim3 grid2((NG + 1) / 2, P.B, P.nchunk);
     if (P.JP == 16) {

@@ -1238,19 +1238,33 @@ def test_wide_scan_over_chunks_at_widths_33_to_64(JR, JC):
                 if nchunk < 0:
                     assert plan.exact_count() == B
             if B == 3 and family == "bench":
-                # the plan gradient at total widths 33..64: the chunk-wise tangent kernels exist at the padded widths 16 / 32
-                # only, so the plan runs the sequential tangent kernel on its resident arrays (every problem counted as a
-                # fallback) -- the same numbers as the one-shot entry, the value the oracle's
+                # the plan gradient at total widths 33..64.  A plan of one chunk (and any plan under CLR_GRAD_SEQUENTIAL) runs
+                # the sequential tangent kernel on its resident arrays, every problem counted as a fallback: the same bits as
+                # the one-shot entry.  Round 6: a CHUNKED plan takes the chunk-wise tangents at the padded width 64 (riders by
+                # wide_grad_riders64_kernel, one tangent wave per (direction, chunk), a walk per direction): the same numbers
+                # to rounding, only the problems the evaluation sent to the sequential recurrence are fallbacks.
                 plan.set_exact(False)
-                for nchunk in (4, 1):
+                v1, g1, st1 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"])
+                for nchunk, sequential in ((4, False), (7, False), (4, True), (1, False)):
                     plan.set_chunks(nchunk)
                     plan.set_coefficients(*coeffs_of(case))
-                    v, g, gst = plan.grad_log_likelihood()
-                    assert plan.grad_fallbacks() == B
-                    v1, g1, st1 = batch.batch_grad_log_likelihood(*coeffs_of(case), case["t"], case["diag"], case["y"])
+                    if sequential:
+                        with batch.option("CLR_GRAD_SEQUENTIAL"):
+                            v, g, gst = plan.grad_log_likelihood()
+                    else:
+                        v, g, gst = plan.grad_log_likelihood()
                     assert np.array_equal(gst, st1) and np.array_equal(gst, s0)
-                    assert np.array_equal(v[ok], v1[ok]) and np.array_equal(g[ok], g1[ok])
-                    within("widths 33..64, plan gradient (sequential tangent kernel): value vs oracle",
+                    if sequential or nchunk == 1:
+                        assert plan.grad_fallbacks() == B
+                        assert np.array_equal(v[ok], v1[ok]) and np.array_equal(g[ok], g1[ok])
+                    else:
+                        assert plan.grad_fallbacks() < B, plan.grad_fallbacks()
+                        within("widths 33..64, plan gradient parallel in n: value vs the sequential tangent kernel",
+                               np.max(np.abs(v[ok] - v1[ok]) / np.abs(v1[ok])), 1e-12, (W, nchunk))
+                        within("widths 33..64, plan gradient parallel in n: partials vs the sequential tangent kernel (of the largest)",
+                               np.max(np.abs(g[ok] - g1[ok])) / np.max(np.abs(g1[ok])), 1e-10, (W, nchunk))
+                        assert np.all(g[~ok] == 0.0) and np.all(np.isneginf(v[~ok]))
+                    within("widths 33..64, plan gradient: value vs oracle",
                            np.max(np.abs(v[ok] + 0.5 * (q0[ok] + d0[ok] + np.pi * np.log(N))) / np.abs(v[ok])), REL, (W, nchunk))  # (solver.cpp:415)
         finally:
             plan.close()

@@ -408,9 +408,10 @@ def test_grad_log_likelihood_above_width_64():
 
 
 @pytest.mark.parametrize("JR,JC,JG,N", [(4, 4, 0, 4200), (0, 8, 0, 20000), (2, 5, 0, 9000), (0, 16, 0, 8000), (6, 13, 0, 5000),
-                                        (2, 3, 4, 6000), (0, 8, 3, 5000), (1, 0, 2, 4096)])
+                                        (2, 3, 4, 6000), (0, 8, 3, 5000), (1, 0, 2, 4096),
+                                        (2, 16, 0, 9000), (1, 24, 0, 6000), (0, 32, 0, 8000)])
 def test_grad_log_likelihood_at_widths_9_to_32_and_with_general_terms_is_parallel_in_n(JR, JC, JG, N):
-    """From N = 4096 on, widths 9..32 -- and any celerite width with general terms up to a total width of 32 -- run
+    """From N = 4096 on, widths 9..32 (round 6: to 64) -- and any celerite width with general terms up to a total width of 32 -- run
     the wide scan + chunk-wise forward-mode tangents on a one-problem plan (csrc/wide_grad_kernels.hip; the reference's AD
     handles any width and J_general, solver.cpp:347-463, general rows :393-399): same numbers as the sequential tangent
     kernel, the dual-number oracle on the shortest cases, the zero-jitter rule, LinAlgError for an indefinite matrix."""
