@@ -186,7 +186,9 @@ int clr_solver_predict(const clr_solver* s, int n_y, const double* y,
  *   then d/d a_real, c_real, a_comp, b_comp, c_comp, d_comp: n_grad must be
  *   1 + 2 n_a_real + 4 n_a_comp.
  * Returns CLR_NOT_POSITIVE_DEFINITE where the reference throws linalg_exception.
- * Total width (with general terms) up to 64. */
+ * Any total width up to CLR_MAX_WIDTH_ANY: widths 1..8 from N = 1024 and widths 9..64 from N = 4096 run parallel in n on a
+ * one-problem plan (general terms: up to a total width of 32); otherwise one wave per partial, sequential in n, up to
+ * width 64 (csrc/grad_kernels.hip) and one workgroup per partial above (round 6: csrc/grad_any_kernels.hip). */
 int clr_solver_grad_log_likelihood(clr_solver* s, double jitter,
                                    int n_a_real, const double* a_real,
                                    int n_c_real, const double* c_real,
@@ -568,9 +570,10 @@ int clr_batch_grad_log_likelihood(int B, int N, int J_real, int J_comp, const do
  * scan routed to the sequential recurrence take the sequential kernel above (count: clr_batch_get_grad_fallbacks).
  * Synchronous; conventions of value / grad / status as above.  clr_batch_grad_log_likelihood uses this path for
  * widths 1..8 and N >= 512.  Chunked plans of widths 9..32 (and with general terms up to a total width of 32) run the
- * same decomposition with a wave per (chunk, direction) (csrc/wide_grad_kernels.hip); plans of widths 33..64 run the
- * sequential tangent kernel on their resident arrays (every problem counted in clr_batch_get_grad_fallbacks); above
- * 64: CLR_UNSUPPORTED. */
+ * same decomposition with a wave per (chunk, direction) (csrc/wide_grad_kernels.hip); round 6: chunked plans of widths
+ * 33..64 too (the riders at the padded width 64 under a workgroup of 256 threads); plans of widths 33..64 with ONE chunk
+ * run the sequential tangent kernel on their resident arrays (every problem counted in clr_batch_get_grad_fallbacks);
+ * above 64: CLR_UNSUPPORTED (CholeskySolver.grad_log_likelihood takes any width). */
 int clr_batch_grad(clr_batch* h, double* value, double* grad, int* status);
 int clr_batch_get_grad_fallbacks(const clr_batch* h, int* count);
 /* How clr_batch_grad differentiates.  mode 0 (default): REVERSE mode -- the riders pass also records w, D, x per
