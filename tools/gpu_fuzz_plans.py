@@ -84,6 +84,18 @@ for k in range(cases):
         if ok.any():
             devs["logdet"] = np.max(np.abs(ld[ok] - d0[ok]) / np.maximum(np.abs(d0[ok]), 1e-300))
             devs["quad"] = np.max(np.abs(q[ok] - q0[ok]) / np.abs(q0[ok]))
+            if width <= 64 and max(devs["logdet"], devs["quad"]) > 1e-11:
+                # attribution: the same recurrence carried in binary128 (oracle/celerite_ref_quad.c) -- device vs truth
+                # beside sequential double oracle vs truth, on the problem that deviates most
+                rel = np.where(ok, np.maximum(np.abs(ld - d0) / np.maximum(np.abs(d0), 1e-300), np.abs(q - q0) / np.maximum(np.abs(q0), 1e-300)), 0.0)
+                pw = int(np.argmax(rel))
+                try:
+                    _, _, _, ldq, qq = ref.quad_factor_solve(0.0, *coeffs_of(case, pw), case["t"][pw], case["diag"][pw], case["y"][pw], want_factor=False)
+                    print("ATTRIBUTION %s problem %d: log det device-truth %.1e, oracle-truth %.1e; quad device-truth %.1e, oracle-truth %.1e%s" % (
+                        tag, pw, abs(ld[pw] - ldq) / abs(ldq), abs(d0[pw] - ldq) / abs(ldq), abs(q[pw] - qq) / abs(qq), abs(q0[pw] - qq) / abs(qq),
+                        "  conditioning (gamma, mu, resid): %s" % (plan.conditioning(),) if plan.chunks[0] > 1 else ""), flush=True)
+                except Exception as e:
+                    print("ATTRIBUTION failed:", tag, repr(e), flush=True)
         if k % 3 == 0 and width <= 64 and plan.chunks[0] > 1 and N >= 512 and ok.all():   # (clr_batch_solve: chunked plans, wide ones from N = 512)
             plan.log_likelihood(materialize=True)
             x = plan.solve()
