@@ -324,6 +324,40 @@ def test_grad_log_likelihood_wide_and_long():
         s.grad_log_likelihood(0.0, *co, *NO_GENERAL, x, y[:-1], diag)
 
 
+def test_gp_gradient_with_many_terms():
+    """``GP.grad_log_likelihood`` (celerite.py:221-305) for a kernel of 34 SHO terms + jitter -- width 68, above the
+    wave-per-partial kernel's 64 -- through the workgroup-per-partial kernel: the reference test's protocol
+    (tests/test_celerite.py:448-465: central differences of the GP's own log-likelihood over every kernel parameter)."""
+    rng = np.random.RandomState(4)
+    kernel = terms.JitterTerm(log_sigma=-1.0)
+    for k in range(34):
+        kernel += terms.SHOTerm(log_S0=rng.uniform(-2.0, 0.0), log_Q=rng.uniform(0.5, 2.0), log_omega0=rng.uniform(-1.0, 2.5))
+    x = np.sort(rng.uniform(0, 20, 160))
+    yerr = rng.uniform(0.1, 0.3, len(x))
+    y = np.sin(x) + 0.1 * rng.randn(len(x))
+    gp = GP(kernel)
+    gp.compute(x, yerr)
+    assert sum(len(c) for c in kernel.coefficients[:2]) // 2 + 2 * len(kernel.coefficients[2]) == 68
+    value, grad = gp.grad_log_likelihood(y)
+    # (the value carries the reference's own constant, pi log N instead of N log 2 pi: solver.cpp:415)
+    within("GP gradient with 34 SHO terms: value vs log_likelihood",
+           abs((value + 0.5 * np.pi * np.log(len(x))) - (gp.log_likelihood(y) + 0.5 * len(x) * np.log(2 * np.pi))) / abs(value), 1e-11)
+    v = gp.get_parameter_vector()
+    assert grad.shape == v.shape == (1 + 3 * 34,)
+    eps = 1.34e-6
+    for i in list(range(0, len(v), 9)) + [len(v) - 1]:
+        pval = v[i]
+        v[i] = pval + eps
+        gp.set_parameter_vector(v)
+        ll = gp.log_likelihood(y)
+        v[i] = pval - eps
+        gp.set_parameter_vector(v)
+        ll -= gp.log_likelihood(y)
+        v[i] = pval
+        gp.set_parameter_vector(v)
+        within("GP gradient with 34 SHO terms: vs central differences (of 1 + |g|)", abs(grad[i] - 0.5 * ll / eps) / (1.0 + abs(grad[i])), 1e-5, i)
+
+
 def _grad_case(rng, JR, JC, JG, N):
     x = np.sort(rng.uniform(0, 30, N))
     diag = rng.uniform(0.1, 0.3, N)
