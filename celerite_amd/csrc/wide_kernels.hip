@@ -1002,6 +1002,29 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) w
   else wide_scan_body<64, FAST, MODE, LAZY, true, GEN, 2, PAIRED, GAPS>(P, JR, JC);
 }
 
+#ifdef CLR_WIDE_SCAN32_ONLY
+// ---------------------------------------------------------------------------
+// wide_scan32.hip: this file compiled a SECOND time for the lazy summarize flavours at the padded width 32 alone
+// (BASELINE configs[4]'s dominant kernel), with -mllvm -amdgpu-sched-strategy=max-ilp (Makefile).  Measured, A/B builds in
+// one GPU call (profiles/r06zj_wide_sched_ab.txt, r06zl_wide_ilp_other_widths.txt): that strategy takes this kernel from
+// 9.52-9.56 to 9.20-9.22 ms (same bits), but costs wide_correct_kernel 0.36 -> 0.48 ms, the 16-wide prefix 0.43 -> 0.54 ms
+// and the width-64 summarize 41.7 -> 45.0 ms when the whole unit is built with it -- hence a unit of its own.
+// ---------------------------------------------------------------------------
+}  // namespace
+void launch_wide_scan32_lazy(const BatchParams& P, int JR, int JC, bool paired, bool gaps, hipStream_t s) {
+  const dim3 grid(P.nchunk, P.B);
+  if (P.fast_trig) {
+    if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
+    else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+  } else {
+    if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
+    else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
+    else hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
+  }
+}
+}  // namespace clr
+#else
 // ---------------------------------------------------------------------------
 // correct at the padded widths 16 / 32: chunk_update + pd_certificate of clr_core.h (same
 // formulas, same thresholds), one WAVE per (problem, chunk) with the matrices in LDS -- the
@@ -1399,6 +1422,9 @@ void launch_wide_f32_probe(const BatchParams& P, int JR, int JC, double* out_log
 namespace {
 }  // namespace
 
+// the lazy summarize flavours at the padded width 32, built by wide_scan32.hip (this file again, CLR_WIDE_SCAN32_ONLY)
+void launch_wide_scan32_lazy(const BatchParams& P, int JR, int JC, bool paired, bool gaps, hipStream_t s);
+
 int wide_max_width() { return 64; }
 int wide_scan_max_width() { return 64; }  // the chunk algebra: prefix_coop_kernel<16>, wide_prefix32_kernel, wide_walk64_kernel (wide64_kernels.hip)
 
@@ -1436,17 +1462,8 @@ static void launch_wide_g(const BatchParams& P, int JR, int JC, hipStream_t s) {
     const bool paired = !GEN && wide_paired(JR);
     const bool gaps = !GEN && P.split_lazy == 2 && W > 16;  // (host: not dense everywhere, max c x max dx < 2)
     if (W <= 16) CLR_GOL(16);
-    else if (W <= 32 && !GEN && (paired || gaps)) {
-      if (P.fast_trig) {
-        if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
-        else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
-        else hipLaunchKernelGGL((wide_scan_kernel<32, true, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
-      } else {
-        if (paired && gaps) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, true>), grid, dim3(64), 0, s, P, JR, JC);
-        else if (paired) hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, true, false>), grid, dim3(64), 0, s, P, JR, JC);
-        else hipLaunchKernelGGL((wide_scan_kernel<32, false, 1, true, false, false, true>), grid, dim3(64), 0, s, P, JR, JC);
-      }
-    } else if (W <= 32) CLR_GOL(32);
+    else if (W <= 32 && !GEN && (paired || gaps)) launch_wide_scan32_lazy(P, JR, JC, paired, gaps, s);  // (wide_scan32.hip: its own scheduling strategy)
+    else if (W <= 32) CLR_GOL(32);
     else if (!wide64_one_wave() && !GEN && (paired || gaps)) {
       if (P.fast_trig) {
         if (paired && gaps) hipLaunchKernelGGL((wide_scan64x2_kernel<true, 1, true, false, true, true>), grid, dim3(128), 0, s, P, JR, JC);
@@ -1764,3 +1781,4 @@ void launch_wide_loglike(const BatchParams& P, int JR, int JC, hipStream_t s) { 
 void launch_wide_summarize(const BatchParams& P, int JR, int JC, hipStream_t s) { launch_wide<1>(P, JR, JC, s); }
 
 }  // namespace clr
+#endif  // CLR_WIDE_SCAN32_ONLY
