@@ -1882,6 +1882,16 @@ int clr_batch_dot_L(clr_batch* h, int nrhs, const double* z, double* y) {
   return CLR_OK;
 }
 
+// the constant diagonal of one problem's K for dot: sum a_real + sum a_comp + jitter (cholesky.h:483-485), N copies
+__global__ void __launch_bounds__(256) dot_diagonal_kernel(const double* a_real, const double* a_comp, const double* jitter, int JR,
+                                                           int JC, double* dg, int N) {
+  double sr = 0.0, sc = 0.0;
+  for (int j = 0; j < JR; ++j) sr += a_real[j];
+  for (int j = 0; j < JC; ++j) sc += a_comp[j];
+  const double d = (sr + sc) + jitter[0];
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) dg[n] = d;
+}
+
 // CholeskySolver::dot (cholesky.h:441-596; GP.dot, celerite.py:453-489) for every problem of the plan: y_p = K_p z_p with
 // K_p given by the plan's resident times and the coefficients in force (diagonal sum a_real + sum a_comp + jitter: no
 // observational variance, :483-485) -- no factor, no materialising run.  Narrow plans: the two triangles as chunked
@@ -1903,25 +1913,11 @@ int clr_batch_dot(clr_batch* h, int nrhs, const double* z, double* y) {
   HIP_TRY(hipMemcpyAsync(h->bs_rm.p, z, B * R * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const double* result = nullptr;
   if (!h->launch) {  // wide plans: problem by problem
-    const size_t nr = B * h->J_real, nc = B * h->J_comp;
-    std::vector<double> hc(2 * nr + 4 * nc + B);
-    HIP_TRY(hipMemcpyAsync(hc.data(), h->coeffs.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    std::vector<double> hdg(B * N);
-    for (size_t p = 0; p < B; ++p) {
-      double sr = 0.0, sc = 0.0;
-      for (int j = 0; j < h->J_real; ++j) sr += hc[p * h->J_real + j];
-      for (int j = 0; j < h->J_comp; ++j) sc += hc[2 * nr + p * h->J_comp + j];
-      const double d = (sr + sc) + hc[2 * nr + 4 * nc + p];  // cholesky.h:483-485
-      for (size_t n = 0; n < N; ++n) hdg[p * N + n] = d;
-    }
     DevBuf feat, dgb, ws;
     auto cleanup = [&](int code) { (void)hipStreamSynchronize(h->stream); feat.release(); dgb.release(); ws.release(); return code; };
     if ((st = feat.reserve(3 * J * N)) != CLR_OK) return cleanup(st);
-    if ((st = dgb.reserve(B * N)) != CLR_OK) return cleanup(st);
+    if ((st = dgb.reserve(N)) != CLR_OK) return cleanup(st);  // the problem's constant diagonal, refilled per problem (same stream)
     if ((st = h->bs_x.reserve(B * R * N)) != CLR_OK) return cleanup(st);
-    if (hipMemcpyAsync(dgb.p, hdg.data(), B * N * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess)
-      return cleanup(fail(CLR_HIP_ERROR, "clr_batch_dot: upload failed"));
     const bool scan = clr::wdotl_scan_supported(h->N, h->J);
     clr::SweepParams SP;
     memset(&SP, 0, sizeof(SP));
@@ -1943,12 +1939,14 @@ int clr_batch_dot(clr_batch* h, int nrhs, const double* z, double* y) {
       g.t = h->t.p + p * (size_t)h->t_stride;
       double *phi = feat.p, *u = feat.p + J * N, *v = feat.p + 2 * J * N;
       clr::launch_dot_setup(g, phi, u, v, h->stream);
+      hipLaunchKernelGGL(dot_diagonal_kernel, dim3((unsigned)std::min<size_t>((N + 255) / 256, 1024)), dim3(256), 0, h->stream,
+                         g.a_real, g.a_comp, P.jitter + p, h->J_real, h->J_comp, dgb.p, h->N);
       if (scan) {
         SP.phi = phi; SP.u = u;
         SP.in = h->bs_rm.p + p * R * N; SP.out = h->bs_x.p + p * R * N;
-        clr::launch_wdot_scan(SP, v, dgb.p + p * N, ws.p, h->stream);
+        clr::launch_wdot_scan(SP, v, dgb.p, ws.p, h->stream);
       } else {
-        clr::launch_dot(h->N, h->J, nrhs, phi, u, v, dgb.p + p * N, h->bs_rm.p + p * R * N, h->bs_x.p + p * R * N, h->stream);
+        clr::launch_dot(h->N, h->J, nrhs, phi, u, v, dgb.p, h->bs_rm.p + p * R * N, h->bs_x.p + p * R * N, h->stream);
       }
     }
     (void)hipEventRecord(h->bs_ev[1], h->stream);
