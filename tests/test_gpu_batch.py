@@ -525,11 +525,14 @@ def test_materialised_factor_at_the_bench_shape_against_the_oracle_state():
     picks = [0, 1, 63, 64, 100, 255, 256, 317, 511, 512, 600, 767, 768, 900, 1022, 1023]
     truth_picks = [0, 317, 768, 1023]
     states, solves, truth = {}, {}, {}
+    dotLs, dots = {}, {}
     for p in picks:
         r = ref.RefSolver()
         r.compute(0.0, *[c[p] for c in coeffs], np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t[p], diag[p])
         states[p] = r.state()
         solves[p] = r.solve(y[p])[:, 0]
+        dotLs[p] = r.dot_L(y[p])[:, 0]                                                    # cholesky.h:409-431
+        dots[p] = r.dot(0.0, *[c[p] for c in coeffs], np.empty(0), np.empty((0, 0)), np.empty((0, 0)), t[p], y[p])[:, 0]   # :441-596
     for p in truth_picks:
         Wq, Dq, xq, ldq, qq = ref.quad_factor_solve(0.0, *[c[p] for c in coeffs], t[p], diag[p], y[p])
         truth[p] = (Wq, Dq, xq)
@@ -551,6 +554,16 @@ def test_materialised_factor_at_the_bench_shape_against_the_oracle_state():
                 assert (st == 0).all()
                 assert (plan.exact_levels() <= 1).all()           # the chunked replay's end states met the scanned ones everywhere
                 x = plan.solve()
+                if refine:      # the other consumers at the bench shape: L y (from this factor) and K y (no factor needed)
+                    Ly = plan.dot_L(y)
+                    within("bench-shape batched dot_L vs oracle dot_L (of the largest entry; 16 problems x 2 layouts)",
+                           max(float(np.max(np.abs(Ly[p] - dotLs[p])) / np.max(np.abs(dotLs[p]))) for p in picks), 1e-12, layout)
+                    del Ly
+                    if layout == "reference":
+                        Ky = plan.dot(y)
+                        within("bench-shape batched dot vs oracle dot (of the largest entry; 16 problems)",
+                               max(float(np.max(np.abs(Ky[p] - dots[p])) / np.max(np.abs(dots[p]))) for p in picks), 1e-12)
+                        del Ky
                 for p in picks:
                     _, _, _, logdet, rphi, ru, rW, rD = states[p]
                     phi, u, W, D = plan.factor(p)
