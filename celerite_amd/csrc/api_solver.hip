@@ -548,7 +548,26 @@ int clr_solver_grad_log_likelihood(clr_solver* s, double jitter, int n_a_real, c
         int nc = std::min(1024 / ((G + 1) / 2), N / 768);
         // (widths 33..64: a wave per direction, S and dS of its row in 512 registers -- one wave per SIMD; the
         //  width-64 scan walks its chunks with one workgroup: a few dozen at most)
-        if (Wt > 32) nc = std::min(std::min(1024 / G, N / 768), 32);
+        if (Wt > 32) {
+          // SEVERAL full rounds of the chip rather than one partly filled: with G x nc just below a multiple of 1024 the
+          // tangent pass costs the same wave-steps, and the evaluation's scan -- one workgroup per chunk -- gets short chunks
+          // (profiles/r06zz2_widegrad_kernel_trace_stats.txt: 7 chunks at width 64, G = 129: tangents 67 ms on 903 waves, the
+          // scan 19 ms on 7 workgroups).  The largest count up to 32 whose last round is at least 93 % full.
+          // (chunks of at least 2048 samples: below, the walk over the chunks and the riders outweigh the shorter scan --
+          //  N = 2e4 at width 64: 21 ms with 7 chunks, 24 with 23)
+          const int single = std::min(1024 / G, N / 768);  // (one round of waves)
+          const int cap = std::min(32, N / 2048);
+          nc = single;
+          if (cap > single) {
+            double best = 0.0;
+            for (int c = cap; c >= 4; --c) {
+              const long waves = (long)G * c;
+              const double eff = (double)waves / (double)(((waves + 1023) / 1024) * 1024);
+              if (eff >= 0.93) { nc = c; break; }
+              if (eff > best) { best = eff; nc = c; }
+            }
+          }
+        }
         nc = std::max(4, std::min(nc, 128));
         if ((st = clr_batch_set_chunks(s->grad_plan, nc)) != CLR_OK) return st;
       }
